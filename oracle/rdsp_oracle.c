@@ -1,0 +1,603 @@
+/*
+ * rdsp_oracle.c -- CPU ORACLE (test infrastructure; see rdsp_oracle.h header).
+ * PARITY UNPINNED: no reference fixtures exist; restated from the reference's
+ * sources and anchored by analytic KATs + an independent float64 model.
+ *
+ * Citation short names (relative to /root/reference/src):
+ *   CONV = RadioDSP_SDR_RX/RDSP_convolutional.h
+ *   NR   = RadioDSP_SDR_RX/RDSP_noise_reduction.h
+ *   SPEC = backup/RDSP_convolutional_spec.h
+ *   INO  = RadioDSP_SDR_RX/RadioDSP_SDR_RX.ino
+ *
+ * Arithmetic types mirror the reference: float32_t -> float, double -> double.
+ * Build with -ffp-contract=off so no FMA contraction changes the rounding.
+ */
+#include "rdsp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.14159265358979323846
+#define ORC_TWO_PI (2.0 * ORC_PI)
+#define LMS_TAPS 96   /* MAX_LMS_TAPS, NR:23; calc_taps NR:39 */
+#define LMS_DELAY 128 /* MAX_LMS_DELAY, NR:24 */
+
+/* ------------------------------------------------------------------------ */
+/* CMSIS-DSP primitive restatements (published semantics)        */
+/* ------------------------------------------------------------------------ */
+
+/* arm_q15_to_float: dst = (float)src / 32768.0f   (call sites CONV:241-242) */
+void orc_q15_to_float(const int16_t *src, float *dst, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) dst[i] = (float)src[i] / 32768.0f;
+}
+
+/* arm_float_to_q15 without ARM_MATH_ROUNDING: truncate toward zero, then
+ * saturate to 16 bits (call sites CONV:346-347). */
+void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    float v = src[i] * 32768.0f;
+    int32_t q;
+    if (!(v > -2147483648.0f)) q = INT32_MIN; /* also catches NaN */
+    else if (v >= 2147483648.0f) q = INT32_MAX;
+    else q = (int32_t)v;
+    if (q > 32767) q = 32767;
+    if (q < -32768) q = -32768;
+    dst[i] = (int16_t)q;
+  }
+}
+
+/* arm_cfft_f32(S, p, ifftFlag, bitReverseFlag=1): in-place interleaved complex
+ * float transform, natural order in and out, inverse scaled by 1/N.  CMSIS
+ * uses a radix-8/4 decomposition; this is an iterative radix-2 DIT with float
+ * twiddles (rounded from double).  Agreement with a float64 DFT is ~1e-7
+ * normwise (tests/test_oracle_kat.py). */
+void orc_cfft_f32(float *buf, uint32_t n, int inverse) {
+  /* bit reversal */
+  for (uint32_t i = 1, j = 0; i < n; i++) {
+    uint32_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      float tr = buf[2 * i], ti = buf[2 * i + 1];
+      buf[2 * i] = buf[2 * j];
+      buf[2 * i + 1] = buf[2 * j + 1];
+      buf[2 * j] = tr;
+      buf[2 * j + 1] = ti;
+    }
+  }
+  for (uint32_t len = 2; len <= n; len <<= 1) {
+    uint32_t half = len >> 1;
+    for (uint32_t k = 0; k < half; k++) {
+      double ang = -ORC_TWO_PI * (double)k / (double)len;
+      float wr = (float)cos(ang);
+      float wi = (float)sin(ang);
+      if (inverse) wi = -wi;
+      for (uint32_t s = k; s < n; s += len) {
+        uint32_t a = s, b = s + half;
+        float xr = buf[2 * b] * wr - buf[2 * b + 1] * wi;
+        float xi = buf[2 * b] * wi + buf[2 * b + 1] * wr;
+        buf[2 * b] = buf[2 * a] - xr;
+        buf[2 * b + 1] = buf[2 * a + 1] - xi;
+        buf[2 * a] = buf[2 * a] + xr;
+        buf[2 * a + 1] = buf[2 * a + 1] + xi;
+      }
+    }
+  }
+  if (inverse) {
+    float sc = 1.0f / (float)n;
+    for (uint32_t i = 0; i < 2 * n; i++) buf[i] *= sc;
+  }
+}
+
+/* arm_cmplx_mult_cmplx_f32 (call site CONV:301) */
+void orc_cmplx_mult_cmplx_f32(const float *a, const float *b, float *dst, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+    dst[2 * i] = ar * br - ai * bi;
+    dst[2 * i + 1] = ar * bi + ai * br;
+  }
+}
+
+/* arm_cmplx_mag_f32 (call site SPEC:182) */
+void orc_cmplx_mag_f32(const float *src, float *dst, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    float re = src[2 * i], im = src[2 * i + 1];
+    dst[i] = sqrtf(re * re + im * im);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* CONV:127-185  windowed-sinc complex band-pass design (double precision)   */
+/* ------------------------------------------------------------------------ */
+static double window_value(int window, int i, int n) {
+  double den = (double)(n - 1);
+  switch (window) {
+    case 1: /* 4-term Blackman-Harris, CONV:153-158 */
+      return 0.35875 - 0.48829 * cos((ORC_TWO_PI * i) / den) +
+             0.14128 * cos((2.0 * ORC_TWO_PI * i) / den) -
+             0.01168 * cos((3.0 * ORC_TWO_PI * i) / den);
+    case 2: /* CONV:159-164 */
+      return 0.355768 - 0.487396 * cos((ORC_TWO_PI * i) / den) +
+             0.144232 * cos((2.0 * ORC_TWO_PI * i) / den) -
+             0.012604 * cos((3.0 * ORC_TWO_PI * i) / den);
+    case 3: /* cosine, CONV:165-168 ((float32_t)i cast is exact for i < 2^24) */
+      return cos((ORC_PI * (double)(float)i) / den);
+    case 4: /* Hann, CONV:169-172 */
+      return 0.5 * (1.0 - cos(ORC_PI * 2 * (double)i / den));
+    default: /* Blackman-Nuttall, CONV:173-179 */
+      return 0.3635819 - 0.4891775 * cos((ORC_TWO_PI * i) / den) +
+             0.1365995 * cos((2.0 * ORC_TWO_PI * i) / den) -
+             0.0106411 * cos((3.0 * ORC_TWO_PI * i) / den);
+  }
+}
+
+void orc_calc_cplx_FIR_coeffs(double *coeffs_I, double *coeffs_Q, int numCoeffs,
+                              double FLoCut, double FHiCut, double SampleRate,
+                              int window) {
+  double nFL = FLoCut / SampleRate;               /* CONV:132 */
+  double nFH = FHiCut / SampleRate;               /* CONV:133 */
+  double nFc = (nFH - nFL) / 2.0;                 /* CONV:134 */
+  double nFs = ORC_PI * (nFH + nFL);              /* CONV:135 */
+  double fCenter = 0.5 * (double)(numCoeffs - 1); /* CONV:136 */
+  for (int i = 0; i < numCoeffs; i++) {
+    double x = (double)(float)i - fCenter; /* CONV:147 */
+    double z;
+    if (fabs((double)i - fCenter) < 0.01) /* CONV:149-150 */
+      z = 2.0 * nFc;
+    else
+      z = sin(ORC_TWO_PI * x * nFc) / (ORC_PI * x) * window_value(window, i, numCoeffs);
+    coeffs_I[i] = z * cos(nFs * x); /* CONV:182 */
+    coeffs_Q[i] = z * sin(nFs * x); /* CONV:183 */
+  }
+}
+
+/* CONV:87-110.  Taps narrowed to float on store (CONV:98-99); zero fill starts
+ * at index FFT_length+1 (CONV:102) which overwrites Q[FFT_L/2] -- reproduced. */
+void orc_init_filter_mask(float *mask, const double *coef_I, const double *coef_Q,
+                          uint32_t fft_l) {
+  uint32_t ntaps = fft_l / 2 + 1; /* m_NumTaps, CONV:72 */
+  for (uint32_t i = 0; i < ntaps; i++) {
+    mask[2 * i] = (float)coef_I[i];
+    mask[2 * i + 1] = (float)coef_Q[i];
+  }
+  for (uint32_t i = fft_l + 1; i < 2 * fft_l; i++) mask[i] = 0.0f;
+  orc_cfft_f32(mask, fft_l, 0); /* CONV:108 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* NLMS instance: arm_lms_norm_instance_f32 + the reference's delay ring     */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  float mu;
+  float energy, x0;
+  float coeffs[LMS_TAPS + LMS_DELAY]; /* LMS_NormCoeff_f32, NR:31 */
+  float state[LMS_TAPS + LMS_DELAY];  /* LMS_StateF32, NR:30      */
+  float delay[256 + LMS_DELAY];       /* LMS_nr_delay, NR:32      */
+  float errsig[256 + 10];             /* LMS_errsig1, NR:26       */
+  uint32_t inbuf, outbuf;             /* statics, NR:69           */
+} orc_lms_t;
+
+/* NR:35-64 */
+static void lms_init(orc_lms_t *s, int strength) {
+  float mu_calc = (float)strength; /* NR:48 */
+  mu_calc /= 2;                    /* NR:51 */
+  mu_calc += 2;                    /* NR:52 */
+  mu_calc /= 10;                   /* NR:53 */
+  mu_calc = powf(10, mu_calc);     /* NR:54 */
+  mu_calc = 1 / mu_calc;           /* NR:55 */
+  s->mu = mu_calc;
+  for (int i = 0; i < 256 + 128; i++) s->delay[i] = 0.0f;      /* NR:58 */
+  for (int i = 0; i < LMS_TAPS + 128; i++) s->state[i] = 0.0f; /* NR:59 */
+  /* arm_lms_norm_init_f32 (NR:62): clears numTaps+blockSize-1 state words,
+   * energy = 0, x0 = 0; the coefficient array is NOT cleared. */
+  s->energy = 0.0f;
+  s->x0 = 0.0f;
+}
+
+/* arm_lms_norm_f32 (call site NR:73), published algorithm */
+static void lms_norm_f32(orc_lms_t *s, const float *src, const float *ref,
+                         float *out, float *err, uint32_t n) {
+  float *state = s->state;
+  float *cur = &s->state[LMS_TAPS - 1];
+  float energy = s->energy, x0 = s->x0, mu = s->mu;
+  for (uint32_t b = 0; b < n; b++) {
+    float in = src[b];
+    *cur++ = in;
+    energy -= x0 * x0;
+    energy += in * in;
+    float sum = 0.0f;
+    for (int i = 0; i < LMS_TAPS; i++) sum += state[i] * s->coeffs[i];
+    float d = ref[b];
+    out[b] = sum; /* may alias src[b]: `in` was read first */
+    float e = d - sum;
+    err[b] = e;
+    float w = (e * mu) / (energy + 0.000000119209289f);
+    for (int i = 0; i < LMS_TAPS; i++) s->coeffs[i] += w * state[i];
+    x0 = state[0];
+    state++;
+  }
+  s->energy = energy;
+  s->x0 = x0;
+  /* keep the last numTaps-1 samples at the head of the state buffer */
+  memmove(s->state, state, (LMS_TAPS - 1) * sizeof(float));
+}
+
+/* NR:66-80 with the ring statics made per-instance */
+static void lms_noise_reduction(orc_lms_t *s, int n, float *nrbuffer, float *errsig_out) {
+  memcpy(&s->delay[s->inbuf], nrbuffer, (size_t)n * sizeof(float)); /* NR:71 */
+  lms_norm_f32(s, nrbuffer, &s->delay[s->outbuf], nrbuffer, s->errsig, (uint32_t)n); /* NR:73 */
+  if (errsig_out) memcpy(errsig_out, s->errsig, (size_t)n * sizeof(float));
+  s->inbuf += (uint32_t)n;             /* NR:76 */
+  s->outbuf = s->inbuf + (uint32_t)n;  /* NR:77 */
+  s->inbuf %= 256;                     /* NR:78 */
+  s->outbuf %= 256;                    /* NR:79 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* chain object: the reference's globals (CONV:34-80, NR:18-32, SPEC:109)    */
+/* ------------------------------------------------------------------------ */
+struct orc_chain {
+  orc_config_t cfg;
+  uint32_t fft_l, hop; /* FFT_length, BUFFER_SIZE*N_BLOCKS */
+  double fs_out;       /* SAMPLE_RATE of the CONV stage */
+  /* front end (build-defined) */
+  uint32_t dphi;
+  uint64_t n_in; /* absolute input sample counter */
+  float *fir_taps;
+  float *fir_ring_re, *fir_ring_im; /* circular, length fir_taps */
+  uint32_t fir_pos;
+  /* CONV globals */
+  float *FFT_buffer, *iFFT_buffer, *FIR_filter_mask;
+  float *float_buffer_L, *float_buffer_R, *last_L, *last_R;
+  float *mag; /* FFTBufferMag, SPEC:55 */
+  double *coef_I, *coef_Q;
+  uint8_t first_block;
+  uint32_t fill; /* samples gathered in float_buffer_* */
+  int oldNRLevel; /* CONV:80 */
+  float NFloor;   /* SPEC:109 */
+  orc_lms_t nr, als;
+  float agc_g;
+  float am_dc;
+};
+
+uint32_t orc_demod_tuning_offset(int demod) {
+  /* build-defined (AudioSDR's values are not in the tree): SSB/AM tune to the
+   * carrier; CW modes place the carrier 700 Hz off so it is heard as a tone */
+  switch (demod) {
+    case ORC_DEMOD_CW_USB:
+    case ORC_DEMOD_CW_LSB:
+      return 700u;
+    default:
+      return 0u;
+  }
+}
+
+static void agc_params(int mode, float *attack, float *decay) {
+  *attack = 0.6f;
+  switch (mode) {
+    case ORC_AGC_FAST: *decay = 0.10f; break;
+    case ORC_AGC_MEDIUM: *decay = 0.03f; break;
+    case ORC_AGC_SLOW: *decay = 0.008f; break;
+    default: *decay = 0.0f; break;
+  }
+}
+
+void orc_Init_LMS_NR(orc_chain_t *c, int strength) { lms_init(&c->nr, strength); }
+void orc_Init_ALS(orc_chain_t *c, int strength) { lms_init(&c->als, strength); }
+void orc_LMS_NoiseReduction(orc_chain_t *c, int16_t n, float *nrbuffer) {
+  lms_noise_reduction(&c->nr, n, nrbuffer, NULL);
+}
+void orc_set_nr_level(orc_chain_t *c, int lms_nr) { c->cfg.lms_nr = lms_nr; }
+
+/* CONV:187-207: the mask is built from whatever the tap arrays hold (all zero
+ * at boot, INO:180 runs before INO:183). */
+void orc_doConvolutionalInitialize(orc_chain_t *c) {
+  orc_init_filter_mask(c->FIR_filter_mask, c->coef_I, c->coef_Q, c->fft_l);
+}
+
+/* CONV:209-224 */
+void orc_reInitializeFilter(orc_chain_t *c, double lo, double hi) {
+  orc_calc_cplx_FIR_coeffs(c->coef_I, c->coef_Q, (int)(c->fft_l / 2 + 1), lo, hi,
+                           c->fs_out, c->cfg.window);
+  orc_init_filter_mask(c->FIR_filter_mask, c->coef_I, c->coef_Q, c->fft_l);
+}
+
+orc_chain_t *orc_chain_create(const orc_config_t *cfg) {
+  orc_chain_t *c = (orc_chain_t *)calloc(1, sizeof(*c));
+  if (!c) return NULL;
+  c->cfg = *cfg;
+  c->fft_l = (uint32_t)cfg->fft_l;
+  c->hop = c->fft_l / 2;
+  int decim = cfg->decim < 1 ? 1 : cfg->decim;
+  c->cfg.decim = decim;
+  c->fs_out = cfg->fs_in / (double)decim;
+  uint32_t n = c->fft_l;
+  c->FFT_buffer = (float *)calloc(2 * n, sizeof(float));
+  c->iFFT_buffer = (float *)calloc(2 * n, sizeof(float));
+  c->FIR_filter_mask = (float *)calloc(2 * n, sizeof(float));
+  c->mag = (float *)calloc(2 * n, sizeof(float));
+  c->float_buffer_L = (float *)calloc(c->hop, sizeof(float));
+  c->float_buffer_R = (float *)calloc(c->hop, sizeof(float));
+  c->last_L = (float *)calloc(c->hop, sizeof(float));
+  c->last_R = (float *)calloc(c->hop, sizeof(float));
+  c->coef_I = (double *)calloc(c->hop + 1, sizeof(double));
+  c->coef_Q = (double *)calloc(c->hop + 1, sizeof(double));
+  c->first_block = 1; /* CONV:42 */
+  c->oldNRLevel = 15; /* CONV:80 */
+  c->NFloor = 0.0f;   /* SPEC:109 */
+  c->agc_g = 1.0f;
+  c->am_dc = 0.0f;
+  /* NCO: 32-bit phase accumulator, closed form of the absolute sample index */
+  {
+    double turns = cfg->nco_hz / cfg->fs_in;
+    long long q = llround(turns * 4294967296.0);
+    c->dphi = (uint32_t)(uint64_t)q;
+  }
+  /* decimator taps: same windowed-sinc law with FLo=-B, FHi=+B (nFs = 0) */
+  if (decim > 1) {
+    int nt = cfg->fir_taps;
+    double *ti = (double *)calloc((size_t)nt, sizeof(double));
+    double *tq = (double *)calloc((size_t)nt, sizeof(double));
+    orc_calc_cplx_FIR_coeffs(ti, tq, nt, -cfg->fir_cut_hz, cfg->fir_cut_hz, cfg->fs_in,
+                             cfg->window);
+    c->fir_taps = (float *)calloc((size_t)nt, sizeof(float));
+    for (int i = 0; i < nt; i++) c->fir_taps[i] = (float)ti[i];
+    free(ti);
+    free(tq);
+    c->fir_ring_re = (float *)calloc((size_t)nt, sizeof(float));
+    c->fir_ring_im = (float *)calloc((size_t)nt, sizeof(float));
+  }
+  /* boot order of the sketch: Init_LMS_NR(15) INO:172,
+   * doConvolutionalInitialize INO:180, reInitializeFilter INO:183 */
+  lms_init(&c->nr, 15);
+  lms_init(&c->als, cfg->als_strength > 0 ? cfg->als_strength : 15);
+  orc_doConvolutionalInitialize(c);
+  orc_reInitializeFilter(c, cfg->flo_hz, cfg->fhi_hz);
+  return c;
+}
+
+void orc_chain_destroy(orc_chain_t *c) {
+  if (!c) return;
+  free(c->FFT_buffer); free(c->iFFT_buffer); free(c->FIR_filter_mask); free(c->mag);
+  free(c->float_buffer_L); free(c->float_buffer_R); free(c->last_L); free(c->last_R);
+  free(c->coef_I); free(c->coef_Q); free(c->fir_taps); free(c->fir_ring_re);
+  free(c->fir_ring_im);
+  free(c);
+}
+
+/* One overlap-save frame: CONV:256-318 (+ SPEC:179-238 when spectral_nr). */
+static void conv_frame(orc_chain_t *c) {
+  const uint32_t N = c->fft_l, H = c->hop;
+  float *F = c->FFT_buffer, *G = c->iFFT_buffer;
+  if (c->first_block) { /* CONV:256-263: history = zeros */
+    for (uint32_t i = 0; i < N; i++) F[i] = 0.0f;
+    c->first_block = 0;
+  } else { /* CONV:267-271 */
+    for (uint32_t i = 0; i < H; i++) {
+      F[2 * i] = c->last_L[i];
+      F[2 * i + 1] = c->last_R[i];
+    }
+  }
+  for (uint32_t i = 0; i < H; i++) { /* CONV:274-278 */
+    c->last_L[i] = c->float_buffer_L[i];
+    c->last_R[i] = c->float_buffer_R[i];
+  }
+  for (uint32_t i = 0; i < H; i++) { /* CONV:281-285 */
+    F[N + 2 * i] = c->float_buffer_L[i];
+    F[N + 2 * i + 1] = c->float_buffer_R[i];
+  }
+  orc_cfft_f32(F, N, 0); /* CONV:291 */
+
+  if (c->cfg.spectral_nr) {
+    /* SPEC:182-238, with the out-of-bounds loop limits restated as j < FFT_L
+     *  and VAD bins scaled with FFT_L (SPEC:34-35 are for 256). */
+    float *mag = c->mag;
+    orc_cmplx_mag_f32(F, mag, N); /* SPEC:182 */
+    int lo = (int)(30u * N / 256u), hi = (int)(180u * N / 256u);
+    float specVal = 0.0f;
+    for (int m = lo; m <= hi; m++) specVal = specVal + mag[m]; /* SPEC:194-197 */
+    float TH = specVal / (float)(hi - lo);                     /* SPEC:200 */
+    TH = (float)((double)TH * ((double)c->cfg.spectral_level * 1.5)); /* SPEC:202 */
+    const float beta = 0.65f;                                  /* SPEC:115 */
+    c->NFloor += (TH - c->NFloor) * beta;                      /* SPEC:205 */
+    c->NFloor = (c->NFloor > 0) ? c->NFloor : 0;               /* SPEC:206 */
+    for (uint32_t j = 0; j < N; j++) {                         /* SPEC:210-218 */
+      float m0 = mag[j], m1;
+      if (m0 <= c->NFloor) m1 = (float)((double)m0 * 0.2);
+      else m1 = m0 - c->NFloor;
+      /* SPEC:226-235: mag' * (cos phi + j sin phi) == X * mag'/mag */
+      float sc = (m0 > 0.0f) ? (m1 / m0) : 0.0f;
+      F[2 * j] = F[2 * j] * sc;
+      F[2 * j + 1] = F[2 * j + 1] * sc;
+    }
+  }
+  if (c->cfg.filter_on) /* CONV:300-301 */
+    orc_cmplx_mult_cmplx_f32(F, c->FIR_filter_mask, G, N);
+  else /* CONV:303 copies only FFT_length floats (bug, never exercised);
+          restated as a full bypass */
+    memcpy(G, F, 2 * N * sizeof(float));
+  orc_cfft_f32(G, N, 1); /* CONV:309 */
+  for (uint32_t i = 0; i < H; i++) { /* CONV:314-318 */
+    c->float_buffer_L[i] = G[N + 2 * i];
+    c->float_buffer_R[i] = G[N + 2 * i + 1];
+  }
+}
+
+/* post-filter stages on one 128-sample block (L, R in place) */
+static void post_block(orc_chain_t *c, float *L, float *R) {
+  const orc_config_t *cf = &c->cfg;
+  /* demodulator selection (build-defined) */
+  if (cf->demod == ORC_DEMOD_AM) {
+    float a[ORC_BLOCK], s = 0.0f;
+    for (int i = 0; i < ORC_BLOCK; i++) {
+      a[i] = sqrtf(L[i] * L[i] + R[i] * R[i]);
+      s += a[i];
+    }
+    float m = s / (float)ORC_BLOCK;
+    float dc_new = c->am_dc + 0.25f * (m - c->am_dc);
+    for (int i = 0; i < ORC_BLOCK; i++) {
+      float dc = c->am_dc + (dc_new - c->am_dc) * ((float)(i + 1) / (float)ORC_BLOCK);
+      L[i] = a[i] - dc;
+      R[i] = L[i];
+    }
+    c->am_dc = dc_new;
+  } else if (cf->demod != ORC_DEMOD_IQ) {
+    for (int i = 0; i < ORC_BLOCK; i++) R[i] = L[i];
+  }
+  /* CONV:326-337 (applied per 128-block: deviation from the N_BLOCKS>1 bug) */
+  if (cf->lms_nr > 0) {
+    if (cf->lms_nr != c->oldNRLevel) { /* CONV:327-330 */
+      lms_init(&c->nr, cf->lms_nr);
+      c->oldNRLevel = cf->lms_nr;
+    }
+    lms_noise_reduction(&c->nr, ORC_BLOCK, L, NULL); /* CONV:332 */
+    for (int i = 0; i < ORC_BLOCK; i++) {            /* CONV:333-336 */
+      L[i] = (float)((double)L[i] * 1.1);
+      R[i] = L[i];
+    }
+  }
+  /* ALS filter: second NLMS instance; notch = error, peak = prediction */
+  if (cf->als_mode != ORC_ALS_OFF) {
+    float y[ORC_BLOCK], e[ORC_BLOCK];
+    memcpy(y, L, sizeof(y));
+    lms_noise_reduction(&c->als, ORC_BLOCK, y, e);
+    const float *o = (cf->als_mode == ORC_ALS_NOTCH) ? e : y;
+    for (int i = 0; i < ORC_BLOCK; i++) {
+      L[i] = o[i];
+      R[i] = o[i];
+    }
+  }
+  /* AGC (build-defined): block power -> target gain -> one-pole attack/decay,
+   * gain ramped linearly across the block */
+  if (cf->agc_mode != ORC_AGC_OFF) {
+    float attack, decay;
+    agc_params(cf->agc_mode, &attack, &decay);
+    float p = 0.0f;
+    for (int i = 0; i < ORC_BLOCK; i++) p += L[i] * L[i] + R[i] * R[i];
+    p = p / (float)(2 * ORC_BLOCK);
+    float rms = sqrtf(p);
+    float gt = 0.25f / (rms + 1e-6f);
+    if (gt > 100.0f) gt = 100.0f;
+    float coef = (gt < c->agc_g) ? attack : decay;
+    float g_new = c->agc_g + coef * (gt - c->agc_g);
+    for (int i = 0; i < ORC_BLOCK; i++) {
+      float g = c->agc_g + (g_new - c->agc_g) * ((float)(i + 1) / (float)ORC_BLOCK);
+      L[i] = L[i] * g;
+      R[i] = R[i] * g;
+    }
+    c->agc_g = g_new;
+  }
+  float og = cf->mute ? 0.0f : cf->output_gain;
+  for (int i = 0; i < ORC_BLOCK; i++) {
+    L[i] = L[i] * og;
+    R[i] = R[i] * og;
+  }
+}
+
+int orc_chain_process(orc_chain_t *c, const int16_t *iq, int n_blocks,
+                      int16_t *out_i16, float *out_f32) {
+  const orc_config_t *cf = &c->cfg;
+  int produced = 0;
+  for (int b = 0; b < n_blocks; b++) {
+    for (int i = 0; i < ORC_BLOCK; i++) {
+      const int16_t *s = &iq[2 * ((size_t)b * ORC_BLOCK + (size_t)i)];
+      /* arm_q15_to_float, CONV:241-242 */
+      float xr = (float)s[0] / 32768.0f;
+      float xi = (float)s[1] / 32768.0f;
+      xr = xr * cf->iq_balance; /* setIQgainBalance, INO:135 */
+      xr = xr * cf->input_gain; /* setInputGain, INO:133 */
+      xi = xi * cf->input_gain;
+      uint64_t n = c->n_in++;
+      if (c->dphi != 0u) { /* y = x * exp(-j*theta_n) */
+        uint32_t ph = (uint32_t)n * c->dphi;
+        double th = ORC_TWO_PI * (double)ph / 4294967296.0;
+        float co = (float)cos(th), si = (float)sin(th);
+        float yr = xr * co + xi * si;
+        float yi = xi * co - xr * si;
+        xr = yr;
+        xi = yi;
+      }
+      if (cf->decim > 1) {
+        uint32_t nt = (uint32_t)cf->fir_taps;
+        c->fir_ring_re[c->fir_pos] = xr;
+        c->fir_ring_im[c->fir_pos] = xi;
+        uint32_t newest = c->fir_pos;
+        c->fir_pos = (c->fir_pos + 1) % nt;
+        if ((n % (uint64_t)cf->decim) != 0) continue;
+        /* y[m] = sum_k h[k] x[4m-k] */
+        float ar = 0.0f, ai = 0.0f;
+        uint32_t p = newest;
+        for (uint32_t k = 0; k < nt; k++) {
+          ar += c->fir_taps[k] * c->fir_ring_re[p];
+          ai += c->fir_taps[k] * c->fir_ring_im[p];
+          p = (p == 0) ? nt - 1 : p - 1;
+        }
+        xr = ar;
+        xi = ai;
+      }
+      c->float_buffer_L[c->fill] = xr;
+      c->float_buffer_R[c->fill] = xi;
+      c->fill++;
+      if (c->fill == c->hop) {
+        c->fill = 0;
+        conv_frame(c);
+        for (uint32_t q = 0; q < c->hop; q += ORC_BLOCK) {
+          float *L = &c->float_buffer_L[q], *R = &c->float_buffer_R[q];
+          post_block(c, L, R);
+          for (int j = 0; j < ORC_BLOCK; j++) {
+            if (out_f32) {
+              out_f32[2 * (produced + j)] = L[j];
+              out_f32[2 * (produced + j) + 1] = R[j];
+            }
+          }
+          if (out_i16) { /* arm_float_to_q15, CONV:346-347 */
+            int16_t l16[ORC_BLOCK], r16[ORC_BLOCK];
+            orc_float_to_q15(L, l16, ORC_BLOCK);
+            orc_float_to_q15(R, r16, ORC_BLOCK);
+            for (int j = 0; j < ORC_BLOCK; j++) {
+              out_i16[2 * (produced + j)] = l16[j];
+              out_i16[2 * (produced + j) + 1] = r16[j];
+            }
+          }
+          produced += ORC_BLOCK;
+        }
+      }
+    }
+  }
+  return produced;
+}
+
+const float *orc_chain_mask(const orc_chain_t *c) { return c->FIR_filter_mask; }
+const float *orc_chain_fir_taps(const orc_chain_t *c) { return c->fir_taps; }
+const float *orc_chain_lms_coeffs(const orc_chain_t *c, int which) {
+  return which ? c->als.coeffs : c->nr.coeffs;
+}
+float orc_chain_nfloor(const orc_chain_t *c) { return c->NFloor; }
+float orc_chain_agc_gain(const orc_chain_t *c) { return c->agc_g; }
+uint32_t orc_chain_nco_dphi(const orc_chain_t *c) { return c->dphi; }
+
+int orc_multi_process(const orc_config_t *cfg, int n_ch, const int16_t *iq,
+                      int n_blocks, int16_t *out_i16, int n_threads) {
+  int decim = cfg->decim < 1 ? 1 : cfg->decim;
+  size_t in_stride = (size_t)n_blocks * ORC_BLOCK * 2;
+  size_t out_stride = (size_t)n_blocks * ORC_BLOCK / (size_t)decim * 2;
+  int produced = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+  (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int ch = 0; ch < n_ch; ch++) {
+    orc_chain_t *c = orc_chain_create(cfg);
+    int p = orc_chain_process(c, iq + (size_t)ch * in_stride, n_blocks,
+                              out_i16 ? out_i16 + (size_t)ch * out_stride : NULL, NULL);
+    orc_chain_destroy(c);
+    if (ch == 0) produced = p;
+  }
+  return produced;
+}

@@ -1,0 +1,135 @@
+/*
+ * rdsp_oracle.h -- CPU ORACLE for the per-block IQ receive chain.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke()
+ * check in __graft_entry__.py and the cpu_baseline leg of bench.py may load
+ * it.  The product path (radiodsp_sdr_rx_amd/) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference (gcallipo/RadioDSP_SDR_RX, an Arduino/Teensy
+ * sketch) ships no tests, golden vectors or fixtures, and cannot be compiled
+ * here (needs the Arduino core, Teensy Audio library, CMSIS-DSP and the
+ * AudioSDR library, none of them vendored or pinned).  This file is therefore
+ * a plain-C restatement of the in-tree algorithm, following the reference
+ * line by line where the code exists:
+ *
+ *   src/RadioDSP_SDR_RX/RDSP_convolutional.h   (CONV)  filter design, mask,
+ *                                                      overlap-save processing
+ *   src/RadioDSP_SDR_RX/RDSP_noise_reduction.h (NR)    NLMS noise reduction
+ *   src/backup/RDSP_convolutional_spec.h       (SPEC)  spectral subtraction NR
+ *
+ * and BUILD-DEFINED semantics (documented in DESIGN.md) for the stages that
+ * live in the un-vendored AudioSDR library: NCO mixer, polyphase FIR
+ * decimator, demodulator selection, LMS auto-notch (ALS filter), AGC.
+ * CMSIS-DSP primitives are restated from their published definitions
+ * (arm_q15_to_float, arm_float_to_q15, arm_cfft_f32, arm_cmplx_mult_cmplx_f32,
+ * arm_cmplx_mag_f32, arm_lms_norm_f32); bit parity with CMSIS is not claimed.
+ * It is anchored by analytic known-answer tests (tests/test_oracle_*.py) and
+ * by an independent float64 NumPy model (tests/np_model.py).
+ */
+#ifndef RDSP_ORACLE_H
+#define RDSP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_BLOCK 128 /* BUFFER_SIZE, CONV:34 */
+
+/* demodulator selection (engine enum names, CTL:330-410) */
+enum {
+  ORC_DEMOD_IQ = 0,  /* L = Re y, R = Im y : literal CONV:314-318            */
+  ORC_DEMOD_USB = 1, /* audio = Re y (one-sided positive passband)            */
+  ORC_DEMOD_LSB = 2, /* audio = Re y (one-sided negative passband)            */
+  ORC_DEMOD_CW_USB = 3,
+  ORC_DEMOD_CW_LSB = 4,
+  ORC_DEMOD_AM = 5 /* audio = |y| - block-smoothed DC                        */
+};
+
+enum { ORC_AGC_OFF = 0, ORC_AGC_FAST = 1, ORC_AGC_MEDIUM = 2, ORC_AGC_SLOW = 3 };
+enum { ORC_ALS_OFF = 0, ORC_ALS_NOTCH = 1, ORC_ALS_PEAK = 2 };
+
+/* One receiver channel's configuration.  Field order is mirrored by
+ * rdsp_chain_config_t in include/rdsp.h (tests fill both from one dict). */
+typedef struct {
+  double fs_in;        /* input IQ rate, Hz                                   */
+  int32_t decim;       /* 1 (no decimator) or 4                               */
+  int32_t fir_taps;    /* decimator taps (256); ignored when decim == 1       */
+  double fir_cut_hz;   /* decimator low-pass half-width B, Hz                 */
+  double nco_hz;       /* tuning offset removed by the mixer (0 = mixer off)  */
+  int32_t fft_l;       /* FFT_L: 256/512/1024/2048/4096 (CONV:36)             */
+  int32_t window;      /* FIR_filter_window id, 1 = Blackman-Harris (CONV:66) */
+  double flo_hz;       /* FLoCut (CONV:67)                                    */
+  double fhi_hz;       /* FHiCut (CONV:68)                                    */
+  int32_t filter_on;   /* bFilterEnabled (CONV:300)                           */
+  int32_t demod;       /* ORC_DEMOD_*                                         */
+  int32_t spectral_nr; /* 0/1: spectral subtraction (SPEC:112-269)            */
+  float spectral_level;/* iNRLevel of SPEC:112 (0..3)                         */
+  int32_t lms_nr;      /* 0 = off, else DSP-NR strength (NR:35; 15,20..50)    */
+  int32_t als_mode;    /* ORC_ALS_* : LMS auto-notch / peak                   */
+  int32_t als_strength;/* strength for the ALS instance's mu (same law)      */
+  int32_t agc_mode;    /* ORC_AGC_*                                           */
+  float input_gain;    /* SDR.setInputGain (INO:133)                          */
+  float output_gain;   /* SDR.setOutputGain (INO:134)                         */
+  float iq_balance;    /* SDR.setIQgainBalance (INO:135): I *= g              */
+  int32_t mute;        /* SDR.setMute                                         */
+} orc_config_t;
+
+typedef struct orc_chain orc_chain_t;
+
+/* ---- CMSIS-DSP primitive restatements ---------------------- */
+void orc_q15_to_float(const int16_t *src, float *dst, uint32_t n);
+void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n);
+void orc_cfft_f32(float *buf, uint32_t n, int inverse);
+void orc_cmplx_mult_cmplx_f32(const float *a, const float *b, float *dst, uint32_t n);
+void orc_cmplx_mag_f32(const float *src, float *dst, uint32_t n);
+
+/* ---- CONV:127-185 / CONV:87-110 ----------------------------------------- */
+void orc_calc_cplx_FIR_coeffs(double *coeffs_I, double *coeffs_Q, int numCoeffs,
+                              double FLoCut, double FHiCut, double SampleRate,
+                              int window);
+/* mask must hold 2*fft_l floats; taps: m_NumTaps = fft_l/2+1 doubles each */
+void orc_init_filter_mask(float *mask, const double *coef_I, const double *coef_Q,
+                          uint32_t fft_l);
+
+/* ---- chain object --------------------------------------------------------*/
+orc_chain_t *orc_chain_create(const orc_config_t *cfg);
+void orc_chain_destroy(orc_chain_t *c);
+
+/* reference-named stage calls, with the context pointer the globals became */
+void orc_doConvolutionalInitialize(orc_chain_t *c);            /* CONV:187 */
+void orc_reInitializeFilter(orc_chain_t *c, double lo, double hi); /* CONV:209 */
+void orc_Init_LMS_NR(orc_chain_t *c, int strength);            /* NR:35    */
+void orc_LMS_NoiseReduction(orc_chain_t *c, int16_t n, float *nrbuffer); /* NR:66 */
+void orc_Init_ALS(orc_chain_t *c, int strength);
+void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327 */
+
+/* Process n_blocks blocks of 128 interleaved int16 IQ samples.  Output is
+ * produced hop by hop (hop = fft_l/2 samples at the decimated rate); returns
+ * the number of output sample pairs written.  out_i16 is interleaved L,R
+ * (arm_float_to_q15 of the float audio); out_f32 (optional) receives the
+ * float L,R pairs before packing. */
+int orc_chain_process(orc_chain_t *c, const int16_t *iq, int n_blocks,
+                      int16_t *out_i16, float *out_f32);
+
+/* read-only views for tests */
+const float *orc_chain_mask(const orc_chain_t *c);
+const float *orc_chain_fir_taps(const orc_chain_t *c);
+const float *orc_chain_lms_coeffs(const orc_chain_t *c, int which);
+float orc_chain_nfloor(const orc_chain_t *c);
+float orc_chain_agc_gain(const orc_chain_t *c);
+uint32_t orc_chain_nco_dphi(const orc_chain_t *c);
+/* build-defined: tuning offset per demod mode, Hz (setDemodMode return) */
+uint32_t orc_demod_tuning_offset(int demod);
+
+/* Many-channel convenience used by the cpu_baseline leg: runs n_ch
+ * independent chains (same config) over iq[ch][n_blocks*128][2] with
+ * n_threads OpenMP threads.  Returns output pairs per channel. */
+int orc_multi_process(const orc_config_t *cfg, int n_ch, const int16_t *iq,
+                      int n_blocks, int16_t *out_i16, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

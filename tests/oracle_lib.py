@@ -1,0 +1,203 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Test infrastructure only: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+DEMOD = {"IQ": 0, "USB": 1, "LSB": 2, "CW_USB": 3, "CW_LSB": 4, "AM": 5}
+AGC = {"off": 0, "fast": 1, "medium": 2, "slow": 3}
+ALS = {"off": 0, "notch": 1, "peak": 2}
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("fs_in", C.c_double),
+        ("decim", C.c_int32),
+        ("fir_taps", C.c_int32),
+        ("fir_cut_hz", C.c_double),
+        ("nco_hz", C.c_double),
+        ("fft_l", C.c_int32),
+        ("window", C.c_int32),
+        ("flo_hz", C.c_double),
+        ("fhi_hz", C.c_double),
+        ("filter_on", C.c_int32),
+        ("demod", C.c_int32),
+        ("spectral_nr", C.c_int32),
+        ("spectral_level", C.c_float),
+        ("lms_nr", C.c_int32),
+        ("als_mode", C.c_int32),
+        ("als_strength", C.c_int32),
+        ("agc_mode", C.c_int32),
+        ("input_gain", C.c_float),
+        ("output_gain", C.c_float),
+        ("iq_balance", C.c_float),
+        ("mute", C.c_int32),
+    ]
+
+
+DEFAULTS = dict(
+    fs_in=96000.0, decim=4, fir_taps=256, fir_cut_hz=10000.0, nco_hz=12000.0,
+    fft_l=256, window=1, flo_hz=300.0, fhi_hz=2700.0, filter_on=1, demod="USB",
+    spectral_nr=0, spectral_level=0.0, lms_nr=0, als_mode="off", als_strength=20,
+    agc_mode="off", input_gain=1.0, output_gain=1.0, iq_balance=1.0, mute=0,
+)
+
+
+def fill_config(struct_cls, **kw):
+    """Build a config struct (oracle's or the product's: same field names)."""
+    d = dict(DEFAULTS)
+    d.update(kw)
+    if isinstance(d["demod"], str):
+        d["demod"] = DEMOD[d["demod"]]
+    if isinstance(d["agc_mode"], str):
+        d["agc_mode"] = AGC[d["agc_mode"]]
+    if isinstance(d["als_mode"], str):
+        d["als_mode"] = ALS[d["als_mode"]]
+    s = struct_cls()
+    for name, _ in struct_cls._fields_:
+        setattr(s, name, d[name])
+    return s
+
+
+def build(native=False, out_dir=None):
+    """Compile the oracle.  native=True builds the -O3 -march=native variant used
+    only for the cpu_baseline timing leg (built on the box it runs on)."""
+    if not native:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+        return os.path.join(ORACLE_DIR, "liboracle.so")
+    out_dir = out_dir or "/tmp"
+    so = os.path.join(out_dir, "liboracle_native.so")
+    subprocess.check_call(
+        ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-fopenmp", "-shared",
+         "-o", so, os.path.join(ORACLE_DIR, "rdsp_oracle.c"), "-lm"])
+    return so
+
+
+_lib = None
+
+
+def load(path=None):
+    global _lib
+    if path is None and _lib is not None:
+        return _lib
+    so = path or os.path.join(ORACLE_DIR, "liboracle.so")
+    if not os.path.exists(so):
+        build()
+    lib = C.CDLL(so)
+    f32p = C.POINTER(C.c_float)
+    f64p = C.POINTER(C.c_double)
+    i16p = C.POINTER(C.c_int16)
+    vp = C.c_void_p
+    lib.orc_q15_to_float.argtypes = [i16p, f32p, C.c_uint32]
+    lib.orc_float_to_q15.argtypes = [f32p, i16p, C.c_uint32]
+    lib.orc_cfft_f32.argtypes = [f32p, C.c_uint32, C.c_int]
+    lib.orc_calc_cplx_FIR_coeffs.argtypes = [f64p, f64p, C.c_int, C.c_double, C.c_double,
+                                             C.c_double, C.c_int]
+    lib.orc_init_filter_mask.argtypes = [f32p, f64p, f64p, C.c_uint32]
+    lib.orc_chain_create.argtypes = [C.POINTER(OrcConfig)]
+    lib.orc_chain_create.restype = vp
+    lib.orc_chain_destroy.argtypes = [vp]
+    lib.orc_reInitializeFilter.argtypes = [vp, C.c_double, C.c_double]
+    lib.orc_doConvolutionalInitialize.argtypes = [vp]
+    lib.orc_Init_LMS_NR.argtypes = [vp, C.c_int]
+    lib.orc_Init_ALS.argtypes = [vp, C.c_int]
+    lib.orc_set_nr_level.argtypes = [vp, C.c_int]
+    lib.orc_LMS_NoiseReduction.argtypes = [vp, C.c_int16, f32p]
+    lib.orc_chain_process.argtypes = [vp, i16p, C.c_int, i16p, f32p]
+    lib.orc_chain_process.restype = C.c_int
+    lib.orc_chain_mask.argtypes = [vp]
+    lib.orc_chain_mask.restype = f32p
+    lib.orc_chain_fir_taps.argtypes = [vp]
+    lib.orc_chain_fir_taps.restype = f32p
+    lib.orc_chain_lms_coeffs.argtypes = [vp, C.c_int]
+    lib.orc_chain_lms_coeffs.restype = f32p
+    lib.orc_chain_nfloor.argtypes = [vp]
+    lib.orc_chain_nfloor.restype = C.c_float
+    lib.orc_chain_agc_gain.argtypes = [vp]
+    lib.orc_chain_agc_gain.restype = C.c_float
+    lib.orc_chain_nco_dphi.argtypes = [vp]
+    lib.orc_chain_nco_dphi.restype = C.c_uint32
+    lib.orc_demod_tuning_offset.argtypes = [C.c_int]
+    lib.orc_demod_tuning_offset.restype = C.c_uint32
+    lib.orc_multi_process.argtypes = [C.POINTER(OrcConfig), C.c_int, i16p, C.c_int, i16p, C.c_int]
+    lib.orc_multi_process.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class OracleChain:
+    """One receiver channel run through the oracle."""
+
+    def __init__(self, lib=None, **kw):
+        self.lib = lib or load()
+        self.cfg = fill_config(OrcConfig, **kw)
+        self.h = self.lib.orc_chain_create(C.byref(self.cfg))
+        assert self.h
+        self.decim = max(1, self.cfg.decim)
+        self.fft_l = self.cfg.fft_l
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_chain_destroy(self.h)
+            self.h = None
+
+    def process(self, iq):
+        """iq: int16 [n_samples, 2] (n_samples multiple of 128).
+        Returns (out_i16 [n_out,2], out_f32 [n_out,2])."""
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        n = iq.shape[0]
+        assert n % 128 == 0
+        nmax = n // self.decim + self.fft_l
+        o16 = np.zeros((nmax, 2), np.int16)
+        o32 = np.zeros((nmax, 2), np.float32)
+        got = self.lib.orc_chain_process(self.h, _p(iq, C.c_int16), n // 128,
+                                         _p(o16, C.c_int16), _p(o32, C.c_float))
+        return o16[:got].copy(), o32[:got].copy()
+
+    def mask(self):
+        return np.ctypeslib.as_array(self.lib.orc_chain_mask(self.h), (2 * self.fft_l,)).copy()
+
+    def fir_taps(self):
+        return np.ctypeslib.as_array(self.lib.orc_chain_fir_taps(self.h), (self.cfg.fir_taps,)).copy()
+
+    def lms_coeffs(self, which=0):
+        return np.ctypeslib.as_array(self.lib.orc_chain_lms_coeffs(self.h, which), (96,)).copy()
+
+    def nfloor(self):
+        return float(self.lib.orc_chain_nfloor(self.h))
+
+    def agc_gain(self):
+        return float(self.lib.orc_chain_agc_gain(self.h))
+
+    def reinit_filter(self, lo, hi):
+        self.lib.orc_reInitializeFilter(self.h, lo, hi)
+
+    def set_nr_level(self, lvl):
+        self.lib.orc_set_nr_level(self.h, lvl)
+
+
+def multi_process(iq, n_threads=1, lib=None, **kw):
+    """iq int16 [n_ch, n_samples, 2] -> out int16 [n_ch, n_out, 2] (fresh chains)."""
+    lib = lib or load()
+    cfg = fill_config(OrcConfig, **kw)
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    n_ch, n, _ = iq.shape
+    decim = max(1, cfg.decim)
+    out = np.zeros((n_ch, n // decim, 2), np.int16)
+    got = lib.orc_multi_process(C.byref(cfg), n_ch, _p(iq, C.c_int16), n // 128,
+                                _p(out, C.c_int16), n_threads)
+    assert got == n // decim, (got, n // decim)
+    return out
