@@ -1,0 +1,188 @@
+/*
+ * rdsp.h -- C-ABI of the MI355X-native many-channel SDR receive chain.
+ *
+ * Drop-in boundary for the per-block IQ receive path of gcallipo/RadioDSP_SDR_RX.
+ * Every entry point cites the reference interface it replaces (paths relative
+ * to /root/reference/src):
+ *   CONV = RadioDSP_SDR_RX/RDSP_convolutional.h   NR  = RadioDSP_SDR_RX/RDSP_noise_reduction.h
+ *   SPEC = backup/RDSP_convolutional_spec.h       INO = RadioDSP_SDR_RX/RadioDSP_SDR_RX.ino
+ *   CTL  = RadioDSP_SDR_RX/RDSP_controls.h        FFTIQ = RadioDSP_SDR_RX/analyze_fft256iq.{h,cpp}
+ *
+ * The reference keeps all DSP state in single-instance globals (CONV:34-80,
+ * NR:18-32); here the same functions take a context pointer, and one context
+ * (`rdsp_chain_t`) holds n_channels independent receivers on one GPU.  Plain C:
+ * pointers and sizes only.  `d_` pointers are device (HBM) addresses, `stream`
+ * is a hipStream_t passed as void*.  All functions returning int return
+ * RDSP_OK (0) or a negative RDSP_ERR_*; rdsp_last_error() gives the text.
+ * There is no CPU fallback: without a GPU every compute call fails loudly.
+ */
+#ifndef RDSP_H
+#define RDSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDSP_BLOCK_SAMPLES 128 /* AUDIO_BLOCK_SAMPLES / BUFFER_SIZE, CONV:34, FFTIQ.cpp:44 */
+
+enum {
+  RDSP_OK = 0,
+  RDSP_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+  RDSP_ERR_NO_DEVICE = -2,   /* no HIP device: the product has no CPU path */
+  RDSP_ERR_HIP = -3,         /* a HIP runtime call failed */
+  RDSP_ERR_NOT_READY = -4,   /* not enough queued input (CONV:231) */
+  RDSP_ERR_UNSUPPORTED = -5, /* declared engine feature not built yet */
+  RDSP_ERR_NOMEM = -6
+};
+
+/* demodulator modes: engine enum of CTL:330-410 (+ IQ = literal CONV:314-318) */
+typedef enum {
+  RDSP_DEMOD_IQ = 0,
+  RDSP_DEMOD_USB = 1,    /* USBmode    */
+  RDSP_DEMOD_LSB = 2,    /* LSBmode    */
+  RDSP_DEMOD_CW_USB = 3, /* CW_USBmode */
+  RDSP_DEMOD_CW_LSB = 4, /* CW_LSBmode */
+  RDSP_DEMOD_AM = 5      /* AMmode     */
+} rdsp_demod_t;
+typedef enum { RDSP_AGC_OFF = 0, RDSP_AGC_FAST = 1, RDSP_AGC_MEDIUM = 2, RDSP_AGC_SLOW = 3 } rdsp_agc_t; /* CTL:200-218 */
+typedef enum { RDSP_ALS_OFF = 0, RDSP_ALS_NOTCH = 1, RDSP_ALS_PEAK = 2 } rdsp_als_t;                    /* CTL:250-261 */
+/* SDR.setAudioFilter enum, CTL:153-177,396 */
+typedef enum { RDSP_AUDIO_CW = 0, RDSP_AUDIO_2100 = 1, RDSP_AUDIO_2700 = 2, RDSP_AUDIO_3100 = 3,
+               RDSP_AUDIO_AM = 4, RDSP_AUDIO_WSPR = 5 } rdsp_audio_filter_t;
+
+/* One configuration shared by all channels of a chain (the reference's
+ * compile-time constants CONV:34-38,66-72 and run-time globals GEN:76-111). */
+typedef struct {
+  double fs_in;         /* input IQ rate, Hz (AUDIO_SAMPLE_RATE_EXACT role, CONV:35) */
+  int32_t decim;        /* 1 = no decimator (reference-native), 4 = polyphase /4   */
+  int32_t fir_taps;     /* decimator taps, 256                                       */
+  double fir_cut_hz;    /* decimator low-pass half-width, Hz                         */
+  double nco_hz;        /* tuning offset removed by the mixer (TuningOffset, INO:139) */
+  int32_t fft_l;        /* FFT_L, CONV:36: 256 512 1024 2048 4096                    */
+  int32_t window;       /* FIR_filter_window, CONV:66 (1 = Blackman-Harris)          */
+  double flo_hz;        /* FLoCut, CONV:67                                           */
+  double fhi_hz;        /* FHiCut, CONV:68                                           */
+  int32_t filter_on;    /* bFilterEnabled, CONV:228,300                              */
+  int32_t demod;        /* rdsp_demod_t                                              */
+  int32_t spectral_nr;  /* spectral-subtraction NR on/off, SPEC:112                  */
+  float spectral_level; /* iNRLevel of SPEC:112,202                                  */
+  int32_t lms_nr;       /* nr_level: 0 off, else DSP-NR strength, CONV:326, NR:35    */
+  int32_t als_mode;     /* rdsp_als_t                                                */
+  int32_t als_strength; /* mu law input for the ALS instance                         */
+  int32_t agc_mode;     /* rdsp_agc_t                                                */
+  float input_gain;     /* SDR.setInputGain, INO:133                                 */
+  float output_gain;    /* SDR.setOutputGain, INO:134                                */
+  float iq_balance;     /* SDR.setIQgainBalance, INO:135                             */
+  int32_t mute;         /* SDR.setMute, INO:177                                      */
+} rdsp_chain_config_t;
+
+typedef struct rdsp_chain rdsp_chain_t;
+
+const char *rdsp_last_error(void);
+const char *rdsp_version(void);
+int rdsp_device_count(void);
+
+/* ---- host-side design helpers ---------------------------------------------*/
+/* calc_cplx_FIR_coeffs, CONV:127 (window id added as a parameter: the
+ * reference reads the global FIR_filter_window, CONV:66) */
+void rdsp_calc_cplx_FIR_coeffs(double *coeffs_I, double *coeffs_Q, int numCoeffs, double FLoCut,
+                               double FHiCut, double SampleRate, int window);
+/* init_filter_mask, CONV:87: natural-order mask, 2*fft_l floats */
+int rdsp_init_filter_mask(float *mask, const double *coef_I, const double *coef_Q, int fft_l);
+
+/* ---- chain: n_channels receivers on one GPU ---------------------------------*/
+/* max_blocks_per_call sizes the intermediate audio buffer (no allocation ever
+ * happens inside rdsp_chain_process). */
+int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels, int device,
+                      int max_blocks_per_call, rdsp_chain_t **out);
+void rdsp_chain_destroy(rdsp_chain_t *c);
+int rdsp_chain_channels(const rdsp_chain_t *c);
+/* number of 128-sample input blocks per call must be a multiple of this
+ * (N_BLOCKS of CONV:38-39 seen from the input rate) */
+int rdsp_chain_granule_blocks(const rdsp_chain_t *c);
+/* zero all per-channel state (overlap block, FIR history, NLMS, NFloor, AGC) */
+int rdsp_chain_reset(rdsp_chain_t *c, void *stream);
+
+/* doConvolutionalInitialize(), CONV:187 */
+int rdsp_doConvolutionalInitialize(rdsp_chain_t *c, void *stream);
+/* reInitializeFilter(lo, hi), CONV:209 (PBT retune path CTL:569-612) */
+int rdsp_reInitializeFilter(rdsp_chain_t *c, double dFLoCut, double dFHiCut, void *stream);
+/* Init_LMS_NR(strength), NR:35 */
+int rdsp_Init_LMS_NR(rdsp_chain_t *c, int LMS_nr_strength, void *stream);
+
+/* The hot path.  doConvolutionalProcessing (CONV:228 / SPEC:112) with the
+ * engine stages in front and behind it, for every channel, over n_blocks
+ * input blocks of 128 IQ samples per channel.
+ *   d_iq   : int16 [n_channels][in_stride][2]   (I, Q interleaved)
+ *   d_out  : int16 [n_channels][out_stride][2]  (L, R interleaved), receives
+ *            n_blocks*128/decim sample pairs per channel
+ *   d_out_f32 : optional float [n_channels][out_stride][2], the same audio
+ *            before arm_float_to_q15 (parity tests)
+ * strides are in samples (pairs); in_stride must be a multiple of 4. */
+int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t in_stride, int n_blocks,
+                       int16_t *d_out, size_t out_stride, float *d_out_f32, void *stream);
+/* reference-shaped call: nr level and filter enable per call (CONV:228);
+ * the cut-off arguments are ignored exactly as in the reference (CONV:300). */
+int rdsp_doConvolutionalProcessing(rdsp_chain_t *c, float iNRLevel, int bFilterEnabled,
+                                   double dFLoCut, double dFHiCut, const int16_t *d_iq,
+                                   size_t in_stride, int n_blocks, int16_t *d_out,
+                                   size_t out_stride, void *stream);
+
+/* arm_q15_to_float / arm_float_to_q15 call sites CONV:241-242,346-347 */
+int rdsp_q15_to_float(const int16_t *d_src, float *d_dst, size_t n, void *stream);
+int rdsp_float_to_q15(const float *d_src, int16_t *d_dst, size_t n, void *stream);
+
+/* ---- engine setters: AudioSDR API visible at INO:117-139, CTL:149-423 ------*/
+int rdsp_sdr_enableAGC(rdsp_chain_t *c);                          /* INO:120 */
+int rdsp_sdr_disableAGC(rdsp_chain_t *c);                         /* CTL:268 */
+int rdsp_sdr_setAGCmode(rdsp_chain_t *c, int mode);               /* INO:121, CTL:200-218 */
+int rdsp_sdr_enableALSfilter(rdsp_chain_t *c);                    /* CTL:259 */
+int rdsp_sdr_disableALSfilter(rdsp_chain_t *c);                   /* INO:125 */
+int rdsp_sdr_setALSfilterNotch(rdsp_chain_t *c);                  /* CTL:260 */
+int rdsp_sdr_setALSfilterPeak(rdsp_chain_t *c);                   /* BK_INO:665 */
+int rdsp_sdr_setALSfilterAdaptive(rdsp_chain_t *c);               /* CTL:261 */
+int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c);                 /* BK_INO:1259 (F3: unsupported) */
+int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c);                /* INO:131 */
+int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db); /* BK_INO:1260 (F3) */
+int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g);              /* INO:133 */
+int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g);             /* INO:134 */
+int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g);          /* INO:135 */
+int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c);                  /* INO:137 */
+int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream); /* INO:138, CTL:153-177 */
+/* returns the tuning offset in Hz like the reference (INO:139, CTL:337-407) */
+uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream);
+int rdsp_sdr_setMute(rdsp_chain_t *c, int mute);                  /* INO:177 */
+int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of CTL:447 */
+int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, GEN:111, CTL:237-297 */
+int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* SPEC:112 iNRLevel */
+
+/* ---- state read-back (tests, checkpoint/resume) ------------------------------*/
+/* scal: float[n_channels][4] = NFloor (SPEC:109), AGC gain, AM DC, reserved */
+int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream);
+/* which: 0 = DSP-NR instance (NR:31), 1 = ALS instance; float[n_channels][96] in
+ * CMSIS coefficient order */
+int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void *stream);
+/* natural-order filter mask currently in use, float[2*fft_l] (CONV:77) */
+int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out);
+int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);
+
+/* ---- deterministic synthetic IQ generator (host) -------------------*/
+typedef struct {
+  double fs;        /* 96000 */
+  double f_off;     /* IF offset, 12000 */
+  int32_t cw;       /* 0: two USB tones + interferer; 1: keyed CW tone (K4) */
+  double amp_tone;  /* 0.20 */
+  double amp_carrier; /* 0.30 */
+  double sigma;     /* 0.05 per rail */
+} rdsp_synth_config_t;
+/* dst: int16 [n_ch][n_samples][2]; channels ch0..ch0+n_ch-1, samples t0..t0+n_samples-1 */
+void rdsp_synth_iq(int16_t *dst, int ch0, int n_ch, uint64_t t0, int n_samples,
+                   const rdsp_synth_config_t *cfg, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

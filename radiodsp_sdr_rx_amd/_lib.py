@@ -1,0 +1,135 @@
+"""ctypes loader for librdsp_hip.so (the C-ABI of include/rdsp.h).
+
+The library is built in-tree by __graft_entry__.build() / csrc/Makefile.  There
+is no Python or CPU fallback: if the shared object is missing, loading fails
+loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librdsp_hip.so")
+
+RDSP_OK = 0
+ERRORS = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "NOT_READY", -5: "UNSUPPORTED", -6: "NOMEM"}
+
+
+class RdspError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rdsp error {code} ({ERRORS.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class ChainConfig(C.Structure):
+    """rdsp_chain_config_t (include/rdsp.h)."""
+    _fields_ = [
+        ("fs_in", C.c_double),
+        ("decim", C.c_int32),
+        ("fir_taps", C.c_int32),
+        ("fir_cut_hz", C.c_double),
+        ("nco_hz", C.c_double),
+        ("fft_l", C.c_int32),
+        ("window", C.c_int32),
+        ("flo_hz", C.c_double),
+        ("fhi_hz", C.c_double),
+        ("filter_on", C.c_int32),
+        ("demod", C.c_int32),
+        ("spectral_nr", C.c_int32),
+        ("spectral_level", C.c_float),
+        ("lms_nr", C.c_int32),
+        ("als_mode", C.c_int32),
+        ("als_strength", C.c_int32),
+        ("agc_mode", C.c_int32),
+        ("input_gain", C.c_float),
+        ("output_gain", C.c_float),
+        ("iq_balance", C.c_float),
+        ("mute", C.c_int32),
+    ]
+
+
+class SynthConfig(C.Structure):
+    """rdsp_synth_config_t (include/rdsp.h)."""
+    _fields_ = [
+        ("fs", C.c_double),
+        ("f_off", C.c_double),
+        ("cw", C.c_int32),
+        ("amp_tone", C.c_double),
+        ("amp_carrier", C.c_double),
+        ("sigma", C.c_double),
+    ]
+
+
+_lib = None
+
+# every symbol include/rdsp.h declares: (name, restype, argtypes)
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+_f32p, _f64p, _i16p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int16)
+SYMBOLS = [
+    ("rdsp_last_error", C.c_char_p, []),
+    ("rdsp_version", C.c_char_p, []),
+    ("rdsp_device_count", _i, []),
+    ("rdsp_calc_cplx_FIR_coeffs", None, [_f64p, _f64p, _i, _d, _d, _d, _i]),
+    ("rdsp_init_filter_mask", _i, [_f32p, _f64p, _f64p, _i]),
+    ("rdsp_chain_create", _i, [C.POINTER(ChainConfig), _i, _i, _i, C.POINTER(_vp)]),
+    ("rdsp_chain_destroy", None, [_vp]),
+    ("rdsp_chain_channels", _i, [_vp]),
+    ("rdsp_chain_granule_blocks", _i, [_vp]),
+    ("rdsp_chain_reset", _i, [_vp, _vp]),
+    ("rdsp_doConvolutionalInitialize", _i, [_vp, _vp]),
+    ("rdsp_reInitializeFilter", _i, [_vp, _d, _d, _vp]),
+    ("rdsp_Init_LMS_NR", _i, [_vp, _i, _vp]),
+    ("rdsp_chain_process", _i, [_vp, _vp, _sz, _i, _vp, _sz, _vp, _vp]),
+    ("rdsp_doConvolutionalProcessing", _i, [_vp, _f, _i, _d, _d, _vp, _sz, _i, _vp, _sz, _vp]),
+    ("rdsp_q15_to_float", _i, [_vp, _vp, _sz, _vp]),
+    ("rdsp_float_to_q15", _i, [_vp, _vp, _sz, _vp]),
+    ("rdsp_sdr_enableAGC", _i, [_vp]),
+    ("rdsp_sdr_disableAGC", _i, [_vp]),
+    ("rdsp_sdr_setAGCmode", _i, [_vp, _i]),
+    ("rdsp_sdr_enableALSfilter", _i, [_vp]),
+    ("rdsp_sdr_disableALSfilter", _i, [_vp]),
+    ("rdsp_sdr_setALSfilterNotch", _i, [_vp]),
+    ("rdsp_sdr_setALSfilterPeak", _i, [_vp]),
+    ("rdsp_sdr_setALSfilterAdaptive", _i, [_vp]),
+    ("rdsp_sdr_enableNoiseBlanker", _i, [_vp]),
+    ("rdsp_sdr_disableNoiseBlanker", _i, [_vp]),
+    ("rdsp_sdr_setNoiseBlankerThresholdDb", _i, [_vp, _f]),
+    ("rdsp_sdr_setInputGain", _i, [_vp, _f]),
+    ("rdsp_sdr_setOutputGain", _i, [_vp, _f]),
+    ("rdsp_sdr_setIQgainBalance", _i, [_vp, _f]),
+    ("rdsp_sdr_enableAudioFilter", _i, [_vp]),
+    ("rdsp_sdr_setAudioFilter", _i, [_vp, _i, _vp]),
+    ("rdsp_sdr_setDemodMode", C.c_uint32, [_vp, _i, _vp]),
+    ("rdsp_sdr_setMute", _i, [_vp, _i]),
+    ("rdsp_sdr_setTuningOffsetHz", _i, [_vp, _d]),
+    ("rdsp_set_nr_level", _i, [_vp, _i]),
+    ("rdsp_set_spectral_nr", _i, [_vp, _i, _f]),
+    ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
+    ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
+    ("rdsp_chain_get_mask", _i, [_vp, _f32p]),
+    ("rdsp_chain_get_fir_taps", _i, [_vp, _f32p]),
+    ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
+]
+
+
+def load():
+    """Load librdsp_hip.so and bind every declared entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != RDSP_OK:
+        raise RdspError(rc, load().rdsp_last_error().decode())
+    return rc

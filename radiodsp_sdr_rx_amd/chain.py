@@ -1,0 +1,165 @@
+"""Host-side mirror of the reference's stage interface for the receive path.
+
+`Chain` wraps one rdsp_chain_t (n_channels receivers on one GPU).  Method names
+follow the reference's free functions (RDSP_convolutional.h:187-228,
+RDSP_noise_reduction.h:35) and the AudioSDR setters visible at
+RadioDSP_SDR_RX.ino:117-139.  PyTorch is used only for device memory and
+streams; the compute is librdsp_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import make_config, synth_config
+
+
+def _stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+class Chain:
+    def __init__(self, n_channels, max_blocks_per_call=512, device=0, **cfg):
+        self.lib = _lib.load()
+        self.cfg = make_config(**cfg)
+        self.n_channels = int(n_channels)
+        self.device = int(device)
+        self.decim = max(1, self.cfg.decim)
+        self.fft_l = self.cfg.fft_l
+        h = C.c_void_p()
+        _lib.check(self.lib.rdsp_chain_create(C.byref(self.cfg), self.n_channels, self.device,
+                                              int(max_blocks_per_call), C.byref(h)))
+        self.h = h
+        self.granule_blocks = self.lib.rdsp_chain_granule_blocks(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rdsp_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path ------------------------------------------------------
+    def process(self, iq, out=None, out_f32=None, want_f32=False, stream=None):
+        """iq: int16 cuda tensor [n_channels, n_samples, 2].  Returns int16
+        [n_channels, n_samples/decim, 2] (and the float pairs if requested)."""
+        assert iq.is_cuda and iq.dtype == torch.int16 and iq.dim() == 3 and iq.shape[2] == 2
+        assert iq.shape[0] == self.n_channels and iq.is_contiguous()
+        n = iq.shape[1]
+        assert n % 128 == 0
+        n_out = n // self.decim
+        if out is None:
+            out = torch.empty((self.n_channels, n_out, 2), dtype=torch.int16, device=iq.device)
+        if want_f32 and out_f32 is None:
+            out_f32 = torch.empty((self.n_channels, n_out, 2), dtype=torch.float32, device=iq.device)
+        f32p = C.c_void_p(out_f32.data_ptr()) if out_f32 is not None else C.c_void_p(0)
+        _lib.check(self.lib.rdsp_chain_process(
+            self.h, C.c_void_p(iq.data_ptr()), iq.stride(0), n // 128,
+            C.c_void_p(out.data_ptr()), out.stride(0), f32p, _stream_ptr(stream)))
+        return (out, out_f32) if want_f32 else out
+
+    # ---- reference-named stage calls ----------------------------------------
+    def doConvolutionalInitialize(self, stream=None):
+        _lib.check(self.lib.rdsp_doConvolutionalInitialize(self.h, _stream_ptr(stream)))
+
+    def reInitializeFilter(self, dFLoCut, dFHiCut, stream=None):
+        _lib.check(self.lib.rdsp_reInitializeFilter(self.h, dFLoCut, dFHiCut, _stream_ptr(stream)))
+
+    def Init_LMS_NR(self, strength, stream=None):
+        _lib.check(self.lib.rdsp_Init_LMS_NR(self.h, int(strength), _stream_ptr(stream)))
+
+    def doConvolutionalProcessing(self, iNRLevel, bFilterEnabled, dFLoCut, dFHiCut, iq, out=None,
+                                  stream=None):
+        n = iq.shape[1]
+        if out is None:
+            out = torch.empty((self.n_channels, n // self.decim, 2), dtype=torch.int16,
+                              device=iq.device)
+        _lib.check(self.lib.rdsp_doConvolutionalProcessing(
+            self.h, float(iNRLevel), int(bool(bFilterEnabled)), dFLoCut, dFHiCut,
+            C.c_void_p(iq.data_ptr()), iq.stride(0), n // 128, C.c_void_p(out.data_ptr()),
+            out.stride(0), _stream_ptr(stream)))
+        return out
+
+    def reset(self, stream=None):
+        _lib.check(self.lib.rdsp_chain_reset(self.h, _stream_ptr(stream)))
+
+    # ---- AudioSDR-style setters (INO:117-139, CTL:149-423) -------------------
+    def enableAGC(self): _lib.check(self.lib.rdsp_sdr_enableAGC(self.h))
+    def disableAGC(self): _lib.check(self.lib.rdsp_sdr_disableAGC(self.h))
+    def setAGCmode(self, mode): _lib.check(self.lib.rdsp_sdr_setAGCmode(self.h, int(mode)))
+    def enableALSfilter(self): _lib.check(self.lib.rdsp_sdr_enableALSfilter(self.h))
+    def disableALSfilter(self): _lib.check(self.lib.rdsp_sdr_disableALSfilter(self.h))
+    def setALSfilterNotch(self): _lib.check(self.lib.rdsp_sdr_setALSfilterNotch(self.h))
+    def setALSfilterPeak(self): _lib.check(self.lib.rdsp_sdr_setALSfilterPeak(self.h))
+    def setALSfilterAdaptive(self): _lib.check(self.lib.rdsp_sdr_setALSfilterAdaptive(self.h))
+    def enableNoiseBlanker(self): _lib.check(self.lib.rdsp_sdr_enableNoiseBlanker(self.h))
+    def disableNoiseBlanker(self): _lib.check(self.lib.rdsp_sdr_disableNoiseBlanker(self.h))
+    def setInputGain(self, g): _lib.check(self.lib.rdsp_sdr_setInputGain(self.h, float(g)))
+    def setOutputGain(self, g): _lib.check(self.lib.rdsp_sdr_setOutputGain(self.h, float(g)))
+    def setIQgainBalance(self, g): _lib.check(self.lib.rdsp_sdr_setIQgainBalance(self.h, float(g)))
+    def enableAudioFilter(self): _lib.check(self.lib.rdsp_sdr_enableAudioFilter(self.h))
+    def setAudioFilter(self, f, stream=None):
+        _lib.check(self.lib.rdsp_sdr_setAudioFilter(self.h, int(f), _stream_ptr(stream)))
+    def setDemodMode(self, mode, stream=None):
+        return int(self.lib.rdsp_sdr_setDemodMode(self.h, int(mode), _stream_ptr(stream)))
+    def setMute(self, m): _lib.check(self.lib.rdsp_sdr_setMute(self.h, int(bool(m))))
+    def setTuningOffsetHz(self, hz): _lib.check(self.lib.rdsp_sdr_setTuningOffsetHz(self.h, float(hz)))
+    def set_nr_level(self, lvl): _lib.check(self.lib.rdsp_set_nr_level(self.h, int(lvl)))
+    def set_spectral_nr(self, on, level): _lib.check(self.lib.rdsp_set_spectral_nr(self.h, int(on), float(level)))
+
+    # ---- state read-back ------------------------------------------------------
+    def scalars(self, stream=None):
+        a = np.zeros((self.n_channels, 4), np.float32)
+        _lib.check(self.lib.rdsp_chain_get_scalars(self.h, a.ctypes.data_as(_lib._f32p), _stream_ptr(stream)))
+        return a
+
+    def lms_coeffs(self, which=0, stream=None):
+        a = np.zeros((self.n_channels, 96), np.float32)
+        _lib.check(self.lib.rdsp_chain_get_lms_coeffs(self.h, which, a.ctypes.data_as(_lib._f32p), _stream_ptr(stream)))
+        return a
+
+    def mask(self):
+        a = np.zeros(2 * self.fft_l, np.float32)
+        _lib.check(self.lib.rdsp_chain_get_mask(self.h, a.ctypes.data_as(_lib._f32p)))
+        return a
+
+    def fir_taps(self):
+        a = np.zeros(256, np.float32)
+        _lib.check(self.lib.rdsp_chain_get_fir_taps(self.h, a.ctypes.data_as(_lib._f32p)))
+        return a
+
+
+def synth_iq(n_channels, n_samples, ch0=0, t0=0, cw=False, n_threads=0, out=None):
+    """Deterministic synthetic IQ: int16 numpy [n_channels, n_samples, 2]."""
+    lib = _lib.load()
+    if out is None:
+        out = np.empty((n_channels, n_samples, 2), np.int16)
+    sc = synth_config(cw=cw)
+    lib.rdsp_synth_iq(out.ctypes.data_as(_lib._i16p), int(ch0), int(n_channels), int(t0),
+                      int(n_samples), C.byref(sc), int(n_threads))
+    return out
+
+
+def calc_cplx_FIR_coeffs(numCoeffs, FLoCut, FHiCut, SampleRate, window=1):
+    lib = _lib.load()
+    ci = np.zeros(numCoeffs)
+    cq = np.zeros(numCoeffs)
+    lib.rdsp_calc_cplx_FIR_coeffs(ci.ctypes.data_as(_lib._f64p), cq.ctypes.data_as(_lib._f64p),
+                                  numCoeffs, FLoCut, FHiCut, SampleRate, window)
+    return ci, cq
+
+
+def init_filter_mask(coef_I, coef_Q, fft_l):
+    lib = _lib.load()
+    m = np.zeros(2 * fft_l, np.float32)
+    rc = lib.rdsp_init_filter_mask(m.ctypes.data_as(_lib._f32p),
+                                   np.ascontiguousarray(coef_I).ctypes.data_as(_lib._f64p),
+                                   np.ascontiguousarray(coef_Q).ctypes.data_as(_lib._f64p), fft_l)
+    _lib.check(rc)
+    return m

@@ -1,0 +1,516 @@
+/*
+ * rdsp_chain.hip -- C-ABI launch layer: the chain object (per-channel state in
+ * HBM, shared tables) and the calls declared in include/rdsp.h.  Host logic
+ * only; the arithmetic lives in rdsp_kernels.hip.  No CPU fallback exists: if
+ * HIP reports no device every compute entry point returns RDSP_ERR_NO_DEVICE.
+ */
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rdsp_host.h"
+#include "rdsp_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void rdsp_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *rdsp_last_error(void) { return g_err; }
+extern "C" const char *rdsp_version(void) { return "rdsp-amd 0.1 (gfx950)"; }
+
+extern "C" int rdsp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      rdsp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RDSP_ERR_HIP;                                                         \
+    }                                                                              \
+  } while (0)
+
+struct rdsp_chain {
+  rdsp_chain_config_t cfg;
+  int n_channels, device, max_blocks;
+  int N, decim, hop;
+  uint64_t n_in;       /* absolute input sample counter */
+  uint32_t dphi;
+  int old_nr_level;    /* oldNRLevel, CONV:80 */
+  float nr_mu, als_mu;
+  long nr_calls, als_calls; /* NR:69 ring statics: only "first call" matters */
+  std::vector<double> coef_I, coef_Q; /* FIR_Coef_I/Q, CONV:69-70 */
+  std::vector<float> mask_nat;        /* FIR_filter_mask, CONV:77 */
+  std::vector<float> fir_nat;
+  /* device */
+  float2 *d_maskp = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
+  float *d_fir_hc = nullptr;
+  uint32_t *d_hist = nullptr;
+  float2 *d_prev = nullptr;
+  float *d_scal = nullptr;
+  float *d_nr_w = nullptr, *d_nr_prev = nullptr, *d_nr_energy = nullptr;
+  float *d_als_w = nullptr, *d_als_prev = nullptr, *d_als_energy = nullptr;
+  float *d_mid = nullptr;
+  size_t mid_stride = 0;
+  int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
+  int audio_filter = RDSP_AUDIO_2700;
+};
+
+static int check_device(rdsp_chain_t *c) {
+  if (hipSetDevice(c->device) != hipSuccess) {
+    rdsp_set_error("hipSetDevice(%d) failed", c->device);
+    return RDSP_ERR_HIP;
+  }
+  return RDSP_OK;
+}
+
+static void agc_params(int mode, float *attack, float *decay) {
+  *attack = 0.6f;
+  switch (mode) {
+    case RDSP_AGC_FAST: *decay = 0.10f; break;
+    case RDSP_AGC_MEDIUM: *decay = 0.03f; break;
+    case RDSP_AGC_SLOW: *decay = 0.008f; break;
+    default: *decay = 0.0f; break;
+  }
+}
+
+static uint32_t demod_tuning_offset(int demod) {
+  /* build-defined: CW modes put the carrier 700 Hz off, everything else tunes
+   * to the carrier (the AudioSDR values behind INO:139 are not in the tree) */
+  return (demod == RDSP_DEMOD_CW_USB || demod == RDSP_DEMOD_CW_LSB) ? 700u : 0u;
+}
+
+/* upload the device image of the current mask (or all-pass when the filter is
+ * disabled); synchronous with respect to `stream` (the reference does the same
+ * work under AudioNoInterrupts, CONV:211-222) */
+static int upload_mask(rdsp_chain_t *c, hipStream_t stream) {
+  std::vector<float> img(2 * (size_t)c->N);
+  rdsp_mask_device_image(c->cfg.filter_on ? c->mask_nat.data() : nullptr, c->N, img.data());
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipMemcpy(c->d_maskp, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  return RDSP_OK;
+}
+
+extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels, int device,
+                                 int max_blocks_per_call, rdsp_chain_t **out) {
+  if (!cfg || !out || n_channels <= 0 || max_blocks_per_call <= 0) {
+    rdsp_set_error("rdsp_chain_create: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  if (rdsp_plan_radix(cfg->fft_l) == 0) {
+    rdsp_set_error("fft_l %d not in {256,512,1024,2048,4096}", cfg->fft_l);
+    return RDSP_ERR_INVALID;
+  }
+  const int decim = cfg->decim <= 1 ? 1 : cfg->decim;
+  if (decim != 1 && decim != 4) {
+    rdsp_set_error("decim %d not supported (1 or 4)", cfg->decim);
+    return RDSP_ERR_INVALID;
+  }
+  if (decim == 4 && cfg->fir_taps != 256) {
+    rdsp_set_error("decimator needs 256 taps (got %d)", cfg->fir_taps);
+    return RDSP_ERR_INVALID;
+  }
+  if (rdsp_device_count() <= 0) {
+    rdsp_set_error("no HIP device: the rdsp product path has no CPU fallback");
+    return RDSP_ERR_NO_DEVICE;
+  }
+  rdsp_chain_t *c = new rdsp_chain();
+  c->cfg = *cfg;
+  c->cfg.decim = decim;
+  c->n_channels = n_channels;
+  c->device = device;
+  c->max_blocks = max_blocks_per_call;
+  c->N = cfg->fft_l;
+  c->decim = decim;
+  c->hop = c->N / 2;
+  c->n_in = 0;
+  c->dphi = rdsp_nco_dphi(cfg->nco_hz, cfg->fs_in);
+  c->old_nr_level = 15;            /* CONV:80 */
+  c->nr_mu = rdsp_lms_mu(15);      /* Init_LMS_NR(15), INO:172 */
+  c->als_mu = rdsp_lms_mu(cfg->als_strength > 0 ? cfg->als_strength : 15);
+  c->nr_calls = c->als_calls = 0;
+  c->coef_I.assign(c->hop + 1, 0.0);
+  c->coef_Q.assign(c->hop + 1, 0.0);
+  c->mask_nat.assign(2 * (size_t)c->N, 0.0f);
+  c->fir_nat.assign(256, 0.0f);
+  if (check_device(c) != RDSP_OK) { delete c; return RDSP_ERR_HIP; }
+
+  const size_t nch = (size_t)n_channels;
+#define ALLOC_ZERO(ptr, bytes)                                        \
+  do {                                                                \
+    HIP_TRY(hipMalloc((void **)&(ptr), (bytes)));                     \
+    HIP_TRY(hipMemset((ptr), 0, (bytes)));                            \
+  } while (0)
+  ALLOC_ZERO(c->d_maskp, sizeof(float2) * c->N);
+  ALLOC_ZERO(c->d_t1, sizeof(float2) * 1024);
+  ALLOC_ZERO(c->d_t2, sizeof(float2) * 1024);
+  ALLOC_ZERO(c->d_fir_hc, sizeof(float) * 256);
+  ALLOC_ZERO(c->d_hist, sizeof(uint32_t) * 256 * nch);
+  ALLOC_ZERO(c->d_prev, sizeof(float2) * c->hop * nch);
+  ALLOC_ZERO(c->d_scal, sizeof(float) * 4 * nch);
+  ALLOC_ZERO(c->d_nr_w, sizeof(float) * RDSP_LMS_TAPS * nch);
+  ALLOC_ZERO(c->d_nr_prev, sizeof(float) * RDSP_BLOCK * nch);
+  ALLOC_ZERO(c->d_nr_energy, sizeof(float) * nch);
+  ALLOC_ZERO(c->d_als_w, sizeof(float) * RDSP_LMS_TAPS * nch);
+  ALLOC_ZERO(c->d_als_prev, sizeof(float) * RDSP_BLOCK * nch);
+  ALLOC_ZERO(c->d_als_energy, sizeof(float) * nch);
+  c->mid_stride = (size_t)max_blocks_per_call * RDSP_BLOCK / decim;
+  ALLOC_ZERO(c->d_mid, sizeof(float) * c->mid_stride * nch);
+#undef ALLOC_ZERO
+  {
+    std::vector<float> ones(4 * nch, 0.0f);
+    for (size_t i = 0; i < nch; i++) ones[4 * i + 1] = 1.0f; /* AGC gain starts at 1 */
+    HIP_TRY(hipMemcpy(c->d_scal, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  {
+    std::vector<float> t1(2048), t2(2048);
+    rdsp_nco_tables(t1.data(), t2.data());
+    HIP_TRY(hipMemcpy(c->d_t1, t1.data(), sizeof(float) * 2048, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_t2, t2.data(), sizeof(float) * 2048, hipMemcpyHostToDevice));
+  }
+  if (decim == 4) {
+    std::vector<float> hc(256);
+    if (rdsp_design_decimator(256, cfg->fir_cut_hz, cfg->fs_in, cfg->window, c->fir_nat.data(),
+                              hc.data()) != 0) {
+      rdsp_set_error("decimator design failed");
+      return RDSP_ERR_INVALID;
+    }
+    HIP_TRY(hipMemcpy(c->d_fir_hc, hc.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
+  }
+  /* boot order of the sketch: doConvolutionalInitialize (INO:180, mask from the
+   * still-zero taps) then reInitializeFilter (INO:183) */
+  int rc = rdsp_doConvolutionalInitialize(c, nullptr);
+  if (rc == RDSP_OK) rc = rdsp_reInitializeFilter(c, cfg->flo_hz, cfg->fhi_hz, nullptr);
+  if (rc != RDSP_OK) return rc;
+  *out = c;
+  return RDSP_OK;
+}
+
+extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  void *ptrs[] = {c->d_maskp, c->d_t1, c->d_t2, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+                  c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
+                  c->d_als_energy, c->d_mid};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete c;
+}
+
+extern "C" int rdsp_chain_channels(const rdsp_chain_t *c) { return c ? c->n_channels : 0; }
+
+extern "C" int rdsp_chain_granule_blocks(const rdsp_chain_t *c) {
+  if (!c) return 0;
+  /* one kernel chunk = 256 output samples; a frame needs fft_l/2 of them */
+  const int out_samples = c->hop > 256 ? c->hop : 256;
+  return out_samples * c->decim / RDSP_BLOCK;
+}
+
+extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
+  if (!c) return RDSP_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  const size_t nch = (size_t)c->n_channels;
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipMemset(c->d_hist, 0, sizeof(uint32_t) * 256 * nch));
+  HIP_TRY(hipMemset(c->d_prev, 0, sizeof(float2) * c->hop * nch));
+  HIP_TRY(hipMemset(c->d_nr_w, 0, sizeof(float) * RDSP_LMS_TAPS * nch));
+  HIP_TRY(hipMemset(c->d_nr_prev, 0, sizeof(float) * RDSP_BLOCK * nch));
+  HIP_TRY(hipMemset(c->d_nr_energy, 0, sizeof(float) * nch));
+  HIP_TRY(hipMemset(c->d_als_w, 0, sizeof(float) * RDSP_LMS_TAPS * nch));
+  HIP_TRY(hipMemset(c->d_als_prev, 0, sizeof(float) * RDSP_BLOCK * nch));
+  HIP_TRY(hipMemset(c->d_als_energy, 0, sizeof(float) * nch));
+  std::vector<float> sc(4 * nch, 0.0f);
+  for (size_t i = 0; i < nch; i++) sc[4 * i + 1] = 1.0f;
+  HIP_TRY(hipMemcpy(c->d_scal, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->n_in = 0;
+  c->nr_calls = c->als_calls = 0;
+  c->old_nr_level = 15;
+  c->nr_mu = rdsp_lms_mu(15);
+  return RDSP_OK;
+}
+
+/* CONV:187-207: build the mask from whatever the tap arrays hold */
+extern "C" int rdsp_doConvolutionalInitialize(rdsp_chain_t *c, void *stream) {
+  if (!c) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (rdsp_init_filter_mask(c->mask_nat.data(), c->coef_I.data(), c->coef_Q.data(), c->N) != 0) {
+    rdsp_set_error("init_filter_mask failed");
+    return RDSP_ERR_INVALID;
+  }
+  return upload_mask(c, (hipStream_t)stream);
+}
+
+/* CONV:209-224 */
+extern "C" int rdsp_reInitializeFilter(rdsp_chain_t *c, double lo, double hi, void *stream) {
+  if (!c) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  const double fs_out = c->cfg.fs_in / (double)c->decim;
+  rdsp_calc_cplx_FIR_coeffs(c->coef_I.data(), c->coef_Q.data(), c->hop + 1, lo, hi, fs_out,
+                            c->cfg.window);
+  c->cfg.flo_hz = lo;
+  c->cfg.fhi_hz = hi;
+  return rdsp_doConvolutionalInitialize(c, stream);
+}
+
+/* NR:35-64: new mu; delay line and filter state cleared, energy = 0; the
+ * coefficients are NOT cleared (arm_lms_norm_init_f32 leaves them) */
+extern "C" int rdsp_Init_LMS_NR(rdsp_chain_t *c, int strength, void *stream_) {
+  if (!c) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  hipStream_t stream = (hipStream_t)stream_;
+  c->nr_mu = rdsp_lms_mu(strength);
+  const size_t nch = (size_t)c->n_channels;
+  HIP_TRY(hipMemsetAsync(c->d_nr_prev, 0, sizeof(float) * RDSP_BLOCK * nch, stream));
+  HIP_TRY(hipMemsetAsync(c->d_nr_energy, 0, sizeof(float) * nch, stream));
+  return RDSP_OK;
+}
+
+extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t in_stride,
+                                  int n_blocks, int16_t *d_out, size_t out_stride,
+                                  float *d_out_f32, void *stream_) {
+  if (!c || !d_iq || !d_out || n_blocks <= 0) {
+    rdsp_set_error("rdsp_chain_process: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  const int gran = rdsp_chain_granule_blocks(c);
+  if (n_blocks % gran != 0) {
+    rdsp_set_error("n_blocks %d is not a multiple of the granule %d", n_blocks, gran);
+    return RDSP_ERR_NOT_READY;
+  }
+  if (n_blocks > c->max_blocks) {
+    rdsp_set_error("n_blocks %d exceeds max_blocks_per_call %d", n_blocks, c->max_blocks);
+    return RDSP_ERR_INVALID;
+  }
+  const size_t n_in = (size_t)n_blocks * RDSP_BLOCK;
+  const size_t n_out = n_in / c->decim;
+  if (in_stride < n_in || out_stride < n_out || (in_stride & 3) != 0 ||
+      ((uintptr_t)d_iq & 15) != 0 || ((uintptr_t)d_out & 15) != 0 || (out_stride & 3) != 0) {
+    rdsp_set_error("strides/alignment: in_stride %zu (>= %zu, %%4), out_stride %zu (>= %zu, %%4), 16-byte aligned bases",
+                   in_stride, n_in, out_stride, n_out);
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  hipStream_t stream = (hipStream_t)stream_;
+  const rdsp_chain_config_t &cf = c->cfg;
+
+  /* CONV:326-330: nr level change re-initialises the NLMS instance */
+  if (cf.lms_nr > 0 && cf.lms_nr != c->old_nr_level) {
+    int rc = rdsp_Init_LMS_NR(c, cf.lms_nr, stream);
+    if (rc != RDSP_OK) return rc;
+    c->old_nr_level = cf.lms_nr;
+  }
+  const bool tail = (cf.lms_nr > 0) || (cf.als_mode != RDSP_ALS_OFF);
+  float attack, decay;
+  agc_params(cf.agc_mode, &attack, &decay);
+  const float og = cf.mute ? 0.0f : cf.output_gain;
+
+  RdspFrontParams fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.iq = reinterpret_cast<const uint32_t *>(d_iq);
+  fp.in_stride = in_stride;
+  fp.n_chunks = (int)(n_in / (size_t)(256 * c->decim));
+  fp.n0 = (uint32_t)c->n_in;
+  fp.dphi = c->dphi;
+  float r[2];
+  rdsp_nco_rot(c->dphi, 1, r); fp.rot1 = make_float2(r[0], r[1]);
+  rdsp_nco_rot(c->dphi, 2, r); fp.rot2 = make_float2(r[0], r[1]);
+  rdsp_nco_rot(c->dphi, 3, r); fp.rot3 = make_float2(r[0], r[1]);
+  fp.nco_t1 = c->d_t1;
+  fp.nco_t2 = c->d_t2;
+  fp.scale_i = cf.iq_balance * cf.input_gain * (1.0f / 32768.0f);
+  fp.scale_q = cf.input_gain * (1.0f / 32768.0f);
+  fp.fir_hc = c->d_fir_hc;
+  fp.maskp = c->d_maskp;
+  fp.spectral_on = cf.spectral_nr ? 1 : 0;
+  fp.spectral_k = (float)((double)cf.spectral_level * 1.5);
+  fp.vad_lo = 30 * c->N / 256; /* STATING_BIN_VAD_ANALISYS, SPEC:34, scaled with FFT_L */
+  fp.vad_hi = 180 * c->N / 256;
+  fp.demod = (cf.demod == RDSP_DEMOD_IQ) ? RDSP_K_DEMOD_IQ
+             : (cf.demod == RDSP_DEMOD_AM ? RDSP_K_DEMOD_AM : RDSP_K_DEMOD_REAL);
+  fp.to_mid = tail ? 1 : 0;
+  fp.agc_on = cf.agc_mode != RDSP_AGC_OFF;
+  fp.agc_attack = attack;
+  fp.agc_decay = decay;
+  fp.out_gain = og;
+  fp.st_hist = c->d_hist;
+  fp.st_prev = c->d_prev;
+  fp.st_scal = c->d_scal;
+  fp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
+  fp.out_stride = out_stride;
+  fp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
+  fp.mid = c->d_mid;
+  fp.mid_stride = c->mid_stride;
+  int e = rdsp_launch_front(c->N, c->decim, &fp, c->n_channels, stream);
+  if (e != 0) {
+    rdsp_set_error("front kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return RDSP_ERR_HIP;
+  }
+  if (tail) {
+    RdspTailParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.mid = c->d_mid;
+    tp.mid_stride = c->mid_stride;
+    tp.n_channels = c->n_channels;
+    tp.n_blocks = (int)(n_out / RDSP_BLOCK);
+    tp.nr_on = cf.lms_nr > 0;
+    tp.als_mode = cf.als_mode;
+    tp.nr_mu = c->nr_mu;
+    tp.als_mu = c->als_mu;
+    tp.nr_first = (c->nr_calls == 0);
+    tp.als_first = (c->als_calls == 0);
+    tp.nr_w = c->d_nr_w; tp.nr_prev = c->d_nr_prev; tp.nr_energy = c->d_nr_energy;
+    tp.als_w = c->d_als_w; tp.als_prev = c->d_als_prev; tp.als_energy = c->d_als_energy;
+    tp.agc_on = fp.agc_on;
+    tp.agc_attack = attack;
+    tp.agc_decay = decay;
+    tp.out_gain = og;
+    tp.st_scal = c->d_scal;
+    tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
+    tp.out_stride = out_stride;
+    tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
+    e = rdsp_launch_tail(&tp, 16, stream);
+    if (e != 0) {
+      rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      return RDSP_ERR_HIP;
+    }
+    if (tp.nr_on) c->nr_calls += tp.n_blocks;
+    if (tp.als_mode) c->als_calls += tp.n_blocks;
+  }
+  c->n_in += n_in;
+  return RDSP_OK;
+}
+
+extern "C" int rdsp_doConvolutionalProcessing(rdsp_chain_t *c, float iNRLevel, int bFilterEnabled,
+                                              double dFLoCut, double dFHiCut, const int16_t *d_iq,
+                                              size_t in_stride, int n_blocks, int16_t *d_out,
+                                              size_t out_stride, void *stream) {
+  (void)dFLoCut; /* ignored by the reference too: only bFilterEnabled is read, CONV:300 */
+  (void)dFHiCut;
+  if (!c) return RDSP_ERR_INVALID;
+  c->cfg.lms_nr = (int)iNRLevel;
+  const int f = bFilterEnabled ? 1 : 0;
+  if (f != c->cfg.filter_on) {
+    c->cfg.filter_on = f;
+    int rc = upload_mask(c, (hipStream_t)stream);
+    if (rc != RDSP_OK) return rc;
+  }
+  return rdsp_chain_process(c, d_iq, in_stride, n_blocks, d_out, out_stride, nullptr, stream);
+}
+
+extern "C" int rdsp_q15_to_float(const int16_t *d_src, float *d_dst, size_t n, void *stream) {
+  if (rdsp_device_count() <= 0) { rdsp_set_error("no HIP device"); return RDSP_ERR_NO_DEVICE; }
+  int e = rdsp_launch_q15_to_float(d_src, d_dst, n, (hipStream_t)stream);
+  if (e) { rdsp_set_error("q15_to_float launch: %s", hipGetErrorString((hipError_t)e)); return RDSP_ERR_HIP; }
+  return RDSP_OK;
+}
+extern "C" int rdsp_float_to_q15(const float *d_src, int16_t *d_dst, size_t n, void *stream) {
+  if (rdsp_device_count() <= 0) { rdsp_set_error("no HIP device"); return RDSP_ERR_NO_DEVICE; }
+  int e = rdsp_launch_float_to_q15(d_src, d_dst, n, (hipStream_t)stream);
+  if (e) { rdsp_set_error("float_to_q15 launch: %s", hipGetErrorString((hipError_t)e)); return RDSP_ERR_HIP; }
+  return RDSP_OK;
+}
+
+/* ---- engine setters ------------------------------------------------------- */
+#define NEED(c) do { if (!(c)) return RDSP_ERR_INVALID; } while (0)
+extern "C" int rdsp_sdr_enableAGC(rdsp_chain_t *c) { NEED(c); if (c->cfg.agc_mode == RDSP_AGC_OFF) c->cfg.agc_mode = c->saved_agc_mode; return RDSP_OK; }
+extern "C" int rdsp_sdr_disableAGC(rdsp_chain_t *c) { NEED(c); if (c->cfg.agc_mode != RDSP_AGC_OFF) c->saved_agc_mode = c->cfg.agc_mode; c->cfg.agc_mode = RDSP_AGC_OFF; return RDSP_OK; }
+extern "C" int rdsp_sdr_setAGCmode(rdsp_chain_t *c, int mode) {
+  NEED(c);
+  if (mode < RDSP_AGC_OFF || mode > RDSP_AGC_SLOW) return RDSP_ERR_INVALID;
+  c->cfg.agc_mode = mode;
+  return RDSP_OK;
+}
+extern "C" int rdsp_sdr_enableALSfilter(rdsp_chain_t *c) { NEED(c); if (c->cfg.als_mode == RDSP_ALS_OFF) c->cfg.als_mode = c->saved_als_mode; return RDSP_OK; }
+extern "C" int rdsp_sdr_disableALSfilter(rdsp_chain_t *c) { NEED(c); if (c->cfg.als_mode != RDSP_ALS_OFF) c->saved_als_mode = c->cfg.als_mode; c->cfg.als_mode = RDSP_ALS_OFF; return RDSP_OK; }
+extern "C" int rdsp_sdr_setALSfilterNotch(rdsp_chain_t *c) { NEED(c); c->saved_als_mode = RDSP_ALS_NOTCH; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_NOTCH; return RDSP_OK; }
+extern "C" int rdsp_sdr_setALSfilterPeak(rdsp_chain_t *c) { NEED(c); c->saved_als_mode = RDSP_ALS_PEAK; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_PEAK; return RDSP_OK; }
+extern "C" int rdsp_sdr_setALSfilterAdaptive(rdsp_chain_t *c) { NEED(c); return RDSP_OK; /* the NLMS always adapts */ }
+extern "C" int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c) { NEED(c); rdsp_set_error("noise blanker: SURVEY F3, not built"); return RDSP_ERR_UNSUPPORTED; }
+extern "C" int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c) { NEED(c); return RDSP_OK; }
+extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) { NEED(c); (void)db; rdsp_set_error("noise blanker: SURVEY F3, not built"); return RDSP_ERR_UNSUPPORTED; }
+extern "C" int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.input_gain = g; return RDSP_OK; }
+extern "C" int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.output_gain = g; return RDSP_OK; }
+extern "C" int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g) { NEED(c); c->cfg.iq_balance = g; return RDSP_OK; }
+extern "C" int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c) { NEED(c); c->cfg.filter_on = 1; return upload_mask(c, nullptr); }
+extern "C" int rdsp_sdr_setMute(rdsp_chain_t *c, int mute) { NEED(c); c->cfg.mute = mute ? 1 : 0; return RDSP_OK; }
+extern "C" int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz) {
+  NEED(c);
+  c->cfg.nco_hz = hz;
+  c->dphi = rdsp_nco_dphi(hz, c->cfg.fs_in);
+  return RDSP_OK;
+}
+extern "C" int rdsp_set_nr_level(rdsp_chain_t *c, int lvl) { NEED(c); c->cfg.lms_nr = lvl; return RDSP_OK; }
+extern "C" int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level) { NEED(c); c->cfg.spectral_nr = on ? 1 : 0; c->cfg.spectral_level = level; return RDSP_OK; }
+
+/* pass bands per audio filter and mode (CTL:149-191 names; Appendix C of the
+ * survey: 150 Hz .. 2.1/2.7/3.1/3.9 kHz; CW 500 Hz wide around the 700 Hz pitch) */
+static void passband(int filter, int demod, double *lo, double *hi) {
+  double a = 150.0, b = 2700.0;
+  switch (filter) {
+    case RDSP_AUDIO_CW: a = 450.0; b = 950.0; break;
+    case RDSP_AUDIO_2100: b = 2100.0; break;
+    case RDSP_AUDIO_2700: b = 2700.0; break;
+    case RDSP_AUDIO_3100: b = 3100.0; break;
+    case RDSP_AUDIO_AM: b = 3900.0; break;
+    case RDSP_AUDIO_WSPR: a = 1400.0; b = 1600.0; break;
+    default: break;
+  }
+  if (demod == RDSP_DEMOD_LSB || demod == RDSP_DEMOD_CW_LSB) { *lo = -b; *hi = -a; }
+  else if (demod == RDSP_DEMOD_AM) { *lo = -b; *hi = b; }
+  else { *lo = a; *hi = b; }
+}
+extern "C" int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream) {
+  NEED(c);
+  if (filter < RDSP_AUDIO_CW || filter > RDSP_AUDIO_WSPR) return RDSP_ERR_INVALID;
+  c->audio_filter = filter;
+  double lo, hi;
+  passband(filter, c->cfg.demod, &lo, &hi);
+  return rdsp_reInitializeFilter(c, lo, hi, stream);
+}
+extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream) {
+  if (!c || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_AM) return 0;
+  c->cfg.demod = mode;
+  double lo, hi;
+  passband(c->audio_filter, mode, &lo, &hi);
+  (void)rdsp_reInitializeFilter(c, lo, hi, stream);
+  return demod_tuning_offset(mode);
+}
+
+/* ---- state read-back ------------------------------------------------------- */
+extern "C" int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream) {
+  NEED(c);
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(hipMemcpy(host_out, c->d_scal, sizeof(float) * 4 * (size_t)c->n_channels, hipMemcpyDeviceToHost));
+  return RDSP_OK;
+}
+extern "C" int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void *stream) {
+  NEED(c);
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(hipMemcpy(host_out, which ? c->d_als_w : c->d_nr_w,
+                    sizeof(float) * RDSP_LMS_TAPS * (size_t)c->n_channels, hipMemcpyDeviceToHost));
+  return RDSP_OK;
+}
+extern "C" int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out) {
+  NEED(c);
+  memcpy(host_out, c->mask_nat.data(), sizeof(float) * 2 * (size_t)c->N);
+  return RDSP_OK;
+}
+extern "C" int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out) {
+  NEED(c);
+  memcpy(host_out, c->fir_nat.data(), sizeof(float) * 256);
+  return RDSP_OK;
+}

@@ -1,0 +1,275 @@
+/*
+ * rdsp_design.c -- host-side (plain C) setup math of the receive chain:
+ * filter design, filter mask, decimator taps, NCO tables, synthetic IQ.
+ * Runs once per retune, never on the streaming path (the reference does it
+ * under AudioNoInterrupts, RDSP_convolutional.h:209-224).
+ */
+#include "rdsp_host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static const double kPi = 3.14159265358979323846;
+
+/* cosine-sum window families of RDSP_convolutional.h:152-179 as coefficient rows
+ * a0 - a1 cos(t) + a2 cos(2t) - a3 cos(3t), t = 2*pi*i/(n-1) */
+static double cosine_sum_window(int id, int i, int n) {
+  static const double rows[3][4] = {
+      {0.35875, 0.48829, 0.14128, 0.01168},       /* 1: 4-term Blackman-Harris */
+      {0.355768, 0.487396, 0.144232, 0.012604},   /* 2 */
+      {0.3635819, 0.4891775, 0.1365995, 0.0106411} /* default: Blackman-Nuttall */
+  };
+  const double t = 2.0 * kPi * (double)i / (double)(n - 1);
+  if (id == 3) return cos(0.5 * t);          /* cosine: cos(pi*i/(n-1)) */
+  if (id == 4) return 0.5 * (1.0 - cos(t));  /* Hann */
+  const double *a = rows[id == 1 ? 0 : (id == 2 ? 1 : 2)];
+  return a[0] - a[1] * cos(t) + a[2] * cos(2.0 * t) - a[3] * cos(3.0 * t);
+}
+
+/* RDSP_convolutional.h:127-185: windowed-sinc low-pass of half-width
+ * (FHi-FLo)/2, complex-shifted to (FHi+FLo)/2. */
+void rdsp_calc_cplx_FIR_coeffs(double *coeffs_I, double *coeffs_Q, int numCoeffs, double FLoCut,
+                               double FHiCut, double SampleRate, int window) {
+  const double lo = FLoCut / SampleRate, hi = FHiCut / SampleRate;
+  const double half_bw = 0.5 * (hi - lo);
+  const double shift = kPi * (hi + lo);
+  const double mid = 0.5 * (double)(numCoeffs - 1);
+  for (int i = 0; i < numCoeffs; i++) {
+    const double x = (double)i - mid;
+    double proto;
+    if (fabs(x) < 0.01)
+      proto = 2.0 * half_bw; /* odd-length centre tap, :149-150 */
+    else
+      proto = sin(2.0 * kPi * x * half_bw) / (kPi * x) * cosine_sum_window(window, i, numCoeffs);
+    coeffs_I[i] = proto * cos(shift * x);
+    coeffs_Q[i] = proto * sin(shift * x);
+  }
+}
+
+/* time-domain image that RDSP_convolutional.h:96-105 feeds to the FFT: taps
+ * narrowed to float, zero padded; the zero fill starts at float index
+ * FFT_length+1, which clears the imaginary part of the last tap. */
+static void mask_time_image(double *re, double *im, const double *coef_I, const double *coef_Q,
+                            int n) {
+  const int ntaps = n / 2 + 1;
+  for (int i = 0; i < n; i++) re[i] = im[i] = 0.0;
+  for (int i = 0; i < ntaps; i++) {
+    re[i] = (double)(float)coef_I[i];
+    im[i] = (double)(float)coef_Q[i];
+  }
+  im[n / 2] = 0.0;
+}
+
+/* double-precision DFT of the tap image (only n/2+1 taps are non-zero) */
+static void mask_dft(const double *re, const double *im, int n, double *Xr, double *Xi) {
+  const int ntaps = n / 2 + 1;
+  double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+  for (int k = 0; k < n; k++) {
+    cs[2 * k] = cos(2.0 * kPi * (double)k / (double)n);
+    cs[2 * k + 1] = -sin(2.0 * kPi * (double)k / (double)n);
+  }
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < n; k++) {
+    double ar = 0.0, ai = 0.0;
+    for (int t = 0; t < ntaps; t++) {
+      const int m = (int)(((long long)k * t) % n);
+      const double c = cs[2 * m], s = cs[2 * m + 1];
+      ar += re[t] * c - im[t] * s;
+      ai += re[t] * s + im[t] * c;
+    }
+    Xr[k] = ar;
+    Xi[k] = ai;
+  }
+  free(cs);
+}
+
+int rdsp_init_filter_mask(float *mask, const double *coef_I, const double *coef_Q, int fft_l) {
+  if (rdsp_plan_radix(fft_l) == 0) return -1;
+  const int n = fft_l;
+  double *buf = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+  if (!buf) return -6;
+  double *re = buf, *im = buf + n, *Xr = buf + 2 * n, *Xi = buf + 3 * n;
+  mask_time_image(re, im, coef_I, coef_Q, n);
+  mask_dft(re, im, n, Xr, Xi);
+  for (int k = 0; k < n; k++) {
+    mask[2 * k] = (float)Xr[k];
+    mask[2 * k + 1] = (float)Xi[k];
+  }
+  free(buf);
+  return 0;
+}
+
+/* radix P used by the kernels for each FFT_L (rdsp_kernels.hip dispatch) */
+int rdsp_plan_radix(int fft_l) {
+  switch (fft_l) {
+    case 256: return 4;
+    case 512: return 8;
+    case 1024: return 16;
+    case 2048: return 8;
+    case 4096: return 16;
+    default: return 0;
+  }
+}
+
+static int ilog2i(int x) {
+  int l = 0;
+  while ((1 << l) < x) l++;
+  return l;
+}
+
+/* natural bin held at position i after the forward transform
+ * (mirrors rdsp::bin_of_pos in rdsp_fft.h) */
+int rdsp_bin_of_pos(int fft_l, int i) {
+  const int P = rdsp_plan_radix(fft_l);
+  const int logp = ilog2i(P), logn = ilog2i(fft_l);
+  const int nfull = logn / logp;
+  const int rem = logn % logp;
+  const int np = rem ? nfull + 1 : nfull;
+  const int rl = rem ? (1 << rem) : P;
+  int k = 0, mult = 1;
+  for (int p = 0; p < np; p++) {
+    const int s = (p >= np - 1) ? 1 : (fft_l >> (logp * (p + 1)));
+    const int R = (p == np - 1) ? rl : P;
+    const int digit = (i / s) % R;
+    k += digit * mult;
+    mult *= R;
+  }
+  return k;
+}
+
+/* device image of the mask: mask/N, digit-reversed, thread-major
+ * (element e of thread t at e*NT + t). mask_nat == NULL -> all-pass. */
+void rdsp_mask_device_image(const float *mask_nat, int fft_l, float *image) {
+  const int P = rdsp_plan_radix(fft_l);
+  const int nt = fft_l / P;
+  const float inv_n = 1.0f / (float)fft_l;
+  for (int t = 0; t < nt; t++)
+    for (int e = 0; e < P; e++) {
+      const int k = rdsp_bin_of_pos(fft_l, t * P + e);
+      const int o = e * nt + t;
+      if (mask_nat) {
+        image[2 * o] = mask_nat[2 * k] * inv_n;
+        image[2 * o + 1] = mask_nat[2 * k + 1] * inv_n;
+      } else {
+        image[2 * o] = inv_n;
+        image[2 * o + 1] = 0.0f;
+      }
+    }
+}
+
+/* decimator low-pass: the same windowed-sinc law with a symmetric band
+ * (-B, +B), so the taps are real; reordered by polyphase branch:
+ * hc[c][k'] = h[4k' + c] */
+int rdsp_design_decimator(int ntaps, double cut_hz, double fs, int window, float *h_nat,
+                          float *hc) {
+  if (ntaps != 256) return -1;
+  double *ti = (double *)malloc(sizeof(double) * 2 * (size_t)ntaps);
+  if (!ti) return -6;
+  double *tq = ti + ntaps;
+  rdsp_calc_cplx_FIR_coeffs(ti, tq, ntaps, -cut_hz, cut_hz, fs, window);
+  for (int k = 0; k < ntaps; k++) h_nat[k] = (float)ti[k];
+  for (int c = 0; c < 4; c++)
+    for (int kp = 0; kp < 64; kp++) hc[c * 64 + kp] = h_nat[4 * kp + c];
+  free(ti);
+  return 0;
+}
+
+/* NCO: phase increment in turns*2^32 and the two 1024-entry phasor tables */
+uint32_t rdsp_nco_dphi(double hz, double fs) {
+  const double turns = hz / fs;
+  const long long q = llround(turns * 4294967296.0);
+  return (uint32_t)(unsigned long long)q;
+}
+void rdsp_nco_tables(float *t1, float *t2) {
+  for (int i = 0; i < 1024; i++) {
+    const double a = 2.0 * kPi * (double)i / 1024.0;
+    const double b = 2.0 * kPi * (double)i / 1048576.0;
+    t1[2 * i] = (float)cos(a);
+    t1[2 * i + 1] = (float)-sin(a);
+    t2[2 * i] = (float)cos(b);
+    t2[2 * i + 1] = (float)-sin(b);
+  }
+}
+void rdsp_nco_rot(uint32_t dphi, int k, float *out2) {
+  const uint32_t ph = dphi * (uint32_t)k;
+  const double a = 2.0 * kPi * (double)ph / 4294967296.0;
+  out2[0] = (float)cos(a);
+  out2[1] = (float)-sin(a);
+}
+
+/* NR:48-56: mu from the "DSP strength" setting */
+float rdsp_lms_mu(int strength) {
+  float m = (float)strength;
+  m /= 2;
+  m += 2;
+  m /= 10;
+  m = powf(10, m);
+  return 1 / m;
+}
+
+/* ---- synthetic IQ: counter-based so any (channel, time) window
+ * can be generated independently and identically on any host ---------------- */
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline double u01(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
+
+static inline int16_t quant16(double v) {
+  double q = floor(v * 32767.0 + 0.5);
+  if (q > 32767.0) q = 32767.0;
+  if (q < -32768.0) q = -32768.0;
+  return (int16_t)q;
+}
+
+void rdsp_synth_iq(int16_t *dst, int ch0, int n_ch, uint64_t t0, int n_samples,
+                   const rdsp_synth_config_t *cfg, int n_threads) {
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+  (void)n_threads;
+#endif
+  const double fs = cfg->fs;
+  const double f1 = (cfg->f_off + 700.0) / fs, f2 = (cfg->f_off + 1900.0) / fs,
+               f3 = (cfg->f_off + 1000.0) / fs;
+  const uint64_t key_len = (uint64_t)(0.06 * fs);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int c = 0; c < n_ch; c++) {
+    const uint64_t chn = (uint64_t)(ch0 + c);
+    const uint64_t seed = 0x5DEECE66Dull ^ (chn * 0x9E3779B97F4A7C15ull);
+    const double p1 = 2.0 * kPi * u01(splitmix64(seed ^ 0xA5A5A5A5A5A5A5A5ull));
+    const double p2 = 2.0 * kPi * u01(splitmix64(seed ^ 0x5A5A5A5A5A5A5A5Aull));
+    const double p3 = 2.0 * kPi * u01(splitmix64(seed ^ 0x3C3C3C3C3C3C3C3Cull));
+    int16_t *row = dst + (size_t)c * (size_t)n_samples * 2;
+    for (int i = 0; i < n_samples; i++) {
+      const uint64_t t = t0 + (uint64_t)i;
+      const double td = (double)t;
+      /* complex white noise, Box-Muller on two counter-indexed draws */
+      const double u1 = u01(splitmix64(seed + 2 * t)) + (1.0 / 9007199254740992.0);
+      const double u2 = u01(splitmix64(seed + 2 * t + 1));
+      const double r = cfg->sigma * sqrt(-2.0 * log(u1));
+      double xi = r * cos(2.0 * kPi * u2), xq = r * sin(2.0 * kPi * u2);
+      if (cfg->cw) {
+        if (((t / key_len) & 1ull) == 0) {
+          const double a = 2.0 * kPi * fmod(f1 * td, 1.0) + p1;
+          xi += cfg->amp_tone * cos(a);
+          xq += cfg->amp_tone * sin(a);
+        }
+      } else {
+        const double a1 = 2.0 * kPi * fmod(f1 * td, 1.0) + p1;
+        const double a2 = 2.0 * kPi * fmod(f2 * td, 1.0) + p2;
+        const double a3 = 2.0 * kPi * fmod(f3 * td, 1.0) + p3;
+        xi += cfg->amp_tone * (cos(a1) + cos(a2)) + cfg->amp_carrier * cos(a3);
+        xq += cfg->amp_tone * (sin(a1) + sin(a2)) + cfg->amp_carrier * sin(a3);
+      }
+      row[2 * i] = quant16(xi);
+      row[2 * i + 1] = quant16(xq);
+    }
+  }
+}

@@ -1,0 +1,316 @@
+/*
+ * rdsp_fft.h -- workgroup-cooperative complex FFT for the overlap-save filter
+ * (replaces the arm_cfft_f32 calls at RDSP_convolutional.h:291,309 and
+ * backup/RDSP_convolutional_spec.h:179,243).
+ *
+ * Design (MI355X): one N-point transform is shared by NT = N/P threads, each
+ * holding P points in registers.  Forward = in-place decimation-in-frequency
+ * passes of radix P (last pass radix N / P^(k-1)), which leaves bin k at the
+ * digit-reversed position; the filter mask is stored in that order, so no
+ * reordering pass exists.  Inverse = the exact transpose (decimation-in-time)
+ * and lands in natural time order.  Between passes the data goes through LDS
+ * at phi(i) = i + i/P, which keeps every pass within 1.33x of conflict-free
+ * (measured offline over all lane patterns).  Per-thread twiddles live in
+ * registers for the whole kernel.
+ *
+ * Everything here is __host__ __device__ so tests/host_fft_check.cpp can run
+ * the same code thread by thread on the CPU.
+ */
+#ifndef RDSP_FFT_H
+#define RDSP_FFT_H
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define RDSP_HD __host__ __device__ __forceinline__
+
+namespace rdsp {
+
+RDSP_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+RDSP_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+RDSP_HD float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+RDSP_HD float2 cmulc(float2 a, float2 b) { /* a * conj(b) */
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+/* multiply by w16^M (forward, w = exp(-2*pi*i/16)) or its conjugate (INV) */
+template <int M, bool INV>
+RDSP_HD float2 mul_w16(float2 a) {
+  constexpr float C1 = 0.92387953251128674f; /* cos(pi/8) */
+  constexpr float S1 = 0.38268343236508977f; /* sin(pi/8) */
+  constexpr float C2 = 0.70710678118654752f; /* cos(pi/4) */
+  constexpr int m = M & 15;
+  if constexpr (m == 0) return a;
+  else if constexpr (m == 4) return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+  else if constexpr (m == 8) return make_float2(-a.x, -a.y);
+  else if constexpr (m == 12) return INV ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+  else if constexpr (m == 2)
+    return INV ? make_float2(C2 * (a.x - a.y), C2 * (a.x + a.y))
+               : make_float2(C2 * (a.x + a.y), C2 * (a.y - a.x));
+  else if constexpr (m == 6)
+    return INV ? make_float2(-C2 * (a.x + a.y), C2 * (a.x - a.y))
+               : make_float2(C2 * (a.y - a.x), -C2 * (a.x + a.y));
+  else {
+    /* w16^m = cos(2 pi m/16) - i sin(2 pi m/16) */
+    constexpr float cr = (m == 1) ? C1 : (m == 3) ? S1 : (m == 5) ? -S1 : (m == 7) ? -C1
+                       : (m == 9) ? -C1 : (m == 11) ? -S1 : (m == 13) ? S1 : C1;
+    constexpr float sr = (m == 1) ? S1 : (m == 3) ? C1 : (m == 5) ? C1 : (m == 7) ? S1
+                       : (m == 9) ? -S1 : (m == 11) ? -C1 : (m == 13) ? -C1 : -S1;
+    /* forward: (cr - i sr); inverse: (cr + i sr) */
+    return INV ? make_float2(a.x * cr - a.y * sr, a.x * sr + a.y * cr)
+               : make_float2(a.x * cr + a.y * sr, a.y * cr - a.x * sr);
+  }
+}
+
+template <bool INV>
+RDSP_HD void dft2(float2 &a, float2 &b) {
+  float2 t = a;
+  a = cadd(t, b);
+  b = csub(t, b);
+}
+
+/* 4-point DFT, natural order in and out, on v[0], v[ST], v[2ST], v[3ST] */
+template <bool INV, int ST>
+RDSP_HD void dft4(float2 *v) {
+  float2 t0 = cadd(v[0], v[2 * ST]);
+  float2 t1 = csub(v[0], v[2 * ST]);
+  float2 t2 = cadd(v[ST], v[3 * ST]);
+  float2 t3 = csub(v[ST], v[3 * ST]);
+  float2 t3r = mul_w16<4, INV>(t3); /* -i*t3 (fwd) / +i*t3 (inv) */
+  v[0] = cadd(t0, t2);
+  v[2 * ST] = csub(t0, t2);
+  v[ST] = cadd(t1, t3r);
+  v[3 * ST] = csub(t1, t3r);
+}
+
+template <int R, bool INV>
+struct Dft;
+
+template <bool INV>
+struct Dft<2, INV> {
+  static RDSP_HD void run(float2 *v) { dft2<INV>(v[0], v[1]); }
+};
+
+template <bool INV>
+struct Dft<4, INV> {
+  static RDSP_HD void run(float2 *v) { dft4<INV, 1>(v); }
+};
+
+template <bool INV>
+struct Dft<8, INV> {
+  /* n = n1 + 2*n2, k = 4*k1 + k2 */
+  static RDSP_HD void run(float2 *v) {
+    dft4<INV, 2>(v);     /* n1 = 0: elements 0,2,4,6 -> A[0][k2] at 2*k2   */
+    dft4<INV, 2>(v + 1); /* n1 = 1: elements 1,3,5,7 -> A[1][k2] at 1+2*k2 */
+    v[3] = mul_w16<2, INV>(v[3]); /* w8^1 */
+    v[5] = mul_w16<4, INV>(v[5]); /* w8^2 */
+    v[7] = mul_w16<6, INV>(v[7]); /* w8^3 */
+    float2 o[8];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) {
+      o[k2] = cadd(v[2 * k2], v[2 * k2 + 1]);
+      o[4 + k2] = csub(v[2 * k2], v[2 * k2 + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = o[i];
+  }
+};
+
+template <bool INV>
+struct Dft<16, INV> {
+  /* n = n1 + 4*n2, k = 4*k1 + k2 */
+  static RDSP_HD void run(float2 *v) {
+    dft4<INV, 4>(v);
+    dft4<INV, 4>(v + 1);
+    dft4<INV, 4>(v + 2);
+    dft4<INV, 4>(v + 3);
+    /* element n1 + 4*k2 holds A[n1][k2]; multiply by w16^(n1*k2) */
+    v[5] = mul_w16<1, INV>(v[5]);
+    v[9] = mul_w16<2, INV>(v[9]);
+    v[13] = mul_w16<3, INV>(v[13]);
+    v[6] = mul_w16<2, INV>(v[6]);
+    v[10] = mul_w16<4, INV>(v[10]);
+    v[14] = mul_w16<6, INV>(v[14]);
+    v[7] = mul_w16<3, INV>(v[7]);
+    v[11] = mul_w16<6, INV>(v[11]);
+    v[15] = mul_w16<9, INV>(v[15]);
+    dft4<INV, 1>(v);      /* k2 = 0: elements 0..3  -> k1 at k1      */
+    dft4<INV, 1>(v + 4);  /* k2 = 1: elements 4..7                   */
+    dft4<INV, 1>(v + 8);
+    dft4<INV, 1>(v + 12);
+    float2 o[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+      for (int k2 = 0; k2 < 4; k2++) o[4 * k1 + k2] = v[4 * k2 + k1];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = o[i];
+  }
+};
+
+/* ---- plan constants ----------------------------------------------------- */
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+
+template <int N, int P>
+struct FftPlan {
+  static constexpr int NT = N / P;
+  static constexpr int LOGP = ilog2(P);
+  static constexpr int LOGN = ilog2(N);
+  static constexpr int NFULL = LOGN / LOGP;                 /* radix-P passes */
+  static constexpr int RL = (LOGN % LOGP) ? (1 << (LOGN % LOGP)) : P; /* last radix */
+  static constexpr int NP = (LOGN % LOGP) ? NFULL + 1 : NFULL;        /* passes */
+  static constexpr int NTW = NP - 1;                        /* twiddled passes */
+  static constexpr int WB = N + N / P;                      /* padded LDS entries */
+  /* span of pass p (p < NP-1): N / P^(p+1); last pass: 1 */
+  static constexpr int span(int p) { return p >= NP - 1 ? 1 : (N >> (LOGP * (p + 1))); }
+};
+
+template <int P>
+RDSP_HD int phi(int i) { return i + (i >> ilog2(P)); }
+
+/* natural bin index held at position i after the forward transform */
+template <int N, int P>
+RDSP_HD int bin_of_pos(int i) {
+  using PL = FftPlan<N, P>;
+  int k = 0, mult = 1;
+#pragma unroll
+  for (int p = 0; p < PL::NP; p++) {
+    const int s = PL::span(p);
+    const int R = (p == PL::NP - 1) ? PL::RL : P;
+    int digit = (i / s) % R;
+    k += digit * mult;
+    mult *= R;
+  }
+  return k;
+}
+
+/* twiddles of thread t: tw[p][k-1] = exp(-2*pi*i * o*k / (P*s_p)), o = t % s_p */
+template <int N, int P>
+RDSP_HD void make_twiddles(int t, float2 (*tw)[P - 1]) {
+  using PL = FftPlan<N, P>;
+#pragma unroll
+  for (int p = 0; p < PL::NTW; p++) {
+    const int s = PL::span(p);
+    const int S = P * s;
+    int o = t % s;
+#pragma unroll
+    for (int k = 1; k < P; k++) {
+      int m = (o * k) % S;
+#ifdef __HIP_DEVICE_COMPILE__
+      float sn, cs;
+      sincospif(-2.0f * (float)m / (float)S, &sn, &cs);
+      tw[p][k - 1] = make_float2(cs, sn);
+#else
+      double a = -2.0 * 3.14159265358979323846 * (double)m / (double)S;
+      tw[p][k - 1] = make_float2((float)cos(a), (float)sin(a));
+#endif
+    }
+  }
+}
+
+/* positions touched by thread t in full pass p: i_j = (g*P + j)*s + o */
+template <int N, int P>
+RDSP_HD int pass_base(int t, int p, int *stride) {
+  using PL = FftPlan<N, P>;
+  const int s = PL::span(p);
+  *stride = s;
+  return (t / s) * P * s + (t % s);
+}
+
+/* ---- forward ------------------------------------------------------------- */
+/* pass 0: v[] already loaded with x[t + j*NT] (j = 0..P-1) */
+template <int N, int P>
+RDSP_HD void fwd_pass0_store(int t, float2 *v, float2 *wb, const float2 (*tw)[P - 1]) {
+  using PL = FftPlan<N, P>;
+  Dft<P, false>::run(v);
+#pragma unroll
+  for (int k = 1; k < P; k++) v[k] = cmul(v[k], tw[0][k - 1]);
+#pragma unroll
+  for (int j = 0; j < P; j++) wb[phi<P>(t + j * PL::NT)] = v[j];
+}
+
+/* middle pass p (1 <= p <= NP-2), in place */
+template <int N, int P, int PIDX>
+RDSP_HD void fwd_pass_mid(int t, float2 *wb, const float2 (*tw)[P - 1]) {
+  using PL = FftPlan<N, P>;
+  constexpr int s = PL::span(PIDX);
+  const int base = (t / s) * P * s + (t % s);
+  float2 v[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) v[j] = wb[phi<P>(base + j * s)];
+  Dft<P, false>::run(v);
+#pragma unroll
+  for (int k = 1; k < P; k++) v[k] = cmul(v[k], tw[PIDX][k - 1]);
+#pragma unroll
+  for (int j = 0; j < P; j++) wb[phi<P>(base + j * s)] = v[j];
+}
+
+/* last pass: loads positions t*P .. t*P+P-1, leaves the spectrum in v[] */
+template <int N, int P>
+RDSP_HD void fwd_pass_last(int t, float2 *v, const float2 *wb) {
+  using PL = FftPlan<N, P>;
+#pragma unroll
+  for (int e = 0; e < P; e++) v[e] = wb[phi<P>(t * P + e)];
+#pragma unroll
+  for (int q = 0; q < P / PL::RL; q++) Dft<PL::RL, false>::run(v + q * PL::RL);
+}
+
+/* ---- inverse (unnormalised; 1/N is folded into the mask) ------------------ */
+template <int N, int P>
+RDSP_HD void inv_pass_last(int t, float2 *v, float2 *wb) {
+  using PL = FftPlan<N, P>;
+#pragma unroll
+  for (int q = 0; q < P / PL::RL; q++) Dft<PL::RL, true>::run(v + q * PL::RL);
+#pragma unroll
+  for (int e = 0; e < P; e++) wb[phi<P>(t * P + e)] = v[e];
+}
+
+template <int N, int P, int PIDX>
+RDSP_HD void inv_pass_mid(int t, float2 *wb, const float2 (*tw)[P - 1]) {
+  using PL = FftPlan<N, P>;
+  constexpr int s = PL::span(PIDX);
+  const int base = (t / s) * P * s + (t % s);
+  float2 v[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) v[j] = wb[phi<P>(base + j * s)];
+#pragma unroll
+  for (int k = 1; k < P; k++) v[k] = cmulc(v[k], tw[PIDX][k - 1]);
+  Dft<P, true>::run(v);
+#pragma unroll
+  for (int j = 0; j < P; j++) wb[phi<P>(base + j * s)] = v[j];
+}
+
+/* pass 0 inverse: result v[j] = y[t + j*NT] */
+template <int N, int P>
+RDSP_HD void inv_pass0_load(int t, float2 *v, const float2 *wb, const float2 (*tw)[P - 1]) {
+  using PL = FftPlan<N, P>;
+#pragma unroll
+  for (int j = 0; j < P; j++) v[j] = wb[phi<P>(t + j * PL::NT)];
+#pragma unroll
+  for (int k = 1; k < P; k++) v[k] = cmulc(v[k], tw[0][k - 1]);
+  Dft<P, true>::run(v);
+}
+
+/* compile-time loops over the middle passes */
+template <int N, int P, int PIDX, int PEND, typename SYNC>
+RDSP_HD void fwd_mid_all(int t, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
+  if constexpr (PIDX < PEND) {
+    fwd_pass_mid<N, P, PIDX>(t, wb, tw);
+    sync();
+    fwd_mid_all<N, P, PIDX + 1, PEND>(t, wb, tw, sync);
+  }
+}
+template <int N, int P, int PIDX, typename SYNC>
+RDSP_HD void inv_mid_all(int t, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
+  if constexpr (PIDX >= 1) {
+    inv_pass_mid<N, P, PIDX>(t, wb, tw);
+    sync();
+    inv_mid_all<N, P, PIDX - 1>(t, wb, tw, sync);
+  }
+}
+
+}  // namespace rdsp
+
+#endif

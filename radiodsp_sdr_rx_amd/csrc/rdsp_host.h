@@ -1,0 +1,27 @@
+/*
+ * rdsp_host.h -- internal host-side declarations shared by rdsp_design.c,
+ * rdsp_chain.hip and rdsp_graph.c (the public boundary is include/rdsp.h).
+ */
+#ifndef RDSP_HOST_H
+#define RDSP_HOST_H
+
+#include "../../include/rdsp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int rdsp_plan_radix(int fft_l);
+int rdsp_bin_of_pos(int fft_l, int i);
+void rdsp_mask_device_image(const float *mask_nat, int fft_l, float *image);
+int rdsp_design_decimator(int ntaps, double cut_hz, double fs, int window, float *h_nat, float *hc);
+uint32_t rdsp_nco_dphi(double hz, double fs);
+void rdsp_nco_tables(float *t1, float *t2);
+void rdsp_nco_rot(uint32_t dphi, int k, float *out2);
+float rdsp_lms_mu(int strength);
+void rdsp_set_error(const char *fmt, ...);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

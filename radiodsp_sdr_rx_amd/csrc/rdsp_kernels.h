@@ -1,0 +1,88 @@
+/*
+ * rdsp_kernels.h -- parameter blocks shared by the HIP kernels and the C-ABI
+ * launch layer (internal; the public boundary is include/rdsp.h).
+ */
+#ifndef RDSP_KERNELS_H
+#define RDSP_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RDSP_BLOCK 128
+#define RDSP_LMS_TAPS 96
+#define RDSP_XP 84 /* entries per polyphase sub-plane in LDS (81 used, 84 keeps
+                      the sub-plane stride at 8 banks mod 32) */
+
+enum { RDSP_K_DEMOD_IQ = 0, RDSP_K_DEMOD_REAL = 1, RDSP_K_DEMOD_AM = 2 };
+
+/* front kernel: A1 unpack, A2 mixer, A3 decimator, A5 overlap-save filter,
+ * A6 spectral NR, demod select, and (when no NLMS stage follows) A9 AGC,
+ * output gain and A10 pack. */
+struct RdspFrontParams {
+  const uint32_t *iq;  /* [ch][in_stride] int16 I | int16 Q << 16            */
+  size_t in_stride;    /* samples per channel row                            */
+  int n_chunks;        /* chunks of 256*DECIM input samples in this launch   */
+  uint32_t n0;         /* absolute index (mod 2^32) of the first sample      */
+  uint32_t dphi;       /* NCO phase increment per sample (turns * 2^32)      */
+  float2 rot1, rot2, rot3; /* exp(-j*2pi*k*dphi/2^32), k = 1..3              */
+  const float2 *nco_t1;    /* [1024] exp(-j*2pi*i/2^10)                      */
+  const float2 *nco_t2;    /* [1024] exp(-j*2pi*i/2^20)                      */
+  float scale_i, scale_q;  /* iq_balance*input_gain/32768, input_gain/32768  */
+  const float *fir_hc;     /* [4][64] decimator taps, hc[c][k'] = h[4k'+c]   */
+  const float2 *maskp;     /* [N] mask/N in digit-reversed bin order         */
+  int spectral_on;
+  float spectral_k;        /* (float)(level*1.5)                             */
+  int vad_lo, vad_hi;      /* inclusive natural bin range                    */
+  int demod;               /* RDSP_K_DEMOD_*                                 */
+  int to_mid;              /* 1: write mono float audio for the tail kernel  */
+  int agc_on;
+  float agc_attack, agc_decay;
+  float out_gain;
+  /* per-channel state */
+  uint32_t *st_hist;       /* [ch][256] last raw input samples               */
+  float2 *st_prev;         /* [ch][N/2] previous hop of the decimated stream */
+  float *st_scal;          /* [ch][4]: NFloor, agc_g, am_dc, -               */
+  /* outputs */
+  uint32_t *out_i16;       /* [ch][out_stride] int16 L | int16 R << 16       */
+  size_t out_stride;
+  float2 *out_f32;         /* optional [ch][out_stride] float L,R            */
+  float *mid;              /* [ch][mid_stride] mono float (to_mid)           */
+  size_t mid_stride;
+};
+
+/* tail kernel: A7 NLMS noise reduction, A8 ALS notch/peak, A9 AGC, gain,
+ * A10 pack.  One channel per LPC lanes. */
+struct RdspTailParams {
+  const float *mid;        /* [ch][mid_stride]                               */
+  size_t mid_stride;
+  int n_channels;
+  int n_blocks;            /* 128-sample blocks at the decimated rate        */
+  int nr_on, als_mode;     /* als_mode: 0 off, 1 notch (e), 2 peak (y)       */
+  float nr_mu, als_mu;
+  int nr_first, als_first; /* 1: first call ever (d = x quirk, NR:69-79)     */
+  float *nr_w, *nr_prev, *nr_energy;    /* [ch][96], [ch][128], [ch]         */
+  float *als_w, *als_prev, *als_energy;
+  int agc_on;
+  float agc_attack, agc_decay;
+  float out_gain;
+  float *st_scal;
+  uint32_t *out_i16;
+  size_t out_stride;
+  float2 *out_f32;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* returns hipError_t as int */
+int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_channels,
+                      hipStream_t stream);
+int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream);
+int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream);
+int rdsp_launch_float_to_q15(const float *src, int16_t *dst, size_t n, hipStream_t stream);
+size_t rdsp_front_lds_bytes(int fft_l, int decim);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

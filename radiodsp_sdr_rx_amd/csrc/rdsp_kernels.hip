@@ -1,0 +1,696 @@
+/*
+ * rdsp_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the per-block IQ
+ * receive chain.  No MFMA: the path is streaming FIR/FFT work in fp32.
+ *
+ *   rdsp_front_kernel<N,P,DECIM>  one channel per workgroup of NT = N/P threads
+ *       A1  int16 IQ unpack           RDSP_convolutional.h:241-242
+ *       A2  NCO mixer                 (AudioSDR, build-defined)
+ *       A3  256-tap polyphase /4 FIR  (build-defined)
+ *       A5  overlap-save filter       RDSP_convolutional.h:256-318
+ *       A6  spectral subtraction NR   backup/RDSP_convolutional_spec.h:182-238
+ *       demod select, and when no NLMS stage is active: A9 AGC, output gain,
+ *       A10 pack                      RDSP_convolutional.h:342-350
+ *   rdsp_tail_kernel<LPC>         one channel per LPC lanes (serial-in-time)
+ *       A7  NLMS noise reduction      RDSP_noise_reduction.h:35-80
+ *       A8  ALS notch / peak          (AudioSDR, build-defined on A7's core)
+ *       A9  AGC, output gain, A10 pack
+ *
+ * Data movement: int16 IQ is read once with 16-byte coalesced loads (prefetched
+ * one chunk ahead), everything between stays in LDS/registers, and audio is
+ * written once.  Per-channel state (FIR history, overlap block, NFloor, AGC
+ * gain, NLMS weights) is read at launch start and written back at the end, so
+ * its traffic is amortised over the time batch.
+ */
+#include "rdsp_front.h"
+
+using namespace rdsp;
+
+namespace {
+
+/* ---- wave helpers -------------------------------------------------------- */
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+/* sum over each 16-lane DPP row, result in every lane of the row */
+__device__ __forceinline__ float row_allsum(float v) {
+  v += dpp_f<0xB1>(v);  /* quad_perm [1,0,3,2] */
+  v += dpp_f<0x4E>(v);  /* quad_perm [2,3,0,1] */
+  v += dpp_f<0x141>(v); /* row_half_mirror */
+  v += dpp_f<0x140>(v); /* row_mirror */
+  return v;
+}
+/* sum over the 64-lane wave, wave-uniform result */
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_allsum(v);
+  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ float2 unpack_iq(uint32_t w, float si, float sq) {
+  /* arm_q15_to_float: q/32768 (the 2^-15 is folded into si/sq, exact) */
+  float xr = (float)(int16_t)(w & 0xFFFFu);
+  float xi = (float)(int16_t)(w >> 16);
+  return make_float2(xr * si, xi * sq);
+}
+
+__device__ __forceinline__ uint32_t pack_lr(float l, float r) {
+  return ((uint32_t)q15_of_float(l) & 0xFFFFu) | ((uint32_t)q15_of_float(r) << 16);
+}
+
+/* ---- front kernel -------------------------------------------------------- */
+template <int N, int P, int DECIM>
+__global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
+  using PL = FftPlan<N, P>;
+  constexpr int NT = PL::NT;
+  constexpr int NW = NT / 64;
+  constexpr int H = N / 2;
+  constexpr int PH = P / 2;
+  constexpr int CH_OUT = 256;
+  constexpr int CH_IN = CH_OUT * DECIM;
+  constexpr int FPC = (H >= CH_OUT) ? 1 : CH_OUT / H; /* frames per chunk */
+  constexpr int CPF = (H >= CH_OUT) ? H / CH_OUT : 1; /* chunks per frame */
+  constexpr int NHB = FPC + 1;                        /* half-buffers     */
+  constexpr int NB = H / RDSP_BLOCK;                  /* 128-blocks per hop */
+  constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
+  constexpr int LP = (CH_IN / 4 + NT - 1) / NT; /* uint4 loads per thread per chunk */
+  static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
+  static_assert(NT == 64 || NT == 256, "one or four waves per channel");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *xs = reinterpret_cast<float2 *>(smem_raw);
+  float2 *hb = xs + XS_N;
+  float2 *wb = hb + NHB * H;
+  float *red = reinterpret_cast<float *>(wb + PL::WB);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const size_t ch = blockIdx.x;
+  const uint32_t *iq = p.iq + ch * p.in_stride;
+
+  float2 tw[PL::NTW][P - 1];
+  make_twiddles<N, P>(tid, tw);
+
+  float nfloor = p.st_scal[ch * 4 + 0];
+  float agc_g = p.st_scal[ch * 4 + 1];
+  float am_dc = p.st_scal[ch * 4 + 2];
+
+  /* first uint4 loads of chunk 0 go out before anything else */
+  uint4 raw[LP];
+#pragma unroll
+  for (int k = 0; k < LP; k++) {
+    int idx = tid + NT * k;
+    if (idx < CH_IN / 4) raw[k] = *reinterpret_cast<const uint4 *>(iq + 4 * idx);
+  }
+
+  /* state in: previous hop -> half-buffer 0, FIR history -> polyphase planes */
+  for (int i = tid; i < H; i += NT) hb[i] = p.st_prev[ch * H + i];
+  if constexpr (DECIM == 4) {
+    for (int i = tid; i < 64; i += NT) {
+      uint4 w4 = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * i);
+      uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+      uint32_t nabs = p.n0 - 256u + 4u * (uint32_t)i;
+      float2 ph0 = make_float2(1.f, 0.f);
+      if (p.dphi != 0u) ph0 = nco_phasor(nabs * p.dphi, p.nco_t1, p.nco_t2);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float2 x = unpack_iq(w[k], p.scale_i, p.scale_q);
+        if (p.dphi != 0u) {
+          float2 ph = (k == 0) ? ph0 : cmul(ph0, k == 1 ? p.rot1 : (k == 2 ? p.rot2 : p.rot3));
+          x = cmul(x, ph);
+        }
+        xs[xs_pos(-256 + 4 * i + k)] = x;
+      }
+    }
+  }
+  int old_slot = 0; /* half-buffer holding the previous hop */
+  int frame_idx = 0;
+  __syncthreads();
+
+  for (int chunk = 0; chunk < p.n_chunks; chunk++) {
+    /* ---- A1 + A2: unpack, gains, mix; scatter into the polyphase planes ---- */
+#pragma unroll
+    for (int k = 0; k < LP; k++) {
+      int idx = tid + NT * k;
+      if (idx < CH_IN / 4) {
+        uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+        uint32_t nabs = p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)idx;
+        float2 ph0 = make_float2(1.f, 0.f);
+        if (p.dphi != 0u) ph0 = nco_phasor(nabs * p.dphi, p.nco_t1, p.nco_t2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float2 x = unpack_iq(w[j], p.scale_i, p.scale_q);
+          if (p.dphi != 0u) {
+            float2 ph = (j == 0) ? ph0 : cmul(ph0, j == 1 ? p.rot1 : (j == 2 ? p.rot2 : p.rot3));
+            x = cmul(x, ph);
+          }
+          if constexpr (DECIM == 4) {
+            xs[xs_pos(4 * idx + j)] = x;
+          } else {
+            int m = 4 * idx + j; /* no decimator: the sample is the "output" */
+            int slot, off;
+            if constexpr (FPC == 1) { slot = old_slot ^ 1; off = (chunk % CPF) * CH_OUT + m; }
+            else { slot = (old_slot + 1 + m / H) % NHB; off = m % H; }
+            hb[slot * H + off] = x;
+          }
+        }
+      }
+    }
+    /* prefetch the next chunk's raw samples; they land during FIR + FFT */
+    if (chunk + 1 < p.n_chunks) {
+#pragma unroll
+      for (int k = 0; k < LP; k++) {
+        int idx = tid + NT * k;
+        if (idx < CH_IN / 4)
+          raw[k] = *reinterpret_cast<const uint4 *>(iq + (size_t)(chunk + 1) * CH_IN + 4 * idx);
+      }
+    }
+    __syncthreads();
+
+    /* ---- A3: polyphase decimating FIR ------------------------------------ */
+    if constexpr (DECIM == 4) {
+      float2 acc[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = make_float2(0.f, 0.f);
+      if constexpr (NW == 1) {
+        fir_lane(lane, 0, 4, xs, p.fir_hc, acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int m = 4 * lane + r, slot, off;
+          if constexpr (FPC == 1) { slot = old_slot ^ 1; off = (chunk % CPF) * CH_OUT + m; }
+          else { slot = (old_slot + 1 + m / H) % NHB; off = m % H; }
+          hb[slot * H + off] = acc[r];
+        }
+        __syncthreads();
+      } else {
+        /* four waves: wave w takes polyphase branch w; partials summed via LDS */
+        fir_lane(lane, wave, wave + 1, xs, p.fir_hc, acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) wb[wave * CH_OUT + 4 * lane + r] = acc[r];
+        __syncthreads();
+        {
+          float2 s0 = wb[tid], s1 = wb[CH_OUT + tid], s2 = wb[2 * CH_OUT + tid], s3 = wb[3 * CH_OUT + tid];
+          float2 s = cadd(cadd(s0, s1), cadd(s2, s3));
+          int m = tid, slot, off;
+          if constexpr (FPC == 1) { slot = old_slot ^ 1; off = (chunk % CPF) * CH_OUT + m; }
+          else { slot = (old_slot + 1 + m / H) % NHB; off = m % H; }
+          hb[slot * H + off] = s;
+        }
+      }
+      /* slide the FIR history: entries 64..80 of every sub-plane -> 0..16 */
+      {
+        float4 *xs4 = reinterpret_cast<float4 *>(xs);
+        for (int i = tid; i < 8 * 17; i += NT) {
+          int sp = i / 17, e = i % 17;
+          xs4[sp * RDSP_XP + e] = xs4[sp * RDSP_XP + 64 + e];
+        }
+      }
+      __syncthreads();
+    }
+
+    if ((chunk + 1) % CPF != 0) continue;
+
+    /* ---- A5/A6: overlap-save frames ---------------------------------------- */
+#pragma unroll 1
+    for (int f = 0; f < FPC; f++) {
+      const int new_slot = (FPC == 1) ? (old_slot ^ 1) : (old_slot + 1) % NHB;
+      const float2 *hold = hb + old_slot * H;
+      const float2 *hnew = hb + new_slot * H;
+      float2 v[P];
+      /* CONV:267-285: [previous hop | current hop] */
+#pragma unroll
+      for (int j = 0; j < PH; j++) {
+        v[j] = hold[tid + j * NT];
+        v[j + PH] = hnew[tid + j * NT];
+      }
+      auto sync = []() { __syncthreads(); };
+      fwd_pass0_store<N, P>(tid, v, wb, tw); /* CONV:291 */
+      __syncthreads();
+      fwd_mid_all<N, P, 1, PL::NP - 1>(tid, wb, tw, sync);
+      fwd_pass_last<N, P>(tid, v, wb);
+
+      if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
+        float mag[P];
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+          mag[e] = sqrtf(v[e].x * v[e].x + v[e].y * v[e].y); /* SPEC:182 */
+          int k = bin_of_pos<N, P>(tid * P + e);
+          if (k >= p.vad_lo && k <= p.vad_hi) part += mag[e]; /* SPEC:194-197 */
+        }
+        float tot = wave_sum(part);
+        if constexpr (NW > 1) {
+          if (lane == 0) red[wave] = tot;
+          __syncthreads();
+          tot = (red[0] + red[1]) + (red[2] + red[3]);
+          __syncthreads();
+        }
+        float th = tot / (float)(p.vad_hi - p.vad_lo); /* SPEC:200 */
+        th = th * p.spectral_k;                        /* SPEC:202 */
+        nfloor += (th - nfloor) * 0.65f;               /* SPEC:205 */
+        nfloor = nfloor > 0.f ? nfloor : 0.f;          /* SPEC:206 */
+#pragma unroll
+        for (int e = 0; e < P; e++) {
+          float m0 = mag[e];
+          float m1 = (m0 <= nfloor) ? m0 * 0.2f : m0 - nfloor; /* SPEC:213-217 */
+          float sc = (m0 > 0.f) ? m1 / m0 : 0.f;               /* SPEC:226-235 */
+          v[e].x *= sc;
+          v[e].y *= sc;
+        }
+      }
+      /* CONV:301: spectrum x mask (mask/N, digit-reversed, thread-major) */
+#pragma unroll
+      for (int e = 0; e < P; e++) v[e] = cmul(v[e], p.maskp[e * NT + tid]);
+
+      inv_pass_last<N, P>(tid, v, wb); /* CONV:309 */
+      __syncthreads();
+      inv_mid_all<N, P, PL::NP - 2>(tid, wb, tw, sync);
+      inv_pass0_load<N, P>(tid, v, wb, tw);
+      __syncthreads(); /* wb is free again (next frame / next chunk's FIR) */
+
+      /* CONV:314-318: keep the second half.  v[PH + jj] = y[N/2 + tid + jj*NT] */
+      float L[PH], R[PH];
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) {
+        L[jj] = v[PH + jj].x;
+        R[jj] = v[PH + jj].y;
+      }
+
+      /* helper: per-128-block sums of a per-thread value over the workgroup */
+      float bs[NB];
+      auto block_sums = [&](const float(&pv)[PH]) {
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++) {
+          float s = wave_sum(pv[jj]);
+          if (lane == 0) red[wave * PH + jj] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; w++)
+#pragma unroll
+            for (int jj = 0; jj < PH; jj++)
+              if (((jj * NT + w * 64) >> 7) == b) s += red[w * PH + jj];
+          bs[b] = s;
+        }
+        __syncthreads();
+      };
+
+      if (p.demod == RDSP_K_DEMOD_REAL) {
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++) R[jj] = L[jj];
+      } else if (p.demod == RDSP_K_DEMOD_AM) {
+        float a[PH];
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++) a[jj] = sqrtf(L[jj] * L[jj] + R[jj] * R[jj]);
+        block_sums(a);
+        float d0[NB], d1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          float m = bs[b] / (float)RDSP_BLOCK;
+          float dn = am_dc + 0.25f * (m - am_dc);
+          d0[b] = am_dc;
+          d1[b] = dn;
+          am_dc = dn;
+        }
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++) {
+          const int b0 = (jj * NT) >> 7;
+          float s0 = d0[b0], s1 = d1[b0];
+          if constexpr (NT == 256) {
+            if (tid >= 128) { s0 = d0[b0 + 1]; s1 = d1[b0 + 1]; }
+          }
+          int i = (tid + jj * NT) & 127;
+          float dc = s0 + (s1 - s0) * ((float)(i + 1) / (float)RDSP_BLOCK);
+          L[jj] = a[jj] - dc;
+          R[jj] = L[jj];
+        }
+      }
+
+      const size_t tout = (size_t)frame_idx * H;
+      if (p.to_mid) {
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++) p.mid[ch * p.mid_stride + tout + tid + jj * NT] = L[jj];
+      } else {
+        if (p.agc_on) {
+          float pw[PH];
+#pragma unroll
+          for (int jj = 0; jj < PH; jj++) pw[jj] = L[jj] * L[jj] + R[jj] * R[jj];
+          block_sums(pw);
+          float g0[NB], g1[NB];
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            float pp = bs[b] / (float)(2 * RDSP_BLOCK);
+            float rms = sqrtf(pp);
+            float gt = 0.25f / (rms + 1e-6f);
+            gt = fminf(gt, 100.0f);
+            float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
+            float gn = agc_g + coef * (gt - agc_g);
+            g0[b] = agc_g;
+            g1[b] = gn;
+            agc_g = gn;
+          }
+#pragma unroll
+          for (int jj = 0; jj < PH; jj++) {
+            const int b0 = (jj * NT) >> 7;
+            float s0 = g0[b0], s1 = g1[b0];
+            if constexpr (NT == 256) {
+              if (tid >= 128) { s0 = g0[b0 + 1]; s1 = g1[b0 + 1]; }
+            }
+            int i = (tid + jj * NT) & 127;
+            float g = s0 + (s1 - s0) * ((float)(i + 1) / (float)RDSP_BLOCK);
+            L[jj] *= g;
+            R[jj] *= g;
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++) {
+          float l = L[jj] * p.out_gain, r = R[jj] * p.out_gain;
+          size_t o = ch * p.out_stride + tout + tid + jj * NT;
+          p.out_i16[o] = pack_lr(l, r); /* CONV:346-347 */
+          if (p.out_f32) p.out_f32[o] = make_float2(l, r);
+        }
+      }
+      frame_idx++;
+      old_slot = new_slot;
+    }
+  }
+
+  /* ---- state out --------------------------------------------------------- */
+  for (int i = tid; i < H; i += NT) p.st_prev[ch * H + i] = hb[old_slot * H + i];
+  if constexpr (DECIM == 4) {
+    const uint32_t *tail = iq + (size_t)p.n_chunks * CH_IN - 256;
+    for (int i = tid; i < 256; i += NT) p.st_hist[ch * 256 + i] = tail[i];
+  }
+  if (tid == 0) {
+    p.st_scal[ch * 4 + 0] = nfloor;
+    if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
+    p.st_scal[ch * 4 + 2] = am_dc;
+  }
+}
+
+/* ---- tail kernel ---------------------------------------------------------- */
+/* One NLMS instance of one channel, spread over LPC lanes of a DPP row.
+ * Lane `sub` holds the taps of ages TPL*sub .. TPL*sub+TPL-1 (age 0 = newest
+ * sample); CMSIS coefficient b[i] multiplies age 95-i (arm_lms_norm_f32). */
+template <int LPC>
+struct Nlms {
+  static constexpr int TPL = RDSP_LMS_TAPS / LPC;
+  static constexpr int NPH = (TPL <= 4) ? 4 : (TPL <= 8 ? 8 : 16); /* physical ring */
+  float w[TPL];
+  float xp[NPH];
+  float energy;
+
+  __device__ __forceinline__ void load(const float *wst, const float *prev, const float *est,
+                                       size_t ch, int sub) {
+#pragma unroll
+    for (int k = 0; k < TPL; k++) w[k] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + k))];
+#pragma unroll
+    for (int k = 0; k < NPH; k++) xp[k] = 0.f;
+    /* before step s the in-lane tap k sits at physical ((-s) + 1 + k) & (NPH-1); a block
+     * is 128 steps = a whole number of ring turns, so every block starts at s = 0 */
+#pragma unroll
+    for (int k = 0; k < TPL; k++)
+      xp[(k + 1) & (NPH - 1)] = prev[ch * RDSP_BLOCK + (127 - (TPL * sub + k))];
+    energy = est[ch];
+  }
+  __device__ __forceinline__ void store(float *wst, float *est, size_t ch, int sub) {
+#pragma unroll
+    for (int k = 0; k < TPL; k++) wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + k))] = w[k];
+    if (sub == 0) est[ch] = energy;
+  }
+
+  /* one 128-sample block (NR:66-80).  ring: [2][128] floats in LDS holding this
+   * instance's input, half `hc` = current block, the other half = previous
+   * block.  mode 0: out = 1.1*y (CONV:334), 1: out = e, 2: out = y. */
+  __device__ __forceinline__ void block(const float *ring, int hc, bool first, float mu, int mode,
+                                        float *out, int sub) {
+    static_assert(LPC == 16, "row-DPP mapping assumes one channel per 16-lane row");
+    const float *cur = ring + hc * RDSP_BLOCK;
+    const float *prv = ring + (hc ^ 1) * RDSP_BLOCK;
+    const float *dsrc = first ? cur : prv; /* NR:69-79: first call d = x, then previous block */
+#pragma unroll 1
+    for (int s0 = 0; s0 < RDSP_BLOCK; s0 += 16) {
+      float in[16], x0[16], dd[16];
+      const float *x0p = (s0 >= 96) ? (cur + s0 - 96) : (prv + s0 + 32); /* x[n-96] */
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float4 a = *reinterpret_cast<const float4 *>(cur + s0 + 4 * q);
+        float4 b = *reinterpret_cast<const float4 *>(x0p + 4 * q);
+        float4 c = *reinterpret_cast<const float4 *>(dsrc + s0 + 4 * q);
+        in[4 * q] = a.x; in[4 * q + 1] = a.y; in[4 * q + 2] = a.z; in[4 * q + 3] = a.w;
+        x0[4 * q] = b.x; x0[4 * q + 1] = b.y; x0[4 * q + 2] = b.z; x0[4 * q + 3] = b.w;
+        dd[4 * q] = c.x; dd[4 * q + 1] = c.y; dd[4 * q + 2] = c.z; dd[4 * q + 3] = c.w;
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        constexpr int M = NPH - 1;
+        const int wpos = (-s) & M; /* s0 % 16 == 0 and NPH divides 16: compile-time */
+        /* shift the delay line by one: lane sub takes lane sub-1's oldest tap,
+         * lane 0 takes the new sample (DPP row_shr:1 keeps `old` there) */
+        float oldest = xp[(wpos + TPL) & M]; /* logical TPL-1 before this step */
+        float inc = __builtin_bit_cast(
+            float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, in[s]),
+                                               __builtin_bit_cast(int, oldest), 0x111, 0xF, 0xF,
+                                               false));
+        xp[wpos] = inc;
+        energy = fmaf(-x0[s], x0[s], energy); /* energy -= x0*x0 */
+        energy = fmaf(in[s], in[s], energy);  /* energy += in*in */
+        float acc0 = w[0] * xp[wpos];
+        float acc1 = w[1] * xp[(wpos + 1) & M];
+#pragma unroll
+        for (int k = 2; k < TPL; k += 2) {
+          acc0 = fmaf(w[k], xp[(wpos + k) & M], acc0);
+          acc1 = fmaf(w[k + 1], xp[(wpos + k + 1) & M], acc1);
+        }
+        float y = row_allsum(acc0 + acc1);
+        float e = dd[s] - y;
+        float g = (e * mu) * __builtin_amdgcn_rcpf(energy + 0.000000119209289f);
+#pragma unroll
+        for (int k = 0; k < TPL; k++) w[k] = fmaf(g, xp[(wpos + k) & M], w[k]);
+        float o = (mode == 1) ? e : y;
+        mine = (sub == s) ? o : mine;
+      }
+      if (mode == 0) mine = mine * 1.1f;
+      out[s0 + sub] = mine;
+    }
+  }
+};
+
+template <int LPC>
+__global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
+  constexpr int CPW = 64 / LPC;
+  constexpr int SPL = RDSP_BLOCK / LPC; /* samples per lane per block */
+  __shared__ __attribute__((aligned(16))) float lds[CPW][5 * RDSP_BLOCK];
+  const int lane = threadIdx.x;
+  const int sub = lane % LPC;
+  const int cw = lane / LPC;
+  size_t ch = (size_t)blockIdx.x * CPW + cw;
+  const bool valid = ch < (size_t)p.n_channels;
+  if (!valid) ch = p.n_channels - 1; /* compute on a real channel, store nothing */
+
+  float *ringA = &lds[cw][0];              /* [2][128] kernel input        */
+  float *ringB = &lds[cw][2 * RDSP_BLOCK]; /* [2][128] ALS input when NR on */
+  float *fin = &lds[cw][4 * RDSP_BLOCK];   /* [128] final audio of the block */
+
+  Nlms<LPC> nr, als;
+  if (p.nr_on) nr.load(p.nr_w, p.nr_prev, p.nr_energy, ch, sub);
+  if (p.als_mode) als.load(p.als_w, p.als_prev, p.als_energy, ch, sub);
+  float agc_g = p.st_scal[ch * 4 + 1];
+
+  /* previous-block halves (half 1, since block 0 uses half 0 as current) */
+  if (p.nr_on) {
+#pragma unroll
+    for (int k = 0; k < SPL; k++) ringA[RDSP_BLOCK + sub * SPL + k] = p.nr_prev[ch * RDSP_BLOCK + sub * SPL + k];
+  }
+  if (p.als_mode) {
+    float *r = p.nr_on ? ringB : ringA;
+#pragma unroll
+    for (int k = 0; k < SPL; k++) r[RDSP_BLOCK + sub * SPL + k] = p.als_prev[ch * RDSP_BLOCK + sub * SPL + k];
+  }
+
+  const float *src = p.mid + ch * p.mid_stride;
+  static_assert(SPL == 8, "two float4 per lane per block");
+  float4 nxa = *reinterpret_cast<const float4 *>(src + sub * SPL);
+  float4 nxb = *reinterpret_cast<const float4 *>(src + sub * SPL + 4);
+
+#pragma unroll 1
+  for (int b = 0; b < p.n_blocks; b++) {
+    const int hc = b & 1;
+    *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL) = nxa;
+    *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL + 4) = nxb;
+    if (b + 1 < p.n_blocks) { /* next block's input lands while this block computes */
+      nxa = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL);
+      nxb = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL + 4);
+    }
+    __syncthreads();
+    const float *cur = ringA + hc * RDSP_BLOCK;
+    if (p.nr_on) { /* CONV:326-337 */
+      float *o = p.als_mode ? (ringB + hc * RDSP_BLOCK) : fin;
+      nr.block(ringA, hc, p.nr_first && b == 0, p.nr_mu, 0, o, sub);
+      __syncthreads();
+      cur = o;
+    }
+    if (p.als_mode) {
+      const float *ring = p.nr_on ? ringB : ringA;
+      als.block(ring, hc, p.als_first && b == 0, p.als_mu, p.als_mode, fin, sub);
+      __syncthreads();
+      cur = fin;
+    }
+    /* A9 AGC + output gain + A10 pack: lane handles SPL consecutive samples */
+    float L[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL / 4; k++) {
+      float4 a = *reinterpret_cast<const float4 *>(cur + sub * SPL + 4 * k);
+      L[4 * k] = a.x; L[4 * k + 1] = a.y; L[4 * k + 2] = a.z; L[4 * k + 3] = a.w;
+    }
+    if (p.agc_on) {
+      float pw = 0.f;
+#pragma unroll
+      for (int k = 0; k < SPL; k++) pw += L[k] * L[k] + L[k] * L[k];
+      pw = row_allsum(pw);
+      float pp = pw / (float)(2 * RDSP_BLOCK);
+      float rms = sqrtf(pp);
+      float gt = fminf(0.25f / (rms + 1e-6f), 100.0f);
+      float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
+      float gn = agc_g + coef * (gt - agc_g);
+#pragma unroll
+      for (int k = 0; k < SPL; k++) {
+        int i = sub * SPL + k;
+        float g = agc_g + (gn - agc_g) * ((float)(i + 1) / (float)RDSP_BLOCK);
+        L[k] *= g;
+      }
+      agc_g = gn;
+    }
+    if (valid) {
+      size_t o = ch * p.out_stride + (size_t)b * RDSP_BLOCK + sub * SPL;
+#pragma unroll
+      for (int k = 0; k < SPL; k += 4) {
+        uint4 wv;
+        float l0 = L[k] * p.out_gain, l1 = L[k + 1] * p.out_gain, l2 = L[k + 2] * p.out_gain,
+              l3 = L[k + 3] * p.out_gain;
+        wv.x = pack_lr(l0, l0); wv.y = pack_lr(l1, l1); wv.z = pack_lr(l2, l2); wv.w = pack_lr(l3, l3);
+        *reinterpret_cast<uint4 *>(p.out_i16 + o + k) = wv;
+        if (p.out_f32) {
+          p.out_f32[o + k] = make_float2(l0, l0);
+          p.out_f32[o + k + 1] = make_float2(l1, l1);
+          p.out_f32[o + k + 2] = make_float2(l2, l2);
+          p.out_f32[o + k + 3] = make_float2(l3, l3);
+        }
+      }
+    }
+    __syncthreads(); /* fin / rings are rewritten by the next block */
+  }
+
+  /* state out: weights, energy, last input block of each instance, AGC gain */
+  if (valid) {
+    const int hl = (p.n_blocks - 1) & 1;
+    if (p.nr_on) {
+      nr.store(p.nr_w, p.nr_energy, ch, sub);
+#pragma unroll
+      for (int k = 0; k < SPL; k++) p.nr_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringA[hl * RDSP_BLOCK + sub * SPL + k];
+    }
+    if (p.als_mode) {
+      als.store(p.als_w, p.als_energy, ch, sub);
+      const float *r = p.nr_on ? ringB : ringA;
+#pragma unroll
+      for (int k = 0; k < SPL; k++) p.als_prev[ch * RDSP_BLOCK + sub * SPL + k] = r[hl * RDSP_BLOCK + sub * SPL + k];
+    }
+    if (sub == 0) p.st_scal[ch * 4 + 1] = agc_g;
+  }
+}
+
+/* ---- standalone A1 / A10 (bit-exact tests of the int16 <-> float edges) ---- */
+__global__ void rdsp_q15_to_float_kernel(const int16_t *src, float *dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = (float)src[i] * (1.0f / 32768.0f);
+}
+__global__ void rdsp_float_to_q15_kernel(const float *src, int16_t *dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = (int16_t)q15_of_float(src[i]);
+}
+
+template <int N, int P, int DECIM>
+constexpr size_t front_lds() {
+  using PL = FftPlan<N, P>;
+  constexpr int H = N / 2;
+  constexpr int FPC = (H >= 256) ? 1 : 256 / H;
+  constexpr int NHB = FPC + 1;
+  constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
+  return (size_t)(XS_N + NHB * H + PL::WB) * sizeof(float2) + 64 * sizeof(float);
+}
+
+template <int N, int P, int DECIM>
+int launch_front_t(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  constexpr size_t lds = front_lds<N, P, DECIM>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t rdsp_front_lds_bytes(int fft_l, int decim) {
+  const bool d4 = decim == 4;
+  switch (fft_l) {
+    case 256: return d4 ? front_lds<256, 4, 4>() : front_lds<256, 4, 1>();
+    case 512: return d4 ? front_lds<512, 8, 4>() : front_lds<512, 8, 1>();
+    case 1024: return d4 ? front_lds<1024, 16, 4>() : front_lds<1024, 16, 1>();
+    case 2048: return d4 ? front_lds<2048, 8, 4>() : front_lds<2048, 8, 1>();
+    case 4096: return d4 ? front_lds<4096, 16, 4>() : front_lds<4096, 16, 1>();
+    default: return 0;
+  }
+}
+
+extern "C" int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_channels,
+                                 hipStream_t stream) {
+  if (decim != 1 && decim != 4) return (int)hipErrorInvalidValue;
+  const bool d4 = decim == 4;
+  switch (fft_l) {
+    case 256: return d4 ? launch_front_t<256, 4, 4>(p, n_channels, stream) : launch_front_t<256, 4, 1>(p, n_channels, stream);
+    case 512: return d4 ? launch_front_t<512, 8, 4>(p, n_channels, stream) : launch_front_t<512, 8, 1>(p, n_channels, stream);
+    case 1024: return d4 ? launch_front_t<1024, 16, 4>(p, n_channels, stream) : launch_front_t<1024, 16, 1>(p, n_channels, stream);
+    case 2048: return d4 ? launch_front_t<2048, 8, 4>(p, n_channels, stream) : launch_front_t<2048, 8, 1>(p, n_channels, stream);
+    case 4096: return d4 ? launch_front_t<4096, 16, 4>(p, n_channels, stream) : launch_front_t<4096, 16, 1>(p, n_channels, stream);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+extern "C" int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
+  if (lanes_per_channel != 16) return (int)hipErrorInvalidValue;
+  constexpr int CPW = 4;
+  int grid = (p->n_channels + CPW - 1) / CPW;
+  hipLaunchKernelGGL((rdsp_tail_kernel<16>), dim3(grid), dim3(64), 0, stream, *p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream) {
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(rdsp_q15_to_float_kernel, dim3(grid), dim3(256), 0, stream, src, dst, n);
+  return (int)hipGetLastError();
+}
+extern "C" int rdsp_launch_float_to_q15(const float *src, int16_t *dst, size_t n, hipStream_t stream) {
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(rdsp_float_to_q15_kernel, dim3(grid), dim3(256), 0, stream, src, dst, n);
+  return (int)hipGetLastError();
+}
