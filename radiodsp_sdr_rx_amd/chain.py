@@ -58,10 +58,12 @@ class Chain:
             out = torch.empty((self.n_channels, n_out, 2), dtype=torch.int16, device=iq.device)
         if want_f32 and out_f32 is None:
             out_f32 = torch.empty((self.n_channels, n_out, 2), dtype=torch.float32, device=iq.device)
+        if out_f32 is not None:
+            assert out_f32.stride(0) == out.stride(0)  # one out_stride for both (samples)
         f32p = C.c_void_p(out_f32.data_ptr()) if out_f32 is not None else C.c_void_p(0)
         _lib.check(self.lib.rdsp_chain_process(
-            self.h, C.c_void_p(iq.data_ptr()), iq.stride(0), n // 128,
-            C.c_void_p(out.data_ptr()), out.stride(0), f32p, _stream_ptr(stream)))
+            self.h, C.c_void_p(iq.data_ptr()), iq.stride(0) // 2, n // 128,
+            C.c_void_p(out.data_ptr()), out.stride(0) // 2, f32p, _stream_ptr(stream)))
         return (out, out_f32) if want_f32 else out
 
     # ---- reference-named stage calls ----------------------------------------
@@ -82,8 +84,8 @@ class Chain:
                               device=iq.device)
         _lib.check(self.lib.rdsp_doConvolutionalProcessing(
             self.h, float(iNRLevel), int(bool(bFilterEnabled)), dFLoCut, dFHiCut,
-            C.c_void_p(iq.data_ptr()), iq.stride(0), n // 128, C.c_void_p(out.data_ptr()),
-            out.stride(0), _stream_ptr(stream)))
+            C.c_void_p(iq.data_ptr()), iq.stride(0) // 2, n // 128, C.c_void_p(out.data_ptr()),
+            out.stride(0) // 2, _stream_ptr(stream)))
         return out
 
     def reset(self, stream=None):
