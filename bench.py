@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the per-block IQ receive chain on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (launched by torch.distributed.run for N > 1).  Channels are
+sharded by rank with no data-path collective (RCCL unused; the only
+communication is the timing barrier / max-reduce, over gloo).  A step = one pass
+of the hot path over one batch: `--blocks` input blocks of 128 IQ samples for
+every channel of the rank, already resident in HBM.  Rank 0 prints ONE JSON
+line.  Default workload = BASELINE.json configs[2] (K3, "full SSB+NR chain":
+4096 channels, USB + 512-pt spectral NR + LMS auto-notch + AGC), the
+configuration the metric is quoted on; --config K2|K4|K5 selects the others.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="K3", choices=["K2", "K3", "K4", "K5"])
+    ap.add_argument("--channels-per-gpu", type=int, default=0)
+    ap.add_argument("--blocks", type=int, default=512, help="128-sample input blocks per channel per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_sample(decim):
+    # int16 I+Q read (4 B) + int16 L+R written per output sample (4/D B)
+    return 4.0 + 4.0 / decim
+
+
+def host_cores(n_gpus):
+    """Host threads this job may use: a GPU box gives 16 cores per GPU (the
+    container may report the whole host)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16 * max(1, n_gpus)))
+
+
+def cpu_baseline_worker(args):
+    """Runs in a fresh process (no torch, no second OpenMP runtime): times the
+    oracle (-O3 -march=native build made on this host) on a bounded sample of the
+    same workload with all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    import radiodsp_sdr_rx_amd as R
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+
+    kc = R.K_CONFIGS[args.config]
+    cfg = dict(kc["cfg"])
+    cores = host_cores(1)
+    so = oracle_lib.build(native=True, out_dir="/tmp")
+    lib = oracle_lib.load(so)
+    # calibrate on a small sample, then size the timed sample to ~cpu-seconds
+    nblk = min(args.blocks, 512)
+    iq = synth_iq(cores, nblk * 128, cw=kc.get("cw", False))
+    t = time.perf_counter()
+    oracle_lib.multi_process(iq, n_threads=cores, lib=lib, **cfg)
+    dt = time.perf_counter() - t
+    rate = iq.shape[0] * iq.shape[1] / dt
+    nch = int(max(cores, min(4096, args.cpu_seconds * rate / (nblk * 128))))
+    nch = (nch // cores) * cores
+    iq = synth_iq(nch, nblk * 128, cw=kc.get("cw", False))
+    best = None
+    for _ in range(2):  # host thread scheduling is noisy: keep the better of two
+        t = time.perf_counter()
+        oracle_lib.multi_process(iq, n_threads=cores, lib=lib, **cfg)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    val = nch * nblk * 128 / best / 1e6
+    print(json.dumps({"value": val, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
+                      "sample": f"{nch} channels x {nblk} blocks of 128 IQ samples, config {args.config}, "
+                                f"oracle gcc -O3 -march=native, OpenMP over channels, best of 2"}))
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import radiodsp_sdr_rx_amd as R
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    kc = R.K_CONFIGS[args.config]
+    cfg = dict(kc["cfg"])
+    nch = args.channels_per_gpu or kc["channels"]
+    nblk = args.blocks
+    decim = cfg.get("decim", 4)
+    n_samples = nblk * 128
+
+    # synthetic IQ generated on the host for this rank's channel range, then resident in HBM
+    threads = host_cores(1)
+    t0 = time.perf_counter()
+    iq_host = synth_iq(nch, n_samples, ch0=rank * nch, cw=kc.get("cw", False), n_threads=threads)
+    iq = torch.from_numpy(iq_host).to(dev)
+    del iq_host
+    out = torch.empty((nch, n_samples // decim, 2), dtype=torch.int16, device=dev)
+    gen_s = time.perf_counter() - t0
+
+    chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, **cfg)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        chain.process(iq, out=out)
+    barrier()
+    chain.set_timing(not args.no_kernel_timing)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.process(iq, out=out)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    front_ms, tail_ms, calls = chain.get_timing()
+    chain.set_timing(False)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_samples = float(world) * nch * n_samples * args.steps
+        value = total_samples / elapsed / 1e6  # IQ Msamples/s, whole job
+        B = algorithmic_bytes_per_sample(decim)
+        # dominant kernel of the step and its roofline (bytes per launch / avg launch time)
+        front_avg = front_ms / max(calls, 1)
+        tail_avg = tail_ms / max(calls, 1)
+        dom = "rdsp_front_kernel" if front_avg >= tail_avg else "rdsp_tail_kernel"
+        dom_ms = max(front_avg, tail_avg)
+        bytes_per_launch = B * nch * n_samples
+        achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.config, {}).get(dom)
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "IQ Msamples/s through full SSB+NR chain; achieved HBM GB/s vs peak",
+            "value": value,
+            "unit": "IQ Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {nch} channels/GPU x {nblk} blocks of 128 int16 IQ samples @96 kHz per step; "
+                            + {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
+                               "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
+                               "K4": "NCO mix + 256-tap polyphase /4 + 4096-pt overlap-save CW filter (2049 taps) + AGC",
+                               "K5": "K3 chain, 8192 channels/GPU"}[args.config],
+                "channels_per_gpu": nch,
+                "blocks_per_step": nblk,
+                "sharding": f"channels x{world}, no collectives",
+            },
+            "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
+                          "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS},
+            "kernels_ms_per_step": {"rdsp_front_kernel": front_avg, "rdsp_tail_kernel": tail_avg},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
+            "input_gen_s": gen_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+                                    "--config", args.config, "--blocks", str(nblk),
+                                    "--cpu-seconds", str(args.cpu_seconds)],
+                                   capture_output=True, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                res["cpu_baseline"] = json.loads(line)
+            except Exception as e:  # the baseline is a reported number, never the target
+                res["cpu_baseline"] = {"value": None, "unit": "IQ Msamples/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

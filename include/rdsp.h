@@ -159,6 +159,11 @@ int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of
 int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, GEN:111, CTL:237-297 */
 int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* SPEC:112 iNRLevel */
 
+/* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/
+int rdsp_chain_set_timing(rdsp_chain_t *c, int on);
+/* total milliseconds spent in the front and tail kernels over `calls` calls */
+int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *tail_ms, int *calls);
+
 /* ---- state read-back (tests, checkpoint/resume) ------------------------------*/
 /* scal: float[n_channels][4] = NFloor (SPEC:109), AGC gain, AM DC, reserved */
 int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream);

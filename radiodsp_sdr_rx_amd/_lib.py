@@ -103,6 +103,8 @@ SYMBOLS = [
     ("rdsp_sdr_setTuningOffsetHz", _i, [_vp, _d]),
     ("rdsp_set_nr_level", _i, [_vp, _i]),
     ("rdsp_set_spectral_nr", _i, [_vp, _i, _f]),
+    ("rdsp_chain_set_timing", _i, [_vp, _i]),
+    ("rdsp_chain_get_timing", _i, [_vp, _f64p, _f64p, C.POINTER(C.c_int)]),
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
     ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
     ("rdsp_chain_get_mask", _i, [_vp, _f32p]),

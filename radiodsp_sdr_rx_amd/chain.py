@@ -115,6 +115,15 @@ class Chain:
     def set_nr_level(self, lvl): _lib.check(self.lib.rdsp_set_nr_level(self.h, int(lvl)))
     def set_spectral_nr(self, on, level): _lib.check(self.lib.rdsp_set_spectral_nr(self.h, int(on), float(level)))
 
+    # ---- per-kernel timing (HIP events on the launch stream) -------------------
+    def set_timing(self, on):
+        _lib.check(self.lib.rdsp_chain_set_timing(self.h, int(bool(on))))
+
+    def get_timing(self):
+        f, t, n = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(self.lib.rdsp_chain_get_timing(self.h, C.byref(f), C.byref(t), C.byref(n)))
+        return f.value, t.value, n.value
+
     # ---- state read-back ------------------------------------------------------
     def scalars(self, stream=None):
         a = np.zeros((self.n_channels, 4), np.float32)

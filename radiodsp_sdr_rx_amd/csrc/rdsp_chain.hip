@@ -63,6 +63,10 @@ struct rdsp_chain {
   float *d_als_w = nullptr, *d_als_prev = nullptr, *d_als_energy = nullptr;
   float *d_mid = nullptr;
   size_t mid_stride = 0;
+  /* optional per-kernel HIP-event timing (bench.py roofline leg) */
+  int timing_on = 0;
+  std::vector<hipEvent_t> ev; /* groups of 3: before front, after front, after tail */
+  std::vector<int> ev_has_tail;
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int audio_filter = RDSP_AUDIO_2700;
 };
@@ -352,7 +356,15 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
   fp.mid = c->d_mid;
   fp.mid_stride = c->mid_stride;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  if (c->timing_on) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventCreate(&ev2));
+    HIP_TRY(hipEventRecord(ev0, stream));
+  }
   int e = rdsp_launch_front(c->N, c->decim, &fp, c->n_channels, stream);
+  if (c->timing_on) HIP_TRY(hipEventRecord(ev1, stream));
   if (e != 0) {
     rdsp_set_error("front kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return RDSP_ERR_HIP;
@@ -387,6 +399,11 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     }
     if (tp.nr_on) c->nr_calls += tp.n_blocks;
     if (tp.als_mode) c->als_calls += tp.n_blocks;
+  }
+  if (c->timing_on) {
+    HIP_TRY(hipEventRecord(ev2, stream));
+    c->ev.push_back(ev0); c->ev.push_back(ev1); c->ev.push_back(ev2);
+    c->ev_has_tail.push_back(tail ? 1 : 0);
   }
   c->n_in += n_in;
   return RDSP_OK;
@@ -486,6 +503,35 @@ extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *strea
   passband(c->audio_filter, mode, &lo, &hi);
   (void)rdsp_reInitializeFilter(c, lo, hi, stream);
   return demod_tuning_offset(mode);
+}
+
+/* ---- per-kernel timing with HIP events on the launch stream -------------------- */
+extern "C" int rdsp_chain_set_timing(rdsp_chain_t *c, int on) {
+  NEED(c);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  c->ev.clear();
+  c->ev_has_tail.clear();
+  c->timing_on = on ? 1 : 0;
+  return RDSP_OK;
+}
+/* sums over the calls recorded since rdsp_chain_set_timing(c, 1) */
+extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *tail_ms, int *calls) {
+  NEED(c);
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  double f = 0.0, t = 0.0;
+  const size_t n = c->ev.size() / 3;
+  for (size_t i = 0; i < n; i++) {
+    HIP_TRY(hipEventSynchronize(c->ev[3 * i + 2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[3 * i], c->ev[3 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[3 * i + 1], c->ev[3 * i + 2]));
+    f += a;
+    if (c->ev_has_tail[i]) t += b;
+  }
+  if (front_ms) *front_ms = f;
+  if (tail_ms) *tail_ms = t;
+  if (calls) *calls = (int)n;
+  return RDSP_OK;
 }
 
 /* ---- state read-back ------------------------------------------------------- */
