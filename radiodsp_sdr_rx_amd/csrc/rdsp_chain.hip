@@ -65,8 +65,9 @@ struct rdsp_chain {
   size_t mid_stride = 0;
   /* optional per-kernel HIP-event timing (bench.py roofline leg) */
   int timing_on = 0;
-  std::vector<hipEvent_t> ev; /* groups of 3: before front, after front, after tail */
+  std::vector<hipEvent_t> ev; /* pool, groups of 3: before front, after front, after tail */
   std::vector<int> ev_has_tail;
+  size_t ev_used = 0; /* calls recorded so far */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int audio_filter = RDSP_AUDIO_2700;
 };
@@ -209,6 +210,7 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -357,14 +359,15 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.mid = c->d_mid;
   fp.mid_stride = c->mid_stride;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-  if (c->timing_on) {
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventCreate(&ev2));
+  const bool timed = c->timing_on && 3 * (c->ev_used + 1) <= c->ev.size();
+  if (timed) { /* events come from a pool created in rdsp_chain_set_timing */
+    ev0 = c->ev[3 * c->ev_used];
+    ev1 = c->ev[3 * c->ev_used + 1];
+    ev2 = c->ev[3 * c->ev_used + 2];
     HIP_TRY(hipEventRecord(ev0, stream));
   }
   int e = rdsp_launch_front(c->N, c->decim, &fp, c->n_channels, stream);
-  if (c->timing_on) HIP_TRY(hipEventRecord(ev1, stream));
+  if (timed) HIP_TRY(hipEventRecord(ev1, stream));
   if (e != 0) {
     rdsp_set_error("front kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return RDSP_ERR_HIP;
@@ -400,10 +403,10 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     if (tp.nr_on) c->nr_calls += tp.n_blocks;
     if (tp.als_mode) c->als_calls += tp.n_blocks;
   }
-  if (c->timing_on) {
+  if (timed) {
     HIP_TRY(hipEventRecord(ev2, stream));
-    c->ev.push_back(ev0); c->ev.push_back(ev1); c->ev.push_back(ev2);
-    c->ev_has_tail.push_back(tail ? 1 : 0);
+    c->ev_has_tail[c->ev_used] = tail ? 1 : 0;
+    c->ev_used++;
   }
   c->n_in += n_in;
   return RDSP_OK;
@@ -508,9 +511,14 @@ extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *strea
 /* ---- per-kernel timing with HIP events on the launch stream -------------------- */
 extern "C" int rdsp_chain_set_timing(rdsp_chain_t *c, int on) {
   NEED(c);
-  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-  c->ev.clear();
-  c->ev_has_tail.clear();
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  const size_t kMaxCalls = 1024; /* calls beyond the pool are simply not timed */
+  if (on && c->ev.empty()) {
+    c->ev.resize(3 * kMaxCalls);
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    c->ev_has_tail.assign(kMaxCalls, 0);
+  }
+  c->ev_used = 0;
   c->timing_on = on ? 1 : 0;
   return RDSP_OK;
 }
@@ -519,7 +527,7 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   double f = 0.0, t = 0.0;
-  const size_t n = c->ev.size() / 3;
+  const size_t n = c->ev_used;
   for (size_t i = 0; i < n; i++) {
     HIP_TRY(hipEventSynchronize(c->ev[3 * i + 2]));
     float a = 0.f, b = 0.f;
