@@ -113,6 +113,12 @@ int rdsp_reInitializeFilter(rdsp_chain_t *c, double dFLoCut, double dFHiCut, voi
 /* Init_LMS_NR(strength), NR:35 */
 int rdsp_Init_LMS_NR(rdsp_chain_t *c, int LMS_nr_strength, void *stream);
 
+/* LMS_NoiseReduction(blockSize, nrbuffer), NR:66: the DSP-NR NLMS instance
+ * alone, in place on float audio d_nrbuffer[n_channels][stride]; n_samples per
+ * channel, a multiple of 128 (the reference calls it with 128, CONV:332) */
+int rdsp_LMS_NoiseReduction(rdsp_chain_t *c, int n_samples, float *d_nrbuffer, size_t stride,
+                            void *stream);
+
 /* The hot path.  doConvolutionalProcessing (CONV:228 / SPEC:112) with the
  * engine stages in front and behind it, for every channel, over n_blocks
  * input blocks of 128 IQ samples per channel.

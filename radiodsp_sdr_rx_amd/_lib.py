@@ -78,6 +78,7 @@ SYMBOLS = [
     ("rdsp_doConvolutionalInitialize", _i, [_vp, _vp]),
     ("rdsp_reInitializeFilter", _i, [_vp, _d, _d, _vp]),
     ("rdsp_Init_LMS_NR", _i, [_vp, _i, _vp]),
+    ("rdsp_LMS_NoiseReduction", _i, [_vp, _i, _vp, _sz, _vp]),
     ("rdsp_chain_process", _i, [_vp, _vp, _sz, _i, _vp, _sz, _vp, _vp]),
     ("rdsp_doConvolutionalProcessing", _i, [_vp, _f, _i, _d, _d, _vp, _sz, _i, _vp, _sz, _vp]),
     ("rdsp_q15_to_float", _i, [_vp, _vp, _sz, _vp]),
@@ -122,6 +123,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7.  Importing
+    # torch first makes the loader hand that same runtime to librdsp_hip.so (same
+    # SONAME); two runtimes in one process see no devices in the second one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure-C / numpy-only users fall back to the system ROCm runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

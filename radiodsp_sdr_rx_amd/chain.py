@@ -76,6 +76,13 @@ class Chain:
     def Init_LMS_NR(self, strength, stream=None):
         _lib.check(self.lib.rdsp_Init_LMS_NR(self.h, int(strength), _stream_ptr(stream)))
 
+    def LMS_NoiseReduction(self, nrbuffer, stream=None):
+        """NR:66 in isolation: float32 cuda tensor [n_channels, n] processed in place."""
+        assert nrbuffer.is_cuda and nrbuffer.dtype == torch.float32 and nrbuffer.is_contiguous()
+        _lib.check(self.lib.rdsp_LMS_NoiseReduction(self.h, nrbuffer.shape[1], C.c_void_p(nrbuffer.data_ptr()),
+                                                   nrbuffer.stride(0), _stream_ptr(stream)))
+        return nrbuffer
+
     def doConvolutionalProcessing(self, iNRLevel, bFilterEnabled, dFLoCut, dFHiCut, iq, out=None,
                                   stream=None):
         n = iq.shape[1]

@@ -412,6 +412,38 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   return RDSP_OK;
 }
 
+/* LMS_NoiseReduction(blockSize, nrbuffer), NR:66-80: the DSP-NR instance alone, in
+ * place on float buffers [n_channels][stride], n_samples a multiple of 128 */
+extern "C" int rdsp_LMS_NoiseReduction(rdsp_chain_t *c, int n_samples, float *d_nrbuffer,
+                                       size_t stride, void *stream_) {
+  if (!c || !d_nrbuffer || n_samples <= 0 || n_samples % RDSP_BLOCK != 0 || stride < (size_t)n_samples ||
+      (stride & 3) != 0 || ((uintptr_t)d_nrbuffer & 15) != 0) {
+    rdsp_set_error("rdsp_LMS_NoiseReduction: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  RdspTailParams tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.mid = d_nrbuffer;
+  tp.mid_stride = stride;
+  tp.raw_out = d_nrbuffer;
+  tp.n_channels = c->n_channels;
+  tp.n_blocks = n_samples / RDSP_BLOCK;
+  tp.nr_on = 1;
+  tp.nr_mode = 2;
+  tp.nr_mu = c->nr_mu;
+  tp.nr_first = (c->nr_calls == 0);
+  tp.nr_w = c->d_nr_w; tp.nr_prev = c->d_nr_prev; tp.nr_energy = c->d_nr_energy;
+  tp.st_scal = c->d_scal;
+  int e = rdsp_launch_tail(&tp, 16, (hipStream_t)stream_);
+  if (e != 0) {
+    rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return RDSP_ERR_HIP;
+  }
+  c->nr_calls += tp.n_blocks;
+  return RDSP_OK;
+}
+
 extern "C" int rdsp_doConvolutionalProcessing(rdsp_chain_t *c, float iNRLevel, int bFilterEnabled,
                                               double dFLoCut, double dFHiCut, const int16_t *d_iq,
                                               size_t in_stride, int n_blocks, int16_t *d_out,

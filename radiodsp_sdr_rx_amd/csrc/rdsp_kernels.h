@@ -58,6 +58,9 @@ struct RdspTailParams {
   int n_channels;
   int n_blocks;            /* 128-sample blocks at the decimated rate        */
   int nr_on, als_mode;     /* als_mode: 0 off, 1 notch (e), 2 peak (y)       */
+  int nr_mode;             /* 0: 1.1*y (CONV:334), 2: plain y (NR:73)        */
+  float *raw_out;          /* non-null: write the stage output as floats
+                              [ch][mid_stride] and skip AGC/gain/pack         */
   float nr_mu, als_mu;
   int nr_first, als_first; /* 1: first call ever (d = x quirk, NR:69-79)     */
   float *nr_w, *nr_prev, *nr_energy;    /* [ch][96], [ch][128], [ch]         */

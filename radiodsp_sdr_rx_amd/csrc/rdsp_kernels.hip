@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
     const float *cur = ringA + hc * RDSP_BLOCK;
     if (p.nr_on) { /* CONV:326-337 */
       float *o = p.als_mode ? (ringB + hc * RDSP_BLOCK) : fin;
-      nr.block(ringA, hc, p.nr_first && b == 0, p.nr_mu, 0, o, sub);
+      nr.block(ringA, hc, p.nr_first && b == 0, p.nr_mu, p.nr_mode, o, sub);
       __syncthreads();
       cur = o;
     }
@@ -551,6 +551,15 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
     for (int k = 0; k < SPL / 4; k++) {
       float4 a = *reinterpret_cast<const float4 *>(cur + sub * SPL + 4 * k);
       L[4 * k] = a.x; L[4 * k + 1] = a.y; L[4 * k + 2] = a.z; L[4 * k + 3] = a.w;
+    }
+    if (p.raw_out) { /* LMS_NoiseReduction(n, nrbuffer) in isolation, NR:66 */
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < SPL; k++)
+          p.raw_out[ch * p.mid_stride + (size_t)b * RDSP_BLOCK + sub * SPL + k] = L[k];
+      }
+      __syncthreads();
+      continue;
     }
     if (p.agc_on) {
       float pw = 0.f;
@@ -604,7 +613,7 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
 #pragma unroll
       for (int k = 0; k < SPL; k++) p.als_prev[ch * RDSP_BLOCK + sub * SPL + k] = r[hl * RDSP_BLOCK + sub * SPL + k];
     }
-    if (sub == 0) p.st_scal[ch * 4 + 1] = agc_g;
+    if (sub == 0 && !p.raw_out) p.st_scal[ch * 4 + 1] = agc_g;
   }
 }
 

@@ -1,0 +1,21 @@
+"""Shared test cases: chain configurations (BASELINE.json K1..K4 at test sizes) and
+the golden-vector manifest."""
+K1 = dict(fft_l=256, demod="USB")                       # K1/K2 chain
+K3 = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, als_mode="notch",
+          als_strength=20, agc_mode="medium", output_gain=0.5)
+K4 = dict(fft_l=4096, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0, agc_mode="fast", output_gain=0.5)
+CONV_LITERAL = dict(fs_in=44117.64706, decim=1, nco_hz=0.0, fft_l=256, flo_hz=300.0, fhi_hz=4000.0,
+                    demod="IQ")                         # the in-tree CONV stage at its native rate
+
+GOLDEN_CASES = {
+    "conv_literal_256": dict(channels=2, blocks=16, cfg=CONV_LITERAL),
+    "k2_usb_256": dict(channels=3, blocks=32, cfg=K1),
+    "k3_full_512": dict(channels=3, blocks=64, cfg=K3),
+    "k4_cw_4096": dict(channels=2, blocks=128, cfg=K4, cw=True),
+    "nr_lms_30": dict(channels=2, blocks=32, cfg=dict(fft_l=256, demod="USB", lms_nr=30)),
+    "am_agc_512": dict(channels=2, blocks=32,
+                       cfg=dict(fft_l=512, demod="AM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="slow")),
+}
+
+# feed-forward chains: the north-star tolerance (normwise, per channel)
+TOL = 1e-5

@@ -1,0 +1,38 @@
+"""Generates the committed golden vectors in tests/golden/*.npz.
+
+The reference ships no fixtures and cannot run here, so these are outputs of the
+CPU oracle (oracle/rdsp_oracle.c) on deterministic synthetic IQ: they pin the
+oracle against accidental change and give the GPU tests fixed expected outputs
+that travel to the GPU box.  Regenerate with:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import oracle_lib  # noqa: E402
+from cases import GOLDEN_CASES  # noqa: E402
+from radiodsp_sdr_rx_amd.chain import synth_iq  # noqa: E402
+
+
+def main():
+    oracle_lib.build()
+    for name, case in GOLDEN_CASES.items():
+        iq = synth_iq(case["channels"], case["blocks"] * 128, cw=case.get("cw", False))
+        o16, o32 = [], []
+        for c in range(case["channels"]):
+            ch = oracle_lib.OracleChain(**case["cfg"])
+            a, b = ch.process(iq[c])
+            o16.append(a)
+            o32.append(b)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), iq=iq, out_i16=np.stack(o16),
+                            out_f32=np.stack(o32))
+        print(name, iq.shape, np.stack(o16).shape)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every
+symbol include/rdsp.h declares, design helpers agree with the oracle, the synthetic
+generator is deterministic and shardable, host emulation of the kernels' index
+arithmetic passes, and the product fails loudly without a GPU.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(rdsp):
+    hdr = open(os.path.join(ROOT, "include", "rdsp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(rdsp_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 45
+    lib = C.CDLL(os.path.join(ROOT, "radiodsp_sdr_rx_amd", "librdsp_hip.so"))
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    from radiodsp_sdr_rx_amd import _lib
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert names <= bound, sorted(names - bound)
+
+
+def test_config_struct_layout_matches_oracle(rdsp, oracle):
+    from radiodsp_sdr_rx_amd._lib import ChainConfig
+    a = [(n, t) for n, t in ChainConfig._fields_]
+    b = [(n, t) for n, t in oracle.OrcConfig._fields_]
+    assert a == b and C.sizeof(ChainConfig) == C.sizeof(oracle.OrcConfig) == 104
+
+
+def test_product_fails_loudly_without_gpu(rdsp):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from radiodsp_sdr_rx_amd import RdspError
+    from radiodsp_sdr_rx_amd.chain import Chain
+    with pytest.raises(RdspError) as e:
+        Chain(4)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "radiodsp_sdr_rx_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("fft_l,lo,hi,fs", [(256, 300.0, 4000.0, 44117.64706), (512, 300.0, 2700.0, 24000.0),
+                                           (4096, 450.0, 950.0, 24000.0), (1024, -2700.0, -300.0, 24000.0)])
+def test_design_helpers_match_oracle(rdsp, oracle, fft_l, lo, hi, fs):
+    from radiodsp_sdr_rx_amd.chain import calc_cplx_FIR_coeffs, init_filter_mask
+    ci, cq = calc_cplx_FIR_coeffs(fft_l // 2 + 1, lo, hi, fs, 1)
+    lib = oracle.load()
+    oi, oq = np.zeros_like(ci), np.zeros_like(cq)
+    lib.orc_calc_cplx_FIR_coeffs(oi.ctypes.data_as(C.POINTER(C.c_double)), oq.ctypes.data_as(C.POINTER(C.c_double)),
+                                 len(ci), lo, hi, fs, 1)
+    assert np.abs(ci - oi).max() < 1e-15 and np.abs(cq - oq).max() < 1e-15
+    m = init_filter_mask(ci, cq, fft_l)
+    om = np.zeros(2 * fft_l, np.float32)
+    lib.orc_init_filter_mask(om.ctypes.data_as(C.POINTER(C.c_float)), oi.ctypes.data_as(C.POINTER(C.c_double)),
+                             oq.ctypes.data_as(C.POINTER(C.c_double)), fft_l)
+    # float64 DFT (product) vs float32 FFT (oracle) of the same float-narrowed taps
+    assert np.abs(m - om).max() < 2e-6
+
+
+def test_synth_is_deterministic_and_shardable(rdsp):
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    a = synth_iq(6, 4096)
+    b = synth_iq(6, 4096, n_threads=3)
+    assert np.array_equal(a, b)
+    # any (channel, time) window can be generated independently
+    part = synth_iq(2, 1024, ch0=3, t0=2048)
+    assert np.array_equal(part, a[3:5, 2048:3072])
+    x = (a[..., 0] + 1j * a[..., 1]) / 32767.0
+    assert 0.3 < np.sqrt((np.abs(x) ** 2).mean()) < 0.6 and np.abs(a).max() < 32767
+    # the two USB tones and the interferer sit at f_off + {700, 1900, 1000} Hz
+    X = np.abs(np.fft.fft(x[0] * np.hanning(4096)))
+    binhz = 96000 / 4096
+    for f, amp in ((12700, 0.2), (13000, 0.3), (13900, 0.2)):
+        k = int(round(f / binhz))
+        peak = X[k - 1:k + 2].max() / (4096 / 2)  # Hann coherent gain 0.5
+        assert 0.7 * amp < peak < 1.2 * amp, (f, peak)
+    assert X[int(round(20000 / binhz))] / 2048 < 0.02  # elsewhere only noise
+    cw = synth_iq(1, 96000 // 4, cw=True)[0]
+    env = np.abs(cw[:, 0] + 1j * cw[:, 1]).reshape(-1, 480).mean(axis=1)
+    assert env[:10].mean() > 2 * env[14:22].mean()  # keyed 60 ms on / 60 ms off
+
+
+def test_k_configs_cover_baseline_json(rdsp):
+    import json
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert len(base["configs"]) == 5
+    K = rdsp.K_CONFIGS
+    assert K["K2"]["channels"] == 4096 and K["K3"]["channels"] == 4096 and K["K4"]["channels"] == 8192
+    assert K["K3"]["cfg"]["fft_l"] == 512 and K["K4"]["cfg"]["fft_l"] == 4096 and K["K5"]["channels"] == 8192
+
+
+@pytest.mark.parametrize("src", ["host_fft_check.cpp", "host_fir_check.cpp"])
+def test_kernel_index_arithmetic_on_host(src, tmp_path):
+    """The FFT passes / LDS layout / FIR lane code are __host__ __device__: run the
+    same source thread-by-thread on the CPU against float64 references."""
+    exe = str(tmp_path / src.replace(".cpp", ""))
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-I",
+                           os.path.join(ROOT, "radiodsp_sdr_rx_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", src), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_bin_of_pos_is_a_permutation(rdsp):
+    lib = C.CDLL(os.path.join(ROOT, "radiodsp_sdr_rx_amd", "librdsp_hip.so"))
+    for n in (256, 512, 1024, 2048, 4096):
+        ks = sorted(lib.rdsp_bin_of_pos(n, i) for i in range(n))
+        assert ks == list(range(n))
+
+
+WORKER = r"""
+import os, sys, numpy as np, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from radiodsp_sdr_rx_amd.chain import synth_iq
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+nch = 3
+mine = synth_iq(nch, 2048, ch0=rank * nch)   # rank-local channel shard, no exchange
+import torch
+t = torch.tensor([float(mine.astype(np.int64).sum())], dtype=torch.float64)
+dist.all_reduce(t)                            # only the test's checksum crosses ranks
+full = synth_iq(nch * world, 2048)
+assert np.array_equal(mine, full[rank * nch:(rank + 1) * nch])
+assert float(t.item()) == float(full.astype(np.int64).sum())
+tt = torch.tensor([1.0 + rank]); dist.all_reduce(tt, op=dist.ReduceOp.MAX); assert tt.item() == world
+dist.barrier(); dist.destroy_process_group(); open(os.path.join(sys.argv[2], f"ok_{rank}"), "w").write("ok")
+"""
+
+
+def test_channel_sharding_world_size_2_gloo(tmp_path):
+    """N > 1 path of bench.py: ranks own contiguous channel ranges, nothing but the
+    timing barrier / max-reduce crosses ranks (gloo, CPU)."""
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(w), ROOT, str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
