@@ -54,7 +54,7 @@ struct rdsp_chain {
   std::vector<float> mask_nat;        /* FIR_filter_mask, CONV:77 */
   std::vector<float> fir_nat;
   /* device */
-  float2 *d_maskp = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
+  float2 *d_maskp = nullptr;
   float *d_fir_hc = nullptr;
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
@@ -158,8 +158,6 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
     HIP_TRY(hipMemset((ptr), 0, (bytes)));                            \
   } while (0)
   ALLOC_ZERO(c->d_maskp, sizeof(float2) * c->N);
-  ALLOC_ZERO(c->d_t1, sizeof(float2) * 1024);
-  ALLOC_ZERO(c->d_t2, sizeof(float2) * 1024);
   ALLOC_ZERO(c->d_fir_hc, sizeof(float) * 256);
   ALLOC_ZERO(c->d_hist, sizeof(uint32_t) * 256 * nch);
   ALLOC_ZERO(c->d_prev, sizeof(float2) * c->hop * nch);
@@ -177,12 +175,6 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
     std::vector<float> ones(4 * nch, 0.0f);
     for (size_t i = 0; i < nch; i++) ones[4 * i + 1] = 1.0f; /* AGC gain starts at 1 */
     HIP_TRY(hipMemcpy(c->d_scal, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
-  }
-  {
-    std::vector<float> t1(2048), t2(2048);
-    rdsp_nco_tables(t1.data(), t2.data());
-    HIP_TRY(hipMemcpy(c->d_t1, t1.data(), sizeof(float) * 2048, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_t2, t2.data(), sizeof(float) * 2048, hipMemcpyHostToDevice));
   }
   if (decim == 4) {
     std::vector<float> hc(256);
@@ -205,7 +197,7 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_maskp, c->d_t1, c->d_t2, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_maskp, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
@@ -333,8 +325,12 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   rdsp_nco_rot(c->dphi, 1, r); fp.rot1 = make_float2(r[0], r[1]);
   rdsp_nco_rot(c->dphi, 2, r); fp.rot2 = make_float2(r[0], r[1]);
   rdsp_nco_rot(c->dphi, 3, r); fp.rot3 = make_float2(r[0], r[1]);
-  fp.nco_t1 = c->d_t1;
-  fp.nco_t2 = c->d_t2;
+  {
+    const int nt = c->N / rdsp_plan_radix(c->N); /* threads per channel */
+    rdsp_nco_rot(c->dphi, 4 * nt, r); fp.rotp1 = make_float2(r[0], r[1]);
+    rdsp_nco_rot(c->dphi, 8 * nt, r); fp.rotp2 = make_float2(r[0], r[1]);
+    rdsp_nco_rot(c->dphi, 12 * nt, r); fp.rotp3 = make_float2(r[0], r[1]);
+  }
   fp.scale_i = cf.iq_balance * cf.input_gain * (1.0f / 32768.0f);
   fp.scale_q = cf.input_gain * (1.0f / 32768.0f);
   fp.fir_hc = c->d_fir_hc;

@@ -210,84 +210,101 @@ RDSP_HD void make_twiddles(int t, float2 (*tw)[P - 1]) {
   }
 }
 
-/* positions touched by thread t in full pass p: i_j = (g*P + j)*s + o */
+/* LDS addressing.  A thread touches, in pass p, the positions base_p + j*s_p
+ * (j = 0..P-1); through the padded map phi(i) = i + i/P that is
+ *     phi(base_p) + j*s_p + (j*s_p)/P        (s_p and P are powers of two, so
+ * the offset inside the span never carries), i.e. a per-thread constant that is
+ * computed once per kernel plus a compile-time offset the assembler folds into
+ * the ds_read/ds_write immediate. */
 template <int N, int P>
-RDSP_HD int pass_base(int t, int p, int *stride) {
+struct LdsBases {
+  int b[FftPlan<N, P>::NP]; /* phi(base) of every pass; last pass: t*(P+1) */
+};
+
+template <int N, int P>
+RDSP_HD void make_lds_bases(int t, LdsBases<N, P> &lb) {
   using PL = FftPlan<N, P>;
-  const int s = PL::span(p);
-  *stride = s;
-  return (t / s) * P * s + (t % s);
+#pragma unroll
+  for (int p = 0; p < PL::NP - 1; p++) {
+    const int s = PL::span(p);
+    const int base = (t / s) * P * s + (t % s);
+    lb.b[p] = phi<P>(base);
+  }
+  lb.b[PL::NP - 1] = t * (P + 1);
 }
+
+template <int P>
+constexpr int phi_off(int j, int s) { return j * s + (j * s) / P; }
 
 /* ---- forward ------------------------------------------------------------- */
 /* pass 0: v[] already loaded with x[t + j*NT] (j = 0..P-1) */
 template <int N, int P>
-RDSP_HD void fwd_pass0_store(int t, float2 *v, float2 *wb, const float2 (*tw)[P - 1]) {
+RDSP_HD void fwd_pass0_store(const LdsBases<N, P> &lb, float2 *v, float2 *wb,
+                             const float2 (*tw)[P - 1]) {
   using PL = FftPlan<N, P>;
   Dft<P, false>::run(v);
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmul(v[k], tw[0][k - 1]);
 #pragma unroll
-  for (int j = 0; j < P; j++) wb[phi<P>(t + j * PL::NT)] = v[j];
+  for (int j = 0; j < P; j++) wb[lb.b[0] + phi_off<P>(j, PL::span(0))] = v[j];
 }
 
 /* middle pass p (1 <= p <= NP-2), in place */
 template <int N, int P, int PIDX>
-RDSP_HD void fwd_pass_mid(int t, float2 *wb, const float2 (*tw)[P - 1]) {
+RDSP_HD void fwd_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1]) {
   using PL = FftPlan<N, P>;
   constexpr int s = PL::span(PIDX);
-  const int base = (t / s) * P * s + (t % s);
   float2 v[P];
 #pragma unroll
-  for (int j = 0; j < P; j++) v[j] = wb[phi<P>(base + j * s)];
+  for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + phi_off<P>(j, s)];
   Dft<P, false>::run(v);
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmul(v[k], tw[PIDX][k - 1]);
 #pragma unroll
-  for (int j = 0; j < P; j++) wb[phi<P>(base + j * s)] = v[j];
+  for (int j = 0; j < P; j++) wb[lb.b[PIDX] + phi_off<P>(j, s)] = v[j];
 }
 
 /* last pass: loads positions t*P .. t*P+P-1, leaves the spectrum in v[] */
 template <int N, int P>
-RDSP_HD void fwd_pass_last(int t, float2 *v, const float2 *wb) {
+RDSP_HD void fwd_pass_last(const LdsBases<N, P> &lb, float2 *v, const float2 *wb) {
   using PL = FftPlan<N, P>;
 #pragma unroll
-  for (int e = 0; e < P; e++) v[e] = wb[phi<P>(t * P + e)];
+  for (int e = 0; e < P; e++) v[e] = wb[lb.b[PL::NP - 1] + e];
 #pragma unroll
   for (int q = 0; q < P / PL::RL; q++) Dft<PL::RL, false>::run(v + q * PL::RL);
 }
 
 /* ---- inverse (unnormalised; 1/N is folded into the mask) ------------------ */
 template <int N, int P>
-RDSP_HD void inv_pass_last(int t, float2 *v, float2 *wb) {
+RDSP_HD void inv_pass_last(const LdsBases<N, P> &lb, float2 *v, float2 *wb) {
   using PL = FftPlan<N, P>;
 #pragma unroll
   for (int q = 0; q < P / PL::RL; q++) Dft<PL::RL, true>::run(v + q * PL::RL);
 #pragma unroll
-  for (int e = 0; e < P; e++) wb[phi<P>(t * P + e)] = v[e];
+  for (int e = 0; e < P; e++) wb[lb.b[PL::NP - 1] + e] = v[e];
 }
 
 template <int N, int P, int PIDX>
-RDSP_HD void inv_pass_mid(int t, float2 *wb, const float2 (*tw)[P - 1]) {
+RDSP_HD void inv_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1]) {
   using PL = FftPlan<N, P>;
   constexpr int s = PL::span(PIDX);
-  const int base = (t / s) * P * s + (t % s);
   float2 v[P];
 #pragma unroll
-  for (int j = 0; j < P; j++) v[j] = wb[phi<P>(base + j * s)];
+  for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + phi_off<P>(j, s)];
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmulc(v[k], tw[PIDX][k - 1]);
   Dft<P, true>::run(v);
 #pragma unroll
-  for (int j = 0; j < P; j++) wb[phi<P>(base + j * s)] = v[j];
+  for (int j = 0; j < P; j++) wb[lb.b[PIDX] + phi_off<P>(j, s)] = v[j];
 }
 
 /* pass 0 inverse: result v[j] = y[t + j*NT] */
 template <int N, int P>
-RDSP_HD void inv_pass0_load(int t, float2 *v, const float2 *wb, const float2 (*tw)[P - 1]) {
+RDSP_HD void inv_pass0_load(const LdsBases<N, P> &lb, float2 *v, const float2 *wb,
+                            const float2 (*tw)[P - 1]) {
   using PL = FftPlan<N, P>;
 #pragma unroll
-  for (int j = 0; j < P; j++) v[j] = wb[phi<P>(t + j * PL::NT)];
+  for (int j = 0; j < P; j++) v[j] = wb[lb.b[0] + phi_off<P>(j, PL::span(0))];
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmulc(v[k], tw[0][k - 1]);
   Dft<P, true>::run(v);
@@ -295,19 +312,19 @@ RDSP_HD void inv_pass0_load(int t, float2 *v, const float2 *wb, const float2 (*t
 
 /* compile-time loops over the middle passes */
 template <int N, int P, int PIDX, int PEND, typename SYNC>
-RDSP_HD void fwd_mid_all(int t, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
+RDSP_HD void fwd_mid_all(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
   if constexpr (PIDX < PEND) {
-    fwd_pass_mid<N, P, PIDX>(t, wb, tw);
+    fwd_pass_mid<N, P, PIDX>(lb, wb, tw);
     sync();
-    fwd_mid_all<N, P, PIDX + 1, PEND>(t, wb, tw, sync);
+    fwd_mid_all<N, P, PIDX + 1, PEND>(lb, wb, tw, sync);
   }
 }
 template <int N, int P, int PIDX, typename SYNC>
-RDSP_HD void inv_mid_all(int t, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
+RDSP_HD void inv_mid_all(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
   if constexpr (PIDX >= 1) {
-    inv_pass_mid<N, P, PIDX>(t, wb, tw);
+    inv_pass_mid<N, P, PIDX>(lb, wb, tw);
     sync();
-    inv_mid_all<N, P, PIDX - 1>(t, wb, tw, sync);
+    inv_mid_all<N, P, PIDX - 1>(lb, wb, tw, sync);
   }
 }
 

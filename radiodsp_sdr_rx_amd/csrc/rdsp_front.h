@@ -9,8 +9,8 @@
  * With k = 4k' + c:  y[m] = sum_c sum_{k'<64} hc[c][k'] * X_c[m - k'],
  * X_c[u] = x[4u - c].  One chunk = 1024 input samples -> 256 outputs.  Lane l
  * of a wave owns outputs m = 4l..4l+3, so each X_c[u] it loads from LDS feeds up
- * to four outputs (register reuse 3.8x) and every tap index is a compile-time
- * constant -> taps come through scalar loads, not LDS or VGPRs.
+ * to four outputs (register reuse 3.8x); every tap index is a compile-time
+ * constant and wave-uniform, so taps are LDS broadcast reads of four at a time.
  *
  * LDS layout: X_c[u], u = 4v + q, lives in plane (c, q>>1) at entry v + 16
  * (v in [-16, 64]), two q per 16-byte entry.  Lanes read entry (l - d + 16) of
@@ -38,49 +38,73 @@ RDSP_HD int xs_pos(int n) {
 }
 
 /* partial FIR of lane l over polyphase branches [c0, c1): acc[r] += ... for the
- * outputs m = 4l + r.  hc = [4][64] taps in branch order. */
-RDSP_HD void fir_lane(int l, int c0, int c1, const float2 *xs, const float *hc, float2 *acc) {
+ * outputs m = 4l + r.  taps = [4][16] float4 in branch order (hc[c][k'] =
+ * h[4k'+c]), read with wave-uniform addresses (LDS broadcast on the device): the
+ * read for step d needs taps 4d-3 .. 4d+3, i.e. the float4 of step d-1 and d.
+ * Data and tap reads of step d+1 are issued before the FMAs of step d, and all
+ * of them are DS operations, so the waits are counted (lgkmcnt(N)), never drained. */
+RDSP_HD void fir_lane(int l, int c0, int c1, const float2 *xs, const float4 *taps, float2 *acc) {
   const float4 *xs4 = reinterpret_cast<const float4 *>(xs);
   for (int c = c0; c < c1; c++) {
-    /* all 64 taps of the branch go to SGPRs up front (one scalar-load wait per
-     * branch); inside the d-loop only LDS reads use lgkmcnt, so the compiler can
-     * count them instead of draining to zero after every read */
-    float h[64];
-#pragma unroll
-    for (int k = 0; k < 64; k++) h[k] = hc[c * 64 + k];
-#ifdef __HIP_DEVICE_COMPILE__
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     const float4 *pl = xs4 + (c * 2) * RDSP_XP + l + 16;
+    const float4 *tp = taps + c * 16;
+    float4 tA = make_float4(0.f, 0.f, 0.f, 0.f), tB = tp[0];
+    float4 X0 = pl[0], X1 = pl[RDSP_XP];
 #pragma unroll
     for (int d = 0; d <= 16; d++) {
+      const float4 Xc[2] = {X0, X1};
+      float4 tN = tB;
+      if (d + 1 <= 16) {
+        X0 = pl[-(d + 1)];
+        X1 = pl[RDSP_XP - (d + 1)];
+        if (d + 1 <= 15) tN = tp[d + 1];
+      }
+      const float ta[8] = {tA.x, tA.y, tA.z, tA.w, tB.x, tB.y, tB.z, tB.w}; /* taps 4d-4 .. 4d+3 */
 #pragma unroll
       for (int qh = 0; qh < 2; qh++) {
-        float4 X4 = pl[qh * RDSP_XP - d];
 #pragma unroll
         for (int ql = 0; ql < 2; ql++) {
           const int q = 2 * qh + ql;
           if (d == 16 && q == 0) continue;
-          const float Xx = ql ? X4.z : X4.x, Xy = ql ? X4.w : X4.y;
+          const float Xx = ql ? Xc[qh].z : Xc[qh].x, Xy = ql ? Xc[qh].w : Xc[qh].y;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int kp = 4 * d + r - q;
             if (kp >= 0 && kp <= 63) {
-              float t = h[kp];
+              const float t = ta[4 + r - q];
               acc[r].x = fmaf(t, Xx, acc[r].x);
               acc[r].y = fmaf(t, Xy, acc[r].y);
             }
           }
         }
-#ifdef __HIP_DEVICE_COMPILE__
-        /* keep one LDS read in flight per 8 packed FMAs instead of letting the
-         * scheduler hoist all 34 reads (136 VGPRs) to the top of the branch */
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-#endif
       }
+      tA = tB;
+      tB = tN;
+#ifdef __HIP_DEVICE_COMPILE__
+      /* one step = 3 LDS reads (for step d+1) + 16 packed FMAs: keep that shape so
+       * the scheduler does not hoist a whole branch of reads into registers */
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+#endif
     }
   }
+}
+
+/* phasor of a 32-bit phase by the ALU: exp(-j*2*pi*ph/2^32).  The top 24 bits go
+ * through sincospi (exact argument), the low 8 bits are a first-order residual
+ * (angle < 3.7e-7 rad). */
+RDSP_HD float2 nco_phasor_alu(uint32_t ph) {
+  const float xh = (float)(ph >> 8) * 1.1920928955078125e-07f; /* (ph>>8) / 2^23 = turns*2 */
+  const float r = (float)(ph & 255u) * 1.4629180792671596e-09f; /* 2*pi/2^32 */
+  float sn, cs;
+#ifdef __HIP_DEVICE_COMPILE__
+  sincospif(xh, &sn, &cs);
+#else
+  sn = (float)sin(3.14159265358979323846 * (double)xh);
+  cs = (float)cos(3.14159265358979323846 * (double)xh);
+#endif
+  /* (cs - j sn)(1 - j r) */
+  return make_float2(fmaf(-sn, r, cs), -fmaf(cs, r, sn));
 }
 
 /* exp(-j*2*pi*ph/2^32) from two 1024-entry tables and a first-order residual:

@@ -25,8 +25,7 @@ struct RdspFrontParams {
   uint32_t n0;         /* absolute index (mod 2^32) of the first sample      */
   uint32_t dphi;       /* NCO phase increment per sample (turns * 2^32)      */
   float2 rot1, rot2, rot3; /* exp(-j*2pi*k*dphi/2^32), k = 1..3              */
-  const float2 *nco_t1;    /* [1024] exp(-j*2pi*i/2^10)                      */
-  const float2 *nco_t2;    /* [1024] exp(-j*2pi*i/2^20)                      */
+  float2 rotp1, rotp2, rotp3; /* the same for k*4*NT samples (next load pass) */
   float scale_i, scale_q;  /* iq_balance*input_gain/32768, input_gain/32768  */
   const float *fir_hc;     /* [4][64] decimator taps, hc[c][k'] = h[4k'+c]   */
   const float2 *maskp;     /* [N] mask/N in digit-reversed bin order         */

@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t pack_lr(float l, float r) {
 
 /* ---- front kernel -------------------------------------------------------- */
 template <int N, int P, int DECIM>
-__global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
+__global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
   constexpr int NW = NT / 64;
@@ -78,27 +78,25 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
   constexpr int NB = H / RDSP_BLOCK;                  /* 128-blocks per hop */
   constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
   constexpr int LP = (CH_IN / 4 + NT - 1) / NT; /* uint4 loads per thread per chunk */
+  /* the decimator taps live in the FFT work buffer while the FIR runs (the
+   * buffer is idle then); with four waves the first 8 KiB hold the partial sums */
+  constexpr int TAPS_OFF = (NW == 1) ? 0 : 4 * CH_OUT; /* float2 units */
   static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
   static_assert(NT == 64 || NT == 256, "one or four waves per channel");
+  static_assert(PL::WB >= TAPS_OFF + 128, "work buffer holds the taps");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *xs = reinterpret_cast<float2 *>(smem_raw);
   float2 *hb = xs + XS_N;
   float2 *wb = hb + NHB * H;
   float *red = reinterpret_cast<float *>(wb + PL::WB);
+  float4 *taps_lds = reinterpret_cast<float4 *>(wb + TAPS_OFF);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const size_t ch = blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
-
-  float2 tw[PL::NTW][P - 1];
-  make_twiddles<N, P>(tid, tw);
-
-  float nfloor = p.st_scal[ch * 4 + 0];
-  float agc_g = p.st_scal[ch * 4 + 1];
-  float am_dc = p.st_scal[ch * 4 + 2];
 
   /* first uint4 loads of chunk 0 go out before anything else */
   uint4 raw[LP];
@@ -108,6 +106,31 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
     if (idx < CH_IN / 4) raw[k] = *reinterpret_cast<const uint4 *>(iq + 4 * idx);
   }
 
+  /* per-thread constants that stay in registers for the whole launch: FFT
+   * twiddles, LDS bases of every pass, this thread's slice of the filter mask
+   * (digit-reversed, /N), its VAD-bin membership bits and its four taps */
+  float2 tw[PL::NTW][P - 1];
+  make_twiddles<N, P>(tid, tw);
+  LdsBases<N, P> lb;
+  make_lds_bases<N, P>(tid, lb);
+  float2 mreg[P];
+#pragma unroll
+  for (int e = 0; e < P; e++) mreg[e] = p.maskp[e * NT + tid];
+  uint32_t vadbits = 0;
+#pragma unroll
+  for (int e = 0; e < P; e++) {
+    int k = bin_of_pos<N, P>(tid * P + e);
+    if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+  }
+  float4 tapreg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (DECIM == 4) {
+    if (tid < 64) tapreg = reinterpret_cast<const float4 *>(p.fir_hc)[tid];
+  }
+
+  float nfloor = p.st_scal[ch * 4 + 0];
+  float agc_g = p.st_scal[ch * 4 + 1];
+  float am_dc = p.st_scal[ch * 4 + 2];
+
   /* state in: previous hop -> half-buffer 0, FIR history -> polyphase planes */
   for (int i = tid; i < H; i += NT) hb[i] = p.st_prev[ch * H + i];
   if constexpr (DECIM == 4) {
@@ -116,7 +139,7 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
       uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
       uint32_t nabs = p.n0 - 256u + 4u * (uint32_t)i;
       float2 ph0 = make_float2(1.f, 0.f);
-      if (p.dphi != 0u) ph0 = nco_phasor(nabs * p.dphi, p.nco_t1, p.nco_t2);
+      if (p.dphi != 0u) ph0 = nco_phasor_alu(nabs * p.dphi);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         float2 x = unpack_iq(w[k], p.scale_i, p.scale_q);
@@ -133,15 +156,20 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
   __syncthreads();
 
   for (int chunk = 0; chunk < p.n_chunks; chunk++) {
-    /* ---- A1 + A2: unpack, gains, mix; scatter into the polyphase planes ---- */
+    /* ---- A1 + A2: unpack, gains, mix; scatter into the polyphase planes ----
+     * One accurate phasor per thread per chunk (ALU only: no memory traffic in
+     * the loop besides the IQ stream); the other samples of the thread follow
+     * by constant rotations (k*4*NT samples between passes, 1..3 inside one). */
+    float2 ph_base = make_float2(1.f, 0.f);
+    if (p.dphi != 0u)
+      ph_base = nco_phasor_alu((p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)tid) * p.dphi);
 #pragma unroll
     for (int k = 0; k < LP; k++) {
       int idx = tid + NT * k;
       if (idx < CH_IN / 4) {
         uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
-        uint32_t nabs = p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)idx;
-        float2 ph0 = make_float2(1.f, 0.f);
-        if (p.dphi != 0u) ph0 = nco_phasor(nabs * p.dphi, p.nco_t1, p.nco_t2);
+        float2 ph0 = ph_base;
+        if (k > 0 && p.dphi != 0u) ph0 = cmul(ph_base, k == 1 ? p.rotp1 : (k == 2 ? p.rotp2 : p.rotp3));
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           float2 x = unpack_iq(w[j], p.scale_i, p.scale_q);
@@ -161,6 +189,9 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
         }
       }
     }
+    if constexpr (DECIM == 4) {
+      if (tid < 64) taps_lds[tid] = tapreg; /* the last frame overwrote the work buffer */
+    }
     /* prefetch the next chunk's raw samples; they land during FIR + FFT */
     if (chunk + 1 < p.n_chunks) {
 #pragma unroll
@@ -178,7 +209,7 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[r] = make_float2(0.f, 0.f);
       if constexpr (NW == 1) {
-        fir_lane(lane, 0, 4, xs, p.fir_hc, acc);
+        fir_lane(lane, 0, 4, xs, taps_lds, acc);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           int m = 4 * lane + r, slot, off;
@@ -189,7 +220,7 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
         __syncthreads();
       } else {
         /* four waves: wave w takes polyphase branch w; partials summed via LDS */
-        fir_lane(lane, wave, wave + 1, xs, p.fir_hc, acc);
+        fir_lane(lane, wave, wave + 1, xs, taps_lds, acc);
 #pragma unroll
         for (int r = 0; r < 4; r++) wb[wave * CH_OUT + 4 * lane + r] = acc[r];
         __syncthreads();
@@ -202,7 +233,7 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
           hb[slot * H + off] = s;
         }
       }
-      /* slide the FIR history: entries 64..80 of every sub-plane -> 0..16 */
+      /* slide the FIR history: entries 64..80 of every plane -> 0..16 */
       {
         float4 *xs4 = reinterpret_cast<float4 *>(xs);
         for (int i = tid; i < 8 * 17; i += NT) {
@@ -229,10 +260,10 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
         v[j + PH] = hnew[tid + j * NT];
       }
       auto sync = []() { __syncthreads(); };
-      fwd_pass0_store<N, P>(tid, v, wb, tw); /* CONV:291 */
+      fwd_pass0_store<N, P>(lb, v, wb, tw); /* CONV:291 */
       __syncthreads();
-      fwd_mid_all<N, P, 1, PL::NP - 1>(tid, wb, tw, sync);
-      fwd_pass_last<N, P>(tid, v, wb);
+      fwd_mid_all<N, P, 1, PL::NP - 1>(lb, wb, tw, sync);
+      fwd_pass_last<N, P>(lb, v, wb);
 
       if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
         float mag[P];
@@ -240,8 +271,7 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
 #pragma unroll
         for (int e = 0; e < P; e++) {
           mag[e] = sqrtf(v[e].x * v[e].x + v[e].y * v[e].y); /* SPEC:182 */
-          int k = bin_of_pos<N, P>(tid * P + e);
-          if (k >= p.vad_lo && k <= p.vad_hi) part += mag[e]; /* SPEC:194-197 */
+          part += ((vadbits >> e) & 1u) ? mag[e] : 0.f;       /* SPEC:194-197 */
         }
         float tot = wave_sum(part);
         if constexpr (NW > 1) {
@@ -263,15 +293,15 @@ __global__ void __launch_bounds__(N / P) rdsp_front_kernel(RdspFrontParams p) {
           v[e].y *= sc;
         }
       }
-      /* CONV:301: spectrum x mask (mask/N, digit-reversed, thread-major) */
+      /* CONV:301: spectrum x mask */
 #pragma unroll
-      for (int e = 0; e < P; e++) v[e] = cmul(v[e], p.maskp[e * NT + tid]);
+      for (int e = 0; e < P; e++) v[e] = cmul(v[e], mreg[e]);
 
-      inv_pass_last<N, P>(tid, v, wb); /* CONV:309 */
+      inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
       __syncthreads();
-      inv_mid_all<N, P, PL::NP - 2>(tid, wb, tw, sync);
-      inv_pass0_load<N, P>(tid, v, wb, tw);
-      __syncthreads(); /* wb is free again (next frame / next chunk's FIR) */
+      inv_mid_all<N, P, PL::NP - 2>(lb, wb, tw, sync);
+      inv_pass0_load<N, P>(lb, v, wb, tw);
+      __syncthreads(); /* wb is free again (next frame / taps / FIR partials) */
 
       /* CONV:314-318: keep the second half.  v[PH + jj] = y[N/2 + tid + jj*NT] */
       float L[PH], R[PH];

@@ -25,23 +25,25 @@ double check() {
   }
   static float2 tw[NT][PL::NTW][P - 1];
   for (int t = 0; t < NT; t++) make_twiddles<N, P>(t, tw[t]);
+  static LdsBases<N, P> lb[NT];
+  for (int t = 0; t < NT; t++) make_lds_bases<N, P>(t, lb[t]);
   auto nosync = []() {};
   // forward pass 0
   for (int t = 0; t < NT; t++) {
     float2 v[P];
     for (int j = 0; j < P; j++) v[j] = x[t + j * NT];
-    fwd_pass0_store<N, P>(t, v, wb.data(), tw[t]);
+    fwd_pass0_store<N, P>(lb[t], v, wb.data(), tw[t]);
   }
   // middle passes: must be emulated pass by pass over all threads
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1>(t, wb.data(), tw[t]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2>(t, wb.data(), tw[t]);
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3>(t, wb.data(), tw[t]);
+  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t]);
+  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t]);
+  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t]);
   static_assert(PL::NP <= 5, "extend harness");
   std::vector<float2> spec(N);
   double emax = 0, xmax = 0;
   for (int t = 0; t < NT; t++) {
     float2 v[P];
-    fwd_pass_last<N, P>(t, v, wb.data());
+    fwd_pass_last<N, P>(lb[t], v, wb.data());
     for (int e = 0; e < P; e++) {
       int pos = t * P + e, k = bin_of_pos<N, P>(pos);
       spec[pos] = v[e];
@@ -55,15 +57,15 @@ double check() {
   for (int t = 0; t < NT; t++) {
     float2 v[P];
     for (int e = 0; e < P; e++) v[e] = spec[t * P + e];
-    inv_pass_last<N, P>(t, v, wb.data());
+    inv_pass_last<N, P>(lb[t], v, wb.data());
   }
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3>(t, wb.data(), tw[t]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2>(t, wb.data(), tw[t]);
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1>(t, wb.data(), tw[t]);
+  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t]);
+  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t]);
+  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t]);
   double imax = 0;
   for (int t = 0; t < NT; t++) {
     float2 v[P];
-    inv_pass0_load<N, P>(t, v, wb.data(), tw[t]);
+    inv_pass0_load<N, P>(lb[t], v, wb.data(), tw[t]);
     for (int j = 0; j < P; j++) {
       int n = t + j * NT;
       double d = std::hypot(v[j].x / (double)N - x[n].x, v[j].y / (double)N - x[n].y);

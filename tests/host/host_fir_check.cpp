@@ -20,8 +20,8 @@ int main() {
     for (int n = 0; n < 1024; n++) xs[xs_pos(n)] = x[256 + chunk * 1024 + n];
     for (int l = 0; l < 64; l++) {
       float2 acc[4] = {};
-      fir_lane(l, 0, 2, xs.data(), hc.data(), acc);   // split like the 4-wave variant
-      fir_lane(l, 2, 4, xs.data(), hc.data(), acc);
+      fir_lane(l, 0, 2, xs.data(), reinterpret_cast<const float4 *>(hc.data()), acc);   // split like the 4-wave variant
+      fir_lane(l, 2, 4, xs.data(), reinterpret_cast<const float4 *>(hc.data()), acc);
       for (int r = 0; r < 4; r++) {
         int m = 4 * l + r;
         double sr = 0, si = 0;
@@ -50,6 +50,15 @@ int main() {
     pw = fmax(pw, fmax(fabs(p.x - cos(th)), fabs(p.y + sin(th))));
   }
   printf("nco max abs err %.3e\n", pw);
+  double pa = 0;
+  for (int i = 0; i < 400000; i++) {
+    uint32_t ph = (uint32_t)rand() * 2654435761u + (uint32_t)i * 7919u;
+    float2 p = nco_phasor_alu(ph);
+    double th = 2 * M_PI * ph / 4294967296.0;
+    pa = fmax(pa, fmax(fabs(p.x - cos(th)), fabs(p.y + sin(th))));
+  }
+  printf("nco alu max abs err %.3e\n", pa);
+  if (pa > 3e-7) { printf("FAIL\n"); return 1; }
   if (worst > 2e-5 || pw > 3e-7) { printf("FAIL\n"); return 1; }
   printf("OK\n");
   return 0;
