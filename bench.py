@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
     return ap.parse_args()
 
 
@@ -131,6 +132,7 @@ def main():
     gen_s = time.perf_counter() - t0
 
     chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, **cfg)
+    chain.set_pipelined(not args.no_pipeline)
 
     def barrier():
         torch.cuda.synchronize()
@@ -139,11 +141,13 @@ def main():
 
     for _ in range(args.warmup):
         chain.process(iq, out=out)
+    chain.flush()
     barrier()
     chain.set_timing(not args.no_kernel_timing)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         chain.process(iq, out=out)
+    chain.flush()  # every step's audio is complete inside the timed region
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -195,6 +199,7 @@ def main():
                 "channels_per_gpu": nch,
                 "blocks_per_step": nblk,
                 "sharding": f"channels x{world}, no collectives",
+                "pipelined": not args.no_pipeline,
             },
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
                           "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS},

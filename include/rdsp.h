@@ -165,6 +165,16 @@ int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of
 int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, GEN:111, CTL:237-297 */
 int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* SPEC:112 iNRLevel */
 
+/* ---- pipelined mode (streaming throughput) -------------------------------------
+ * The NLMS/AGC tail stage is serial in time, so its duration is set by the batch
+ * length, not by the channel count.  With pipelining on, the tail stage of call k
+ * runs on an internal stream concurrently with the front stage of call k+1 (the
+ * intermediate audio is double-buffered).  rdsp_chain_process then returns with
+ * the tail possibly still queued: d_out of a call is complete after the next
+ * rdsp_chain_flush(c, stream) on the consuming stream. */
+int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on);
+int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
+
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/
 int rdsp_chain_set_timing(rdsp_chain_t *c, int on);
 /* total milliseconds spent in the front and tail kernels over `calls` calls */
@@ -179,6 +189,57 @@ int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void 
 /* natural-order filter mask currently in use, float[2*fft_l] (CONV:77) */
 int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out);
 int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);
+
+/* ---- block graph: the AudioStream node/connection API --------------
+ * A block is a tile int16 [n_channels][128]; n_channels = 1 is the reference's
+ * audio_block_t (FFTIQ.cpp:44,67).  Host-side plumbing in plain C. */
+typedef struct rdsp_graph rdsp_graph_t;
+typedef struct rdsp_node rdsp_node_t;   /* AudioStream, FFTIQ.h:52-57 */
+typedef struct rdsp_block rdsp_block_t; /* audio_block_t */
+typedef void (*rdsp_update_fn)(rdsp_node_t *self, void *user); /* virtual void update(void), FFTIQ.h:98 */
+
+rdsp_graph_t *rdsp_graph_create(int n_channels);
+void rdsp_graph_destroy(rdsp_graph_t *g);
+int rdsp_graph_channels(const rdsp_graph_t *g);
+int rdsp_memory(rdsp_graph_t *g, int n_blocks);          /* AudioMemory(40), INO:151 */
+int rdsp_memory_usage(const rdsp_graph_t *g);            /* AudioMemoryUsage() */
+int rdsp_memory_usage_max(const rdsp_graph_t *g);
+/* AudioStream(ninputs, inputQueueArray), FFTIQ.h:55: nodes update in creation order */
+rdsp_node_t *rdsp_node_create(rdsp_graph_t *g, int ninputs, rdsp_update_fn update, void *user);
+void rdsp_node_set_destructor(rdsp_node_t *n, void (*fn)(void *));
+void *rdsp_node_user(rdsp_node_t *n);
+rdsp_graph_t *rdsp_node_graph(rdsp_node_t *n);
+/* AudioConnection c(src, srcPort, dst, dstPort), INO:71-89 (fan-out allowed) */
+int rdsp_connect(rdsp_node_t *src, int src_port, rdsp_node_t *dst, int dst_port);
+int rdsp_update_all(rdsp_graph_t *g);                    /* one audio-ISR tick */
+void rdsp_no_interrupts(rdsp_graph_t *g);                /* AudioNoInterrupts(), INO:152, CONV:211 */
+void rdsp_interrupts(rdsp_graph_t *g);                   /* AudioInterrupts(), INO:175, CONV:222 */
+/* inside update() */
+rdsp_block_t *rdsp_allocate(rdsp_node_t *n);
+rdsp_block_t *rdsp_receive_readonly(rdsp_node_t *n, int port); /* FFTIQ.cpp:70-71 */
+rdsp_block_t *rdsp_receive_writable(rdsp_node_t *n, int port);
+void rdsp_transmit(rdsp_node_t *n, rdsp_block_t *b, int port);
+void rdsp_release(rdsp_block_t *b);                            /* FFTIQ.cpp:114-115 */
+int16_t *rdsp_block_data(rdsp_block_t *b);
+int rdsp_block_refcount(const rdsp_block_t *b);
+/* AudioRecordQueue, CONV:205-206,231-244 */
+rdsp_node_t *rdsp_record_queue_create(rdsp_graph_t *g);
+void rdsp_record_queue_begin(rdsp_node_t *q);
+void rdsp_record_queue_end(rdsp_node_t *q);
+int rdsp_record_queue_available(const rdsp_node_t *q);
+int16_t *rdsp_record_queue_readBuffer(rdsp_node_t *q);
+void rdsp_record_queue_freeBuffer(rdsp_node_t *q);
+/* AudioPlayQueue, CONV:344-349 */
+rdsp_node_t *rdsp_play_queue_create(rdsp_graph_t *g);
+int16_t *rdsp_play_queue_getBuffer(rdsp_node_t *q);
+int rdsp_play_queue_playBuffer(rdsp_node_t *q);
+/* AudioInputI2S role (INO:52): port 0 = I tile, port 1 = Q tile of this tick */
+rdsp_node_t *rdsp_input_node_create(rdsp_graph_t *g);
+int rdsp_input_node_push(rdsp_node_t *n, const int16_t *i_tile, const int16_t *q_tile);
+/* AudioSDR engine node (INO:53-54,81-86): inputs I,Q; outputs L,R; runs `chain` */
+rdsp_node_t *rdsp_sdr_node_create(rdsp_graph_t *g, rdsp_chain_t *chain);
+int rdsp_sdr_node_status(rdsp_node_t *n);
+int rdsp_chain_decim(const rdsp_chain_t *c);
 
 /* ---- deterministic synthetic IQ generator (host) -------------------*/
 typedef struct {

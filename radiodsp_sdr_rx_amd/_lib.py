@@ -61,6 +61,8 @@ class SynthConfig(C.Structure):
 
 _lib = None
 
+UPDATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)  # rdsp_update_fn
+
 # every symbol include/rdsp.h declares: (name, restype, argtypes)
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 _f32p, _f64p, _i16p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int16)
@@ -104,12 +106,49 @@ SYMBOLS = [
     ("rdsp_sdr_setTuningOffsetHz", _i, [_vp, _d]),
     ("rdsp_set_nr_level", _i, [_vp, _i]),
     ("rdsp_set_spectral_nr", _i, [_vp, _i, _f]),
+    ("rdsp_chain_set_pipelined", _i, [_vp, _i]),
+    ("rdsp_chain_flush", _i, [_vp, _vp]),
     ("rdsp_chain_set_timing", _i, [_vp, _i]),
     ("rdsp_chain_get_timing", _i, [_vp, _f64p, _f64p, C.POINTER(C.c_int)]),
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
     ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
     ("rdsp_chain_get_mask", _i, [_vp, _f32p]),
     ("rdsp_chain_get_fir_taps", _i, [_vp, _f32p]),
+    ("rdsp_graph_create", _vp, [_i]),
+    ("rdsp_graph_destroy", None, [_vp]),
+    ("rdsp_graph_channels", _i, [_vp]),
+    ("rdsp_memory", _i, [_vp, _i]),
+    ("rdsp_memory_usage", _i, [_vp]),
+    ("rdsp_memory_usage_max", _i, [_vp]),
+    ("rdsp_node_create", _vp, [_vp, _i, UPDATE_FN, _vp]),
+    ("rdsp_node_set_destructor", None, [_vp, _vp]),
+    ("rdsp_node_user", _vp, [_vp]),
+    ("rdsp_node_graph", _vp, [_vp]),
+    ("rdsp_connect", _i, [_vp, _i, _vp, _i]),
+    ("rdsp_update_all", _i, [_vp]),
+    ("rdsp_no_interrupts", None, [_vp]),
+    ("rdsp_interrupts", None, [_vp]),
+    ("rdsp_allocate", _vp, [_vp]),
+    ("rdsp_receive_readonly", _vp, [_vp, _i]),
+    ("rdsp_receive_writable", _vp, [_vp, _i]),
+    ("rdsp_transmit", None, [_vp, _vp, _i]),
+    ("rdsp_release", None, [_vp]),
+    ("rdsp_block_data", _i16p, [_vp]),
+    ("rdsp_block_refcount", _i, [_vp]),
+    ("rdsp_record_queue_create", _vp, [_vp]),
+    ("rdsp_record_queue_begin", None, [_vp]),
+    ("rdsp_record_queue_end", None, [_vp]),
+    ("rdsp_record_queue_available", _i, [_vp]),
+    ("rdsp_record_queue_readBuffer", _i16p, [_vp]),
+    ("rdsp_record_queue_freeBuffer", None, [_vp]),
+    ("rdsp_play_queue_create", _vp, [_vp]),
+    ("rdsp_play_queue_getBuffer", _i16p, [_vp]),
+    ("rdsp_play_queue_playBuffer", _i, [_vp]),
+    ("rdsp_input_node_create", _vp, [_vp]),
+    ("rdsp_input_node_push", _i, [_vp, _i16p, _i16p]),
+    ("rdsp_sdr_node_create", _vp, [_vp, _vp]),
+    ("rdsp_sdr_node_status", _i, [_vp]),
+    ("rdsp_chain_decim", _i, [_vp]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
 

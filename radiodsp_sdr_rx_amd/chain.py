@@ -122,6 +122,13 @@ class Chain:
     def set_nr_level(self, lvl): _lib.check(self.lib.rdsp_set_nr_level(self.h, int(lvl)))
     def set_spectral_nr(self, on, level): _lib.check(self.lib.rdsp_set_spectral_nr(self.h, int(on), float(level)))
 
+    # ---- pipelined mode: tail of call k overlaps the front of call k+1 ------------
+    def set_pipelined(self, on):
+        _lib.check(self.lib.rdsp_chain_set_pipelined(self.h, int(bool(on))))
+
+    def flush(self, stream=None):
+        _lib.check(self.lib.rdsp_chain_flush(self.h, _stream_ptr(stream)))
+
     # ---- per-kernel timing (HIP events on the launch stream) -------------------
     def set_timing(self, on):
         _lib.check(self.lib.rdsp_chain_set_timing(self.h, int(bool(on))))

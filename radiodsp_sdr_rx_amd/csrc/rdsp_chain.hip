@@ -63,9 +63,16 @@ struct rdsp_chain {
   float *d_als_w = nullptr, *d_als_prev = nullptr, *d_als_energy = nullptr;
   float *d_mid = nullptr;
   size_t mid_stride = 0;
+  /* pipelined mode: the serial tail stage of call k runs on an internal stream,
+   * concurrently with the front stage of call k+1 (double-buffered intermediate) */
+  int pipe_on = 0;
+  hipStream_t s_tail = nullptr;
+  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_misc = nullptr;
+  float *d_mid2 = nullptr;
+  long call_idx = 0;
   /* optional per-kernel HIP-event timing (bench.py roofline leg) */
   int timing_on = 0;
-  std::vector<hipEvent_t> ev; /* pool, groups of 3: before front, after front, after tail */
+  std::vector<hipEvent_t> ev; /* pool, groups of 4: front begin/end, tail begin/end */
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
@@ -203,10 +210,18 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->s_tail) {
+    (void)hipStreamSynchronize(c->s_tail);
+    (void)hipStreamDestroy(c->s_tail);
+    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_front[i]); (void)hipEventDestroy(c->ev_tail[i]); }
+    (void)hipEventDestroy(c->ev_misc);
+    (void)hipFree(c->d_mid2);
+  }
   delete c;
 }
 
 extern "C" int rdsp_chain_channels(const rdsp_chain_t *c) { return c ? c->n_channels : 0; }
+extern "C" int rdsp_chain_decim(const rdsp_chain_t *c) { return c ? c->decim : 0; }
 
 extern "C" int rdsp_chain_granule_blocks(const rdsp_chain_t *c) {
   if (!c) return 0;
@@ -220,6 +235,8 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   const size_t nch = (size_t)c->n_channels;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
+  c->call_idx = 0;
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipMemset(c->d_hist, 0, sizeof(uint32_t) * 256 * nch));
   HIP_TRY(hipMemset(c->d_prev, 0, sizeof(float2) * c->hop * nch));
@@ -270,8 +287,13 @@ extern "C" int rdsp_Init_LMS_NR(rdsp_chain_t *c, int strength, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   c->nr_mu = rdsp_lms_mu(strength);
   const size_t nch = (size_t)c->n_channels;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail)); /* the tail stage owns these arrays */
   HIP_TRY(hipMemsetAsync(c->d_nr_prev, 0, sizeof(float) * RDSP_BLOCK * nch, stream));
   HIP_TRY(hipMemsetAsync(c->d_nr_energy, 0, sizeof(float) * nch, stream));
+  if (c->s_tail) {
+    HIP_TRY(hipEventRecord(c->ev_misc, stream));
+    HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_misc, 0));
+  }
   return RDSP_OK;
 }
 
@@ -354,12 +376,21 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
   fp.mid = c->d_mid;
   fp.mid_stride = c->mid_stride;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-  const bool timed = c->timing_on && 3 * (c->ev_used + 1) <= c->ev.size();
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  const bool timed = c->timing_on && 4 * (c->ev_used + 1) <= c->ev.size();
+  const bool piped = tail && c->pipe_on;
+  const int slot = (int)(c->call_idx & 1);
+  hipStream_t tstream = piped ? c->s_tail : stream;
+  if (piped) {
+    fp.mid = slot ? c->d_mid2 : c->d_mid;
+    /* the tail of call k-2 read this intermediate buffer: wait for it */
+    if (c->call_idx >= 2) HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[slot], 0));
+  }
   if (timed) { /* events come from a pool created in rdsp_chain_set_timing */
-    ev0 = c->ev[3 * c->ev_used];
-    ev1 = c->ev[3 * c->ev_used + 1];
-    ev2 = c->ev[3 * c->ev_used + 2];
+    ev0 = c->ev[4 * c->ev_used];
+    ev1 = c->ev[4 * c->ev_used + 1];
+    ev2 = c->ev[4 * c->ev_used + 2];
+    ev3 = c->ev[4 * c->ev_used + 3];
     HIP_TRY(hipEventRecord(ev0, stream));
   }
   int e = rdsp_launch_front(c->N, c->decim, &fp, c->n_channels, stream);
@@ -368,10 +399,14 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     rdsp_set_error("front kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return RDSP_ERR_HIP;
   }
+  if (piped) {
+    HIP_TRY(hipEventRecord(c->ev_front[slot], stream));
+    HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front[slot], 0));
+  }
   if (tail) {
     RdspTailParams tp;
     memset(&tp, 0, sizeof(tp));
-    tp.mid = c->d_mid;
+    tp.mid = fp.mid;
     tp.mid_stride = c->mid_stride;
     tp.n_channels = c->n_channels;
     tp.n_blocks = (int)(n_out / RDSP_BLOCK);
@@ -391,19 +426,22 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
-    e = rdsp_launch_tail(&tp, 16, stream);
+    if (timed) HIP_TRY(hipEventRecord(ev2, tstream));
+    e = rdsp_launch_tail(&tp, 16, tstream);
     if (e != 0) {
       rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
       return RDSP_ERR_HIP;
     }
+    if (timed) HIP_TRY(hipEventRecord(ev3, tstream));
+    if (piped) HIP_TRY(hipEventRecord(c->ev_tail[slot], c->s_tail));
     if (tp.nr_on) c->nr_calls += tp.n_blocks;
     if (tp.als_mode) c->als_calls += tp.n_blocks;
   }
   if (timed) {
-    HIP_TRY(hipEventRecord(ev2, stream));
     c->ev_has_tail[c->ev_used] = tail ? 1 : 0;
     c->ev_used++;
   }
+  c->call_idx++;
   c->n_in += n_in;
   return RDSP_OK;
 }
@@ -418,6 +456,7 @@ extern "C" int rdsp_LMS_NoiseReduction(rdsp_chain_t *c, int n_samples, float *d_
     return RDSP_ERR_INVALID;
   }
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   RdspTailParams tp;
   memset(&tp, 0, sizeof(tp));
   tp.mid = d_nrbuffer;
@@ -536,13 +575,47 @@ extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *strea
   return demod_tuning_offset(mode);
 }
 
+/* ---- pipelined mode ---------------------------------------------------------------- */
+/* everything queued on the internal tail stream has finished when this returns */
+static int drain_tail(rdsp_chain_t *c) {
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
+  return RDSP_OK;
+}
+extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
+  NEED(c);
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (on && !c->s_tail) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_tail, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&c->d_mid2, sizeof(float) * c->mid_stride * (size_t)c->n_channels));
+  }
+  c->pipe_on = on ? 1 : 0;
+  c->call_idx = 0;
+  return RDSP_OK;
+}
+/* `stream` waits for every call issued so far (outputs complete after it) */
+extern "C" int rdsp_chain_flush(rdsp_chain_t *c, void *stream) {
+  NEED(c);
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (c->pipe_on && c->call_idx > 0) {
+    const int last = (int)((c->call_idx - 1) & 1);
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ev_tail[last], 0));
+  }
+  return RDSP_OK;
+}
+
 /* ---- per-kernel timing with HIP events on the launch stream -------------------- */
 extern "C" int rdsp_chain_set_timing(rdsp_chain_t *c, int on) {
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   const size_t kMaxCalls = 1024; /* calls beyond the pool are simply not timed */
   if (on && c->ev.empty()) {
-    c->ev.resize(3 * kMaxCalls);
+    c->ev.resize(4 * kMaxCalls);
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_has_tail.assign(kMaxCalls, 0);
   }
@@ -557,12 +630,15 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
   double f = 0.0, t = 0.0;
   const size_t n = c->ev_used;
   for (size_t i = 0; i < n; i++) {
-    HIP_TRY(hipEventSynchronize(c->ev[3 * i + 2]));
     float a = 0.f, b = 0.f;
-    HIP_TRY(hipEventElapsedTime(&a, c->ev[3 * i], c->ev[3 * i + 1]));
-    HIP_TRY(hipEventElapsedTime(&b, c->ev[3 * i + 1], c->ev[3 * i + 2]));
+    HIP_TRY(hipEventSynchronize(c->ev[4 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[4 * i], c->ev[4 * i + 1]));
     f += a;
-    if (c->ev_has_tail[i]) t += b;
+    if (c->ev_has_tail[i]) {
+      HIP_TRY(hipEventSynchronize(c->ev[4 * i + 3]));
+      HIP_TRY(hipEventElapsedTime(&b, c->ev[4 * i + 2], c->ev[4 * i + 3]));
+      t += b;
+    }
   }
   if (front_ms) *front_ms = f;
   if (tail_ms) *tail_ms = t;
@@ -574,6 +650,7 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
 extern "C" int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream) {
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   HIP_TRY(hipMemcpy(host_out, c->d_scal, sizeof(float) * 4 * (size_t)c->n_channels, hipMemcpyDeviceToHost));
   return RDSP_OK;
@@ -581,6 +658,7 @@ extern "C" int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *st
 extern "C" int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void *stream) {
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   HIP_TRY(hipMemcpy(host_out, which ? c->d_als_w : c->d_nr_w,
                     sizeof(float) * RDSP_LMS_TAPS * (size_t)c->n_channels, hipMemcpyDeviceToHost));

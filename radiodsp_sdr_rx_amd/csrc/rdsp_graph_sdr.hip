@@ -1,0 +1,143 @@
+/*
+ * rdsp_graph_sdr.hip -- the SDR engine node of the block graph: the role of
+ * `AudioSDR SDR;` (+ the convolutional stage that loop() runs between the record
+ * and play queues) in RadioDSP_SDR_RX.ino:53-54,81-89.  Two inputs (I, Q tiles),
+ * two outputs (L, R tiles).  update() gathers input tiles until the chain's
+ * granule is available (the `available() > N_BLOCKS` gate of
+ * RDSP_convolutional.h:231), runs the GPU chain on them and hands the audio out
+ * one 128-sample tile pair per tick.  Every compute step is rdsp_chain_process;
+ * there is no host DSP here.
+ */
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <deque>
+#include <vector>
+
+#include "rdsp_host.h"
+
+namespace {
+struct SdrNode {
+  rdsp_chain_t *chain;
+  int n_channels, gran, decim;
+  int have; /* input blocks staged */
+  std::vector<int16_t> h_iq;  /* [ch][gran*128][2] */
+  std::vector<int16_t> h_out; /* [ch][gran*128/decim][2] */
+  int16_t *d_iq = nullptr, *d_out = nullptr;
+  hipStream_t stream = nullptr;
+  std::deque<std::vector<int16_t>> out_l, out_r; /* audio tiles waiting for a tick */
+  int status = RDSP_OK;
+};
+
+void sdr_destroy(void *u) {
+  SdrNode *s = static_cast<SdrNode *>(u);
+  if (s->d_iq) (void)hipFree(s->d_iq);
+  if (s->d_out) (void)hipFree(s->d_out);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+void sdr_update(rdsp_node_t *n, void *u) {
+  SdrNode *s = static_cast<SdrNode *>(u);
+  rdsp_block_t *bi = rdsp_receive_readonly(n, 0);
+  rdsp_block_t *bq = rdsp_receive_readonly(n, 1);
+  if (bi && bq) {
+    const int16_t *pi = rdsp_block_data(bi), *pq = rdsp_block_data(bq);
+    const size_t row = (size_t)s->gran * RDSP_BLOCK_SAMPLES;
+    for (int c = 0; c < s->n_channels; c++) {
+      int16_t *dst = &s->h_iq[((size_t)c * row + (size_t)s->have * RDSP_BLOCK_SAMPLES) * 2];
+      const int16_t *si = pi + (size_t)c * RDSP_BLOCK_SAMPLES, *sq = pq + (size_t)c * RDSP_BLOCK_SAMPLES;
+      for (int i = 0; i < RDSP_BLOCK_SAMPLES; i++) {
+        dst[2 * i] = si[i];
+        dst[2 * i + 1] = sq[i];
+      }
+    }
+    s->have++;
+  }
+  rdsp_release(bi); /* a lone I or Q block is dropped, like a node returning early */
+  rdsp_release(bq);
+
+  if (s->have == s->gran) {
+    const size_t in_row = (size_t)s->gran * RDSP_BLOCK_SAMPLES;
+    const size_t out_row = in_row / (size_t)s->decim;
+    hipError_t e = hipMemcpyAsync(s->d_iq, s->h_iq.data(), s->h_iq.size() * sizeof(int16_t),
+                                  hipMemcpyHostToDevice, s->stream);
+    int rc = RDSP_OK;
+    if (e == hipSuccess)
+      rc = rdsp_chain_process(s->chain, s->d_iq, in_row, s->gran, s->d_out, out_row, nullptr, s->stream);
+    if (e == hipSuccess && rc == RDSP_OK)
+      e = hipMemcpyAsync(s->h_out.data(), s->d_out, s->h_out.size() * sizeof(int16_t),
+                         hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && rc == RDSP_OK) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess || rc != RDSP_OK) {
+      s->status = (rc != RDSP_OK) ? rc : RDSP_ERR_HIP;
+      if (e != hipSuccess) rdsp_set_error("sdr node: %s", hipGetErrorString(e));
+    } else {
+      const int n_tiles = (int)(out_row / RDSP_BLOCK_SAMPLES);
+      for (int t = 0; t < n_tiles; t++) {
+        std::vector<int16_t> L((size_t)s->n_channels * RDSP_BLOCK_SAMPLES), R(L.size());
+        for (int c = 0; c < s->n_channels; c++) {
+          const int16_t *src = &s->h_out[((size_t)c * out_row + (size_t)t * RDSP_BLOCK_SAMPLES) * 2];
+          for (int i = 0; i < RDSP_BLOCK_SAMPLES; i++) {
+            L[(size_t)c * RDSP_BLOCK_SAMPLES + i] = src[2 * i];
+            R[(size_t)c * RDSP_BLOCK_SAMPLES + i] = src[2 * i + 1];
+          }
+        }
+        s->out_l.push_back(std::move(L));
+        s->out_r.push_back(std::move(R));
+      }
+    }
+    s->have = 0;
+  }
+
+  if (!s->out_l.empty()) {
+    rdsp_block_t *bl = rdsp_allocate(n), *br = rdsp_allocate(n);
+    if (bl && br) {
+      memcpy(rdsp_block_data(bl), s->out_l.front().data(), s->out_l.front().size() * sizeof(int16_t));
+      memcpy(rdsp_block_data(br), s->out_r.front().data(), s->out_r.front().size() * sizeof(int16_t));
+      s->out_l.pop_front();
+      s->out_r.pop_front();
+      rdsp_transmit(n, bl, 0);
+      rdsp_transmit(n, br, 1);
+    }
+    rdsp_release(bl);
+    rdsp_release(br);
+  }
+}
+}  // namespace
+
+extern "C" rdsp_node_t *rdsp_sdr_node_create(rdsp_graph_t *g, rdsp_chain_t *chain) {
+  if (!g || !chain || rdsp_graph_channels(g) != rdsp_chain_channels(chain)) {
+    rdsp_set_error("rdsp_sdr_node_create: graph and chain must have the same channel count");
+    return nullptr;
+  }
+  SdrNode *s = new SdrNode();
+  s->chain = chain;
+  s->n_channels = rdsp_chain_channels(chain);
+  s->gran = rdsp_chain_granule_blocks(chain);
+  s->decim = rdsp_chain_decim(chain);
+  s->have = 0;
+  const size_t in_n = (size_t)s->n_channels * s->gran * RDSP_BLOCK_SAMPLES * 2;
+  s->h_iq.assign(in_n, 0);
+  s->h_out.assign(in_n / s->decim, 0);
+  if (hipMalloc((void **)&s->d_iq, in_n * sizeof(int16_t)) != hipSuccess ||
+      hipMalloc((void **)&s->d_out, in_n / s->decim * sizeof(int16_t)) != hipSuccess ||
+      hipStreamCreate(&s->stream) != hipSuccess) {
+    rdsp_set_error("rdsp_sdr_node_create: device allocation failed");
+    sdr_destroy(s);
+    return nullptr;
+  }
+  rdsp_node_t *n = rdsp_node_create(g, 2, sdr_update, s);
+  if (!n) {
+    sdr_destroy(s);
+    return nullptr;
+  }
+  rdsp_node_set_destructor(n, sdr_destroy);
+  return n;
+}
+
+extern "C" int rdsp_sdr_node_status(rdsp_node_t *n) {
+  SdrNode *s = static_cast<SdrNode *>(rdsp_node_user(n));
+  return s ? s->status : RDSP_ERR_INVALID;
+}

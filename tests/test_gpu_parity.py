@@ -250,6 +250,30 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
 
 
+def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
+    """rdsp_chain_set_pipelined: the tail stage of call k overlaps the front stage of
+    call k+1 on an internal stream; results must not change by a bit."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, nblk, calls = 64, 32, 6
+    iq = synth_iq(nch, nblk * 128 * calls)
+    parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
+             for k in range(calls)]
+    ref_chain = Chain(nch, max_blocks_per_call=nblk, **K3)
+    ref = [ref_chain.process(p).cpu().numpy() for p in parts]
+    ch = Chain(nch, max_blocks_per_call=nblk, **K3)
+    ch.set_pipelined(True)
+    outs = [torch.empty((nch, nblk * 32, 2), dtype=torch.int16, device="cuda") for _ in range(calls)]
+    for p, o in zip(parts, outs):
+        ch.process(p, out=o)
+    ch.flush()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, outs):
+        assert np.array_equal(a, b.cpu().numpy())
+    assert np.array_equal(ref_chain.scalars(), ch.scalars())
+    assert np.array_equal(ref_chain.lms_coeffs(1), ch.lms_coeffs(1))
+
+
 def test_channel_partition_invariance(rdsp, torch_cuda):
     """Multi-GPU sharding contract: a channel's output does not depend on
     which shard / position it is processed at -- bitwise."""

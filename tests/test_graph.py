@@ -1,0 +1,161 @@
+"""Block-graph runtime (csrc/rdsp_graph.c): the AudioStream semantics the reference
+relies on, tested on the CPU with pure-plumbing nodes; the SDR engine node that runs
+the GPU chain is tested under -m gpu with the K1 configuration (1 channel, 96 kHz IQ,
+128-sample blocks, USB, NR/notch off) wired like RadioDSP_SDR_RX.ino:71-89."""
+import numpy as np
+import pytest
+
+from cases import K1
+
+
+def test_wiring_fanout_refcounts_and_update_order(rdsp):
+    from radiodsp_sdr_rx_amd.graph import Graph
+    g = Graph(n_channels=2)
+    g.AudioMemory(8)
+    order = []
+    src = g.input_node()                      # IQinput
+
+    def pre_update(n):                        # preProcessor: pass-through, 2 in / 2 out
+        order.append("pre")
+        bi, bq = n.receiveReadOnly(0), n.receiveReadOnly(1)
+        if bi is None or bq is None:          # FFTIQ.cpp:72: silent early return
+            n.release(bi); n.release(bq)
+            return
+        n.transmit(bi, 0); n.transmit(bq, 1)
+        n.release(bi); n.release(bq)
+
+    pre = g.node(2, pre_update)
+    seen = {}
+
+    def tap_update(n):                        # second consumer of IQinput port 0 (fan-out, INO:71,75)
+        order.append("tap")
+        b = n.receiveReadOnly(0)
+        if b is not None:
+            seen["ref"] = b.refcount()
+            seen["val"] = int(b.data()[1, 5])
+            n.release(b)
+
+    tap = g.node(1, tap_update)
+    ql, qr = g.record_queue(), g.record_queue()
+    g.AudioConnection(src, 0, pre, 0)
+    g.AudioConnection(src, 1, pre, 1)
+    g.AudioConnection(src, 0, tap, 0)         # fan-out of port 0
+    g.AudioConnection(pre, 0, ql, 0)
+    g.AudioConnection(pre, 1, qr, 0)
+    ql.begin(); qr.begin()
+    for t in range(3):
+        i = np.full((2, 128), 10 * t, np.int16); i[1, 5] = 77 + t
+        q = np.full((2, 128), -t, np.int16)
+        src.push(i, q)
+        assert g.update_all() == 0
+    assert order[:2] == ["pre", "tap"]        # creation order
+    assert seen["val"] == 79
+    assert ql.available() == 3 and qr.available() == 3
+    b0 = ql.readBuffer()
+    assert b0[0, 0] == 0 and b0[1, 5] == 77
+    assert ql.readBuffer() is None            # one user block at a time until freeBuffer
+    ql.freeBuffer()
+    assert ql.readBuffer()[0, 0] == 10
+    ql.freeBuffer()
+    assert qr.readBuffer()[0, 0] == 0
+    qr.freeBuffer()
+    used, peak = g.memory_usage()
+    assert used == 3 and peak <= 8            # 1 left in ql, 2 in qr
+    # a tick with no capture: nodes see no input and return early
+    assert g.update_all() == 0 and ql.available() == 1
+
+
+def test_pool_exhaustion_and_queue_gate(rdsp):
+    from radiodsp_sdr_rx_amd.graph import Graph
+    g = Graph(1)
+    g.AudioMemory(4)
+    src = g.input_node()
+    q = g.record_queue()
+    g.AudioConnection(src, 0, q, 0)
+    q.begin()
+    z = np.zeros((1, 128), np.int16)
+    for _ in range(6):
+        src.push(z, z)
+        g.update_all()
+    # 4 blocks in the pool; each tick needs 2 (I and Q): after two ticks the pool holds
+    # 2 queued I blocks and the Q blocks were freed; later allocations succeed until empty
+    assert q.available() <= 4 and g.memory_usage()[0] <= 4
+    # `available() > N_BLOCKS` (CONV:231) is a strict gate: N_BLOCKS+1 must be queued
+    n_blocks = 1
+    assert (q.available() > n_blocks) == (q.available() >= 2)
+
+
+def test_play_queue_and_interrupt_gate(rdsp):
+    from radiodsp_sdr_rx_amd.graph import Graph
+    g = Graph(1)
+    g.AudioMemory(6)
+    pq = g.play_queue()                       # Q_out_L
+    got = []
+
+    def sink_update(n):                       # audio_out
+        b = n.receiveReadOnly(0)
+        if b is not None:
+            got.append(b.data().copy())
+            n.release(b)
+
+    sink = g.node(1, sink_update)
+    fft = g.node(1, sink_update)              # AudioFFT also listens to Q_out_L (INO:87-88)
+    g.AudioConnection(pq, 0, fft, 0)
+    g.AudioConnection(pq, 0, sink, 0)
+    buf = pq.getBuffer()
+    buf[:] = 123
+    assert pq.playBuffer() == 0
+    g.AudioNoInterrupts()                     # CONV:211: the ISR is held off
+    assert g.update_all() != 0 and not got
+    g.AudioInterrupts()
+    assert g.update_all() == 0
+    assert len(got) == 2 and (got[0] == 123).all()
+    assert g.memory_usage()[0] == 0
+
+
+@pytest.mark.gpu
+def test_k1_one_channel_through_the_graph_matches_oracle(rdsp, oracle):
+    """BASELINE config K1 through the update()/connect() API with the GPU engine node."""
+    import torch
+    assert torch.cuda.is_available()
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.graph import Graph
+    nblk = 64
+    iq = synth_iq(1, nblk * 128)
+    chain = Chain(1, max_blocks_per_call=8, **K1)
+    g = Graph(1)
+    g.AudioMemory(40)                          # INO:151
+    IQinput = g.input_node()                   # INO:52
+
+    def pre_update(n):                         # AudioSDRpreProcessor: pass-through here
+        bi, bq = n.receiveReadOnly(0), n.receiveReadOnly(1)
+        if bi is not None and bq is not None:
+            n.transmit(bi, 0); n.transmit(bq, 1)
+        n.release(bi); n.release(bq)
+
+    preProcessor = g.node(2, pre_update)       # INO:53
+    SDR = g.sdr_node(chain)                    # INO:54
+    Q_in_L, Q_in_R = g.record_queue(), g.record_queue()   # INO:63-64
+    g.AudioConnection(IQinput, 0, preProcessor, 0)        # c1
+    g.AudioConnection(IQinput, 1, preProcessor, 1)        # c2
+    g.AudioConnection(preProcessor, 0, SDR, 0)            # a3
+    g.AudioConnection(preProcessor, 1, SDR, 1)            # a4
+    g.AudioConnection(SDR, 0, Q_in_L, 0)                  # c5
+    g.AudioConnection(SDR, 1, Q_in_R, 0)                  # c6
+    Q_in_L.begin(); Q_in_R.begin()                        # CONV:205-206
+    L, R = [], []
+    for b in range(nblk + 8):                  # a few extra ticks drain the engine's output fifo
+        if b < nblk:
+            blk = iq[0, b * 128:(b + 1) * 128]
+            IQinput.push(blk[None, :, 0], blk[None, :, 1])
+        assert g.update_all() == 0
+        while Q_in_L.available() > 0 and Q_in_R.available() > 0:
+            L.append(Q_in_L.readBuffer()[0].copy()); Q_in_L.freeBuffer()
+            R.append(Q_in_R.readBuffer()[0].copy()); Q_in_R.freeBuffer()
+    assert SDR.status() == 0
+    L, R = np.concatenate(L), np.concatenate(R)
+    r16, _ = oracle.OracleChain(**K1).process(iq[0])
+    assert len(L) == len(r16) == nblk * 128 // 4
+    d = np.abs(np.stack([L, R], 1).astype(np.int32) - r16.astype(np.int32))
+    assert d.max() <= 1
+    assert g.memory_usage()[1] <= 40
