@@ -210,6 +210,50 @@ RDSP_HD void make_twiddles(int t, float2 (*tw)[P - 1]) {
   }
 }
 
+/* Twiddles of one pass from their base w1 = w^o by a short product chain
+ * (w2 = w1^2, w3 = w2 w1, w4 = w2^2, w5 = w4 w1, w6 = w3^2, w7 = w4 w3, ...): at most
+ * 4 roundings deep for k <= 15, ~2e-7.  Keeps one float2 per pass in registers
+ * instead of P-1 (the kernel trades ~6 complex multiplies per pass for 24 VGPRs). */
+template <int P>
+RDSP_HD void twiddle_chain(float2 w1, float2 *tw /* [P-1]: w^1 .. w^(P-1) */) {
+  tw[0] = w1;
+  if constexpr (P >= 4) {
+    tw[1] = cmul(w1, w1);
+    tw[2] = cmul(tw[1], w1);
+  }
+  if constexpr (P >= 8) {
+    tw[3] = cmul(tw[1], tw[1]);
+    tw[4] = cmul(tw[3], w1);
+    tw[5] = cmul(tw[2], tw[2]);
+    tw[6] = cmul(tw[3], tw[2]);
+  }
+  if constexpr (P >= 16) {
+    tw[7] = cmul(tw[3], tw[3]);
+#pragma unroll
+    for (int k = 9; k <= 15; k++) tw[k - 1] = cmul(tw[7], tw[k - 9]);
+  }
+}
+
+/* base twiddle of every twiddled pass: w1[p] = exp(-2*pi*i * o / (P*s_p)) */
+template <int N, int P>
+RDSP_HD void make_twiddle_bases(int t, float2 *w1) {
+  using PL = FftPlan<N, P>;
+#pragma unroll
+  for (int p = 0; p < PL::NTW; p++) {
+    const int s = PL::span(p);
+    const int S = P * s;
+    int o = t % s;
+#ifdef __HIP_DEVICE_COMPILE__
+    float sn, cs;
+    sincospif(-2.0f * (float)o / (float)S, &sn, &cs);
+    w1[p] = make_float2(cs, sn);
+#else
+    double a = -2.0 * 3.14159265358979323846 * (double)o / (double)S;
+    w1[p] = make_float2((float)cos(a), (float)sin(a));
+#endif
+  }
+}
+
 /* LDS addressing.  A thread touches, in pass p, the positions base_p + j*s_p
  * (j = 0..P-1); through the padded map phi(i) = i + i/P that is
  *     phi(base_p) + j*s_p + (j*s_p)/P        (s_p and P are powers of two, so
@@ -239,19 +283,18 @@ constexpr int phi_off(int j, int s) { return j * s + (j * s) / P; }
 /* ---- forward ------------------------------------------------------------- */
 /* pass 0: v[] already loaded with x[t + j*NT] (j = 0..P-1) */
 template <int N, int P>
-RDSP_HD void fwd_pass0_store(const LdsBases<N, P> &lb, float2 *v, float2 *wb,
-                             const float2 (*tw)[P - 1]) {
+RDSP_HD void fwd_pass0_store(const LdsBases<N, P> &lb, float2 *v, float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
   Dft<P, false>::run(v);
 #pragma unroll
-  for (int k = 1; k < P; k++) v[k] = cmul(v[k], tw[0][k - 1]);
+  for (int k = 1; k < P; k++) v[k] = cmul(v[k], twp[k - 1]);
 #pragma unroll
   for (int j = 0; j < P; j++) wb[lb.b[0] + phi_off<P>(j, PL::span(0))] = v[j];
 }
 
 /* middle pass p (1 <= p <= NP-2), in place */
 template <int N, int P, int PIDX>
-RDSP_HD void fwd_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1]) {
+RDSP_HD void fwd_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
   constexpr int s = PL::span(PIDX);
   float2 v[P];
@@ -259,7 +302,7 @@ RDSP_HD void fwd_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 (*t
   for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + phi_off<P>(j, s)];
   Dft<P, false>::run(v);
 #pragma unroll
-  for (int k = 1; k < P; k++) v[k] = cmul(v[k], tw[PIDX][k - 1]);
+  for (int k = 1; k < P; k++) v[k] = cmul(v[k], twp[k - 1]);
 #pragma unroll
   for (int j = 0; j < P; j++) wb[lb.b[PIDX] + phi_off<P>(j, s)] = v[j];
 }
@@ -285,14 +328,14 @@ RDSP_HD void inv_pass_last(const LdsBases<N, P> &lb, float2 *v, float2 *wb) {
 }
 
 template <int N, int P, int PIDX>
-RDSP_HD void inv_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1]) {
+RDSP_HD void inv_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
   constexpr int s = PL::span(PIDX);
   float2 v[P];
 #pragma unroll
   for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + phi_off<P>(j, s)];
 #pragma unroll
-  for (int k = 1; k < P; k++) v[k] = cmulc(v[k], tw[PIDX][k - 1]);
+  for (int k = 1; k < P; k++) v[k] = cmulc(v[k], twp[k - 1]);
   Dft<P, true>::run(v);
 #pragma unroll
   for (int j = 0; j < P; j++) wb[lb.b[PIDX] + phi_off<P>(j, s)] = v[j];
@@ -300,29 +343,64 @@ RDSP_HD void inv_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 (*t
 
 /* pass 0 inverse: result v[j] = y[t + j*NT] */
 template <int N, int P>
-RDSP_HD void inv_pass0_load(const LdsBases<N, P> &lb, float2 *v, const float2 *wb,
-                            const float2 (*tw)[P - 1]) {
+RDSP_HD void inv_pass0_load(const LdsBases<N, P> &lb, float2 *v, const float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
 #pragma unroll
   for (int j = 0; j < P; j++) v[j] = wb[lb.b[0] + phi_off<P>(j, PL::span(0))];
 #pragma unroll
-  for (int k = 1; k < P; k++) v[k] = cmulc(v[k], tw[0][k - 1]);
+  for (int k = 1; k < P; k++) v[k] = cmulc(v[k], twp[k - 1]);
   Dft<P, true>::run(v);
 }
 
+/* Twiddle storage of a thread.  CHAIN = false: all P-1 twiddles of every pass
+ * in registers.  CHAIN = true: one base per pass, the rest regenerated by
+ * twiddle_chain() right before the pass uses them. */
+template <int N, int P, bool CHAIN>
+struct Twiddles;
+
+template <int N, int P>
+struct Twiddles<N, P, false> {
+  float2 tw[FftPlan<N, P>::NTW][P - 1];
+  RDSP_HD void init(int t) { make_twiddles<N, P>(t, tw); }
+  template <int PIDX>
+  RDSP_HD void get(float2 *out) const {
+#pragma unroll
+    for (int k = 0; k < P - 1; k++) out[k] = tw[PIDX][k];
+  }
+};
+template <int N, int P>
+struct Twiddles<N, P, true> {
+  float2 w1[FftPlan<N, P>::NTW];
+  RDSP_HD void init(int t) { make_twiddle_bases<N, P>(t, w1); }
+  template <int PIDX>
+  RDSP_HD void get(float2 *out) const {
+    float2 b = w1[PIDX];
+#ifdef __HIP_DEVICE_COMPILE__
+    /* opaque copy: stops loop-invariant code motion from hoisting the whole chain
+     * out of the chunk loop (which would put all P-1 twiddles back in registers) */
+    asm volatile("" : "+v"(b.x), "+v"(b.y));
+#endif
+    twiddle_chain<P>(b, out);
+  }
+};
+
 /* compile-time loops over the middle passes */
-template <int N, int P, int PIDX, int PEND, typename SYNC>
-RDSP_HD void fwd_mid_all(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
+template <int N, int P, int PIDX, int PEND, typename TW, typename SYNC>
+RDSP_HD void fwd_mid_all(const LdsBases<N, P> &lb, float2 *wb, const TW &tw, SYNC sync) {
   if constexpr (PIDX < PEND) {
-    fwd_pass_mid<N, P, PIDX>(lb, wb, tw);
+    float2 twp[P - 1];
+    tw.template get<PIDX>(twp);
+    fwd_pass_mid<N, P, PIDX>(lb, wb, twp);
     sync();
     fwd_mid_all<N, P, PIDX + 1, PEND>(lb, wb, tw, sync);
   }
 }
-template <int N, int P, int PIDX, typename SYNC>
-RDSP_HD void inv_mid_all(const LdsBases<N, P> &lb, float2 *wb, const float2 (*tw)[P - 1], SYNC sync) {
+template <int N, int P, int PIDX, typename TW, typename SYNC>
+RDSP_HD void inv_mid_all(const LdsBases<N, P> &lb, float2 *wb, const TW &tw, SYNC sync) {
   if constexpr (PIDX >= 1) {
-    inv_pass_mid<N, P, PIDX>(lb, wb, tw);
+    float2 twp[P - 1];
+    tw.template get<PIDX>(twp);
+    inv_pass_mid<N, P, PIDX>(lb, wb, twp);
     sync();
     inv_mid_all<N, P, PIDX - 1>(lb, wb, tw, sync);
   }

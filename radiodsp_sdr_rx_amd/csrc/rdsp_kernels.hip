@@ -63,8 +63,10 @@ __device__ __forceinline__ uint32_t pack_lr(float l, float r) {
 }
 
 /* ---- front kernel -------------------------------------------------------- */
+/* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
+ * mask slice re-read per chunk); it pays when it buys a wave per SIMD (radix 16). */
 template <int N, int P, int DECIM>
-__global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(RdspFrontParams p) {
+__global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
   constexpr int NW = NT / 64;
@@ -81,6 +83,7 @@ __global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(Rd
   /* the decimator taps live in the FFT work buffer while the FIR runs (the
    * buffer is idle then); with four waves the first 8 KiB hold the partial sums */
   constexpr int TAPS_OFF = (NW == 1) ? 0 : 4 * CH_OUT; /* float2 units */
+  constexpr bool LEAN = (P == 16);
   static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
   static_assert(NT == 64 || NT == 256, "one or four waves per channel");
   static_assert(PL::WB >= TAPS_OFF + 128, "work buffer holds the taps");
@@ -109,13 +112,10 @@ __global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(Rd
   /* per-thread constants that stay in registers for the whole launch: FFT
    * twiddles, LDS bases of every pass, this thread's slice of the filter mask
    * (digit-reversed, /N), its VAD-bin membership bits and its four taps */
-  float2 tw[PL::NTW][P - 1];
-  make_twiddles<N, P>(tid, tw);
+  Twiddles<N, P, LEAN> tw;
+  tw.init(tid);
   LdsBases<N, P> lb;
   make_lds_bases<N, P>(tid, lb);
-  float2 mreg[P];
-#pragma unroll
-  for (int e = 0; e < P; e++) mreg[e] = p.maskp[e * NT + tid];
   uint32_t vadbits = 0;
 #pragma unroll
   for (int e = 0; e < P; e++) {
@@ -160,6 +160,17 @@ __global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(Rd
      * One accurate phasor per thread per chunk (ALU only: no memory traffic in
      * the loop besides the IQ stream); the other samples of the thread follow
      * by constant rotations (k*4*NT samples between passes, 1..3 inside one). */
+    /* this thread's slice of the mask (digit-reversed, /N, thread-major): L2-resident,
+     * requested at the top of the chunk and consumed after the forward transform, so
+     * its latency hides behind the FIR.  The pointer is made opaque so the loads are
+     * not hoisted out of the chunk loop into 2P persistent registers. */
+    float2 mreg[P];
+    {
+      const float2 *mp = p.maskp;
+      if constexpr (LEAN) asm volatile("" : "+s"(mp));
+#pragma unroll
+      for (int e = 0; e < P; e++) mreg[e] = mp[e * NT + tid];
+    }
     float2 ph_base = make_float2(1.f, 0.f);
     if (p.dphi != 0u)
       ph_base = nco_phasor_alu((p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)tid) * p.dphi);
@@ -260,7 +271,11 @@ __global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(Rd
         v[j + PH] = hnew[tid + j * NT];
       }
       auto sync = []() { __syncthreads(); };
-      fwd_pass0_store<N, P>(lb, v, wb, tw); /* CONV:291 */
+      {
+        float2 twp[P - 1];
+        tw.template get<0>(twp);
+        fwd_pass0_store<N, P>(lb, v, wb, twp); /* CONV:291 */
+      }
       __syncthreads();
       fwd_mid_all<N, P, 1, PL::NP - 1>(lb, wb, tw, sync);
       fwd_pass_last<N, P>(lb, v, wb);
@@ -300,7 +315,11 @@ __global__ void __launch_bounds__(N / P, (P == 16 ? 1 : 2)) rdsp_front_kernel(Rd
       inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
       __syncthreads();
       inv_mid_all<N, P, PL::NP - 2>(lb, wb, tw, sync);
-      inv_pass0_load<N, P>(lb, v, wb, tw);
+      {
+        float2 twp[P - 1];
+        tw.template get<0>(twp);
+        inv_pass0_load<N, P>(lb, v, wb, twp);
+      }
       __syncthreads(); /* wb is free again (next frame / taps / FIR partials) */
 
       /* CONV:314-318: keep the second half.  v[PH + jj] = y[N/2 + tid + jj*NT] */

@@ -9,7 +9,7 @@
 #include "rdsp_fft.h"
 using namespace rdsp;
 
-template <int N, int P>
+template <int N, int P, bool CHAIN>
 double check() {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
@@ -24,7 +24,15 @@ double check() {
     X[k] = a;
   }
   static float2 tw[NT][PL::NTW][P - 1];
-  for (int t = 0; t < NT; t++) make_twiddles<N, P>(t, tw[t]);
+  for (int t = 0; t < NT; t++) {
+    if (CHAIN) {
+      float2 w1[PL::NTW];
+      make_twiddle_bases<N, P>(t, w1);
+      for (int p = 0; p < PL::NTW; p++) twiddle_chain<P>(w1[p], tw[t][p]);
+    } else {
+      make_twiddles<N, P>(t, tw[t]);
+    }
+  }
   static LdsBases<N, P> lb[NT];
   for (int t = 0; t < NT; t++) make_lds_bases<N, P>(t, lb[t]);
   auto nosync = []() {};
@@ -32,12 +40,12 @@ double check() {
   for (int t = 0; t < NT; t++) {
     float2 v[P];
     for (int j = 0; j < P; j++) v[j] = x[t + j * NT];
-    fwd_pass0_store<N, P>(lb[t], v, wb.data(), tw[t]);
+    fwd_pass0_store<N, P>(lb[t], v, wb.data(), tw[t][0]);
   }
   // middle passes: must be emulated pass by pass over all threads
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t]);
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t]);
+  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t][1]);
+  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t][2]);
+  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t][3]);
   static_assert(PL::NP <= 5, "extend harness");
   std::vector<float2> spec(N);
   double emax = 0, xmax = 0;
@@ -59,13 +67,13 @@ double check() {
     for (int e = 0; e < P; e++) v[e] = spec[t * P + e];
     inv_pass_last<N, P>(lb[t], v, wb.data());
   }
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t]);
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t]);
+  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t][3]);
+  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t][2]);
+  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t][1]);
   double imax = 0;
   for (int t = 0; t < NT; t++) {
     float2 v[P];
-    inv_pass0_load<N, P>(lb[t], v, wb.data(), tw[t]);
+    inv_pass0_load<N, P>(lb[t], v, wb.data(), tw[t][0]);
     for (int j = 0; j < P; j++) {
       int n = t + j * NT;
       double d = std::hypot(v[j].x / (double)N - x[n].x, v[j].y / (double)N - x[n].y);
@@ -73,17 +81,22 @@ double check() {
     }
   }
   (void)nosync;
-  printf("N=%d P=%d NT=%d NP=%d RL=%d fwd_err=%.3e roundtrip_err=%.3e\n", N, P, NT, PL::NP, PL::RL, fwd_err, imax);
+  printf("N=%d P=%d NT=%d NP=%d RL=%d chain=%d fwd_err=%.3e roundtrip_err=%.3e\n", N, P, NT, PL::NP, PL::RL, (int)CHAIN, fwd_err, imax);
   return fwd_err > imax ? fwd_err : imax;
 }
 
 int main() {
   double w = 0;
-  w = fmax(w, check<256, 4>());
-  w = fmax(w, check<512, 8>());
-  w = fmax(w, check<1024, 16>());
-  w = fmax(w, check<2048, 8>());
-  w = fmax(w, check<4096, 16>());
+  w = fmax(w, check<256, 4, false>());
+  w = fmax(w, check<512, 8, false>());
+  w = fmax(w, check<1024, 16, false>());
+  w = fmax(w, check<2048, 8, false>());
+  w = fmax(w, check<4096, 16, false>());
+  w = fmax(w, check<256, 4, true>());
+  w = fmax(w, check<512, 8, true>());
+  w = fmax(w, check<1024, 16, true>());
+  w = fmax(w, check<2048, 8, true>());
+  w = fmax(w, check<4096, 16, true>());
   if (w > 2e-6) { printf("FAIL %.3e\n", w); return 1; }
   printf("OK\n");
   return 0;
