@@ -259,57 +259,80 @@ RDSP_HD void make_twiddle_bases(int t, float2 *w1) {
  *     phi(base_p) + j*s_p + (j*s_p)/P        (s_p and P are powers of two, so
  * the offset inside the span never carries), i.e. a per-thread constant that is
  * computed once per kernel plus a compile-time offset the assembler folds into
- * the ds_read/ds_write immediate. */
-template <int N, int P>
-struct LdsBases {
-  int b[FftPlan<N, P>::NP]; /* phi(base) of every pass; last pass: t*(P+1) */
+ * the ds_read/ds_write immediate.
+ *
+ * ALIAS = true places the work buffer inside the polyphase planes of the FIR
+ * (rdsp_front.h): after the FIR of a chunk only the first 17 entries of each of
+ * the 8 planes (the history) are live, so the N/8 elements [p*N/8, (p+1)*N/8) go
+ * to plane p behind its history.  Offsets stay "per-thread constant + compile-time
+ * constant" because N/8 is a multiple of every group size that does not span it. */
+#ifndef RDSP_XP
+#define RDSP_XP 84
+#endif
+template <int N, int P, bool ALIAS>
+struct WbMap {
+  static constexpr int SEG = N / 8;              /* elements per plane          */
+  static constexpr int CS = SEG + SEG / P;       /* padded float2 per plane     */
+  static constexpr int PLANE = 2 * RDSP_XP;      /* float2 per plane            */
+  static constexpr int HIST = 2 * 17;            /* float2 of history per plane */
+  static_assert(!ALIAS || CS <= PLANE - HIST, "work buffer segment fits behind the history");
+  static RDSP_HD int base(int elem) {
+    int b = phi<P>(elem);
+    if constexpr (ALIAS) b += (elem / SEG) * (PLANE - CS) + HIST;
+    return b;
+  }
+  static constexpr int off(int j, int s) {
+    return j * s + (j * s) / P + (ALIAS ? ((j * s) / SEG) * (PLANE - CS) : 0);
+  }
 };
 
-template <int N, int P>
-RDSP_HD void make_lds_bases(int t, LdsBases<N, P> &lb) {
+template <int N, int P, bool ALIAS = false>
+struct LdsBases {
+  int b[FftPlan<N, P>::NP]; /* mapped base of every pass; last pass: element t*P */
+};
+
+template <int N, int P, bool A>
+RDSP_HD void make_lds_bases(int t, LdsBases<N, P, A> &lb) {
   using PL = FftPlan<N, P>;
 #pragma unroll
   for (int p = 0; p < PL::NP - 1; p++) {
     const int s = PL::span(p);
     const int base = (t / s) * P * s + (t % s);
-    lb.b[p] = phi<P>(base);
+    lb.b[p] = WbMap<N, P, A>::base(base);
   }
-  lb.b[PL::NP - 1] = t * (P + 1);
+  lb.b[PL::NP - 1] = WbMap<N, P, A>::base(t * P);
 }
-
-template <int P>
-constexpr int phi_off(int j, int s) { return j * s + (j * s) / P; }
 
 /* ---- forward ------------------------------------------------------------- */
 /* pass 0: v[] already loaded with x[t + j*NT] (j = 0..P-1) */
-template <int N, int P>
-RDSP_HD void fwd_pass0_store(const LdsBases<N, P> &lb, float2 *v, float2 *wb, const float2 *twp) {
+template <int N, int P, bool A>
+RDSP_HD void fwd_pass0_store(const LdsBases<N, P, A> &lb, float2 *v, float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
   Dft<P, false>::run(v);
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmul(v[k], twp[k - 1]);
 #pragma unroll
-  for (int j = 0; j < P; j++) wb[lb.b[0] + phi_off<P>(j, PL::span(0))] = v[j];
+  for (int j = 0; j < P; j++) wb[lb.b[0] + WbMap<N, P, A>::off(j, PL::span(0))] = v[j];
 }
 
 /* middle pass p (1 <= p <= NP-2), in place */
-template <int N, int P, int PIDX>
-RDSP_HD void fwd_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 *twp) {
+template <int N, int P, int PIDX, bool A>
+RDSP_HD void fwd_pass_mid(const LdsBases<N, P, A> &lb, float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
   constexpr int s = PL::span(PIDX);
   float2 v[P];
 #pragma unroll
-  for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + phi_off<P>(j, s)];
+  for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + WbMap<N, P, A>::off(j, s)];
   Dft<P, false>::run(v);
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmul(v[k], twp[k - 1]);
 #pragma unroll
-  for (int j = 0; j < P; j++) wb[lb.b[PIDX] + phi_off<P>(j, s)] = v[j];
+  for (int j = 0; j < P; j++) wb[lb.b[PIDX] + WbMap<N, P, A>::off(j, s)] = v[j];
 }
 
 /* last pass: loads positions t*P .. t*P+P-1, leaves the spectrum in v[] */
-template <int N, int P>
-RDSP_HD void fwd_pass_last(const LdsBases<N, P> &lb, float2 *v, const float2 *wb) {
+template <int N, int P, bool A>
+RDSP_HD void fwd_pass_last(const LdsBases<N, P, A> &lb, float2 *v, const float2 *wb) {
   using PL = FftPlan<N, P>;
 #pragma unroll
   for (int e = 0; e < P; e++) v[e] = wb[lb.b[PL::NP - 1] + e];
@@ -318,8 +341,8 @@ RDSP_HD void fwd_pass_last(const LdsBases<N, P> &lb, float2 *v, const float2 *wb
 }
 
 /* ---- inverse (unnormalised; 1/N is folded into the mask) ------------------ */
-template <int N, int P>
-RDSP_HD void inv_pass_last(const LdsBases<N, P> &lb, float2 *v, float2 *wb) {
+template <int N, int P, bool A>
+RDSP_HD void inv_pass_last(const LdsBases<N, P, A> &lb, float2 *v, float2 *wb) {
   using PL = FftPlan<N, P>;
 #pragma unroll
   for (int q = 0; q < P / PL::RL; q++) Dft<PL::RL, true>::run(v + q * PL::RL);
@@ -327,26 +350,26 @@ RDSP_HD void inv_pass_last(const LdsBases<N, P> &lb, float2 *v, float2 *wb) {
   for (int e = 0; e < P; e++) wb[lb.b[PL::NP - 1] + e] = v[e];
 }
 
-template <int N, int P, int PIDX>
-RDSP_HD void inv_pass_mid(const LdsBases<N, P> &lb, float2 *wb, const float2 *twp) {
+template <int N, int P, int PIDX, bool A>
+RDSP_HD void inv_pass_mid(const LdsBases<N, P, A> &lb, float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
   constexpr int s = PL::span(PIDX);
   float2 v[P];
 #pragma unroll
-  for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + phi_off<P>(j, s)];
+  for (int j = 0; j < P; j++) v[j] = wb[lb.b[PIDX] + WbMap<N, P, A>::off(j, s)];
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmulc(v[k], twp[k - 1]);
   Dft<P, true>::run(v);
 #pragma unroll
-  for (int j = 0; j < P; j++) wb[lb.b[PIDX] + phi_off<P>(j, s)] = v[j];
+  for (int j = 0; j < P; j++) wb[lb.b[PIDX] + WbMap<N, P, A>::off(j, s)] = v[j];
 }
 
 /* pass 0 inverse: result v[j] = y[t + j*NT] */
-template <int N, int P>
-RDSP_HD void inv_pass0_load(const LdsBases<N, P> &lb, float2 *v, const float2 *wb, const float2 *twp) {
+template <int N, int P, bool A>
+RDSP_HD void inv_pass0_load(const LdsBases<N, P, A> &lb, float2 *v, const float2 *wb, const float2 *twp) {
   using PL = FftPlan<N, P>;
 #pragma unroll
-  for (int j = 0; j < P; j++) v[j] = wb[lb.b[0] + phi_off<P>(j, PL::span(0))];
+  for (int j = 0; j < P; j++) v[j] = wb[lb.b[0] + WbMap<N, P, A>::off(j, PL::span(0))];
 #pragma unroll
   for (int k = 1; k < P; k++) v[k] = cmulc(v[k], twp[k - 1]);
   Dft<P, true>::run(v);
@@ -385,24 +408,24 @@ struct Twiddles<N, P, true> {
 };
 
 /* compile-time loops over the middle passes */
-template <int N, int P, int PIDX, int PEND, typename TW, typename SYNC>
-RDSP_HD void fwd_mid_all(const LdsBases<N, P> &lb, float2 *wb, const TW &tw, SYNC sync) {
+template <int N, int P, int PIDX, int PEND, bool A, typename TW, typename SYNC>
+RDSP_HD void fwd_mid_all(const LdsBases<N, P, A> &lb, float2 *wb, const TW &tw, SYNC sync) {
   if constexpr (PIDX < PEND) {
     float2 twp[P - 1];
     tw.template get<PIDX>(twp);
-    fwd_pass_mid<N, P, PIDX>(lb, wb, twp);
+    fwd_pass_mid<N, P, PIDX, A>(lb, wb, twp);
     sync();
-    fwd_mid_all<N, P, PIDX + 1, PEND>(lb, wb, tw, sync);
+    fwd_mid_all<N, P, PIDX + 1, PEND, A>(lb, wb, tw, sync);
   }
 }
-template <int N, int P, int PIDX, typename TW, typename SYNC>
-RDSP_HD void inv_mid_all(const LdsBases<N, P> &lb, float2 *wb, const TW &tw, SYNC sync) {
+template <int N, int P, int PIDX, bool A, typename TW, typename SYNC>
+RDSP_HD void inv_mid_all(const LdsBases<N, P, A> &lb, float2 *wb, const TW &tw, SYNC sync) {
   if constexpr (PIDX >= 1) {
     float2 twp[P - 1];
     tw.template get<PIDX>(twp);
-    inv_pass_mid<N, P, PIDX>(lb, wb, twp);
+    inv_pass_mid<N, P, PIDX, A>(lb, wb, twp);
     sync();
-    inv_mid_all<N, P, PIDX - 1>(lb, wb, tw, sync);
+    inv_mid_all<N, P, PIDX - 1, A>(lb, wb, tw, sync);
   }
 }
 

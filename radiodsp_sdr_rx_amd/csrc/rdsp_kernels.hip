@@ -23,6 +23,10 @@
  */
 #include "rdsp_front.h"
 
+#ifndef RDSP_FRONT_LEAN_ALL
+#define RDSP_FRONT_LEAN_ALL 0
+#endif
+
 using namespace rdsp;
 
 namespace {
@@ -63,10 +67,30 @@ __device__ __forceinline__ uint32_t pack_lr(float l, float r) {
 }
 
 /* ---- front kernel -------------------------------------------------------- */
+/* LDS plan of the front kernel (float2 units), shared with the launch code */
+template <int N, int P, int DECIM>
+struct FrontLds {
+  static constexpr int NT = N / P;
+  static constexpr int H = N / 2;
+  static constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
+  static constexpr int HB_N = (H > 256) ? H : 256; /* new samples of one chunk / one hop */
+  /* one-wave kernels with a work buffer that fits behind the FIR history reuse the planes */
+  static constexpr bool ALIAS = (DECIM == 4) && (NT == 64) && (N <= 512);
+  static constexpr int WB_N = ALIAS ? 0 : FftPlan<N, P>::WB;
+  static constexpr int TAPS_N = (DECIM == 4) ? 128 : 0;
+  static constexpr size_t BYTES = (size_t)(XS_N + HB_N + WB_N + TAPS_N) * sizeof(float2) + 64 * sizeof(float);
+};
+/* LEAN = trade registers for recomputation (twiddle power chains, mask slice
+ * re-read per chunk) where that buys residency */
+template <int N, int P>
+struct FrontLean {
+  static constexpr bool value = RDSP_FRONT_LEAN_ALL || (P == 16);
+};
+
 /* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
  * mask slice re-read per chunk); it pays when it buys a wave per SIMD (radix 16). */
 template <int N, int P, int DECIM>
-__global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p) {
+__global__ void __launch_bounds__(N / P, ((RDSP_FRONT_LEAN_ALL && P <= 8) ? 3 : 2)) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
   constexpr int NW = NT / 64;
@@ -76,24 +100,24 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   constexpr int CH_IN = CH_OUT * DECIM;
   constexpr int FPC = (H >= CH_OUT) ? 1 : CH_OUT / H; /* frames per chunk */
   constexpr int CPF = (H >= CH_OUT) ? H / CH_OUT : 1; /* chunks per frame */
-  constexpr int NHB = FPC + 1;                        /* half-buffers     */
   constexpr int NB = H / RDSP_BLOCK;                  /* 128-blocks per hop */
-  constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
+  using LY = FrontLds<N, P, DECIM>;
+  constexpr bool ALIAS = LY::ALIAS;
   constexpr int LP = (CH_IN / 4 + NT - 1) / NT; /* uint4 loads per thread per chunk */
-  /* the decimator taps live in the FFT work buffer while the FIR runs (the
-   * buffer is idle then); with four waves the first 8 KiB hold the partial sums */
-  constexpr int TAPS_OFF = (NW == 1) ? 0 : 4 * CH_OUT; /* float2 units */
-  constexpr bool LEAN = (P == 16);
+  constexpr bool LEAN = FrontLean<N, P>::value;
   static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
   static_assert(NT == 64 || NT == 256, "one or four waves per channel");
-  static_assert(PL::WB >= TAPS_OFF + 128, "work buffer holds the taps");
+  static_assert(NW == 1 || PL::WB >= 4 * CH_OUT, "work buffer holds the FIR partial sums");
 
+  /* LDS: [polyphase planes | new hop(s) | work buffer (unless aliased into the
+   * planes) | decimator taps | reduction scratch].  The previous hop is not in
+   * LDS: every thread keeps its own P/2 elements of it in registers (vprev). */
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *xs = reinterpret_cast<float2 *>(smem_raw);
-  float2 *hb = xs + XS_N;
-  float2 *wb = hb + NHB * H;
-  float *red = reinterpret_cast<float *>(wb + PL::WB);
-  float4 *taps_lds = reinterpret_cast<float4 *>(wb + TAPS_OFF);
+  float2 *hb = xs + LY::XS_N;
+  float2 *wb = ALIAS ? xs : hb + LY::HB_N;
+  float4 *taps_lds = reinterpret_cast<float4 *>(hb + LY::HB_N + (ALIAS ? 0 : PL::WB));
+  float *red = reinterpret_cast<float *>(reinterpret_cast<float2 *>(taps_lds) + LY::TAPS_N);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,25 +138,26 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
    * (digit-reversed, /N), its VAD-bin membership bits and its four taps */
   Twiddles<N, P, LEAN> tw;
   tw.init(tid);
-  LdsBases<N, P> lb;
-  make_lds_bases<N, P>(tid, lb);
+  LdsBases<N, P, ALIAS> lb;
+  make_lds_bases<N, P, ALIAS>(tid, lb);
   uint32_t vadbits = 0;
 #pragma unroll
   for (int e = 0; e < P; e++) {
     int k = bin_of_pos<N, P>(tid * P + e);
     if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
   }
-  float4 tapreg = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (DECIM == 4) {
-    if (tid < 64) tapreg = reinterpret_cast<const float4 *>(p.fir_hc)[tid];
+    if (tid < 64) taps_lds[tid] = reinterpret_cast<const float4 *>(p.fir_hc)[tid];
   }
 
   float nfloor = p.st_scal[ch * 4 + 0];
   float agc_g = p.st_scal[ch * 4 + 1];
   float am_dc = p.st_scal[ch * 4 + 2];
 
-  /* state in: previous hop -> half-buffer 0, FIR history -> polyphase planes */
-  for (int i = tid; i < H; i += NT) hb[i] = p.st_prev[ch * H + i];
+  /* state in: previous hop -> registers, FIR history -> polyphase planes */
+  float2 vprev[PH];
+#pragma unroll
+  for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
   if constexpr (DECIM == 4) {
     for (int i = tid; i < 64; i += NT) {
       uint4 w4 = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * i);
@@ -151,7 +176,6 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       }
     }
   }
-  int old_slot = 0; /* half-buffer holding the previous hop */
   int frame_idx = 0;
   __syncthreads();
 
@@ -192,16 +216,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
             xs[xs_pos(4 * idx + j)] = x;
           } else {
             int m = 4 * idx + j; /* no decimator: the sample is the "output" */
-            int slot, off;
-            if constexpr (FPC == 1) { slot = old_slot ^ 1; off = (chunk % CPF) * CH_OUT + m; }
-            else { slot = (old_slot + 1 + m / H) % NHB; off = m % H; }
-            hb[slot * H + off] = x;
+            hb[(chunk % CPF) * CH_OUT + m] = x;
           }
         }
       }
-    }
-    if constexpr (DECIM == 4) {
-      if (tid < 64) taps_lds[tid] = tapreg; /* the last frame overwrote the work buffer */
     }
     /* prefetch the next chunk's raw samples; they land during FIR + FFT */
     if (chunk + 1 < p.n_chunks) {
@@ -222,12 +240,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       if constexpr (NW == 1) {
         fir_lane(lane, 0, 4, xs, taps_lds, acc);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int m = 4 * lane + r, slot, off;
-          if constexpr (FPC == 1) { slot = old_slot ^ 1; off = (chunk % CPF) * CH_OUT + m; }
-          else { slot = (old_slot + 1 + m / H) % NHB; off = m % H; }
-          hb[slot * H + off] = acc[r];
-        }
+        for (int r = 0; r < 4; r++) hb[(chunk % CPF) * CH_OUT + 4 * lane + r] = acc[r];
         __syncthreads();
       } else {
         /* four waves: wave w takes polyphase branch w; partials summed via LDS */
@@ -238,10 +251,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         {
           float2 s0 = wb[tid], s1 = wb[CH_OUT + tid], s2 = wb[2 * CH_OUT + tid], s3 = wb[3 * CH_OUT + tid];
           float2 s = cadd(cadd(s0, s1), cadd(s2, s3));
-          int m = tid, slot, off;
-          if constexpr (FPC == 1) { slot = old_slot ^ 1; off = (chunk % CPF) * CH_OUT + m; }
-          else { slot = (old_slot + 1 + m / H) % NHB; off = m % H; }
-          hb[slot * H + off] = s;
+          hb[(chunk % CPF) * CH_OUT + tid] = s;
         }
       }
       /* slide the FIR history: entries 64..80 of every plane -> 0..16 */
@@ -260,15 +270,15 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     /* ---- A5/A6: overlap-save frames ---------------------------------------- */
 #pragma unroll 1
     for (int f = 0; f < FPC; f++) {
-      const int new_slot = (FPC == 1) ? (old_slot ^ 1) : (old_slot + 1) % NHB;
-      const float2 *hold = hb + old_slot * H;
-      const float2 *hnew = hb + new_slot * H;
+      const float2 *hnew = hb + f * H;
       float2 v[P];
-      /* CONV:267-285: [previous hop | current hop] */
+      /* CONV:267-285: [previous hop | current hop]; CONV:274-278: the current hop is
+       * the next frame's previous hop (this thread's elements stay in its registers) */
 #pragma unroll
       for (int j = 0; j < PH; j++) {
-        v[j] = hold[tid + j * NT];
+        v[j] = vprev[j];
         v[j + PH] = hnew[tid + j * NT];
+        vprev[j] = v[j + PH];
       }
       auto sync = []() { __syncthreads(); };
       {
@@ -277,7 +287,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         fwd_pass0_store<N, P>(lb, v, wb, twp); /* CONV:291 */
       }
       __syncthreads();
-      fwd_mid_all<N, P, 1, PL::NP - 1>(lb, wb, tw, sync);
+      fwd_mid_all<N, P, 1, PL::NP - 1, ALIAS>(lb, wb, tw, sync);
       fwd_pass_last<N, P>(lb, v, wb);
 
       if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
@@ -314,7 +324,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 
       inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
       __syncthreads();
-      inv_mid_all<N, P, PL::NP - 2>(lb, wb, tw, sync);
+      inv_mid_all<N, P, PL::NP - 2, ALIAS>(lb, wb, tw, sync);
       {
         float2 twp[P - 1];
         tw.template get<0>(twp);
@@ -428,12 +438,12 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         }
       }
       frame_idx++;
-      old_slot = new_slot;
     }
   }
 
   /* ---- state out --------------------------------------------------------- */
-  for (int i = tid; i < H; i += NT) p.st_prev[ch * H + i] = hb[old_slot * H + i];
+#pragma unroll
+  for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
   if constexpr (DECIM == 4) {
     const uint32_t *tail = iq + (size_t)p.n_chunks * CH_IN - 256;
     for (int i = tid; i < 256; i += NT) p.st_hist[ch * 256 + i] = tail[i];
@@ -680,12 +690,7 @@ __global__ void rdsp_float_to_q15_kernel(const float *src, int16_t *dst, size_t 
 
 template <int N, int P, int DECIM>
 constexpr size_t front_lds() {
-  using PL = FftPlan<N, P>;
-  constexpr int H = N / 2;
-  constexpr int FPC = (H >= 256) ? 1 : 256 / H;
-  constexpr int NHB = FPC + 1;
-  constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
-  return (size_t)(XS_N + NHB * H + PL::WB) * sizeof(float2) + 64 * sizeof(float);
+  return FrontLds<N, P, DECIM>::BYTES;
 }
 
 template <int N, int P, int DECIM>

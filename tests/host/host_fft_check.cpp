@@ -9,11 +9,13 @@
 #include "rdsp_fft.h"
 using namespace rdsp;
 
-template <int N, int P, bool CHAIN>
+template <int N, int P, bool CHAIN, bool ALIAS = false>
 double check() {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
-  std::vector<float2> x(N), wb(PL::WB);
+  // ALIAS: the work buffer lives inside the 8 polyphase planes (16*XP float2), behind
+  // the 17-entry history of each plane, which is poisoned here and must stay intact
+  std::vector<float2> x(N), wb(ALIAS ? 16 * RDSP_XP : PL::WB, make_float2(7e33f, 7e33f));
   srand(N * 31 + P);
   for (auto &v : x) v = make_float2(rand() / (float)RAND_MAX - 0.5f, rand() / (float)RAND_MAX - 0.5f);
   std::vector<std::complex<double>> X(N);
@@ -33,8 +35,8 @@ double check() {
       make_twiddles<N, P>(t, tw[t]);
     }
   }
-  static LdsBases<N, P> lb[NT];
-  for (int t = 0; t < NT; t++) make_lds_bases<N, P>(t, lb[t]);
+  static LdsBases<N, P, ALIAS> lb[NT];
+  for (int t = 0; t < NT; t++) make_lds_bases<N, P, ALIAS>(t, lb[t]);
   auto nosync = []() {};
   // forward pass 0
   for (int t = 0; t < NT; t++) {
@@ -43,9 +45,9 @@ double check() {
     fwd_pass0_store<N, P>(lb[t], v, wb.data(), tw[t][0]);
   }
   // middle passes: must be emulated pass by pass over all threads
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t][1]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t][2]);
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t][3]);
+  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1, ALIAS>(lb[t], wb.data(), tw[t][1]);
+  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2, ALIAS>(lb[t], wb.data(), tw[t][2]);
+  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3, ALIAS>(lb[t], wb.data(), tw[t][3]);
   static_assert(PL::NP <= 5, "extend harness");
   std::vector<float2> spec(N);
   double emax = 0, xmax = 0;
@@ -67,9 +69,9 @@ double check() {
     for (int e = 0; e < P; e++) v[e] = spec[t * P + e];
     inv_pass_last<N, P>(lb[t], v, wb.data());
   }
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3>(lb[t], wb.data(), tw[t][3]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2>(lb[t], wb.data(), tw[t][2]);
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1>(lb[t], wb.data(), tw[t][1]);
+  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3, ALIAS>(lb[t], wb.data(), tw[t][3]);
+  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2, ALIAS>(lb[t], wb.data(), tw[t][2]);
+  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1, ALIAS>(lb[t], wb.data(), tw[t][1]);
   double imax = 0;
   for (int t = 0; t < NT; t++) {
     float2 v[P];
@@ -81,7 +83,12 @@ double check() {
     }
   }
   (void)nosync;
-  printf("N=%d P=%d NT=%d NP=%d RL=%d chain=%d fwd_err=%.3e roundtrip_err=%.3e\n", N, P, NT, PL::NP, PL::RL, (int)CHAIN, fwd_err, imax);
+  if (ALIAS) {
+    for (int pl = 0; pl < 8; pl++)
+      for (int e = 0; e < 34; e++)
+        if (wb[pl * 2 * RDSP_XP + e].x != 7e33f) { printf("history entry clobbered: plane %d float2 %d\n", pl, e); return 1.0; }
+  }
+  printf("N=%d P=%d NT=%d NP=%d RL=%d alias=%d chain=%d fwd_err=%.3e roundtrip_err=%.3e\n", N, P, NT, PL::NP, PL::RL, (int)ALIAS, (int)CHAIN, fwd_err, imax);
   return fwd_err > imax ? fwd_err : imax;
 }
 
@@ -97,6 +104,9 @@ int main() {
   w = fmax(w, check<1024, 16, true>());
   w = fmax(w, check<2048, 8, true>());
   w = fmax(w, check<4096, 16, true>());
+  w = fmax(w, check<256, 4, false, true>());
+  w = fmax(w, check<512, 8, false, true>());
+  w = fmax(w, check<512, 8, true, true>());
   if (w > 2e-6) { printf("FAIL %.3e\n", w); return 1; }
   printf("OK\n");
   return 0;
