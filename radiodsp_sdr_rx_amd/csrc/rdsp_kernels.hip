@@ -456,13 +456,34 @@ __global__ void __launch_bounds__(N / P, ((RDSP_FRONT_LEAN_ALL && P <= 8) ? 3 : 
 }
 
 /* ---- tail kernel ---------------------------------------------------------- */
-/* One NLMS instance of one channel, spread over LPC lanes of a DPP row.
- * Lane `sub` holds the taps of ages TPL*sub .. TPL*sub+TPL-1 (age 0 = newest
- * sample); CMSIS coefficient b[i] multiplies age 95-i (arm_lms_norm_f32). */
+/* sum over the 16 lanes of one channel (one DPP row), result in every lane */
+template <int LPC>
+__device__ __forceinline__ float chan_allsum(float v) {
+  static_assert(LPC == 16, "one channel per DPP row");
+  return row_allsum(v);
+}
+/* lane sub takes lane sub-1's value; lane 0 of the row keeps the DPP `old` operand = xin */
+template <int LPC>
+__device__ __forceinline__ float chan_shift_in(float xin, float oldest, int sub) {
+  (void)sub;
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, xin),
+                                                               __builtin_bit_cast(int, oldest), 0x111, 0xF, 0xF, false));
+}
+
+/* One NLMS instance of one channel, spread over the 16 lanes of a DPP row (four
+ * channels per wave).  Measured alternatives on MI355X: 32 lanes per channel
+ * (two waves per SIMD at 4096 channels) needs ~31 instructions per wave-step for two
+ * channels against 24 for four and ran 1.6x slower; a one-step lookahead of the
+ * recursion raised the instruction count and ran 1.3x slower.  A lone wave issues
+ * a dependent VALU op every ~7 cycles and a dependent DPP op every ~14
+ * (tests/micro/valu_rate.hip), which is what bounds this kernel.  Lane `sub` holds the taps of ages
+ * TPL*sub .. TPL*sub+TPL-1 (age 0 = newest sample); CMSIS coefficient b[i]
+ * multiplies age 95-i (arm_lms_norm_f32). */
 template <int LPC>
 struct Nlms {
   static constexpr int TPL = RDSP_LMS_TAPS / LPC;
-  static constexpr int NPH = (TPL <= 4) ? 4 : (TPL <= 8 ? 8 : 16); /* physical ring */
+  static constexpr int NPH = (TPL <= 3) ? 4 : 8; /* physical ring (> TPL, divides 128) */
+  static_assert(LPC == 16, "one channel per 16-lane DPP row");
   float w[TPL];
   float xp[NPH];
   float energy;
@@ -491,10 +512,10 @@ struct Nlms {
    * block.  mode 0: out = 1.1*y (CONV:334), 1: out = e, 2: out = y. */
   __device__ __forceinline__ void block(const float *ring, int hc, bool first, float mu, int mode,
                                         float *out, int sub) {
-    static_assert(LPC == 16, "row-DPP mapping assumes one channel per 16-lane row");
     const float *cur = ring + hc * RDSP_BLOCK;
     const float *prv = ring + (hc ^ 1) * RDSP_BLOCK;
     const float *dsrc = first ? cur : prv; /* NR:69-79: first call d = x, then previous block */
+    float mine = 0.f;
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += 16) {
       float in[16], x0[16], dd[16];
@@ -508,38 +529,36 @@ struct Nlms {
         x0[4 * q] = b.x; x0[4 * q + 1] = b.y; x0[4 * q + 2] = b.z; x0[4 * q + 3] = b.w;
         dd[4 * q] = c.x; dd[4 * q + 1] = c.y; dd[4 * q + 2] = c.z; dd[4 * q + 3] = c.w;
       }
-      float mine = 0.f;
+      const int sg0 = s0 & (LPC - 1); /* position of this 16-step group inside the LPC-step output group */
 #pragma unroll
       for (int s = 0; s < 16; s++) {
         constexpr int M = NPH - 1;
         const int wpos = (-s) & M; /* s0 % 16 == 0 and NPH divides 16: compile-time */
-        /* shift the delay line by one: lane sub takes lane sub-1's oldest tap,
-         * lane 0 takes the new sample (DPP row_shr:1 keeps `old` there) */
-        float oldest = xp[(wpos + TPL) & M]; /* logical TPL-1 before this step */
-        float inc = __builtin_bit_cast(
-            float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, in[s]),
-                                               __builtin_bit_cast(int, oldest), 0x111, 0xF, 0xF,
-                                               false));
-        xp[wpos] = inc;
+        /* shift the delay line by one */
+        float oldest = xp[(wpos + TPL) & M]; /* in-lane tap TPL-1 before this step */
+        xp[wpos] = chan_shift_in<LPC>(in[s], oldest, sub);
         energy = fmaf(-x0[s], x0[s], energy); /* energy -= x0*x0 */
         energy = fmaf(in[s], in[s], energy);  /* energy += in*in */
         float acc0 = w[0] * xp[wpos];
         float acc1 = w[1] * xp[(wpos + 1) & M];
+        acc0 = fmaf(w[2], xp[(wpos + 2) & M], acc0);
 #pragma unroll
-        for (int k = 2; k < TPL; k += 2) {
-          acc0 = fmaf(w[k], xp[(wpos + k) & M], acc0);
-          acc1 = fmaf(w[k + 1], xp[(wpos + k + 1) & M], acc1);
+        for (int k = 3; k < TPL; k += 2) {
+          acc1 = fmaf(w[k], xp[(wpos + k) & M], acc1);
+          if (k + 1 < TPL) acc0 = fmaf(w[k + 1], xp[(wpos + k + 1) & M], acc0);
         }
-        float y = row_allsum(acc0 + acc1);
+        float y = chan_allsum<LPC>(acc0 + acc1);
         float e = dd[s] - y;
         float g = (e * mu) * __builtin_amdgcn_rcpf(energy + 0.000000119209289f);
 #pragma unroll
         for (int k = 0; k < TPL; k++) w[k] = fmaf(g, xp[(wpos + k) & M], w[k]);
         float o = (mode == 1) ? e : y;
-        mine = (sub == s) ? o : mine;
+        mine = (sub == sg0 + s) ? o : mine;
       }
-      if (mode == 0) mine = mine * 1.1f;
-      out[s0 + sub] = mine;
+      if (((s0 + 16) & (LPC - 1)) == 0) { /* every lane of the channel holds one output */
+        if (mode == 0) mine = mine * 1.1f;
+        out[s0 + 16 - LPC + sub] = mine;
+      }
     }
   }
 };
@@ -547,7 +566,7 @@ struct Nlms {
 template <int LPC>
 __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
   constexpr int CPW = 64 / LPC;
-  constexpr int SPL = RDSP_BLOCK / LPC; /* samples per lane per block */
+  constexpr int SPL = RDSP_BLOCK / LPC; /* samples per lane per block: 8 or 4 */
   __shared__ __attribute__((aligned(16))) float lds[CPW][5 * RDSP_BLOCK];
   const int lane = threadIdx.x;
   const int sub = lane % LPC;
@@ -577,18 +596,18 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
   }
 
   const float *src = p.mid + ch * p.mid_stride;
-  static_assert(SPL == 8, "two float4 per lane per block");
   float4 nxa = *reinterpret_cast<const float4 *>(src + sub * SPL);
-  float4 nxb = *reinterpret_cast<const float4 *>(src + sub * SPL + 4);
+  float4 nxb = nxa;
+  if constexpr (SPL == 8) nxb = *reinterpret_cast<const float4 *>(src + sub * SPL + 4);
 
 #pragma unroll 1
   for (int b = 0; b < p.n_blocks; b++) {
     const int hc = b & 1;
     *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL) = nxa;
-    *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL + 4) = nxb;
+    if constexpr (SPL == 8) *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL + 4) = nxb;
     if (b + 1 < p.n_blocks) { /* next block's input lands while this block computes */
       nxa = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL);
-      nxb = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL + 4);
+      if constexpr (SPL == 8) nxb = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL + 4);
     }
     __syncthreads();
     const float *cur = ringA + hc * RDSP_BLOCK;
@@ -624,7 +643,7 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
       float pw = 0.f;
 #pragma unroll
       for (int k = 0; k < SPL; k++) pw += L[k] * L[k] + L[k] * L[k];
-      pw = row_allsum(pw);
+      pw = chan_allsum<LPC>(pw);
       float pp = pw / (float)(2 * RDSP_BLOCK);
       float rms = sqrtf(pp);
       float gt = fminf(0.25f / (rms + 1e-6f), 100.0f);
@@ -737,8 +756,7 @@ extern "C" int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p,
 
 extern "C" int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
   if (lanes_per_channel != 16) return (int)hipErrorInvalidValue;
-  constexpr int CPW = 4;
-  int grid = (p->n_channels + CPW - 1) / CPW;
+  int grid = (p->n_channels + 3) / 4;
   hipLaunchKernelGGL((rdsp_tail_kernel<16>), dim3(grid), dim3(64), 0, stream, *p);
   return (int)hipGetLastError();
 }
