@@ -174,6 +174,9 @@ int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* SPEC:112 iN
  * rdsp_chain_flush(c, stream) on the consuming stream. */
 int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on);
 int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
+/* front-kernel variant: -1 auto (register-lean when the tail stage runs concurrently,
+ * so both kernels fit one SIMD), 0 full-register, 1 lean */
+int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean);
 
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/
 int rdsp_chain_set_timing(rdsp_chain_t *c, int on);

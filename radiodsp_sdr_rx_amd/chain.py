@@ -126,6 +126,9 @@ class Chain:
     def set_pipelined(self, on):
         _lib.check(self.lib.rdsp_chain_set_pipelined(self.h, int(bool(on))))
 
+    def set_front_variant(self, lean):
+        _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
+
     def flush(self, stream=None):
         _lib.check(self.lib.rdsp_chain_flush(self.h, _stream_ptr(stream)))
 

@@ -75,6 +75,7 @@ struct rdsp_chain {
   std::vector<hipEvent_t> ev; /* pool, groups of 4: front begin/end, tail begin/end */
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
+  int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int audio_filter = RDSP_AUDIO_2700;
 };
@@ -381,6 +382,8 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   const bool piped = tail && c->pipe_on;
   const int slot = (int)(c->call_idx & 1);
   hipStream_t tstream = piped ? c->s_tail : stream;
+  /* the lean variant leaves registers and LDS for the concurrent tail kernel */
+  fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
   if (piped) {
     fp.mid = slot ? c->d_mid2 : c->d_mid;
     /* the tail of call k-2 read this intermediate buffer: wait for it */
@@ -596,6 +599,15 @@ extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   }
   c->pipe_on = on ? 1 : 0;
   c->call_idx = 0;
+  return RDSP_OK;
+}
+/* front-kernel variant: -1 = auto (lean when the tail stage runs concurrently),
+ * 0 = full-register, 1 = lean.  Both compute the same chain; they differ in the
+ * rounding of the FFT twiddles (power chain vs direct), ~3e-7. */
+extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
+  NEED(c);
+  if (lean < -1 || lean > 1) return RDSP_ERR_INVALID;
+  c->lean_mode = lean;
   return RDSP_OK;
 }
 /* `stream` waits for every call issued so far (outputs complete after it) */

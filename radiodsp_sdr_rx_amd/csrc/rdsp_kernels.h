@@ -34,6 +34,7 @@ struct RdspFrontParams {
   int vad_lo, vad_hi;      /* inclusive natural bin range                    */
   int demod;               /* RDSP_K_DEMOD_*                                 */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
+  int lean;                /* 1: register-lean variant (co-resident with the tail kernel) */
   int agc_on;
   float agc_attack, agc_decay;
   float out_gain;

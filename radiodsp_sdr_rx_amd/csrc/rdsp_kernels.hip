@@ -23,10 +23,6 @@
  */
 #include "rdsp_front.h"
 
-#ifndef RDSP_FRONT_LEAN_ALL
-#define RDSP_FRONT_LEAN_ALL 0
-#endif
-
 using namespace rdsp;
 
 namespace {
@@ -80,17 +76,15 @@ struct FrontLds {
   static constexpr int TAPS_N = (DECIM == 4) ? 128 : 0;
   static constexpr size_t BYTES = (size_t)(XS_N + HB_N + WB_N + TAPS_N) * sizeof(float2) + 64 * sizeof(float);
 };
-/* LEAN = trade registers for recomputation (twiddle power chains, mask slice
- * re-read per chunk) where that buys residency */
-template <int N, int P>
-struct FrontLean {
-  static constexpr bool value = RDSP_FRONT_LEAN_ALL || (P == 16);
-};
-
 /* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
- * mask slice re-read per chunk); it pays when it buys a wave per SIMD (radix 16). */
-template <int N, int P, int DECIM>
-__global__ void __launch_bounds__(N / P, ((RDSP_FRONT_LEAN_ALL && P <= 8) ? 3 : 2)) rdsp_front_kernel(RdspFrontParams p) {
+ * mask slice re-read per chunk): ~173 instead of ~237 VGPRs at radix 8.  It pays
+ * (a) at radix 16, where it buys the second wave per SIMD, and (b) whenever the
+ * serial tail kernel runs concurrently (pipelined mode): two lean front waves plus
+ * one tail wave fit the 512-register file of a SIMD, so the latency-bound
+ * instruction stream of the tail fills issue slots the front leaves idle.  Alone, the
+ * full-register variant is ~15 % faster, so the launch code picks per call. */
+template <int N, int P, int DECIM, bool LEAN>
+__global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
   constexpr int NW = NT / 64;
@@ -104,7 +98,6 @@ __global__ void __launch_bounds__(N / P, ((RDSP_FRONT_LEAN_ALL && P <= 8) ? 3 : 
   using LY = FrontLds<N, P, DECIM>;
   constexpr bool ALIAS = LY::ALIAS;
   constexpr int LP = (CH_IN / 4 + NT - 1) / NT; /* uint4 loads per thread per chunk */
-  constexpr bool LEAN = FrontLean<N, P>::value;
   static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
   static_assert(NT == 64 || NT == 256, "one or four waves per channel");
   static_assert(NW == 1 || PL::WB >= 4 * CH_OUT, "work buffer holds the FIR partial sums");
@@ -712,18 +705,24 @@ constexpr size_t front_lds() {
   return FrontLds<N, P, DECIM>::BYTES;
 }
 
-template <int N, int P, int DECIM>
-int launch_front_t(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+template <int N, int P, int DECIM, bool LEAN>
+int launch_front_v(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   constexpr size_t lds = front_lds<N, P, DECIM>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
+}
+template <int N, int P, int DECIM>
+int launch_front_t(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  if constexpr (P == 16) return launch_front_v<N, P, DECIM, true>(p, n_channels, stream);
+  else return p->lean ? launch_front_v<N, P, DECIM, true>(p, n_channels, stream)
+                      : launch_front_v<N, P, DECIM, false>(p, n_channels, stream);
 }
 
 }  // namespace

@@ -260,6 +260,7 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
     parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
              for k in range(calls)]
     ref_chain = Chain(nch, max_blocks_per_call=nblk, **K3)
+    ref_chain.set_front_variant(1)  # pipelined mode picks the register-lean front kernel
     ref = [ref_chain.process(p).cpu().numpy() for p in parts]
     ch = Chain(nch, max_blocks_per_call=nblk, **K3)
     ch.set_pipelined(True)
@@ -272,6 +273,21 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
         assert np.array_equal(a, b.cpu().numpy())
     assert np.array_equal(ref_chain.scalars(), ch.scalars())
     assert np.array_equal(ref_chain.lms_coeffs(1), ch.lms_coeffs(1))
+
+
+def test_front_kernel_variants_agree(rdsp, oracle, torch_cuda):
+    """The full-register and the register-lean front kernels are the same chain with
+    differently rounded FFT twiddles: both meet TOL against the oracle."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, agc_mode="medium")
+    iq = synth_iq(4, 32 * 128)
+    _, r32 = oracle_run(oracle, iq, cfg)
+    for lean in (0, 1):
+        ch = Chain(4, max_blocks_per_call=32, **cfg)
+        ch.set_front_variant(lean)
+        f = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)[1].cpu().numpy()
+        assert normwise(f, r32) <= TOL, lean
 
 
 def test_channel_partition_invariance(rdsp, torch_cuda):
