@@ -22,6 +22,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# algorithmic flops per input IQ sample: direct 256-tap /4 FIR 256, mixer ~14,
+# overlap-save FFT pair + mask 42-62, spectral NR ~8, NLMS 96, AGC/pack ~2
+FLOP_PER_SAMPLE = {"K2": 256 + 14 + 42 + 2, "K3": 256 + 14 + 47 + 8 + 96 + 2, "K4": 256 + 14 + 62 + 2, "K5": 256 + 14 + 47 + 8 + 96 + 2}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3
 
@@ -153,6 +156,18 @@ def main():
     barrier()
     front_ms, tail_ms, calls = chain.get_timing()
     chain.set_timing(False)
+    # extra, un-timed: the same kernels back to back without overlap (reference durations)
+    iso = None
+    if not args.no_kernel_timing and not args.no_pipeline:
+        chain.set_pipelined(False)
+        chain.set_front_variant(-1)
+        chain.set_timing(True)
+        for _ in range(min(args.steps, 5)):
+            chain.process(iq, out=out)
+        torch.cuda.synchronize()
+        f2, t2, n2 = chain.get_timing()
+        chain.set_timing(False)
+        iso = {"rdsp_front_kernel": f2 / max(n2, 1), "rdsp_tail_kernel": t2 / max(n2, 1)}
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -204,6 +219,10 @@ def main():
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
                           "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS},
             "kernels_ms_per_step": {"rdsp_front_kernel": front_avg, "rdsp_tail_kernel": tail_avg},
+            "kernels_ms_isolated": iso,
+            "fp32_valu": {"flop_per_sample_model": FLOP_PER_SAMPLE.get(args.config), "peak_TFLOPs": FP32_PEAK_TFLOPS,
+                          "achieved_TFLOPs": (FLOP_PER_SAMPLE.get(args.config, 0) * value * 1e6 / 1e12 / world),
+                          "note": "SURVEY Appendix D flop model; the chain is fp32-VALU-bound before it is HBM-bound"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
             "input_gen_s": gen_s,

@@ -384,6 +384,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   hipStream_t tstream = piped ? c->s_tail : stream;
   /* the lean variant leaves registers and LDS for the concurrent tail kernel */
   fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
+  fp.front_prio = piped ? 1 : 0;
   if (piped) {
     fp.mid = slot ? c->d_mid2 : c->d_mid;
     /* the tail of call k-2 read this intermediate buffer: wait for it */

@@ -35,6 +35,7 @@ struct RdspFrontParams {
   int demod;               /* RDSP_K_DEMOD_*                                 */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
   int lean;                /* 1: register-lean variant (co-resident with the tail kernel) */
+  int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
   int agc_on;
   float agc_attack, agc_decay;
   float out_gain;

@@ -231,7 +231,12 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[r] = make_float2(0.f, 0.f);
       if constexpr (NW == 1) {
+        /* when a tail-kernel wave shares the SIMD (pipelined mode), the FIR -- the
+         * throughput-bound part -- takes issue priority; the rest of the chunk runs at
+         * normal priority so the latency-bound tail keeps pace (measured balance) */
+        if (p.front_prio > 0) __builtin_amdgcn_s_setprio(2);
         fir_lane(lane, 0, 4, xs, taps_lds, acc);
+        if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int r = 0; r < 4; r++) hb[(chunk % CPF) * CH_OUT + 4 * lane + r] = acc[r];
         __syncthreads();
