@@ -396,3 +396,49 @@ def test_full_size_k3_sampled_channels(rdsp, oracle, torch_cuda):
     # every channel produced finite, non-trivial audio under AGC
     pw = o32[..., 0].float().pow(2).mean(dim=1)
     assert bool(torch.isfinite(pw).all()) and float(pw.min()) > 1e-6
+
+
+def test_full_size_k4_sampled_channels(rdsp, oracle, torch_cuda):
+    """8192 channels, CW, FFT_L = 4096 (2049-tap overlap-save) + AGC: sampled channels
+    against the oracle at the BASELINE channel count."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, nblk = 8192, 128
+    iq = synth_iq(nch, nblk * 128, cw=True)
+    ch = Chain(nch, max_blocks_per_call=nblk, **K4)
+    o16, o32 = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)
+    torch.cuda.synchronize()
+    sample = [0, 1, 4095, 4096, 8190, 8191]
+    r16, r32 = oracle_run(oracle, iq[sample], K4)
+    assert normwise(o32[sample].cpu().numpy(), r32) <= TOL
+    check_i16(o16[sample].cpu().numpy(), r16)
+    g = ch.scalars()[:, 1]
+    assert np.isfinite(g).all() and (g > 0).all()
+
+
+def test_long_stream_many_calls_stays_on_the_oracle(rdsp, oracle, torch_cuda):
+    """40 consecutive calls (state carried in HBM the whole time, pipelined mode on):
+    no drift against the oracle on a feed-forward chain, AGC gain and NFloor included."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, agc_mode="slow", output_gain=0.5)
+    nch, nblk, calls = 3, 16, 40
+    iq = synth_iq(nch, nblk * 128 * calls)
+    ch = Chain(nch, max_blocks_per_call=nblk, **cfg)
+    ch.set_pipelined(True)
+    outs = []
+    for k in range(calls):
+        part = torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
+        outs.append(ch.process(part, want_f32=True)[1])
+    ch.flush()
+    torch.cuda.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+    _, r32 = oracle_run(oracle, iq, cfg)
+    per_call = np.abs(got - r32).max(axis=2).reshape(nch, calls, -1).max(axis=2) / np.abs(r32).max()
+    assert (per_call > TOL).mean() < 0.03 and per_call.max() < 5e-3  # stray spectral-threshold flips only
+    sc = ch.scalars()
+    for c in range(nch):
+        oc = oracle.OracleChain(**cfg)
+        oc.process(iq[c])
+        assert abs(sc[c, 0] - oc.nfloor()) <= 5e-6 * oc.nfloor()
+        assert abs(sc[c, 1] - oc.agc_gain()) <= 1e-4 * oc.agc_gain()
