@@ -244,6 +244,21 @@ rdsp_node_t *rdsp_sdr_node_create(rdsp_graph_t *g, rdsp_chain_t *chain);
 int rdsp_sdr_node_status(rdsp_node_t *n);
 int rdsp_chain_decim(const rdsp_chain_t *c);
 
+/* ---- F1: IQ panadapter spectrum analyser (AudioAnalyzeFFT256IQ, FFTIQ.h:52-110) ----
+ * Integer q15 path batched over channels; bit-exact against the oracle.  window_id:
+ * 0 none, 1 Hann, 2 Blackman-Harris (build-defined q15 tables: Teensy windows.c is not
+ * in the tree).  read(bin) of the reference is output[bin] * (1.0 / 16384.0). */
+typedef struct rdsp_spectrum rdsp_spectrum_t;
+void rdsp_window_q15(int window_id, int16_t *w256);
+int rdsp_spectrum_create(int n_channels, int device, int naverage, int window_id, rdsp_spectrum_t **out);
+void rdsp_spectrum_destroy(rdsp_spectrum_t *s);
+int rdsp_spectrum_averageTogether(rdsp_spectrum_t *s, int n);      /* FFTIQ.h:88 */
+int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id); /* FFTIQ.h:93 */
+int rdsp_spectrum_outputs_for(const rdsp_spectrum_t *s, int n_blocks);
+/* n_blocks update() ticks (FFTIQ.cpp:65); d_out uint16 [n_channels][out_stride][256] */
+int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, size_t in_stride, int n_blocks,
+                         uint16_t *d_out, size_t out_stride, int *n_outputs, void *stream);
+
 /* ---- deterministic synthetic IQ generator (host) -------------------*/
 typedef struct {
   double fs;        /* 96000 */

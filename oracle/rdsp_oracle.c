@@ -601,3 +601,129 @@ int orc_multi_process(const orc_config_t *cfg, int n_ch, const int16_t *iq,
   }
   return produced;
 }
+
+/* ======================================================================== */
+/* F1: IQ panadapter spectrum, analyze_fft256iq.cpp (FFTIQ)                   */
+/* ======================================================================== */
+
+/* q15 window tables (Teensy windows.c is not in the tree): build-defined as
+ * w[i] = lround(32767 * window(i / 256)) */
+void orc_window_q15(int window_id, int16_t *w) {
+  for (int i = 0; i < 256; i++) {
+    double t = ORC_TWO_PI * (double)i / 256.0, v;
+    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
+    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
+    else v = 1.0;
+    long q = lround(32767.0 * v);
+    w[i] = (int16_t)(q > 32767 ? 32767 : q);
+  }
+}
+
+static inline int32_t sat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+
+/* arm_cfft_radix4_q15 role (FFTIQ.cpp:82, init 256/forward/bit-reverse FFTIQ.h:58):
+ * build-defined fixed-point radix-4 decimation-in-frequency, four stages, every
+ * butterfly output >> 2 (total 1/256), twiddles lround(32767*cos/sin), products
+ * >> 15 with saturation to int16, result in natural bin order. */
+void orc_cfft_radix4_q15_256(int16_t *buf) {
+  int32_t re[256], im[256];
+  for (int i = 0; i < 256; i++) { re[i] = buf[2 * i]; im[i] = buf[2 * i + 1]; }
+  for (int L = 64; L >= 1; L >>= 2) { /* span between the four butterfly inputs */
+    for (int g = 0; g < 256; g += 4 * L) {
+      for (int j = 0; j < L; j++) {
+        int i0 = g + j, i1 = i0 + L, i2 = i0 + 2 * L, i3 = i0 + 3 * L;
+        int32_t s0r = re[i0] + re[i2], s0i = im[i0] + im[i2];
+        int32_t s1r = re[i0] - re[i2], s1i = im[i0] - im[i2];
+        int32_t s2r = re[i1] + re[i3], s2i = im[i1] + im[i3];
+        int32_t s3r = re[i1] - re[i3], s3i = im[i1] - im[i3];
+        int32_t yr[4], yi[4];
+        yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
+        yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2; /* s1 - j*s3 */
+        yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
+        yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2; /* s1 + j*s3 */
+        for (int k = 0; k < 4; k++) {
+          int m = (k * j * (64 / L)) & 255; /* W_256^m, W = exp(-2*pi*i/256) */
+          int32_t wr = (int32_t)lround(32767.0 * cos(ORC_TWO_PI * m / 256.0));
+          int32_t wi = (int32_t)lround(-32767.0 * sin(ORC_TWO_PI * m / 256.0));
+          int32_t pr = (yr[k] * wr - yi[k] * wi) >> 15;
+          int32_t pi = (yr[k] * wi + yi[k] * wr) >> 15;
+          re[g + j + k * L] = sat16(pr);
+          im[g + j + k * L] = sat16(pi);
+        }
+      }
+    }
+  }
+  /* position p holds bin digit-reverse_4(p) */
+  for (int p = 0; p < 256; p++) {
+    int k = ((p & 3) << 6) | (((p >> 2) & 3) << 4) | (((p >> 4) & 3) << 2) | ((p >> 6) & 3);
+    buf[2 * k] = (int16_t)re[p];
+    buf[2 * k + 1] = (int16_t)im[p];
+  }
+}
+
+/* sqrt_uint32_approx role (FFTIQ.cpp:105): build-defined as the exact floor(sqrt(x)) */
+uint32_t orc_sqrt_uint32(uint32_t x) {
+  uint32_t r = (uint32_t)sqrt((double)x);
+  while ((uint64_t)r * r > x) r--;
+  while ((uint64_t)(r + 1) * (r + 1) <= x) r++;
+  return r;
+}
+
+struct orc_fft256iq {
+  int16_t window[256];
+  int has_window;
+  int16_t prev_i[128], prev_q[128];
+  int have_prev;
+  int16_t buffer[512]; /* FFTIQ.h:103 */
+  uint32_t sum[256];   /* FFTIQ.h:104 */
+  uint8_t count, naverage;
+  uint16_t output[256]; /* FFTIQ.h:99 */
+};
+
+orc_fft256iq_t *orc_fft256iq_create(int naverage, int window_id) {
+  orc_fft256iq_t *s = (orc_fft256iq_t *)calloc(1, sizeof(*s));
+  s->naverage = (uint8_t)(naverage <= 0 ? 1 : naverage); /* averageTogether, FFTIQ.h:88-91 */
+  s->has_window = window_id != 0;
+  orc_window_q15(window_id, s->window);
+  return s;
+}
+void orc_fft256iq_destroy(orc_fft256iq_t *s) { free(s); }
+const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s) { return s->output; }
+
+int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *bi, const int16_t *bq) {
+  if (!s->have_prev) { /* FFTIQ.cpp:73-77 */
+    memcpy(s->prev_i, bi, sizeof(s->prev_i));
+    memcpy(s->prev_q, bq, sizeof(s->prev_q));
+    s->have_prev = 1;
+    return 0;
+  }
+  /* copy_to_fft_buffer, FFTIQ.cpp:38-48: word = I | Q << 16 */
+  for (int i = 0; i < 128; i++) {
+    s->buffer[2 * i] = s->prev_i[i];
+    s->buffer[2 * i + 1] = s->prev_q[i];
+    s->buffer[256 + 2 * i] = bi[i];
+    s->buffer[256 + 2 * i + 1] = bq[i];
+  }
+  if (s->has_window) { /* apply_window_to_fft_buffer, FFTIQ.cpp:50-63 */
+    for (int i = 0; i < 256; i++) {
+      s->buffer[2 * i] = (int16_t)(((int32_t)s->buffer[2 * i] * s->window[i]) >> 15);
+      s->buffer[2 * i + 1] = (int16_t)(((int32_t)s->buffer[2 * i + 1] * s->window[i]) >> 15);
+    }
+  }
+  orc_cfft_radix4_q15_256(s->buffer); /* FFTIQ.cpp:82 */
+  for (int i = 0; i < 256; i++) { /* FFTIQ.cpp:86-98 */
+    int32_t r = s->buffer[2 * i], q = s->buffer[2 * i + 1];
+    uint32_t magsq = (uint32_t)(r * r + q * q); /* multiply_16tx16t_add_16bx16b */
+    if (s->count == 0) s->sum[i] = magsq / s->naverage;
+    else s->sum[i] += magsq / s->naverage;
+  }
+  int fresh = 0;
+  if (++s->count == s->naverage) { /* FFTIQ.cpp:99-113 */
+    s->count = 0;
+    for (int i = 0; i < 256; i++) s->output[255 - (i ^ 128)] = (uint16_t)orc_sqrt_uint32(s->sum[i]);
+    fresh = 1;
+  }
+  memcpy(s->prev_i, bi, sizeof(s->prev_i)); /* FFTIQ.cpp:114-117 */
+  memcpy(s->prev_q, bq, sizeof(s->prev_q));
+  return fresh;
+}

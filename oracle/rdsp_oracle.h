@@ -133,3 +133,27 @@ int orc_multi_process(const orc_config_t *cfg, int n_ch, const int16_t *iq,
 }
 #endif
 #endif
+
+/* ---- F1: IQ panadapter spectrum (analyze_fft256iq.{h,cpp}) -----------------------
+ * Restatement of AudioAnalyzeFFT256IQ::update (FFTIQ.cpp:65-118).  The pieces that
+ * live outside the tree are build-defined and integer-exact: the q15 window table
+ * (Teensy windows.c), arm_cfft_radix4_q15 (CMSIS) and sqrt_uint32_approx (Teensy
+ * utility/sqrt_integer.h) -- see oracle/rdsp_oracle.c. */
+#ifndef RDSP_ORACLE_SPECTRUM
+#define RDSP_ORACLE_SPECTRUM
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct orc_fft256iq orc_fft256iq_t;
+void orc_window_q15(int window_id, int16_t *w256);           /* 0 none, 1 Hann, 2 Blackman-Harris */
+void orc_cfft_radix4_q15_256(int16_t *buf /* 512: re,im */); /* scaled by 1/256, natural order */
+uint32_t orc_sqrt_uint32(uint32_t x);
+orc_fft256iq_t *orc_fft256iq_create(int naverage, int window_id);
+void orc_fft256iq_destroy(orc_fft256iq_t *s);
+/* one update() tick with a 128-sample I block and Q block; returns 1 when output[] was refreshed */
+int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *block_i, const int16_t *block_q);
+const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s); /* uint16 output[256], FFTIQ.h:99 */
+#ifdef __cplusplus
+}
+#endif
+#endif

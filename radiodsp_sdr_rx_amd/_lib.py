@@ -150,6 +150,13 @@ SYMBOLS = [
     ("rdsp_sdr_node_create", _vp, [_vp, _vp]),
     ("rdsp_sdr_node_status", _i, [_vp]),
     ("rdsp_chain_decim", _i, [_vp]),
+    ("rdsp_window_q15", None, [_i, _i16p]),
+    ("rdsp_spectrum_create", _i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    ("rdsp_spectrum_destroy", None, [_vp]),
+    ("rdsp_spectrum_averageTogether", _i, [_vp, _i]),
+    ("rdsp_spectrum_windowFunction", _i, [_vp, _i]),
+    ("rdsp_spectrum_outputs_for", _i, [_vp, _i]),
+    ("rdsp_spectrum_update", _i, [_vp, _vp, _sz, _i, _vp, _sz, C.POINTER(C.c_int), _vp]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
 

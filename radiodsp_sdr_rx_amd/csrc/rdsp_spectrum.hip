@@ -1,0 +1,328 @@
+/*
+ * rdsp_spectrum.hip -- SURVEY 8f row F1: the IQ panadapter spectrum analyser
+ * (AudioAnalyzeFFT256IQ, analyze_fft256iq.{h,cpp}) batched over channels.
+ * Integer q15 path, bit-exact against the CPU restatement kept with the tests: pack I | Q << 16
+ * (FFTIQ.cpp:38-48), q15 window (x*w) >> 15 (:50-63), 256-point fixed-point
+ * radix-4 FFT (arm_cfft_radix4_q15 role, :82), |.|^2 / naverage accumulation
+ * (:86-98), integer sqrt and the output[255 - (i ^ 128)] reorder (:99-113).
+ *
+ * One wave per channel: lane t owns the four inputs t + 64k of a 256-point frame
+ * ([previous block | current block], so the previous block simply stays in two
+ * registers), runs one radix-4 butterfly per stage and exchanges packed int16
+ * pairs through LDS between the four stages.  The interleaved int16 IQ stream is
+ * already the packed word the reference builds, so the only HBM traffic is one
+ * coalesced 4-byte read per input sample.
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rdsp_host.h"
+
+struct RdspSpecParams {
+  const uint32_t *iq; /* [ch][in_stride] I | Q << 16 */
+  size_t in_stride;
+  int n_blocks;
+  int have_prev; /* 0: the very first block only primes prevblock (FFTIQ.cpp:73-77) */
+  int count0;    /* `count` at entry (FFTIQ.h:105) */
+  int naverage;
+  int use_window;
+  const int16_t *window;  /* [256] q15 */
+  const uint32_t *twid;   /* [256] wr | wi << 16, W_256^m */
+  uint32_t *st_prev;      /* [ch][128] previous block */
+  uint32_t *st_sum;       /* [ch][256] sum[], position order */
+  uint16_t *out;          /* [ch][out_stride][256] */
+  size_t out_stride;      /* spectra per channel row */
+};
+
+namespace {
+__device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+__device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ int hi16(uint32_t w) { return (int)(int16_t)(w >> 16); }
+__device__ __forceinline__ uint32_t pack16(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
+
+/* one fixed-point radix-4 butterfly: x[k] (packed) -> y[k] = ((sum) >> 2) * W^{m_k} >> 15, saturated */
+__device__ __forceinline__ void bfly(uint32_t *x, const uint32_t *tw) {
+  int ar = lo16(x[0]), ai = hi16(x[0]), br = lo16(x[1]), bi = hi16(x[1]);
+  int cr = lo16(x[2]), ci = hi16(x[2]), dr = lo16(x[3]), di = hi16(x[3]);
+  int s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+  int s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
+  int yr[4], yi[4];
+  yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
+  yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2;
+  yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
+  yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int wr = lo16(tw[k]), wi = hi16(tw[k]);
+    int pr = (yr[k] * wr - yi[k] * wi) >> 15;
+    int pi = (yr[k] * wi + yi[k] * wr) >> 15;
+    x[k] = pack16(sat16(pr), sat16(pi));
+  }
+}
+
+__device__ __forceinline__ uint32_t isqrt32(uint32_t x) {
+  uint32_t r = (uint32_t)sqrtf((float)x);
+  while ((unsigned long long)r * r > x) r--;
+  while ((unsigned long long)(r + 1) * (r + 1) <= x) r++;
+  return r;
+}
+
+__global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
+  __shared__ uint32_t ex[256];
+  const int t = threadIdx.x;
+  const size_t ch = blockIdx.x;
+  const uint32_t *iq = p.iq + ch * p.in_stride;
+
+  /* per-lane constants: twiddles of stages 1..3 (stage 4 has j = 0), window taps */
+  uint32_t tw[4][4];
+#pragma unroll
+  for (int st = 0; st < 4; st++) {
+    const int L = 64 >> (2 * st);
+    const int j = t % L;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tw[st][k] = p.twid[(k * j * (64 / L)) & 255];
+  }
+  int win[4] = {32767, 32767, 32767, 32767};
+  if (p.use_window) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) win[k] = p.window[t + 64 * k];
+  }
+  /* bin of the position 4t + k this lane ends with: base-4 digit reversal */
+  const int rbase = ((t & 3) << 4) | (((t >> 2) & 3) << 2) | ((t >> 4) & 3);
+
+  uint32_t prev0 = p.st_prev[ch * 128 + t], prev1 = p.st_prev[ch * 128 + 64 + t];
+  uint32_t sum[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) sum[k] = p.st_sum[ch * 256 + 4 * t + k];
+  int count = p.count0;
+  int n_out = 0;
+  int b = 0;
+  if (!p.have_prev && p.n_blocks > 0) { /* FFTIQ.cpp:73-77 */
+    prev0 = iq[t];
+    prev1 = iq[64 + t];
+    b = 1;
+  }
+  uint32_t cur0 = 0, cur1 = 0;
+  if (b < p.n_blocks) { cur0 = iq[(size_t)b * 128 + t]; cur1 = iq[(size_t)b * 128 + 64 + t]; }
+  for (; b < p.n_blocks; b++) {
+    uint32_t x[4] = {prev0, prev1, cur0, cur1}; /* copy_to_fft_buffer, FFTIQ.cpp:78-79 */
+    prev0 = cur0;                                /* FFTIQ.cpp:116-117 */
+    prev1 = cur1;
+    if (b + 1 < p.n_blocks) { /* next block's words land while this frame computes */
+      cur0 = iq[(size_t)(b + 1) * 128 + t];
+      cur1 = iq[(size_t)(b + 1) * 128 + 64 + t];
+    }
+    if (p.use_window) { /* FFTIQ.cpp:50-63 */
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        x[k] = pack16((lo16(x[k]) * win[k]) >> 15, (hi16(x[k]) * win[k]) >> 15);
+    }
+    /* four stages, span L = 64, 16, 4, 1; positions base + k*L */
+    bfly(x, tw[0]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ex[t + 64 * k] = x[k];
+    __syncthreads();
+    {
+      const int base = (t / 16) * 64 + (t % 16);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = ex[base + 16 * k];
+      bfly(x, tw[1]);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; k++) ex[base + 16 * k] = x[k];
+    }
+    __syncthreads();
+    {
+      const int base = (t / 4) * 16 + (t % 4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = ex[base + 4 * k];
+      bfly(x, tw[2]);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; k++) ex[base + 4 * k] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = ex[4 * t + k];
+    bfly(x, tw[3]);
+    __syncthreads();
+    /* FFTIQ.cpp:86-98 */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int r = lo16(x[k]), q = hi16(x[k]);
+      uint32_t magsq = (uint32_t)(r * r + q * q);
+      uint32_t term = magsq / (uint32_t)p.naverage;
+      sum[k] = (count == 0) ? term : sum[k] + term;
+    }
+    if (++count == p.naverage) { /* FFTIQ.cpp:99-113 */
+      count = 0;
+      uint16_t *o = p.out + (ch * p.out_stride + (size_t)n_out) * 256;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int bin = 64 * k + rbase;
+        o[255 - (bin ^ 128)] = (uint16_t)isqrt32(sum[k]);
+      }
+      n_out++;
+    }
+  }
+  p.st_prev[ch * 128 + t] = prev0;
+  p.st_prev[ch * 128 + 64 + t] = prev1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) p.st_sum[ch * 256 + 4 * t + k] = sum[k];
+}
+}  // namespace
+
+/* ---- host side -------------------------------------------------------------- */
+struct rdsp_spectrum {
+  int n_channels, device;
+  int naverage, window_id;
+  int have_prev, count;
+  int16_t *d_window = nullptr;
+  uint32_t *d_twid = nullptr, *d_prev = nullptr, *d_sum = nullptr;
+};
+
+/* build-defined q15 window tables (Teensy windows.c is not in the tree) */
+extern "C" void rdsp_window_q15(int window_id, int16_t *w) {
+  const double two_pi = 6.28318530717958647692;
+  for (int i = 0; i < 256; i++) {
+    double t = two_pi * (double)i / 256.0, v;
+    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
+    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
+    else v = 1.0;
+    long q = lround(32767.0 * v);
+    w[i] = (int16_t)(q > 32767 ? 32767 : q);
+  }
+}
+
+#define SPEC_TRY(expr)                                                          \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      rdsp_set_error("%s failed: %s", #expr, hipGetErrorString(e_));            \
+      return RDSP_ERR_HIP;                                                      \
+    }                                                                           \
+  } while (0)
+
+static int upload_window(rdsp_spectrum_t *s) {
+  int16_t w[256];
+  rdsp_window_q15(s->window_id, w);
+  SPEC_TRY(hipMemcpy(s->d_window, w, sizeof(w), hipMemcpyHostToDevice));
+  return RDSP_OK;
+}
+
+/* AudioAnalyzeFFT256IQ(), FFTIQ.h:55-60 (default window there: BlackmanNuttall, naverage 8) */
+extern "C" int rdsp_spectrum_create(int n_channels, int device, int naverage, int window_id,
+                                    rdsp_spectrum_t **out) {
+  if (!out || n_channels <= 0 || naverage > 255) {
+    rdsp_set_error("rdsp_spectrum_create: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  if (rdsp_device_count() <= 0) {
+    rdsp_set_error("no HIP device: the rdsp product path has no CPU fallback");
+    return RDSP_ERR_NO_DEVICE;
+  }
+  rdsp_spectrum_t *s = new rdsp_spectrum();
+  s->n_channels = n_channels;
+  s->device = device;
+  s->naverage = naverage <= 0 ? 1 : naverage; /* averageTogether, FFTIQ.h:88-91 */
+  s->window_id = window_id;
+  s->have_prev = 0;
+  s->count = 0;
+  SPEC_TRY(hipSetDevice(device));
+  SPEC_TRY(hipMalloc((void **)&s->d_window, 256 * sizeof(int16_t)));
+  SPEC_TRY(hipMalloc((void **)&s->d_twid, 256 * sizeof(uint32_t)));
+  SPEC_TRY(hipMalloc((void **)&s->d_prev, (size_t)n_channels * 128 * sizeof(uint32_t)));
+  SPEC_TRY(hipMalloc((void **)&s->d_sum, (size_t)n_channels * 256 * sizeof(uint32_t)));
+  SPEC_TRY(hipMemset(s->d_prev, 0, (size_t)n_channels * 128 * sizeof(uint32_t)));
+  SPEC_TRY(hipMemset(s->d_sum, 0, (size_t)n_channels * 256 * sizeof(uint32_t)));
+  uint32_t tw[256];
+  const double two_pi = 6.28318530717958647692;
+  for (int m = 0; m < 256; m++) {
+    int wr = (int)lround(32767.0 * cos(two_pi * m / 256.0));
+    int wi = (int)lround(-32767.0 * sin(two_pi * m / 256.0));
+    tw[m] = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
+  }
+  SPEC_TRY(hipMemcpy(s->d_twid, tw, sizeof(tw), hipMemcpyHostToDevice));
+  int rc = upload_window(s);
+  if (rc != RDSP_OK) return rc;
+  *out = s;
+  return RDSP_OK;
+}
+
+extern "C" void rdsp_spectrum_destroy(rdsp_spectrum_t *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  (void)hipFree(s->d_window);
+  (void)hipFree(s->d_twid);
+  (void)hipFree(s->d_prev);
+  (void)hipFree(s->d_sum);
+  delete s;
+}
+
+extern "C" int rdsp_spectrum_averageTogether(rdsp_spectrum_t *s, int n) { /* FFTIQ.h:88-91 */
+  if (!s || n > 255) return RDSP_ERR_INVALID;
+  s->naverage = n <= 0 ? 1 : n;
+  return RDSP_OK;
+}
+extern "C" int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id) { /* FFTIQ.h:93-95 */
+  if (!s) return RDSP_ERR_INVALID;
+  SPEC_TRY(hipSetDevice(s->device));
+  SPEC_TRY(hipDeviceSynchronize());
+  s->window_id = window_id;
+  return upload_window(s);
+}
+
+/* number of spectra the next update over n_blocks will produce */
+extern "C" int rdsp_spectrum_outputs_for(const rdsp_spectrum_t *s, int n_blocks) {
+  if (!s || n_blocks <= 0) return 0;
+  const int frames = n_blocks - (s->have_prev ? 0 : 1);
+  return (s->count + frames) / s->naverage;
+}
+
+/* n_blocks update() ticks for every channel (FFTIQ.cpp:65-118).  d_iq: int16
+ * [n_channels][in_stride][2]; d_out: uint16 [n_channels][out_stride][256] receives
+ * the spectra completed in this call (`available()` became true that many times). */
+extern "C" int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, size_t in_stride,
+                                    int n_blocks, uint16_t *d_out, size_t out_stride,
+                                    int *n_outputs, void *stream) {
+  if (!s || !d_iq || n_blocks <= 0 || in_stride < (size_t)n_blocks * 128) {
+    rdsp_set_error("rdsp_spectrum_update: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  const int nout = rdsp_spectrum_outputs_for(s, n_blocks);
+  if (nout > 0 && (!d_out || out_stride < (size_t)nout)) {
+    rdsp_set_error("rdsp_spectrum_update: output buffer holds %zu spectra per channel, %d needed", out_stride, nout);
+    return RDSP_ERR_INVALID;
+  }
+  SPEC_TRY(hipSetDevice(s->device));
+  RdspSpecParams p;
+  memset(&p, 0, sizeof(p));
+  p.iq = reinterpret_cast<const uint32_t *>(d_iq);
+  p.in_stride = in_stride;
+  p.n_blocks = n_blocks;
+  p.have_prev = s->have_prev;
+  p.count0 = s->count;
+  p.naverage = s->naverage;
+  p.use_window = s->window_id != 0;
+  p.window = s->d_window;
+  p.twid = s->d_twid;
+  p.st_prev = s->d_prev;
+  p.st_sum = s->d_sum;
+  p.out = d_out;
+  p.out_stride = out_stride;
+  hipLaunchKernelGGL(rdsp_spectrum_kernel, dim3(s->n_channels), dim3(64), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    rdsp_set_error("spectrum kernel launch failed: %s", hipGetErrorString(e));
+    return RDSP_ERR_HIP;
+  }
+  const int frames = n_blocks - (s->have_prev ? 0 : 1);
+  s->count = (s->count + frames) % s->naverage;
+  s->have_prev = 1;
+  if (n_outputs) *n_outputs = nout;
+  return RDSP_OK;
+}

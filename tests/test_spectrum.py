@@ -1,0 +1,101 @@
+"""IQ panadapter spectrum analyser (AudioAnalyzeFFT256IQ).
+CPU: known-answer tests of the oracle's integer restatement.  GPU: bit-exact parity of
+the batched kernel through the C-ABI (integer path => exact, split calls included)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+I16P = C.POINTER(C.c_int16)
+
+
+def _olib(oracle):
+    lib = oracle.load()
+    lib.orc_fft256iq_create.restype = C.c_void_p
+    lib.orc_fft256iq_create.argtypes = [C.c_int, C.c_int]
+    lib.orc_fft256iq_destroy.argtypes = [C.c_void_p]
+    lib.orc_fft256iq_update.argtypes = [C.c_void_p, I16P, I16P]
+    lib.orc_fft256iq_update.restype = C.c_int
+    lib.orc_fft256iq_output.restype = C.POINTER(C.c_uint16)
+    lib.orc_fft256iq_output.argtypes = [C.c_void_p]
+    lib.orc_cfft_radix4_q15_256.argtypes = [I16P]
+    lib.orc_window_q15.argtypes = [C.c_int, I16P]
+    lib.orc_sqrt_uint32.argtypes = [C.c_uint32]
+    lib.orc_sqrt_uint32.restype = C.c_uint32
+    return lib
+
+
+def oracle_spectra(lib, iq, naverage, window):
+    """iq int16 [n, 2] (n multiple of 128) -> list of uint16[256] spectra, in order."""
+    s = lib.orc_fft256iq_create(naverage, window)
+    outs = []
+    i = np.ascontiguousarray(iq[:, 0])
+    q = np.ascontiguousarray(iq[:, 1])
+    for b in range(len(iq) // 128):
+        if lib.orc_fft256iq_update(s, i[b * 128:].ctypes.data_as(I16P), q[b * 128:].ctypes.data_as(I16P)):
+            outs.append(np.ctypeslib.as_array(lib.orc_fft256iq_output(s), (256,)).copy())
+    lib.orc_fft256iq_destroy(s)
+    return outs
+
+
+def test_fixed_point_fft_tracks_float_dft(oracle):
+    lib = _olib(oracle)
+    rng = np.random.default_rng(2)
+    x = rng.integers(-20000, 20000, size=(256, 2)).astype(np.int16)
+    buf = x.reshape(-1).copy()
+    lib.orc_cfft_radix4_q15_256(buf.ctypes.data_as(I16P))
+    X = np.fft.fft(x[:, 0].astype(float) + 1j * x[:, 1]) / 256
+    got = buf[0::2] + 1j * buf[1::2]
+    assert np.abs(got - X).max() < 8  # scaled fixed-point: a few LSB of truncation noise
+    assert lib.orc_sqrt_uint32(0) == 0 and lib.orc_sqrt_uint32(15) == 3 and lib.orc_sqrt_uint32(16) == 4
+    assert lib.orc_sqrt_uint32(4294967295) == 65535
+    w = np.zeros(256, np.int16)
+    lib.orc_window_q15(1, w.ctypes.data_as(I16P))
+    assert w[0] == 0 and w[128] == 32767 and np.array_equal(w[1:], w[:0:-1])
+
+
+def test_tone_lands_on_the_reference_bin_order(oracle):
+    """output[255 - (i ^ 128)] (FFTIQ.cpp:105): bin +20 of the IQ stream is index 107;
+    naverage frames are averaged (sum of |X|^2 / n, then sqrt), first block only primes."""
+    lib = _olib(oracle)
+    n = np.arange(128 * 9)
+    x = 8000 * np.exp(2j * np.pi * (20 / 256) * n)
+    iq = np.stack([np.round(x.real), np.round(x.imag)], 1).astype(np.int16)
+    outs = oracle_spectra(lib, iq, 4, 0)
+    assert len(outs) == 2  # 9 blocks -> 8 frames -> 2 outputs
+    assert outs[0].argmax() == 255 - (20 ^ 128) == 107
+    # sum_n (|X|^2 / n) with |X| ~ 8000 - a few LSB; sqrt back to ~ |X|
+    assert abs(int(outs[0][107]) - 8000) < 16
+    assert np.sort(outs[0])[-2] < 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("naverage,window,calls", [(1, "none", 1), (8, "AudioWindowHanning256", 1),
+                                                    (30, "AudioWindowHanning256", 3), (5, "AudioWindowBlackmanHarris256", 4)])
+def test_gpu_spectrum_is_bit_exact(rdsp, oracle, naverage, window, calls):
+    import torch
+    assert torch.cuda.is_available()
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.spectrum import WINDOWS, AnalyzeFFT256IQ
+    lib = _olib(oracle)
+    nch, nblk = 7, 96
+    iq = synth_iq(nch, nblk * 128)
+    iq[3] = np.clip(iq[3].astype(np.int32) * 4, -32768, 32767).astype(np.int16)  # drive saturation paths
+    iq[4, :, :] = -32768
+    fft = AnalyzeFFT256IQ(nch, naverage=naverage, window=window)
+    got = []
+    step = nblk // calls * 128
+    for k in range(calls):
+        part = torch.from_numpy(np.ascontiguousarray(iq[:, k * step:(k + 1) * step])).cuda()
+        o = fft.update(part)
+        torch.cuda.synchronize()
+        got.append(o.cpu().numpy().view(np.uint16))
+    got = np.concatenate(got, axis=1)
+    for c in range(nch):
+        ref = oracle_spectra(lib, iq[c], naverage, WINDOWS[window])
+        assert got.shape[1] == len(ref)
+        assert np.array_equal(got[c], np.stack(ref)) if ref else got.shape[1] == 0
+    if got.shape[1]:
+        assert fft.available() and not fft.available()
+        assert fft.read(0, 300) == 0.0
+        assert fft.read(0, 5) == got[0, -1, 5] / 16384.0
