@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="K3", choices=["K2", "K3", "K4", "K5"])
+    ap.add_argument("--config", default="K3", choices=["K2", "K3", "K4", "K5", "F1"])
     ap.add_argument("--channels-per-gpu", type=int, default=0)
     ap.add_argument("--blocks", type=int, default=512, help="128-sample input blocks per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,6 +58,73 @@ def host_cores(n_gpus):
     except AttributeError:
         avail = os.cpu_count() or 1
     return max(1, min(avail, 16 * max(1, n_gpus)))
+
+
+def f1_cpu_baseline(args):
+    """cpu_baseline leg of the F1 (panadapter) workload: the oracle's integer analyser."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import numpy as np
+    import oracle_lib
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    cores = host_cores(1)
+    lib = C.CDLL(oracle_lib.build(native=True, out_dir="/tmp"))
+    lib.orc_fft256iq_multi.restype = C.c_uint64
+    lib.orc_fft256iq_multi.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int]
+    nblk, nch = 512, cores * 16
+    iq = synth_iq(nch, nblk * 128)
+    best = None
+    for _ in range(2):
+        t = time.perf_counter()
+        lib.orc_fft256iq_multi(30, 1, nch, iq.ctypes.data_as(C.POINTER(C.c_int16)), nblk, cores)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    print(json.dumps({"value": nch * nblk * 128 / best / 1e6, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
+                      "sample": f"{nch} channels x {nblk} blocks, AudioAnalyzeFFT256IQ restatement, naverage 30, Hann, "
+                                f"gcc -O3 -march=native, OpenMP over channels, best of 2"}))
+
+
+def f1_main(args):
+    """IQ panadapter spectrum analyser batched over channels."""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    assert torch.cuda.is_available()
+    nch, nblk = args.channels_per_gpu or 4096, args.blocks
+    iq = torch.from_numpy(synth_iq(nch, nblk * 128, n_threads=host_cores(1))).cuda()
+    fft = AnalyzeFFT256IQ(nch, naverage=30, window="AudioWindowHanning256")  # INO:144-145
+    for _ in range(args.warmup):
+        fft.update(iq)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fft.update(iq)
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    samples = nch * nblk * 128
+    value = samples * args.steps / elapsed / 1e6
+    achieved = 4.0 * samples / (kms * 1e-3) / 1e9
+    res = {"metric": "IQ Msamples/s through the IQ panadapter spectrum analyser (SURVEY 8f row F1)", "value": value,
+           "unit": "IQ Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "q15", "data": "synthetic",
+           "config": {"workload": f"F1: {nch} channels x {nblk} blocks of 128 int16 IQ samples per step; 256-pt q15 "
+                                  "radix-4 FFT per block pair, Hann window, 30-frame power average, integer sqrt"},
+           "roofline": {"bound": "hbm", "kernel": "rdsp_spectrum_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "note": "algorithmic bytes = 4 B per input sample (the spectra written are < 0.1 %)"}}
+    if not args.no_cpu_baseline:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", "F1"],
+                               capture_output=True, text=True, timeout=600)
+            res["cpu_baseline"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:
+            res["cpu_baseline"] = {"value": None, "unit": "IQ Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(res))
 
 
 def cpu_baseline_worker(args):
@@ -100,7 +167,9 @@ def cpu_baseline_worker(args):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args)
+        return f1_cpu_baseline(args) if args.config == "F1" else cpu_baseline_worker(args)
+    if args.config == "F1":
+        return f1_main(args)
 
     import numpy as np
     import torch

@@ -727,3 +727,31 @@ int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *bi, const int16_t *bq)
   memcpy(s->prev_q, bq, sizeof(s->prev_q));
   return fresh;
 }
+
+/* many channels of the F1 analyser (cpu_baseline leg); returns a checksum of the
+ * last spectrum of every channel so the work cannot be optimised away */
+uint64_t orc_fft256iq_multi(int naverage, int window_id, int n_ch, const int16_t *iq, int n_blocks,
+                            int n_threads) {
+  uint64_t total = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+  (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+  for (int c = 0; c < n_ch; c++) {
+    orc_fft256iq_t *s = orc_fft256iq_create(naverage, window_id);
+    const int16_t *row = iq + (size_t)c * n_blocks * 128 * 2;
+    int16_t bi[128], bq[128];
+    for (int b = 0; b < n_blocks; b++) {
+      for (int i = 0; i < 128; i++) {
+        bi[i] = row[2 * (b * 128 + i)];
+        bq[i] = row[2 * (b * 128 + i) + 1];
+      }
+      orc_fft256iq_update(s, bi, bq);
+    }
+    for (int i = 0; i < 256; i++) total += s->output[i];
+    orc_fft256iq_destroy(s);
+  }
+  return total;
+}

@@ -153,6 +153,7 @@ void orc_fft256iq_destroy(orc_fft256iq_t *s);
 /* one update() tick with a 128-sample I block and Q block; returns 1 when output[] was refreshed */
 int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *block_i, const int16_t *block_q);
 const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s); /* uint16 output[256], FFTIQ.h:99 */
+uint64_t orc_fft256iq_multi(int naverage, int window_id, int n_ch, const int16_t *iq, int n_blocks, int n_threads);
 #ifdef __cplusplus
 }
 #endif
