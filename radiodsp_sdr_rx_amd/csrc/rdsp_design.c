@@ -178,21 +178,11 @@ int rdsp_design_decimator(int ntaps, double cut_hz, double fs, int window, float
   return 0;
 }
 
-/* NCO: phase increment in turns*2^32 and the two 1024-entry phasor tables */
+/* NCO: phase increment in turns*2^32; constant rotations for k samples */
 uint32_t rdsp_nco_dphi(double hz, double fs) {
   const double turns = hz / fs;
   const long long q = llround(turns * 4294967296.0);
   return (uint32_t)(unsigned long long)q;
-}
-void rdsp_nco_tables(float *t1, float *t2) {
-  for (int i = 0; i < 1024; i++) {
-    const double a = 2.0 * kPi * (double)i / 1024.0;
-    const double b = 2.0 * kPi * (double)i / 1048576.0;
-    t1[2 * i] = (float)cos(a);
-    t1[2 * i + 1] = (float)-sin(a);
-    t2[2 * i] = (float)cos(b);
-    t2[2 * i + 1] = (float)-sin(b);
-  }
 }
 void rdsp_nco_rot(uint32_t dphi, int k, float *out2) {
   const uint32_t ph = dphi * (uint32_t)k;

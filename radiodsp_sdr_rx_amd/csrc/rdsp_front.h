@@ -107,17 +107,6 @@ RDSP_HD float2 nco_phasor_alu(uint32_t ph) {
   return make_float2(fmaf(-sn, r, cs), -fmaf(cs, r, sn));
 }
 
-/* exp(-j*2*pi*ph/2^32) from two 1024-entry tables and a first-order residual:
- * ph = i1*2^22 + i2*2^12 + rem; the residual angle is < 2*pi/2^20, so
- * exp(-j r) = 1 - j r to 2e-11. */
-RDSP_HD float2 nco_phasor(uint32_t ph, const float2 *t1, const float2 *t2) {
-  float2 a = t1[ph >> 22];
-  float2 b = t2[(ph >> 12) & 1023u];
-  float r = (float)(ph & 4095u) * 1.4629180792671596e-09f; /* 2*pi/2^32 */
-  float2 p = cmul(a, b);
-  return make_float2(fmaf(p.y, r, p.x), fmaf(-p.x, r, p.y));
-}
-
 /* arm_float_to_q15 semantics (CONV:346-347): x*32768, truncate, saturate */
 RDSP_HD int q15_of_float(float x) {
   float v = x * 32768.0f;
