@@ -223,6 +223,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("RDSP_FRONT_VARIANT"):  # A/B runs: force the full (0) or lean (1) front kernel
+        chain.set_front_variant(int(os.environ["RDSP_FRONT_VARIANT"]))
     for _ in range(args.warmup):
         chain.process(iq, out=out)
     chain.flush()

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdsp_hip.so")
+# RDSP_LIB_PATH selects another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("RDSP_LIB_PATH") or os.path.join(_HERE, "librdsp_hip.so")
 
 RDSP_OK = 0
 ERRORS = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "NOT_READY", -5: "UNSUPPORTED", -6: "NOMEM"}

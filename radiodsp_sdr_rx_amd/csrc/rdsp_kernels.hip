@@ -22,45 +22,11 @@
  * its traffic is amortised over the time batch.
  */
 #include "rdsp_front.h"
+#include "rdsp_wave.h"
 
 using namespace rdsp;
 
 namespace {
-
-/* ---- wave helpers -------------------------------------------------------- */
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-/* sum over each 16-lane DPP row, result in every lane of the row */
-__device__ __forceinline__ float row_allsum(float v) {
-  v += dpp_f<0xB1>(v);  /* quad_perm [1,0,3,2] */
-  v += dpp_f<0x4E>(v);  /* quad_perm [2,3,0,1] */
-  v += dpp_f<0x141>(v); /* row_half_mirror */
-  v += dpp_f<0x140>(v); /* row_mirror */
-  return v;
-}
-/* sum over the 64-lane wave, wave-uniform result */
-__device__ __forceinline__ float wave_sum(float v) {
-  v = row_allsum(v);
-  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  return (a + b) + (c + d);
-}
-
-__device__ __forceinline__ float2 unpack_iq(uint32_t w, float si, float sq) {
-  /* arm_q15_to_float: q/32768 (the 2^-15 is folded into si/sq, exact) */
-  float xr = (float)(int16_t)(w & 0xFFFFu);
-  float xi = (float)(int16_t)(w >> 16);
-  return make_float2(xr * si, xi * sq);
-}
-
-__device__ __forceinline__ uint32_t pack_lr(float l, float r) {
-  return ((uint32_t)q15_of_float(l) & 0xFFFFu) | ((uint32_t)q15_of_float(r) << 16);
-}
 
 /* ---- front kernel -------------------------------------------------------- */
 /* LDS plan of the front kernel (float2 units), shared with the launch code */
@@ -453,246 +419,6 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   }
 }
 
-/* ---- tail kernel ---------------------------------------------------------- */
-/* sum over the 16 lanes of one channel (one DPP row), result in every lane */
-template <int LPC>
-__device__ __forceinline__ float chan_allsum(float v) {
-  static_assert(LPC == 16, "one channel per DPP row");
-  return row_allsum(v);
-}
-/* lane sub takes lane sub-1's value; lane 0 of the row keeps the DPP `old` operand = xin */
-template <int LPC>
-__device__ __forceinline__ float chan_shift_in(float xin, float oldest, int sub) {
-  (void)sub;
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, xin),
-                                                               __builtin_bit_cast(int, oldest), 0x111, 0xF, 0xF, false));
-}
-
-/* One NLMS instance of one channel, spread over the 16 lanes of a DPP row (four
- * channels per wave).  Measured alternatives on MI355X: 32 lanes per channel
- * (two waves per SIMD at 4096 channels) needs ~31 instructions per wave-step for two
- * channels against 24 for four and ran 1.6x slower; a one-step lookahead of the
- * recursion raised the instruction count and ran 1.3x slower.  A lone wave issues
- * a dependent VALU op every ~7 cycles and a dependent DPP op every ~14
- * (tests/micro/valu_rate.hip), which is what bounds this kernel.  Lane `sub` holds the taps of ages
- * TPL*sub .. TPL*sub+TPL-1 (age 0 = newest sample); CMSIS coefficient b[i]
- * multiplies age 95-i (arm_lms_norm_f32). */
-template <int LPC>
-struct Nlms {
-  static constexpr int TPL = RDSP_LMS_TAPS / LPC;
-  static constexpr int NPH = (TPL <= 3) ? 4 : 8; /* physical ring (> TPL, divides 128) */
-  static_assert(LPC == 16, "one channel per 16-lane DPP row");
-  float w[TPL];
-  float xp[NPH];
-  float energy;
-
-  __device__ __forceinline__ void load(const float *wst, const float *prev, const float *est,
-                                       size_t ch, int sub) {
-#pragma unroll
-    for (int k = 0; k < TPL; k++) w[k] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + k))];
-#pragma unroll
-    for (int k = 0; k < NPH; k++) xp[k] = 0.f;
-    /* before step s the in-lane tap k sits at physical ((-s) + 1 + k) & (NPH-1); a block
-     * is 128 steps = a whole number of ring turns, so every block starts at s = 0 */
-#pragma unroll
-    for (int k = 0; k < TPL; k++)
-      xp[(k + 1) & (NPH - 1)] = prev[ch * RDSP_BLOCK + (127 - (TPL * sub + k))];
-    energy = est[ch];
-  }
-  __device__ __forceinline__ void store(float *wst, float *est, size_t ch, int sub) {
-#pragma unroll
-    for (int k = 0; k < TPL; k++) wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + k))] = w[k];
-    if (sub == 0) est[ch] = energy;
-  }
-
-  /* one 128-sample block (NR:66-80).  ring: [2][128] floats in LDS holding this
-   * instance's input, half `hc` = current block, the other half = previous
-   * block.  mode 0: out = 1.1*y (CONV:334), 1: out = e, 2: out = y. */
-  __device__ __forceinline__ void block(const float *ring, int hc, bool first, float mu, int mode,
-                                        float *out, int sub) {
-    const float *cur = ring + hc * RDSP_BLOCK;
-    const float *prv = ring + (hc ^ 1) * RDSP_BLOCK;
-    const float *dsrc = first ? cur : prv; /* NR:69-79: first call d = x, then previous block */
-    float mine = 0.f;
-#pragma unroll 1
-    for (int s0 = 0; s0 < RDSP_BLOCK; s0 += 16) {
-      float in[16], x0[16], dd[16];
-      const float *x0p = (s0 >= 96) ? (cur + s0 - 96) : (prv + s0 + 32); /* x[n-96] */
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        float4 a = *reinterpret_cast<const float4 *>(cur + s0 + 4 * q);
-        float4 b = *reinterpret_cast<const float4 *>(x0p + 4 * q);
-        float4 c = *reinterpret_cast<const float4 *>(dsrc + s0 + 4 * q);
-        in[4 * q] = a.x; in[4 * q + 1] = a.y; in[4 * q + 2] = a.z; in[4 * q + 3] = a.w;
-        x0[4 * q] = b.x; x0[4 * q + 1] = b.y; x0[4 * q + 2] = b.z; x0[4 * q + 3] = b.w;
-        dd[4 * q] = c.x; dd[4 * q + 1] = c.y; dd[4 * q + 2] = c.z; dd[4 * q + 3] = c.w;
-      }
-      const int sg0 = s0 & (LPC - 1); /* position of this 16-step group inside the LPC-step output group */
-#pragma unroll
-      for (int s = 0; s < 16; s++) {
-        constexpr int M = NPH - 1;
-        const int wpos = (-s) & M; /* s0 % 16 == 0 and NPH divides 16: compile-time */
-        /* shift the delay line by one */
-        float oldest = xp[(wpos + TPL) & M]; /* in-lane tap TPL-1 before this step */
-        xp[wpos] = chan_shift_in<LPC>(in[s], oldest, sub);
-        energy = fmaf(-x0[s], x0[s], energy); /* energy -= x0*x0 */
-        energy = fmaf(in[s], in[s], energy);  /* energy += in*in */
-        float acc0 = w[0] * xp[wpos];
-        float acc1 = w[1] * xp[(wpos + 1) & M];
-        acc0 = fmaf(w[2], xp[(wpos + 2) & M], acc0);
-#pragma unroll
-        for (int k = 3; k < TPL; k += 2) {
-          acc1 = fmaf(w[k], xp[(wpos + k) & M], acc1);
-          if (k + 1 < TPL) acc0 = fmaf(w[k + 1], xp[(wpos + k + 1) & M], acc0);
-        }
-        float y = chan_allsum<LPC>(acc0 + acc1);
-        float e = dd[s] - y;
-        float g = (e * mu) * __builtin_amdgcn_rcpf(energy + 0.000000119209289f);
-#pragma unroll
-        for (int k = 0; k < TPL; k++) w[k] = fmaf(g, xp[(wpos + k) & M], w[k]);
-        float o = (mode == 1) ? e : y;
-        mine = (sub == sg0 + s) ? o : mine;
-      }
-      if (((s0 + 16) & (LPC - 1)) == 0) { /* every lane of the channel holds one output */
-        if (mode == 0) mine = mine * 1.1f;
-        out[s0 + 16 - LPC + sub] = mine;
-      }
-    }
-  }
-};
-
-template <int LPC>
-__global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
-  constexpr int CPW = 64 / LPC;
-  constexpr int SPL = RDSP_BLOCK / LPC; /* samples per lane per block: 8 or 4 */
-  __shared__ __attribute__((aligned(16))) float lds[CPW][5 * RDSP_BLOCK];
-  const int lane = threadIdx.x;
-  const int sub = lane % LPC;
-  const int cw = lane / LPC;
-  size_t ch = (size_t)blockIdx.x * CPW + cw;
-  const bool valid = ch < (size_t)p.n_channels;
-  if (!valid) ch = p.n_channels - 1; /* compute on a real channel, store nothing */
-
-  float *ringA = &lds[cw][0];              /* [2][128] kernel input        */
-  float *ringB = &lds[cw][2 * RDSP_BLOCK]; /* [2][128] ALS input when NR on */
-  float *fin = &lds[cw][4 * RDSP_BLOCK];   /* [128] final audio of the block */
-
-  Nlms<LPC> nr, als;
-  if (p.nr_on) nr.load(p.nr_w, p.nr_prev, p.nr_energy, ch, sub);
-  if (p.als_mode) als.load(p.als_w, p.als_prev, p.als_energy, ch, sub);
-  float agc_g = p.st_scal[ch * 4 + 1];
-
-  /* previous-block halves (half 1, since block 0 uses half 0 as current) */
-  if (p.nr_on) {
-#pragma unroll
-    for (int k = 0; k < SPL; k++) ringA[RDSP_BLOCK + sub * SPL + k] = p.nr_prev[ch * RDSP_BLOCK + sub * SPL + k];
-  }
-  if (p.als_mode) {
-    float *r = p.nr_on ? ringB : ringA;
-#pragma unroll
-    for (int k = 0; k < SPL; k++) r[RDSP_BLOCK + sub * SPL + k] = p.als_prev[ch * RDSP_BLOCK + sub * SPL + k];
-  }
-
-  const float *src = p.mid + ch * p.mid_stride;
-  float4 nxa = *reinterpret_cast<const float4 *>(src + sub * SPL);
-  float4 nxb = nxa;
-  if constexpr (SPL == 8) nxb = *reinterpret_cast<const float4 *>(src + sub * SPL + 4);
-
-#pragma unroll 1
-  for (int b = 0; b < p.n_blocks; b++) {
-    const int hc = b & 1;
-    *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL) = nxa;
-    if constexpr (SPL == 8) *reinterpret_cast<float4 *>(ringA + hc * RDSP_BLOCK + sub * SPL + 4) = nxb;
-    if (b + 1 < p.n_blocks) { /* next block's input lands while this block computes */
-      nxa = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL);
-      if constexpr (SPL == 8) nxb = *reinterpret_cast<const float4 *>(src + (size_t)(b + 1) * RDSP_BLOCK + sub * SPL + 4);
-    }
-    __syncthreads();
-    const float *cur = ringA + hc * RDSP_BLOCK;
-    if (p.nr_on) { /* CONV:326-337 */
-      float *o = p.als_mode ? (ringB + hc * RDSP_BLOCK) : fin;
-      nr.block(ringA, hc, p.nr_first && b == 0, p.nr_mu, p.nr_mode, o, sub);
-      __syncthreads();
-      cur = o;
-    }
-    if (p.als_mode) {
-      const float *ring = p.nr_on ? ringB : ringA;
-      als.block(ring, hc, p.als_first && b == 0, p.als_mu, p.als_mode, fin, sub);
-      __syncthreads();
-      cur = fin;
-    }
-    /* A9 AGC + output gain + A10 pack: lane handles SPL consecutive samples */
-    float L[SPL];
-#pragma unroll
-    for (int k = 0; k < SPL / 4; k++) {
-      float4 a = *reinterpret_cast<const float4 *>(cur + sub * SPL + 4 * k);
-      L[4 * k] = a.x; L[4 * k + 1] = a.y; L[4 * k + 2] = a.z; L[4 * k + 3] = a.w;
-    }
-    if (p.raw_out) { /* LMS_NoiseReduction(n, nrbuffer) in isolation, NR:66 */
-      if (valid) {
-#pragma unroll
-        for (int k = 0; k < SPL; k++)
-          p.raw_out[ch * p.mid_stride + (size_t)b * RDSP_BLOCK + sub * SPL + k] = L[k];
-      }
-      __syncthreads();
-      continue;
-    }
-    if (p.agc_on) {
-      float pw = 0.f;
-#pragma unroll
-      for (int k = 0; k < SPL; k++) pw += L[k] * L[k] + L[k] * L[k];
-      pw = chan_allsum<LPC>(pw);
-      float pp = pw / (float)(2 * RDSP_BLOCK);
-      float rms = sqrtf(pp);
-      float gt = fminf(0.25f / (rms + 1e-6f), 100.0f);
-      float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
-      float gn = agc_g + coef * (gt - agc_g);
-#pragma unroll
-      for (int k = 0; k < SPL; k++) {
-        int i = sub * SPL + k;
-        float g = agc_g + (gn - agc_g) * ((float)(i + 1) / (float)RDSP_BLOCK);
-        L[k] *= g;
-      }
-      agc_g = gn;
-    }
-    if (valid) {
-      size_t o = ch * p.out_stride + (size_t)b * RDSP_BLOCK + sub * SPL;
-#pragma unroll
-      for (int k = 0; k < SPL; k += 4) {
-        uint4 wv;
-        float l0 = L[k] * p.out_gain, l1 = L[k + 1] * p.out_gain, l2 = L[k + 2] * p.out_gain,
-              l3 = L[k + 3] * p.out_gain;
-        wv.x = pack_lr(l0, l0); wv.y = pack_lr(l1, l1); wv.z = pack_lr(l2, l2); wv.w = pack_lr(l3, l3);
-        *reinterpret_cast<uint4 *>(p.out_i16 + o + k) = wv;
-        if (p.out_f32) {
-          p.out_f32[o + k] = make_float2(l0, l0);
-          p.out_f32[o + k + 1] = make_float2(l1, l1);
-          p.out_f32[o + k + 2] = make_float2(l2, l2);
-          p.out_f32[o + k + 3] = make_float2(l3, l3);
-        }
-      }
-    }
-    __syncthreads(); /* fin / rings are rewritten by the next block */
-  }
-
-  /* state out: weights, energy, last input block of each instance, AGC gain */
-  if (valid) {
-    const int hl = (p.n_blocks - 1) & 1;
-    if (p.nr_on) {
-      nr.store(p.nr_w, p.nr_energy, ch, sub);
-#pragma unroll
-      for (int k = 0; k < SPL; k++) p.nr_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringA[hl * RDSP_BLOCK + sub * SPL + k];
-    }
-    if (p.als_mode) {
-      als.store(p.als_w, p.als_energy, ch, sub);
-      const float *r = p.nr_on ? ringB : ringA;
-#pragma unroll
-      for (int k = 0; k < SPL; k++) p.als_prev[ch * RDSP_BLOCK + sub * SPL + k] = r[hl * RDSP_BLOCK + sub * SPL + k];
-    }
-    if (sub == 0 && !p.raw_out) p.st_scal[ch * 4 + 1] = agc_g;
-  }
-}
-
 /* ---- standalone A1 / A10 (bit-exact tests of the int16 <-> float edges) ---- */
 __global__ void rdsp_q15_to_float_kernel(const int16_t *src, float *dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,13 +482,6 @@ extern "C" int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p,
     case 4096: return d4 ? launch_front_t<4096, 16, 4>(p, n_channels, stream) : launch_front_t<4096, 16, 1>(p, n_channels, stream);
     default: return (int)hipErrorInvalidValue;
   }
-}
-
-extern "C" int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
-  if (lanes_per_channel != 16) return (int)hipErrorInvalidValue;
-  int grid = (p->n_channels + 3) / 4;
-  hipLaunchKernelGGL((rdsp_tail_kernel<16>), dim3(grid), dim3(64), 0, stream, *p);
-  return (int)hipGetLastError();
 }
 
 extern "C" int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream) {

@@ -1,0 +1,47 @@
+/*
+ * rdsp_wave.h -- wave-level helpers shared by the HIP kernels (device only).
+ */
+#ifndef RDSP_WAVE_H
+#define RDSP_WAVE_H
+
+#include "rdsp_front.h"
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+/* sum over each 16-lane DPP row, result in every lane of the row */
+__device__ __forceinline__ float row_allsum(float v) {
+  v += dpp_f<0xB1>(v);  /* quad_perm [1,0,3,2] */
+  v += dpp_f<0x4E>(v);  /* quad_perm [2,3,0,1] */
+  v += dpp_f<0x141>(v); /* row_half_mirror */
+  v += dpp_f<0x140>(v); /* row_mirror */
+  return v;
+}
+/* sum over the 64-lane wave, wave-uniform result */
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_allsum(v);
+  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ float2 unpack_iq(uint32_t w, float si, float sq) {
+  /* arm_q15_to_float: q/32768 (the 2^-15 is folded into si/sq, exact) */
+  float xr = (float)(int16_t)(w & 0xFFFFu);
+  float xi = (float)(int16_t)(w >> 16);
+  return make_float2(xr * si, xi * sq);
+}
+
+__device__ __forceinline__ uint32_t pack_lr(float l, float r) {
+  return ((uint32_t)rdsp::q15_of_float(l) & 0xFFFFu) | ((uint32_t)rdsp::q15_of_float(r) << 16);
+}
+
+}  // namespace
+
+#endif
