@@ -165,6 +165,38 @@ int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of
 int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, GEN:111, CTL:237-297 */
 int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* SPEC:112 iNRLevel */
 
+/* ---- receiver groups: per-group retune / PBT / mode tables -------
+ * The sketch has one receiver, so one filter mask, one tuning offset and one
+ * demodulator (globals of CONV:66-80, CTL:330-423).  A chain of many channels is
+ * partitioned into groups that each carry their own; channels of a group share
+ * the group's mask (a gather by group index in the kernel).  Every group call is
+ * the per-group form of a reference call and is non-blocking for the processing
+ * stream: the new mask is designed on the host, uploaded on an internal copy
+ * stream into the group's idle mask buffer (masks are double-buffered on the
+ * device) and switched in, in stream order, by the next rdsp_chain_process; calls
+ * already queued keep the old mask.  The chain-wide calls above
+ * (rdsp_reInitializeFilter, rdsp_sdr_setDemodMode, ...) apply to every group. */
+int rdsp_chain_set_groups(rdsp_chain_t *c, int n_groups, const uint16_t *group_of_channel);
+int rdsp_chain_groups(const rdsp_chain_t *c);
+int rdsp_group_reInitializeFilter(rdsp_chain_t *c, int group, double dFLoCut, double dFHiCut,
+                                  void *stream);                                  /* CONV:209 */
+int rdsp_group_setAudioFilter(rdsp_chain_t *c, int group, int filter, void *stream); /* CTL:153-177 */
+uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode, void *stream); /* CTL:337-407 */
+int rdsp_group_setTuningOffsetHz(rdsp_chain_t *c, int group, double hz);          /* CTL:447 */
+int rdsp_group_get_mask(rdsp_chain_t *c, int group, float *host_out);
+/* checkPBT_Increase / checkPBT_Decrease (CTL:569-612): one 50 Hz step of the low
+ * (edge 0, button D3) or high (edge 1, button D6) cut-off, dir = +1 / -1, with the
+ * limits MIN_LOW 0, MAX_LOW 700, MIN_HI 800, MAX_HI 4000 (GEN:79-82) and the
+ * reference's comparisons.  rdsp_pbt_step is the pure host function; rdsp_group_pbt
+ * steps a group's cut-offs and calls reInitializeFilter like CTL:575,582,597,605. */
+int rdsp_pbt_step(double *dFLoCut, double *dFHiCut, int edge, int dir);
+int rdsp_group_pbt(rdsp_chain_t *c, int group, int edge, int dir, void *stream);
+/* tuningMode() (CTL:330-423): mndx 0 "CW N", 1 "CW", 2 "USB", 3 "LSB", 4 "AM",
+ * 6 "RTTY" (5 "SAM" is SURVEY F3: returns 0 and sets the error text); the CW side
+ * follows vfoFreq > 10 MHz (CTL:337).  Sets the group's audio filter and
+ * demodulator, returns TuningOffset in Hz. */
+uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, double vfo_hz, void *stream);
+
 /* ---- pipelined mode (streaming throughput) -------------------------------------
  * The NLMS/AGC tail stage is serial in time, so its duration is set by the batch
  * length, not by the channel count.  With pipelining on, the tail stage of call k

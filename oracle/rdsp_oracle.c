@@ -306,6 +306,66 @@ void orc_reInitializeFilter(orc_chain_t *c, double lo, double hi) {
   orc_init_filter_mask(c->FIR_filter_mask, c->coef_I, c->coef_Q, c->fft_l);
 }
 
+/* ---- F2: retune / PBT / mode table (the callers of CONV:209) ------------------- */
+/* run-time changes of the engine settings a mode switch touches */
+void orc_set_demod(orc_chain_t *c, int demod) { c->cfg.demod = demod; }
+void orc_set_nco_hz(orc_chain_t *c, double hz) {
+  c->cfg.nco_hz = hz;
+  c->dphi = (uint32_t)(unsigned long long)llround(hz / c->cfg.fs_in * 4294967296.0);
+}
+
+/* checkPBT_Increase (CTL:569-588) / checkPBT_Decrease (CTL:590-612): edge 0 is the
+ * LOCUT branch (BUTTON_D3), edge 1 the HICUT branch (BUTTON_D6). */
+void orc_pbt_step(double *dFLoCut, double *dFHiCut, int edge, int dir) {
+  const double MIN_LOW = 0.0, MAX_LOW = 700.0, MIN_HI = 800.0, MAX_HI = 4000.0; /* GEN:79-82 */
+  if (dir > 0) {
+    if (edge == 0)
+      *dFLoCut = (*dFLoCut + 50) <= MAX_LOW ? (*dFLoCut + 50) : *dFLoCut; /* CTL:574 */
+    else
+      *dFHiCut = (*dFHiCut + 50) <= MAX_HI ? (*dFHiCut + 50) : *dFHiCut; /* CTL:581 */
+  } else {
+    if (edge == 0) {
+      *dFLoCut = (*dFLoCut - 50) > MIN_LOW ? (*dFLoCut - 50) : *dFLoCut; /* CTL:595 */
+      if (*dFLoCut < 0.0) *dFLoCut = 0.0;                                /* CTL:596 */
+    } else {
+      *dFHiCut = (*dFHiCut - 50) > MIN_HI ? (*dFHiCut - 50) : *dFHiCut; /* CTL:604 */
+    }
+  }
+}
+
+/* build-defined pass band of an audio filter name (CTL:153-177: audioCW "500 Hz",
+ * audio2100, audio2700, audio3100, audioAM "3.9 kHz"; SURVEY Appendix C: the
+ * engine's band-passes start at 150 Hz) on the side the demodulator listens to */
+void orc_passband(int filter, int demod, double *lo, double *hi) {
+  double a = 150.0, b = 2700.0;
+  switch (filter) {
+    case 0: a = 450.0; b = 950.0; break; /* audioCW: 500 Hz around the 700 Hz pitch */
+    case 1: b = 2100.0; break;
+    case 2: b = 2700.0; break;
+    case 3: b = 3100.0; break;
+    case 4: b = 3900.0; break;
+    case 5: a = 1400.0; b = 1600.0; break; /* audioWSPR, CTL:399 */
+    default: break;
+  }
+  if (demod == ORC_DEMOD_LSB || demod == ORC_DEMOD_CW_LSB) { *lo = -b; *hi = -a; }
+  else if (demod == ORC_DEMOD_AM) { *lo = -b; *hi = b; }
+  else { *lo = a; *hi = b; }
+}
+
+/* tuningMode() (CTL:330-423): filter and demodulator of menu entry mndx; returns 0
+ * for the entries that need engine features outside the build (5 = SAM). */
+int orc_tuning_mode(int mndx, double vfoFreq, int *filter, int *demod) {
+  switch (mndx) {
+    case 0: *filter = 0; *demod = vfoFreq > 10000000 ? ORC_DEMOD_CW_USB : ORC_DEMOD_CW_LSB; return 1; /* CTL:334-342 */
+    case 1: *filter = 1; *demod = vfoFreq > 10000000 ? ORC_DEMOD_CW_USB : ORC_DEMOD_CW_LSB; return 1; /* CTL:345-356 */
+    case 2: *filter = 2; *demod = ORC_DEMOD_USB; return 1; /* CTL:358-365 */
+    case 3: *filter = 2; *demod = ORC_DEMOD_LSB; return 1; /* CTL:367-374 */
+    case 4: *filter = 4; *demod = ORC_DEMOD_AM; return 1;  /* CTL:376-383 */
+    case 6: *filter = 1; *demod = ORC_DEMOD_USB; return 1; /* CTL:404-411 "RTTY" */
+    default: return 0;
+  }
+}
+
 orc_chain_t *orc_chain_create(const orc_config_t *cfg) {
   orc_chain_t *c = (orc_chain_t *)calloc(1, sizeof(*c));
   if (!c) return NULL;

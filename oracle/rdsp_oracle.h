@@ -105,6 +105,14 @@ void orc_LMS_NoiseReduction(orc_chain_t *c, int16_t n, float *nrbuffer); /* NR:6
 void orc_Init_ALS(orc_chain_t *c, int strength);
 void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327 */
 
+/* F2: retune / PBT / mode table -- the callers of reInitializeFilter (CTL:569-612)
+ * and the mode menu (CTL:330-423) */
+void orc_set_demod(orc_chain_t *c, int demod);
+void orc_set_nco_hz(orc_chain_t *c, double hz);
+void orc_pbt_step(double *dFLoCut, double *dFHiCut, int edge, int dir);
+void orc_passband(int filter, int demod, double *lo, double *hi);
+int orc_tuning_mode(int mndx, double vfoFreq, int *filter, int *demod);
+
 /* Process n_blocks blocks of 128 interleaved int16 IQ samples.  Output is
  * produced hop by hop (hop = fft_l/2 samples at the decimated rate); returns
  * the number of output sample pairs written.  out_i16 is interleaved L,R

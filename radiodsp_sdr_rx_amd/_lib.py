@@ -115,6 +115,16 @@ SYMBOLS = [
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
     ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
     ("rdsp_chain_get_mask", _i, [_vp, _f32p]),
+    ("rdsp_chain_set_groups", _i, [_vp, _i, C.POINTER(C.c_uint16)]),
+    ("rdsp_chain_groups", _i, [_vp]),
+    ("rdsp_group_reInitializeFilter", _i, [_vp, _i, _d, _d, _vp]),
+    ("rdsp_group_setAudioFilter", _i, [_vp, _i, _i, _vp]),
+    ("rdsp_group_setDemodMode", C.c_uint32, [_vp, _i, _i, _vp]),
+    ("rdsp_group_setTuningOffsetHz", _i, [_vp, _i, _d]),
+    ("rdsp_group_get_mask", _i, [_vp, _i, _f32p]),
+    ("rdsp_pbt_step", _i, [_f64p, _f64p, _i, _i]),
+    ("rdsp_group_pbt", _i, [_vp, _i, _i, _i, _vp]),
+    ("rdsp_group_tuningMode", C.c_uint32, [_vp, _i, _i, _d, _vp]),
     ("rdsp_chain_get_fir_taps", _i, [_vp, _f32p]),
     ("rdsp_graph_create", _vp, [_i]),
     ("rdsp_graph_destroy", None, [_vp]),

@@ -122,6 +122,44 @@ class Chain:
     def set_nr_level(self, lvl): _lib.check(self.lib.rdsp_set_nr_level(self.h, int(lvl)))
     def set_spectral_nr(self, on, level): _lib.check(self.lib.rdsp_set_spectral_nr(self.h, int(on), float(level)))
 
+    # ---- receiver groups: per-group retune / PBT / mode table (CTL:330-423,569-612) --
+    def set_groups(self, group_of_channel):
+        """Partition the channels into receiver groups (ids 0..G-1); None = one group."""
+        if group_of_channel is None:
+            _lib.check(self.lib.rdsp_chain_set_groups(self.h, 1, None))
+            return
+        g = np.ascontiguousarray(group_of_channel, dtype=np.uint16)
+        if g.shape != (self.n_channels,):
+            raise ValueError("one group id per channel")
+        _lib.check(self.lib.rdsp_chain_set_groups(self.h, int(g.max()) + 1, g.ctypes.data_as(C.POINTER(C.c_uint16))))
+
+    @property
+    def n_groups(self):
+        return int(self.lib.rdsp_chain_groups(self.h))
+
+    def group_reInitializeFilter(self, group, lo, hi, stream=None):
+        _lib.check(self.lib.rdsp_group_reInitializeFilter(self.h, int(group), float(lo), float(hi), _stream_ptr(stream)))
+
+    def group_setAudioFilter(self, group, f, stream=None):
+        _lib.check(self.lib.rdsp_group_setAudioFilter(self.h, int(group), int(f), _stream_ptr(stream)))
+
+    def group_setDemodMode(self, group, mode, stream=None):
+        return int(self.lib.rdsp_group_setDemodMode(self.h, int(group), int(mode), _stream_ptr(stream)))
+
+    def group_setTuningOffsetHz(self, group, hz):
+        _lib.check(self.lib.rdsp_group_setTuningOffsetHz(self.h, int(group), float(hz)))
+
+    def group_pbt(self, group, edge, direction, stream=None):
+        _lib.check(self.lib.rdsp_group_pbt(self.h, int(group), int(edge), int(direction), _stream_ptr(stream)))
+
+    def group_tuningMode(self, group, mndx, vfo_hz, stream=None):
+        return int(self.lib.rdsp_group_tuningMode(self.h, int(group), int(mndx), float(vfo_hz), _stream_ptr(stream)))
+
+    def group_mask(self, group):
+        a = np.zeros(2 * self.fft_l, np.float32)
+        _lib.check(self.lib.rdsp_group_get_mask(self.h, int(group), a.ctypes.data_as(_lib._f32p)))
+        return a
+
     # ---- pipelined mode: tail of call k overlaps the front of call k+1 ------------
     def set_pipelined(self, on):
         _lib.check(self.lib.rdsp_chain_set_pipelined(self.h, int(bool(on))))
@@ -161,6 +199,14 @@ class Chain:
         a = np.zeros(256, np.float32)
         _lib.check(self.lib.rdsp_chain_get_fir_taps(self.h, a.ctypes.data_as(_lib._f32p)))
         return a
+
+
+def pbt_step(lo, hi, edge, direction):
+    """checkPBT_Increase/Decrease (CTL:569-612) on a pair of cut-offs; returns (lo, hi)."""
+    lib = _lib.load()
+    a, b = C.c_double(float(lo)), C.c_double(float(hi))
+    _lib.check(lib.rdsp_pbt_step(C.byref(a), C.byref(b), int(edge), int(direction)))
+    return a.value, b.value
 
 
 def synth_iq(n_channels, n_samples, ch0=0, t0=0, cw=False, n_threads=0, out=None):

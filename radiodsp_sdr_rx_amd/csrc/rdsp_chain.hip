@@ -41,20 +41,42 @@ extern "C" int rdsp_device_count(void) {
     }                                                                              \
   } while (0)
 
+/* host side of one receiver group: filter, tuning offset, demodulator.
+ * The device sees it as one RdspGroup record plus two mask buffers; a retune fills
+ * the buffer the record does not point to (copy stream) and the record is rewritten
+ * in stream order at the next processing call. */
+struct GroupState {
+  double lo = 0.0, hi = 0.0, nco_hz = 0.0;
+  int demod = RDSP_DEMOD_USB, audio_filter = RDSP_AUDIO_2700;
+  std::vector<double> coef_I, coef_Q; /* FIR_Coef_I/Q, CONV:69-70 */
+  std::vector<float> mask_nat;        /* FIR_filter_mask, CONV:77 */
+  int applied = 0;   /* mask buffer the device record points to (as queued) */
+  int staged = -1;   /* buffer holding a newer mask that is not yet switched in */
+  bool dirty = true; /* the device record must be rewritten before the next launch */
+  bool has_dev_dphi = false; /* dev_dphi: increment the last launch mixed with */
+  uint32_t dev_dphi = 0;
+  hipEvent_t ev_copy = nullptr;
+  float *staging = nullptr; /* pinned, N float2 */
+};
+
 struct rdsp_chain {
   rdsp_chain_config_t cfg;
   int n_channels, device, max_blocks;
   int N, decim, hop;
   uint64_t n_in;       /* absolute input sample counter */
-  uint32_t dphi;
   int old_nr_level;    /* oldNRLevel, CONV:80 */
   float nr_mu, als_mu;
   long nr_calls, als_calls; /* NR:69 ring statics: only "first call" matters */
-  std::vector<double> coef_I, coef_Q; /* FIR_Coef_I/Q, CONV:69-70 */
-  std::vector<float> mask_nat;        /* FIR_filter_mask, CONV:77 */
   std::vector<float> fir_nat;
+  std::vector<GroupState> groups;     /* at least one */
+  std::vector<uint16_t> group_of;     /* empty: every channel in group 0 */
   /* device */
-  float2 *d_maskp = nullptr;
+  RdspGroup *d_groups = nullptr;
+  uint16_t *d_group_of = nullptr;
+  float2 *d_mask_pool = nullptr;      /* [n_groups][2][N] */
+  hipStream_t s_copy = nullptr;       /* mask uploads, concurrent with processing */
+  hipEvent_t ev_fence = nullptr;      /* after the most recent front launch */
+  bool fence_valid = false;
   float *d_fir_hc = nullptr;
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
@@ -77,9 +99,9 @@ struct rdsp_chain {
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
-  int audio_filter = RDSP_AUDIO_2700;
 };
 
+static int drain_tail_fwd(rdsp_chain_t *c);
 static int check_device(rdsp_chain_t *c) {
   if (hipSetDevice(c->device) != hipSuccess) {
     rdsp_set_error("hipSetDevice(%d) failed", c->device);
@@ -104,14 +126,134 @@ static uint32_t demod_tuning_offset(int demod) {
   return (demod == RDSP_DEMOD_CW_USB || demod == RDSP_DEMOD_CW_LSB) ? 700u : 0u;
 }
 
-/* upload the device image of the current mask (or all-pass when the filter is
- * disabled); synchronous with respect to `stream` (the reference does the same
- * work under AudioNoInterrupts, CONV:211-222) */
-static int upload_mask(rdsp_chain_t *c, hipStream_t stream) {
-  std::vector<float> img(2 * (size_t)c->N);
-  rdsp_mask_device_image(c->cfg.filter_on ? c->mask_nat.data() : nullptr, c->N, img.data());
-  HIP_TRY(hipStreamSynchronize(stream));
-  HIP_TRY(hipMemcpy(c->d_maskp, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+/* ---- receiver groups: double-buffered masks, records rewritten in stream order ---- */
+static void group_design(rdsp_chain_t *c, GroupState &g) { /* CONV:209-224 without the upload */
+  const double fs_out = c->cfg.fs_in / (double)c->decim;
+  rdsp_calc_cplx_FIR_coeffs(g.coef_I.data(), g.coef_Q.data(), c->hop + 1, g.lo, g.hi, fs_out, c->cfg.window);
+}
+
+static void group_free(GroupState &g) {
+  if (g.ev_copy) (void)hipEventDestroy(g.ev_copy);
+  if (g.staging) (void)hipHostFree(g.staging);
+  g.ev_copy = nullptr;
+  g.staging = nullptr;
+}
+
+/* (re)allocate the device side for n groups; existing groups keep their settings,
+ * new ones copy group 0.  Synchronous: called at create time and from
+ * rdsp_chain_set_groups, never on the streaming path. */
+static int groups_resize(rdsp_chain_t *c, int n) {
+  HIP_TRY(hipDeviceSynchronize());
+  if (!c->s_copy) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
+  }
+  const size_t old = c->groups.size();
+  for (size_t i = (size_t)n; i < old; i++) group_free(c->groups[i]);
+  c->groups.resize((size_t)n);
+  for (size_t i = old; i < (size_t)n; i++) {
+    GroupState &g = c->groups[i];
+    if (i > 0) {
+      const GroupState &g0 = c->groups[0];
+      g.lo = g0.lo; g.hi = g0.hi; g.nco_hz = g0.nco_hz; g.demod = g0.demod; g.audio_filter = g0.audio_filter;
+      g.coef_I = g0.coef_I; g.coef_Q = g0.coef_Q; g.mask_nat = g0.mask_nat;
+    } else {
+      g.coef_I.assign(c->hop + 1, 0.0);
+      g.coef_Q.assign(c->hop + 1, 0.0);
+      g.mask_nat.assign(2 * (size_t)c->N, 0.0f);
+    }
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_copy, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **)&g.staging, sizeof(float2) * (size_t)c->N, hipHostMallocDefault));
+  }
+  if (c->d_groups) (void)hipFree(c->d_groups);
+  if (c->d_mask_pool) (void)hipFree(c->d_mask_pool);
+  c->d_groups = nullptr;
+  c->d_mask_pool = nullptr;
+  HIP_TRY(hipMalloc((void **)&c->d_groups, sizeof(RdspGroup) * (size_t)n));
+  HIP_TRY(hipMemset(c->d_groups, 0, sizeof(RdspGroup) * (size_t)n));
+  HIP_TRY(hipMalloc((void **)&c->d_mask_pool, sizeof(float2) * 2 * (size_t)c->N * (size_t)n));
+  HIP_TRY(hipMemset(c->d_mask_pool, 0, sizeof(float2) * 2 * (size_t)c->N * (size_t)n));
+  for (auto &g : c->groups) { /* pool contents are gone: every group restages */
+    g.applied = 0;
+    g.staged = -1;
+    g.dirty = true;
+  }
+  c->fence_valid = false;
+  return RDSP_OK;
+}
+
+/* queue the upload of group gi's current mask (all-pass when the filter is off)
+ * into the buffer its device record does not point to; never blocks the
+ * processing stream (the reference does this under AudioNoInterrupts, CONV:211-222) */
+static int group_stage(rdsp_chain_t *c, int gi) {
+  GroupState &g = c->groups[(size_t)gi];
+  if (g.staged >= 0) HIP_TRY(hipEventSynchronize(g.ev_copy)); /* the pinned image is ours again */
+  rdsp_mask_device_image(c->cfg.filter_on ? g.mask_nat.data() : nullptr, c->N, g.staging);
+  const int target = (g.staged >= 0) ? g.staged : (1 - g.applied);
+  /* front kernels launched so far may still read `target` (it was live before the last switch) */
+  if (c->fence_valid) HIP_TRY(hipStreamWaitEvent(c->s_copy, c->ev_fence, 0));
+  float2 *dst = c->d_mask_pool + ((size_t)gi * 2 + (size_t)target) * (size_t)c->N;
+  HIP_TRY(hipMemcpyAsync(dst, g.staging, sizeof(float2) * (size_t)c->N, hipMemcpyHostToDevice, c->s_copy));
+  HIP_TRY(hipEventRecord(g.ev_copy, c->s_copy));
+  g.staged = target;
+  g.dirty = true;
+  return RDSP_OK;
+}
+
+static void group_record(const rdsp_chain_t *c, const GroupState &g, int gi, int buf, RdspGroup *r) {
+  memset(r, 0, sizeof(*r));
+  r->dphi = rdsp_nco_dphi(g.nco_hz, c->cfg.fs_in);
+  r->demod = (g.demod == RDSP_DEMOD_IQ) ? RDSP_K_DEMOD_IQ
+             : (g.demod == RDSP_DEMOD_AM ? RDSP_K_DEMOD_AM : RDSP_K_DEMOD_REAL);
+  float t[2];
+  rdsp_nco_rot(r->dphi, 1, t); r->rot1 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 2, t); r->rot2 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 3, t); r->rot3 = make_float2(t[0], t[1]);
+  const int nt = c->N / rdsp_plan_radix(c->N); /* threads per channel */
+  rdsp_nco_rot(r->dphi, 4 * nt, t); r->rotp1 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 8 * nt, t); r->rotp2 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 12 * nt, t); r->rotp3 = make_float2(t[0], t[1]);
+  r->mask_off = (uint32_t)(((size_t)gi * 2 + (size_t)buf) * (size_t)c->N);
+  /* the FIR history was mixed with the increment of the launch that brought it in */
+  r->dphi_hist = g.has_dev_dphi ? g.dev_dphi : r->dphi;
+  rdsp_nco_rot(r->dphi_hist, 1, t); r->roth1 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi_hist, 2, t); r->roth2 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi_hist, 3, t); r->roth3 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi_hist, 12 * nt, t); r->rothp3 = make_float2(t[0], t[1]);
+}
+
+/* before a launch on `stream`: switch every changed group over, in stream order */
+static int groups_commit(rdsp_chain_t *c, hipStream_t stream) {
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    GroupState &g = c->groups[i];
+    if (!g.dirty) continue;
+    int buf = g.applied;
+    if (g.staged >= 0) {
+      HIP_TRY(hipStreamWaitEvent(stream, g.ev_copy, 0));
+      buf = g.staged;
+    }
+    RdspGroup r;
+    group_record(c, g, (int)i, buf, &r);
+    int e = rdsp_launch_group_store(c->d_groups + i, &r, stream);
+    if (e != 0) {
+      rdsp_set_error("group record update failed: %s", hipGetErrorString((hipError_t)e));
+      return RDSP_ERR_HIP;
+    }
+    g.applied = buf;
+    g.staged = -1;
+    /* after a tuning change the record is written once more, for the launch after this one */
+    g.dirty = (r.dphi_hist != r.dphi);
+    g.has_dev_dphi = true;
+    g.dev_dphi = r.dphi;
+  }
+  return RDSP_OK;
+}
+
+static int check_group(const rdsp_chain_t *c, int group) {
+  if (!c || group < 0 || (size_t)group >= c->groups.size()) {
+    rdsp_set_error("group %d out of range", group);
+    return RDSP_ERR_INVALID;
+  }
   return RDSP_OK;
 }
 
@@ -148,16 +290,18 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
   c->decim = decim;
   c->hop = c->N / 2;
   c->n_in = 0;
-  c->dphi = rdsp_nco_dphi(cfg->nco_hz, cfg->fs_in);
   c->old_nr_level = 15;            /* CONV:80 */
   c->nr_mu = rdsp_lms_mu(15);      /* Init_LMS_NR(15), INO:172 */
   c->als_mu = rdsp_lms_mu(cfg->als_strength > 0 ? cfg->als_strength : 15);
   c->nr_calls = c->als_calls = 0;
-  c->coef_I.assign(c->hop + 1, 0.0);
-  c->coef_Q.assign(c->hop + 1, 0.0);
-  c->mask_nat.assign(2 * (size_t)c->N, 0.0f);
   c->fir_nat.assign(256, 0.0f);
   if (check_device(c) != RDSP_OK) { delete c; return RDSP_ERR_HIP; }
+  {
+    int rc = groups_resize(c, 1);
+    if (rc != RDSP_OK) return rc;
+    GroupState &g0 = c->groups[0];
+    g0.lo = cfg->flo_hz; g0.hi = cfg->fhi_hz; g0.nco_hz = cfg->nco_hz; g0.demod = cfg->demod;
+  }
 
   const size_t nch = (size_t)n_channels;
 #define ALLOC_ZERO(ptr, bytes)                                        \
@@ -165,7 +309,6 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
     HIP_TRY(hipMalloc((void **)&(ptr), (bytes)));                     \
     HIP_TRY(hipMemset((ptr), 0, (bytes)));                            \
   } while (0)
-  ALLOC_ZERO(c->d_maskp, sizeof(float2) * c->N);
   ALLOC_ZERO(c->d_fir_hc, sizeof(float) * 256);
   ALLOC_ZERO(c->d_hist, sizeof(uint32_t) * 256 * nch);
   ALLOC_ZERO(c->d_prev, sizeof(float2) * c->hop * nch);
@@ -205,12 +348,18 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_maskp, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->s_copy) {
+    (void)hipStreamSynchronize(c->s_copy);
+    (void)hipStreamDestroy(c->s_copy);
+    (void)hipEventDestroy(c->ev_fence);
+  }
+  for (auto &g : c->groups) group_free(g);
   if (c->s_tail) {
     (void)hipStreamSynchronize(c->s_tail);
     (void)hipStreamDestroy(c->s_tail);
@@ -254,30 +403,53 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   c->nr_calls = c->als_calls = 0;
   c->old_nr_level = 15;
   c->nr_mu = rdsp_lms_mu(15);
+  for (auto &g : c->groups) { g.has_dev_dphi = false; g.dirty = true; }
   return RDSP_OK;
 }
 
-/* CONV:187-207: build the mask from whatever the tap arrays hold */
-extern "C" int rdsp_doConvolutionalInitialize(rdsp_chain_t *c, void *stream) {
-  if (!c) return RDSP_ERR_INVALID;
-  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
-  if (rdsp_init_filter_mask(c->mask_nat.data(), c->coef_I.data(), c->coef_Q.data(), c->N) != 0) {
+/* CONV:187-207 for one group: build the mask from whatever the tap arrays hold */
+static int group_initialize(rdsp_chain_t *c, int gi) {
+  GroupState &g = c->groups[(size_t)gi];
+  if (rdsp_init_filter_mask(g.mask_nat.data(), g.coef_I.data(), g.coef_Q.data(), c->N) != 0) {
     rdsp_set_error("init_filter_mask failed");
     return RDSP_ERR_INVALID;
   }
-  return upload_mask(c, (hipStream_t)stream);
+  return group_stage(c, gi);
 }
 
-/* CONV:209-224 */
-extern "C" int rdsp_reInitializeFilter(rdsp_chain_t *c, double lo, double hi, void *stream) {
+extern "C" int rdsp_doConvolutionalInitialize(rdsp_chain_t *c, void *stream) {
+  (void)stream; /* the new mask is switched in by the next processing call, in its stream's order */
   if (!c) return RDSP_ERR_INVALID;
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
-  const double fs_out = c->cfg.fs_in / (double)c->decim;
-  rdsp_calc_cplx_FIR_coeffs(c->coef_I.data(), c->coef_Q.data(), c->hop + 1, lo, hi, fs_out,
-                            c->cfg.window);
-  c->cfg.flo_hz = lo;
-  c->cfg.fhi_hz = hi;
-  return rdsp_doConvolutionalInitialize(c, stream);
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    int rc = group_initialize(c, (int)i);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
+}
+
+/* CONV:209-224 for one group.  Host-side design, asynchronous upload into
+ * the group's idle mask buffer; processing never waits on the host. */
+extern "C" int rdsp_group_reInitializeFilter(rdsp_chain_t *c, int group, double lo, double hi, void *stream) {
+  (void)stream;
+  if (check_group(c, group) != RDSP_OK) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  GroupState &g = c->groups[(size_t)group];
+  g.lo = lo;
+  g.hi = hi;
+  group_design(c, g);
+  if (group == 0) { c->cfg.flo_hz = lo; c->cfg.fhi_hz = hi; }
+  return group_initialize(c, group);
+}
+
+/* CONV:209-224: every group gets the same band */
+extern "C" int rdsp_reInitializeFilter(rdsp_chain_t *c, double lo, double hi, void *stream) {
+  if (!c) return RDSP_ERR_INVALID;
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    int rc = rdsp_group_reInitializeFilter(c, (int)i, lo, hi, stream);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
 }
 
 /* NR:35-64: new mu; delay line and filter state cleared, energy = 0; the
@@ -343,27 +515,16 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.in_stride = in_stride;
   fp.n_chunks = (int)(n_in / (size_t)(256 * c->decim));
   fp.n0 = (uint32_t)c->n_in;
-  fp.dphi = c->dphi;
-  float r[2];
-  rdsp_nco_rot(c->dphi, 1, r); fp.rot1 = make_float2(r[0], r[1]);
-  rdsp_nco_rot(c->dphi, 2, r); fp.rot2 = make_float2(r[0], r[1]);
-  rdsp_nco_rot(c->dphi, 3, r); fp.rot3 = make_float2(r[0], r[1]);
-  {
-    const int nt = c->N / rdsp_plan_radix(c->N); /* threads per channel */
-    rdsp_nco_rot(c->dphi, 4 * nt, r); fp.rotp1 = make_float2(r[0], r[1]);
-    rdsp_nco_rot(c->dphi, 8 * nt, r); fp.rotp2 = make_float2(r[0], r[1]);
-    rdsp_nco_rot(c->dphi, 12 * nt, r); fp.rotp3 = make_float2(r[0], r[1]);
-  }
   fp.scale_i = cf.iq_balance * cf.input_gain * (1.0f / 32768.0f);
   fp.scale_q = cf.input_gain * (1.0f / 32768.0f);
   fp.fir_hc = c->d_fir_hc;
-  fp.maskp = c->d_maskp;
+  fp.groups = c->d_groups;
+  fp.group_of = c->d_group_of;
+  fp.mask_pool = c->d_mask_pool;
   fp.spectral_on = cf.spectral_nr ? 1 : 0;
   fp.spectral_k = (float)((double)cf.spectral_level * 1.5);
   fp.vad_lo = 30 * c->N / 256; /* STATING_BIN_VAD_ANALISYS, SPEC:34, scaled with FFT_L */
   fp.vad_hi = 180 * c->N / 256;
-  fp.demod = (cf.demod == RDSP_DEMOD_IQ) ? RDSP_K_DEMOD_IQ
-             : (cf.demod == RDSP_DEMOD_AM ? RDSP_K_DEMOD_AM : RDSP_K_DEMOD_REAL);
   fp.to_mid = tail ? 1 : 0;
   fp.agc_on = cf.agc_mode != RDSP_AGC_OFF;
   fp.agc_attack = attack;
@@ -397,8 +558,14 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     ev3 = c->ev[4 * c->ev_used + 3];
     HIP_TRY(hipEventRecord(ev0, stream));
   }
+  {
+    int rc = groups_commit(c, stream);
+    if (rc != RDSP_OK) return rc;
+  }
   int e = rdsp_launch_front(c->N, c->decim, &fp, c->n_channels, stream);
   if (timed) HIP_TRY(hipEventRecord(ev1, stream));
+  HIP_TRY(hipEventRecord(c->ev_fence, stream));
+  c->fence_valid = true;
   if (e != 0) {
     rdsp_set_error("front kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return RDSP_ERR_HIP;
@@ -494,8 +661,10 @@ extern "C" int rdsp_doConvolutionalProcessing(rdsp_chain_t *c, float iNRLevel, i
   const int f = bFilterEnabled ? 1 : 0;
   if (f != c->cfg.filter_on) {
     c->cfg.filter_on = f;
-    int rc = upload_mask(c, (hipStream_t)stream);
-    if (rc != RDSP_OK) return rc;
+    for (size_t i = 0; i < c->groups.size(); i++) {
+      int rc = group_stage(c, (int)i);
+      if (rc != RDSP_OK) return rc;
+    }
   }
   return rdsp_chain_process(c, d_iq, in_stride, n_blocks, d_out, out_stride, nullptr, stream);
 }
@@ -534,12 +703,26 @@ extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) { 
 extern "C" int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.input_gain = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.output_gain = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g) { NEED(c); c->cfg.iq_balance = g; return RDSP_OK; }
-extern "C" int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c) { NEED(c); c->cfg.filter_on = 1; return upload_mask(c, nullptr); }
+extern "C" int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c) {
+  NEED(c);
+  c->cfg.filter_on = 1;
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    int rc = group_stage(c, (int)i);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
+}
 extern "C" int rdsp_sdr_setMute(rdsp_chain_t *c, int mute) { NEED(c); c->cfg.mute = mute ? 1 : 0; return RDSP_OK; }
+extern "C" int rdsp_group_setTuningOffsetHz(rdsp_chain_t *c, int group, double hz) {
+  if (check_group(c, group) != RDSP_OK) return RDSP_ERR_INVALID;
+  c->groups[(size_t)group].nco_hz = hz;
+  c->groups[(size_t)group].dirty = true;
+  if (group == 0) c->cfg.nco_hz = hz;
+  return RDSP_OK;
+}
 extern "C" int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz) {
   NEED(c);
-  c->cfg.nco_hz = hz;
-  c->dphi = rdsp_nco_dphi(hz, c->cfg.fs_in);
+  for (size_t i = 0; i < c->groups.size(); i++) (void)rdsp_group_setTuningOffsetHz(c, (int)i, hz);
   return RDSP_OK;
 }
 extern "C" int rdsp_set_nr_level(rdsp_chain_t *c, int lvl) { NEED(c); c->cfg.lms_nr = lvl; return RDSP_OK; }
@@ -562,21 +745,127 @@ static void passband(int filter, int demod, double *lo, double *hi) {
   else if (demod == RDSP_DEMOD_AM) { *lo = -b; *hi = b; }
   else { *lo = a; *hi = b; }
 }
+extern "C" int rdsp_group_setAudioFilter(rdsp_chain_t *c, int group, int filter, void *stream) {
+  if (check_group(c, group) != RDSP_OK) return RDSP_ERR_INVALID;
+  if (filter < RDSP_AUDIO_CW || filter > RDSP_AUDIO_WSPR) return RDSP_ERR_INVALID;
+  GroupState &g = c->groups[(size_t)group];
+  g.audio_filter = filter;
+  double lo, hi;
+  passband(filter, g.demod, &lo, &hi);
+  return rdsp_group_reInitializeFilter(c, group, lo, hi, stream);
+}
 extern "C" int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream) {
   NEED(c);
-  if (filter < RDSP_AUDIO_CW || filter > RDSP_AUDIO_WSPR) return RDSP_ERR_INVALID;
-  c->audio_filter = filter;
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    int rc = rdsp_group_setAudioFilter(c, (int)i, filter, stream);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
+}
+extern "C" uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode, void *stream) {
+  if (check_group(c, group) != RDSP_OK || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_AM) return 0;
+  GroupState &g = c->groups[(size_t)group];
+  g.demod = mode;
+  if (group == 0) c->cfg.demod = mode;
   double lo, hi;
-  passband(filter, c->cfg.demod, &lo, &hi);
-  return rdsp_reInitializeFilter(c, lo, hi, stream);
+  passband(g.audio_filter, mode, &lo, &hi);
+  (void)rdsp_group_reInitializeFilter(c, group, lo, hi, stream);
+  return demod_tuning_offset(mode);
 }
 extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream) {
   if (!c || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_AM) return 0;
-  c->cfg.demod = mode;
-  double lo, hi;
-  passband(c->audio_filter, mode, &lo, &hi);
-  (void)rdsp_reInitializeFilter(c, lo, hi, stream);
+  for (size_t i = 0; i < c->groups.size(); i++) (void)rdsp_group_setDemodMode(c, (int)i, mode, stream);
   return demod_tuning_offset(mode);
+}
+
+/* ---- receiver groups ---------------------------------------------------- */
+extern "C" int rdsp_chain_groups(const rdsp_chain_t *c) { return c ? (int)c->groups.size() : 0; }
+
+/* partition the channels into n_groups receiver groups; group_of_channel[ch] < n_groups
+ * (NULL with n_groups == 1 restores the single shared group).  Synchronises the
+ * device: a set-up call, not a streaming one.  New groups start as copies of group 0. */
+extern "C" int rdsp_chain_set_groups(rdsp_chain_t *c, int n_groups, const uint16_t *group_of_channel) {
+  NEED(c);
+  if (n_groups < 1 || n_groups > 65535 || (n_groups > 1 && !group_of_channel)) {
+    rdsp_set_error("rdsp_chain_set_groups: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (group_of_channel)
+    for (int i = 0; i < c->n_channels; i++)
+      if (group_of_channel[i] >= n_groups) {
+        rdsp_set_error("channel %d: group %d >= n_groups %d", i, (int)group_of_channel[i], n_groups);
+        return RDSP_ERR_INVALID;
+      }
+  if (drain_tail_fwd(c) != RDSP_OK) return RDSP_ERR_HIP;
+  int rc = groups_resize(c, n_groups);
+  if (rc != RDSP_OK) return rc;
+  if (c->d_group_of) { (void)hipFree(c->d_group_of); c->d_group_of = nullptr; }
+  c->group_of.clear();
+  if (group_of_channel && n_groups > 1) {
+    c->group_of.assign(group_of_channel, group_of_channel + c->n_channels);
+    HIP_TRY(hipMalloc((void **)&c->d_group_of, sizeof(uint16_t) * (size_t)c->n_channels));
+    HIP_TRY(hipMemcpy(c->d_group_of, c->group_of.data(), sizeof(uint16_t) * (size_t)c->n_channels, hipMemcpyHostToDevice));
+  }
+  for (int g = 0; g < n_groups; g++) {
+    rc = group_stage(c, g);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
+}
+
+extern "C" int rdsp_group_get_mask(rdsp_chain_t *c, int group, float *host_out) {
+  if (check_group(c, group) != RDSP_OK || !host_out) return RDSP_ERR_INVALID;
+  memcpy(host_out, c->groups[(size_t)group].mask_nat.data(), sizeof(float) * 2 * (size_t)c->N);
+  return RDSP_OK;
+}
+
+/* checkPBT_Increase / checkPBT_Decrease (CTL:569-612) on a pair of cut-offs:
+ * edge 0 = LOCUT (button D3), 1 = HICUT (D6); dir +1 / -1; 50 Hz steps inside
+ * [MIN_LOW, MAX_LOW] and [MIN_HI, MAX_HI] (RDSP_general_includes.h:79-82), with the
+ * reference's comparisons (<= when increasing, > when decreasing). */
+extern "C" int rdsp_pbt_step(double *lo, double *hi, int edge, int dir) {
+  if (!lo || !hi || (edge != 0 && edge != 1) || (dir != 1 && dir != -1)) return RDSP_ERR_INVALID;
+  const double MIN_LOW = 0.0, MAX_LOW = 700.0, MIN_HI = 800.0, MAX_HI = 4000.0;
+  if (dir > 0) {
+    if (edge == 0) *lo = (*lo + 50) <= MAX_LOW ? (*lo + 50) : *lo; /* CTL:574 */
+    else *hi = (*hi + 50) <= MAX_HI ? (*hi + 50) : *hi;            /* CTL:581 */
+  } else {
+    if (edge == 0) {
+      *lo = (*lo - 50) > MIN_LOW ? (*lo - 50) : *lo; /* CTL:595 */
+      if (*lo < 0.0) *lo = 0.0;                      /* CTL:596 */
+    } else {
+      *hi = (*hi - 50) > MIN_HI ? (*hi - 50) : *hi;  /* CTL:604 */
+    }
+  }
+  return RDSP_OK;
+}
+extern "C" int rdsp_group_pbt(rdsp_chain_t *c, int group, int edge, int dir, void *stream) {
+  if (check_group(c, group) != RDSP_OK) return RDSP_ERR_INVALID;
+  GroupState &g = c->groups[(size_t)group];
+  double lo = g.lo, hi = g.hi;
+  int rc = rdsp_pbt_step(&lo, &hi, edge, dir);
+  if (rc != RDSP_OK) return rc;
+  return rdsp_group_reInitializeFilter(c, group, lo, hi, stream); /* CTL:575,582,597,605 */
+}
+
+/* tuningMode() (CTL:330-423): the mode table of the sketch.  mndx 0 "CW N" (500 Hz),
+ * 1 "CW" (2.1 kHz), 2 "USB", 3 "LSB", 4 "AM", 5 "SAM", 6 "RTTY"; CW side chosen by
+ * vfoFreq > 10 MHz (CTL:337,349).  Returns TuningOffset; SAM is SURVEY F3 (not built). */
+extern "C" uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, double vfo_hz, void *stream) {
+  if (check_group(c, group) != RDSP_OK) return 0;
+  int filter, mode;
+  switch (mndx) {
+    case 0: filter = RDSP_AUDIO_CW; mode = vfo_hz > 10000000.0 ? RDSP_DEMOD_CW_USB : RDSP_DEMOD_CW_LSB; break;
+    case 1: filter = RDSP_AUDIO_2100; mode = vfo_hz > 10000000.0 ? RDSP_DEMOD_CW_USB : RDSP_DEMOD_CW_LSB; break;
+    case 2: filter = RDSP_AUDIO_2700; mode = RDSP_DEMOD_USB; break;
+    case 3: filter = RDSP_AUDIO_2700; mode = RDSP_DEMOD_LSB; break;
+    case 4: filter = RDSP_AUDIO_AM; mode = RDSP_DEMOD_AM; break;
+    case 6: filter = RDSP_AUDIO_2100; mode = RDSP_DEMOD_USB; break;
+    default: rdsp_set_error("tuningMode %d not built (SAM: SURVEY F3)", mndx); return 0;
+  }
+  c->groups[(size_t)group].audio_filter = filter;      /* SDR.setAudioFilter(...) */
+  return rdsp_group_setDemodMode(c, group, mode, stream); /* TuningOffset = SDR.setDemodMode(...) */
 }
 
 /* ---- pipelined mode ---------------------------------------------------------------- */
@@ -585,6 +874,7 @@ static int drain_tail(rdsp_chain_t *c) {
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   return RDSP_OK;
 }
+static int drain_tail_fwd(rdsp_chain_t *c) { return drain_tail(c); }
 extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
@@ -679,7 +969,7 @@ extern "C" int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host
 }
 extern "C" int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out) {
   NEED(c);
-  memcpy(host_out, c->mask_nat.data(), sizeof(float) * 2 * (size_t)c->N);
+  memcpy(host_out, c->groups[0].mask_nat.data(), sizeof(float) * 2 * (size_t)c->N);
   return RDSP_OK;
 }
 extern "C" int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out) {

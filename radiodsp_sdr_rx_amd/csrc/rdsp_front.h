@@ -107,6 +107,12 @@ RDSP_HD float2 nco_phasor_alu(uint32_t ph) {
   return make_float2(fmaf(-sn, r, cs), -fmaf(cs, r, sn));
 }
 
+/* complex product with the contraction written out: the mixer's phasors must come
+ * out bit-identical wherever they are recomputed (FIR history at the start of a call) */
+RDSP_HD float2 cmul_pinned(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
 /* arm_float_to_q15 semantics (CONV:346-347): x*32768, truncate, saturate */
 RDSP_HD int q15_of_float(float x) {
   float v = x * 32768.0f;

@@ -15,6 +15,23 @@
 
 enum { RDSP_K_DEMOD_IQ = 0, RDSP_K_DEMOD_REAL = 1, RDSP_K_DEMOD_AM = 2 };
 
+/* One receiver group: channels of a group share tuning offset, filter
+ * mask and demodulator.  128 bytes, read once per workgroup into scalar registers;
+ * the host rewrites single records in stream order (rdsp_launch_group_store), so a
+ * retune never stalls the processing stream. */
+struct RdspGroup {
+  uint32_t dphi;       /* NCO phase increment per sample (turns * 2^32)      */
+  int32_t demod;       /* RDSP_K_DEMOD_*                                     */
+  float2 rot1, rot2, rot3;    /* exp(-j*2pi*k*dphi/2^32), k = 1..3           */
+  float2 rotp1, rotp2, rotp3; /* the same for k*4*NT samples (next load pass) */
+  uint32_t mask_off;   /* float2 offset of the group's active mask in the pool */
+  uint32_t dphi_hist;  /* increment the 256 history samples were mixed with: differs
+                          from dphi only in the first call after a tuning change   */
+  float2 roth1, roth2, roth3; /* rot1..3 for dphi_hist                            */
+  float2 rothp3;       /* rotp3 for dphi_hist                                      */
+  uint32_t pad[8];
+};
+
 /* front kernel: A1 unpack, A2 mixer, A3 decimator, A5 overlap-save filter,
  * A6 spectral NR, demod select, and (when no NLMS stage follows) A9 AGC,
  * output gain and A10 pack. */
@@ -23,16 +40,14 @@ struct RdspFrontParams {
   size_t in_stride;    /* samples per channel row                            */
   int n_chunks;        /* chunks of 256*DECIM input samples in this launch   */
   uint32_t n0;         /* absolute index (mod 2^32) of the first sample      */
-  uint32_t dphi;       /* NCO phase increment per sample (turns * 2^32)      */
-  float2 rot1, rot2, rot3; /* exp(-j*2pi*k*dphi/2^32), k = 1..3              */
-  float2 rotp1, rotp2, rotp3; /* the same for k*4*NT samples (next load pass) */
+  const RdspGroup *groups;   /* [n_groups] tuning / mask / demod records     */
+  const uint16_t *group_of;  /* [ch] group of each channel; NULL: all group 0 */
   float scale_i, scale_q;  /* iq_balance*input_gain/32768, input_gain/32768  */
   const float *fir_hc;     /* [4][64] decimator taps, hc[c][k'] = h[4k'+c]   */
-  const float2 *maskp;     /* [N] mask/N in digit-reversed bin order         */
+  const float2 *mask_pool; /* [n_groups][2][N] masks/N, digit-reversed, thread-major (double-buffered) */
   int spectral_on;
   float spectral_k;        /* (float)(level*1.5)                             */
   int vad_lo, vad_hi;      /* inclusive natural bin range                    */
-  int demod;               /* RDSP_K_DEMOD_*                                 */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
   int lean;                /* 1: register-lean variant (co-resident with the tail kernel) */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
@@ -82,6 +97,7 @@ extern "C" {
 int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_channels,
                       hipStream_t stream);
 int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream);
+int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hipStream_t stream);
 int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream);
 int rdsp_launch_float_to_q15(const float *src, int16_t *dst, size_t n, hipStream_t stream);
 size_t rdsp_front_lds_bytes(int fft_l, int decim);

@@ -21,6 +21,8 @@
  * gain, NLMS weights) is read at launch start and written back at the end, so
  * its traffic is amortised over the time batch.
  */
+#include <string.h>
+
 #include "rdsp_front.h"
 #include "rdsp_wave.h"
 
@@ -67,6 +69,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
   static_assert(NT == 64 || NT == 256, "one or four waves per channel");
   static_assert(NW == 1 || PL::WB >= 4 * CH_OUT, "work buffer holds the FIR partial sums");
+  static_assert(LP == 4 || LP == 1, "the history phasor below follows the scatter loop's passes");
 
   /* LDS: [polyphase planes | new hop(s) | work buffer (unless aliased into the
    * planes) | decimator taps | reduction scratch].  The previous hop is not in
@@ -83,6 +86,16 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   const int wave = tid >> 6;
   const size_t ch = blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
+  /* this channel's group record into scalar registers */
+  RdspGroup G;
+  {
+    const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
+    const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
+    uint32_t r[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) r[i] = (i < 24) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gw[i]) : 0u;
+    G = __builtin_bit_cast(RdspGroup, r);
+  }
 
   /* first uint4 loads of chunk 0 go out before anything else */
   uint4 raw[LP];
@@ -121,15 +134,24 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     for (int i = tid; i < 64; i += NT) {
       uint4 w4 = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * i);
       uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-      uint32_t nabs = p.n0 - 256u + 4u * (uint32_t)i;
+      /* the same phasor arithmetic these samples went through as the last 256 of the
+       * previous chunk (pass LP-1 of the scatter loop below), so that a stream gives
+       * the same bits however it is cut into calls */
       float2 ph0 = make_float2(1.f, 0.f);
-      if (p.dphi != 0u) ph0 = nco_phasor_alu(nabs * p.dphi);
+      if (G.dphi_hist != 0u) {
+        if constexpr (LP == 4) {
+          ph0 = nco_phasor_alu((p.n0 - (uint32_t)CH_IN + 4u * (uint32_t)i) * G.dphi_hist);
+          ph0 = cmul_pinned(ph0, G.rothp3);
+        } else {
+          ph0 = nco_phasor_alu((p.n0 - 256u + 4u * (uint32_t)i) * G.dphi_hist);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         float2 x = unpack_iq(w[k], p.scale_i, p.scale_q);
-        if (p.dphi != 0u) {
-          float2 ph = (k == 0) ? ph0 : cmul(ph0, k == 1 ? p.rot1 : (k == 2 ? p.rot2 : p.rot3));
-          x = cmul(x, ph);
+        if (G.dphi_hist != 0u) { /* the history keeps the mixing it went through when it was new */
+          float2 ph = (k == 0) ? ph0 : cmul_pinned(ph0, k == 1 ? G.roth1 : (k == 2 ? G.roth2 : G.roth3));
+          x = cmul_pinned(x, ph);
         }
         xs[xs_pos(-256 + 4 * i + k)] = x;
       }
@@ -149,27 +171,27 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
      * not hoisted out of the chunk loop into 2P persistent registers. */
     float2 mreg[P];
     {
-      const float2 *mp = p.maskp;
+      const float2 *mp = p.mask_pool + G.mask_off;
       if constexpr (LEAN) asm volatile("" : "+s"(mp));
 #pragma unroll
       for (int e = 0; e < P; e++) mreg[e] = mp[e * NT + tid];
     }
     float2 ph_base = make_float2(1.f, 0.f);
-    if (p.dphi != 0u)
-      ph_base = nco_phasor_alu((p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)tid) * p.dphi);
+    if (G.dphi != 0u)
+      ph_base = nco_phasor_alu((p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)tid) * G.dphi);
 #pragma unroll
     for (int k = 0; k < LP; k++) {
       int idx = tid + NT * k;
       if (idx < CH_IN / 4) {
         uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
         float2 ph0 = ph_base;
-        if (k > 0 && p.dphi != 0u) ph0 = cmul(ph_base, k == 1 ? p.rotp1 : (k == 2 ? p.rotp2 : p.rotp3));
+        if (k > 0 && G.dphi != 0u) ph0 = cmul_pinned(ph_base, k == 1 ? G.rotp1 : (k == 2 ? G.rotp2 : G.rotp3));
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           float2 x = unpack_iq(w[j], p.scale_i, p.scale_q);
-          if (p.dphi != 0u) {
-            float2 ph = (j == 0) ? ph0 : cmul(ph0, j == 1 ? p.rot1 : (j == 2 ? p.rot2 : p.rot3));
-            x = cmul(x, ph);
+          if (G.dphi != 0u) {
+            float2 ph = (j == 0) ? ph0 : cmul_pinned(ph0, j == 1 ? G.rot1 : (j == 2 ? G.rot2 : G.rot3));
+            x = cmul_pinned(x, ph);
           }
           if constexpr (DECIM == 4) {
             xs[xs_pos(4 * idx + j)] = x;
@@ -326,10 +348,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         __syncthreads();
       };
 
-      if (p.demod == RDSP_K_DEMOD_REAL) {
+      if (G.demod == RDSP_K_DEMOD_REAL) {
 #pragma unroll
         for (int jj = 0; jj < PH; jj++) R[jj] = L[jj];
-      } else if (p.demod == RDSP_K_DEMOD_AM) {
+      } else if (G.demod == RDSP_K_DEMOD_AM) {
         float a[PH];
 #pragma unroll
         for (int jj = 0; jj < PH; jj++) a[jj] = sqrtf(L[jj] * L[jj] + R[jj] * R[jj]);
@@ -419,6 +441,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   }
 }
 
+/* one group record, rewritten in stream order (32 threads, one dword each) */
+struct RdspGroupWords { uint32_t w[32]; };
+__global__ void rdsp_group_store_kernel(uint32_t *dst, RdspGroupWords v) { dst[threadIdx.x] = v.w[threadIdx.x]; }
+
 /* ---- standalone A1 / A10 (bit-exact tests of the int16 <-> float edges) ---- */
 __global__ void rdsp_q15_to_float_kernel(const int16_t *src, float *dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,6 +508,14 @@ extern "C" int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p,
     case 4096: return d4 ? launch_front_t<4096, 16, 4>(p, n_channels, stream) : launch_front_t<4096, 16, 1>(p, n_channels, stream);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+extern "C" int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hipStream_t stream) {
+  static_assert(sizeof(RdspGroup) == 128, "group record is 32 dwords");
+  RdspGroupWords v;
+  memcpy(&v, val, sizeof(v));
+  hipLaunchKernelGGL(rdsp_group_store_kernel, dim3(1), dim3(32), 0, stream, reinterpret_cast<uint32_t *>(dst), v);
+  return (int)hipGetLastError();
 }
 
 extern "C" int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream) {

@@ -127,6 +127,12 @@ def load(path=None):
     lib.orc_chain_nco_dphi.restype = C.c_uint32
     lib.orc_demod_tuning_offset.argtypes = [C.c_int]
     lib.orc_demod_tuning_offset.restype = C.c_uint32
+    lib.orc_set_demod.argtypes = [vp, C.c_int]
+    lib.orc_set_nco_hz.argtypes = [vp, C.c_double]
+    lib.orc_pbt_step.argtypes = [f64p, f64p, C.c_int, C.c_int]
+    lib.orc_passband.argtypes = [C.c_int, C.c_int, f64p, f64p]
+    lib.orc_tuning_mode.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.orc_tuning_mode.restype = C.c_int
     lib.orc_multi_process.argtypes = [C.POINTER(OrcConfig), C.c_int, i16p, C.c_int, i16p, C.c_int]
     lib.orc_multi_process.restype = C.c_int
     if path is None:
@@ -187,6 +193,35 @@ class OracleChain:
 
     def set_nr_level(self, lvl):
         self.lib.orc_set_nr_level(self.h, lvl)
+
+    def set_demod(self, demod):
+        self.lib.orc_set_demod(self.h, int(demod))
+
+    def set_nco_hz(self, hz):
+        self.lib.orc_set_nco_hz(self.h, float(hz))
+
+
+def pbt_step(lo, hi, edge, direction, lib=None):
+    """checkPBT_Increase/Decrease (CTL:569-612) restated; returns (lo, hi)."""
+    lib = lib or load()
+    a, b = C.c_double(lo), C.c_double(hi)
+    lib.orc_pbt_step(C.byref(a), C.byref(b), edge, direction)
+    return a.value, b.value
+
+
+def passband(filt, demod, lib=None):
+    lib = lib or load()
+    a, b = C.c_double(), C.c_double()
+    lib.orc_passband(filt, demod, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def tuning_mode(mndx, vfo_hz, lib=None):
+    """tuningMode() table (CTL:330-423): (ok, filter, demod)."""
+    lib = lib or load()
+    f, d = C.c_int(), C.c_int()
+    ok = lib.orc_tuning_mode(mndx, vfo_hz, C.byref(f), C.byref(d))
+    return bool(ok), f.value, d.value
 
 
 def multi_process(iq, n_threads=1, lib=None, **kw):
