@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="receiver groups (SURVEY F2): channel c in group c %% G, every group with its own pass band")
+    ap.add_argument("--retune-every", type=int, default=0,
+                    help="with --groups: re-tune one group (PBT step) every N timed steps, without synchronising")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
     return ap.parse_args()
 
@@ -217,6 +221,12 @@ def main():
 
     chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, **cfg)
     chain.set_pipelined(not args.no_pipeline)
+    if args.groups > 1:
+        import numpy as np
+        chain.set_groups(np.arange(nch, dtype=np.uint16) % args.groups)
+        for g in range(args.groups):  # distinct masks: the kernel's mask reads become a gather by group
+            chain.group_reInitializeFilter(g, cfg.get("flo_hz", 300.0) + 10.0 * (g % 16),
+                                           cfg.get("fhi_hz", 2700.0) - 10.0 * (g // 16 % 16))
 
     def barrier():
         torch.cuda.synchronize()
@@ -231,7 +241,9 @@ def main():
     barrier()
     chain.set_timing(not args.no_kernel_timing)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if args.groups > 1 and args.retune_every and k % args.retune_every == 0:
+            chain.group_pbt((k // args.retune_every) % args.groups, k & 1, 1 if (k >> 1) & 1 else -1)
         chain.process(iq, out=out)
     chain.flush()  # every step's audio is complete inside the timed region
     torch.cuda.synchronize()
@@ -298,6 +310,8 @@ def main():
                 "blocks_per_step": nblk,
                 "sharding": f"channels x{world}, no collectives",
                 "pipelined": not args.no_pipeline,
+                "groups": args.groups,
+                "retune_every_steps": args.retune_every,
             },
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
                           "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS},
