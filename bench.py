@@ -45,6 +45,8 @@ def parse():
                     help="receiver groups (SURVEY F2): channel c in group c %% G, every group with its own pass band")
     ap.add_argument("--retune-every", type=int, default=0,
                     help="with --groups: re-tune one group (PBT step) every N timed steps, without synchronising")
+    ap.add_argument("--no-host-io", action="store_true",
+                    help="skip the extra PCIe-inclusive leg (host memory -> chain -> host memory)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
     return ap.parse_args()
 
@@ -324,6 +326,29 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
             "input_gen_s": gen_s,
         }
+        if world == 1 and not args.no_host_io:
+            # extra, un-timed for `value`: the same chain fed from and drained to host memory through
+            # rdsp_stream_run_memory (pinned double buffers, upload / kernels / download overlapped)
+            try:
+                from radiodsp_sdr_rx_amd.io import stream_memory
+                h_blocks, h_per = 256, 64
+                h_iq = synth_iq(nch, h_blocks * 128, cw=kc.get("cw", False), n_threads=threads)
+                chain.set_pipelined(not args.no_pipeline)
+                chain.reset()
+                import numpy as np
+                h_out = np.zeros((nch, h_blocks * 128 // decim, 2), np.int16)
+                stream_memory(chain, h_iq[:, :h_per * 2 * 128], h_per)  # warm-up
+                chain.reset()
+                _, st = stream_memory(chain, h_iq, h_per, out=h_out)
+                tot = float(nch) * st["samples_in"]
+                res["host_io"] = {"value": tot / st["seconds"] / 1e6, "unit": "IQ Msamples/s",
+                                  "pcie_GBps": (tot * 4 + float(nch) * st["samples_out"] * 4) / st["seconds"] / 1e9,
+                                  "sample": f"{nch} channels x {h_blocks} blocks from pageable host memory, "
+                                            f"{h_per} blocks per batch; set-up (pinned allocation) inside the timed run",
+                                  "seconds": st["seconds"]}
+                del h_iq, h_out
+            except Exception as e:
+                res["host_io"] = {"value": None, "sample": f"failed: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",

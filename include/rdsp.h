@@ -225,6 +225,55 @@ int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void 
 int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out);
 int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);
 
+/* ---- recorded IQ in, audio out ----------------------------------
+ * The ends of the sketch's graph are an I2S bus and a codec (AudioInputI2S IQinput,
+ * AudioOutputI2S audio_out, AudioControlSGTL5000 codec: INO:52,55,159-169).  A
+ * host has recordings: little-endian int16 I,Q pairs, RAW (no header) or RIFF/WAVE
+ * PCM 16-bit stereo with I on the left channel and Q on the right (the codec wiring
+ * INO:71-72); audio goes out as int16 L,R pairs (Q_out_L / Q_out_R, CONV:344-349). */
+enum { RDSP_IO_AUTO = 0, RDSP_IO_RAW = 1, RDSP_IO_WAV = 2 };
+typedef struct rdsp_iq_reader rdsp_iq_reader_t;
+typedef struct rdsp_audio_writer rdsp_audio_writer_t;
+int rdsp_iq_reader_open(const char *path, int format, rdsp_iq_reader_t **out);
+double rdsp_iq_reader_sample_rate(const rdsp_iq_reader_t *r); /* 0: the container does not say */
+int64_t rdsp_iq_reader_frames(const rdsp_iq_reader_t *r);     /* IQ pairs, -1 unknown */
+int rdsp_iq_reader_format(const rdsp_iq_reader_t *r);
+size_t rdsp_iq_reader_read(rdsp_iq_reader_t *r, int16_t *dst, size_t n_pairs);
+void rdsp_iq_reader_close(rdsp_iq_reader_t *r);
+int rdsp_audio_writer_open(const char *path, int format, double sample_rate, rdsp_audio_writer_t **out);
+size_t rdsp_audio_writer_write(rdsp_audio_writer_t *w, const int16_t *lr, size_t n_pairs);
+int64_t rdsp_audio_writer_frames(const rdsp_audio_writer_t *w);
+int rdsp_audio_writer_close(rdsp_audio_writer_t *w); /* patches the WAV sizes */
+
+/* Streaming runner: what loop() does with the record/play queues (INO:195-198,
+ * CONV:231-244,344-349), for host data.  source fills int16 IQ rows
+ * dst[ch * stride_pairs * 2 ...] with n_blocks * 128 pairs per channel and returns
+ * the blocks delivered (fewer = end of stream; a trailing partial granule is not
+ * processed, as the sketch never processes one); sink receives the int16 L,R rows.
+ * Uploads, kernels and downloads of consecutive batches overlap (three streams,
+ * two pinned slots).  blocks_per_call must be a multiple of the chain's granule;
+ * max_blocks <= 0 means "until the source ends". */
+typedef int (*rdsp_source_fn)(void *user, int16_t *dst, size_t stride_pairs, int n_blocks);
+typedef int (*rdsp_sink_fn)(void *user, const int16_t *src, size_t stride_pairs, int n_pairs);
+typedef struct {
+  int64_t blocks;      /* 128-sample input blocks processed per channel */
+  int64_t samples_in;  /* per channel */
+  int64_t samples_out; /* per channel */
+  double seconds;      /* wall time of the run, set-up included */
+  double read_seconds; /* host time inside source() */
+  double write_seconds;/* host time inside sink()   */
+} rdsp_stream_stats_t;
+int rdsp_stream_run(rdsp_chain_t *c, rdsp_source_fn source, void *source_user, rdsp_sink_fn sink,
+                    void *sink_user, int blocks_per_call, int64_t max_blocks, rdsp_stream_stats_t *stats);
+/* one reader and one writer per channel; the shortest recording ends the run */
+int rdsp_stream_run_files(rdsp_chain_t *c, rdsp_iq_reader_t *const *readers,
+                          rdsp_audio_writer_t *const *writers, int blocks_per_call, int64_t max_blocks,
+                          rdsp_stream_stats_t *stats);
+/* host arrays int16 [n_channels][stride_pairs][2] at both ends */
+int rdsp_stream_run_memory(rdsp_chain_t *c, const int16_t *host_iq, size_t in_stride_pairs, int64_t n_blocks,
+                           int16_t *host_out, size_t out_stride_pairs, int blocks_per_call,
+                           rdsp_stream_stats_t *stats);
+
 /* ---- block graph: the AudioStream node/connection API --------------
  * A block is a tile int16 [n_channels][128]; n_channels = 1 is the reference's
  * audio_block_t (FFTIQ.cpp:44,67).  Host-side plumbing in plain C. */

@@ -60,7 +60,15 @@ class SynthConfig(C.Structure):
     ]
 
 
+class StreamStats(C.Structure):
+    """rdsp_stream_stats_t (include/rdsp.h)."""
+    _fields_ = [("blocks", C.c_int64), ("samples_in", C.c_int64), ("samples_out", C.c_int64),
+                ("seconds", C.c_double), ("read_seconds", C.c_double), ("write_seconds", C.c_double)]
+
+
 _lib = None
+SOURCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int16), C.c_size_t, C.c_int)  # rdsp_source_fn
+SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int16), C.c_size_t, C.c_int)    # rdsp_sink_fn
 
 UPDATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)  # rdsp_update_fn
 
@@ -115,6 +123,19 @@ SYMBOLS = [
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
     ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
     ("rdsp_chain_get_mask", _i, [_vp, _f32p]),
+    ("rdsp_iq_reader_open", _i, [C.c_char_p, _i, C.POINTER(_vp)]),
+    ("rdsp_iq_reader_sample_rate", _d, [_vp]),
+    ("rdsp_iq_reader_frames", C.c_int64, [_vp]),
+    ("rdsp_iq_reader_format", _i, [_vp]),
+    ("rdsp_iq_reader_read", _sz, [_vp, _i16p, _sz]),
+    ("rdsp_iq_reader_close", None, [_vp]),
+    ("rdsp_audio_writer_open", _i, [C.c_char_p, _i, _d, C.POINTER(_vp)]),
+    ("rdsp_audio_writer_write", _sz, [_vp, _i16p, _sz]),
+    ("rdsp_audio_writer_frames", C.c_int64, [_vp]),
+    ("rdsp_audio_writer_close", _i, [_vp]),
+    ("rdsp_stream_run", _i, [_vp, SOURCE_FN, _vp, SINK_FN, _vp, _i, C.c_int64, C.POINTER(StreamStats)]),
+    ("rdsp_stream_run_files", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, C.c_int64, C.POINTER(StreamStats)]),
+    ("rdsp_stream_run_memory", _i, [_vp, _i16p, _sz, C.c_int64, _i16p, _sz, _i, C.POINTER(StreamStats)]),
     ("rdsp_chain_set_groups", _i, [_vp, _i, C.POINTER(C.c_uint16)]),
     ("rdsp_chain_groups", _i, [_vp]),
     ("rdsp_group_reInitializeFilter", _i, [_vp, _i, _d, _d, _vp]),

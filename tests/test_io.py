@@ -1,0 +1,188 @@
+"""recorded-IQ reader, audio writer, streaming runner.
+
+CPU part: the file layer against independent implementations (Python's `wave`
+module and numpy's raw int16 reader) -- byte-exact, since this is integer data.
+GPU part: files -> rdsp_stream_run_files -> files equals (bit for bit) what the
+chain gives for the same samples resident in HBM, and follows the oracle within
++-1 LSB of the int16 audio (float parity is covered by test_gpu_parity.py)."""
+import os
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+from cases import K1, K3
+
+
+def _write_wav_py(path, iq, rate):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(np.ascontiguousarray(iq, dtype="<i2").tobytes())
+
+
+def test_reader_raw_and_wav_byte_exact(rdsp, tmp_path):
+    from radiodsp_sdr_rx_amd.io import IO_RAW, IO_WAV, IqReader
+    rng = np.random.default_rng(11)
+    iq = rng.integers(-32768, 32768, size=(5000, 2), dtype=np.int16)
+    raw = tmp_path / "a.iq"
+    iq.astype("<i2").tofile(raw)
+    r = IqReader(raw)
+    assert r.format == IO_RAW and r.frames == 5000 and r.sample_rate == 0.0
+    got = np.concatenate([r.read(1234), r.read(1234), r.read(5000)])
+    assert np.array_equal(got, iq) and len(r.read(10)) == 0
+    wav = tmp_path / "a.wav"
+    _write_wav_py(wav, iq, 96000)
+    r = IqReader(wav)
+    assert r.format == IO_WAV and r.frames == 5000 and r.sample_rate == 96000.0
+    assert np.array_equal(r.read(6000), iq)
+
+
+def test_reader_wav_with_extra_chunks_and_extensible_header(rdsp, tmp_path):
+    """LIST chunk before fmt, odd-sized chunk padding, WAVE_FORMAT_EXTENSIBLE, unfinalised data size."""
+    from radiodsp_sdr_rx_amd.io import IqReader
+    iq = (np.arange(600, dtype=np.int16).reshape(300, 2) - 300)
+    data = iq.astype("<i2").tobytes()
+    fmt_ext = struct.pack("<HHIIHHHHIH14s", 0xFFFE, 2, 48000, 48000 * 4, 4, 16, 22, 16, 3, 1,
+                          bytes.fromhex("000000001000800000aa00389b71"))
+    body = b"WAVE" + b"LIST" + struct.pack("<I", 5) + b"abcde\0" + b"fmt " + struct.pack("<I", len(fmt_ext)) + fmt_ext
+    body += b"data" + struct.pack("<I", 0xFFFFFFFF) + data          # recorder never patched the size
+    p = tmp_path / "x.wav"
+    p.write_bytes(b"RIFF" + struct.pack("<I", 0xFFFFFFFF) + body)
+    r = IqReader(p)
+    assert r.sample_rate == 48000.0 and r.frames == -1
+    assert np.array_equal(r.read(1000), iq)
+
+
+def test_reader_rejects_what_it_cannot_play(rdsp, tmp_path):
+    from radiodsp_sdr_rx_amd import RdspError
+    from radiodsp_sdr_rx_amd.io import IO_WAV, IqReader
+    with pytest.raises(RdspError):
+        IqReader(tmp_path / "missing.iq")
+    mono = tmp_path / "mono.wav"
+    with wave.open(str(mono), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000); w.writeframes(b"\0\0" * 10)
+    with pytest.raises(RdspError):
+        IqReader(mono)
+    junk = tmp_path / "junk.wav"
+    junk.write_bytes(b"not a wave file at all")
+    with pytest.raises(RdspError):
+        IqReader(junk, IO_WAV)
+
+
+def test_writer_wav_is_readable_by_the_wave_module(rdsp, tmp_path):
+    from radiodsp_sdr_rx_amd.io import IO_RAW, IO_WAV, AudioWriter
+    rng = np.random.default_rng(12)
+    lr = rng.integers(-32768, 32768, size=(3001, 2), dtype=np.int16)
+    p = tmp_path / "o.wav"
+    w = AudioWriter(p, IO_WAV, 24000.0)
+    assert w.write(lr[:1000]) == 1000 and w.write(lr[1000:]) == 2001 and w.frames == 3001
+    w.close()
+    with wave.open(str(p), "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (2, 2, 24000, 3001)
+        assert np.array_equal(np.frombuffer(f.readframes(3001), "<i2").reshape(-1, 2), lr)
+    assert os.path.getsize(p) == 44 + 3001 * 4
+    q = tmp_path / "o.raw"
+    w = AudioWriter(q, IO_RAW)
+    w.write(lr); w.close()
+    assert np.array_equal(np.fromfile(q, "<i2").reshape(-1, 2), lr)
+
+
+# ---- GPU: the streaming runner ------------------------------------------------------------
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg,pipelined", [("k1", K1, False), ("k3", K3, True)])
+def test_files_through_the_runner_match_resident_processing_and_oracle(rdsp, oracle, torch_cuda, tmp_path, name, cfg, pipelined):
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.io import IO_RAW, IO_WAV, AudioWriter, IqReader, stream_files
+    nch, per, calls = 3, 16, 5
+    nblk = per * calls
+    iq = synth_iq(nch, nblk * 128 + 300)       # 300 trailing samples: two blocks and a partial one, never a granule
+    readers, writers = [], []
+    for c in range(nch):
+        if c % 2 == 0:
+            p = tmp_path / f"in{c}.wav"
+            _write_wav_py(p, iq[c], 96000)
+        else:
+            p = tmp_path / f"in{c}.iq"
+            iq[c].astype("<i2").tofile(p)
+        readers.append(IqReader(p))
+        writers.append(AudioWriter(tmp_path / f"out{c}.wav", IO_WAV, 24000.0) if c % 2 == 0
+                       else AudioWriter(tmp_path / f"out{c}.raw", IO_RAW))
+    ch = Chain(nch, max_blocks_per_call=per, **cfg)
+    ch.set_pipelined(pipelined)
+    st = stream_files(ch, readers, writers, per)
+    for w in writers:
+        w.close()
+    gran = 8 if cfg["fft_l"] <= 512 else cfg["fft_l"] // 64
+    exp_blocks = (iq.shape[1] // 128) // gran * gran
+    assert st["blocks"] == exp_blocks and st["samples_out"] == exp_blocks * 32
+    got = []
+    for c in range(nch):
+        if c % 2 == 0:
+            with wave.open(str(tmp_path / f"out{c}.wav"), "rb") as f:
+                assert f.getframerate() == 24000
+                got.append(np.frombuffer(f.readframes(f.getnframes()), "<i2").reshape(-1, 2))
+        else:
+            got.append(np.fromfile(tmp_path / f"out{c}.raw", "<i2").reshape(-1, 2))
+    got = np.stack(got)
+    assert got.shape == (nch, exp_blocks * 32, 2)
+    # the same samples resident in HBM, one call per batch of `per` blocks + the tail batch
+    ref_chain = Chain(nch, max_blocks_per_call=per, **cfg)
+    if pipelined:
+        ref_chain.set_front_variant(1)   # pipelined mode runs the register-lean front kernel
+    parts, pos = [], 0
+    while pos < exp_blocks:
+        take = min(per, exp_blocks - pos)
+        dev = torch.from_numpy(np.ascontiguousarray(iq[:, pos * 128:(pos + take) * 128])).cuda()
+        parts.append(ref_chain.process(dev).cpu().numpy())
+        pos += take
+    assert np.array_equal(got, np.concatenate(parts, 1))
+    # and the oracle on the int16 audio
+    for c in range(nch):
+        r16 = oracle.OracleChain(**cfg).process(iq[c, :exp_blocks * 128])[0]
+        d = np.abs(got[c].astype(np.int32) - r16.astype(np.int32))
+        lim = 1 if name == "k1" else 16          # k3 carries the NLMS start-up conditioning (test_gpu_parity.py)
+        assert d.max() <= lim
+
+
+@pytest.mark.gpu
+def test_memory_runner_and_callbacks(rdsp, torch_cuda):
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.io import stream_callbacks, stream_memory
+    nch, nblk, per = 4, 64, 8
+    iq = synth_iq(nch, nblk * 128)
+    out, st = stream_memory(Chain(nch, max_blocks_per_call=per, **K1), iq, per)
+    ref = Chain(nch, max_blocks_per_call=nblk, **K1).process(torch.from_numpy(iq).cuda()).cpu().numpy()
+    assert st["blocks"] == nblk and np.array_equal(out, ref)
+    # generic callbacks: a source that dries up mid-batch (5 of 8 blocks: not a granule -> dropped)
+    state = {"pos": 0}
+    chunks = []
+
+    def source(dst):
+        n = min(dst.shape[1] // 128, (nblk - 3) - state["pos"])
+        dst[:, :n * 128] = iq[:, state["pos"] * 128:(state["pos"] + n) * 128]
+        state["pos"] += n
+        return n
+
+    st = stream_callbacks(Chain(nch, max_blocks_per_call=per, **K1), source, chunks.append, per)
+    assert st["blocks"] == 56
+    assert np.array_equal(np.concatenate(chunks, 1), ref[:, :56 * 32])
+
+
+@pytest.mark.gpu
+def test_runner_argument_errors(rdsp, torch_cuda):
+    from radiodsp_sdr_rx_amd import RdspError
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.io import stream_memory
+    iq = synth_iq(2, 16 * 128)
+    with pytest.raises(RdspError):
+        stream_memory(Chain(2, max_blocks_per_call=16, **K1), iq, 12)     # not a granule multiple
