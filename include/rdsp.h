@@ -150,9 +150,16 @@ int rdsp_sdr_disableALSfilter(rdsp_chain_t *c);                   /* INO:125 */
 int rdsp_sdr_setALSfilterNotch(rdsp_chain_t *c);                  /* CTL:260 */
 int rdsp_sdr_setALSfilterPeak(rdsp_chain_t *c);                   /* BK_INO:665 */
 int rdsp_sdr_setALSfilterAdaptive(rdsp_chain_t *c);               /* CTL:261 */
-int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c);                 /* BK_INO:1259 (F3: unsupported) */
+/* noise blanker: engine feature, arithmetic build-defined: on the
+ * wide-band IQ stream before the mixer, a sample whose power exceeds the reference
+ * level by threshold dB (default 10, range 0..60) is zeroed; the reference level is
+ * the smoothed mean power of the previous windows of 256*decim input samples */
+int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c);                 /* BK_INO:1259 */
 int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c);                /* INO:131 */
-int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db); /* BK_INO:1260 (F3) */
+int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db); /* BK_INO:1260 */
+/* AudioSDRpreProcessor */
+int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap);                   /* INO:118 */
+int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c);         /* INO:117: no I2S bus here, accepted and ignored */
 int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g);              /* INO:133 */
 int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g);             /* INO:134 */
 int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g);          /* INO:135 */
@@ -216,7 +223,7 @@ int rdsp_chain_set_timing(rdsp_chain_t *c, int on);
 int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *tail_ms, int *calls);
 
 /* ---- state read-back (tests, checkpoint/resume) ------------------------------*/
-/* scal: float[n_channels][4] = NFloor (SPEC:109), AGC gain, AM DC, reserved */
+/* scal: float[n_channels][4] = NFloor (SPEC:109), AGC gain, AM DC, noise-blanker level */
 int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream);
 /* which: 0 = DSP-NR instance (NR:31), 1 = ALS instance; float[n_channels][96] in
  * CMSIS coefficient order */

@@ -262,6 +262,13 @@ struct orc_chain {
   orc_lms_t nr, als;
   float agc_g;
   float am_dc;
+  /* F3 (build-defined): pre-processor IQ swap, noise blanker */
+  int swap_iq;
+  int nb_on;
+  float nb_thr;   /* threshold as a power ratio, 10^(dB/10) */
+  float nb_level; /* reference power: smoothed mean |x|^2 of the past windows */
+  float nb_acc;   /* post-blanking power accumulated in the current window */
+  uint32_t nb_fill;
 };
 
 uint32_t orc_demod_tuning_offset(int demod) {
@@ -305,6 +312,20 @@ void orc_reInitializeFilter(orc_chain_t *c, double lo, double hi) {
                            c->fs_out, c->cfg.window);
   orc_init_filter_mask(c->FIR_filter_mask, c->coef_I, c->coef_Q, c->fft_l);
 }
+
+/* ---- F3: pre-processor swapIQ (INO:118) and the engine's noise blanker (BK_INO:1259-1260,
+ * INO:131).  Both live in the AudioSDR library, so the arithmetic is build-defined:
+ * the blanker works on the wide-band IQ stream before the mixer, in windows of
+ * 256*decim input samples (the chunk the stage works in).  A sample whose power
+ * exceeds  level * 10^(dB/10)  is replaced by zero; `level` is the smoothed
+ * (alpha 0.2) mean post-blanking power of the previous windows, so every decision
+ * inside a window uses state from before the window. */
+void orc_set_swap_iq(orc_chain_t *c, int on) { c->swap_iq = on ? 1 : 0; }
+void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db) {
+  c->nb_on = on ? 1 : 0;
+  c->nb_thr = (float)pow(10.0, (double)threshold_db / 10.0);
+}
+float orc_chain_nb_level(const orc_chain_t *c) { return c->nb_level; }
 
 /* ---- F2: retune / PBT / mode table (the callers of CONV:209) ------------------- */
 /* run-time changes of the engine settings a mode switch touches */
@@ -566,11 +587,26 @@ int orc_chain_process(orc_chain_t *c, const int16_t *iq, int n_blocks,
     for (int i = 0; i < ORC_BLOCK; i++) {
       const int16_t *s = &iq[2 * ((size_t)b * ORC_BLOCK + (size_t)i)];
       /* arm_q15_to_float, CONV:241-242 */
-      float xr = (float)s[0] / 32768.0f;
-      float xi = (float)s[1] / 32768.0f;
+      float xr = (float)s[c->swap_iq ? 1 : 0] / 32768.0f; /* preProcessor.swapIQ, INO:118 */
+      float xi = (float)s[c->swap_iq ? 0 : 1] / 32768.0f;
       xr = xr * cf->iq_balance; /* setIQgainBalance, INO:135 */
       xr = xr * cf->input_gain; /* setInputGain, INO:133 */
       xi = xi * cf->input_gain;
+      if (c->nb_on) { /* noise blanker (build-defined, see orc_set_noise_blanker) */
+        const float pw = xr * xr + xi * xi;
+        if (c->nb_level > 0.0f && pw > c->nb_level * c->nb_thr) {
+          xr = 0.0f;
+          xi = 0.0f;
+        } else {
+          c->nb_acc += pw;
+        }
+        if (++c->nb_fill == 256u * (uint32_t)(cf->decim > 1 ? cf->decim : 1)) {
+          const float mean = c->nb_acc / (float)c->nb_fill;
+          c->nb_level = (c->nb_level > 0.0f) ? c->nb_level + 0.2f * (mean - c->nb_level) : mean;
+          c->nb_acc = 0.0f;
+          c->nb_fill = 0;
+        }
+      }
       uint64_t n = c->n_in++;
       if (c->dphi != 0u) { /* y = x * exp(-j*theta_n) */
         uint32_t ph = (uint32_t)n * c->dphi;

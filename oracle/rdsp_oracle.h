@@ -105,6 +105,12 @@ void orc_LMS_NoiseReduction(orc_chain_t *c, int16_t n, float *nrbuffer); /* NR:6
 void orc_Init_ALS(orc_chain_t *c, int strength);
 void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327 */
 
+/* F3 (build-defined engine features): preProcessor.swapIQ (INO:118), noise blanker
+ * (BK_INO:1259-1260, INO:131) */
+void orc_set_swap_iq(orc_chain_t *c, int on);
+void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db);
+float orc_chain_nb_level(const orc_chain_t *c);
+
 /* F2: retune / PBT / mode table -- the callers of reInitializeFilter (CTL:569-612)
  * and the mode menu (CTL:330-423) */
 void orc_set_demod(orc_chain_t *c, int demod);

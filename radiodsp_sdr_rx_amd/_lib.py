@@ -105,6 +105,8 @@ SYMBOLS = [
     ("rdsp_sdr_enableNoiseBlanker", _i, [_vp]),
     ("rdsp_sdr_disableNoiseBlanker", _i, [_vp]),
     ("rdsp_sdr_setNoiseBlankerThresholdDb", _i, [_vp, _f]),
+    ("rdsp_pre_swapIQ", _i, [_vp, _i]),
+    ("rdsp_pre_startAutoI2SerrorDetection", _i, [_vp]),
     ("rdsp_sdr_setInputGain", _i, [_vp, _f]),
     ("rdsp_sdr_setOutputGain", _i, [_vp, _f]),
     ("rdsp_sdr_setIQgainBalance", _i, [_vp, _f]),

@@ -109,6 +109,9 @@ class Chain:
     def setALSfilterAdaptive(self): _lib.check(self.lib.rdsp_sdr_setALSfilterAdaptive(self.h))
     def enableNoiseBlanker(self): _lib.check(self.lib.rdsp_sdr_enableNoiseBlanker(self.h))
     def disableNoiseBlanker(self): _lib.check(self.lib.rdsp_sdr_disableNoiseBlanker(self.h))
+    def setNoiseBlankerThresholdDb(self, db): _lib.check(self.lib.rdsp_sdr_setNoiseBlankerThresholdDb(self.h, float(db)))
+    def swapIQ(self, on): _lib.check(self.lib.rdsp_pre_swapIQ(self.h, int(bool(on))))
+    def startAutoI2SerrorDetection(self): _lib.check(self.lib.rdsp_pre_startAutoI2SerrorDetection(self.h))
     def setInputGain(self, g): _lib.check(self.lib.rdsp_sdr_setInputGain(self.h, float(g)))
     def setOutputGain(self, g): _lib.check(self.lib.rdsp_sdr_setOutputGain(self.h, float(g)))
     def setIQgainBalance(self, g): _lib.check(self.lib.rdsp_sdr_setIQgainBalance(self.h, float(g)))

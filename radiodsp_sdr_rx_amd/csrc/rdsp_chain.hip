@@ -5,6 +5,7 @@
  * HIP reports no device every compute entry point returns RDSP_ERR_NO_DEVICE.
  */
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -99,6 +100,9 @@ struct rdsp_chain {
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
+  int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
+  int nb_on = 0;              /* SDR.enableNoiseBlanker, BK_INO:1259 */
+  float nb_threshold_db = 10.0f;
 };
 
 static int drain_tail_fwd(rdsp_chain_t *c);
@@ -517,6 +521,9 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.n0 = (uint32_t)c->n_in;
   fp.scale_i = cf.iq_balance * cf.input_gain * (1.0f / 32768.0f);
   fp.scale_q = cf.input_gain * (1.0f / 32768.0f);
+  fp.swap_iq = c->swap_iq;
+  fp.nb_on = c->nb_on;
+  fp.nb_thr = (float)pow(10.0, (double)c->nb_threshold_db / 10.0);
   fp.fir_hc = c->d_fir_hc;
   fp.groups = c->d_groups;
   fp.group_of = c->d_group_of;
@@ -697,9 +704,20 @@ extern "C" int rdsp_sdr_disableALSfilter(rdsp_chain_t *c) { NEED(c); if (c->cfg.
 extern "C" int rdsp_sdr_setALSfilterNotch(rdsp_chain_t *c) { NEED(c); c->saved_als_mode = RDSP_ALS_NOTCH; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_NOTCH; return RDSP_OK; }
 extern "C" int rdsp_sdr_setALSfilterPeak(rdsp_chain_t *c) { NEED(c); c->saved_als_mode = RDSP_ALS_PEAK; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_PEAK; return RDSP_OK; }
 extern "C" int rdsp_sdr_setALSfilterAdaptive(rdsp_chain_t *c) { NEED(c); return RDSP_OK; /* the NLMS always adapts */ }
-extern "C" int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c) { NEED(c); rdsp_set_error("noise blanker: SURVEY F3, not built"); return RDSP_ERR_UNSUPPORTED; }
-extern "C" int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c) { NEED(c); return RDSP_OK; }
-extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) { NEED(c); (void)db; rdsp_set_error("noise blanker: SURVEY F3, not built"); return RDSP_ERR_UNSUPPORTED; }
+/* noise blanker (AudioSDR feature; arithmetic build-defined): wide-band,
+ * before the mixer; windows of 256*decim input samples */
+extern "C" int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c) { NEED(c); c->nb_on = 1; return RDSP_OK; }
+extern "C" int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c) { NEED(c); c->nb_on = 0; return RDSP_OK; }
+extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) {
+  NEED(c);
+  if (!(db >= 0.0f && db <= 60.0f)) { rdsp_set_error("noise blanker threshold %g dB outside 0..60", (double)db); return RDSP_ERR_INVALID; }
+  c->nb_threshold_db = db;
+  return RDSP_OK;
+}
+/* AudioSDRpreProcessor (INO:117-118) */
+extern "C" int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap) { NEED(c); c->swap_iq = swap ? 1 : 0; return RDSP_OK; }
+/* the I2S slip it guards against is a Teensy bus fault; recorded streams have none */
+extern "C" int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c) { NEED(c); return RDSP_OK; }
 extern "C" int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.input_gain = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.output_gain = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g) { NEED(c); c->cfg.iq_balance = g; return RDSP_OK; }

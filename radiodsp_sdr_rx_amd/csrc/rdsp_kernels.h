@@ -43,6 +43,9 @@ struct RdspFrontParams {
   const RdspGroup *groups;   /* [n_groups] tuning / mask / demod records     */
   const uint16_t *group_of;  /* [ch] group of each channel; NULL: all group 0 */
   float scale_i, scale_q;  /* iq_balance*input_gain/32768, input_gain/32768  */
+  int swap_iq;             /* preProcessor.swapIQ(true), INO:118             */
+  int nb_on;               /* noise blanker (engine feature, build-defined)  */
+  float nb_thr;            /* blanking threshold as a power ratio            */
   const float *fir_hc;     /* [4][64] decimator taps, hc[c][k'] = h[4k'+c]   */
   const float2 *mask_pool; /* [n_groups][2][N] masks/N, digit-reversed, thread-major (double-buffered) */
   int spectral_on;
@@ -57,7 +60,7 @@ struct RdspFrontParams {
   /* per-channel state */
   uint32_t *st_hist;       /* [ch][256] last raw input samples               */
   float2 *st_prev;         /* [ch][N/2] previous hop of the decimated stream */
-  float *st_scal;          /* [ch][4]: NFloor, agc_g, am_dc, -               */
+  float *st_scal;          /* [ch][4]: NFloor, agc_g, am_dc, blanker level   */
   /* outputs */
   uint32_t *out_i16;       /* [ch][out_stride] int16 L | int16 R << 16       */
   size_t out_stride;

@@ -51,7 +51,7 @@ struct FrontLds {
  * one tail wave fit the 512-register file of a SIMD, so the latency-bound
  * instruction stream of the tail fills issue slots the front leaves idle.  Alone, the
  * full-register variant is ~15 % faster, so the launch code picks per call. */
-template <int N, int P, int DECIM, bool LEAN>
+template <int N, int P, int DECIM, bool LEAN, bool PRE>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   float4 *taps_lds = reinterpret_cast<float4 *>(hb + LY::HB_N + (ALIAS ? 0 : PL::WB));
   float *red = reinterpret_cast<float *>(reinterpret_cast<float2 *>(taps_lds) + LY::TAPS_N);
 
+  /* PRE: the pre-processor's IQ swap and the noise blanker are compiled in (their
+   * run-time tests inside the unpack loop cost ~2 % when both are off, measured) */
+  const bool NB_ON = PRE && p.nb_on != 0, SWAP_IQ = PRE && p.swap_iq != 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -125,6 +128,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   float nfloor = p.st_scal[ch * 4 + 0];
   float agc_g = p.st_scal[ch * 4 + 1];
   float am_dc = p.st_scal[ch * 4 + 2];
+  float nb_level = p.st_scal[ch * 4 + 3];
 
   /* state in: previous hop -> registers, FIR history -> polyphase planes */
   float2 vprev[PH];
@@ -134,6 +138,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     for (int i = tid; i < 64; i += NT) {
       uint4 w4 = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * i);
       uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+      if (SWAP_IQ) { /* preProcessor.swapIQ: the stored history is the raw stream */
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = __builtin_amdgcn_alignbit(w[k], w[k], 16);
+      }
       /* the same phasor arithmetic these samples went through as the last 256 of the
        * previous chunk (pass LP-1 of the scatter loop below), so that a stream gives
        * the same bits however it is cut into calls */
@@ -179,16 +187,31 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     float2 ph_base = make_float2(1.f, 0.f);
     if (G.dphi != 0u)
       ph_base = nco_phasor_alu((p.n0 + (uint32_t)chunk * CH_IN + 4u * (uint32_t)tid) * G.dphi);
+    /* noise blanker (engine feature, build-defined): one decision window per chunk; the
+     * threshold comes from the windows before this one, so the chunk stays parallel */
+    const float nb_t = nb_level * p.nb_thr;
+    float nb_acc = 0.f;
 #pragma unroll
     for (int k = 0; k < LP; k++) {
       int idx = tid + NT * k;
       if (idx < CH_IN / 4) {
         uint32_t w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+        if (SWAP_IQ) { /* preProcessor.swapIQ(true), INO:118 */
+#pragma unroll
+          for (int j = 0; j < 4; j++) w[j] = __builtin_amdgcn_alignbit(w[j], w[j], 16);
+        }
         float2 ph0 = ph_base;
         if (k > 0 && G.dphi != 0u) ph0 = cmul_pinned(ph_base, k == 1 ? G.rotp1 : (k == 2 ? G.rotp2 : G.rotp3));
+        bool blanked[4] = {false, false, false, false};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           float2 x = unpack_iq(w[j], p.scale_i, p.scale_q);
+          if (NB_ON) {
+            const float pw = x.x * x.x + x.y * x.y;
+            blanked[j] = nb_level > 0.f && pw > nb_t;
+            x = blanked[j] ? make_float2(0.f, 0.f) : x;
+            nb_acc += blanked[j] ? 0.f : pw;
+          }
           if (G.dphi != 0u) {
             float2 ph = (j == 0) ? ph0 : cmul_pinned(ph0, j == 1 ? G.rot1 : (j == 2 ? G.rot2 : G.rot3));
             x = cmul_pinned(x, ph);
@@ -200,7 +223,24 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
             hb[(chunk % CPF) * CH_OUT + m] = x;
           }
         }
+        if (NB_ON) { /* a blanked sample stays blanked when it becomes FIR history */
+          raw[k].x = blanked[0] ? 0u : raw[k].x;
+          raw[k].y = blanked[1] ? 0u : raw[k].y;
+          raw[k].z = blanked[2] ? 0u : raw[k].z;
+          raw[k].w = blanked[3] ? 0u : raw[k].w;
+        }
       }
+    }
+    if (NB_ON) {
+      float tot = wave_sum(nb_acc);
+      if constexpr (NW > 1) {
+        if (lane == 0) red[wave] = tot;
+        __syncthreads();
+        tot = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+      }
+      const float mean = tot / (float)CH_IN;
+      nb_level = (nb_level > 0.f) ? nb_level + 0.2f * (mean - nb_level) : mean;
     }
     /* prefetch the next chunk's raw samples; they land during FIR + FFT */
     if (chunk + 1 < p.n_chunks) {
@@ -431,13 +471,19 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 #pragma unroll
   for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
   if constexpr (DECIM == 4) {
-    const uint32_t *tail = iq + (size_t)p.n_chunks * CH_IN - 256;
-    for (int i = tid; i < 256; i += NT) p.st_hist[ch * 256 + i] = tail[i];
+    /* the last 256 input samples as they entered the FIR (blanked ones as zero): the
+     * registers of the last load pass still hold them, no prefetch followed */
+    if constexpr (LP == 4) {
+      *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) = raw[LP - 1];
+    } else {
+      if (tid >= NT - 64) *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * (tid - (NT - 64))) = raw[0];
+    }
   }
   if (tid == 0) {
     p.st_scal[ch * 4 + 0] = nfloor;
     if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
     p.st_scal[ch * 4 + 2] = am_dc;
+    p.st_scal[ch * 4 + 3] = nb_level;
   }
 }
 
@@ -462,18 +508,23 @@ constexpr size_t front_lds() {
   return FrontLds<N, P, DECIM>::BYTES;
 }
 
-template <int N, int P, int DECIM, bool LEAN>
-int launch_front_v(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+template <int N, int P, int DECIM, bool LEAN, bool PRE>
+int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   constexpr size_t lds = front_lds<N, P, DECIM>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN, PRE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN, PRE>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
+}
+template <int N, int P, int DECIM, bool LEAN>
+int launch_front_v(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  return (p->nb_on || p->swap_iq) ? launch_front_w<N, P, DECIM, LEAN, true>(p, n_channels, stream)
+                                  : launch_front_w<N, P, DECIM, LEAN, false>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM>
 int launch_front_t(const RdspFrontParams *p, int n_channels, hipStream_t stream) {

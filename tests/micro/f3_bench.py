@@ -1,0 +1,16 @@
+import sys, time, torch, numpy as np
+sys.path.insert(0, "/root/repo")
+import radiodsp_sdr_rx_amd as R
+from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+kc = R.K_CONFIGS["K3"]; nch, nblk = 4096, 512
+iq = torch.from_numpy(synth_iq(nch, nblk*128, n_threads=16)).cuda()
+out = torch.empty((nch, nblk*32, 2), dtype=torch.int16, device="cuda")
+for nb, sw in [(0,0),(1,0),(1,1)]:
+    ch = Chain(nch, max_blocks_per_call=nblk, **kc["cfg"]); ch.set_pipelined(True)
+    if nb: ch.enableNoiseBlanker()
+    ch.swapIQ(bool(sw))
+    for _ in range(3): ch.process(iq, out=out)
+    ch.flush(); torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(20): ch.process(iq, out=out)
+    ch.flush(); torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/20
+    print(f"K3 noise_blanker={nb} swapIQ={sw}: {dt*1e3:.3f} ms/step, {nch*nblk*128/dt/1e9:.1f} Gsamples/s")

@@ -127,6 +127,10 @@ def load(path=None):
     lib.orc_chain_nco_dphi.restype = C.c_uint32
     lib.orc_demod_tuning_offset.argtypes = [C.c_int]
     lib.orc_demod_tuning_offset.restype = C.c_uint32
+    lib.orc_set_swap_iq.argtypes = [vp, C.c_int]
+    lib.orc_set_noise_blanker.argtypes = [vp, C.c_int, C.c_float]
+    lib.orc_chain_nb_level.argtypes = [vp]
+    lib.orc_chain_nb_level.restype = C.c_float
     lib.orc_set_demod.argtypes = [vp, C.c_int]
     lib.orc_set_nco_hz.argtypes = [vp, C.c_double]
     lib.orc_pbt_step.argtypes = [f64p, f64p, C.c_int, C.c_int]
@@ -193,6 +197,15 @@ class OracleChain:
 
     def set_nr_level(self, lvl):
         self.lib.orc_set_nr_level(self.h, lvl)
+
+    def set_swap_iq(self, on):
+        self.lib.orc_set_swap_iq(self.h, int(bool(on)))
+
+    def set_noise_blanker(self, on, threshold_db=10.0):
+        self.lib.orc_set_noise_blanker(self.h, int(bool(on)), float(threshold_db))
+
+    def nb_level(self):
+        return float(self.lib.orc_chain_nb_level(self.h))
 
     def set_demod(self, demod):
         self.lib.orc_set_demod(self.h, int(demod))

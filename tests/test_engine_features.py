@@ -1,0 +1,107 @@
+"""SURVEY 8f row F3 (first part): engine features that live in the AudioSDR library and
+are therefore build-defined (stated in DESIGN.md 6e and in the oracle): the
+pre-processor's IQ swap (INO:118) and the noise blanker (BK_INO:1259-1260, INO:131).
+GPU through the C-ABI against the oracle; tolerance TOL = 1e-5 normwise per channel."""
+import numpy as np
+import pytest
+
+from cases import K1, K3, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _impulses(iq, seed=4, per_channel=24, burst=3):
+    """ignition-noise style bursts: a few full-scale samples, far above any threshold"""
+    rng = np.random.default_rng(seed)
+    out = iq.copy()
+    for c in range(iq.shape[0]):
+        for pos in rng.integers(3000, iq.shape[1] - burst, per_channel):
+            out[c, pos:pos + burst] = rng.choice([-30000, 30000], size=(burst, 2))
+    return out
+
+
+def test_swap_iq_matches_oracle_and_is_a_pure_relabelling(rdsp, oracle, torch_cuda):
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    iq = synth_iq(3, 32 * 128)
+    cfg = dict(K1, fft_l=512, iq_balance=1.02)
+    ch = Chain(3, max_blocks_per_call=32, **cfg)
+    ch.startAutoI2SerrorDetection()                  # accepted, nothing to detect without an I2S bus
+    ch.swapIQ(True)
+    got16, got = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)
+    got = got.cpu().numpy()
+    for c in range(3):
+        oc = oracle.OracleChain(**cfg)
+        oc.set_swap_iq(True)
+        ref = oc.process(iq[c])[1]
+        assert np.abs(got[c] - ref).max() / np.abs(ref).max() <= TOL
+    plain = Chain(3, max_blocks_per_call=32, **cfg).process(torch.from_numpy(np.ascontiguousarray(iq[..., ::-1])).cuda())
+    assert np.array_equal(got16.cpu().numpy(), plain.cpu().numpy())
+
+
+@pytest.mark.parametrize("name,cfg", [("k1", K1), ("k3_front", dict(K3, als_mode="off")), ("literal", None)])
+def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, name, cfg):
+    torch = torch_cuda
+    from cases import CONV_LITERAL
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg = CONV_LITERAL if cfg is None else cfg
+    nch, nblk = 4, 64
+    clean = synth_iq(nch, nblk * 128)
+    iq = _impulses(clean)
+    ch = Chain(nch, max_blocks_per_call=nblk, **cfg)
+    ch.enableNoiseBlanker()
+    ch.setNoiseBlankerThresholdDb(8.0)
+    dev = torch.from_numpy(iq).cuda()
+    got = ch.process(dev, want_f32=True)[1].cpu().numpy()
+    levels = ch.scalars()[:, 3]
+    off = Chain(nch, max_blocks_per_call=nblk, **cfg).process(dev, want_f32=True)[1].cpu().numpy()
+    ref_clean = Chain(nch, max_blocks_per_call=nblk, **cfg).process(torch.from_numpy(clean).cuda(), want_f32=True)[1].cpu().numpy()
+    for c in range(nch):
+        oc = oracle.OracleChain(**cfg)
+        oc.set_noise_blanker(True, 8.0)
+        ref = oc.process(iq[c])[1]
+        err = np.abs(got[c] - ref).max() / np.abs(ref).max()
+        assert err <= TOL, f"channel {c}: {err:.2e}"
+        assert abs(levels[c] - oc.nb_level()) <= 1e-5 * oc.nb_level()
+        # it does its job: with the blanker the audio is closer to the impulse-free audio
+        # (the AGC-free configs; with AGC the gains differ and the comparison is not meaningful)
+        if "agc_mode" not in cfg:
+            e_on = np.abs(got[c] - ref_clean[c])[200:].max()
+            e_off = np.abs(off[c] - ref_clean[c])[200:].max()
+            assert e_on < 0.75 * e_off, (e_on, e_off)   # a zeroed sample leaves a hole of its own
+
+
+def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, torch_cuda):
+    """a blanked sample stays blanked when it becomes FIR history of the next call"""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, per, calls = 3, 8, 6
+    iq = _impulses(synth_iq(nch, per * calls * 128), per_channel=80)
+    # bursts right at call boundaries
+    for k in range(1, calls):
+        iq[:, k * per * 128 - 2:k * per * 128 + 1] = 30000
+
+    def run(n_calls, pipelined, lean):
+        ch = Chain(nch, max_blocks_per_call=per * calls // n_calls, **K3)
+        ch.enableNoiseBlanker()
+        ch.setNoiseBlankerThresholdDb(8.0)
+        ch.set_pipelined(pipelined)
+        if lean:
+            ch.set_front_variant(1)
+        step = iq.shape[1] // n_calls
+        outs = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * step:(k + 1) * step])).cuda())
+                for k in range(n_calls)]
+        ch.flush()
+        torch.cuda.synchronize()
+        return np.concatenate([o.cpu().numpy() for o in outs], 1)
+
+    one = run(1, False, True)
+    assert np.array_equal(one, run(calls, False, True))
+    assert np.array_equal(one, run(calls, True, False))

@@ -336,7 +336,7 @@ def test_engine_setters_and_reference_shaped_call(rdsp, oracle, torch_cuda):
     ch.setInputGain(1.0); ch.setOutputGain(0.5); ch.setIQgainBalance(1.02)
     ch.enableAGC(); ch.setAGCmode(rdsp.AGC["medium"]); ch.disableALSfilter(); ch.disableNoiseBlanker()
     with pytest.raises(RdspError):
-        ch.enableNoiseBlanker()  # declared, not built
+        ch.setNoiseBlankerThresholdDb(-3.0)  # outside 0..60 dB
     ch.reset()
     out = ch.doConvolutionalProcessing(0, True, 300.0, 4000.0, dev)  # cut-offs ignored like CONV:300
     torch.cuda.synchronize()
