@@ -45,7 +45,8 @@ typedef enum {
   RDSP_DEMOD_LSB = 2,    /* LSBmode    */
   RDSP_DEMOD_CW_USB = 3, /* CW_USBmode */
   RDSP_DEMOD_CW_LSB = 4, /* CW_LSBmode */
-  RDSP_DEMOD_AM = 5      /* AMmode     */
+  RDSP_DEMOD_AM = 5,     /* AMmode     */
+  RDSP_DEMOD_SAM = 6     /* SAMmode (CTL:387): PLL synchronous detector, build-defined */
 } rdsp_demod_t;
 typedef enum { RDSP_AGC_OFF = 0, RDSP_AGC_FAST = 1, RDSP_AGC_MEDIUM = 2, RDSP_AGC_SLOW = 3 } rdsp_agc_t; /* CTL:200-218 */
 typedef enum { RDSP_ALS_OFF = 0, RDSP_ALS_NOTCH = 1, RDSP_ALS_PEAK = 2 } rdsp_als_t;                    /* CTL:250-261 */
@@ -199,8 +200,7 @@ int rdsp_group_get_mask(rdsp_chain_t *c, int group, float *host_out);
 int rdsp_pbt_step(double *dFLoCut, double *dFHiCut, int edge, int dir);
 int rdsp_group_pbt(rdsp_chain_t *c, int group, int edge, int dir, void *stream);
 /* tuningMode() (CTL:330-423): mndx 0 "CW N", 1 "CW", 2 "USB", 3 "LSB", 4 "AM",
- * 6 "RTTY" (5 "SAM" is SURVEY F3: returns 0 and sets the error text); the CW side
- * follows vfoFreq > 10 MHz (CTL:337).  Sets the group's audio filter and
+ * 5 "SAM", 6 "RTTY"; the CW side follows vfoFreq > 10 MHz (CTL:337).  Sets the group's audio filter and
  * demodulator, returns TuningOffset in Hz. */
 uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, double vfo_hz, void *stream);
 

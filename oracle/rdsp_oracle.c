@@ -269,6 +269,9 @@ struct orc_chain {
   float nb_level; /* reference power: smoothed mean |x|^2 of the past windows */
   float nb_acc;   /* post-blanking power accumulated in the current window */
   uint32_t nb_fill;
+  /* F3: SAM demodulator (PLL) */
+  float sam_g1, sam_g2, sam_wmin, sam_wmax;
+  float sam_phs, sam_omega, sam_fil, sam_dc;
 };
 
 uint32_t orc_demod_tuning_offset(int demod) {
@@ -327,6 +330,46 @@ void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db) {
 }
 float orc_chain_nb_level(const orc_chain_t *c) { return c->nb_level; }
 
+/* SAMmode (CTL:384-391) is an AudioSDR demodulator; build-defined here as the
+ * classic second-order PLL synchronous detector on the filtered base band y:
+ *   corr0 = Re(y e^{-j phs}), corr1 = Im(y e^{-j phs}), det = atan2(corr1, corr0)
+ *   weighted by |y|^2/(|y|^2 + 1e-6), omega += g2 det (clamped to +-2 kHz),
+ *   phs += previous (g1 det + omega),
+ *   audio = corr0 - dc,  dc += (corr0 - dc)/512.
+ * Loop constants for zeta = 0.65, omegaN = 200 rad/s at the decimated rate. */
+void orc_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax) {
+  const double zeta = 0.65, omegaN = 200.0, fmax = 2000.0;
+  const double a = 1.0 - exp(-2.0 * omegaN * zeta / fs_out);
+  const double b = -a + 2.0 * (1.0 - exp(-omegaN * zeta / fs_out) * cos(omegaN / fs_out * sqrt(1.0 - zeta * zeta)));
+  *g1 = (float)a;
+  *g2 = (float)b;
+  *wmax = (float)(ORC_TWO_PI * fmax / fs_out);
+  *wmin = -*wmax;
+}
+static void sam_block(orc_chain_t *c, float *L, float *R) {
+  const float two_pi = (float)ORC_TWO_PI;
+  for (int i = 0; i < ORC_BLOCK; i++) {
+    const float sn = sinf(c->sam_phs), cs = cosf(c->sam_phs);
+    const float corr0 = L[i] * cs + R[i] * sn;
+    const float corr1 = R[i] * cs - L[i] * sn;
+    /* the detector fades out below about -60 dBFS (filter start-up, muted input): the
+     * angle of rounding residue would otherwise steer the loop at random */
+    const float mag2 = corr0 * corr0 + corr1 * corr1;
+    const float det = atan2f(corr1, corr0) * (mag2 / (mag2 + 1e-6f));
+    const float del_out = c->sam_fil;
+    c->sam_omega = c->sam_omega + c->sam_g2 * det;
+    if (c->sam_omega < c->sam_wmin) c->sam_omega = c->sam_wmin;
+    if (c->sam_omega > c->sam_wmax) c->sam_omega = c->sam_wmax;
+    c->sam_fil = c->sam_g1 * det + c->sam_omega;
+    c->sam_phs = c->sam_phs + del_out;
+    if (c->sam_phs >= two_pi) c->sam_phs -= two_pi;
+    if (c->sam_phs < 0.0f) c->sam_phs += two_pi;
+    c->sam_dc = c->sam_dc + (corr0 - c->sam_dc) * (1.0f / 512.0f);
+    L[i] = corr0 - c->sam_dc;
+    R[i] = L[i];
+  }
+}
+
 /* ---- F2: retune / PBT / mode table (the callers of CONV:209) ------------------- */
 /* run-time changes of the engine settings a mode switch touches */
 void orc_set_demod(orc_chain_t *c, int demod) { c->cfg.demod = demod; }
@@ -369,7 +412,7 @@ void orc_passband(int filter, int demod, double *lo, double *hi) {
     default: break;
   }
   if (demod == ORC_DEMOD_LSB || demod == ORC_DEMOD_CW_LSB) { *lo = -b; *hi = -a; }
-  else if (demod == ORC_DEMOD_AM) { *lo = -b; *hi = b; }
+  else if (demod == ORC_DEMOD_AM || demod == ORC_DEMOD_SAM) { *lo = -b; *hi = b; }
   else { *lo = a; *hi = b; }
 }
 
@@ -382,6 +425,7 @@ int orc_tuning_mode(int mndx, double vfoFreq, int *filter, int *demod) {
     case 2: *filter = 2; *demod = ORC_DEMOD_USB; return 1; /* CTL:358-365 */
     case 3: *filter = 2; *demod = ORC_DEMOD_LSB; return 1; /* CTL:367-374 */
     case 4: *filter = 4; *demod = ORC_DEMOD_AM; return 1;  /* CTL:376-383 */
+    case 5: *filter = 4; *demod = ORC_DEMOD_SAM; return 1; /* CTL:385-392 */
     case 6: *filter = 1; *demod = ORC_DEMOD_USB; return 1; /* CTL:404-411 "RTTY" */
     default: return 0;
   }
@@ -411,6 +455,7 @@ orc_chain_t *orc_chain_create(const orc_config_t *cfg) {
   c->oldNRLevel = 15; /* CONV:80 */
   c->NFloor = 0.0f;   /* SPEC:109 */
   c->agc_g = 1.0f;
+  orc_sam_constants(c->fs_out, &c->sam_g1, &c->sam_g2, &c->sam_wmin, &c->sam_wmax);
   c->am_dc = 0.0f;
   /* NCO: 32-bit phase accumulator, closed form of the absolute sample index */
   {
@@ -526,6 +571,8 @@ static void post_block(orc_chain_t *c, float *L, float *R) {
       R[i] = L[i];
     }
     c->am_dc = dc_new;
+  } else if (cf->demod == ORC_DEMOD_SAM) {
+    sam_block(c, L, R);
   } else if (cf->demod != ORC_DEMOD_IQ) {
     for (int i = 0; i < ORC_BLOCK; i++) R[i] = L[i];
   }

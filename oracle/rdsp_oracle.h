@@ -44,7 +44,8 @@ enum {
   ORC_DEMOD_LSB = 2, /* audio = Re y (one-sided negative passband)            */
   ORC_DEMOD_CW_USB = 3,
   ORC_DEMOD_CW_LSB = 4,
-  ORC_DEMOD_AM = 5 /* audio = |y| - block-smoothed DC                        */
+  ORC_DEMOD_AM = 5, /* audio = |y| - block-smoothed DC                       */
+  ORC_DEMOD_SAM = 6 /* synchronous AM: PLL on the carrier, audio = Re(y e^-j phi) */
 };
 
 enum { ORC_AGC_OFF = 0, ORC_AGC_FAST = 1, ORC_AGC_MEDIUM = 2, ORC_AGC_SLOW = 3 };
@@ -110,6 +111,8 @@ void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327
 void orc_set_swap_iq(orc_chain_t *c, int on);
 void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db);
 float orc_chain_nb_level(const orc_chain_t *c);
+/* SAM PLL loop constants at the decimated rate (build-defined, see rdsp_oracle.c) */
+void orc_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax);
 
 /* F2: retune / PBT / mode table -- the callers of reInitializeFilter (CTL:569-612)
  * and the mode menu (CTL:330-423) */

@@ -1,7 +1,7 @@
 """Chain configuration helpers: enums and the BASELINE.json configs K1..K5."""
 from ._lib import ChainConfig, SynthConfig
 
-DEMOD = {"IQ": 0, "USB": 1, "LSB": 2, "CW_USB": 3, "CW_LSB": 4, "AM": 5}
+DEMOD = {"IQ": 0, "USB": 1, "LSB": 2, "CW_USB": 3, "CW_LSB": 4, "AM": 5, "SAM": 6}
 AGC = {"off": 0, "fast": 1, "medium": 2, "slow": 3}
 ALS = {"off": 0, "notch": 1, "peak": 2}
 AUDIO_FILTER = {"audioCW": 0, "audio2100": 1, "audio2700": 2, "audio3100": 3, "audioAM": 4,

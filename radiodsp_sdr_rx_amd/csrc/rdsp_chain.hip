@@ -86,6 +86,8 @@ struct rdsp_chain {
   float *d_als_w = nullptr, *d_als_prev = nullptr, *d_als_energy = nullptr;
   float *d_mid = nullptr;
   size_t mid_stride = 0;
+  /* SAM groups: quadrature part of the base band (double-buffered like d_mid), PLL state */
+  float *d_mid_q = nullptr, *d_mid_q2 = nullptr, *d_sam = nullptr;
   /* pipelined mode: the serial tail stage of call k runs on an internal stream,
    * concurrently with the front stage of call k+1 (double-buffered intermediate) */
   int pipe_on = 0;
@@ -208,7 +210,8 @@ static void group_record(const rdsp_chain_t *c, const GroupState &g, int gi, int
   memset(r, 0, sizeof(*r));
   r->dphi = rdsp_nco_dphi(g.nco_hz, c->cfg.fs_in);
   r->demod = (g.demod == RDSP_DEMOD_IQ) ? RDSP_K_DEMOD_IQ
-             : (g.demod == RDSP_DEMOD_AM ? RDSP_K_DEMOD_AM : RDSP_K_DEMOD_REAL);
+             : (g.demod == RDSP_DEMOD_AM ? RDSP_K_DEMOD_AM
+                : (g.demod == RDSP_DEMOD_SAM ? RDSP_K_DEMOD_SAM : RDSP_K_DEMOD_REAL));
   float t[2];
   rdsp_nco_rot(r->dphi, 1, t); r->rot1 = make_float2(t[0], t[1]);
   rdsp_nco_rot(r->dphi, 2, t); r->rot2 = make_float2(t[0], t[1]);
@@ -352,7 +355,7 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_mid_q, c->d_mid_q2, c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
@@ -408,6 +411,7 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   c->old_nr_level = 15;
   c->nr_mu = rdsp_lms_mu(15);
   for (auto &g : c->groups) { g.has_dev_dphi = false; g.dirty = true; }
+  if (c->d_sam) HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch));
   return RDSP_OK;
 }
 
@@ -508,7 +512,16 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     if (rc != RDSP_OK) return rc;
     c->old_nr_level = cf.lms_nr;
   }
-  const bool tail = (cf.lms_nr > 0) || (cf.als_mode != RDSP_ALS_OFF);
+  bool sam = false; /* any group on the PLL demodulator: its serial stage runs before the tail */
+  for (const auto &g : c->groups) sam = sam || (g.demod == RDSP_DEMOD_SAM);
+  if (sam && !c->d_sam) {
+    const size_t nch_ = (size_t)c->n_channels, mid_bytes = sizeof(float) * c->mid_stride * nch_;
+    HIP_TRY(hipMalloc((void **)&c->d_mid_q, mid_bytes));
+    HIP_TRY(hipMalloc((void **)&c->d_mid_q2, mid_bytes));
+    HIP_TRY(hipMalloc((void **)&c->d_sam, sizeof(float) * 4 * nch_));
+    HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch_));
+  }
+  const bool tail = sam || (cf.lms_nr > 0) || (cf.als_mode != RDSP_ALS_OFF);
   float attack, decay;
   agc_params(cf.agc_mode, &attack, &decay);
   const float og = cf.mute ? 0.0f : cf.output_gain;
@@ -553,8 +566,10 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   /* the lean variant leaves registers and LDS for the concurrent tail kernel */
   fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
   fp.front_prio = piped ? 1 : 0;
+  fp.mid_q = c->d_mid_q;
   if (piped) {
     fp.mid = slot ? c->d_mid2 : c->d_mid;
+    fp.mid_q = slot ? c->d_mid_q2 : c->d_mid_q;
     /* the tail of call k-2 read this intermediate buffer: wait for it */
     if (c->call_idx >= 2) HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[slot], 0));
   }
@@ -580,6 +595,24 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   if (piped) {
     HIP_TRY(hipEventRecord(c->ev_front[slot], stream));
     HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front[slot], 0));
+  }
+  if (sam) {
+    RdspSamParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.mid = fp.mid;
+    sp.mid_q = fp.mid_q;
+    sp.mid_stride = c->mid_stride;
+    sp.n_channels = c->n_channels;
+    sp.n_samples = (int)n_out;
+    sp.groups = c->d_groups;
+    sp.group_of = c->d_group_of;
+    rdsp_sam_constants(cf.fs_in / (double)c->decim, &sp.g1, &sp.g2, &sp.wmin, &sp.wmax);
+    sp.st_sam = c->d_sam;
+    int es = rdsp_launch_sam(&sp, tstream);
+    if (es != 0) {
+      rdsp_set_error("SAM kernel launch failed: %s", hipGetErrorString((hipError_t)es));
+      return RDSP_ERR_HIP;
+    }
   }
   if (tail) {
     RdspTailParams tp;
@@ -760,7 +793,7 @@ static void passband(int filter, int demod, double *lo, double *hi) {
     default: break;
   }
   if (demod == RDSP_DEMOD_LSB || demod == RDSP_DEMOD_CW_LSB) { *lo = -b; *hi = -a; }
-  else if (demod == RDSP_DEMOD_AM) { *lo = -b; *hi = b; }
+  else if (demod == RDSP_DEMOD_AM || demod == RDSP_DEMOD_SAM) { *lo = -b; *hi = b; }
   else { *lo = a; *hi = b; }
 }
 extern "C" int rdsp_group_setAudioFilter(rdsp_chain_t *c, int group, int filter, void *stream) {
@@ -781,7 +814,7 @@ extern "C" int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream
   return RDSP_OK;
 }
 extern "C" uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode, void *stream) {
-  if (check_group(c, group) != RDSP_OK || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_AM) return 0;
+  if (check_group(c, group) != RDSP_OK || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_SAM) return 0;
   GroupState &g = c->groups[(size_t)group];
   g.demod = mode;
   if (group == 0) c->cfg.demod = mode;
@@ -791,7 +824,7 @@ extern "C" uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode
   return demod_tuning_offset(mode);
 }
 extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream) {
-  if (!c || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_AM) return 0;
+  if (!c || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_SAM) return 0;
   for (size_t i = 0; i < c->groups.size(); i++) (void)rdsp_group_setDemodMode(c, (int)i, mode, stream);
   return demod_tuning_offset(mode);
 }
@@ -869,7 +902,7 @@ extern "C" int rdsp_group_pbt(rdsp_chain_t *c, int group, int edge, int dir, voi
 
 /* tuningMode() (CTL:330-423): the mode table of the sketch.  mndx 0 "CW N" (500 Hz),
  * 1 "CW" (2.1 kHz), 2 "USB", 3 "LSB", 4 "AM", 5 "SAM", 6 "RTTY"; CW side chosen by
- * vfoFreq > 10 MHz (CTL:337,349).  Returns TuningOffset; SAM is SURVEY F3 (not built). */
+ * vfoFreq > 10 MHz (CTL:337,349).  Returns TuningOffset. */
 extern "C" uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, double vfo_hz, void *stream) {
   if (check_group(c, group) != RDSP_OK) return 0;
   int filter, mode;
@@ -879,8 +912,9 @@ extern "C" uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, 
     case 2: filter = RDSP_AUDIO_2700; mode = RDSP_DEMOD_USB; break;
     case 3: filter = RDSP_AUDIO_2700; mode = RDSP_DEMOD_LSB; break;
     case 4: filter = RDSP_AUDIO_AM; mode = RDSP_DEMOD_AM; break;
+    case 5: filter = RDSP_AUDIO_AM; mode = RDSP_DEMOD_SAM; break;
     case 6: filter = RDSP_AUDIO_2100; mode = RDSP_DEMOD_USB; break;
-    default: rdsp_set_error("tuningMode %d not built (SAM: SURVEY F3)", mndx); return 0;
+    default: rdsp_set_error("tuningMode: no menu entry %d (CTL:330-423 has 0..6)", mndx); return 0;
   }
   c->groups[(size_t)group].audio_filter = filter;      /* SDR.setAudioFilter(...) */
   return rdsp_group_setDemodMode(c, group, mode, stream); /* TuningOffset = SDR.setDemodMode(...) */

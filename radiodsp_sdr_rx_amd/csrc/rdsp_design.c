@@ -201,6 +201,18 @@ float rdsp_lms_mu(int strength) {
   return 1 / m;
 }
 
+/* loop constants of the SAM demodulator's PLL (build-defined: zeta 0.65, omegaN 200 rad/s,
+ * lock range +-2 kHz) at the decimated rate */
+void rdsp_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax) {
+  const double zeta = 0.65, omegaN = 200.0, fmax = 2000.0;
+  const double a = 1.0 - exp(-2.0 * omegaN * zeta / fs_out);
+  const double b = -a + 2.0 * (1.0 - exp(-omegaN * zeta / fs_out) * cos(omegaN / fs_out * sqrt(1.0 - zeta * zeta)));
+  *g1 = (float)a;
+  *g2 = (float)b;
+  *wmax = (float)(2.0 * kPi * fmax / fs_out);
+  *wmin = -*wmax;
+}
+
 /* ---- synthetic IQ: counter-based so any (channel, time) window
  * can be generated independently and identically on any host ---------------- */
 static inline uint64_t splitmix64(uint64_t x) {

@@ -18,6 +18,7 @@ int rdsp_design_decimator(int ntaps, double cut_hz, double fs, int window, float
 uint32_t rdsp_nco_dphi(double hz, double fs);
 void rdsp_nco_rot(uint32_t dphi, int k, float *out2);
 float rdsp_lms_mu(int strength);
+void rdsp_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax);
 void rdsp_set_error(const char *fmt, ...);
 
 #ifdef __cplusplus

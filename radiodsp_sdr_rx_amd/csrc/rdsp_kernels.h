@@ -13,7 +13,7 @@
 #define RDSP_XP 84 /* entries per polyphase sub-plane in LDS (81 used, 84 keeps
                       the sub-plane stride at 8 banks mod 32) */
 
-enum { RDSP_K_DEMOD_IQ = 0, RDSP_K_DEMOD_REAL = 1, RDSP_K_DEMOD_AM = 2 };
+enum { RDSP_K_DEMOD_IQ = 0, RDSP_K_DEMOD_REAL = 1, RDSP_K_DEMOD_AM = 2, RDSP_K_DEMOD_SAM = 3 };
 
 /* One receiver group: channels of a group share tuning offset, filter
  * mask and demodulator.  128 bytes, read once per workgroup into scalar registers;
@@ -66,7 +66,22 @@ struct RdspFrontParams {
   size_t out_stride;
   float2 *out_f32;         /* optional [ch][out_stride] float L,R            */
   float *mid;              /* [ch][mid_stride] mono float (to_mid)           */
+  float *mid_q;            /* [ch][mid_stride] Im y for SAM channels, else unused */
   size_t mid_stride;
+};
+
+/* SAM demodulator (PLL, serial in time): one channel per lane, in place on `mid`
+ * for the channels whose group demodulates SAM */
+struct RdspSamParams {
+  float *mid;              /* in: Re y, out: audio                           */
+  const float *mid_q;      /* Im y                                           */
+  size_t mid_stride;
+  int n_channels;
+  int n_samples;           /* multiple of 4                                  */
+  const RdspGroup *groups;
+  const uint16_t *group_of;
+  float g1, g2, wmin, wmax;
+  float *st_sam;           /* [ch][4]: phase, omega, loop filter output, dc  */
 };
 
 /* tail kernel: A7 NLMS noise reduction, A8 ALS notch/peak, A9 AGC, gain,
@@ -100,6 +115,7 @@ extern "C" {
 int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_channels,
                       hipStream_t stream);
 int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream);
+int rdsp_launch_sam(const RdspSamParams *p, hipStream_t stream);
 int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hipStream_t stream);
 int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream);
 int rdsp_launch_float_to_q15(const float *src, int16_t *dst, size_t n, hipStream_t stream);

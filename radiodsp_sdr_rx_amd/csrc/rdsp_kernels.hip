@@ -423,6 +423,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       if (p.to_mid) {
 #pragma unroll
         for (int jj = 0; jj < PH; jj++) p.mid[ch * p.mid_stride + tout + tid + jj * NT] = L[jj];
+        if (G.demod == RDSP_K_DEMOD_SAM) { /* the PLL stage needs the quadrature part too */
+#pragma unroll
+          for (int jj = 0; jj < PH; jj++) p.mid_q[ch * p.mid_stride + tout + tid + jj * NT] = R[jj];
+        }
       } else {
         if (p.agc_on) {
           float pw[PH];

@@ -14,3 +14,12 @@ for nb, sw in [(0,0),(1,0),(1,1)]:
     for _ in range(20): ch.process(iq, out=out)
     ch.flush(); torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/20
     print(f"K3 noise_blanker={nb} swapIQ={sw}: {dt*1e3:.3f} ms/step, {nch*nblk*128/dt/1e9:.1f} Gsamples/s")
+# SAM: the PLL stage is serial per sample, one channel per lane (64 waves at 4096 channels)
+cfg = dict(kc["cfg"], demod="SAM", flo_hz=-3900.0, fhi_hz=3900.0, als_mode="off")
+for piped in (False, True):
+    ch = Chain(nch, max_blocks_per_call=nblk, **cfg); ch.set_pipelined(piped)
+    for _ in range(2): ch.process(iq, out=out)
+    ch.flush(); torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(10): ch.process(iq, out=out)
+    ch.flush(); torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/10
+    print(f"K3 front + SAM + AGC, pipelined={piped}: {dt*1e3:.3f} ms/step, {nch*nblk*128/dt/1e9:.1f} Gsamples/s")

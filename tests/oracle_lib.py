@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 
-DEMOD = {"IQ": 0, "USB": 1, "LSB": 2, "CW_USB": 3, "CW_LSB": 4, "AM": 5}
+DEMOD = {"IQ": 0, "USB": 1, "LSB": 2, "CW_USB": 3, "CW_LSB": 4, "AM": 5, "SAM": 6}
 AGC = {"off": 0, "fast": 1, "medium": 2, "slow": 3}
 ALS = {"off": 0, "notch": 1, "peak": 2}
 

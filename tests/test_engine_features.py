@@ -105,3 +105,64 @@ def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, tor
     one = run(1, False, True)
     assert np.array_equal(one, run(calls, False, True))
     assert np.array_equal(one, run(calls, True, False))
+
+
+# ---- SAM: PLL synchronous detector (CTL:384-391; build-defined arithmetic) ---------------
+def _am_signal(nch, n, fs=96000.0, seed=9, off0=60.0, doff=20.0):
+    """AM carriers off0 + c*doff Hz off the 12 kHz tuning offset, 700/1100 Hz modulation, noise"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    out = np.empty((nch, n, 2), np.int16)
+    for c in range(nch):
+        fc = 12000.0 + off0 + doff * c
+        m = 0.5 * np.sin(2 * np.pi * 700.0 * t + c) + 0.3 * np.sin(2 * np.pi * 1100.0 * t)
+        x = 0.35 * (1.0 + m) * np.exp(2j * np.pi * fc * t + 1j * rng.uniform(0, 6.28))
+        x = x + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        out[c, :, 0] = np.clip(np.round(x.real * 32767), -32768, 32767)
+        out[c, :, 1] = np.clip(np.round(x.imag * 32767), -32768, 32767)
+    return out
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_sam_demodulator_matches_oracle_and_recovers_the_modulation(rdsp, oracle, torch_cuda, pipelined):
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain
+    nch, per, calls = 5, 32, 4
+    iq = _am_signal(nch, per * calls * 128)
+    cfg = dict(fft_l=512, demod="SAM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="slow", output_gain=0.5)
+    ch = Chain(nch, max_blocks_per_call=per, **cfg)
+    ch.set_pipelined(pipelined)
+    outs = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * per * 128:(k + 1) * per * 128])).cuda(),
+                       want_f32=True)[1] for k in range(calls)]
+    ch.flush()
+    torch.cuda.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in outs], 1)
+    for c in range(nch):
+        ref = oracle.OracleChain(**cfg).process(iq[c])[1]
+        err = np.abs(got[c] - ref).max() / np.abs(ref).max()
+        assert err <= 2e-5, f"channel {c}: {err:.2e}"      # PLL feedback: 2 x TOL (1e-5), see DESIGN.md 6e
+        a = got[c, 2048:, 0]
+        spec = np.abs(np.fft.rfft(a * np.hanning(len(a))))
+        f = np.fft.rfftfreq(len(a), 1 / 24000.0)
+        assert abs(f[spec.argmax()] - 700.0) < 12.0        # the 700 Hz tone is what comes out
+
+
+def test_sam_group_beside_other_groups_and_mode_table_entry(rdsp, oracle, torch_cuda):
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain
+    nch, nblk = 4, 64
+    iq = _am_signal(nch, nblk * 128)
+    base = dict(fft_l=512)
+    ch = Chain(nch, max_blocks_per_call=nblk, **base)
+    ch.set_groups(np.array([0, 1, 0, 1], np.uint16))
+    assert ch.group_tuningMode(1, 5, 7.2e6) == 0            # "SAM": audioAM + SAMmode, CTL:385-392
+    ch.group_tuningMode(0, 4, 7.2e6)                        # "AM"
+    got = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)[1].cpu().numpy()
+    ok, filt, demod = oracle.tuning_mode(5, 7.2e6)
+    lo, hi = oracle.passband(filt, demod)
+    assert ok and demod == rdsp.DEMOD["SAM"] and (lo, hi) == (-3900.0, 3900.0)
+    for c in range(nch):
+        d = "SAM" if c % 2 else "AM"
+        ref = oracle.OracleChain(**dict(base, demod=d, flo_hz=lo, fhi_hz=hi)).process(iq[c])[1]
+        err = np.abs(got[c] - ref).max() / np.abs(ref).max()
+        assert err <= (2e-5 if c % 2 else TOL), f"channel {c} ({d}): {err:.2e}"

@@ -171,7 +171,9 @@ def test_tuning_mode_table_per_group(rdsp, oracle, torch_cuda):
         lo, hi = oracle.passband(filt, demod)
         ch.group_setTuningOffsetHz(g, 12000.0 - off)
         settings.append(dict(demod=names[demod], lo=lo, hi=hi, nco=12000.0 - off))
-    assert ch.group_tuningMode(0, 5, 7.1e6) == 0 and b"SAM" in rdsp.load().rdsp_last_error()
+    assert ch.group_tuningMode(0, 9, 7.1e6) == 0 and b"no menu entry" in rdsp.load().rdsp_last_error()
+    ch.group_tuningMode(0, *modes[0])
+    ch.group_setTuningOffsetHz(0, settings[0]["nco"])
     got = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)[1].cpu().numpy()
     for c in range(nch):
         ref, _ = _oracle_channel(oracle, base, settings[c], [iq[c]])
