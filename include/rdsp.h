@@ -347,6 +347,13 @@ int rdsp_spectrum_outputs_for(const rdsp_spectrum_t *s, int n_blocks);
 int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, size_t in_stride, int n_blocks,
                          uint16_t *d_out, size_t out_stride, int *n_outputs, void *stream);
 
+/* the analyser as a node of the block graph (`AudioAnalyzeFFT256IQ FFT;` wired to the
+ * pre-processor's I and Q outputs, INO:57,73-74): 2 inputs, no outputs */
+rdsp_node_t *rdsp_spectrum_node_create(rdsp_graph_t *g, rdsp_spectrum_t *spec);
+int rdsp_spectrum_node_available(rdsp_node_t *n);            /* FFTIQ.h:62-68 */
+const uint16_t *rdsp_spectrum_node_output(rdsp_node_t *n);   /* FFTIQ.h:99, [n_channels][256] */
+int rdsp_spectrum_node_status(rdsp_node_t *n);
+
 /* ---- deterministic synthetic IQ generator (host) -------------------*/
 typedef struct {
   double fs;        /* 96000 */

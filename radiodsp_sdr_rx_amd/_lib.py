@@ -138,6 +138,10 @@ SYMBOLS = [
     ("rdsp_stream_run", _i, [_vp, SOURCE_FN, _vp, SINK_FN, _vp, _i, C.c_int64, C.POINTER(StreamStats)]),
     ("rdsp_stream_run_files", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, C.c_int64, C.POINTER(StreamStats)]),
     ("rdsp_stream_run_memory", _i, [_vp, _i16p, _sz, C.c_int64, _i16p, _sz, _i, C.POINTER(StreamStats)]),
+    ("rdsp_spectrum_node_create", _vp, [_vp, _vp]),
+    ("rdsp_spectrum_node_available", _i, [_vp]),
+    ("rdsp_spectrum_node_output", C.POINTER(C.c_uint16), [_vp]),
+    ("rdsp_spectrum_node_status", _i, [_vp]),
     ("rdsp_chain_set_groups", _i, [_vp, _i, C.POINTER(C.c_uint16)]),
     ("rdsp_chain_groups", _i, [_vp]),
     ("rdsp_group_reInitializeFilter", _i, [_vp, _i, _d, _d, _vp]),

@@ -141,3 +141,110 @@ extern "C" int rdsp_sdr_node_status(rdsp_node_t *n) {
   SdrNode *s = static_cast<SdrNode *>(rdsp_node_user(n));
   return s ? s->status : RDSP_ERR_INVALID;
 }
+
+/* ---- AudioAnalyzeFFT256IQ as a graph node (analyze_fft256iq.h:52-110) -----------------
+ * `AudioAnalyzeFFT256IQ FFT;` with `AudioConnection(preProcessor, 0, FFT, 0)` and
+ * (.., 1, FFT, 1) in the sketch (RadioDSP_SDR_RX.ino:57,73-74).  Two inputs (I, Q
+ * tiles), no outputs; update() is FFTIQ.cpp:65-118 for every channel of the tile: the
+ * tick's blocks are interleaved, uploaded and handed to rdsp_spectrum_update (which keeps
+ * the previous block on the device); available()/output[] follow FFTIQ.h:62-73,99. */
+namespace {
+struct SpectrumNode {
+  rdsp_spectrum_t *spec;
+  int n_channels;
+  std::vector<int16_t> h_iq;      /* [ch][128][2] */
+  std::vector<uint16_t> h_out;    /* [ch][256]    */
+  int16_t *d_iq = nullptr;
+  uint16_t *d_out = nullptr;
+  hipStream_t stream = nullptr;
+  int outputflag = 0;             /* FFTIQ.h:63 */
+  int status = RDSP_OK;
+};
+
+void spectrum_destroy(void *u) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(u);
+  if (s->d_iq) (void)hipFree(s->d_iq);
+  if (s->d_out) (void)hipFree(s->d_out);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+void spectrum_update(rdsp_node_t *n, void *u) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(u);
+  rdsp_block_t *bi = rdsp_receive_readonly(n, 0); /* FFTIQ.cpp:70-71 */
+  rdsp_block_t *bq = rdsp_receive_readonly(n, 1);
+  if (!bi || !bq) { /* FFTIQ.cpp:72: return when a block is missing */
+    rdsp_release(bi);
+    rdsp_release(bq);
+    return;
+  }
+  const int16_t *pi = rdsp_block_data(bi), *pq = rdsp_block_data(bq);
+  for (int c = 0; c < s->n_channels; c++) {
+    int16_t *dst = &s->h_iq[(size_t)c * RDSP_BLOCK_SAMPLES * 2];
+    for (int i = 0; i < RDSP_BLOCK_SAMPLES; i++) {
+      dst[2 * i] = pi[(size_t)c * RDSP_BLOCK_SAMPLES + i];
+      dst[2 * i + 1] = pq[(size_t)c * RDSP_BLOCK_SAMPLES + i];
+    }
+  }
+  rdsp_release(bi); /* FFTIQ.cpp:114-115 (the previous block lives on the device) */
+  rdsp_release(bq);
+  int n_out = 0;
+  hipError_t e = hipMemcpyAsync(s->d_iq, s->h_iq.data(), s->h_iq.size() * sizeof(int16_t), hipMemcpyHostToDevice, s->stream);
+  int rc = RDSP_OK;
+  if (e == hipSuccess)
+    rc = rdsp_spectrum_update(s->spec, s->d_iq, RDSP_BLOCK_SAMPLES, 1, s->d_out, 1, &n_out, s->stream);
+  if (e == hipSuccess && rc == RDSP_OK && n_out > 0)
+    e = hipMemcpyAsync(s->h_out.data(), s->d_out, s->h_out.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && rc == RDSP_OK) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || rc != RDSP_OK) {
+    s->status = (rc != RDSP_OK) ? rc : RDSP_ERR_HIP;
+    if (e != hipSuccess) rdsp_set_error("spectrum node: %s", hipGetErrorString(e));
+    return;
+  }
+  if (n_out > 0) s->outputflag = 1; /* FFTIQ.cpp:112 */
+}
+}  // namespace
+
+extern "C" rdsp_node_t *rdsp_spectrum_node_create(rdsp_graph_t *g, rdsp_spectrum_t *spec) {
+  if (!g || !spec) {
+    rdsp_set_error("rdsp_spectrum_node_create: bad argument");
+    return nullptr;
+  }
+  SpectrumNode *s = new SpectrumNode();
+  s->spec = spec;
+  s->n_channels = rdsp_graph_channels(g);
+  s->h_iq.assign((size_t)s->n_channels * RDSP_BLOCK_SAMPLES * 2, 0);
+  s->h_out.assign((size_t)s->n_channels * 256, 0);
+  if (hipMalloc((void **)&s->d_iq, s->h_iq.size() * sizeof(int16_t)) != hipSuccess ||
+      hipMalloc((void **)&s->d_out, s->h_out.size() * sizeof(uint16_t)) != hipSuccess ||
+      hipStreamCreate(&s->stream) != hipSuccess) {
+    rdsp_set_error("rdsp_spectrum_node_create: device allocation failed");
+    spectrum_destroy(s);
+    return nullptr;
+  }
+  rdsp_node_t *n = rdsp_node_create(g, 2, spectrum_update, s);
+  if (!n) {
+    spectrum_destroy(s);
+    return nullptr;
+  }
+  rdsp_node_set_destructor(n, spectrum_destroy);
+  return n;
+}
+
+/* FFTIQ.h:62-68: true once per finished average, cleared by the call */
+extern "C" int rdsp_spectrum_node_available(rdsp_node_t *n) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
+  if (!s) return 0;
+  const int f = s->outputflag;
+  s->outputflag = 0;
+  return f;
+}
+/* FFTIQ.h:99 `uint16_t output[256]` of every channel: [n_channels][256], valid until the next update */
+extern "C" const uint16_t *rdsp_spectrum_node_output(rdsp_node_t *n) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
+  return s ? s->h_out.data() : nullptr;
+}
+extern "C" int rdsp_spectrum_node_status(rdsp_node_t *n) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
+  return s ? s->status : RDSP_ERR_INVALID;
+}

@@ -64,6 +64,14 @@ class Graph:
         self._keep.append(chain)
         return Node(self, C.c_void_p(h))
 
+    def spectrum_node(self, analyser):
+        """AudioAnalyzeFFT256IQ as a node (INO:57,73-74): inputs I, Q; available()/output like FFTIQ.h"""
+        h = self.lib.rdsp_spectrum_node_create(self.h, analyser.h)
+        if not h:
+            raise _lib.RdspError(-1, self.lib.rdsp_last_error().decode())
+        self._keep.append(analyser)
+        return SpectrumNode(self, C.c_void_p(h))
+
     def AudioConnection(self, src, src_port, dst, dst_port):
         _lib.check(self.lib.rdsp_connect(src.h, src_port, dst.h, dst_port))
 
@@ -114,6 +122,21 @@ class Node:
 
     def status(self):
         return self.g.lib.rdsp_sdr_node_status(self.h)
+
+
+class SpectrumNode(Node):
+    def available(self):  # FFTIQ.h:62-68
+        return bool(self.g.lib.rdsp_spectrum_node_available(self.h))
+
+    def output(self):     # FFTIQ.h:99, uint16 [n_channels, 256]
+        p = self.g.lib.rdsp_spectrum_node_output(self.h)
+        return np.ctypeslib.as_array(p, (self.g.n_channels, 256)).copy()
+
+    def read(self, channel, binNumber):  # FFTIQ.h:70-73
+        return float(self.output()[channel, binNumber]) * (1.0 / 16384.0)
+
+    def status(self):
+        return self.g.lib.rdsp_spectrum_node_status(self.h)
 
 
 class InputNode(Node):

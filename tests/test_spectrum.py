@@ -99,3 +99,39 @@ def test_gpu_spectrum_is_bit_exact(rdsp, oracle, naverage, window, calls):
         assert fft.available() and not fft.available()
         assert fft.read(0, 300) == 0.0
         assert fft.read(0, 5) == got[0, -1, 5] / 16384.0
+
+
+@pytest.mark.gpu
+def test_analyser_as_a_graph_node_like_the_sketch(rdsp, oracle):
+    """IQinput -> (I, Q) -> FFT node, ticked block by block (INO:52,57,71-74): every
+    completed average equals the oracle's, available() fires once per output."""
+    import torch
+    assert torch.cuda.is_available()
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.graph import Graph
+    from radiodsp_sdr_rx_amd.spectrum import WINDOWS, AnalyzeFFT256IQ
+    lib = _olib(oracle)
+    nch, nblk, nav = 3, 25, 4
+    iq = synth_iq(nch, nblk * 128)
+    g = Graph(nch)
+    g.AudioMemory(12)
+    src = g.input_node()
+    fft = g.spectrum_node(AnalyzeFFT256IQ(nch, naverage=nav, window="AudioWindowHanning256"))
+    g.AudioConnection(src, 0, fft, 0)
+    g.AudioConnection(src, 1, fft, 1)
+    outs = []
+    for b in range(nblk):
+        blk = iq[:, b * 128:(b + 1) * 128]
+        src.push(blk[:, :, 0], blk[:, :, 1])
+        g.update_all()
+        assert fft.status() == 0
+        if fft.available():
+            outs.append(fft.output())
+            assert not fft.available()
+    assert g.memory_usage()[0] == 0          # (blocks in use, peak)
+    for c in range(nch):
+        ref = oracle_spectra(lib, iq[c], nav, WINDOWS["AudioWindowHanning256"])
+        assert len(outs) == len(ref) == (nblk - 1) // nav
+        for k, r in enumerate(ref):
+            assert np.array_equal(outs[k][c], r)
+    assert fft.read(0, 10) == outs[-1][0, 10] / 16384.0
