@@ -170,6 +170,9 @@ class Chain:
     def set_front_variant(self, lean):
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 
+    def set_tail_variant(self, lanes_per_channel):
+        _lib.check(self.lib.rdsp_chain_set_tail_variant(self.h, int(lanes_per_channel)))
+
     def flush(self, stream=None):
         _lib.check(self.lib.rdsp_chain_flush(self.h, _stream_ptr(stream)))
 

@@ -101,6 +101,7 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
+  int tail_lpc = 16;  /* lanes per channel of the tail kernel: 16 (DPP reduction) or 8 (matrix-pipe reduction) */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
   int nb_on = 0;              /* SDR.enableNoiseBlanker, BK_INO:1259 */
@@ -638,7 +639,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
     if (timed) HIP_TRY(hipEventRecord(ev2, tstream));
-    e = rdsp_launch_tail(&tp, 16, tstream);
+    e = rdsp_launch_tail(&tp, c->tail_lpc, tstream);
     if (e != 0) {
       rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
       return RDSP_ERR_HIP;
@@ -681,7 +682,7 @@ extern "C" int rdsp_LMS_NoiseReduction(rdsp_chain_t *c, int n_samples, float *d_
   tp.nr_first = (c->nr_calls == 0);
   tp.nr_w = c->d_nr_w; tp.nr_prev = c->d_nr_prev; tp.nr_energy = c->d_nr_energy;
   tp.st_scal = c->d_scal;
-  int e = rdsp_launch_tail(&tp, 16, (hipStream_t)stream_);
+  int e = rdsp_launch_tail(&tp, c->tail_lpc, (hipStream_t)stream_);
   if (e != 0) {
     rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return RDSP_ERR_HIP;
@@ -951,6 +952,15 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   NEED(c);
   if (lean < -1 || lean > 1) return RDSP_ERR_INVALID;
   c->lean_mode = lean;
+  return RDSP_OK;
+}
+/* tail-kernel variant: 16 lanes per channel (DPP reduction) or 8 (reduction on the matrix
+ * pipe, half the waves); both compute the same recursion, sums associate differently */
+extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel) {
+  NEED(c);
+  if (lanes_per_channel != 8 && lanes_per_channel != 16) return RDSP_ERR_INVALID;
+  if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
+  c->tail_lpc = lanes_per_channel;
   return RDSP_OK;
 }
 /* `stream` waits for every call issued so far (outputs complete after it) */

@@ -452,7 +452,10 @@ extern "C" int rdsp_launch_sam(const RdspSamParams *p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+extern "C" int rdsp_launch_tail8(const RdspTailParams *p, hipStream_t stream); /* rdsp_tail8.hip */
+
 extern "C" int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
+  if (lanes_per_channel == 8) return rdsp_launch_tail8(p, stream);
   if (lanes_per_channel != LPC) return (int)hipErrorInvalidValue;
   const int grid = (p->n_channels + 3) / 4;
   if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tail_kernel<true>), dim3(grid), dim3(64), 0, stream, *p);

@@ -33,10 +33,12 @@ def torch_cuda():
     return torch
 
 
-def gpu_run(torch, iq, cfg, calls=1):
+def gpu_run(torch, iq, cfg, calls=1, tail_lanes=None):
     from radiodsp_sdr_rx_amd.chain import Chain
     nch, n = iq.shape[0], iq.shape[1]
     ch = Chain(nch, max_blocks_per_call=n // 128 // calls, **cfg)
+    if tail_lanes:
+        ch.set_tail_variant(tail_lanes)
     o16, o32 = [], []
     step = n // calls
     for k in range(calls):
@@ -212,13 +214,15 @@ NLMS_CASES = {
 }
 
 
+@pytest.mark.parametrize("tail_lanes", [16, 8])
 @pytest.mark.parametrize("name", sorted(NLMS_CASES))
-def test_chain_with_nlms_matches_oracle_within_conditioning(rdsp, oracle, torch_cuda, name):
+def test_chain_with_nlms_matches_oracle_within_conditioning(rdsp, oracle, torch_cuda, name, tail_lanes):
+    """tail_lanes 16: DPP reduction (default); 8: the matrix-pipe variant (rdsp_tail8.hip)"""
     from radiodsp_sdr_rx_amd.chain import synth_iq
     cfg = NLMS_CASES[name]
-    nch, nblk = 5, 64
+    nch, nblk = 11 if tail_lanes == 8 else 5, 64          # 11: a partly filled last wave of 8 channels
     iq = synth_iq(nch, nblk * 128)
-    o16, o32, _ = gpu_run(torch_cuda, iq, cfg, calls=2)
+    o16, o32, _ = gpu_run(torch_cuda, iq, cfg, calls=2, tail_lanes=tail_lanes)
     r16, r32 = oracle_run(oracle, iq, cfg)
     # front-end difference with the recursive stages switched off
     ff = dict(cfg, lms_nr=0, als_mode="off", agc_mode="off")
@@ -248,6 +252,11 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     calls = 4 if name != "k4" else 2
     b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
+    if name == "k3":  # the 8-lane tail kernel carries the same state
+        c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail_lanes=8)
+        d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail_lanes=8)
+        assert np.array_equal(c16, d16) and np.array_equal(c32, d32)
+        assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
 
 def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
