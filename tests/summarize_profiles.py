@@ -1,0 +1,85 @@
+"""Turn the rocprofv3 output of tests/profile_round.sh (gpurun_out/prof_*, pmc_*) into the
+tracked summaries under profiles/: <round>_<cfg>_kernel_stats.csv, <round>_<cfg>_bench.json,
+<round>_k3_pmc_summary.txt and traffic.json (HBM bytes per launch of the K3 kernels,
+FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as read).
+usage: python tests/summarize_profiles.py r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+
+
+def newest(pattern):
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def short(name):
+    for k in ("rdsp_front_kernel", "rdsp_tail_kernel", "rdsp_tail8_kernel", "rdsp_sam_kernel", "rdsp_spectrum_kernel",
+              "rdsp_group_store_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+def pmc_per_launch(tag):
+    """mean counter value per dispatch, per kernel"""
+    f = newest(os.path.join(OUT, f"pmc_{tag}", "**", "*counter_collection.csv"))
+    if not f:
+        return {}
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = short(row.get("Kernel_Name", ""))
+            if k:
+                acc[k][row["Counter_Name"]].append((row.get("Dispatch_Id"), float(row["Counter_Value"])))
+    res = {}
+    for k, counters in acc.items():
+        res[k] = {}
+        for cname, vals in counters.items():
+            per_dispatch = defaultdict(float)
+            for d, v in vals:
+                per_dispatch[d] += v          # rows are per XCD / instance: sum them
+            res[k][cname] = sum(per_dispatch.values()) / len(per_dispatch)
+    return res
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(PROF, exist_ok=True)
+    for cfg in ("K3", "K2", "K4", "F1", "K5"):
+        stats = newest(os.path.join(OUT, f"prof_{cfg}", "**", "*kernel_stats.csv"))
+        if stats:
+            shutil.copy(stats, os.path.join(PROF, f"{rnd}_{cfg.lower()}_kernel_stats.csv"))
+        bj = os.path.join(OUT, f"prof_{cfg}.json")
+        if os.path.exists(bj):
+            lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
+            if lines:
+                open(os.path.join(PROF, f"{rnd}_{cfg.lower()}_bench.json"), "w").write(lines[-1] + "\n")
+    fetch, write, sq = pmc_per_launch("FETCH_SIZE"), pmc_per_launch("WRITE_SIZE"), pmc_per_launch("SQ")
+    traffic = {"K3": {}}
+    lines = ["K3 per-launch PMC (rocprofv3, separate passes; FETCH_SIZE doubled per the gfx950 note in "
+             "MI355X_MICROARCH.md, WRITE_SIZE as read; units of both: KB):"]
+    for k in sorted(set(fetch) | set(write)):
+        rd = 2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
+        wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+        traffic["K3"][k] = rd + wr
+        lines.append(f"  {k}: read {rd / 1e9:.3f} GB (FETCH_SIZE {fetch.get(k, {}).get('FETCH_SIZE', 0):.0f} KB x2), "
+                     f"write {wr / 1e9:.3f} GB, total {(rd + wr) / 1e9:.3f} GB")
+    for k, c in sorted(sq.items()):
+        lines.append(f"  {k}: " + ", ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())))
+    if traffic["K3"]:
+        json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
+    open(os.path.join(PROF, f"{rnd}_k3_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
