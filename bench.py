@@ -235,8 +235,9 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if os.environ.get("RDSP_TAIL_LPC"):  # A/B runs: tail kernel with 16 or 8 lanes per channel
-        chain.set_tail_variant(int(os.environ["RDSP_TAIL_LPC"]))
+    if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
+        v = os.environ["RDSP_TAIL_VARIANT"]
+        chain.set_tail_variant(int(v.rstrip("m")), v.endswith("m"))
     if os.environ.get("RDSP_FRONT_VARIANT"):  # A/B runs: force the full (0) or lean (1) front kernel
         chain.set_front_variant(int(os.environ["RDSP_FRONT_VARIANT"]))
     for _ in range(args.warmup):

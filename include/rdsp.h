@@ -217,9 +217,9 @@ int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
  * so both kernels fit one SIMD), 0 full-register, 1 lean */
 int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean);
 
-/* tail-kernel variant: 16 lanes per channel with a DPP reduction, or 8 with the
- * reduction on the matrix pipe */
-int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel);
+/* tail-kernel variant: lanes per channel 16 or 8; matrix_reduce = the
+ * cross-lane sums run on the matrix pipe (required for 8 lanes) */
+int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce);
 
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/
 int rdsp_chain_set_timing(rdsp_chain_t *c, int on);

@@ -101,7 +101,7 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
-  int tail_lpc = 16;  /* lanes per channel of the tail kernel: 16 (DPP reduction) or 8 (matrix-pipe reduction) */
+  int tail_lpc = 16;  /* tail kernel: 16 = 16 lanes/channel, DPP reduction; 116 / 108 = 16 / 8 lanes, matrix-pipe reduction */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
   int nb_on = 0;              /* SDR.enableNoiseBlanker, BK_INO:1259 */
@@ -954,13 +954,14 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   c->lean_mode = lean;
   return RDSP_OK;
 }
-/* tail-kernel variant: 16 lanes per channel (DPP reduction) or 8 (reduction on the matrix
- * pipe, half the waves); both compute the same recursion, sums associate differently */
-extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel) {
+/* tail-kernel variant: 16 lanes per channel with the DPP reduction (rdsp_tail.hip), or 16 / 8
+ * lanes with the reduction on the matrix pipe (rdsp_tailm.hip); all compute the same
+ * recursion, the sums associate differently */
+extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce) {
   NEED(c);
-  if (lanes_per_channel != 8 && lanes_per_channel != 16) return RDSP_ERR_INVALID;
+  if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce)) return RDSP_ERR_INVALID;
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
-  c->tail_lpc = lanes_per_channel;
+  c->tail_lpc = lanes_per_channel + (matrix_reduce ? 100 : 0);
   return RDSP_OK;
 }
 /* `stream` waits for every call issued so far (outputs complete after it) */

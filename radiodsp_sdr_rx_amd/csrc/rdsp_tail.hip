@@ -452,11 +452,12 @@ extern "C" int rdsp_launch_sam(const RdspSamParams *p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-extern "C" int rdsp_launch_tail8(const RdspTailParams *p, hipStream_t stream); /* rdsp_tail8.hip */
+extern "C" int rdsp_launch_tail_matrix(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream); /* rdsp_tailm.hip */
 
-extern "C" int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
-  if (lanes_per_channel == 8) return rdsp_launch_tail8(p, stream);
-  if (lanes_per_channel != LPC) return (int)hipErrorInvalidValue;
+/* variant = lanes per channel (16 or 8), +100 for the kernels that reduce on the matrix pipe */
+extern "C" int rdsp_launch_tail(const RdspTailParams *p, int variant, hipStream_t stream) {
+  if (variant >= 100) return rdsp_launch_tail_matrix(p, variant - 100, stream);
+  if (variant != LPC) return (int)hipErrorInvalidValue;
   const int grid = (p->n_channels + 3) / 4;
   if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tail_kernel<true>), dim3(grid), dim3(64), 0, stream, *p);
   else hipLaunchKernelGGL((rdsp_tail_kernel<false>), dim3(grid), dim3(64), 0, stream, *p);

@@ -1,23 +1,25 @@
 /*
- * rdsp_tail8.hip -- the serial-in-time stages with eight lanes per channel and the
- * cross-lane sums on the matrix pipe (gfx950).  Same arithmetic as rdsp_tail.hip
- * (one-step lookahead NLMS, see there); what changes is where the cycles go.
+ * rdsp_tailm.hip -- the serial-in-time stages with the cross-lane sums on the matrix
+ * pipe (gfx950).  Same arithmetic as rdsp_tail.hip (one-step lookahead NLMS, see there);
+ * what changes is where the cycles go.
  *
- * A DPP op occupies the VALU for ~11.6 cycles on MI355X (tests/micro/dpp_rate.hip), and
- * in the 16-lane kernel five of them per step (4-stage reduction + delay-line shift)
- * are half of its issue time -- time the front kernel of the next call wants, since
- * both kernels share the SIMDs in pipelined mode and the pair is VALU-bound.  Here
- *   * a channel is 8 lanes: columns j = 2c, 2c+1 of the 16x4 lane grid (lane = 16k + j),
- *     12 taps per lane, 8 channels per wave;
- *   * the reduction is one DPP (the column pair) plus one v_mfma_f32_16x16x4_f32
- *     with A = 1: D[i][j] = sum_k B[k][j] puts the sum over the four rows k of a column
- *     in every lane of that column (tests/micro/mfma_colsum.hip); fp32 products with
- *     1.0 are exact, the matrix pipe is otherwise idle, and the VALU is not involved;
- *   * the prefix sums of the per-group scalars use the same instruction with a
- *     triangular A (A[i][k] = k <= i/4);
- *   * the delay line is not shifted between lanes at all: every lane reads its next
- *     sample x[n+1-12*sub] from the input ring in LDS.
- * Per channel-step: ~1/8 DPP and ~4 plain VALU ops against 5/4 and ~4.5.
+ * A DPP op occupies the VALU for ~11.6 cycles on MI355X (tests/micro/dpp_rate.hip), and in
+ * rdsp_tail.hip five of them per step (4-stage reduction + delay-line shift) are half of
+ * its issue time -- time the front kernel of the next call wants, since both kernels share
+ * the SIMDs in pipelined mode and the pair is VALU-bound (profiles/r01_k3_pmc_summary.txt:
+ * VALU busy 80 % in the front kernel, 67 % in the tail).  Here the 64 lanes of a wave are
+ * a 4 x 16 grid (lane = 16 row + col) and a channel owns COLS adjacent columns:
+ *   * COLS = 4: 16 lanes and 6 taps per lane, 4 channels per wave (as rdsp_tail.hip);
+ *     COLS = 2: 8 lanes and 12 taps per lane, 8 channels per wave, half the waves;
+ *   * the reduction is log2(COLS) quad_perm DPP steps across the columns, then one
+ *     v_mfma_f32_16x16x4_f32 with A = 1: D[i][j] = sum_k B[k][j] puts the sum over the four
+ *     rows of a column in every lane of that column (tests/micro/mfma_colsum.hip); fp32
+ *     products with 1.0 are exact, the matrix pipe is otherwise idle, the VALU is not involved;
+ *   * the prefix sums of the per-group scalars use the same instruction with a triangular
+ *     A (A[i][k] = k <= i/4);
+ *   * the delay line is not shifted between lanes at all: every lane reads its next sample
+ *     x[n+1-TPL*sub] from the input ring in LDS (one ds_read_b32 per step).
+ * DPP ops per step and wave: 2 (COLS 4) or 1 (COLS 2) instead of 5.
  */
 #include "rdsp_wave.h"
 
@@ -27,13 +29,19 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int LPC = 8;                    /* lanes per channel */
-constexpr int CPW = 64 / LPC;             /* channels per wave */
-constexpr int TPL = RDSP_LMS_TAPS / LPC;  /* 12 taps per lane */
-constexpr int NPH = 16;                   /* physical delay-line ring per lane (>= TPL + 2, divides 128) */
-constexpr int M = NPH - 1;
-constexpr int SCR = 48;                   /* per-group scalars: step size, B, energy */
-constexpr int SPL = RDSP_BLOCK / LPC;     /* samples per lane per block */
+constexpr int SCR = 48; /* per-group scalars: step size, B, energy */
+
+template <int COLS>
+struct Geo {
+  static_assert(COLS == 2 || COLS == 4, "a channel owns 2 or 4 columns of the lane grid");
+  static constexpr int LPC = 4 * COLS;               /* lanes per channel */
+  static constexpr int CPW = 16 / COLS;              /* channels per wave */
+  static constexpr int TPL = RDSP_LMS_TAPS / LPC;    /* taps per lane: 12 or 6 */
+  static constexpr int NPH = (TPL == 12) ? 16 : 8;   /* physical delay-line ring (>= TPL + 2, divides 128) */
+  static constexpr int M = NPH - 1;
+  static constexpr int SPL = RDSP_BLOCK / LPC;       /* samples per lane per block */
+  static constexpr int NA = (TPL == 12) ? 3 : 2;     /* accumulators of the dot product */
+};
 
 /* sum over the four rows of a column: lanes j, j+16, j+32, j+48 -> every one of them */
 __device__ __forceinline__ float col_sum(float v) {
@@ -47,13 +55,20 @@ __device__ __forceinline__ float col_prefix(float v, float tri) {
   const v4f d = __builtin_amdgcn_mfma_f32_16x16x4f32(tri, v, z, 0, 0, 0);
   return d[0];
 }
-__device__ __forceinline__ float pair_other(float v) { return dpp_f<0xB1>(v); } /* quad_perm [1,0,3,2] */
-/* sum over the 8 lanes of a channel, result in all of them */
-__device__ __forceinline__ float chan_sum(float v) { return col_sum(v + pair_other(v)); }
+/* sum over the lanes of a channel, result in all of them */
+template <int COLS>
+__device__ __forceinline__ float chan_sum(float v) {
+  v += dpp_f<0xB1>(v);                          /* quad_perm [1,0,3,2] */
+  if constexpr (COLS == 4) v += dpp_f<0x4E>(v); /* quad_perm [2,3,0,1] */
+  return col_sum(v);
+}
 
-/* One NLMS instance of one channel.  Lane `sub` (= 2*row + column parity) holds the taps of
- * ages TPL*sub .. TPL*sub+TPL-1; CMSIS coefficient b[i] multiplies age 95-i. */
-struct Nlms8 {
+/* One NLMS instance of one channel.  Lane `sub` (= COLS*row + column inside the channel)
+ * holds the taps of ages TPL*sub .. TPL*sub+TPL-1; CMSIS coefficient b[i] multiplies age 95-i. */
+template <int COLS>
+struct NlmsM {
+  using G = Geo<COLS>;
+  static constexpr int TPL = G::TPL, NPH = G::NPH, M = G::M, NA = G::NA;
   float w[TPL];
   float xp[NPH];
   float energy;
@@ -74,24 +89,46 @@ struct Nlms8 {
     if (sub == 0) est[ch] = energy;
   }
 
-  /* lane `sub` prepares steps n0 = s0 + 2*sub and n0 + 1 of a 16-step group */
-  static __device__ __forceinline__ void prepare(const float *cur, int s0, int sub, bool odd, float tri,
+  /* the lanes of a channel prepare the 16 steps of a group (step order = lane order `sub`,
+   * 16/LPC consecutive steps per lane): E_n, B_n by prefix sums of their increments, step size
+   * mu/(E_n + eps).  ci = column inside the channel. */
+  static __device__ __forceinline__ void prepare(const float *cur, int s0, int sub, int ci, float tri,
                                                  float mu, float e_base, float b_base, float *dst) {
-    const float *x = cur + s0 + 2 * sub; /* the previous block sits right below the current one */
-    const float xm = x[-1], x0 = x[0], x1 = x[1];
-    const float qm = x[-97], q0 = x[-96], q1 = x[-95];
-    const float ea0 = fmaf(x0, x0, -(q0 * q0)), ea1 = ea0 + fmaf(x1, x1, -(q1 * q1));
-    const float ba0 = fmaf(x0, xm, -(q0 * qm)), ba1 = ba0 + fmaf(x1, x0, -(q1 * q0));
-    /* exclusive offset of this lane: all lanes of the rows above, plus the even lane of its pair */
-    const float se = ea1 + pair_other(ea1), sb = ba1 + pair_other(ba1);
-    const float pe = col_prefix(se, tri), pb = col_prefix(sb, tri);
-    const float oe = pe - (odd ? ea1 : se), ob = pb - (odd ? ba1 : sb);
-    const float e0 = e_base + (oe + ea0), e1 = e_base + (oe + ea1);
-    float2 *d2 = reinterpret_cast<float2 *>(dst);
-    d2[sub] = make_float2(mu * __builtin_amdgcn_rcpf(e0 + 0.000000119209289f),
-                          mu * __builtin_amdgcn_rcpf(e1 + 0.000000119209289f));
-    d2[8 + sub] = make_float2(b_base + (ob + ba0), b_base + (ob + ba1));
-    d2[16 + sub] = make_float2(e0, e1);
+    if constexpr (COLS == 2) {
+      const float *x = cur + s0 + 2 * sub; /* the previous block sits right below the current one */
+      const float xm = x[-1], x0 = x[0], x1 = x[1];
+      const float qm = x[-97], q0 = x[-96], q1 = x[-95];
+      const float ea0 = fmaf(x0, x0, -(q0 * q0)), ea1 = ea0 + fmaf(x1, x1, -(q1 * q1));
+      const float ba0 = fmaf(x0, xm, -(q0 * qm)), ba1 = ba0 + fmaf(x1, x0, -(q1 * q0));
+      /* exclusive offset of this lane: all lanes of the rows above, plus the even lane of its pair */
+      const float se = ea1 + dpp_f<0xB1>(ea1), sb = ba1 + dpp_f<0xB1>(ba1);
+      const float pe = col_prefix(se, tri), pb = col_prefix(sb, tri);
+      const float oe = pe - (ci ? ea1 : se), ob = pb - (ci ? ba1 : sb);
+      const float e0 = e_base + (oe + ea0), e1 = e_base + (oe + ea1);
+      float2 *d2 = reinterpret_cast<float2 *>(dst);
+      d2[sub] = make_float2(mu * __builtin_amdgcn_rcpf(e0 + 0.000000119209289f),
+                            mu * __builtin_amdgcn_rcpf(e1 + 0.000000119209289f));
+      d2[8 + sub] = make_float2(b_base + (ob + ba0), b_base + (ob + ba1));
+      d2[16 + sub] = make_float2(e0, e1);
+    } else {
+      const float *x = cur + s0 + sub;
+      const float xm = x[-1], x0 = x[0], qm = x[-97], q0 = x[-96];
+      float ea = fmaf(x0, x0, -(q0 * q0)); /* E_n - E_{n-1} */
+      float ba = fmaf(x0, xm, -(q0 * qm)); /* B_n - B_{n-1} */
+      /* inclusive scan over the quad, then the rows above through the matrix pipe */
+      const float e1 = dpp_f<0x90>(ea), b1 = dpp_f<0x90>(ba); /* quad_perm [0,0,1,2] */
+      ea += (ci >= 1) ? e1 : 0.f;
+      ba += (ci >= 1) ? b1 : 0.f;
+      const float e2 = dpp_f<0x44>(ea), b2 = dpp_f<0x44>(ba); /* quad_perm [0,1,0,1] */
+      ea += (ci >= 2) ? e2 : 0.f;
+      ba += (ci >= 2) ? b2 : 0.f;
+      const float se = dpp_f<0xFF>(ea), sb = dpp_f<0xFF>(ba); /* quad_perm [3,3,3,3]: the quad's sum */
+      const float pe = col_prefix(se, tri), pb = col_prefix(sb, tri);
+      const float en = e_base + ((pe - se) + ea);
+      dst[sub] = mu * __builtin_amdgcn_rcpf(en + 0.000000119209289f);
+      dst[16 + sub] = b_base + ((pb - sb) + ba);
+      dst[32 + sub] = en;
+    }
   }
 
   /* one 128-sample block; see Nlms::block in rdsp_tail.hip for the recursion.  ring is
@@ -99,28 +136,25 @@ struct Nlms8 {
    * is at a fixed distance below it (no wrap) */
   template <bool OUT_E>
   __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr,
-                                        int sub, bool odd, float tri) {
+                                        int sub, int ci, float tri) {
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;    /* this lane's newest tap of X_n is mine[n] */
     float bb = 0.f; /* B_{-1} = X_{-2}.X_{-1} */
 #pragma unroll
     for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
-    float b_base = chan_sum(bb);
+    float b_base = chan_sum<COLS>(bb);
     float e_base = energy;
-    prepare(cur, 0, sub, odd, tri, mu, e_base, b_base, scr);
+    prepare(cur, 0, sub, ci, tri, mu, e_base, b_base, scr);
     /* prologue: pp = lane part of A_0 = W_0.X_0 */
     xp[0] = mine[0];
     float pp;
     {
-      float q0 = w[0] * xp[0], q1 = w[1] * xp[1], q2 = w[2] * xp[2];
+      float q[NA];
 #pragma unroll
-      for (int t = 3; t < TPL; t += 3) {
-        q0 = fmaf(w[t], xp[t], q0);
-        q1 = fmaf(w[t + 1], xp[t + 1], q1);
-        q2 = fmaf(w[t + 2], xp[t + 2], q2);
-      }
-      pp = (q0 + q1) + q2;
+      for (int t = 0; t < TPL; t++) q[t % NA] = (t < NA) ? w[t] * xp[t] : fmaf(w[t], xp[t], q[t % NA]);
+      pp = q[0] + q[1];
+      if constexpr (NA == 3) pp += q[2];
     }
     float g = 0.f;
 #pragma unroll 1
@@ -136,7 +170,7 @@ struct Nlms8 {
       e_base = sc[32 + 15];
       b_base = sc[16 + 15];
       if (s0 + 16 < RDSP_BLOCK)
-        prepare(cur, s0 + 16, sub, odd, tri, mu, e_base, b_base, scr + (((s0 >> 4) + 1) & 1) * SCR);
+        prepare(cur, s0 + 16, sub, ci, tri, mu, e_base, b_base, scr + (((s0 >> 4) + 1) & 1) * SCR);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, bn[4] = {bq.x, bq.y, bq.z, bq.w};
@@ -152,26 +186,24 @@ struct Nlms8 {
           /* slot of step n = s0 + s.  On entry: g = g_{n-1}, w = W_{n-1}, pp = lane part of
            * A_n = W_{n-1}.X_n; ring: X_n[t] at xp[(wp + t) & M], X_{n-1}[t] one further. */
           const int wp = (-s) & M;
-          const float A = chan_sum(pp); /* one DPP, one MFMA; needed only after the update below */
+          const float A = chan_sum<COLS>(pp); /* needed only after the update below */
           const bool more = s < 15 || s0 < RDSP_BLOCK - 16; /* x_{n+1} exists */
           const float xnew = more ? mine[s0 + s + 1] : 0.f;
 #pragma unroll
           for (int t = 0; t < TPL; t++) w[t] = fmaf(g, xp[(wp + t + 1) & M], w[t]); /* W_n */
           /* lane part of A_{n+1} = W_n.X_{n+1}; X_{n+1}[t] = X_n[t-1] for t >= 1 */
-          float q0 = w[1] * xp[wp], q1 = w[2] * xp[(wp + 1) & M], q2 = w[3] * xp[(wp + 2) & M];
+          float acc[NA];
 #pragma unroll
-          for (int t = 4; t + 2 < TPL; t += 3) {
-            q0 = fmaf(w[t], xp[(wp + t - 1) & M], q0);
-            q1 = fmaf(w[t + 1], xp[(wp + t) & M], q1);
-            q2 = fmaf(w[t + 2], xp[(wp + t + 1) & M], q2);
+          for (int t = 1; t < TPL; t++) {
+            const int a = (t - 1) % NA;
+            acc[a] = (t - 1 < NA) ? w[t] * xp[(wp + t - 1) & M] : fmaf(w[t], xp[(wp + t - 1) & M], acc[a]);
           }
-          q0 = fmaf(w[10], xp[(wp + 9) & M], q0);
-          q1 = fmaf(w[11], xp[(wp + 10) & M], q1);
           const float y = fmaf(g, bn[u], A);
           const float e = dd[u] - y;
-          if (more) xp[(wp + 15) & M] = xnew;
-          q2 = fmaf(w[0], xnew, q2);
-          pp = (q0 + q1) + q2;
+          if (more) xp[(wp + NPH - 1) & M] = xnew;
+          acc[(TPL - 1) % NA] = fmaf(w[0], xnew, acc[(TPL - 1) % NA]);
+          pp = acc[0] + acc[1];
+          if constexpr (NA == 3) pp += acc[2];
           g = e * gi[u];
           out[s0 + s] = OUT_E ? e : y; /* every lane of the channel holds the same value */
         }
@@ -184,17 +216,18 @@ struct Nlms8 {
   }
 };
 
-template <bool DUAL>
-__global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
+template <int COLS, bool DUAL>
+__global__ void __launch_bounds__(64) rdsp_tailm_kernel(RdspTailParams p) {
+  using G = Geo<COLS>;
+  constexpr int CPW = G::CPW, SPL = G::SPL;
   constexpr int RINGS = DUAL ? 2 : 1;
-  /* +4: consecutive channels start four LDS banks apart (broadcast reads of 8 channels hit 32 banks) */
+  /* +4: consecutive channels start four LDS banks apart */
   constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * SCR + 4;
   __shared__ __attribute__((aligned(16))) float lds[CPW][PER_CH];
   const int lane = threadIdx.x;
   const int row = lane >> 4, col = lane & 15;
-  const int cw = col >> 1;
-  const bool odd = (col & 1) != 0;
-  const int sub = 2 * row + (col & 1);
+  const int cw = col / COLS, ci = col % COLS;
+  const int sub = COLS * row + ci;
   const float tri = (row <= (col >> 2)) ? 1.0f : 0.0f;
   size_t ch = (size_t)blockIdx.x * CPW + cw;
   const bool valid = ch < (size_t)p.n_channels;
@@ -214,7 +247,7 @@ __global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
   const int o_first = one_is_nr ? p.nr_first : p.als_first;
   const int o_mode = one_is_nr ? p.nr_mode : p.als_mode; /* 0: 1.1*y, 1: e, 2: y */
 
-  Nlms8 nr, als; /* !DUAL: `als` is the one instance */
+  NlmsM<COLS> nr, als; /* !DUAL: `als` is the one instance */
   if constexpr (DUAL) {
     nr.load(p.nr_w, p.nr_prev, p.nr_energy, ch, sub);
     als.load(p.als_w, p.als_prev, p.als_energy, ch, sub);
@@ -223,6 +256,7 @@ __global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
   }
   float agc_g = p.st_scal[ch * 4 + 1];
 
+  /* the lower half of a ring is the previous block */
   if constexpr (DUAL) {
 #pragma unroll
     for (int k = 0; k < SPL; k++) {
@@ -233,11 +267,7 @@ __global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
 #pragma unroll
     for (int k = 0; k < SPL; k++) ringA[sub * SPL + k] = o_prev[ch * RDSP_BLOCK + sub * SPL + k];
   }
-
-  const float *src = p.mid + ch * p.mid_stride;
-  static_assert(SPL == 16, "four float4 per lane per block");
-  const float4 *src4 = reinterpret_cast<const float4 *>(src + sub * SPL);
-  float4 nxa = src4[0], nxb = src4[1], nxc = src4[2], nxd = src4[3];
+  const float4 *src4 = reinterpret_cast<const float4 *>(p.mid + ch * p.mid_stride + sub * SPL);
 
 #pragma unroll 1
   for (int b = 0; b < p.n_blocks; b++) {
@@ -251,40 +281,28 @@ __global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
         for (int k = 0; k < SPL / 4; k++) q4[k] = q4[RDSP_BLOCK / 4 + k];
       }
     }
-#ifndef RDSP_T8_PREFETCH
-#define RDSP_T8_PREFETCH 0 /* 1: next block in registers through the step loop: +12 VGPRs, 3 % faster alone, but then two front waves + this one no longer fit a SIMD */
-#endif
-#if !RDSP_T8_PREFETCH
-    if (b > 0) {
+    { /* this block's input: not kept in registers through the step loop (that would cost the
+         registers that let two front waves and this one share a SIMD; measured 3 % alone) */
       const float4 *n4 = src4 + (size_t)b * (RDSP_BLOCK / 4);
-      nxa = n4[0]; nxb = n4[1]; nxc = n4[2]; nxd = n4[3];
-    }
-#endif
-    {
       float4 *dst4 = reinterpret_cast<float4 *>(ringA + RDSP_BLOCK + sub * SPL);
-      dst4[0] = nxa; dst4[1] = nxb; dst4[2] = nxc; dst4[3] = nxd;
+#pragma unroll
+      for (int k = 0; k < SPL / 4; k++) dst4[k] = n4[k];
     }
-#if RDSP_T8_PREFETCH
-    if (b + 1 < p.n_blocks) { /* next block's input lands while this block computes */
-      const float4 *n4 = src4 + (size_t)(b + 1) * (RDSP_BLOCK / 4);
-      nxa = n4[0]; nxb = n4[1]; nxc = n4[2]; nxd = n4[3];
-    }
-#endif
     __syncthreads();
     if constexpr (DUAL) { /* CONV:326-337, then the ALS filter */
       float *o = ringB + RDSP_BLOCK;
-      nr.template block<false>(ringA, p.nr_first && b == 0, p.nr_mu, o, scr, sub, odd, tri);
+      nr.template block<false>(ringA, p.nr_first && b == 0, p.nr_mu, o, scr, sub, ci, tri);
       __syncthreads();
       if (p.nr_mode == 0) { /* CONV:334 */
 #pragma unroll
         for (int k = 0; k < SPL; k++) o[sub * SPL + k] *= 1.1f;
         __syncthreads();
       }
-      if (p.als_mode == 1) als.template block<true>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub, odd, tri);
-      else als.template block<false>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub, odd, tri);
+      if (p.als_mode == 1) als.template block<true>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub, ci, tri);
+      else als.template block<false>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub, ci, tri);
     } else if (has_inst) {
-      if (o_mode == 1) als.template block<true>(ringA, o_first && b == 0, o_mu, fin, scr, sub, odd, tri);
-      else als.template block<false>(ringA, o_first && b == 0, o_mu, fin, scr, sub, odd, tri);
+      if (o_mode == 1) als.template block<true>(ringA, o_first && b == 0, o_mu, fin, scr, sub, ci, tri);
+      else als.template block<false>(ringA, o_first && b == 0, o_mu, fin, scr, sub, ci, tri);
     } else {
 #pragma unroll
       for (int k = 0; k < SPL / 4; k++)
@@ -316,7 +334,7 @@ __global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
       float pw = 0.f;
 #pragma unroll
       for (int k = 0; k < SPL; k++) pw += L[k] * L[k] + L[k] * L[k];
-      pw = chan_sum(pw);
+      pw = chan_sum<COLS>(pw);
       float pp = pw / (float)(2 * RDSP_BLOCK);
       float rms = sqrtf(pp);
       float gt = fminf(0.25f / (rms + 1e-6f), 100.0f);
@@ -350,30 +368,37 @@ __global__ void __launch_bounds__(64) rdsp_tail8_kernel(RdspTailParams p) {
     __syncthreads();
   }
 
-  if (valid) {
-    const int hl = 1; /* the last block processed is the upper half of the ring */
+  if (valid) { /* the last block processed is the upper half of the ring */
     if constexpr (DUAL) {
       nr.store(p.nr_w, p.nr_energy, ch, sub);
       als.store(p.als_w, p.als_energy, ch, sub);
 #pragma unroll
       for (int k = 0; k < SPL; k++) {
-        p.nr_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringA[hl * RDSP_BLOCK + sub * SPL + k];
-        p.als_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringB[hl * RDSP_BLOCK + sub * SPL + k];
+        p.nr_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringA[RDSP_BLOCK + sub * SPL + k];
+        p.als_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringB[RDSP_BLOCK + sub * SPL + k];
       }
     } else if (has_inst) {
       als.store(o_w, o_energy, ch, sub);
 #pragma unroll
-      for (int k = 0; k < SPL; k++) o_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringA[hl * RDSP_BLOCK + sub * SPL + k];
+      for (int k = 0; k < SPL; k++) o_prev[ch * RDSP_BLOCK + sub * SPL + k] = ringA[RDSP_BLOCK + sub * SPL + k];
     }
     if (sub == 0 && !p.raw_out) p.st_scal[ch * 4 + 1] = agc_g;
   }
 }
 
+template <int COLS>
+int launch_m(const RdspTailParams *p, hipStream_t stream) {
+  const int grid = (p->n_channels + Geo<COLS>::CPW - 1) / Geo<COLS>::CPW;
+  if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tailm_kernel<COLS, true>), dim3(grid), dim3(64), 0, stream, *p);
+  else hipLaunchKernelGGL((rdsp_tailm_kernel<COLS, false>), dim3(grid), dim3(64), 0, stream, *p);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
-extern "C" int rdsp_launch_tail8(const RdspTailParams *p, hipStream_t stream) {
-  const int grid = (p->n_channels + CPW - 1) / CPW;
-  if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tail8_kernel<true>), dim3(grid), dim3(64), 0, stream, *p);
-  else hipLaunchKernelGGL((rdsp_tail8_kernel<false>), dim3(grid), dim3(64), 0, stream, *p);
-  return (int)hipGetLastError();
+/* lanes_per_channel: 16 or 8 */
+extern "C" int rdsp_launch_tail_matrix(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
+  if (lanes_per_channel == 16) return launch_m<4>(p, stream);
+  if (lanes_per_channel == 8) return launch_m<2>(p, stream);
+  return (int)hipErrorInvalidValue;
 }

@@ -33,12 +33,13 @@ def torch_cuda():
     return torch
 
 
-def gpu_run(torch, iq, cfg, calls=1, tail_lanes=None):
+def gpu_run(torch, iq, cfg, calls=1, tail=None):
+    """tail: None (default kernel) or "16m" / "8m": the matrix-pipe tail kernels (rdsp_tailm.hip)"""
     from radiodsp_sdr_rx_amd.chain import Chain
     nch, n = iq.shape[0], iq.shape[1]
     ch = Chain(nch, max_blocks_per_call=n // 128 // calls, **cfg)
-    if tail_lanes:
-        ch.set_tail_variant(tail_lanes)
+    if tail:
+        ch.set_tail_variant(int(tail.rstrip("m")), tail.endswith("m"))
     o16, o32 = [], []
     step = n // calls
     for k in range(calls):
@@ -214,15 +215,16 @@ NLMS_CASES = {
 }
 
 
-@pytest.mark.parametrize("tail_lanes", [16, 8])
+@pytest.mark.parametrize("tail", ["16", "16m", "8m"])
 @pytest.mark.parametrize("name", sorted(NLMS_CASES))
-def test_chain_with_nlms_matches_oracle_within_conditioning(rdsp, oracle, torch_cuda, name, tail_lanes):
-    """tail_lanes 16: DPP reduction (default); 8: the matrix-pipe variant (rdsp_tail8.hip)"""
+def test_chain_with_nlms_matches_oracle_within_conditioning(rdsp, oracle, torch_cuda, name, tail):
+    """tail "16": DPP reduction (rdsp_tail.hip); "16m", "8m": 16 / 8 lanes per channel with the
+    reduction on the matrix pipe (rdsp_tailm.hip)"""
     from radiodsp_sdr_rx_amd.chain import synth_iq
     cfg = NLMS_CASES[name]
-    nch, nblk = 11 if tail_lanes == 8 else 5, 64          # 11: a partly filled last wave of 8 channels
+    nch, nblk = 11 if tail == "8m" else 5, 64          # partly filled last waves (8 / 4 channels per wave)
     iq = synth_iq(nch, nblk * 128)
-    o16, o32, _ = gpu_run(torch_cuda, iq, cfg, calls=2, tail_lanes=tail_lanes)
+    o16, o32, _ = gpu_run(torch_cuda, iq, cfg, calls=2, tail=tail)
     r16, r32 = oracle_run(oracle, iq, cfg)
     # front-end difference with the recursive stages switched off
     ff = dict(cfg, lms_nr=0, als_mode="off", agc_mode="off")
@@ -252,11 +254,12 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     calls = 4 if name != "k4" else 2
     b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
-    if name == "k3":  # the 8-lane tail kernel carries the same state
-        c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail_lanes=8)
-        d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail_lanes=8)
-        assert np.array_equal(c16, d16) and np.array_equal(c32, d32)
-        assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
+    if name == "k3":  # the other tail kernels carry the same state
+        for tail in ("16m", "8m"):
+            c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail=tail)
+            d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail=tail)
+            assert np.array_equal(c16, d16) and np.array_equal(c32, d32)
+            assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
 
 def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
