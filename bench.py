@@ -235,6 +235,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 packed-FMA FIR, 1 matrix FIR
+        chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]
         chain.set_tail_variant(int(v.rstrip("m")), v.endswith("m"))

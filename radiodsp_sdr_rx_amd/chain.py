@@ -170,6 +170,9 @@ class Chain:
     def set_front_variant(self, lean):
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 
+    def set_fir_variant(self, matrix):
+        _lib.check(self.lib.rdsp_chain_set_fir_variant(self.h, int(matrix)))
+
     def set_tail_variant(self, lanes_per_channel, matrix_reduce=None):
         if matrix_reduce is None:
             matrix_reduce = lanes_per_channel == 8

@@ -101,6 +101,7 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
+  int fir_mode = -1;  /* -1 auto (matrix FIR unless the tail shares the SIMDs), 0 packed-FMA FIR, 1 matrix FIR */
   int tail_lpc = 16;  /* tail kernel: 16 = 16 lanes/channel, DPP reduction; 116 / 108 = 16 / 8 lanes, matrix-pipe reduction */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
@@ -567,6 +568,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   /* the lean variant leaves registers and LDS for the concurrent tail kernel */
   fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
   fp.front_prio = piped ? 1 : 0;
+  fp.fir_matrix = (c->fir_mode < 0) ? (piped ? 0 : 1) : c->fir_mode;
   fp.mid_q = c->d_mid_q;
   if (piped) {
     fp.mid = slot ? c->d_mid2 : c->d_mid;
@@ -952,6 +954,15 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   NEED(c);
   if (lean < -1 || lean > 1) return RDSP_ERR_INVALID;
   c->lean_mode = lean;
+  return RDSP_OK;
+}
+/* decimating FIR of the front kernel: -1 = auto (v_mfma GEMM slices unless the tail stage
+ * runs concurrently), 0 = packed FMAs, 1 = matrix.  Same taps and products; the sums
+ * associate differently (~1e-7). */
+extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix) {
+  NEED(c);
+  if (matrix < -1 || matrix > 1) return RDSP_ERR_INVALID;
+  c->fir_mode = matrix;
   return RDSP_OK;
 }
 /* tail-kernel variant: 16 lanes per channel with the DPP reduction (rdsp_tail.hip), or 16 / 8

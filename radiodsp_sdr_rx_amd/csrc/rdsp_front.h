@@ -90,6 +90,40 @@ RDSP_HD void fir_lane(int l, int c0, int c1, const float2 *xs, const float4 *tap
   }
 }
 
+/* ---- the same FIR on the matrix pipe ------------------------------------------------
+ * With m = 16a + b:  y[16a+b] = sum_d x[64a+d] h[4b-d],  d in [-256, 63], i.e. a GEMM
+ *     Y[a][b] = A[a][d] B[d][b],   A[a][d] = x[64a + d]  (the chunk and its history, reshaped)
+ *                                   B[d][b] = h[4b - d]   (banded Toeplitz of the taps)
+ * of 16 x 320 x 16 per component: 80 K-slices of v_mfma_f32_16x16x4_f32, 320/256 of the
+ * direct form's multiplies but on the matrix pipe, which the rest of the chain leaves idle
+ * (the chain is fp32-VALU-bound).  A comes from LDS with one ds_read_b64 (re, im) per lane
+ * and slice: the input is stored linearly with two float2 of padding per 64 samples so the
+ * 16 rows of a slice fall in different banks; B is one ds_read_b32 per lane and slice
+ * from the tap line hz[t + 64] = h[t], zero outside 0..255. */
+constexpr int RDSP_XL_N = 1280 + (1280 / 64) * 2; /* float2: 256 history + 1024 chunk, padded */
+constexpr int RDSP_HZ_N = 384;                    /* floats: taps -64 .. 319 */
+/* float2 index of chunk-local input sample n, n in [-256, 1023] */
+constexpr RDSP_HD int xl_pos(int n) { return (n + 256) + ((n + 256) >> 6) * 2; }
+typedef float rdsp_v4f __attribute__((ext_vector_type(4)));
+/* K-slices [s0, s1) of the product; lane l = 16 kq + i holds, in d?[r], output m = 64 kq + 16 r + i */
+template <int S0, int S1>
+__device__ __forceinline__ void fir_matrix(int lane, const float2 *xl, const float *hz, rdsp_v4f &dre, rdsp_v4f &dim) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const int i = lane & 15, kq = lane >> 4;
+  const float2 *ap = xl + (66 * i + kq); /* xl_pos(64 i + kq - 256) */
+  const float *bp = hz + (320 + 4 * i - kq);
+#pragma unroll
+  for (int s = S0; s < S1; s++) {
+    const float2 a = ap[4 * s + (s >> 4) * 2]; /* 4 s + kq never crosses a 64-sample row on its own */
+    const float b = bp[-4 * s];
+    dre = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, dre, 0, 0, 0);
+    dim = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, dim, 0, 0, 0);
+  }
+#else
+  (void)lane; (void)xl; (void)hz; (void)dre; (void)dim;
+#endif
+}
+
 /* phasor of a 32-bit phase by the ALU: exp(-j*2*pi*ph/2^32).  The top 24 bits go
  * through sincospi (exact argument), the low 8 bits are a first-order residual
  * (angle < 3.7e-7 rad). */

@@ -32,16 +32,18 @@ namespace {
 
 /* ---- front kernel -------------------------------------------------------- */
 /* LDS plan of the front kernel (float2 units), shared with the launch code */
-template <int N, int P, int DECIM>
+/* FMX: the decimating FIR as a GEMM with v_mfma (fir_matrix, rdsp_front.h) instead of packed FMAs */
+template <int N, int P, int DECIM, bool FMX>
 struct FrontLds {
   static constexpr int NT = N / P;
   static constexpr int H = N / 2;
-  static constexpr int XS_N = (DECIM == 4) ? 16 * RDSP_XP : 0;
+  static constexpr bool FM = FMX && (DECIM == 4);
+  static constexpr int XS_N = (DECIM == 4) ? (FM ? RDSP_XL_N : 16 * RDSP_XP) : 0;
   static constexpr int HB_N = (H > 256) ? H : 256; /* new samples of one chunk / one hop */
   /* one-wave kernels with a work buffer that fits behind the FIR history reuse the planes */
   static constexpr bool ALIAS = (DECIM == 4) && (NT == 64) && (N <= 512);
   static constexpr int WB_N = ALIAS ? 0 : FftPlan<N, P>::WB;
-  static constexpr int TAPS_N = (DECIM == 4) ? 128 : 0;
+  static constexpr int TAPS_N = (DECIM == 4) ? (FM ? RDSP_HZ_N / 2 : 128) : 0;
   static constexpr size_t BYTES = (size_t)(XS_N + HB_N + WB_N + TAPS_N) * sizeof(float2) + 64 * sizeof(float);
 };
 /* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
@@ -50,8 +52,14 @@ struct FrontLds {
  * serial tail kernel runs concurrently (pipelined mode): two lean front waves plus
  * one tail wave fit the 512-register file of a SIMD, so the latency-bound
  * instruction stream of the tail fills issue slots the front leaves idle.  Alone, the
- * full-register variant is ~15 % faster, so the launch code picks per call. */
-template <int N, int P, int DECIM, bool LEAN, bool PRE>
+ * full-register variant is ~15 % faster, so the launch code picks per call.
+ * FMX = true runs the decimating FIR as v_mfma_f32_16x16x4_f32 GEMM slices.  fp32 MFMA and
+ * fp32 VALU work do not overlap on a gfx950 SIMD (tests/micro/mfma_valu_overlap.hip: one wave
+ * of each takes the sum of both times), so this is not a second pipe; it wins 10 % at K2,
+ * 6 % on the K3 front kernel and 2 % at K4 through fewer LDS reads and instructions and 40-60
+ * fewer VGPRs -- but its 32-cycle instructions starve a co-resident tail wave (pipelined
+ * K3: 2.21 -> 2.58 ms), so the launch code uses it only when the tail does not share the SIMDs. */
+template <int N, int P, int DECIM, bool LEAN, bool PRE, bool FMX>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;
   constexpr int NT = PL::NT;
@@ -63,8 +71,12 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   constexpr int FPC = (H >= CH_OUT) ? 1 : CH_OUT / H; /* frames per chunk */
   constexpr int CPF = (H >= CH_OUT) ? H / CH_OUT : 1; /* chunks per frame */
   constexpr int NB = H / RDSP_BLOCK;                  /* 128-blocks per hop */
-  using LY = FrontLds<N, P, DECIM>;
+  using LY = FrontLds<N, P, DECIM, FMX>;
   constexpr bool ALIAS = LY::ALIAS;
+  constexpr bool FM = LY::FM;
+  /* matrix FIR: the input is one padded line; after the FIR only its first 256 samples (the
+   * history) are live, so the work buffer sits right behind them with the plain map */
+  constexpr bool WALIAS = ALIAS && !FM;
   constexpr int LP = (CH_IN / 4 + NT - 1) / NT; /* uint4 loads per thread per chunk */
   static_assert(DECIM == 1 || DECIM == 4, "decimation 1 or 4");
   static_assert(NT == 64 || NT == 256, "one or four waves per channel");
@@ -77,8 +89,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *xs = reinterpret_cast<float2 *>(smem_raw);
   float2 *hb = xs + LY::XS_N;
-  float2 *wb = ALIAS ? xs : hb + LY::HB_N;
+  float2 *wb = ALIAS ? (FM ? xs + xl_pos(0) : xs) : hb + LY::HB_N;
+  static_assert(!FM || !ALIAS || xl_pos(0) + PL::WB <= RDSP_XL_N, "work buffer fits behind the history");
   float4 *taps_lds = reinterpret_cast<float4 *>(hb + LY::HB_N + (ALIAS ? 0 : PL::WB));
+  float *hz = reinterpret_cast<float *>(taps_lds);
   float *red = reinterpret_cast<float *>(reinterpret_cast<float2 *>(taps_lds) + LY::TAPS_N);
 
   /* PRE: the pre-processor's IQ swap and the noise blanker are compiled in (their
@@ -113,8 +127,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
    * (digit-reversed, /N), its VAD-bin membership bits and its four taps */
   Twiddles<N, P, LEAN> tw;
   tw.init(tid);
-  LdsBases<N, P, ALIAS> lb;
-  make_lds_bases<N, P, ALIAS>(tid, lb);
+  LdsBases<N, P, WALIAS> lb;
+  make_lds_bases<N, P, WALIAS>(tid, lb);
   uint32_t vadbits = 0;
 #pragma unroll
   for (int e = 0; e < P; e++) {
@@ -122,7 +136,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
   }
   if constexpr (DECIM == 4) {
-    if (tid < 64) taps_lds[tid] = reinterpret_cast<const float4 *>(p.fir_hc)[tid];
+    if constexpr (FM) { /* tap line hz[t + 64] = h[t] = hc[t % 4][t / 4], zero outside 0..255 */
+      for (int t = tid; t < RDSP_HZ_N; t += NT) {
+        const int tt = t - 64;
+        hz[t] = (tt >= 0 && tt < 256) ? p.fir_hc[(tt & 3) * 64 + (tt >> 2)] : 0.f;
+      }
+    } else {
+      if (tid < 64) taps_lds[tid] = reinterpret_cast<const float4 *>(p.fir_hc)[tid];
+    }
   }
 
   float nfloor = p.st_scal[ch * 4 + 0];
@@ -161,7 +182,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
           float2 ph = (k == 0) ? ph0 : cmul_pinned(ph0, k == 1 ? G.roth1 : (k == 2 ? G.roth2 : G.roth3));
           x = cmul_pinned(x, ph);
         }
-        xs[xs_pos(-256 + 4 * i + k)] = x;
+        xs[FM ? xl_pos(-256 + 4 * i + k) : xs_pos(-256 + 4 * i + k)] = x;
       }
     }
   }
@@ -217,7 +238,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
             x = cmul_pinned(x, ph);
           }
           if constexpr (DECIM == 4) {
-            xs[xs_pos(4 * idx + j)] = x;
+            xs[FM ? xl_pos(4 * idx + j) : xs_pos(4 * idx + j)] = x;
           } else {
             int m = 4 * idx + j; /* no decimator: the sample is the "output" */
             hb[(chunk % CPF) * CH_OUT + m] = x;
@@ -254,7 +275,36 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     __syncthreads();
 
     /* ---- A3: polyphase decimating FIR ------------------------------------ */
-    if constexpr (DECIM == 4) {
+    if constexpr (DECIM == 4 && FM) {
+      /* on the matrix pipe (rdsp_front.h): lane 16 kq + i gets outputs m = 64 kq + 16 r + i */
+      rdsp_v4f dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
+      const int mi = lane & 15, mk = lane >> 4;
+      if constexpr (NW == 1) {
+        if (p.front_prio > 0) __builtin_amdgcn_s_setprio(2);
+        fir_matrix<0, 80>(lane, xs, hz, dre, dim);
+        if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) hb[(chunk % CPF) * CH_OUT + 64 * mk + 16 * r + mi] = make_float2(dre[r], dim[r]);
+        __syncthreads();
+      } else {
+        /* four waves: wave w takes a quarter of the K-slices; partials summed via LDS */
+        if (wave == 0) fir_matrix<0, 20>(lane, xs, hz, dre, dim);
+        else if (wave == 1) fir_matrix<20, 40>(lane, xs, hz, dre, dim);
+        else if (wave == 2) fir_matrix<40, 60>(lane, xs, hz, dre, dim);
+        else fir_matrix<60, 80>(lane, xs, hz, dre, dim);
+#pragma unroll
+        for (int r = 0; r < 4; r++) wb[wave * CH_OUT + 64 * mk + 16 * r + mi] = make_float2(dre[r], dim[r]);
+        __syncthreads();
+        {
+          float2 s0 = wb[tid], s1 = wb[CH_OUT + tid], s2 = wb[2 * CH_OUT + tid], s3 = wb[3 * CH_OUT + tid];
+          float2 s = cadd(cadd(s0, s1), cadd(s2, s3));
+          hb[(chunk % CPF) * CH_OUT + tid] = s;
+        }
+      }
+      /* the last 256 samples of the chunk are the next chunk's history */
+      for (int t = tid; t < 256; t += NT) xs[xl_pos(t - 256)] = xs[xl_pos(768 + t)];
+      __syncthreads();
+    } else if constexpr (DECIM == 4) {
       float2 acc[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[r] = make_float2(0.f, 0.f);
@@ -313,7 +363,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         fwd_pass0_store<N, P>(lb, v, wb, twp); /* CONV:291 */
       }
       __syncthreads();
-      fwd_mid_all<N, P, 1, PL::NP - 1, ALIAS>(lb, wb, tw, sync);
+      fwd_mid_all<N, P, 1, PL::NP - 1, WALIAS>(lb, wb, tw, sync);
       fwd_pass_last<N, P>(lb, v, wb);
 
       if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
@@ -350,7 +400,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 
       inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
       __syncthreads();
-      inv_mid_all<N, P, PL::NP - 2, ALIAS>(lb, wb, tw, sync);
+      inv_mid_all<N, P, PL::NP - 2, WALIAS>(lb, wb, tw, sync);
       {
         float2 twp[P - 1];
         tw.template get<0>(twp);
@@ -507,23 +557,30 @@ __global__ void rdsp_float_to_q15_kernel(const float *src, int16_t *dst, size_t 
   for (; i < n; i += stride) dst[i] = (int16_t)q15_of_float(src[i]);
 }
 
-template <int N, int P, int DECIM>
+template <int N, int P, int DECIM, bool FMX>
 constexpr size_t front_lds() {
-  return FrontLds<N, P, DECIM>::BYTES;
+  return FrontLds<N, P, DECIM, FMX>::BYTES;
 }
 
-template <int N, int P, int DECIM, bool LEAN, bool PRE>
-int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  constexpr size_t lds = front_lds<N, P, DECIM>();
+template <int N, int P, int DECIM, bool LEAN, bool PRE, bool FMX>
+int launch_front_x(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  constexpr size_t lds = front_lds<N, P, DECIM, FMX>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN, PRE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN, PRE>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
+}
+template <int N, int P, int DECIM, bool LEAN, bool PRE>
+int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  if constexpr (DECIM == 4) {
+    if (p->fir_matrix) return launch_front_x<N, P, DECIM, LEAN, PRE, true>(p, n_channels, stream);
+  }
+  return launch_front_x<N, P, DECIM, LEAN, PRE, false>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM, bool LEAN>
 int launch_front_v(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
@@ -542,11 +599,11 @@ int launch_front_t(const RdspFrontParams *p, int n_channels, hipStream_t stream)
 extern "C" size_t rdsp_front_lds_bytes(int fft_l, int decim) {
   const bool d4 = decim == 4;
   switch (fft_l) {
-    case 256: return d4 ? front_lds<256, 4, 4>() : front_lds<256, 4, 1>();
-    case 512: return d4 ? front_lds<512, 8, 4>() : front_lds<512, 8, 1>();
-    case 1024: return d4 ? front_lds<1024, 16, 4>() : front_lds<1024, 16, 1>();
-    case 2048: return d4 ? front_lds<2048, 8, 4>() : front_lds<2048, 8, 1>();
-    case 4096: return d4 ? front_lds<4096, 16, 4>() : front_lds<4096, 16, 1>();
+    case 256: return d4 ? front_lds<256, 4, 4, true>() : front_lds<256, 4, 1, false>();
+    case 512: return d4 ? front_lds<512, 8, 4, true>() : front_lds<512, 8, 1, false>();
+    case 1024: return d4 ? front_lds<1024, 16, 4, true>() : front_lds<1024, 16, 1, false>();
+    case 2048: return d4 ? front_lds<2048, 8, 4, true>() : front_lds<2048, 8, 1, false>();
+    case 4096: return d4 ? front_lds<4096, 16, 4, true>() : front_lds<4096, 16, 1, false>();
     default: return 0;
   }
 }

@@ -273,6 +273,7 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
              for k in range(calls)]
     ref_chain = Chain(nch, max_blocks_per_call=nblk, **K3)
     ref_chain.set_front_variant(1)  # pipelined mode picks the register-lean front kernel
+    ref_chain.set_fir_variant(0)    # ... with the packed-FMA FIR
     ref = [ref_chain.process(p).cpu().numpy() for p in parts]
     ch = Chain(nch, max_blocks_per_call=nblk, **K3)
     ch.set_pipelined(True)
@@ -295,11 +296,12 @@ def test_front_kernel_variants_agree(rdsp, oracle, torch_cuda):
     cfg = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, agc_mode="medium")
     iq = synth_iq(4, 32 * 128)
     _, r32 = oracle_run(oracle, iq, cfg)
-    for lean in (0, 1):
+    for lean, fir in ((0, 0), (1, 0), (0, 1), (1, 1)):   # register-lean x (packed-FMA | matrix) FIR
         ch = Chain(4, max_blocks_per_call=32, **cfg)
         ch.set_front_variant(lean)
+        ch.set_fir_variant(fir)
         f = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)[1].cpu().numpy()
-        assert normwise(f, r32) <= TOL, lean
+        assert normwise(f, r32) <= TOL, (lean, fir)
 
 
 def test_channel_partition_invariance(rdsp, torch_cuda):

@@ -138,6 +138,7 @@ def test_files_through_the_runner_match_resident_processing_and_oracle(rdsp, ora
     ref_chain = Chain(nch, max_blocks_per_call=per, **cfg)
     if pipelined:
         ref_chain.set_front_variant(1)   # pipelined mode runs the register-lean front kernel
+        ref_chain.set_fir_variant(0)     # with the packed-FMA FIR
     parts, pos = [], 0
     while pos < exp_blocks:
         take = min(per, exp_blocks - pos)
