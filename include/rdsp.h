@@ -217,8 +217,8 @@ int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
  * so both kernels fit one SIMD), 0 full-register, 1 lean */
 int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean);
 
-/* decimating FIR variant: -1 auto (matrix-core GEMM slices unless the tail stage shares the
- * SIMDs), 0 packed FMAs, 1 matrix */
+/* decimating FIR variant: 0 packed FMAs (default), 1 matrix-core GEMM slices (opt-in,
+ * +10 % at K2), -1 matrix unless the tail stage shares the SIMDs */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix);
 /* tail-kernel variant: lanes per channel 16 or 8; matrix_reduce = the
  * cross-lane sums run on the matrix pipe (required for 8 lanes) */

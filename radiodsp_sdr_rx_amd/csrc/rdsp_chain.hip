@@ -101,7 +101,7 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
-  int fir_mode = -1;  /* -1 auto (matrix FIR unless the tail shares the SIMDs), 0 packed-FMA FIR, 1 matrix FIR */
+  int fir_mode = 0;   /* 0 packed-FMA FIR (default: the north-star path has no MFMA), 1 matrix FIR, -1 matrix unless the tail shares the SIMDs */
   int tail_lpc = 16;  /* tail kernel: 16 = 16 lanes/channel, DPP reduction; 116 / 108 = 16 / 8 lanes, matrix-pipe reduction */
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
@@ -956,9 +956,10 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   c->lean_mode = lean;
   return RDSP_OK;
 }
-/* decimating FIR of the front kernel: -1 = auto (v_mfma GEMM slices unless the tail stage
- * runs concurrently), 0 = packed FMAs, 1 = matrix.  Same taps and products; the sums
- * associate differently (~1e-7). */
+/* decimating FIR of the front kernel: 0 = packed FMAs (default), 1 = v_mfma GEMM slices,
+ * -1 = matrix unless the tail stage runs concurrently (where it loses).  Same taps and
+ * products; the sums associate differently (~1e-7).  Opt-in: the north-star defines the path
+ * without MFMA, and the measurement agrees that there is no idle pipe to win. */
 extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix) {
   NEED(c);
   if (matrix < -1 || matrix > 1) return RDSP_ERR_INVALID;

@@ -53,12 +53,12 @@ struct FrontLds {
  * one tail wave fit the 512-register file of a SIMD, so the latency-bound
  * instruction stream of the tail fills issue slots the front leaves idle.  Alone, the
  * full-register variant is ~15 % faster, so the launch code picks per call.
- * FMX = true runs the decimating FIR as v_mfma_f32_16x16x4_f32 GEMM slices.  fp32 MFMA and
- * fp32 VALU work do not overlap on a gfx950 SIMD (tests/micro/mfma_valu_overlap.hip: one wave
- * of each takes the sum of both times), so this is not a second pipe; it wins 10 % at K2,
- * 6 % on the K3 front kernel and 2 % at K4 through fewer LDS reads and instructions and 40-60
- * fewer VGPRs -- but its 32-cycle instructions starve a co-resident tail wave (pipelined
- * K3: 2.21 -> 2.58 ms), so the launch code uses it only when the tail does not share the SIMDs. */
+ * FMX = true (opt-in, rdsp_chain_set_fir_variant) runs the decimating FIR as
+ * v_mfma_f32_16x16x4_f32 GEMM slices.  fp32 MFMA and fp32 VALU work do not overlap on a gfx950
+ * SIMD (tests/micro/mfma_valu_overlap.hip: one wave of each takes the sum of both times), so
+ * this is not a second pipe; it wins 10 % at K2, 6 % on the K3 front kernel and 2 % at K4
+ * through fewer LDS reads and instructions and 40-60 fewer VGPRs -- and its 32-cycle
+ * instructions starve a co-resident tail wave (pipelined K3: 2.21 -> 2.58 ms). */
 template <int N, int P, int DECIM, bool LEAN, bool PRE, bool FMX>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;

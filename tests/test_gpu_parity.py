@@ -121,6 +121,21 @@ FF_CASES = {
 }
 
 
+@pytest.mark.parametrize("name", ["k2_usb_256", "usb_1024", "lsb_2048", "k4_cw_4096_agc", "spectral_512"])
+def test_matrix_fir_variant_matches_oracle(rdsp, oracle, torch_cuda, name):
+    """rdsp_chain_set_fir_variant(1): the decimating FIR as v_mfma GEMM slices (opt-in)"""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg, nch, nblk, cw = FF_CASES[name]
+    iq = synth_iq(nch, nblk * 128, cw=cw)
+    ch = Chain(nch, max_blocks_per_call=nblk // 2, **cfg)
+    ch.set_fir_variant(1)
+    got = np.concatenate([ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * (nblk // 2) * 128:(k + 1) * (nblk // 2) * 128])).cuda(),
+                                     want_f32=True)[1].cpu().numpy() for k in range(2)], 1)
+    _, r32 = oracle_run(oracle, iq, cfg)
+    assert normwise(got, r32) <= TOL
+
+
 @pytest.mark.parametrize("name", sorted(FF_CASES))
 def test_feed_forward_chain_matches_oracle(rdsp, oracle, torch_cuda, name):
     from radiodsp_sdr_rx_amd.chain import synth_iq
