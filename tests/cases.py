@@ -17,5 +17,38 @@ GOLDEN_CASES = {
                        cfg=dict(fft_l=512, demod="AM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="slow")),
 }
 
+# SURVEY 8f row F3 (engine features, build-defined): SAM demodulator; noise blanker + IQ swap on
+# an input with ignition-style bursts.  `setup` is applied to the oracle chain and to the GPU chain.
+GOLDEN_CASES["sam_agc_512"] = dict(channels=2, blocks=48,
+                                   cfg=dict(fft_l=512, demod="SAM", flo_hz=-3900.0, fhi_hz=3900.0,
+                                            nco_hz=12950.0, agc_mode="slow"))   # the 13 kHz carrier sits 50 Hz off tune
+GOLDEN_CASES["blanker_swap_256"] = dict(channels=2, blocks=32, cfg=K1, impulses=True,
+                                        setup=dict(noise_blanker_db=8.0, swap_iq=True))
+
+
+def add_impulses(iq, every=1777, burst=3):
+    """deterministic full-scale bursts (golden inputs): samples n*every .. +burst of every channel"""
+    out = iq.copy()
+    for c in range(iq.shape[0]):
+        for pos in range(3000 + 97 * c, iq.shape[1] - burst, every):
+            out[c, pos:pos + burst, 0] = 30000 if (pos // every) % 2 else -30000
+            out[c, pos:pos + burst, 1] = -30000 if (pos // every) % 3 else 30000
+    return out
+
+
+def apply_setup(chain, setup, oracle=False):
+    """engine setters that are not part of the config struct, on an OracleChain or a GPU Chain"""
+    if not setup:
+        return
+    if "noise_blanker_db" in setup:
+        if oracle:
+            chain.set_noise_blanker(True, setup["noise_blanker_db"])
+        else:
+            chain.enableNoiseBlanker()
+            chain.setNoiseBlankerThresholdDb(setup["noise_blanker_db"])
+    if setup.get("swap_iq"):
+        chain.set_swap_iq(True) if oracle else chain.swapIQ(True)
+
+
 # feed-forward chains: the north-star tolerance (normwise, per channel)
 TOL = 1e-5

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import oracle_lib  # noqa: E402
-from cases import GOLDEN_CASES  # noqa: E402
+from cases import GOLDEN_CASES, add_impulses, apply_setup  # noqa: E402
 from radiodsp_sdr_rx_amd.chain import synth_iq  # noqa: E402
 
 
@@ -23,9 +23,12 @@ def main():
     oracle_lib.build()
     for name, case in GOLDEN_CASES.items():
         iq = synth_iq(case["channels"], case["blocks"] * 128, cw=case.get("cw", False))
+        if case.get("impulses"):
+            iq = add_impulses(iq)
         o16, o32 = [], []
         for c in range(case["channels"]):
             ch = oracle_lib.OracleChain(**case["cfg"])
+            apply_setup(ch, case.get("setup"), oracle=True)
             a, b = ch.process(iq[c])
             o16.append(a)
             o32.append(b)

@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4, TOL
+from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4, TOL, apply_setup
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -33,13 +33,14 @@ def torch_cuda():
     return torch
 
 
-def gpu_run(torch, iq, cfg, calls=1, tail=None):
+def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None):
     """tail: None (default kernel) or "16m" / "8m": the matrix-pipe tail kernels (rdsp_tailm.hip)"""
     from radiodsp_sdr_rx_amd.chain import Chain
     nch, n = iq.shape[0], iq.shape[1]
     ch = Chain(nch, max_blocks_per_call=n // 128 // calls, **cfg)
     if tail:
         ch.set_tail_variant(int(tail.rstrip("m")), tail.endswith("m"))
+    apply_setup(ch, setup)
     o16, o32 = [], []
     step = n // calls
     for k in range(calls):
@@ -174,9 +175,11 @@ def test_spectral_threshold_flip_is_the_only_discontinuity(rdsp, oracle, torch_c
 def test_golden_vectors(rdsp, torch_cuda, name):
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    o16, o32, _ = gpu_run(torch_cuda, g["iq"], case["cfg"])
+    o16, o32, _ = gpu_run(torch_cuda, g["iq"], case["cfg"], setup=case.get("setup"))
     nlms = case["cfg"].get("lms_nr", 0) > 0 or case["cfg"].get("als_mode", "off") != "off"
     tol = 3e-4 if nlms else TOL  # see module docstring for the NLMS bound
+    if case["cfg"].get("demod") == "SAM":
+        tol = 2e-5               # PLL feedback (tests/test_engine_features.py)
     assert normwise(o32, g["out_f32"]) <= tol
     d = np.abs(o16.astype(np.int32) - g["out_i16"].astype(np.int32))
     assert d.max() <= (8 if nlms else 1)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import np_model
-from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4
+from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4, apply_setup
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FS_T4 = 44117.64706  # AUDIO_SAMPLE_RATE_EXACT on Teensy 4
@@ -283,6 +283,8 @@ def test_oracle_reproduces_golden_vectors(oracle, name):
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
     for c in range(case["channels"]):
-        o16, o32 = oracle.OracleChain(**case["cfg"]).process(g["iq"][c])
+        oc = oracle.OracleChain(**case["cfg"])
+        apply_setup(oc, case.get("setup"), oracle=True)
+        o16, o32 = oc.process(g["iq"][c])
         assert np.array_equal(o16, g["out_i16"][c])
         assert np.array_equal(o32, g["out_f32"][c])
