@@ -165,9 +165,15 @@ def cpu_baseline_worker(args):
         dt = time.perf_counter() - t
         best = dt if best is None else min(best, dt)
     val = nch * nblk * 128 / best / 1e6
+    # the same oracle on one thread (case (i)), on a smaller sample
+    n1 = max(1, min(64, nch // cores))
+    t = time.perf_counter()
+    oracle_lib.multi_process(iq[:n1], n_threads=1, lib=lib, **cfg)
+    one = n1 * nblk * 128 / (time.perf_counter() - t) / 1e6
     print(json.dumps({"value": val, "unit": "IQ Msamples/s", "cores": cores, "kind": "port",
                       "sample": f"{nch} channels x {nblk} blocks of 128 IQ samples, config {args.config}, "
-                                f"oracle gcc -O3 -march=native, OpenMP over channels, best of 2"}))
+                                f"oracle gcc -O3 -march=native, OpenMP over channels, best of 2",
+                      "single_thread_value": one, "single_thread_sample": f"{n1} channels x {nblk} blocks"}))
 
 
 def main():
