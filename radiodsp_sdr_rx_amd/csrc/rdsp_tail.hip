@@ -42,6 +42,21 @@ __device__ __forceinline__ float row_shift_in(float xin, float oldest) {
                                                                __builtin_bit_cast(int, oldest), 0x111, 0xF, 0xF, false));
 }
 
+#ifndef RDSP_TAIL_SWZ
+#define RDSP_TAIL_SWZ 0 /* 1: the per-step reduction with ds_swizzle (LDS crossbar) instead of DPP */
+#endif
+/* butterfly partner inside the 16-lane row: DPP (VALU, ~11.6 cycles of issue) or ds_swizzle
+ * (LDS pipe; the add that follows is a plain 3-cycle VALU op) */
+template <int STAGE>
+__device__ __forceinline__ float red_partner(float v) {
+#if RDSP_TAIL_SWZ
+  constexpr int pat = ((1 << STAGE) << 10) | 0x1F; /* bit mode: lane ^ (1 << STAGE) */
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pat));
+#else
+  return STAGE == 0 ? dpp_f<0xB1>(v) : STAGE == 1 ? dpp_f<0x4E>(v) : STAGE == 2 ? dpp_f<0x141>(v) : dpp_f<0x140>(v);
+#endif
+}
+
 constexpr int LPC = 16;                  /* lanes per channel: one DPP row */
 constexpr int TPL = RDSP_LMS_TAPS / LPC; /* taps per lane */
 constexpr int NPH = 8;                   /* physical delay-line ring per lane (> TPL + 1, divides 128) */
@@ -154,21 +169,21 @@ struct Nlms {
         /* slot of step n = s0 + s.  On entry: g = g_{n-1}, w = W_{n-1}, pp = lane part of
          * A_n = W_{n-1}.X_n; ring: X_n[k] at xp[(wp + k) & M], X_{n-1}[k] one further. */
         const int wp = (-s) & M; /* s0 % 16 == 0 and NPH divides 16: compile-time */
-        float r = pp + dpp_f<0xB1>(pp); /* reduction of A_n, stage 1 */
+        float r = pp + red_partner<0>(pp); /* reduction of A_n, stage 1 */
         w[0] = fmaf(g, xp[(wp + 1) & M], w[0]); /* W_n = W_{n-1} + g_{n-1} X_{n-1} */
         w[1] = fmaf(g, xp[(wp + 2) & M], w[1]);
         w[2] = fmaf(g, xp[(wp + 3) & M], w[2]);
-        r += dpp_f<0x4E>(r);
+        r += red_partner<1>(r);
         w[3] = fmaf(g, xp[(wp + 4) & M], w[3]);
         w[4] = fmaf(g, xp[(wp + 5) & M], w[4]);
         w[5] = fmaf(g, xp[(wp + 6) & M], w[5]);
-        r += dpp_f<0x141>(r);
+        r += red_partner<2>(r);
         /* lane part of A_{n+1} = W_n.X_{n+1}; X_{n+1}[k] = X_n[k-1] for k >= 1 */
         float q1 = w[1] * xp[wp];
         float q0 = w[2] * xp[(wp + 1) & M];
         q1 = fmaf(w[3], xp[(wp + 2) & M], q1);
         q0 = fmaf(w[4], xp[(wp + 3) & M], q0);
-        const float A = r + dpp_f<0x140>(r);
+        const float A = r + red_partner<3>(r);
         q1 = fmaf(w[5], xp[(wp + 4) & M], q1);
         float xnew = 0.f;
         if (s < 15 || s0 < RDSP_BLOCK - 16) { /* x_{n+1} exists: shift it in */
