@@ -432,9 +432,16 @@ __global__ void __launch_bounds__(64) rdsp_sam_kernel(RdspSamParams p) {
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      /* rotation for the next sample: phs += fil, with fil from the previous sample */
+      /* the oscillator for the next sample first: phs += fil with fil from the previous
+       * sample, so this rotation does not wait for this sample's detector */
       float sd, cd;
       sam_sincos_small(fil, &sd, &cd);
+      float c1 = cs * cd - sn * sd, s1 = sn * cd + cs * sd;
+      if (k == 3) { /* one Newton step back to |.| = 1, once per quad (drift per rotation ~6e-8) */
+        const float nrm = fmaf(-0.5f, c1 * c1 + s1 * s1, 1.5f);
+        c1 *= nrm;
+        s1 *= nrm;
+      }
       const float corr0 = I[k] * cs + Q[k] * sn;
       const float corr1 = Q[k] * cs - I[k] * sn;
       const float mag2 = corr0 * corr0 + corr1 * corr1;
@@ -442,10 +449,8 @@ __global__ void __launch_bounds__(64) rdsp_sam_kernel(RdspSamParams p) {
       omega = omega + p.g2 * det;
       omega = fminf(fmaxf(omega, p.wmin), p.wmax);
       fil = p.g1 * det + omega;
-      const float c1 = cs * cd - sn * sd, s1 = sn * cd + cs * sd;
-      const float nrm = fmaf(-0.5f, c1 * c1 + s1 * s1, 1.5f); /* one Newton step back to |.| = 1 */
-      cs = c1 * nrm;
-      sn = s1 * nrm;
+      cs = c1;
+      sn = s1;
       dc = dc + (corr0 - dc) * (1.0f / 512.0f);
       o[k] = corr0 - dc;
     }
