@@ -250,6 +250,89 @@ static int mem_sink(void *user, const int16_t *src, size_t stride_pairs, int n_p
   return n_pairs;
 }
 
+/* both arrays page-locked (hipHostMalloc / hipHostRegister / torch pin_memory): the DMA engines
+ * read and write them directly, no staging slots and no host copies */
+static bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+static int stream_pinned(rdsp_chain_t *c, const int16_t *host_iq, size_t in_stride, int64_t n_blocks, int16_t *host_out,
+                         size_t out_stride, int blocks_per_call, rdsp_stream_stats_t *stats) {
+  const int gran = rdsp_chain_granule_blocks(c);
+  if (blocks_per_call <= 0 || blocks_per_call % gran != 0) {
+    rdsp_set_error("blocks_per_call %d is not a multiple of the granule %d", blocks_per_call, gran);
+    return RDSP_ERR_NOT_READY;
+  }
+  const int nch = rdsp_chain_channels(c), decim = rdsp_chain_decim(c);
+  const size_t d_in = (size_t)blocks_per_call * RDSP_BLOCK_SAMPLES, d_out = d_in / (size_t)decim;
+  int rc = RDSP_OK;
+  int16_t *din[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+  hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+  int64_t done = 0, it = 0;
+  const double t_begin = now_s();
+  for (int i = 0; i < 2; i++) {
+    HIP_TRYS(hipMalloc((void **)&din[i], d_in * 4 * (size_t)nch));
+    HIP_TRYS(hipMalloc((void **)&dout[i], d_out * 4 * (size_t)nch));
+    HIP_TRYS(hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming));
+    HIP_TRYS(hipEventCreateWithFlags(&ev_comp[i], hipEventDisableTiming));
+    HIP_TRYS(hipEventCreateWithFlags(&ev_down[i], hipEventDisableTiming));
+  }
+  HIP_TRYS(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+  HIP_TRYS(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+  HIP_TRYS(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+  for (; done < n_blocks; it++) {
+    const int slot = (int)(it & 1);
+    int take = (int)((n_blocks - done) < (int64_t)blocks_per_call ? (n_blocks - done) : (int64_t)blocks_per_call);
+    take -= take % gran;
+    if (take <= 0) break;
+    const size_t pin = (size_t)take * RDSP_BLOCK_SAMPLES, pout = pin / (size_t)decim;
+    if (it >= 2) HIP_TRYS(hipStreamWaitEvent(s_up, ev_comp[slot], 0)); /* din[slot] consumed */
+    HIP_TRYS(hipMemcpy2DAsync(din[slot], d_in * 4, host_iq + (size_t)done * RDSP_BLOCK_SAMPLES * 2, in_stride * 4, pin * 4,
+                              (size_t)nch, hipMemcpyHostToDevice, s_up));
+    HIP_TRYS(hipEventRecord(ev_up[slot], s_up));
+    HIP_TRYS(hipStreamWaitEvent(s_comp, ev_up[slot], 0));
+    if (it >= 2) HIP_TRYS(hipStreamWaitEvent(s_comp, ev_down[slot], 0)); /* dout[slot] drained */
+    rc = rdsp_chain_process(c, din[slot], d_in, take, dout[slot], d_out, nullptr, s_comp);
+    if (rc != RDSP_OK) goto done;
+    HIP_TRYS(hipEventRecord(ev_comp[slot], s_comp));
+    HIP_TRYS(hipStreamWaitEvent(s_down, ev_comp[slot], 0));
+    rc = rdsp_chain_flush(c, s_down);
+    if (rc != RDSP_OK) goto done;
+    HIP_TRYS(hipMemcpy2DAsync(host_out + (size_t)done * RDSP_BLOCK_SAMPLES / (size_t)decim * 2, out_stride * 4, dout[slot],
+                              d_out * 4, pout * 4, (size_t)nch, hipMemcpyDeviceToHost, s_down));
+    HIP_TRYS(hipEventRecord(ev_down[slot], s_down));
+    done += take;
+  }
+done:
+  if (s_up) (void)hipStreamSynchronize(s_up);
+  if (s_comp) (void)hipStreamSynchronize(s_comp);
+  if (s_down) (void)hipStreamSynchronize(s_down);
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->blocks = done;
+    stats->samples_in = done * RDSP_BLOCK_SAMPLES;
+    stats->samples_out = done * RDSP_BLOCK_SAMPLES / decim;
+    stats->seconds = now_s() - t_begin;
+  }
+  for (int i = 0; i < 2; i++) {
+    if (din[i]) (void)hipFree(din[i]);
+    if (dout[i]) (void)hipFree(dout[i]);
+    if (ev_up[i]) (void)hipEventDestroy(ev_up[i]);
+    if (ev_comp[i]) (void)hipEventDestroy(ev_comp[i]);
+    if (ev_down[i]) (void)hipEventDestroy(ev_down[i]);
+  }
+  if (s_up) (void)hipStreamDestroy(s_up);
+  if (s_comp) (void)hipStreamDestroy(s_comp);
+  if (s_down) (void)hipStreamDestroy(s_down);
+  return rc;
+}
+
 extern "C" int rdsp_stream_run_memory(rdsp_chain_t *c, const int16_t *host_iq, size_t in_stride_pairs,
                                       int64_t n_blocks, int16_t *host_out, size_t out_stride_pairs,
                                       int blocks_per_call, rdsp_stream_stats_t *stats) {
@@ -260,6 +343,8 @@ extern "C" int rdsp_stream_run_memory(rdsp_chain_t *c, const int16_t *host_iq, s
     rdsp_set_error("rdsp_stream_run_memory: strides too small");
     return RDSP_ERR_INVALID;
   }
+  if (is_pinned_host(host_iq) && is_pinned_host(host_out))
+    return stream_pinned(c, host_iq, in_stride_pairs, n_blocks, host_out, out_stride_pairs, blocks_per_call, stats);
   MemEnds m = {host_iq, in_stride_pairs, n_blocks, 0, host_out, out_stride_pairs, 0, rdsp_chain_channels(c)};
   return rdsp_stream_run(c, mem_source, &m, mem_sink, &m, blocks_per_call, n_blocks, stats);
 }

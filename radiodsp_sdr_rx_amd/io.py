@@ -87,17 +87,25 @@ def stream_files(chain, readers, writers, blocks_per_call, max_blocks=0):
 
 
 def stream_memory(chain, iq, blocks_per_call, out=None):
-    """rdsp_stream_run_memory: host int16 [n_channels, n_samples, 2] -> host int16 [n_channels, n_samples/decim, 2]."""
+    """rdsp_stream_run_memory: host int16 [n_channels, n_samples, 2] -> host int16 [n_channels, n_samples/decim, 2].
+    numpy arrays go through pinned staging slots; pinned torch tensors (pin_memory=True) at both
+    ends are used by the DMA engines directly."""
     lib = _lib.load()
-    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    is_torch = hasattr(iq, "data_ptr")
+    if not is_torch:
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
     nch, n, _ = iq.shape
     assert nch == chain.n_channels and n % 128 == 0
     decim = int(lib.rdsp_chain_decim(chain.h))
     if out is None:
-        out = np.zeros((nch, n // decim, 2), np.int16)
+        if is_torch:
+            import torch
+            out = torch.zeros((nch, n // decim, 2), dtype=torch.int16, pin_memory=iq.is_pinned())
+        else:
+            out = np.zeros((nch, n // decim, 2), np.int16)
+    ptr = (lambda a: C.cast(a.data_ptr(), _lib._i16p)) if is_torch else (lambda a: a.ctypes.data_as(_lib._i16p))
     st = _lib.StreamStats()
-    _lib.check(lib.rdsp_stream_run_memory(chain.h, iq.ctypes.data_as(_lib._i16p), n, n // 128,
-                                          out.ctypes.data_as(_lib._i16p), out.shape[1], int(blocks_per_call),
+    _lib.check(lib.rdsp_stream_run_memory(chain.h, ptr(iq), n, n // 128, ptr(out), out.shape[1], int(blocks_per_call),
                                           C.byref(st)))
     return out, _stats(st)
 

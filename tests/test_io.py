@@ -164,6 +164,10 @@ def test_memory_runner_and_callbacks(rdsp, torch_cuda):
     out, st = stream_memory(Chain(nch, max_blocks_per_call=per, **K1), iq, per)
     ref = Chain(nch, max_blocks_per_call=nblk, **K1).process(torch.from_numpy(iq).cuda()).cpu().numpy()
     assert st["blocks"] == nblk and np.array_equal(out, ref)
+    # page-locked arrays at both ends: the zero-copy path (DMA straight from / to the user's memory)
+    pin = torch.from_numpy(iq).pin_memory()
+    out_p, st = stream_memory(Chain(nch, max_blocks_per_call=per, **K1), pin, per)
+    assert st["blocks"] == nblk and out_p.is_pinned() and np.array_equal(out_p.numpy(), ref)
     # generic callbacks: a source that dries up mid-batch (5 of 8 blocks: not a granule -> dropped)
     state = {"pos": 0}
     chunks = []
