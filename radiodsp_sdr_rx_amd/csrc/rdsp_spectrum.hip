@@ -29,6 +29,11 @@ struct RdspSpecParams {
   int have_prev; /* 0: the very first block only primes prevblock (FFTIQ.cpp:73-77) */
   int count0;    /* `count` at entry (FFTIQ.h:105) */
   int naverage;
+  /* x / naverage without the ~30-instruction 32-bit division (4 per frame and lane):
+   * power of two -> shift; else q = (((x - t) >> 1) + t) >> div_shift, t = mulhi(div_magic, x)
+   * (round-up method with the 33-bit multiplier folded into the add; exact for every uint32) */
+  uint32_t div_magic;
+  int div_shift, div_pow2;
   int use_window;
   const int16_t *window;  /* [256] q15 */
   const uint32_t *twid;   /* [256] wr | wi << 16, W_256^m */
@@ -157,7 +162,13 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
     for (int k = 0; k < 4; k++) {
       int r = lo16(x[k]), q = hi16(x[k]);
       uint32_t magsq = (uint32_t)(__mul24(r, r) + __mul24(q, q));
-      uint32_t term = magsq / (uint32_t)p.naverage;
+      uint32_t term; /* magsq / naverage, FFTIQ.cpp:90 */
+      if (p.div_pow2) {
+        term = magsq >> p.div_shift;
+      } else {
+        const uint32_t tq = __umulhi(p.div_magic, magsq);
+        term = (((magsq - tq) >> 1) + tq) >> p.div_shift;
+      }
       sum[k] = (count == 0) ? term : sum[k] + term;
     }
     if (++count == p.naverage) { /* FFTIQ.cpp:99-113 */
@@ -309,6 +320,21 @@ extern "C" int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, siz
   p.have_prev = s->have_prev;
   p.count0 = s->count;
   p.naverage = s->naverage;
+  {
+    const uint32_t d = (uint32_t)s->naverage;
+    int fl = 0;
+    while ((2u << fl) <= d) fl++; /* floor(log2 d) */
+    p.div_shift = fl;
+    p.div_pow2 = (d & (d - 1)) == 0;
+    p.div_magic = 0;
+    if (!p.div_pow2) {
+      const unsigned long long n = 1ull << (32 + fl);
+      unsigned long long m = n / d, rem = n - m * d;
+      m += m;
+      if (rem + rem >= d) m += 1;
+      p.div_magic = (uint32_t)(m + 1); /* low 32 bits of the 33-bit multiplier */
+    }
+  }
   p.use_window = s->window_id != 0;
   p.window = s->d_window;
   p.twid = s->d_twid;
