@@ -241,11 +241,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("RDSP_PRIO"):  # A/B runs: "front_fir_prio,tail_prio"
+        fpr, tpr = (int(x) for x in os.environ["RDSP_PRIO"].split(","))
+        assert chain.lib.rdsp_chain_set_priorities(chain.h, fpr, tpr) == 0
     if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 packed-FMA FIR, 1 matrix FIR
         chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]
-        chain.set_tail_variant(int(v.rstrip("m")), v.endswith("m"))
+        chain.set_tail_variant(16, 2) if v == "16r" else chain.set_tail_variant(int(v.rstrip("m")), int(v.endswith("m")))
     if os.environ.get("RDSP_FRONT_VARIANT"):  # A/B runs: force the full (0) or lean (1) front kernel
         chain.set_front_variant(int(os.environ["RDSP_FRONT_VARIANT"]))
     for _ in range(args.warmup):

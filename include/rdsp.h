@@ -217,11 +217,15 @@ int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
  * so both kernels fit one SIMD), 0 full-register, 1 lean */
 int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean);
 
+/* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
+int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
 /* decimating FIR variant: 0 packed FMAs (default), 1 matrix-core GEMM slices (opt-in,
  * +10 % at K2), -1 matrix unless the tail stage shares the SIMDs */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix);
-/* tail-kernel variant: lanes per channel 16 or 8; matrix_reduce = the
- * cross-lane sums run on the matrix pipe (required for 8 lanes) */
+/* tail-kernel variant: lanes per channel 16 or 8; matrix_reduce 0: DPP
+ * reduction with the delay line shifted by DPP (rdsp_tail.hip), 2: DPP reduction with the delay
+ * line fed from LDS (rdsp_tailm.hip row layout; the default), 1: cross-lane sums on the matrix
+ * pipe (required for 8 lanes) */
 int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce);
 
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/

@@ -144,6 +144,7 @@ SYMBOLS = [
     ("rdsp_spectrum_node_status", _i, [_vp]),
     ("rdsp_chain_set_tail_variant", _i, [_vp, _i, _i]),
     ("rdsp_chain_set_fir_variant", _i, [_vp, _i]),
+    ("rdsp_chain_set_priorities", _i, [_vp, _i, _i]),
     ("rdsp_chain_set_groups", _i, [_vp, _i, C.POINTER(C.c_uint16)]),
     ("rdsp_chain_groups", _i, [_vp]),
     ("rdsp_group_reInitializeFilter", _i, [_vp, _i, _d, _d, _vp]),

@@ -176,7 +176,7 @@ class Chain:
     def set_tail_variant(self, lanes_per_channel, matrix_reduce=None):
         if matrix_reduce is None:
             matrix_reduce = lanes_per_channel == 8
-        _lib.check(self.lib.rdsp_chain_set_tail_variant(self.h, int(lanes_per_channel), int(bool(matrix_reduce))))
+        _lib.check(self.lib.rdsp_chain_set_tail_variant(self.h, int(lanes_per_channel), int(matrix_reduce)))
 
     def flush(self, stream=None):
         _lib.check(self.lib.rdsp_chain_flush(self.h, _stream_ptr(stream)))

@@ -102,7 +102,11 @@ struct rdsp_chain {
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
   int fir_mode = 0;   /* 0 packed-FMA FIR (default: the north-star path has no MFMA), 1 matrix FIR, -1 matrix unless the tail shares the SIMDs */
-  int tail_lpc = 16;  /* tail kernel: 16 = 16 lanes/channel, DPP reduction; 116 / 108 = 16 / 8 lanes, matrix-pipe reduction */
+  int front_fir_prio = 2, tail_prio = 1; /* wave priorities while both kernels share the SIMDs (measured balance) */
+  /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
+   * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
+   * with the reduction on the matrix pipe */
+  int tail_lpc = 100;
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
   int nb_on = 0;              /* SDR.enableNoiseBlanker, BK_INO:1259 */
@@ -567,7 +571,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   hipStream_t tstream = piped ? c->s_tail : stream;
   /* the lean variant leaves registers and LDS for the concurrent tail kernel */
   fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
-  fp.front_prio = piped ? 1 : 0;
+  fp.front_prio = piped ? c->front_fir_prio : 0;
   fp.fir_matrix = (c->fir_mode < 0) ? (piped ? 0 : 1) : c->fir_mode;
   fp.mid_q = c->d_mid_q;
   if (piped) {
@@ -637,6 +641,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.agc_decay = decay;
     tp.out_gain = og;
     tp.st_scal = c->d_scal;
+    tp.prio = piped ? c->tail_prio : 0;
     tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
@@ -956,6 +961,15 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   c->lean_mode = lean;
   return RDSP_OK;
 }
+/* wave priorities (s_setprio 0..3) used while the tail stage shares the SIMDs with the front
+ * stage of the next call: the front kernel's during its FIR, the tail kernel's throughout */
+extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio) {
+  NEED(c);
+  if (front_fir_prio < 0 || front_fir_prio > 3 || tail_prio < 0 || tail_prio > 3) return RDSP_ERR_INVALID;
+  c->front_fir_prio = front_fir_prio;
+  c->tail_prio = tail_prio;
+  return RDSP_OK;
+}
 /* decimating FIR of the front kernel: 0 = packed FMAs (default), 1 = v_mfma GEMM slices,
  * -1 = matrix unless the tail stage runs concurrently (where it loses).  Same taps and
  * products; the sums associate differently (~1e-7).  Opt-in: the north-star defines the path
@@ -973,7 +987,8 @@ extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channe
   NEED(c);
   if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce)) return RDSP_ERR_INVALID;
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
-  c->tail_lpc = lanes_per_channel + (matrix_reduce ? 100 : 0);
+  /* matrix_reduce 2: the row layout of rdsp_tailm.hip (DPP reduction, delay line fed from LDS: the default) */
+  c->tail_lpc = (matrix_reduce == 2) ? 100 : lanes_per_channel + (matrix_reduce ? 100 : 0);
   return RDSP_OK;
 }
 /* `stream` waits for every call issued so far (outputs complete after it) */

@@ -94,6 +94,7 @@ struct RdspTailParams {
   int n_blocks;            /* 128-sample blocks at the decimated rate        */
   int nr_on, als_mode;     /* als_mode: 0 off, 1 notch (e), 2 peak (y)       */
   int nr_mode;             /* 0: 1.1*y (CONV:334), 2: plain y (NR:73)        */
+  int prio;                /* wave priority of the tail kernel (s_setprio), 0..3 */
   float *raw_out;          /* non-null: write the stage output as floats
                               [ch][mid_stride] and skip AGC/gain/pack         */
   float nr_mu, als_mu;

@@ -280,7 +280,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       rdsp_v4f dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
       const int mi = lane & 15, mk = lane >> 4;
       if constexpr (NW == 1) {
-        if (p.front_prio > 0) __builtin_amdgcn_s_setprio(2);
+        if (p.front_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.front_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p.front_prio == 3) __builtin_amdgcn_s_setprio(3);
         fir_matrix<0, 80>(lane, xs, hz, dre, dim);
         if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -312,7 +314,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         /* when a tail-kernel wave shares the SIMD (pipelined mode), the FIR -- the
          * throughput-bound part -- takes issue priority; the rest of the chunk runs at
          * normal priority so the latency-bound tail keeps pace (measured balance) */
-        if (p.front_prio > 0) __builtin_amdgcn_s_setprio(2);
+        if (p.front_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.front_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p.front_prio == 3) __builtin_amdgcn_s_setprio(3);
         fir_lane(lane, 0, 4, xs, taps_lds, acc);
         if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll

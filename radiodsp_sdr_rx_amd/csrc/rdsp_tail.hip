@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
   constexpr int RINGS = DUAL ? 2 : 1;
   constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * SCR;
   __shared__ __attribute__((aligned(16))) float lds[CPW][PER_CH];
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int sub = lane % LPC;
   const int cw = lane / LPC;

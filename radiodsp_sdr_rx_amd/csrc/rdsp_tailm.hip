@@ -31,11 +31,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int SCR = 48; /* per-group scalars: step size, B, energy */
 
+/* COLS = 16 is the third layout: a channel is one DPP row of 16 consecutive lanes and the
+ * reduction is the 4-stage DPP butterfly (no matrix pipe); it shares everything else,
+ * in particular the delay line fed from LDS instead of shifted by DPP */
 template <int COLS>
 struct Geo {
-  static_assert(COLS == 2 || COLS == 4, "a channel owns 2 or 4 columns of the lane grid");
-  static constexpr int LPC = 4 * COLS;               /* lanes per channel */
-  static constexpr int CPW = 16 / COLS;              /* channels per wave */
+  static_assert(COLS == 2 || COLS == 4 || COLS == 16, "2 or 4 columns of the lane grid, or a whole row");
+  static constexpr bool ROW = COLS == 16;
+  static constexpr int LPC = ROW ? 16 : 4 * COLS;    /* lanes per channel */
+  static constexpr int CPW = 64 / LPC;               /* channels per wave */
   static constexpr int TPL = RDSP_LMS_TAPS / LPC;    /* taps per lane: 12 or 6 */
   static constexpr int NPH = (TPL == 12) ? 16 : 8;   /* physical delay-line ring (>= TPL + 2, divides 128) */
   static constexpr int M = NPH - 1;
@@ -58,9 +62,16 @@ __device__ __forceinline__ float col_prefix(float v, float tri) {
 /* sum over the lanes of a channel, result in all of them */
 template <int COLS>
 __device__ __forceinline__ float chan_sum(float v) {
+  if constexpr (COLS == 16) return row_allsum(v);
   v += dpp_f<0xB1>(v);                          /* quad_perm [1,0,3,2] */
   if constexpr (COLS == 4) v += dpp_f<0x4E>(v); /* quad_perm [2,3,0,1] */
   return col_sum(v);
+}
+/* as dpp_f, lanes whose source falls outside the row read 0 (bound_ctrl) */
+template <int CTRL>
+__device__ __forceinline__ float dpp0_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 /* One NLMS instance of one channel.  Lane `sub` (= COLS*row + column inside the channel)
@@ -110,6 +121,19 @@ struct NlmsM {
                             mu * __builtin_amdgcn_rcpf(e1 + 0.000000119209289f));
       d2[8 + sub] = make_float2(b_base + (ob + ba0), b_base + (ob + ba1));
       d2[16 + sub] = make_float2(e0, e1);
+    } else if constexpr (COLS == 16) {
+      const float *x = cur + s0 + sub;
+      const float xm = x[-1], x0 = x[0], qm = x[-97], q0 = x[-96];
+      float ea = fmaf(x0, x0, -(q0 * q0)); /* E_n - E_{n-1} */
+      float ba = fmaf(x0, xm, -(q0 * qm)); /* B_n - B_{n-1} */
+      ea += dpp0_f<0x111>(ea); ba += dpp0_f<0x111>(ba); /* inclusive scans over the row: row_shr 1, 2, 4, 8 */
+      ea += dpp0_f<0x112>(ea); ba += dpp0_f<0x112>(ba);
+      ea += dpp0_f<0x114>(ea); ba += dpp0_f<0x114>(ba);
+      ea += dpp0_f<0x118>(ea); ba += dpp0_f<0x118>(ba);
+      const float en = e_base + ea;
+      dst[sub] = mu * __builtin_amdgcn_rcpf(en + 0.000000119209289f);
+      dst[16 + sub] = b_base + ba;
+      dst[32 + sub] = en;
     } else {
       const float *x = cur + s0 + sub;
       const float xm = x[-1], x0 = x[0], qm = x[-97], q0 = x[-96];
@@ -224,10 +248,13 @@ __global__ void __launch_bounds__(64) rdsp_tailm_kernel(RdspTailParams p) {
   /* +4: consecutive channels start four LDS banks apart */
   constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * SCR + 4;
   __shared__ __attribute__((aligned(16))) float lds[CPW][PER_CH];
+  if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int row = lane >> 4, col = lane & 15;
-  const int cw = col / COLS, ci = col % COLS;
-  const int sub = COLS * row + ci;
+  const int cw = G::ROW ? row : col / COLS, ci = G::ROW ? col : col % COLS;
+  const int sub = G::ROW ? col : COLS * row + ci;
   const float tri = (row <= (col >> 2)) ? 1.0f : 0.0f;
   size_t ch = (size_t)blockIdx.x * CPW + cw;
   const bool valid = ch < (size_t)p.n_channels;
@@ -396,9 +423,10 @@ int launch_m(const RdspTailParams *p, hipStream_t stream) {
 
 }  // namespace
 
-/* lanes_per_channel: 16 or 8 */
+/* lanes_per_channel: 16 or 8 with the matrix-pipe reduction; 0: the row layout (16 lanes, DPP reduction) */
 extern "C" int rdsp_launch_tail_matrix(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
   if (lanes_per_channel == 16) return launch_m<4>(p, stream);
   if (lanes_per_channel == 8) return launch_m<2>(p, stream);
+  if (lanes_per_channel == 0) return launch_m<16>(p, stream);
   return (int)hipErrorInvalidValue;
 }
