@@ -7,7 +7,7 @@
  * rdsp_tail.hip five of them per step (4-stage reduction + delay-line shift) are half of
  * its issue time -- time the front kernel of the next call wants, since both kernels share
  * the SIMDs in pipelined mode and the pair is VALU-bound (profiles/r01_k3_pmc_summary.txt:
- * VALU busy 80 % in the front kernel, 67 % in the tail).  Here the 64 lanes of a wave are
+ * VALU busy 76 % in the front kernel, 54-67 % in the tail).  Here the 64 lanes of a wave are
  * a 4 x 16 grid (lane = 16 row + col) and a channel owns COLS adjacent columns:
  *   * COLS = 4: 16 lanes and 6 taps per lane, 4 channels per wave (as rdsp_tail.hip);
  *     COLS = 2: 8 lanes and 12 taps per lane, 8 channels per wave, half the waves;
