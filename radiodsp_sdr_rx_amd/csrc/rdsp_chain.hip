@@ -87,13 +87,16 @@ struct rdsp_chain {
   float *d_mid = nullptr;
   size_t mid_stride = 0;
   /* SAM groups: quadrature part of the base band (double-buffered like d_mid), PLL state */
-  float *d_mid_q = nullptr, *d_mid_q2 = nullptr, *d_sam = nullptr;
+  float *d_mid_q[3] = {nullptr, nullptr, nullptr}, *d_sam = nullptr;
   /* pipelined mode: the serial tail stage of call k runs on an internal stream,
    * concurrently with the front stage of call k+1 (double-buffered intermediate) */
   int pipe_on = 0;
   hipStream_t s_tail = nullptr;
-  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_misc = nullptr;
-  float *d_mid2 = nullptr;
+  /* three intermediate buffers: the front stage may run two calls ahead of the tail stage, so
+   * neither stream waits on the other in steady state (with two, every call paid two
+   * cross-stream event waits, ~0.1 ms of a 2 ms step) */
+  hipEvent_t ev_front[3] = {nullptr, nullptr, nullptr}, ev_tail[3] = {nullptr, nullptr, nullptr}, ev_misc = nullptr;
+  float *d_midx[2] = {nullptr, nullptr}; /* slots 1 and 2 (slot 0 is d_mid) */
   long call_idx = 0;
   /* optional per-kernel HIP-event timing (bench.py roofline leg) */
   int timing_on = 0;
@@ -361,7 +364,7 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_mid_q, c->d_mid_q2, c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
@@ -376,9 +379,10 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (c->s_tail) {
     (void)hipStreamSynchronize(c->s_tail);
     (void)hipStreamDestroy(c->s_tail);
-    for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->ev_front[i]); (void)hipEventDestroy(c->ev_tail[i]); }
+    for (int i = 0; i < 3; i++) { (void)hipEventDestroy(c->ev_front[i]); (void)hipEventDestroy(c->ev_tail[i]); }
     (void)hipEventDestroy(c->ev_misc);
-    (void)hipFree(c->d_mid2);
+    (void)hipFree(c->d_midx[0]);
+    (void)hipFree(c->d_midx[1]);
   }
   delete c;
 }
@@ -522,8 +526,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   for (const auto &g : c->groups) sam = sam || (g.demod == RDSP_DEMOD_SAM);
   if (sam && !c->d_sam) {
     const size_t nch_ = (size_t)c->n_channels, mid_bytes = sizeof(float) * c->mid_stride * nch_;
-    HIP_TRY(hipMalloc((void **)&c->d_mid_q, mid_bytes));
-    HIP_TRY(hipMalloc((void **)&c->d_mid_q2, mid_bytes));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipMalloc((void **)&c->d_mid_q[i], mid_bytes));
     HIP_TRY(hipMalloc((void **)&c->d_sam, sizeof(float) * 4 * nch_));
     HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch_));
   }
@@ -567,18 +570,18 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   const bool timed = c->timing_on && 4 * (c->ev_used + 1) <= c->ev.size();
   const bool piped = tail && c->pipe_on;
-  const int slot = (int)(c->call_idx & 1);
+  const int slot = (int)(c->call_idx % 3);
   hipStream_t tstream = piped ? c->s_tail : stream;
   /* the lean variant leaves registers and LDS for the concurrent tail kernel */
   fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
   fp.front_prio = piped ? c->front_fir_prio : 0;
   fp.fir_matrix = (c->fir_mode < 0) ? (piped ? 0 : 1) : c->fir_mode;
-  fp.mid_q = c->d_mid_q;
+  fp.mid_q = c->d_mid_q[0];
   if (piped) {
-    fp.mid = slot ? c->d_mid2 : c->d_mid;
-    fp.mid_q = slot ? c->d_mid_q2 : c->d_mid_q;
+    fp.mid = slot ? c->d_midx[slot - 1] : c->d_mid;
+    fp.mid_q = c->d_mid_q[slot];
     /* the tail of call k-2 read this intermediate buffer: wait for it */
-    if (c->call_idx >= 2) HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[slot], 0));
+    if (c->call_idx >= 3) HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[slot], 0));
   }
   if (timed) { /* events come from a pool created in rdsp_chain_set_timing */
     ev0 = c->ev[4 * c->ev_used];
@@ -941,12 +944,13 @@ extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
   if (on && !c->s_tail) {
     HIP_TRY(hipStreamCreateWithFlags(&c->s_tail, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
       HIP_TRY(hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_misc, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&c->d_mid2, sizeof(float) * c->mid_stride * (size_t)c->n_channels));
+    for (int i = 0; i < 2; i++)
+      HIP_TRY(hipMalloc((void **)&c->d_midx[i], sizeof(float) * c->mid_stride * (size_t)c->n_channels));
   }
   c->pipe_on = on ? 1 : 0;
   c->call_idx = 0;
@@ -996,7 +1000,7 @@ extern "C" int rdsp_chain_flush(rdsp_chain_t *c, void *stream) {
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   if (c->pipe_on && c->call_idx > 0) {
-    const int last = (int)((c->call_idx - 1) & 1);
+    const int last = (int)((c->call_idx - 1) % 3);
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ev_tail[last], 0));
   }
   return RDSP_OK;
