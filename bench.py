@@ -32,8 +32,8 @@ FP32_PEAK_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="K3", choices=["K2", "K3", "K4", "K5", "F1"])
     ap.add_argument("--channels-per-gpu", type=int, default=0)
     ap.add_argument("--blocks", type=int, default=512, help="128-sample input blocks per channel per step")

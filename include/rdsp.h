@@ -213,8 +213,8 @@ uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, double vfo_
  * rdsp_chain_flush(c, stream) on the consuming stream. */
 int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on);
 int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
-/* front-kernel variant: -1 auto (register-lean when the tail stage runs concurrently,
- * so both kernels fit one SIMD), 0 full-register, 1 lean */
+/* front-kernel variant: -1 auto (full-register), 0 full-register, 1 lean (FFT twiddles
+ * rebuilt per pass from one base each: 24 fewer VGPRs, ~3 % slower) */
 int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */

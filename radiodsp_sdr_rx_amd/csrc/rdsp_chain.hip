@@ -103,9 +103,9 @@ struct rdsp_chain {
   std::vector<hipEvent_t> ev; /* pool, groups of 4: front begin/end, tail begin/end */
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
-  int lean_mode = -1; /* -1 auto, 0 full-register front kernel, 1 lean */
+  int lean_mode = -1; /* -1 auto (= full), 0 full-register front kernel, 1 lean */
   int fir_mode = 0;   /* 0 packed-FMA FIR (default: the north-star path has no MFMA), 1 matrix FIR, -1 matrix unless the tail shares the SIMDs */
-  int front_fir_prio = 2, tail_prio = 1; /* wave priorities while both kernels share the SIMDs (measured balance) */
+  int front_fir_prio = 2, tail_prio = 2; /* wave priorities while both kernels share the SIMDs (measured balance) */
   /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
    * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
    * with the reduction on the matrix pipe */
@@ -572,8 +572,9 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   const bool piped = tail && c->pipe_on;
   const int slot = (int)(c->call_idx % 3);
   hipStream_t tstream = piped ? c->s_tail : stream;
-  /* the lean variant leaves registers and LDS for the concurrent tail kernel */
-  fp.lean = (c->lean_mode < 0) ? (piped ? 1 : 0) : c->lean_mode;
+  /* full-register front kernel in both modes: since its butterflies shrank to 199 VGPRs two of
+   * its waves and a tail wave fit one SIMD, and the lean variant's twiddle chains only cost */
+  fp.lean = (c->lean_mode < 0) ? 0 : c->lean_mode;
   fp.front_prio = piped ? c->front_fir_prio : 0;
   fp.fir_matrix = (c->fir_mode < 0) ? (piped ? 0 : 1) : c->fir_mode;
   fp.mid_q = c->d_mid_q[0];
@@ -956,8 +957,8 @@ extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   c->call_idx = 0;
   return RDSP_OK;
 }
-/* front-kernel variant: -1 = auto (lean when the tail stage runs concurrently),
- * 0 = full-register, 1 = lean.  Both compute the same chain; they differ in the
+/* front-kernel variant: -1 = auto (full-register; measured faster with and without the
+ * concurrent tail stage), 0 = full-register, 1 = lean (FFT twiddles rebuilt per pass).  Both compute the same chain; they differ in the
  * rounding of the FFT twiddles (power chain vs direct), ~3e-7. */
 extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   NEED(c);

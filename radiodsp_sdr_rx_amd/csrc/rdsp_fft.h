@@ -93,9 +93,58 @@ RDSP_HD void dft2(float2 &a, float2 &b) {
   b = csub(t, b);
 }
 
+#ifdef __HIP_DEVICE_COMPILE__
+/* Device butterflies on native <2 x float> values: every complex add is one
+ * v_pk_add_f32, and the rotations by -i/+i and by w8^1, w8^3 are folded into the
+ * op_sel / neg modifiers of the add that consumes them, written out by hand --
+ * left to the SLP vectoriser the scalar formulas pair real parts of different
+ * values and glue the halves back together with v_mov (59 of the 260 instructions
+ * of a 512-point forward transform). */
+namespace pk {
+typedef rdsp_v2f V;
+RDSP_HD V ld(float2 a) { return V{a.x, a.y}; }
+RDSP_HD float2 st(V a) { return make_float2(a.x, a.y); }
+/* a + r*b with r = -i (forward) or +i (INV); add_rot<!INV> is a - r*b */
+template <bool INV>
+RDSP_HD V add_rot(V a, V b) {
+  V r;
+  if constexpr (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+/* sqrt(2) * a * w8^1: (x + y, y - x) forward, (x - y, x + y) inverse */
+template <bool INV>
+RDSP_HD V rot8_1(V a) { return add_rot<INV>(a, a); }
+/* sqrt(2) * a * w8^3: (y - x, -x - y) forward, (-x - y, x - y) inverse */
+template <bool INV>
+RDSP_HD V rot8_3(V a) {
+  V r;
+  if constexpr (INV) asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(a));
+  else asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+template <bool INV>
+RDSP_HD void dft4(V &a0, V &a1, V &a2, V &a3) {
+  const V t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = add_rot<INV>(t1, t3);
+  a3 = add_rot<!INV>(t1, t3);
+}
+} // namespace pk
+#endif
+
 /* 4-point DFT, natural order in and out, on v[0], v[ST], v[2ST], v[3ST] */
 template <bool INV, int ST>
 RDSP_HD void dft4(float2 *v) {
+#ifdef __HIP_DEVICE_COMPILE__
+  pk::V a0 = pk::ld(v[0]), a1 = pk::ld(v[ST]), a2 = pk::ld(v[2 * ST]), a3 = pk::ld(v[3 * ST]);
+  pk::dft4<INV>(a0, a1, a2, a3);
+  v[0] = pk::st(a0);
+  v[ST] = pk::st(a1);
+  v[2 * ST] = pk::st(a2);
+  v[3 * ST] = pk::st(a3);
+#else
   float2 t0 = cadd(v[0], v[2 * ST]);
   float2 t1 = csub(v[0], v[2 * ST]);
   float2 t2 = cadd(v[ST], v[3 * ST]);
@@ -105,6 +154,7 @@ RDSP_HD void dft4(float2 *v) {
   v[2 * ST] = csub(t0, t2);
   v[ST] = cadd(t1, t3r);
   v[3 * ST] = csub(t1, t3r);
+#endif
 }
 
 template <int R, bool INV>
@@ -124,6 +174,23 @@ template <bool INV>
 struct Dft<8, INV> {
   /* n = n1 + 2*n2, k = 4*k1 + k2 */
   static RDSP_HD void run(float2 *v) {
+#ifdef __HIP_DEVICE_COMPILE__
+    using pk::V;
+    V x0 = pk::ld(v[0]), x1 = pk::ld(v[1]), x2 = pk::ld(v[2]), x3 = pk::ld(v[3]);
+    V x4 = pk::ld(v[4]), x5 = pk::ld(v[5]), x6 = pk::ld(v[6]), x7 = pk::ld(v[7]);
+    pk::dft4<INV>(x0, x2, x4, x6); /* A[k2] at x(2 k2)     */
+    pk::dft4<INV>(x1, x3, x5, x7); /* B[k2] at x(2 k2 + 1) */
+    const V b1 = pk::rot8_1<INV>(x3), b3 = pk::rot8_3<INV>(x7);
+    const V c2 = {0.70710678118654752f, 0.70710678118654752f};
+    v[0] = pk::st(x0 + x1);
+    v[4] = pk::st(x0 - x1);
+    v[1] = pk::st(x2 + b1 * c2);
+    v[5] = pk::st(x2 - b1 * c2);
+    v[2] = pk::st(pk::add_rot<INV>(x4, x5));
+    v[6] = pk::st(pk::add_rot<!INV>(x4, x5));
+    v[3] = pk::st(x6 + b3 * c2);
+    v[7] = pk::st(x6 - b3 * c2);
+#else
     dft4<INV, 2>(v);     /* n1 = 0: elements 0,2,4,6 -> A[0][k2] at 2*k2   */
     dft4<INV, 2>(v + 1); /* n1 = 1: elements 1,3,5,7 -> A[1][k2] at 1+2*k2 */
     v[3] = mul_w16<2, INV>(v[3]); /* w8^1 */
@@ -137,6 +204,7 @@ struct Dft<8, INV> {
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = o[i];
+#endif
   }
 };
 

@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   }
 
   float nfloor = p.st_scal[ch * 4 + 0];
+  const float vad_inv = 1.0f / (float)(p.vad_hi - p.vad_lo); /* SPEC:200, once per launch */
   float agc_g = p.st_scal[ch * 4 + 1];
   float am_dc = p.st_scal[ch * 4 + 2];
   float nb_level = p.st_scal[ch * 4 + 3];
@@ -371,13 +372,15 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       fwd_pass_last<N, P>(lb, v, wb);
 
       if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
-        float mag[P];
+        float mag[P], rmag[P];
         float part = 0.f;
 #pragma unroll
         for (int e = 0; e < P; e++) {
-          /* v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded sequences: 16 of those
-           * per frame were ~6 % of the kernel's instructions */
-          mag[e] = __builtin_amdgcn_sqrtf(v[e].x * v[e].x + v[e].y * v[e].y); /* SPEC:182 */
+          /* |X| and 1/|X| from one v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt and a
+           * division per bin; the floor keeps rsq finite on empty bins, where |X| = 0 * r = 0 */
+          const float pw = v[e].x * v[e].x + v[e].y * v[e].y;
+          rmag[e] = __builtin_amdgcn_rsqf(fmaxf(pw, 1e-30f));
+          mag[e] = pw * rmag[e];                              /* SPEC:182 */
           part += ((vadbits >> e) & 1u) ? mag[e] : 0.f;       /* SPEC:194-197 */
         }
         float tot = wave_sum(part);
@@ -387,15 +390,15 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
           tot = (red[0] + red[1]) + (red[2] + red[3]);
           __syncthreads();
         }
-        float th = tot / (float)(p.vad_hi - p.vad_lo); /* SPEC:200 */
+        float th = tot * vad_inv;                      /* SPEC:200 */
         th = th * p.spectral_k;                        /* SPEC:202 */
         nfloor += (th - nfloor) * 0.65f;               /* SPEC:205 */
         nfloor = nfloor > 0.f ? nfloor : 0.f;          /* SPEC:206 */
 #pragma unroll
         for (int e = 0; e < P; e++) {
-          float m0 = mag[e];
-          float m1 = (m0 <= nfloor) ? m0 * 0.2f : m0 - nfloor; /* SPEC:213-217 */
-          float sc = (m0 > 0.f) ? m1 * __builtin_amdgcn_rcpf(m0) : 0.f; /* SPEC:226-235 */
+          /* SPEC:213-217, 226-235: X * mag'/mag with mag' = 0.2 mag at or under the floor and
+           * mag - floor above it, i.e. a gain of 0.2 or 1 - floor/mag (an empty bin stays 0) */
+          const float sc = (mag[e] <= nfloor) ? 0.2f : fmaf(-nfloor, rmag[e], 1.f);
           v[e].x *= sc;
           v[e].y *= sc;
         }

@@ -292,7 +292,7 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
     parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
              for k in range(calls)]
     ref_chain = Chain(nch, max_blocks_per_call=nblk, **K3)
-    ref_chain.set_front_variant(1)  # pipelined mode picks the register-lean front kernel
+    ref_chain.set_front_variant(0)  # pipelined mode runs the full-register front kernel
     ref_chain.set_fir_variant(0)    # ... with the packed-FMA FIR
     ref = [ref_chain.process(p).cpu().numpy() for p in parts]
     ch = Chain(nch, max_blocks_per_call=nblk, **K3)

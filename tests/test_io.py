@@ -137,7 +137,7 @@ def test_files_through_the_runner_match_resident_processing_and_oracle(rdsp, ora
     # the same samples resident in HBM, one call per batch of `per` blocks + the tail batch
     ref_chain = Chain(nch, max_blocks_per_call=per, **cfg)
     if pipelined:
-        ref_chain.set_front_variant(1)   # pipelined mode runs the register-lean front kernel
+        ref_chain.set_front_variant(0)   # pipelined mode runs the full-register front kernel
         ref_chain.set_fir_variant(0)     # with the packed-FMA FIR
     parts, pos = [], 0
     while pos < exp_blocks:
