@@ -45,6 +45,19 @@ RDSP_HD float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 #endif
 }
+/* cmul with a wave-uniform second factor kept in scalar registers (one SGPR pair per packed
+ * instruction is within the constant-bus limit); same arithmetic as cmul() */
+RDSP_HD float2 cmul_uniform(float2 a, float2 b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
+  rdsp_v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "s"(bv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(av), "s"(bv), "v"(t));
+  return make_float2(r.x, r.y);
+#else
+  return cmul(a, b);
+#endif
+}
 RDSP_HD float2 cmulc(float2 a, float2 b) { /* a * conj(b) */
 #ifdef __HIP_DEVICE_COMPILE__
   const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};

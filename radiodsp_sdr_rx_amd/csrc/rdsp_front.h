@@ -141,11 +141,13 @@ RDSP_HD float2 nco_phasor_alu(uint32_t ph) {
   return make_float2(fmaf(-sn, r, cs), -fmaf(cs, r, sn));
 }
 
-/* complex product with the contraction written out: the mixer's phasors must come
- * out bit-identical wherever they are recomputed (FIR history at the start of a call) */
-RDSP_HD float2 cmul_pinned(float2 a, float2 b) {
-  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
-}
+/* the mixer's complex product: its phasors must come out bit-identical wherever they are
+ * recomputed (FIR history at the start of a call).  cmul() is two hand-placed packed
+ * instructions on the device, re = fma(a.x, b.x, -(a.y b.y)), im = fma(a.x, b.y, a.y b.x),
+ * so no compiler contraction choice can differ between the two places. */
+RDSP_HD float2 cmul_pinned(float2 a, float2 b) { return cmul(a, b); }
+/* ... with b a field of the group record (wave-uniform) */
+RDSP_HD float2 cmul_pinned_u(float2 a, float2 b) { return cmul_uniform(a, b); }
 
 /* arm_float_to_q15 semantics (CONV:346-347): x*32768, truncate, saturate */
 RDSP_HD int q15_of_float(float x) {

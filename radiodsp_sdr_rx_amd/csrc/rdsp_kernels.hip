@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       if (G.dphi_hist != 0u) {
         if constexpr (LP == 4) {
           ph0 = nco_phasor_alu((p.n0 - (uint32_t)CH_IN + 4u * (uint32_t)i) * G.dphi_hist);
-          ph0 = cmul_pinned(ph0, G.rothp3);
+          ph0 = cmul_pinned_u(ph0, G.rothp3);
         } else {
           ph0 = nco_phasor_alu((p.n0 - 256u + 4u * (uint32_t)i) * G.dphi_hist);
         }
@@ -179,8 +179,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         float2 x = unpack_iq(w[k], p.scale_i, p.scale_q);
-        if (G.dphi_hist != 0u) { /* the history keeps the mixing it went through when it was new */
-          float2 ph = (k == 0) ? ph0 : cmul_pinned(ph0, k == 1 ? G.roth1 : (k == 2 ? G.roth2 : G.roth3));
+        { /* the history keeps the mixing it went through when it was new (identity phasors when
+           * the NCO was off: roth* are (1, -0) then and the products are exact) */
+          float2 ph = (k == 0) ? ph0 : cmul_pinned_u(ph0, k == 1 ? G.roth1 : (k == 2 ? G.roth2 : G.roth3));
           x = cmul_pinned(x, ph);
         }
         xs[FM ? xl_pos(-256 + 4 * i + k) : xs_pos(-256 + 4 * i + k)] = x;
@@ -223,26 +224,36 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
           for (int j = 0; j < 4; j++) w[j] = __builtin_amdgcn_alignbit(w[j], w[j], 16);
         }
         float2 ph0 = ph_base;
-        if (k > 0 && G.dphi != 0u) ph0 = cmul_pinned(ph_base, k == 1 ? G.rotp1 : (k == 2 ? G.rotp2 : G.rotp3));
+        if (k > 0) ph0 = cmul_pinned_u(ph_base, k == 1 ? G.rotp1 : (k == 2 ? G.rotp2 : G.rotp3));
         bool blanked[4] = {false, false, false, false};
+        /* the four phasors first, then the four products: independent chains the scheduler can
+         * interleave (each complex product is a dependent pair of packed instructions).
+         * NCO off: the record's rotations are (1, -0) and every product is exact, so the
+         * multiplies stay unconditional (a select per sample cost more than they do). */
+        float2 ph[4], x[4];
+        ph[0] = ph0;
+        ph[1] = cmul_pinned_u(ph0, G.rot1);
+        ph[2] = cmul_pinned_u(ph0, G.rot2);
+        ph[3] = cmul_pinned_u(ph0, G.rot3);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          float2 x = unpack_iq(w[j], p.scale_i, p.scale_q);
+          x[j] = unpack_iq(w[j], p.scale_i, p.scale_q);
           if (NB_ON) {
-            const float pw = x.x * x.x + x.y * x.y;
+            const float pw = x[j].x * x[j].x + x[j].y * x[j].y;
             blanked[j] = nb_level > 0.f && pw > nb_t;
-            x = blanked[j] ? make_float2(0.f, 0.f) : x;
+            x[j] = blanked[j] ? make_float2(0.f, 0.f) : x[j];
             nb_acc += blanked[j] ? 0.f : pw;
           }
-          if (G.dphi != 0u) {
-            float2 ph = (j == 0) ? ph0 : cmul_pinned(ph0, j == 1 ? G.rot1 : (j == 2 ? G.rot2 : G.rot3));
-            x = cmul_pinned(x, ph);
-          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = cmul_pinned(x[j], ph[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
           if constexpr (DECIM == 4) {
-            xs[FM ? xl_pos(4 * idx + j) : xs_pos(4 * idx + j)] = x;
+            xs[FM ? xl_pos(4 * idx + j) : xs_pos(4 * idx + j)] = x[j];
           } else {
             int m = 4 * idx + j; /* no decimator: the sample is the "output" */
-            hb[(chunk % CPF) * CH_OUT + m] = x;
+            hb[(chunk % CPF) * CH_OUT + m] = x[j];
           }
         }
         if (NB_ON) { /* a blanked sample stays blanked when it becomes FIR history */
