@@ -28,6 +28,7 @@ using namespace rdsp;
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int SCR = 48; /* per-group scalars: step size, B, energy */
 
@@ -80,23 +81,42 @@ template <int COLS>
 struct NlmsM {
   using G = Geo<COLS>;
   static constexpr int TPL = G::TPL, NPH = G::NPH, M = G::M, NA = G::NA;
-  float w[TPL];
-  float xp[NPH];
+  /* Taps and delay line as <2 x float> values so that the update and the dot product are
+   * packed instructions (TPL/2 each instead of TPL; every VALU instruction costs a wave the
+   * same 4 cycles).  w2[k] = (w[2k], w[2k+1]).  A step needs pairs of ring neighbours that
+   * start at an even or an odd slot depending on the step's parity, and a packed operand
+   * must be an aligned register pair, so the ring exists twice: xe[k] = (x[2k], x[2k+1]) and
+   * xo[k] = (x[2k+1], x[2k+2]) (slots mod NPH).  The second copy costs no VALU work: the
+   * lane's next sample is one more LDS read. */
+  static_assert(TPL % 2 == 0 && NPH % 2 == 0, "taps pair up");
+  v2f w2[TPL / 2];
+  v2f xe[NPH / 2], xo[NPH / 2];
   float energy;
+
+  /* the ring neighbours (x[i], x[i+1]); i is a compile-time constant wherever this is used */
+  __device__ __forceinline__ v2f pair_at(int i) const {
+    const int r = i & M;
+    return (r & 1) ? xo[r >> 1] : xe[r >> 1];
+  }
+  __device__ __forceinline__ void put(int i, float v) {
+    const int r = i & M, j = (i - 1) & M;
+    xe[r >> 1][r & 1] = v;
+    xo[j >> 1][j & 1] = v;
+  }
 
   __device__ __forceinline__ void load(const float *wst, const float *prev, const float *est, size_t ch, int sub) {
 #pragma unroll
-    for (int t = 0; t < TPL; t++) w[t] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))];
+    for (int t = 0; t < TPL; t++) w2[t >> 1][t & 1] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))];
 #pragma unroll
-    for (int t = 0; t < NPH; t++) xp[t] = 0.f;
+    for (int t = 0; t < NPH; t++) put(t, 0.f);
     /* before step s the in-lane tap t sits at physical ((-s) + 1 + t) & M */
 #pragma unroll
-    for (int t = 0; t < TPL; t++) xp[(t + 1) & M] = prev[ch * RDSP_BLOCK + (127 - (TPL * sub + t))];
+    for (int t = 0; t < TPL; t++) put(t + 1, prev[ch * RDSP_BLOCK + (127 - (TPL * sub + t))]);
     energy = est[ch];
   }
   __device__ __forceinline__ void store(float *wst, float *est, size_t ch, int sub) {
 #pragma unroll
-    for (int t = 0; t < TPL; t++) wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))] = w[t];
+    for (int t = 0; t < TPL; t++) wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))] = w2[t >> 1][t & 1];
     if (sub == 0) est[ch] = energy;
   }
 
@@ -171,14 +191,13 @@ struct NlmsM {
     float e_base = energy;
     prepare(cur, 0, sub, ci, tri, mu, e_base, b_base, scr);
     /* prologue: pp = lane part of A_0 = W_0.X_0 */
-    xp[0] = mine[0];
+    put(0, mine[0]);
     float pp;
     {
-      float q[NA];
+      v2f q = w2[0] * pair_at(0);
 #pragma unroll
-      for (int t = 0; t < TPL; t++) q[t % NA] = (t < NA) ? w[t] * xp[t] : fmaf(w[t], xp[t], q[t % NA]);
+      for (int k = 1; k < TPL / 2; k++) q = __builtin_elementwise_fma(w2[k], pair_at(2 * k), q);
       pp = q[0] + q[1];
-      if constexpr (NA == 3) pp += q[2];
     }
     float g = 0.f;
 #pragma unroll 1
@@ -213,35 +232,38 @@ struct NlmsM {
           const float A = chan_sum<COLS>(pp); /* needed only after the update below */
           const bool more = s < 15 || s0 < RDSP_BLOCK - 16; /* x_{n+1} exists */
           const float xnew = more ? mine[s0 + s + 1] : 0.f;
+          const v2f gg = {g, g};
 #pragma unroll
-          for (int t = 0; t < TPL; t++) w[t] = fmaf(g, xp[(wp + t + 1) & M], w[t]); /* W_n */
-          /* lane part of A_{n+1} = W_n.X_{n+1}; X_{n+1}[t] = X_n[t-1] for t >= 1 */
-          float acc[NA];
+          for (int k = 0; k < TPL / 2; k++) w2[k] = __builtin_elementwise_fma(gg, pair_at(wp + 2 * k + 1), w2[k]); /* W_n */
+          /* lane part of A_{n+1} = W_n.X_{n+1}; X_{n+1}[t] = X_n[t-1] for t >= 1 and X_{n+1}[0] =
+           * x_{n+1}, which goes to the slot below X_n[0] (after step 127 nothing reads that slot
+           * before the next block's first sample replaces it).  The pair that holds the new
+           * sample comes last: its LDS read has the other products to land behind. */
+          v2f acc = w2[1] * pair_at(wp + 1);
 #pragma unroll
-          for (int t = 1; t < TPL; t++) {
-            const int a = (t - 1) % NA;
-            acc[a] = (t - 1 < NA) ? w[t] * xp[(wp + t - 1) & M] : fmaf(w[t], xp[(wp + t - 1) & M], acc[a]);
-          }
+          for (int k = 2; k < TPL / 2; k++) acc = __builtin_elementwise_fma(w2[k], pair_at(wp + 2 * k - 1), acc);
           const float y = fmaf(g, bn[u], A);
           const float e = dd[u] - y;
-          if (more) xp[(wp + NPH - 1) & M] = xnew;
-          acc[(TPL - 1) % NA] = fmaf(w[0], xnew, acc[(TPL - 1) % NA]);
+          put(wp + NPH - 1, xnew);
+          acc = __builtin_elementwise_fma(w2[0], pair_at(wp - 1), acc);
           pp = acc[0] + acc[1];
-          if constexpr (NA == 3) pp += acc[2];
           g = e * gi[u];
           out[s0 + s] = OUT_E ? e : y; /* every lane of the channel holds the same value */
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    {
+      const v2f gg = {g, g};
 #pragma unroll
-    for (int t = 0; t < TPL; t++) w[t] = fmaf(g, xp[(1 + t) & M], w[t]); /* the pending update of step 127 */
+      for (int k = 0; k < TPL / 2; k++) w2[k] = __builtin_elementwise_fma(gg, pair_at(1 + 2 * k), w2[k]); /* the pending update of step 127 */
+    }
     energy = e_base;
   }
 };
 
 template <int COLS, bool DUAL>
-__global__ void __launch_bounds__(64) rdsp_tailm_kernel(RdspTailParams p) {
+__device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   using G = Geo<COLS>;
   constexpr int CPW = G::CPW, SPL = G::SPL;
   constexpr int RINGS = DUAL ? 2 : 1;
@@ -413,10 +435,23 @@ __global__ void __launch_bounds__(64) rdsp_tailm_kernel(RdspTailParams p) {
   }
 }
 
+template <int COLS, bool DUAL>
+__global__ void __launch_bounds__(64) rdsp_tailm_kernel(RdspTailParams p) { tailm_body<COLS, DUAL>(p); }
+
+/* The default (row layout, one NLMS instance) with its registers capped at 112: in pipelined
+ * mode it shares a SIMD's 512 VGPRs with two waves of the front kernel (2 x 200), and a tail
+ * wave that does not fit waits for a front wave to retire (measured: 1.8 -> 2.4 ms per K3
+ * step at 122 registers).  amdgpu_num_vgpr counts half of the unified file on gfx950; the
+ * cap costs three dwords of scratch outside the step loop. */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(56))) rdsp_tailm_row1_kernel(RdspTailParams p) {
+  tailm_body<16, false>(p);
+}
+
 template <int COLS>
 int launch_m(const RdspTailParams *p, hipStream_t stream) {
   const int grid = (p->n_channels + Geo<COLS>::CPW - 1) / Geo<COLS>::CPW;
   if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tailm_kernel<COLS, true>), dim3(grid), dim3(64), 0, stream, *p);
+  else if constexpr (COLS == 16) hipLaunchKernelGGL(rdsp_tailm_row1_kernel, dim3(grid), dim3(64), 0, stream, *p);
   else hipLaunchKernelGGL((rdsp_tailm_kernel<COLS, false>), dim3(grid), dim3(64), 0, stream, *p);
   return (int)hipGetLastError();
 }

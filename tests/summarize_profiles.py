@@ -22,7 +22,7 @@ def newest(pattern):
 
 
 def short(name):
-    if "rdsp_tailm_kernel" in name:   # the default tail kernel (rdsp_tailm.hip), reported under the stage's name
+    if "rdsp_tailm" in name:   # the default tail kernel (rdsp_tailm.hip), reported under the stage's name
         return "rdsp_tail_kernel"
     for k in ("rdsp_front_kernel", "rdsp_tail_kernel", "rdsp_sam_kernel", "rdsp_spectrum_kernel", "rdsp_group_store_kernel"):
         if k in name:
