@@ -248,7 +248,10 @@ def main():
         chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]
-        chain.set_tail_variant(16, 2) if v == "16r" else chain.set_tail_variant(int(v.rstrip("m")), int(v.endswith("m")))
+        if v.endswith("r"):   # row layouts: "16r", "8r"
+            chain.set_tail_variant(int(v[:-1]), 2)
+        else:
+            chain.set_tail_variant(int(v.rstrip("m")), int(v.endswith("m")))
     if os.environ.get("RDSP_FRONT_VARIANT"):  # A/B runs: force the full (0) or lean (1) front kernel
         chain.set_front_variant(int(os.environ["RDSP_FRONT_VARIANT"]))
     for _ in range(args.warmup):

@@ -992,8 +992,9 @@ extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channe
   NEED(c);
   if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce)) return RDSP_ERR_INVALID;
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
-  /* matrix_reduce 2: the row layout of rdsp_tailm.hip (DPP reduction, delay line fed from LDS: the default) */
-  c->tail_lpc = (matrix_reduce == 2) ? 100 : lanes_per_channel + (matrix_reduce ? 100 : 0);
+  /* matrix_reduce 2: the row layouts of rdsp_tailm.hip (DPP reduction, delay line fed from LDS):
+   * a whole DPP row of 16 lanes per channel, or half a row */
+  c->tail_lpc = (matrix_reduce == 2) ? (lanes_per_channel == 8 ? 101 : 100) : lanes_per_channel + (matrix_reduce ? 100 : 0);
   return RDSP_OK;
 }
 /* `stream` waits for every call issued so far (outputs complete after it) */

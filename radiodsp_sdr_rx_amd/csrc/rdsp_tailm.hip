@@ -34,18 +34,21 @@ constexpr int SCR = 48; /* per-group scalars: step size, B, energy */
 
 /* COLS = 16 is the third layout: a channel is one DPP row of 16 consecutive lanes and the
  * reduction is the 4-stage DPP butterfly (no matrix pipe); it shares everything else,
- * in particular the delay line fed from LDS instead of shifted by DPP */
+ * in particular the delay line fed from LDS instead of shifted by DPP.  COLS = 8 is the same
+ * with half a row per channel: 12 taps per lane, 3 DPP stages, 8 channels per wave, i.e. half
+ * the waves and 40 % fewer issue cycles per channel and step, which is what the front kernel
+ * of the next call competes for. */
 template <int COLS>
 struct Geo {
-  static_assert(COLS == 2 || COLS == 4 || COLS == 16, "2 or 4 columns of the lane grid, or a whole row");
-  static constexpr bool ROW = COLS == 16;
-  static constexpr int LPC = ROW ? 16 : 4 * COLS;    /* lanes per channel */
+  static_assert(COLS == 2 || COLS == 4 || COLS == 16 || COLS == 8, "2 or 4 columns of the lane grid, a whole row, or half a row");
+  static constexpr bool ROW = COLS == 16 || COLS == 8; /* a channel is COLS consecutive lanes */
+  static constexpr int LPC = ROW ? COLS : 4 * COLS;    /* lanes per channel */
   static constexpr int CPW = 64 / LPC;               /* channels per wave */
   static constexpr int TPL = RDSP_LMS_TAPS / LPC;    /* taps per lane: 12 or 6 */
   static constexpr int NPH = (TPL == 12) ? 16 : 8;   /* physical delay-line ring (>= TPL + 2, divides 128) */
   static constexpr int M = NPH - 1;
   static constexpr int SPL = RDSP_BLOCK / LPC;       /* samples per lane per block */
-  static constexpr int NA = (TPL == 12) ? 3 : 2;     /* accumulators of the dot product */
+  static constexpr int NAC = (TPL == 12) ? 2 : 1;    /* packed accumulator chains of the dot product */
 };
 
 /* sum over the four rows of a column: lanes j, j+16, j+32, j+48 -> every one of them */
@@ -65,6 +68,10 @@ template <int COLS>
 __device__ __forceinline__ float chan_sum(float v) {
   if constexpr (COLS == 16) return row_allsum(v);
   v += dpp_f<0xB1>(v);                          /* quad_perm [1,0,3,2] */
+  if constexpr (COLS == 8) {
+    v += dpp_f<0x4E>(v);                        /* quad_perm [2,3,0,1] */
+    return v + dpp_f<0x141>(v);                 /* row_half_mirror */
+  }
   if constexpr (COLS == 4) v += dpp_f<0x4E>(v); /* quad_perm [2,3,0,1] */
   return col_sum(v);
 }
@@ -80,7 +87,7 @@ __device__ __forceinline__ float dpp0_f(float v) {
 template <int COLS>
 struct NlmsM {
   using G = Geo<COLS>;
-  static constexpr int TPL = G::TPL, NPH = G::NPH, M = G::M, NA = G::NA;
+  static constexpr int TPL = G::TPL, NPH = G::NPH, M = G::M, NAC = G::NAC;
   /* Taps and delay line as <2 x float> values so that the update and the dot product are
    * packed instructions (TPL/2 each instead of TPL; every VALU instruction costs a wave the
    * same 4 cycles).  w2[k] = (w[2k], w[2k+1]).  A step needs pairs of ring neighbours that
@@ -98,10 +105,13 @@ struct NlmsM {
     const int r = i & M;
     return (r & 1) ? xo[r >> 1] : xe[r >> 1];
   }
-  __device__ __forceinline__ void put(int i, float v) {
+  __device__ __forceinline__ void put(int i, float v) { put(i, v, v); }
+  /* ve and vo are the same sample read twice from LDS: a second read is LDS-pipe work, a copy
+   * between the two rings would be one more VALU instruction per step */
+  __device__ __forceinline__ void put(int i, float ve, float vo) {
     const int r = i & M, j = (i - 1) & M;
-    xe[r >> 1][r & 1] = v;
-    xo[j >> 1][j & 1] = v;
+    xe[r >> 1][r & 1] = ve;
+    xo[j >> 1][j & 1] = vo;
   }
 
   __device__ __forceinline__ void load(const float *wst, const float *prev, const float *est, size_t ch, int sub) {
@@ -135,6 +145,25 @@ struct NlmsM {
       const float se = ea1 + dpp_f<0xB1>(ea1), sb = ba1 + dpp_f<0xB1>(ba1);
       const float pe = col_prefix(se, tri), pb = col_prefix(sb, tri);
       const float oe = pe - (ci ? ea1 : se), ob = pb - (ci ? ba1 : sb);
+      const float e0 = e_base + (oe + ea0), e1 = e_base + (oe + ea1);
+      float2 *d2 = reinterpret_cast<float2 *>(dst);
+      d2[sub] = make_float2(mu * __builtin_amdgcn_rcpf(e0 + 0.000000119209289f),
+                            mu * __builtin_amdgcn_rcpf(e1 + 0.000000119209289f));
+      d2[8 + sub] = make_float2(b_base + (ob + ba0), b_base + (ob + ba1));
+      d2[16 + sub] = make_float2(e0, e1);
+    } else if constexpr (COLS == 8) {
+      /* two consecutive steps per lane; inclusive scan of the lane totals over the half row
+       * (row_shr 1, 2, 4; a lane takes nothing from the neighbouring channel) */
+      const float *x = cur + s0 + 2 * sub;
+      const float xm = x[-1], x0 = x[0], x1 = x[1];
+      const float qm = x[-97], q0 = x[-96], q1 = x[-95];
+      const float ea0 = fmaf(x0, x0, -(q0 * q0)), ea1 = ea0 + fmaf(x1, x1, -(q1 * q1));
+      const float ba0 = fmaf(x0, xm, -(q0 * qm)), ba1 = ba0 + fmaf(x1, x0, -(q1 * q0));
+      float ie = ea1, ib = ba1;
+      { const float te = dpp0_f<0x111>(ie), tb = dpp0_f<0x111>(ib); ie += (ci >= 1) ? te : 0.f; ib += (ci >= 1) ? tb : 0.f; }
+      { const float te = dpp0_f<0x112>(ie), tb = dpp0_f<0x112>(ib); ie += (ci >= 2) ? te : 0.f; ib += (ci >= 2) ? tb : 0.f; }
+      { const float te = dpp0_f<0x114>(ie), tb = dpp0_f<0x114>(ib); ie += (ci >= 4) ? te : 0.f; ib += (ci >= 4) ? tb : 0.f; }
+      const float oe = ie - ea1, ob = ib - ba1; /* the lanes before this one */
       const float e0 = e_base + (oe + ea0), e1 = e_base + (oe + ea1);
       float2 *d2 = reinterpret_cast<float2 *>(dst);
       d2[sub] = make_float2(mu * __builtin_amdgcn_rcpf(e0 + 0.000000119209289f),
@@ -200,6 +229,12 @@ struct NlmsM {
       pp = q[0] + q[1];
     }
     float g = 0.f;
+    /* x_{n+1} of the step about to run, read from LDS a whole step before its use -- twice, through
+     * an offset the compiler cannot see through, so that each ring copy gets its own load */
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    const float *mine_b = mine + zero;
+    float xn = mine[1], xnb = mine_b[1];
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += 16) {
       const float *sc = scr + ((s0 >> 4) & 1) * SCR;
@@ -230,8 +265,12 @@ struct NlmsM {
            * A_n = W_{n-1}.X_n; ring: X_n[t] at xp[(wp + t) & M], X_{n-1}[t] one further. */
           const int wp = (-s) & M;
           const float A = chan_sum<COLS>(pp); /* needed only after the update below */
-          const bool more = s < 15 || s0 < RDSP_BLOCK - 16; /* x_{n+1} exists */
-          const float xnew = more ? mine[s0 + s + 1] : 0.f;
+          /* the lane's next-but-one sample: the read is issued a step ahead, so its LDS latency
+           * is not part of the recursion (it was: ~60 cycles of every step) */
+          const bool more2 = s < 14 || s0 < RDSP_BLOCK - 16; /* x_{n+2} exists */
+          const float xn2 = more2 ? mine[s0 + s + 2] : 0.f;
+          const float xn2b = more2 ? mine_b[s0 + s + 2] : 0.f;
+          const float xnew = xn; /* 0 after the last sample of the block */
           const v2f gg = {g, g};
 #pragma unroll
           for (int k = 0; k < TPL / 2; k++) w2[k] = __builtin_elementwise_fma(gg, pair_at(wp + 2 * k + 1), w2[k]); /* W_n */
@@ -239,14 +278,21 @@ struct NlmsM {
            * x_{n+1}, which goes to the slot below X_n[0] (after step 127 nothing reads that slot
            * before the next block's first sample replaces it).  The pair that holds the new
            * sample comes last: its LDS read has the other products to land behind. */
-          v2f acc = w2[1] * pair_at(wp + 1);
+          v2f acc[NAC];
 #pragma unroll
-          for (int k = 2; k < TPL / 2; k++) acc = __builtin_elementwise_fma(w2[k], pair_at(wp + 2 * k - 1), acc);
+          for (int k = 1; k < TPL / 2; k++) {
+            const int a = (k - 1) % NAC;
+            acc[a] = (k - 1 < NAC) ? w2[k] * pair_at(wp + 2 * k - 1)
+                                   : __builtin_elementwise_fma(w2[k], pair_at(wp + 2 * k - 1), acc[a]);
+          }
           const float y = fmaf(g, bn[u], A);
           const float e = dd[u] - y;
-          put(wp + NPH - 1, xnew);
-          acc = __builtin_elementwise_fma(w2[0], pair_at(wp - 1), acc);
-          pp = acc[0] + acc[1];
+          put(wp + NPH - 1, xnew, xnb);
+          xn = xn2;
+          xnb = xn2b;
+          acc[NAC - 1] = __builtin_elementwise_fma(w2[0], pair_at(wp - 1), acc[NAC - 1]);
+          if constexpr (NAC == 2) acc[0] += acc[1];
+          pp = acc[0][0] + acc[0][1];
           g = e * gi[u];
           out[s0 + s] = OUT_E ? e : y; /* every lane of the channel holds the same value */
         }
@@ -275,8 +321,8 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int row = lane >> 4, col = lane & 15;
-  const int cw = G::ROW ? row : col / COLS, ci = G::ROW ? col : col % COLS;
-  const int sub = G::ROW ? col : COLS * row + ci;
+  const int cw = G::ROW ? lane / G::LPC : col / COLS, ci = G::ROW ? lane % G::LPC : col % COLS;
+  const int sub = G::ROW ? ci : COLS * row + ci;
   const float tri = (row <= (col >> 2)) ? 1.0f : 0.0f;
   size_t ch = (size_t)blockIdx.x * CPW + cw;
   const bool valid = ch < (size_t)p.n_channels;
@@ -458,10 +504,12 @@ int launch_m(const RdspTailParams *p, hipStream_t stream) {
 
 }  // namespace
 
-/* lanes_per_channel: 16 or 8 with the matrix-pipe reduction; 0: the row layout (16 lanes, DPP reduction) */
+/* lanes_per_channel: 16 or 8 with the matrix-pipe reduction; 0: the row layout (16 lanes, DPP
+ * reduction); 1: the half-row layout (8 lanes, DPP reduction) */
 extern "C" int rdsp_launch_tail_matrix(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream) {
   if (lanes_per_channel == 16) return launch_m<4>(p, stream);
   if (lanes_per_channel == 8) return launch_m<2>(p, stream);
   if (lanes_per_channel == 0) return launch_m<16>(p, stream);
+  if (lanes_per_channel == 1) return launch_m<8>(p, stream); /* half-row layout */
   return (int)hipErrorInvalidValue;
 }

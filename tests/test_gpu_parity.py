@@ -38,8 +38,8 @@ def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None):
     from radiodsp_sdr_rx_amd.chain import Chain
     nch, n = iq.shape[0], iq.shape[1]
     ch = Chain(nch, max_blocks_per_call=n // 128 // calls, **cfg)
-    if tail == "16r":   # row layout of rdsp_tailm.hip (the default): DPP reduction, delay line fed from LDS
-        ch.set_tail_variant(16, 2)
+    if tail in ("16r", "8r"):   # row layouts of rdsp_tailm.hip (16r = the default): DPP reduction, delay line fed from LDS
+        ch.set_tail_variant(int(tail[:-1]), 2)
     elif tail:          # "16": rdsp_tail.hip; "16m" / "8m": matrix-pipe reduction
         ch.set_tail_variant(int(tail.rstrip("m")), int(tail.endswith("m")))
     apply_setup(ch, setup)
@@ -235,7 +235,7 @@ NLMS_CASES = {
 }
 
 
-@pytest.mark.parametrize("tail", ["16", "16r", "16m", "8m"])
+@pytest.mark.parametrize("tail", ["16", "16r", "8r", "16m", "8m"])
 @pytest.mark.parametrize("name", sorted(NLMS_CASES))
 def test_chain_with_nlms_matches_oracle_within_conditioning(rdsp, oracle, torch_cuda, name, tail):
     """tail "16": DPP reduction (rdsp_tail.hip); "16m", "8m": 16 / 8 lanes per channel with the
@@ -275,7 +275,7 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
     if name == "k3":  # the other tail kernels carry the same state
-        for tail in ("16r", "16m", "8m"):
+        for tail in ("16r", "8r", "16m", "8m"):
             c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail=tail)
             d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail=tail)
             assert np.array_equal(c16, d16) and np.array_equal(c32, d32)
