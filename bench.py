@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events")
+    ap.add_argument("--no-iso", action="store_true",
+                    help="skip the extra un-timed run of the kernels without overlap (profiling runs: keeps the "
+                         "profiler's per-kernel average to the launches of the timed configuration)")
     ap.add_argument("--groups", type=int, default=1,
                     help="receiver groups (SURVEY F2): channel c in group c %% G, every group with its own pass band")
     ap.add_argument("--retune-every", type=int, default=0,
@@ -272,7 +275,7 @@ def main():
     chain.set_timing(False)
     # extra, un-timed: the same kernels back to back without overlap (reference durations)
     iso = None
-    if not args.no_kernel_timing and not args.no_pipeline:
+    if not args.no_kernel_timing and not args.no_pipeline and not args.no_iso:
         chain.set_pipelined(False)
         chain.set_front_variant(-1)
         chain.set_timing(True)
