@@ -298,9 +298,14 @@ def main():
         # dominant kernel of the step and its roofline (bytes per launch / avg launch time)
         front_avg = front_ms / max(calls, 1)
         tail_avg = tail_ms / max(calls, 1)
-        dom = "rdsp_front_kernel" if front_avg >= tail_avg else "rdsp_tail_kernel"
-        dom_ms = max(front_avg, tail_avg)
-        bytes_per_launch = B * nch * n_samples
+        # dominant kernel: the front kernel (it carries the IQ stream: 4 B in + 4/D B out per input
+        # sample, the chain's own figure) unless the tail kernel -- 4 B in + 4 B out per OUTPUT sample --
+        # runs clearly longer; in pipelined mode both run for the whole step, within a few percent
+        if tail_avg > 1.10 * front_avg:
+            dom, dom_ms, B_dom = "rdsp_tail_kernel", tail_avg, 8.0 / decim
+        else:
+            dom, dom_ms, B_dom = "rdsp_front_kernel", front_avg, B
+        bytes_per_launch = B_dom * nch * n_samples
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
