@@ -216,6 +216,11 @@ int rdsp_chain_flush(rdsp_chain_t *c, void *stream);
 /* front-kernel variant: -1 auto (full-register), 0 full-register, 1 lean (FFT twiddles
  * rebuilt per pass from one base each: 24 fewer VGPRs, ~3 % slower) */
 int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean);
+/* pipelined mode launches a call in channel sub-batches of this many channels (multiple of 64,
+ * default 4096, 0 = off) once the chain has at least 1.5 of them: every launch then has the shape
+ * the two kernels share a SIMD at, and the sub-batches of one call overlap each other (8192
+ * channels: -8 % per step).  Outputs do not depend on it, bit for bit. */
+int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);

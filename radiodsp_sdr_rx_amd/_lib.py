@@ -120,6 +120,7 @@ SYMBOLS = [
     ("rdsp_chain_set_pipelined", _i, [_vp, _i]),
     ("rdsp_chain_flush", _i, [_vp, _vp]),
     ("rdsp_chain_set_front_variant", _i, [_vp, _i]),
+    ("rdsp_chain_set_sub_batch", _i, [_vp, _i]),
     ("rdsp_chain_set_timing", _i, [_vp, _i]),
     ("rdsp_chain_get_timing", _i, [_vp, _f64p, _f64p, C.POINTER(C.c_int)]),
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),

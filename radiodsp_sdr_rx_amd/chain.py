@@ -167,6 +167,10 @@ class Chain:
     def set_pipelined(self, on):
         _lib.check(self.lib.rdsp_chain_set_pipelined(self.h, int(bool(on))))
 
+    def set_sub_batch(self, channels):
+        """pipelined mode: channels per launch (multiple of 64, 0 = one launch per stage)"""
+        _lib.check(self.lib.rdsp_chain_set_sub_batch(self.h, int(channels)))
+
     def set_front_variant(self, lean):
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 

@@ -96,6 +96,12 @@ struct rdsp_chain {
    * neither stream waits on the other in steady state (with two, every call paid two
    * cross-stream event waits, ~0.1 ms of a 2 ms step) */
   hipEvent_t ev_front[3] = {nullptr, nullptr, nullptr}, ev_tail[3] = {nullptr, nullptr, nullptr}, ev_misc = nullptr;
+  /* pipelined calls over many channels go out as channel sub-batches: front(A), front(B), ... on the
+   * caller's stream, tail(A), tail(B), ... on the tail stream, tail(A) waiting for front(A) only.
+   * Every launch then has the shape the kernels' co-residency was balanced for (one tail wave and
+   * two front waves per SIMD at 4096 channels), and the halves of one call overlap each other. */
+  int sub_batch = 4096;
+  std::vector<hipEvent_t> ev_front_sb[3]; /* [slot][sub-batch], created on first use */
   float *d_midx[2] = {nullptr, nullptr}; /* slots 1 and 2 (slot 0 is d_mid) */
   long call_idx = 0;
   /* optional per-kernel HIP-event timing (bench.py roofline leg) */
@@ -380,6 +386,7 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
     (void)hipStreamSynchronize(c->s_tail);
     (void)hipStreamDestroy(c->s_tail);
     for (int i = 0; i < 3; i++) { (void)hipEventDestroy(c->ev_front[i]); (void)hipEventDestroy(c->ev_tail[i]); }
+    for (int i = 0; i < 3; i++) for (hipEvent_t ev : c->ev_front_sb[i]) (void)hipEventDestroy(ev);
     (void)hipEventDestroy(c->ev_misc);
     (void)hipFree(c->d_midx[0]);
     (void)hipFree(c->d_midx[1]);
@@ -595,7 +602,24 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     int rc = groups_commit(c, stream);
     if (rc != RDSP_OK) return rc;
   }
-  int e = rdsp_launch_front(c->N, c->decim, &fp, c->n_channels, stream);
+  /* channel sub-batches (see sub_batch): only where the tail runs on its own stream */
+  int nsb = 1, sbn = c->n_channels;
+  if (piped && !sam && c->sub_batch > 0 && c->n_channels >= c->sub_batch + c->sub_batch / 2) {
+    sbn = c->sub_batch;
+    nsb = (c->n_channels + sbn - 1) / sbn;
+    while (c->ev_front_sb[slot].size() < (size_t)nsb) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      c->ev_front_sb[slot].push_back(ev);
+    }
+  }
+  int e = 0;
+  for (int k = 0; k < nsb && e == 0; k++) {
+    fp.ch_base = k * sbn;
+    const int count = (c->n_channels - fp.ch_base < sbn) ? c->n_channels - fp.ch_base : sbn;
+    e = rdsp_launch_front(c->N, c->decim, &fp, count, stream);
+    if (nsb > 1 && e == 0) HIP_TRY(hipEventRecord(c->ev_front_sb[slot][k], stream));
+  }
   if (timed) HIP_TRY(hipEventRecord(ev1, stream));
   HIP_TRY(hipEventRecord(c->ev_fence, stream));
   c->fence_valid = true;
@@ -603,7 +627,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     rdsp_set_error("front kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return RDSP_ERR_HIP;
   }
-  if (piped) {
+  if (piped && nsb == 1) {
     HIP_TRY(hipEventRecord(c->ev_front[slot], stream));
     HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front[slot], 0));
   }
@@ -650,7 +674,12 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
     if (timed) HIP_TRY(hipEventRecord(ev2, tstream));
-    e = rdsp_launch_tail(&tp, c->tail_lpc, tstream);
+    for (int k = 0; k < nsb && e == 0; k++) {
+      tp.ch_base = k * sbn;
+      tp.n_channels = (c->n_channels - tp.ch_base < sbn) ? c->n_channels : tp.ch_base + sbn;
+      if (nsb > 1) HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front_sb[slot][k], 0));
+      e = rdsp_launch_tail(&tp, c->tail_lpc, tstream);
+    }
     if (e != 0) {
       rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
       return RDSP_ERR_HIP;
@@ -964,6 +993,14 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
   NEED(c);
   if (lean < -1 || lean > 1) return RDSP_ERR_INVALID;
   c->lean_mode = lean;
+  return RDSP_OK;
+}
+/* pipelined calls are launched in channel sub-batches of this size (a multiple of 64; 0 = one
+ * launch per stage whatever the channel count).  Results do not depend on it. */
+extern "C" int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels) {
+  NEED(c);
+  if (channels < 0 || channels % 64 != 0) return RDSP_ERR_INVALID;
+  c->sub_batch = channels;
   return RDSP_OK;
 }
 /* wave priorities (s_setprio 0..3) used while the tail stage shares the SIMDs with the front

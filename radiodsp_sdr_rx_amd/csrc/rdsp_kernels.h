@@ -69,6 +69,7 @@ struct RdspFrontParams {
   float *mid;              /* [ch][mid_stride] mono float (to_mid)           */
   float *mid_q;            /* [ch][mid_stride] Im y for SAM channels, else unused */
   size_t mid_stride;
+  int ch_base;             /* first channel of this launch (workgroup b works on ch_base + b) */
 };
 
 /* SAM demodulator (PLL, serial in time): one channel per lane, in place on `mid`
@@ -90,7 +91,8 @@ struct RdspSamParams {
 struct RdspTailParams {
   const float *mid;        /* [ch][mid_stride]                               */
   size_t mid_stride;
-  int n_channels;
+  int n_channels;          /* one past the last channel of this launch       */
+  int ch_base;             /* first channel of this launch                   */
   int n_blocks;            /* 128-sample blocks at the decimated rate        */
   int nr_on, als_mode;     /* als_mode: 0 off, 1 notch (e), 2 peak (y)       */
   int nr_mode;             /* 0: 1.1*y (CONV:334), 2: plain y (NR:73)        */

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const size_t ch = blockIdx.x;
+  const size_t ch = (size_t)p.ch_base + blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
   /* this channel's group record into scalar registers */
   RdspGroup G;

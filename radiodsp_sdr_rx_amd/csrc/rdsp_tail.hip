@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
   const int lane = threadIdx.x;
   const int sub = lane % LPC;
   const int cw = lane / LPC;
-  size_t ch = (size_t)blockIdx.x * CPW + cw;
+  size_t ch = (size_t)p.ch_base + (size_t)blockIdx.x * CPW + cw;
   const bool valid = ch < (size_t)p.n_channels;
   if (!valid) ch = p.n_channels - 1; /* compute on a real channel, store nothing */
 
@@ -481,7 +481,7 @@ extern "C" int rdsp_launch_tail_matrix(const RdspTailParams *p, int lanes_per_ch
 extern "C" int rdsp_launch_tail(const RdspTailParams *p, int variant, hipStream_t stream) {
   if (variant >= 100) return rdsp_launch_tail_matrix(p, variant - 100, stream);
   if (variant != LPC) return (int)hipErrorInvalidValue;
-  const int grid = (p->n_channels + 3) / 4;
+  const int grid = (p->n_channels - p->ch_base + 3) / 4;
   if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tail_kernel<true>), dim3(grid), dim3(64), 0, stream, *p);
   else hipLaunchKernelGGL((rdsp_tail_kernel<false>), dim3(grid), dim3(64), 0, stream, *p);
   return (int)hipGetLastError();

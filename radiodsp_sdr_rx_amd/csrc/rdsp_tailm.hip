@@ -324,7 +324,7 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   const int cw = G::ROW ? lane / G::LPC : col / COLS, ci = G::ROW ? lane % G::LPC : col % COLS;
   const int sub = G::ROW ? ci : COLS * row + ci;
   const float tri = (row <= (col >> 2)) ? 1.0f : 0.0f;
-  size_t ch = (size_t)blockIdx.x * CPW + cw;
+  size_t ch = (size_t)p.ch_base + (size_t)blockIdx.x * CPW + cw;
   const bool valid = ch < (size_t)p.n_channels;
   if (!valid) ch = p.n_channels - 1; /* compute on a real channel, store nothing */
 
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(56))) rdsp_
 
 template <int COLS>
 int launch_m(const RdspTailParams *p, hipStream_t stream) {
-  const int grid = (p->n_channels + Geo<COLS>::CPW - 1) / Geo<COLS>::CPW;
+  const int grid = (p->n_channels - p->ch_base + Geo<COLS>::CPW - 1) / Geo<COLS>::CPW;
   if (p->nr_on && p->als_mode) hipLaunchKernelGGL((rdsp_tailm_kernel<COLS, true>), dim3(grid), dim3(64), 0, stream, *p);
   else if constexpr (COLS == 16) hipLaunchKernelGGL(rdsp_tailm_row1_kernel, dim3(grid), dim3(64), 0, stream, *p);
   else hipLaunchKernelGGL((rdsp_tailm_kernel<COLS, false>), dim3(grid), dim3(64), 0, stream, *p);

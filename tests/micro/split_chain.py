@@ -10,7 +10,7 @@ import torch
 import radiodsp_sdr_rx_amd as R
 from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
 
-nblk, steps, warm = 512, 60, 15
+nblk, steps, warm = 512, 100, 30
 cfg = dict(R.K_CONFIGS["K5"]["cfg"])
 nch = 8192
 small = synth_iq(256, nblk * 128, n_threads=8)
@@ -41,5 +41,5 @@ def run(parts):
     print(f"{parts} chain(s) of {per} channels: {ms:.3f} ms per 8192-channel step", flush=True)
 
 
-for parts in (1, 2, 4, 1, 2):
+for parts in (1, 2, 1, 2, 1, 2):
     run(parts)

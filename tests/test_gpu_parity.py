@@ -308,6 +308,34 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
     assert np.array_equal(ref_chain.lms_coeffs(1), ch.lms_coeffs(1))
 
 
+def test_channel_sub_batches_are_bitwise_identical(rdsp, torch_cuda):
+    """rdsp_chain_set_sub_batch: a pipelined call goes out as launches of `sub` channels each
+    (ragged last one), front and tail of a sub-batch chained by their own event; nothing changes."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, nblk, calls = 200, 16, 4
+    iq = synth_iq(nch, nblk * 128 * calls)
+    parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
+             for k in range(calls)]
+
+    def run(sub):
+        ch = Chain(nch, max_blocks_per_call=nblk, **K3)
+        ch.set_pipelined(True)
+        ch.set_sub_batch(sub)
+        outs = [ch.process(p, want_f32=True) for p in parts]
+        ch.flush()
+        torch.cuda.synchronize()
+        return (np.concatenate([o[0].cpu().numpy() for o in outs], 1),
+                np.concatenate([o[1].cpu().numpy() for o in outs], 1))
+
+    a16, a32 = run(0)
+    for sub in (64, 128):       # 64: four launches (64, 64, 64, 8 channels); 128: two (128, 72)
+        b16, b32 = run(sub)
+        assert np.array_equal(a16, b16) and np.array_equal(a32, b32), sub
+    with pytest.raises(Exception):
+        Chain(4, max_blocks_per_call=8, **K3).set_sub_batch(100)   # not a multiple of 64
+
+
 def test_front_kernel_variants_agree(rdsp, oracle, torch_cuda):
     """The full-register and the register-lean front kernels are the same chain with
     differently rounded FFT twiddles: both meet TOL against the oracle."""
