@@ -507,8 +507,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 #pragma unroll
           for (int b = 0; b < NB; b++) {
             float pp = bs[b] / (float)(2 * RDSP_BLOCK);
-            float rms = sqrtf(pp);
-            float gt = 0.25f / (rms + 1e-6f);
+            float rms = __builtin_amdgcn_sqrtf(pp); /* 1 ulp; the loop gain is a contraction */
+            float gt = 0.25f * __builtin_amdgcn_rcpf(rms + 1e-6f);
             gt = fminf(gt, 100.0f);
             float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
             float gn = agc_g + coef * (gt - agc_g);

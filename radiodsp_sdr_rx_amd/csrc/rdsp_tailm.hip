@@ -431,8 +431,8 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
       for (int k = 0; k < SPL; k++) pw += L[k] * L[k] + L[k] * L[k];
       pw = chan_sum<COLS>(pw);
       float pp = pw / (float)(2 * RDSP_BLOCK);
-      float rms = sqrtf(pp);
-      float gt = fminf(0.25f / (rms + 1e-6f), 100.0f);
+      float rms = __builtin_amdgcn_sqrtf(pp); /* 1 ulp; the loop gain is a contraction */
+      float gt = fminf(0.25f * __builtin_amdgcn_rcpf(rms + 1e-6f), 100.0f);
       float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
       float gn = agc_g + coef * (gt - agc_g);
 #pragma unroll
