@@ -30,7 +30,7 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int SCR = 48; /* per-group scalars: step size, B, energy */
+/* per-group scalars in LDS: step size, B, energy for each of the GS steps of a group */
 
 /* COLS = 16 is the third layout: a channel is one DPP row of 16 consecutive lanes and the
  * reduction is the 4-stage DPP butterfly (no matrix pipe); it shares everything else,
@@ -49,6 +49,11 @@ struct Geo {
   static constexpr int M = NPH - 1;
   static constexpr int SPL = RDSP_BLOCK / LPC;       /* samples per lane per block */
   static constexpr int NAC = (TPL == 12) ? 2 : 1;    /* packed accumulator chains of the dot product */
+  /* steps per group: the lanes of a channel prepare a group's scalars together, GS / LPC
+   * consecutive steps each.  The 16-lane row takes 32: its two prefix scans (8 DPP operations)
+   * then serve 32 steps instead of 16 */
+  static constexpr int GS = (COLS == 16) ? 32 : 16;
+  static constexpr int SCR = 3 * GS;
 };
 
 /* sum over the four rows of a column: lanes j, j+16, j+32, j+48 -> every one of them */
@@ -87,7 +92,7 @@ __device__ __forceinline__ float dpp0_f(float v) {
 template <int COLS>
 struct NlmsM {
   using G = Geo<COLS>;
-  static constexpr int TPL = G::TPL, NPH = G::NPH, M = G::M, NAC = G::NAC;
+  static constexpr int TPL = G::TPL, NPH = G::NPH, M = G::M, NAC = G::NAC, GS = G::GS, SCR = G::SCR;
   /* Taps and delay line as <2 x float> values so that the update and the dot product are
    * packed instructions (TPL/2 each instead of TPL; every VALU instruction costs a wave the
    * same 4 cycles).  w2[k] = (w[2k], w[2k+1]).  A step needs pairs of ring neighbours that
@@ -171,18 +176,25 @@ struct NlmsM {
       d2[8 + sub] = make_float2(b_base + (ob + ba0), b_base + (ob + ba1));
       d2[16 + sub] = make_float2(e0, e1);
     } else if constexpr (COLS == 16) {
-      const float *x = cur + s0 + sub;
-      const float xm = x[-1], x0 = x[0], qm = x[-97], q0 = x[-96];
-      float ea = fmaf(x0, x0, -(q0 * q0)); /* E_n - E_{n-1} */
-      float ba = fmaf(x0, xm, -(q0 * qm)); /* B_n - B_{n-1} */
-      ea += dpp0_f<0x111>(ea); ba += dpp0_f<0x111>(ba); /* inclusive scans over the row: row_shr 1, 2, 4, 8 */
-      ea += dpp0_f<0x112>(ea); ba += dpp0_f<0x112>(ba);
-      ea += dpp0_f<0x114>(ea); ba += dpp0_f<0x114>(ba);
-      ea += dpp0_f<0x118>(ea); ba += dpp0_f<0x118>(ba);
-      const float en = e_base + ea;
-      dst[sub] = mu * __builtin_amdgcn_rcpf(en + 0.000000119209289f);
-      dst[16 + sub] = b_base + ba;
-      dst[32 + sub] = en;
+      /* two consecutive steps per lane (32 per group); inclusive scans of the lane totals over
+       * the row: row_shr 1, 2, 4, 8 with zero fill */
+      const float *x = cur + s0 + 2 * sub;
+      const float xm = x[-1], x0 = x[0], x1 = x[1];
+      const float qm = x[-97], q0 = x[-96], q1 = x[-95];
+      const float ea0 = fmaf(x0, x0, -(q0 * q0)), ea1 = ea0 + fmaf(x1, x1, -(q1 * q1)); /* E_n - E_{n-1}, summed */
+      const float ba0 = fmaf(x0, xm, -(q0 * qm)), ba1 = ba0 + fmaf(x1, x0, -(q1 * q0)); /* B_n - B_{n-1}, summed */
+      float ie = ea1, ib = ba1;
+      ie += dpp0_f<0x111>(ie); ib += dpp0_f<0x111>(ib);
+      ie += dpp0_f<0x112>(ie); ib += dpp0_f<0x112>(ib);
+      ie += dpp0_f<0x114>(ie); ib += dpp0_f<0x114>(ib);
+      ie += dpp0_f<0x118>(ie); ib += dpp0_f<0x118>(ib);
+      const float oe = ie - ea1, ob = ib - ba1; /* the lanes before this one */
+      const float e0 = e_base + (oe + ea0), e1 = e_base + (oe + ea1);
+      float2 *d2 = reinterpret_cast<float2 *>(dst);
+      d2[sub] = make_float2(mu * __builtin_amdgcn_rcpf(e0 + 0.000000119209289f),
+                            mu * __builtin_amdgcn_rcpf(e1 + 0.000000119209289f));
+      d2[GS / 2 + sub] = make_float2(b_base + (ob + ba0), b_base + (ob + ba1));
+      d2[GS + sub] = make_float2(e0, e1);
     } else {
       const float *x = cur + s0 + sub;
       const float xm = x[-1], x0 = x[0], qm = x[-97], q0 = x[-96];
@@ -236,26 +248,26 @@ struct NlmsM {
     const float *mine_b = mine + zero;
     float xn = mine[1], xnb = mine_b[1];
 #pragma unroll 1
-    for (int s0 = 0; s0 < RDSP_BLOCK; s0 += 16) {
-      const float *sc = scr + ((s0 >> 4) & 1) * SCR;
+    for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
+      const float *sc = scr + ((s0 / GS) & 1) * SCR;
       __syncthreads();
       /* per-step scalars a quad of steps at a time (the loads of quad q+1 are issued before
        * the steps of quad q; sched_barrier keeps the compiler from hoisting a whole group
        * into registers); the lane's next sample is a one-dword LDS read per step */
       float4 gq = *reinterpret_cast<const float4 *>(sc);
-      float4 bq = *reinterpret_cast<const float4 *>(sc + 16);
+      float4 bq = *reinterpret_cast<const float4 *>(sc + GS);
       float4 dq = *reinterpret_cast<const float4 *>(dsrc + s0);
-      e_base = sc[32 + 15];
-      b_base = sc[16 + 15];
-      if (s0 + 16 < RDSP_BLOCK)
-        prepare(cur, s0 + 16, sub, ci, tri, mu, e_base, b_base, scr + (((s0 >> 4) + 1) & 1) * SCR);
+      e_base = sc[2 * GS + GS - 1];
+      b_base = sc[GS + GS - 1];
+      if (s0 + GS < RDSP_BLOCK)
+        prepare(cur, s0 + GS, sub, ci, tri, mu, e_base, b_base, scr + (((s0 / GS) + 1) & 1) * SCR);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < GS / 4; q++) {
         const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, bn[4] = {bq.x, bq.y, bq.z, bq.w};
         const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
-        if (q < 3) {
+        if (q < GS / 4 - 1) {
           gq = *reinterpret_cast<const float4 *>(sc + 4 * (q + 1));
-          bq = *reinterpret_cast<const float4 *>(sc + 16 + 4 * (q + 1));
+          bq = *reinterpret_cast<const float4 *>(sc + GS + 4 * (q + 1));
           dq = *reinterpret_cast<const float4 *>(dsrc + s0 + 4 * (q + 1));
         }
 #pragma unroll
@@ -267,7 +279,7 @@ struct NlmsM {
           const float A = chan_sum<COLS>(pp); /* needed only after the update below */
           /* the lane's next-but-one sample: the read is issued a step ahead, so its LDS latency
            * is not part of the recursion (it was: ~60 cycles of every step) */
-          const bool more2 = s < 14 || s0 < RDSP_BLOCK - 16; /* x_{n+2} exists */
+          const bool more2 = s < GS - 2 || s0 < RDSP_BLOCK - GS; /* x_{n+2} exists */
           const float xn2 = more2 ? mine[s0 + s + 2] : 0.f;
           const float xn2b = more2 ? mine_b[s0 + s + 2] : 0.f;
           const float xnew = xn; /* 0 after the last sample of the block */
@@ -314,7 +326,7 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   constexpr int CPW = G::CPW, SPL = G::SPL;
   constexpr int RINGS = DUAL ? 2 : 1;
   /* +4: consecutive channels start four LDS banks apart */
-  constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * SCR + 4;
+  constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * G::SCR + 4;
   __shared__ __attribute__((aligned(16))) float lds[CPW][PER_CH];
   if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
