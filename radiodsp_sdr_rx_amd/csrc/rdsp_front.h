@@ -43,8 +43,61 @@ RDSP_HD int xs_pos(int n) {
  * read for step d needs taps 4d-3 .. 4d+3, i.e. the float4 of step d-1 and d.
  * Data and tap reads of step d+1 are issued before the FMAs of step d, and all
  * of them are DS operations, so the waits are counted (lgkmcnt(N)), never drained. */
+template <bool HAND = false>
 RDSP_HD void fir_lane(int l, int c0, int c1, const float2 *xs, const float4 *taps, float2 *acc) {
   const float4 *xs4 = reinterpret_cast<const float4 *>(xs);
+#ifdef __HIP_DEVICE_COMPILE__
+  if constexpr (HAND) {
+  /* HAND: the packed FMAs written out -- tap = one half of an aligned pair of the tap window,
+   * broadcast by op_sel, times a complex sample -- with the reads two steps ahead of the FMAs
+   * that use them.  The compiler's own code for the loop below copies 17 taps per branch into
+   * fresh pairs (v_mov) and holds 14-26 more VGPRs; without them the un-overlapped front kernel
+   * is 2 % (FFT_L 512) to 7 % (4096) faster.  Not for FFT_L 256: at 162 VGPRs that kernel runs
+   * three waves per SIMD, whose LDS traffic costs more than the copies did (+8 %). */
+  rdsp_v2f a[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) a[r] = rdsp_v2f{acc[r].x, acc[r].y};
+  for (int c = c0; c < c1; c++) {
+    const float4 *pl = xs4 + (c * 2) * RDSP_XP + l + 16;
+    const float4 *tp = taps + c * 16;
+    float4 X0n[2], X1n[2], Tn[2];
+    X0n[0] = pl[0]; X1n[0] = pl[RDSP_XP]; Tn[0] = tp[0];
+    X0n[1] = pl[-1]; X1n[1] = pl[RDSP_XP - 1]; Tn[1] = tp[1];
+    float4 tA = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int d = 0; d <= 16; d++) {
+      const int cur = d & 1;
+      const float4 X0 = X0n[cur], X1 = X1n[cur], tB = Tn[cur];
+      if (d + 2 <= 16) {
+        X0n[cur] = pl[-(d + 2)];
+        X1n[cur] = pl[RDSP_XP - (d + 2)];
+        if (d + 2 <= 15) Tn[cur] = tp[d + 2];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (d == 16 && q == 0) continue;
+        const float4 Xq = (q < 2) ? X0 : X1;
+        const rdsp_v2f xv = (q & 1) ? rdsp_v2f{Xq.z, Xq.w} : rdsp_v2f{Xq.x, Xq.y};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int kp = 4 * d + r - q;
+          if (kp >= 0 && kp <= 63) {
+            const int ti = 4 + r - q; /* index into the window {tA, tB} */
+            const rdsp_v2f tp2 = (ti < 4) ? ((ti < 2) ? rdsp_v2f{tA.x, tA.y} : rdsp_v2f{tA.z, tA.w})
+                                          : ((ti < 6) ? rdsp_v2f{tB.x, tB.y} : rdsp_v2f{tB.z, tB.w});
+            if (ti & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a[r]) : "v"(tp2), "v"(xv));
+            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(a[r]) : "v"(tp2), "v"(xv));
+          }
+        }
+      }
+      tA = tB;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = make_float2(a[r].x, a[r].y);
+  return;
+  }
+#endif
   for (int c = c0; c < c1; c++) {
     const float4 *pl = xs4 + (c * 2) * RDSP_XP + l + 16;
     const float4 *tp = taps + c * 16;

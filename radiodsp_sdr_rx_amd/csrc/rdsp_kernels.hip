@@ -329,14 +329,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         if (p.front_prio == 1) __builtin_amdgcn_s_setprio(1);
         else if (p.front_prio == 2) __builtin_amdgcn_s_setprio(2);
         else if (p.front_prio == 3) __builtin_amdgcn_s_setprio(3);
-        fir_lane(lane, 0, 4, xs, taps_lds, acc);
+        fir_lane<(P >= 8)>(lane, 0, 4, xs, taps_lds, acc);
         if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int r = 0; r < 4; r++) hb[(chunk % CPF) * CH_OUT + 4 * lane + r] = acc[r];
         __syncthreads();
       } else {
         /* four waves: wave w takes polyphase branch w; partials summed via LDS */
-        fir_lane(lane, wave, wave + 1, xs, taps_lds, acc);
+        fir_lane<(P >= 8)>(lane, wave, wave + 1, xs, taps_lds, acc);
 #pragma unroll
         for (int r = 0; r < 4; r++) wb[wave * CH_OUT + 4 * lane + r] = acc[r];
         __syncthreads();
