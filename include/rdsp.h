@@ -208,7 +208,7 @@ uint32_t rdsp_group_tuningMode(rdsp_chain_t *c, int group, int mndx, double vfo_
  * The NLMS/AGC tail stage is serial in time, so its duration is set by the batch
  * length, not by the channel count.  With pipelining on, the tail stage of call k
  * runs on an internal stream concurrently with the front stage of call k+1 (the
- * intermediate audio is double-buffered).  rdsp_chain_process then returns with
+ * intermediate audio lives in three buffers).  rdsp_chain_process then returns with
  * the tail possibly still queued: d_out of a call is complete after the next
  * rdsp_chain_flush(c, stream) on the consuming stream. */
 int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on);

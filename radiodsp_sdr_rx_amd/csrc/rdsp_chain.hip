@@ -86,10 +86,11 @@ struct rdsp_chain {
   float *d_als_w = nullptr, *d_als_prev = nullptr, *d_als_energy = nullptr;
   float *d_mid = nullptr;
   size_t mid_stride = 0;
-  /* SAM groups: quadrature part of the base band (double-buffered like d_mid), PLL state */
+  /* SAM groups: quadrature part of the base band (three buffers, like d_mid), PLL state */
   float *d_mid_q[3] = {nullptr, nullptr, nullptr}, *d_sam = nullptr;
   /* pipelined mode: the serial tail stage of call k runs on an internal stream,
-   * concurrently with the front stage of call k+1 (double-buffered intermediate) */
+   * concurrently with the front stage of call k+1 (three intermediate buffers: the front
+   * stage of call k+1 never waits for the tail stage of call k-1) */
   int pipe_on = 0;
   hipStream_t s_tail = nullptr;
   /* three intermediate buffers: the front stage may run two calls ahead of the tail stage, so

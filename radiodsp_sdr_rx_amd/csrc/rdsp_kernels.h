@@ -52,7 +52,7 @@ struct RdspFrontParams {
   float spectral_k;        /* (float)(level*1.5)                             */
   int vad_lo, vad_hi;      /* inclusive natural bin range                    */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
-  int lean;                /* 1: register-lean variant (co-resident with the tail kernel) */
+  int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */
   int fir_matrix;          /* 1: decimating FIR as v_mfma GEMM slices (not beside a tail wave) */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
   int agc_on;

@@ -47,12 +47,11 @@ struct FrontLds {
   static constexpr size_t BYTES = (size_t)(XS_N + HB_N + WB_N + TAPS_N) * sizeof(float2) + 64 * sizeof(float);
 };
 /* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
- * mask slice re-read per chunk): ~173 instead of ~237 VGPRs at radix 8.  It pays
- * (a) at radix 16, where it buys the second wave per SIMD, and (b) whenever the
- * serial tail kernel runs concurrently (pipelined mode): two lean front waves plus
- * one tail wave fit the 512-register file of a SIMD, so the latency-bound
- * instruction stream of the tail fills issue slots the front leaves idle.  Alone, the
- * full-register variant is ~15 % faster, so the launch code picks per call.
+ * mask slice re-read per chunk).  It pays at radix 16, where it buys the second wave per
+ * SIMD.  At radix 8 it was what let two front waves and a tail wave share the 512-register
+ * file of a SIMD in pipelined mode; since the butterflies and the FIR were written out by
+ * hand the full-register kernel needs 185 VGPRs, fits as well (2 x 192 + 112) and is the
+ * default in both modes (the lean one stays selectable, rdsp_chain_set_front_variant).
  * FMX = true (opt-in, rdsp_chain_set_fir_variant) runs the decimating FIR as
  * v_mfma_f32_16x16x4_f32 GEMM slices.  fp32 MFMA and fp32 VALU work do not overlap on a gfx950
  * SIMD (tests/micro/mfma_valu_overlap.hip: one wave of each takes the sum of both times), so

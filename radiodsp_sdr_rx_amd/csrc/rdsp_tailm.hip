@@ -135,8 +135,8 @@ struct NlmsM {
     if (sub == 0) est[ch] = energy;
   }
 
-  /* the lanes of a channel prepare the 16 steps of a group (step order = lane order `sub`,
-   * 16/LPC consecutive steps per lane): E_n, B_n by prefix sums of their increments, step size
+  /* the lanes of a channel prepare the GS steps of a group (step order = lane order `sub`,
+   * GS/LPC consecutive steps per lane): E_n, B_n by prefix sums of their increments, step size
    * mu/(E_n + eps).  ci = column inside the channel. */
   static __device__ __forceinline__ void prepare(const float *cur, int s0, int sub, int ci, float tri,
                                                  float mu, float e_base, float b_base, float *dst) {
