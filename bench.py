@@ -259,6 +259,21 @@ def main():
         chain.set_sub_batch(int(os.environ["RDSP_SUB_BATCH"]))
     if os.environ.get("RDSP_FRONT_VARIANT"):  # A/B runs: force the full (0) or lean (1) front kernel
         chain.set_front_variant(int(os.environ["RDSP_FRONT_VARIANT"]))
+    # set-up, un-timed: the same kernels back to back without overlap (reference durations for the
+    # JSON line).  It runs before the warm-up so that the GPU has left its idle clocks by then.
+    iso = None
+    if not args.no_kernel_timing and not args.no_pipeline and not args.no_iso:
+        chain.set_pipelined(False)
+        for _ in range(20):      # the clocks of an idle GPU ramp over ~15 steps
+            chain.process(iq, out=out)
+        chain.set_timing(True)
+        for _ in range(10):
+            chain.process(iq, out=out)
+        torch.cuda.synchronize()
+        f2, t2, n2 = chain.get_timing()
+        chain.set_timing(False)
+        iso = {"rdsp_front_kernel": f2 / max(n2, 1), "rdsp_tail_kernel": t2 / max(n2, 1)}
+        chain.set_pipelined(True)
     for _ in range(args.warmup):
         chain.process(iq, out=out)
     chain.flush()
@@ -275,19 +290,6 @@ def main():
     barrier()
     front_ms, tail_ms, calls = chain.get_timing()
     chain.set_timing(False)
-    # extra, un-timed: the same kernels back to back without overlap (reference durations)
-    iso = None
-    if not args.no_kernel_timing and not args.no_pipeline and not args.no_iso:
-        chain.set_pipelined(False)
-        chain.set_front_variant(-1)
-        chain.set_timing(True)
-        for _ in range(min(args.steps, 5)):
-            chain.process(iq, out=out)
-        torch.cuda.synchronize()
-        f2, t2, n2 = chain.get_timing()
-        chain.set_timing(False)
-        iso = {"rdsp_front_kernel": f2 / max(n2, 1), "rdsp_tail_kernel": t2 / max(n2, 1)}
-
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
