@@ -8,11 +8,10 @@
  *
  * The NLMS recursion is serial in time: every step is a chain  dot product ->
  * 16-lane reduction -> error -> step size -> update, one wave per SIMD at 4096
- * channels.  Measured on MI355X (tests/micro/dpp_rate.hip, tail_bench.hip): a DPP op
- * occupies the VALU for ~11.6 cycles whether or not it depends on its neighbour,
- * a plain fp32 op ~3.3 (lone wave), and packed fp32 ops bring nothing to a lone
- * wave (6.5).  Five DPP ops per step (4-stage reduction + delay-line shift) are
- * therefore about half of the ~115 issue cycles of a step.  The kernel uses a
+ * channels.  Measured on MI355X (tests/micro/dpp_kinds.hip, tail_bench.hip): a lone wave
+ * issues one instruction per ~5 cycles whatever its kind (a DPP add 4.4, a plain fp32 op 3.0,
+ * a packed one 4.2 with three waves on the SIMD), so a step costs its instruction count and
+ * its dependency chain.  The kernel uses a
  * one-step lookahead of the recursion,
  *        y_n = W_{n-1}.X_n + g_{n-1} (X_{n-1}.X_n) = A_n + g_{n-1} B_n,
  * which takes the reduction (A_n) off the g -> g chain (what stays loop-carried
@@ -45,8 +44,8 @@ __device__ __forceinline__ float row_shift_in(float xin, float oldest) {
 #ifndef RDSP_TAIL_SWZ
 #define RDSP_TAIL_SWZ 0 /* 1: the per-step reduction with ds_swizzle (LDS crossbar) instead of DPP */
 #endif
-/* butterfly partner inside the 16-lane row: DPP (VALU, ~11.6 cycles of issue) or ds_swizzle
- * (LDS pipe; the add that follows is a plain 3-cycle VALU op) */
+/* butterfly partner inside the 16-lane row: DPP (fused into the add, 4.4 cycles of issue) or
+ * ds_swizzle (LDS pipe, ~125 cycles of latency per stage; the add that follows is a plain VALU op) */
 template <int STAGE>
 __device__ __forceinline__ float red_partner(float v) {
 #if RDSP_TAIL_SWZ

@@ -3,11 +3,12 @@
  * pipe (gfx950).  Same arithmetic as rdsp_tail.hip (one-step lookahead NLMS, see there);
  * what changes is where the cycles go.
  *
- * A DPP op occupies the VALU for ~11.6 cycles on MI355X (tests/micro/dpp_rate.hip), and in
- * rdsp_tail.hip five of them per step (4-stage reduction + delay-line shift) are half of
- * its issue time -- time the front kernel of the next call wants, since both kernels share
- * the SIMDs in pipelined mode and the pair is VALU-bound (profiles/r01_k3_pmc_summary.txt:
- * VALU busy 76 % in the front kernel, 54-67 % in the tail).  Here the 64 lanes of a wave are
+ * rdsp_tail.hip spends five DPP operations per step (4-stage reduction + delay-line shift) --
+ * issue time the front kernel of the next call wants, since both kernels share the SIMDs in
+ * pipelined mode and the pair is VALU-bound (profiles/r01_k3_pmc_summary.txt).  The matrix-pipe
+ * layouts below were built on a microbenchmark that overstated a DPP add (11.6 cycles; it is
+ * 4.4, tests/micro/dpp_kinds.hip) and lose end to end; what this file's default, the row layout
+ * (COLS = 16), keeps from them is the delay line fed from LDS.  Here the 64 lanes of a wave are
  * a 4 x 16 grid (lane = 16 row + col) and a channel owns COLS adjacent columns:
  *   * COLS = 4: 16 lanes and 6 taps per lane, 4 channels per wave (as rdsp_tail.hip);
  *     COLS = 2: 8 lanes and 12 taps per lane, 8 channels per wave, half the waves;
