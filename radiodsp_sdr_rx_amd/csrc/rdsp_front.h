@@ -52,8 +52,9 @@ RDSP_HD void fir_lane(int l, int c0, int c1, const float2 *xs, const float4 *tap
    * broadcast by op_sel, times a complex sample -- with the reads two steps ahead of the FMAs
    * that use them.  The compiler's own code for the loop below copies 17 taps per branch into
    * fresh pairs (v_mov) and holds 14-26 more VGPRs; without them the un-overlapped front kernel
-   * is 2 % (FFT_L 512) to 7 % (4096) faster.  Not for FFT_L 256: at 162 VGPRs that kernel runs
-   * three waves per SIMD, whose LDS traffic costs more than the copies did (+8 %). */
+   * is 2 % (FFT_L 512) to 7 % (4096) faster.  Not for FFT_L 256, where it measured 8 % slower
+   * (10 % with the kernel held at two waves per SIMD by LDS padding, so not an occupancy effect;
+   * unexplained), hence the template switch. */
   rdsp_v2f a[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) a[r] = rdsp_v2f{acc[r].x, acc[r].y};
