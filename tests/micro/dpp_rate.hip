@@ -1,4 +1,7 @@
 // Issue cost of DPP and plain VALU ops for one wave per SIMD on gfx950 (cycles from s_memtime).
+// CAUTION: dppadd() below is `v + update_dpp(0, v, ...)` with bound_ctrl off, which compiles to
+// v_mov (old = 0) + v_mov_dpp + v_add -- three instructions, ~11.6 cycles -- not to the fused
+// v_add_f32_dpp the kernels contain (4.4 cycles; see dpp_kinds.hip, which times that one).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int CTRL> __device__ __forceinline__ float dppadd(float v) {
