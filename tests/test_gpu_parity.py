@@ -282,18 +282,26 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
             assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
 
-def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
+@pytest.mark.parametrize("name,cfg,nch,nblk", [
+    ("k3", K3, 64, 32),
+    ("usb256_nr", dict(fft_l=256, demod="USB", lms_nr=10, agc_mode="slow"), 24, 16),           # DSP-NR instance, radix 4
+    ("lsb2048_notch", dict(fft_l=2048, demod="LSB", als_mode="notch", als_strength=15), 9, 32),  # four waves per channel
+    ("am1024_peak", dict(fft_l=1024, demod="AM", als_mode="peak", agc_mode="fast"), 5, 32),      # radix 16, lean kernel
+])
+def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda, name, cfg, nch, nblk):
     """rdsp_chain_set_pipelined: the tail stage of call k overlaps the front stage of
-    call k+1 on an internal stream; results must not change by a bit."""
+    call k+1 on an internal stream; results must not change by a bit -- at every FFT size
+    (front kernels of 1 and 4 waves, full-register and lean) and tail instance."""
     torch = torch_cuda
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
-    nch, nblk, calls = 64, 32, 6
+    calls = 6
+    K3 = cfg  # noqa: N806 -- the body below was written for the K3 case
     iq = synth_iq(nch, nblk * 128 * calls)
     parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
              for k in range(calls)]
     ref_chain = Chain(nch, max_blocks_per_call=nblk, **K3)
-    ref_chain.set_front_variant(0)  # pipelined mode runs the full-register front kernel
-    ref_chain.set_fir_variant(0)    # ... with the packed-FMA FIR
+    ref_chain.set_front_variant(-1)  # the same (automatic) kernel choice as the pipelined chain
+    ref_chain.set_fir_variant(0)     # ... with the packed-FMA FIR
     ref = [ref_chain.process(p).cpu().numpy() for p in parts]
     ch = Chain(nch, max_blocks_per_call=nblk, **K3)
     ch.set_pipelined(True)
@@ -305,7 +313,8 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda):
     for a, b in zip(ref, outs):
         assert np.array_equal(a, b.cpu().numpy())
     assert np.array_equal(ref_chain.scalars(), ch.scalars())
-    assert np.array_equal(ref_chain.lms_coeffs(1), ch.lms_coeffs(1))
+    for which in (0, 1):   # DSP-NR and ALS instances
+        assert np.array_equal(ref_chain.lms_coeffs(which), ch.lms_coeffs(which))
 
 
 def test_channel_sub_batches_are_bitwise_identical(rdsp, torch_cuda):
