@@ -322,7 +322,7 @@ def test_channel_sub_batches_are_bitwise_identical(rdsp, torch_cuda):
     (ragged last one), front and tail of a sub-batch chained by their own event; nothing changes."""
     torch = torch_cuda
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
-    nch, nblk, calls = 200, 16, 4
+    nch, nblk, calls = 202, 16, 4   # the last sub-batch is ragged and so is its last tail workgroup (2 of 4 channels)
     iq = synth_iq(nch, nblk * 128 * calls)
     parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
              for k in range(calls)]
@@ -338,7 +338,7 @@ def test_channel_sub_batches_are_bitwise_identical(rdsp, torch_cuda):
                 np.concatenate([o[1].cpu().numpy() for o in outs], 1))
 
     a16, a32 = run(0)
-    for sub in (64, 128):       # 64: four launches (64, 64, 64, 8 channels); 128: two (128, 72)
+    for sub in (64, 128):       # 64: four launches (64, 64, 64, 10 channels); 128: two (128, 74)
         b16, b32 = run(sub)
         assert np.array_equal(a16, b16) and np.array_equal(a32, b32), sub
     with pytest.raises(Exception):
