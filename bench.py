@@ -51,7 +51,32 @@ def parse():
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra PCIe-inclusive leg (host memory -> chain -> host memory)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction / JSON plumbing only, no device work (CPU-side test of --gpus N)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N
+    ranks as a CHILD (`python -m torch.distributed.run`, one process per GPU) and relay rank 0's
+    JSON line.  This process has not touched torch or HIP, and it does not exec: a process that
+    initialised the GPU must never be replaced on this pool."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores(args.gpus) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout)
+        sys.exit(r.returncode or 1)
+    print(lines[-1])
+    sys.exit(0)
 
 
 def algorithmic_bytes_per_sample(decim):
@@ -179,12 +204,39 @@ def cpu_baseline_worker(args):
                       "single_thread_value": one, "single_thread_sample": f"{n1} channels x {nblk} blocks"}))
 
 
+def dry_run(args, rank, world, dist):
+    """No device work: every rank pretends one step takes (1 + rank) ms, then the same barrier /
+    max-over-ranks / one-JSON-line protocol as the real run.  Exercised by the CPU-side test of
+    `bench.py --gpus 2`; its line is marked so that it can never be read as a measurement."""
+    import torch
+    kc_channels = args.channels_per_gpu or 4096
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(1e-3 * (1 + rank) * args.steps)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the launcher (no device work)", "value": None, "unit": "IQ Msamples/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "data": "dry-run",
+                          "config": {"workload": f"{args.config}: {kc_channels} channels/GPU (not run)",
+                                     "sharding": f"channels x{world}, no collectives"}}))
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         return f1_cpu_baseline(args) if args.config == "F1" else cpu_baseline_worker(args)
     if args.config == "F1":
         return f1_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)   # before any torch / HIP call in this process
 
     import numpy as np
     import torch
@@ -208,6 +260,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}"
+    if args.dry_run:
+        return dry_run(args, rank, world, dist)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     if os.environ.get("RDSP_BENCH_ONE_DEVICE"):  # rehearsal of N > 1 on a one-GPU box
         local_rank = 0
@@ -311,18 +366,25 @@ def main():
             dom, dom_ms, B_dom = "rdsp_front_kernel", front_avg, B
         bytes_per_launch = B_dom * nch * n_samples
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # counters of a committed PMC pass of this configuration (tests/profile_round.sh ->
+        # profiles/counters.json): HBM bytes and VALU busy fraction per launch of each kernel
+        ctr = {}
+        cpath = os.path.join(ROOT, "profiles", "counters.json")
+        if os.path.exists(cpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get(dom)
+                ctr = json.load(open(cpath)).get(args.config, {})
             except Exception:
-                traffic = None
+                ctr = {}
+        traffic = ctr.get(dom, {}).get("hbm_bytes")
+        chain_traffic = sum(v.get("hbm_bytes", 0.0) for k, v in ctr.items() if k in ("rdsp_front_kernel", "rdsp_tail_kernel")) or None
+        flops = FLOP_PER_SAMPLE.get(args.config, 0) * float(nch) * n_samples   # per launch of the chain
+        achieved_tf = flops / (elapsed / args.steps) / 1e12
         res = {
             "metric": "IQ Msamples/s through full SSB+NR chain; achieved HBM GB/s vs peak",
             "value": value,
             "unit": "IQ Msamples/s",
             "n_gpus": world,
+            "devices_visible": torch.cuda.device_count(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -345,14 +407,22 @@ def main():
                 "retune_every_steps": args.retune_every,
             },
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
-                          "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS},
+                          "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS,
+                          "traffic_bytes_per_step": chain_traffic},
             "kernels_ms_per_step": {"rdsp_front_kernel": front_avg, "rdsp_tail_kernel": tail_avg},
             "kernels_ms_isolated": iso,
-            "fp32_valu": {"flop_per_sample_model": FLOP_PER_SAMPLE.get(args.config), "peak_TFLOPs": FP32_PEAK_TFLOPS,
-                          "achieved_TFLOPs": (FLOP_PER_SAMPLE.get(args.config, 0) * value * 1e6 / 1e12 / world),
-                          "note": "SURVEY Appendix D flop model; the chain is fp32-VALU-bound before it is HBM-bound"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
+            # The north-star's roofline is HBM, and that is what `roofline` reports (algorithmic bytes of
+            # the dominant kernel / its measured duration / 8 TB/s).  What binds first is the fp32 VALU
+            # (SURVEY 0.7, Appendix D): `limiter` says so and `valu` carries that roofline -- the flop model
+            # of the chain as run / step time against the 157.3 TFLOP/s vector peak, and the VALU-busy
+            # fraction of the dominant kernel from the committed PMC pass.
+            "roofline": {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": achieved_tf / FP32_PEAK_TFLOPS,
+                                  "flop_per_sample_model": FLOP_PER_SAMPLE.get(args.config),
+                                  "busy_frac_pmc": {k: v.get("valu_busy_frac") for k, v in ctr.items()
+                                                    if k in ("rdsp_front_kernel", "rdsp_tail_kernel")} or None}},
             "input_gen_s": gen_s,
         }
         if world == 1 and not args.no_host_io:

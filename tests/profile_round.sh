@@ -1,23 +1,27 @@
 #!/bin/bash
-# One GPU call: rocprofv3 kernel-trace stats of the bench lines and the PMC passes of the K3
-# workload (FETCH_SIZE and WRITE_SIZE in separate passes, SQ counters in a third), all under
-# gpurun_out/prof_<tag>/; tests/summarize_profiles.py turns them into profiles/<round>_*.
-# usage: bash tests/profile_round.sh   (on the GPU box; `cd /tmp && export TMPDIR=/tmp` per the guide)
+# One GPU call: rocprofv3 kernel-trace stats of the bench lines and the PMC passes of every
+# configuration (FETCH_SIZE and WRITE_SIZE in separate passes, SQ counters in a third), all under
+# gpurun_out/prof_<cfg>/ and gpurun_out/pmc_<cfg>_<pass>/; tests/summarize_profiles.py turns them
+# into profiles/<round>_* and profiles/counters.json.
+# usage: bash tests/profile_round.sh [configs...]   (on the GPU box)
 set -o pipefail
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+CFGS=${@:-K3 K2 K4 K5 F1}
 B="--steps 100 --warmup 20 --no-cpu-baseline --no-host-io --no-iso"
-for K in K3 K2 K4 F1 K5; do
+P="--steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing"
+for K in $CFGS; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$K -o trace -- python3 $ROOT/bench.py --config $K $B > $OUT/prof_$K.json 2> $OUT/prof_$K.err) || { echo "rocprof $K failed"; tail -5 $OUT/prof_$K.err; }
   echo "trace $K done"
 done
-# PMC: one counter family per pass (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), no tracing domains besides the kernel trace
-for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_$C -o pmc -- python3 $ROOT/bench.py --config K3 --steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err) || { echo "pmc $C failed"; tail -5 $OUT/pmc_$C.err; }
-  echo "pmc $C done"
+# PMC: one counter family per pass (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel trace only
+for K in $CFGS; do
+  [ $K = F1 ] && continue
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_${K}_$C -o pmc -- python3 $ROOT/bench.py --config $K $P > $OUT/pmc_${K}_$C.json 2> $OUT/pmc_${K}_$C.err) || { echo "pmc $K $C failed"; tail -5 $OUT/pmc_${K}_$C.err; }
+  done
+  (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_${K}_SQ -o pmc -- python3 $ROOT/bench.py --config $K $P > $OUT/pmc_${K}_SQ.json 2> $OUT/pmc_${K}_SQ.err) || { echo "pmc $K SQ failed"; tail -5 $OUT/pmc_${K}_SQ.err; }
+  echo "pmc $K done"
 done
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_SQ -o pmc -- python3 $ROOT/bench.py --config K3 --steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing > $OUT/pmc_SQ.json 2> $OUT/pmc_SQ.err) || { echo "pmc SQ failed"; tail -5 $OUT/pmc_SQ.err; }
-echo "pmc SQ done"
-find $OUT -name "*.csv" | head -40

@@ -1,8 +1,9 @@
 """Turn the rocprofv3 output of tests/profile_round.sh (gpurun_out/prof_*, pmc_*) into the
 tracked summaries under profiles/: <round>_<cfg>_kernel_stats.csv, <round>_<cfg>_bench.json,
-<round>_k3_pmc_summary.txt and traffic.json (HBM bytes per launch of the K3 kernels,
-FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as read).
-usage: python tests/summarize_profiles.py r01"""
+<round>_<cfg>_pmc_summary.txt and counters.json (per configuration and kernel: HBM bytes per
+launch -- FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as read --
+VALU instructions and the VALU-busy fraction), which bench.py reads for roofline.traffic.
+usage: python tests/summarize_profiles.py r02"""
 import csv
 import glob
 import json
@@ -53,7 +54,7 @@ def pmc_per_launch(tag):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     os.makedirs(PROF, exist_ok=True)
     for cfg in ("K3", "K2", "K4", "F1", "K5"):
         stats = newest(os.path.join(OUT, f"prof_{cfg}", "**", "*kernel_stats.csv"))
@@ -64,22 +65,35 @@ def main():
             lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
             if lines:
                 open(os.path.join(PROF, f"{rnd}_{cfg.lower()}_bench.json"), "w").write(lines[-1] + "\n")
-    fetch, write, sq = pmc_per_launch("FETCH_SIZE"), pmc_per_launch("WRITE_SIZE"), pmc_per_launch("SQ")
-    traffic = {"K3": {}}
-    lines = ["K3 per-launch PMC (rocprofv3, separate passes; FETCH_SIZE doubled per the gfx950 note in "
-             "MI355X_MICROARCH.md, WRITE_SIZE as read; units of both: KB):"]
-    for k in sorted(set(fetch) | set(write)):
-        rd = 2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
-        wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
-        traffic["K3"][k] = rd + wr
-        lines.append(f"  {k}: read {rd / 1e9:.3f} GB (FETCH_SIZE {fetch.get(k, {}).get('FETCH_SIZE', 0):.0f} KB x2), "
-                     f"write {wr / 1e9:.3f} GB, total {(rd + wr) / 1e9:.3f} GB")
-    for k, c in sorted(sq.items()):
-        lines.append(f"  {k}: " + ", ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())))
-    if traffic["K3"]:
-        json.dump(traffic, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
-    open(os.path.join(PROF, f"{rnd}_k3_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines))
+    cpath = os.path.join(PROF, "counters.json")
+    counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
+    for cfg in ("K2", "K3", "K4", "K5"):
+        fetch, write, sq = (pmc_per_launch(f"{cfg}_{t}") for t in ("FETCH_SIZE", "WRITE_SIZE", "SQ"))
+        if not (fetch or write or sq):
+            continue
+        counters[cfg] = {"round": rnd}
+        lines = [f"{cfg} per-launch PMC (rocprofv3, separate passes; FETCH_SIZE doubled per the gfx950 note in "
+                 "MI355X_MICROARCH.md, WRITE_SIZE as read; units of both: KB):"]
+        for k in sorted(set(fetch) | set(write) | set(sq)):
+            rd = 2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
+            wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+            c = sq.get(k, {})
+            ent = {"hbm_bytes": rd + wr, "hbm_read_bytes": rd, "hbm_write_bytes": wr}
+            if c.get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles over
+                # all 1024 SIMDs: busy fraction = 4 * active / (1024 SIMDs * cycles of the launch)
+                cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+                ent.update(valu_insts=c.get("SQ_INSTS_VALU"), lds_insts=c.get("SQ_INSTS_LDS"), gpu_cycles=cyc,
+                           valu_busy_frac=4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * cyc))
+            counters[cfg][k] = ent
+            lines.append(f"  {k}: read {rd / 1e9:.3f} GB (FETCH_SIZE {fetch.get(k, {}).get('FETCH_SIZE', 0):.0f} KB x2), "
+                         f"write {wr / 1e9:.3f} GB, total {(rd + wr) / 1e9:.3f} GB"
+                         + (f", VALU busy {ent['valu_busy_frac']:.3f}" if "valu_busy_frac" in ent else ""))
+        for k, c in sorted(sq.items()):
+            lines.append(f"  {k}: " + ", ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())))
+        open(os.path.join(PROF, f"{rnd}_{cfg.lower()}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
+    json.dump(counters, open(cpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -152,3 +152,24 @@ def test_channel_sharding_world_size_2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_bench_gpus_2_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` (the driver's command form, no WORLD_SIZE in the environment)
+    starts two ranks as a child process and relays rank 0's single JSON line with n_gpus = 2.
+    --dry-run replaces the device work by a sleep: launcher, rendezvous (gloo, 127.0.0.1), the
+    barrier + max-over-ranks reduction and the one-line protocol are the real ones."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
+                        "--dry-run"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["data"] == "dry-run"
+    assert d["ms_per_step"] >= 2.0                     # the MAX over ranks: rank 1 sleeps 2 ms per step
+    # a worker whose world size disagrees with --gpus refuses to run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                         text=True, env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
