@@ -84,6 +84,11 @@ typedef struct rdsp_chain rdsp_chain_t;
 
 const char *rdsp_last_error(void);
 const char *rdsp_version(void);
+/* 1 if the library was built with EXPERIMENTAL=1 (csrc/Makefile): it then also carries the
+ * kernel variants that were measured and not adopted (matrix-core FIR and tail reductions,
+ * half-row / DPP-shift tail layouts); the product build has none of them and the variant
+ * setters below return RDSP_ERR_UNSUPPORTED for anything but the defaults. */
+int rdsp_experimental_build(void);
 int rdsp_device_count(void);
 
 /* ---- host-side design helpers ---------------------------------------------*/
@@ -224,13 +229,14 @@ int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
-/* decimating FIR variant: 0 packed FMAs (default), 1 matrix-core GEMM slices (opt-in,
- * +10 % at K2), -1 matrix unless the tail stage shares the SIMDs */
+/* decimating FIR variant: 0 packed FMAs (the product).  EXPERIMENTAL=1 builds: 1 matrix-core
+ * GEMM slices (+10 % at K2, outside the north-star's "no MFMA"), -1 matrix unless the tail stage
+ * shares the SIMDs */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix);
-/* tail-kernel variant: lanes per channel 16 or 8; matrix_reduce 0: DPP
- * reduction with the delay line shifted by DPP (rdsp_tail.hip), 2: DPP reduction with the delay
- * line fed from LDS (rdsp_tailm.hip row layout; the default), 1: cross-lane sums on the matrix
- * pipe (required for 8 lanes) */
+/* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row,
+ * DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: lanes per channel 16 or 8;
+ * matrix_reduce 0: delay line shifted by DPP (experimental/rdsp_tail_shift.hip), 2: row / half-row
+ * layout, 1: cross-lane sums on the matrix pipe */
 int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce);
 
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/

@@ -78,6 +78,7 @@ _f32p, _f64p, _i16p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c
 SYMBOLS = [
     ("rdsp_last_error", C.c_char_p, []),
     ("rdsp_version", C.c_char_p, []),
+    ("rdsp_experimental_build", _i, []),
     ("rdsp_device_count", _i, []),
     ("rdsp_calc_cplx_FIR_coeffs", None, [_f64p, _f64p, _i, _d, _d, _d, _i]),
     ("rdsp_init_filter_mask", _i, [_f32p, _f64p, _f64p, _i]),

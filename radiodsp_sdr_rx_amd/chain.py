@@ -50,7 +50,8 @@ class Chain:
         """iq: int16 cuda tensor [n_channels, n_samples, 2].  Returns int16
         [n_channels, n_samples/decim, 2] (and the float pairs if requested)."""
         assert iq.is_cuda and iq.dtype == torch.int16 and iq.dim() == 3 and iq.shape[2] == 2
-        assert iq.shape[0] == self.n_channels and iq.is_contiguous()
+        # rows may be slices of a longer buffer: [ch][in_stride][2] with the sample pairs contiguous
+        assert iq.shape[0] == self.n_channels and iq.stride(2) == 1 and iq.stride(1) == 2
         n = iq.shape[1]
         assert n % 128 == 0
         n_out = n // self.decim

@@ -25,7 +25,13 @@ extern "C" void rdsp_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *rdsp_last_error(void) { return g_err; }
-extern "C" const char *rdsp_version(void) { return "rdsp-amd 0.1 (gfx950)"; }
+#ifdef RDSP_EXPERIMENTAL
+extern "C" const char *rdsp_version(void) { return "rdsp-amd 0.2 (gfx950, experimental variants)"; }
+extern "C" int rdsp_experimental_build(void) { return 1; }
+#else
+extern "C" const char *rdsp_version(void) { return "rdsp-amd 0.2 (gfx950)"; }
+extern "C" int rdsp_experimental_build(void) { return 0; }
+#endif
 
 extern "C" int rdsp_device_count(void) {
   int n = 0;
@@ -105,6 +111,8 @@ struct rdsp_chain {
   std::vector<hipEvent_t> ev_front_sb[3]; /* [slot][sub-batch], created on first use */
   float *d_midx[2] = {nullptr, nullptr}; /* slots 1 and 2 (slot 0 is d_mid) */
   long call_idx = 0;
+  int tail_slot = -1; /* slot of the last call whose tail stage went to s_tail (its ev_tail marks
+                         when d_out, the AGC gain and the NLMS state of that call are final); -1: none */
   /* optional per-kernel HIP-event timing (bench.py roofline leg) */
   int timing_on = 0;
   std::vector<hipEvent_t> ev; /* pool, groups of 4: front begin/end, tail begin/end */
@@ -124,6 +132,10 @@ struct rdsp_chain {
 };
 
 static int drain_tail_fwd(rdsp_chain_t *c);
+static int ensure_sam(rdsp_chain_t *c);
+static int ensure_sub_batch_events(rdsp_chain_t *c);
+static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_channels, int device,
+                       int max_blocks_per_call, int decim);
 static int check_device(rdsp_chain_t *c) {
   if (hipSetDevice(c->device) != hipSuccess) {
     rdsp_set_error("hipSetDevice(%d) failed", c->device);
@@ -304,6 +316,17 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
     return RDSP_ERR_NO_DEVICE;
   }
   rdsp_chain_t *c = new rdsp_chain();
+  const int rc_build = chain_build(c, cfg, n_channels, device, max_blocks_per_call, decim);
+  if (rc_build != RDSP_OK) {
+    rdsp_chain_destroy(c); /* frees whatever was allocated before the failure */
+    return rc_build;
+  }
+  *out = c;
+  return RDSP_OK;
+}
+
+static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_channels, int device,
+                       int max_blocks_per_call, int decim) {
   c->cfg = *cfg;
   c->cfg.decim = decim;
   c->n_channels = n_channels;
@@ -318,7 +341,7 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
   c->als_mu = rdsp_lms_mu(cfg->als_strength > 0 ? cfg->als_strength : 15);
   c->nr_calls = c->als_calls = 0;
   c->fir_nat.assign(256, 0.0f);
-  if (check_device(c) != RDSP_OK) { delete c; return RDSP_ERR_HIP; }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   {
     int rc = groups_resize(c, 1);
     if (rc != RDSP_OK) return rc;
@@ -363,9 +386,8 @@ extern "C" int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels,
    * still-zero taps) then reInitializeFilter (INO:183) */
   int rc = rdsp_doConvolutionalInitialize(c, nullptr);
   if (rc == RDSP_OK) rc = rdsp_reInitializeFilter(c, cfg->flo_hz, cfg->fhi_hz, nullptr);
-  if (rc != RDSP_OK) return rc;
-  *out = c;
-  return RDSP_OK;
+  if (rc == RDSP_OK && cfg->demod == RDSP_DEMOD_SAM) rc = ensure_sam(c);
+  return rc;
 }
 
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
@@ -412,6 +434,7 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   const size_t nch = (size_t)c->n_channels;
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   c->call_idx = 0;
+  c->tail_slot = -1;
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipMemset(c->d_hist, 0, sizeof(uint32_t) * 256 * nch));
   HIP_TRY(hipMemset(c->d_prev, 0, sizeof(float2) * c->hop * nch));
@@ -532,11 +555,9 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   }
   bool sam = false; /* any group on the PLL demodulator: its serial stage runs before the tail */
   for (const auto &g : c->groups) sam = sam || (g.demod == RDSP_DEMOD_SAM);
-  if (sam && !c->d_sam) {
-    const size_t nch_ = (size_t)c->n_channels, mid_bytes = sizeof(float) * c->mid_stride * nch_;
-    for (int i = 0; i < 3; i++) HIP_TRY(hipMalloc((void **)&c->d_mid_q[i], mid_bytes));
-    HIP_TRY(hipMalloc((void **)&c->d_sam, sizeof(float) * 4 * nch_));
-    HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch_));
+  if (sam && !c->d_sam) { /* rdsp_*_setDemodMode(SAM) allocates them; nothing is allocated here */
+    rdsp_set_error("SAM group without PLL buffers (internal)");
+    return RDSP_ERR_INVALID;
   }
   const bool tail = sam || (cf.lms_nr > 0) || (cf.als_mode != RDSP_ALS_OFF);
   float attack, decay;
@@ -592,6 +613,13 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     /* the tail of call k-2 read this intermediate buffer: wait for it */
     if (c->call_idx >= 3) HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[slot], 0));
   }
+  if (!piped && c->tail_slot >= 0) {
+    /* the previous call's tail stage may still be running on s_tail: it owns that call's d_out and
+     * updates the AGC gain (st_scal) this call's front kernel reads and writes when it packs itself
+     * (tail stage switched off between two calls), and the NLMS state an in-stream tail uses */
+    HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[c->tail_slot], 0));
+    c->tail_slot = -1;
+  }
   if (timed) { /* events come from a pool created in rdsp_chain_set_timing */
     ev0 = c->ev[4 * c->ev_used];
     ev1 = c->ev[4 * c->ev_used + 1];
@@ -600,6 +628,11 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     HIP_TRY(hipEventRecord(ev0, stream));
   }
   {
+    /* the PLL kernel of the previous call (on s_tail) reads the group records: a record is only
+     * rewritten after it has finished */
+    bool any_dirty = false;
+    for (const auto &g : c->groups) any_dirty = any_dirty || g.dirty;
+    if (any_dirty && c->d_sam && c->tail_slot >= 0) HIP_TRY(hipStreamWaitEvent(stream, c->ev_tail[c->tail_slot], 0));
     int rc = groups_commit(c, stream);
     if (rc != RDSP_OK) return rc;
   }
@@ -608,10 +641,9 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   if (piped && !sam && c->sub_batch > 0 && c->n_channels >= c->sub_batch + c->sub_batch / 2) {
     sbn = c->sub_batch;
     nsb = (c->n_channels + sbn - 1) / sbn;
-    while (c->ev_front_sb[slot].size() < (size_t)nsb) {
-      hipEvent_t ev;
-      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      c->ev_front_sb[slot].push_back(ev);
+    if (c->ev_front_sb[slot].size() < (size_t)nsb) { /* made by set_pipelined / set_sub_batch */
+      rdsp_set_error("sub-batch events missing (internal)");
+      return RDSP_ERR_INVALID;
     }
   }
   int e = 0;
@@ -686,7 +718,10 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
       return RDSP_ERR_HIP;
     }
     if (timed) HIP_TRY(hipEventRecord(ev3, tstream));
-    if (piped) HIP_TRY(hipEventRecord(c->ev_tail[slot], c->s_tail));
+    if (piped) {
+      HIP_TRY(hipEventRecord(c->ev_tail[slot], c->s_tail));
+      c->tail_slot = slot;
+    }
     if (tp.nr_on) c->nr_calls += tp.n_blocks;
     if (tp.als_mode) c->als_calls += tp.n_blocks;
   }
@@ -858,6 +893,7 @@ extern "C" int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream
 extern "C" uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode, void *stream) {
   if (check_group(c, group) != RDSP_OK || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_SAM) return 0;
   GroupState &g = c->groups[(size_t)group];
+  if (mode == RDSP_DEMOD_SAM && ensure_sam(c) != RDSP_OK) return 0;
   g.demod = mode;
   if (group == 0) c->cfg.demod = mode;
   double lo, hi;
@@ -985,6 +1021,31 @@ extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   }
   c->pipe_on = on ? 1 : 0;
   c->call_idx = 0;
+  c->tail_slot = -1; /* drained above */
+  return on ? ensure_sub_batch_events(c) : RDSP_OK;
+}
+/* one event per channel sub-batch and intermediate buffer; made here and in
+ * rdsp_chain_set_sub_batch, never on the streaming path */
+static int ensure_sub_batch_events(rdsp_chain_t *c) {
+  if (!c->s_tail || c->sub_batch <= 0) return RDSP_OK;
+  const size_t nsb = (size_t)((c->n_channels + c->sub_batch - 1) / c->sub_batch);
+  for (int slot = 0; slot < 3; slot++)
+    while (c->ev_front_sb[slot].size() < nsb) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      c->ev_front_sb[slot].push_back(ev);
+    }
+  return RDSP_OK;
+}
+/* PLL state and the quadrature intermediates of the SAM demodulator: allocated when a group is
+ * first switched to SAMmode (a control-path call), not by the processing call */
+static int ensure_sam(rdsp_chain_t *c) {
+  if (c->d_sam) return RDSP_OK;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  const size_t nch = (size_t)c->n_channels, mid_bytes = sizeof(float) * c->mid_stride * nch;
+  for (int i = 0; i < 3; i++) HIP_TRY(hipMalloc((void **)&c->d_mid_q[i], mid_bytes));
+  HIP_TRY(hipMalloc((void **)&c->d_sam, sizeof(float) * 4 * nch));
+  HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch));
   return RDSP_OK;
 }
 /* front-kernel variant: -1 = auto (full-register; measured faster with and without the
@@ -1001,8 +1062,9 @@ extern "C" int rdsp_chain_set_front_variant(rdsp_chain_t *c, int lean) {
 extern "C" int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels) {
   NEED(c);
   if (channels < 0 || channels % 64 != 0) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   c->sub_batch = channels;
-  return RDSP_OK;
+  return ensure_sub_batch_events(c);
 }
 /* wave priorities (s_setprio 0..3) used while the tail stage shares the SIMDs with the front
  * stage of the next call: the front kernel's during its FIR, the tail kernel's throughout */
@@ -1020,6 +1082,12 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
 extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix) {
   NEED(c);
   if (matrix < -1 || matrix > 1) return RDSP_ERR_INVALID;
+#ifndef RDSP_EXPERIMENTAL
+  if (matrix != 0) {
+    rdsp_set_error("the matrix-core FIR is only in EXPERIMENTAL=1 builds of the library");
+    return RDSP_ERR_UNSUPPORTED;
+  }
+#endif
   c->fir_mode = matrix;
   return RDSP_OK;
 }
@@ -1029,6 +1097,12 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix) {
 extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce) {
   NEED(c);
   if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce)) return RDSP_ERR_INVALID;
+#ifndef RDSP_EXPERIMENTAL
+  if (!(lanes_per_channel == 16 && matrix_reduce == 2)) {
+    rdsp_set_error("tail-kernel layouts other than the 16-lane row are only in EXPERIMENTAL=1 builds of the library");
+    return RDSP_ERR_UNSUPPORTED;
+  }
+#endif
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
   /* matrix_reduce 2: the row layouts of rdsp_tailm.hip (DPP reduction, delay line fed from LDS):
    * a whole DPP row of 16 lanes per channel, or half a row */
@@ -1039,10 +1113,7 @@ extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channe
 extern "C" int rdsp_chain_flush(rdsp_chain_t *c, void *stream) {
   NEED(c);
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
-  if (c->pipe_on && c->call_idx > 0) {
-    const int last = (int)((c->call_idx - 1) % 3);
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ev_tail[last], 0));
-  }
+  if (c->tail_slot >= 0) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ev_tail[c->tail_slot], 0));
   return RDSP_OK;
 }
 

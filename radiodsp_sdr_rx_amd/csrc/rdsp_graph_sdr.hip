@@ -66,6 +66,8 @@ void sdr_update(rdsp_node_t *n, void *u) {
     int rc = RDSP_OK;
     if (e == hipSuccess)
       rc = rdsp_chain_process(s->chain, s->d_iq, in_row, s->gran, s->d_out, out_row, nullptr, s->stream);
+    /* a chain in pipelined mode finishes d_out on its internal tail stream: the copy below waits for it */
+    if (e == hipSuccess && rc == RDSP_OK) rc = rdsp_chain_flush(s->chain, s->stream);
     if (e == hipSuccess && rc == RDSP_OK)
       e = hipMemcpyAsync(s->h_out.data(), s->d_out, s->h_out.size() * sizeof(int16_t),
                          hipMemcpyDeviceToHost, s->stream);

@@ -23,6 +23,8 @@
  */
 #include <string.h>
 
+#include <mutex>
+
 #include "rdsp_front.h"
 #include "rdsp_wave.h"
 
@@ -584,21 +586,33 @@ constexpr size_t front_lds() {
 template <int N, int P, int DECIM, bool LEAN, bool PRE, bool FMX>
 int launch_front_x(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   constexpr size_t lds = front_lds<N, P, DECIM, FMX>();
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
+  /* the raised dynamic-LDS limit is a per-device property of the function: one bit per device,
+   * set under a lock (chains on several devices may launch from several host threads) */
+  static std::mutex attr_mu;
+  static uint64_t attr_done = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return (int)hipErrorInvalidDevice;
+  {
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!((attr_done >> dev) & 1u)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_done |= (uint64_t)1 << dev;
+    }
   }
   hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
 }
 template <int N, int P, int DECIM, bool LEAN, bool PRE>
 int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+#ifdef RDSP_EXPERIMENTAL
   if constexpr (DECIM == 4) {
     if (p->fir_matrix) return launch_front_x<N, P, DECIM, LEAN, PRE, true>(p, n_channels, stream);
   }
+#else
+  if (p->fir_matrix) return (int)hipErrorNotSupported; /* matrix-core FIR: EXPERIMENTAL=1 builds only */
+#endif
   return launch_front_x<N, P, DECIM, LEAN, PRE, false>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM, bool LEAN>
@@ -618,11 +632,11 @@ int launch_front_t(const RdspFrontParams *p, int n_channels, hipStream_t stream)
 extern "C" size_t rdsp_front_lds_bytes(int fft_l, int decim) {
   const bool d4 = decim == 4;
   switch (fft_l) {
-    case 256: return d4 ? front_lds<256, 4, 4, true>() : front_lds<256, 4, 1, false>();
-    case 512: return d4 ? front_lds<512, 8, 4, true>() : front_lds<512, 8, 1, false>();
-    case 1024: return d4 ? front_lds<1024, 16, 4, true>() : front_lds<1024, 16, 1, false>();
-    case 2048: return d4 ? front_lds<2048, 8, 4, true>() : front_lds<2048, 8, 1, false>();
-    case 4096: return d4 ? front_lds<4096, 16, 4, true>() : front_lds<4096, 16, 1, false>();
+    case 256: return d4 ? front_lds<256, 4, 4, false>() : front_lds<256, 4, 1, false>();
+    case 512: return d4 ? front_lds<512, 8, 4, false>() : front_lds<512, 8, 1, false>();
+    case 1024: return d4 ? front_lds<1024, 16, 4, false>() : front_lds<1024, 16, 1, false>();
+    case 2048: return d4 ? front_lds<2048, 8, 4, false>() : front_lds<2048, 8, 1, false>();
+    case 4096: return d4 ? front_lds<4096, 16, 4, false>() : front_lds<4096, 16, 1, false>();
     default: return 0;
   }
 }

@@ -31,6 +31,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (a + b) + (c + d);
 }
 
+/* `float_buffer_L[i] * 1.1` of CONV:334: the literal is a double, so the product is formed in
+ * double and rounded to float once (x * 1.1f can differ in the last bit) */
+__device__ __forceinline__ float mul_1p1(float x) { return (float)((double)x * 1.1); }
+
 __device__ __forceinline__ float2 unpack_iq(uint32_t w, float si, float sq) {
   /* arm_q15_to_float: q/32768 (the 2^-15 is folded into si/sq, exact) */
   float xr = (float)(int16_t)(w & 0xFFFFu);

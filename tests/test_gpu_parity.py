@@ -7,13 +7,19 @@ Tolerances (written here, used below):
   * feed-forward chains (mixer, decimator, overlap-save filter, spectral NR, demod,
     AGC): TOL = 1e-5 normwise per channel, max|y - y_ref| / max|y_ref| (north-star).
   * chains with an NLMS stage (DSP-NR, ALS notch/peak): the NLMS kernel itself meets
-    1e-5 on identical float input (test_lms_noise_reduction_isolated); through the
-    whole chain the start-up of the recursion (energy ~ 0) amplifies the ~3e-7
-    front-end difference by the factor the oracle itself shows for a 1-ulp input
-    change (tests/test_oracle_kat.py::test_nlms_conditioning), so the bound is
-    max(TOL, 4 * kappa * front_err) with kappa measured on the oracle in the test.
+    1e-5 on identical float input (test_lms_noise_reduction_isolated).  Through a whole
+    chain the start-up of the recursion (energy ~ 0) amplifies float32 rounding: the
+    float32 oracle itself sits 4e-5 .. 1.1e-4 away from the float64 evaluation of the same
+    chain (tests/np_model.py), so two float32 implementations cannot agree to 1e-5 there
+    and a bound against the oracle would only measure the oracle's own noise.  The
+    criterion is anchored on truth instead: per channel,
+        err(gpu, f64) <= max(TOL, 1.5 * err(oracle, f64)),
+    i.e. the GPU may not be further from the exact result than the reference arithmetic
+    is (assert_truth_anchored).  No tolerance looser than 1e-5 is expressed against the
+    float32 oracle.
   * int16 outputs: +-1 LSB where the float audio differs across a truncation
-    boundary (count reported), never more.
+    boundary (count reported), never more; on NLMS chains the same truth-anchored rule
+    in LSB against the int16 of the float64 result.
 """
 import os
 
@@ -26,6 +32,19 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _experimental():
+    """the library under test was built with EXPERIMENTAL=1 (not the product build)"""
+    try:
+        import radiodsp_sdr_rx_amd as R
+        return bool(R.load().rdsp_experimental_build())
+    except Exception:
+        return False
+
+
+EXPERIMENTAL = _experimental()
+TAILS = ["16r"] + (["16", "8r", "16m", "8m"] if EXPERIMENTAL else [])
+
+
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
@@ -34,12 +53,14 @@ def torch_cuda():
 
 
 def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None):
-    """tail: None (default kernel) or "16m" / "8m": the matrix-pipe tail kernels (rdsp_tailm.hip)"""
+    """tail: None or "16r" (the product's tail kernel); "16", "8r", "16m", "8m": experimental layouts"""
     from radiodsp_sdr_rx_amd.chain import Chain
     nch, n = iq.shape[0], iq.shape[1]
     ch = Chain(nch, max_blocks_per_call=n // 128 // calls, **cfg)
-    if tail in ("16r", "8r"):   # row layouts of rdsp_tailm.hip (16r = the default): DPP reduction, delay line fed from LDS
-        ch.set_tail_variant(int(tail[:-1]), 2)
+    if tail == "16r":
+        pass
+    elif tail == "8r":  # half-row layout of rdsp_tailm.hip
+        ch.set_tail_variant(8, 2)
     elif tail:          # "16": rdsp_tail.hip; "16m" / "8m": matrix-pipe reduction
         ch.set_tail_variant(int(tail.rstrip("m")), int(tail.endswith("m")))
     apply_setup(ch, setup)
@@ -66,6 +87,35 @@ def oracle_run(oracle, iq, cfg):
 def normwise(y, ref):
     """max over channels of max|y - ref| / max|ref|"""
     return max(np.abs(y[c] - ref[c]).max() / max(np.abs(ref[c]).max(), 1e-30) for c in range(len(ref)))
+
+
+def model_run(iq, cfg):
+    """float64 evaluation of the same chain (tests/np_model.py), one channel at a time"""
+    import np_model
+    return np.stack([np_model.Model(**cfg).process(iq[c]) for c in range(iq.shape[0])])
+
+
+def q15_of(x64):
+    """arm_float_to_q15 of the float64 result (truncate, saturate; CONV:346-347)"""
+    return np.clip(np.trunc(x64 * 32768.0), -32768, 32767).astype(np.int32)
+
+
+def assert_truth_anchored(g32, r32, f64, what, g16=None, r16=None):
+    """NLMS chains: per channel the GPU is no further from the float64 result than
+    max(TOL, 1.5 x the float32 oracle's own distance); int16 likewise, in LSB."""
+    worst = 0.0
+    for c in range(len(f64)):
+        den = max(np.abs(f64[c]).max(), 1e-30)
+        eg = np.abs(g32[c] - f64[c]).max() / den
+        eo = np.abs(r32[c] - f64[c]).max() / den
+        worst = max(worst, eg / max(eo, 1e-30))
+        assert eg <= max(TOL, 1.5 * eo), f"{what} ch {c}: err(gpu,f64) {eg:.3e} vs err(oracle,f64) {eo:.3e}"
+        if g16 is not None:
+            t16 = q15_of(f64[c])
+            lg = np.abs(g16[c].astype(np.int32) - t16).max()
+            lo = np.abs(r16[c].astype(np.int32) - t16).max()
+            assert lg <= max(1, int(np.ceil(1.5 * lo))), f"{what} ch {c}: {lg} LSB vs oracle {lo} LSB from the float64 result"
+    return worst
 
 
 def check_i16(o16, r16):
@@ -124,6 +174,7 @@ FF_CASES = {
 }
 
 
+@pytest.mark.skipif(not EXPERIMENTAL, reason="matrix-core FIR: EXPERIMENTAL=1 builds only")
 @pytest.mark.parametrize("name", ["k2_usb_256", "usb_1024", "lsb_2048", "k4_cw_4096_agc", "spectral_512"])
 def test_matrix_fir_variant_matches_oracle(rdsp, oracle, torch_cuda, name):
     """rdsp_chain_set_fir_variant(1): the decimating FIR as v_mfma GEMM slices (opt-in)"""
@@ -179,12 +230,15 @@ def test_golden_vectors(rdsp, torch_cuda, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     o16, o32, _ = gpu_run(torch_cuda, g["iq"], case["cfg"], setup=case.get("setup"))
     nlms = case["cfg"].get("lms_nr", 0) > 0 or case["cfg"].get("als_mode", "off") != "off"
-    tol = 3e-4 if nlms else TOL  # see module docstring for the NLMS bound
+    if nlms:   # truth-anchored (module docstring): the fixture carries the float64 result too
+        assert_truth_anchored(o32, g["out_f32"], g["out_f64"], name, o16, g["out_i16"])
+        return
+    tol = TOL
     if case["cfg"].get("demod") == "SAM":
         tol = 2e-5               # PLL feedback (tests/test_engine_features.py)
     assert normwise(o32, g["out_f32"]) <= tol
     d = np.abs(o16.astype(np.int32) - g["out_i16"].astype(np.int32))
-    assert d.max() <= (8 if nlms else 1)
+    assert d.max() <= 1
 
 
 # ---- NLMS stages --------------------------------------------------------------------
@@ -235,32 +289,25 @@ NLMS_CASES = {
 }
 
 
-@pytest.mark.parametrize("tail", ["16", "16r", "8r", "16m", "8m"])
+@pytest.mark.parametrize("tail", TAILS)
 @pytest.mark.parametrize("name", sorted(NLMS_CASES))
-def test_chain_with_nlms_matches_oracle_within_conditioning(rdsp, oracle, torch_cuda, name, tail):
-    """tail "16": DPP reduction (rdsp_tail.hip); "16m", "8m": 16 / 8 lanes per channel with the
-    reduction on the matrix pipe (rdsp_tailm.hip)"""
+def test_chain_with_nlms_is_as_close_to_float64_truth_as_the_oracle(rdsp, oracle, torch_cuda, name, tail):
+    """tail "16r": the product's tail kernel (row layout of rdsp_tailm.hip).  The experimental
+    layouts ("16": delay line shifted by DPP; "8r": half a row; "16m", "8m": reduction on the
+    matrix pipe) are only in the library when it is built with EXPERIMENTAL=1."""
     from radiodsp_sdr_rx_amd.chain import synth_iq
     cfg = NLMS_CASES[name]
     nch, nblk = 11 if tail == "8m" else 5, 64          # partly filled last waves (8 / 4 channels per wave)
     iq = synth_iq(nch, nblk * 128)
     o16, o32, _ = gpu_run(torch_cuda, iq, cfg, calls=2, tail=tail)
     r16, r32 = oracle_run(oracle, iq, cfg)
-    # front-end difference with the recursive stages switched off
+    # the front end alone (recursive stages off) meets the north-star tolerance against the oracle
     ff = dict(cfg, lms_nr=0, als_mode="off", agc_mode="off")
     _, f32, _ = gpu_run(torch_cuda, iq, ff)
     _, fr32 = oracle_run(oracle, iq, ff)
-    front_err = normwise(f32, fr32)
-    assert front_err <= TOL
-    # conditioning of the recursion, measured on the oracle alone (1-ulp input gain change)
-    g1 = float(np.float32(1) + np.float32(1.1920929e-07))
-    _, p32 = oracle_run(oracle, iq, dict(cfg, input_gain=g1))
-    kappa = normwise(p32, r32) / 1.1920929e-07
-    bound = max(TOL, 4.0 * kappa * front_err)
-    err = normwise(o32, r32)
-    assert err <= bound, f"{name}: err {err:.3e} bound {bound:.3e} (kappa {kappa:.1f}, front {front_err:.2e})"
-    assert err <= 5e-4
-    assert np.abs(o16.astype(np.int32) - r16.astype(np.int32)).max() <= 16
+    assert normwise(f32, fr32) <= TOL
+    ratio = assert_truth_anchored(o32, r32, model_run(iq, cfg), name, o16, r16)
+    print(f"{name}: worst err(gpu,f64)/err(oracle,f64) = {ratio:.2f}; gpu vs oracle {normwise(o32, r32):.2e}")
 
 
 # ---- streaming state ---------------------------------------------------------------------
@@ -275,7 +322,7 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
     if name == "k3":  # the other tail kernels carry the same state
-        for tail in ("16r", "8r", "16m", "8m"):
+        for tail in TAILS:
             c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail=tail)
             d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail=tail)
             assert np.array_equal(c16, d16) and np.array_equal(c32, d32)
@@ -317,6 +364,36 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda, name, cfg, nch, n
         assert np.array_equal(ref_chain.lms_coeffs(which), ch.lms_coeffs(which))
 
 
+def test_tail_stage_toggled_between_pipelined_calls_is_bitwise_identical(rdsp, torch_cuda):
+    """disableALSfilter / enableALSfilter / set_nr_level between pipelined calls: a call whose tail
+    stage is off packs in the front kernel on the caller's stream, and must wait for the previous
+    call's tail stage (internal stream), which still owns that call's output and the AGC gain."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, nblk = 70, 32
+    plan = ["on", "on", "off", "off", "on", "nr", "off", "on"]   # ALS on/off, DSP-NR instead of ALS
+    iq = synth_iq(nch, nblk * 128 * len(plan))
+    parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
+             for k in range(len(plan))]
+
+    def run(pipelined):
+        ch = Chain(nch, max_blocks_per_call=nblk, **K3)
+        ch.set_pipelined(pipelined)
+        out = torch.zeros((nch, nblk * 32 * len(plan), 2), dtype=torch.int16, device="cuda")
+        for k, what in enumerate(plan):
+            ch.disableALSfilter() if what in ("off", "nr") else ch.enableALSfilter()
+            ch.set_nr_level(20 if what == "nr" else 0)
+            # all calls write into ONE buffer back to back, as a streaming sink would
+            ch.process(parts[k], out=out[:, k * nblk * 32:(k + 1) * nblk * 32])
+        ch.flush()
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), ch.scalars(), ch.lms_coeffs(0), ch.lms_coeffs(1)
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_channel_sub_batches_are_bitwise_identical(rdsp, torch_cuda):
     """rdsp_chain_set_sub_batch: a pipelined call goes out as launches of `sub` channels each
     (ragged last one), front and tail of a sub-batch chained by their own event; nothing changes."""
@@ -353,7 +430,7 @@ def test_front_kernel_variants_agree(rdsp, oracle, torch_cuda):
     cfg = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, agc_mode="medium")
     iq = synth_iq(4, 32 * 128)
     _, r32 = oracle_run(oracle, iq, cfg)
-    for lean, fir in ((0, 0), (1, 0), (0, 1), (1, 1)):   # register-lean x (packed-FMA | matrix) FIR
+    for lean, fir in ((0, 0), (1, 0)) + (((0, 1), (1, 1)) if EXPERIMENTAL else ()):   # register-lean x (packed-FMA | matrix) FIR
         ch = Chain(4, max_blocks_per_call=32, **cfg)
         ch.set_front_variant(lean)
         ch.set_fir_variant(fir)
@@ -463,10 +540,48 @@ def test_full_size_k3_sampled_channels(rdsp, oracle, torch_cuda):
     torch.cuda.synchronize()
     sample = [0, 3, 4, 1023, 2048, 4093, 4095]
     r16, r32 = oracle_run(oracle, iq[sample], K3)
-    assert normwise(o32[sample].cpu().numpy(), r32) <= 3e-4  # NLMS conditioning, see docstring
+    assert_truth_anchored(o32[sample].cpu().numpy(), r32, model_run(iq[sample], K3), "K3 full size",
+                          o16[sample].cpu().numpy(), r16)
     # every channel produced finite, non-trivial audio under AGC
     pw = o32[..., 0].float().pow(2).mean(dim=1)
     assert bool(torch.isfinite(pw).all()) and float(pw.min()) > 1e-6
+
+
+def test_k5_per_gpu_shape_pipelined_sub_batched(rdsp, oracle, torch_cuda):
+    """BASELINE config K5 as one GPU sees it: 8192 channels of the K3 chain in pipelined mode, which
+    is the shape that takes the default 4096-channel sub-batch path (front(A), front(B) on the
+    caller's stream, tail(A), tail(B) on the tail stream).  Three calls of 32 blocks: sampled
+    channels of both sub-batches against the oracle (truth-anchored NLMS criterion), and the
+    whole output bitwise equal to the same chain un-pipelined, state included."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, nblk, calls = 8192, 32, 3
+    iq = synth_iq(nch, nblk * 128 * calls, n_threads=16)
+    dev = torch.from_numpy(iq).cuda()
+    n_out = nblk * 32
+
+    def run(pipelined):
+        ch = Chain(nch, max_blocks_per_call=nblk, **K3)
+        ch.set_pipelined(pipelined)            # sub_batch stays at its default (4096)
+        o16 = torch.zeros((nch, n_out * calls, 2), dtype=torch.int16, device="cuda")
+        o32 = torch.zeros((nch, n_out * calls, 2), dtype=torch.float32, device="cuda")
+        for k in range(calls):
+            ch.process(dev[:, k * nblk * 128:(k + 1) * nblk * 128], out=o16[:, k * n_out:(k + 1) * n_out],
+                       out_f32=o32[:, k * n_out:(k + 1) * n_out])
+        ch.flush()
+        torch.cuda.synchronize()
+        return o16, o32, ch.scalars(), ch.lms_coeffs(1)
+
+    p16, p32, psc, pw = run(True)
+    sample = [0, 1, 2047, 4095, 4096, 4097, 6000, 8191]
+    r16, r32 = oracle_run(oracle, iq[sample], K3)
+    assert_truth_anchored(p32[sample].cpu().numpy(), r32, model_run(iq[sample], K3), "K5 shape",
+                          p16[sample].cpu().numpy(), r16)
+    u16, u32, usc, uw = run(False)
+    assert bool((p16 == u16).all()) and bool((p32 == u32).all())
+    assert np.array_equal(psc, usc) and np.array_equal(pw, uw)
+    pw_ch = p32[..., 0].pow(2).mean(dim=1)
+    assert bool(torch.isfinite(pw_ch).all()) and float(pw_ch.min()) > 1e-6
 
 
 def test_full_size_k4_sampled_channels(rdsp, oracle, torch_cuda):

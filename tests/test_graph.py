@@ -114,6 +114,42 @@ def test_play_queue_and_interrupt_gate(rdsp):
 
 
 @pytest.mark.gpu
+def test_engine_node_with_a_pipelined_chain_is_bit_identical_to_resident_processing(rdsp):
+    """A chain in pipelined mode finishes its output on an internal stream; the engine node
+    flushes before it copies the audio back (3 channels, K3: NLMS tail stage + AGC)."""
+    import torch
+    from cases import K3
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.graph import Graph
+    nch, nblk = 3, 48
+    iq = synth_iq(nch, nblk * 128)
+    ref = Chain(nch, max_blocks_per_call=8, **K3)
+    want = np.concatenate([ref.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * 1024:(k + 1) * 1024])).cuda()).cpu().numpy()
+                           for k in range(nblk // 8)], axis=1)
+    chain = Chain(nch, max_blocks_per_call=8, **K3)
+    chain.set_pipelined(True)
+    g = Graph(nch)
+    g.AudioMemory(60)
+    src, sdr = g.input_node(), g.sdr_node(chain)
+    ql, qr = g.record_queue(), g.record_queue()
+    g.AudioConnection(src, 0, sdr, 0); g.AudioConnection(src, 1, sdr, 1)
+    g.AudioConnection(sdr, 0, ql, 0); g.AudioConnection(sdr, 1, qr, 0)
+    ql.begin(); qr.begin()
+    L, R = [], []
+    for b in range(nblk + 8):
+        if b < nblk:
+            blk = np.ascontiguousarray(iq[:, b * 128:(b + 1) * 128])
+            src.push(np.ascontiguousarray(blk[..., 0]), np.ascontiguousarray(blk[..., 1]))
+        assert g.update_all() == 0
+        while ql.available() > 0 and qr.available() > 0:
+            L.append(ql.readBuffer().copy()); ql.freeBuffer()
+            R.append(qr.readBuffer().copy()); qr.freeBuffer()
+    assert sdr.status() == 0
+    got = np.stack([np.concatenate(L, axis=1), np.concatenate(R, axis=1)], axis=2)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
 def test_k1_one_channel_through_the_graph_matches_oracle(rdsp, oracle):
     """BASELINE config K1 through the update()/connect() API with the GPU engine node."""
     import torch
