@@ -1,0 +1,99 @@
+/*
+ * rdsp_binding.h -- the reference-side binding of INTEGRATION.md section 2, as a file that
+ * meets a compiler: drop-in replacements for the free functions of RDSP_convolutional.h /
+ * RDSP_noise_reduction.h and for the `SDR.` / `preProcessor.` call sites of
+ * RadioDSP_SDR_RX.ino:117-139,177, over the C-ABI of include/rdsp.h.  Plain C.
+ *
+ * A host port of the sketch provides the three transport shims declared below (the roles of
+ * the record/play queues, RDSP_convolutional.h:231-244,344-349) and the two sizes.
+ */
+#ifndef RDSP_BINDING_H
+#define RDSP_BINDING_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+
+#include "rdsp.h"
+
+#ifndef N_CH
+#define N_CH 1          /* receivers on this GPU */
+#endif
+#ifndef MAX_BLOCKS
+#define MAX_BLOCKS 64   /* 128-sample blocks per call and channel */
+#endif
+#define IN_STRIDE ((size_t)MAX_BLOCKS * RDSP_BLOCK_SAMPLES)
+#define OUT_STRIDE (IN_STRIDE / 4)
+
+typedef int boolean; /* Arduino */
+
+/* transport shims supplied by the host program */
+int queued_blocks(void);                                        /* Q_in_L.available(), CONV:231 */
+void upload_queued_iq(int16_t *d_iq, int n_blocks, hipStream_t s); /* readBuffer/freeBuffer, CONV:236-244 */
+void play_audio(const int16_t *d_out, int n_pairs, hipStream_t s); /* getBuffer/playBuffer, CONV:344-349 */
+
+static rdsp_chain_t *g_chain;          /* replaces the globals of RDSP_convolutional.h:34-80 */
+static hipStream_t g_stream;
+static int16_t *g_d_iq, *g_d_out;      /* device staging for N_CH x MAX_BLOCKS blocks */
+static int g_binding_status = RDSP_OK; /* the sketch has no error channel: first failure is kept here */
+
+#define RDSP_BIND_CHECK(call)                                                      \
+  do {                                                                             \
+    int rc_ = (call);                                                              \
+    if (rc_ != RDSP_OK && g_binding_status == RDSP_OK) {                           \
+      g_binding_status = rc_;                                                      \
+      fprintf(stderr, "%s -> %d: %s\n", #call, rc_, rdsp_last_error());            \
+    }                                                                              \
+  } while (0)
+
+static void doConvolutionalInitialize(void) { /* RDSP_convolutional.h:187 */
+  rdsp_chain_config_t cfg = {
+      .fs_in = 96000.0, .decim = 4, .fir_taps = 256, .fir_cut_hz = 10000.0, .nco_hz = 12000.0,
+      .fft_l = 256, .window = 1, .flo_hz = 300.0, .fhi_hz = 4000.0, .filter_on = 1,
+      .demod = RDSP_DEMOD_USB, .als_strength = 20, .agc_mode = RDSP_AGC_OFF,
+      .input_gain = 1.0f, .output_gain = 1.0f, .iq_balance = 1.0f};
+  if (hipStreamCreate(&g_stream) != hipSuccess || hipMalloc((void **)&g_d_iq, N_CH * IN_STRIDE * 4) != hipSuccess ||
+      hipMalloc((void **)&g_d_out, N_CH * OUT_STRIDE * 4) != hipSuccess) {
+    g_binding_status = RDSP_ERR_HIP;
+    return;
+  }
+  RDSP_BIND_CHECK(rdsp_chain_create(&cfg, N_CH, /*device*/ 0, MAX_BLOCKS, &g_chain)); /* runs CONV:187 and :209 */
+}
+static void reInitializeFilter(double lo, double hi) { /* RDSP_convolutional.h:209 */
+  RDSP_BIND_CHECK(rdsp_reInitializeFilter(g_chain, lo, hi, g_stream));
+}
+static void Init_LMS_NR(int strength) { /* RDSP_noise_reduction.h:35 */
+  RDSP_BIND_CHECK(rdsp_Init_LMS_NR(g_chain, strength, g_stream));
+}
+static void doConvolutionalProcessing(float nr, boolean filt, double lo, double hi) { /* CONV:228 */
+  int n = queued_blocks();                     /* Q_in_L.available(), CONV:231 */
+  if (n > MAX_BLOCKS) n = MAX_BLOCKS;
+  n -= n % rdsp_chain_granule_blocks(g_chain);
+  if (n <= 0) return;                          /* the same silent skip as the sketch */
+  upload_queued_iq(g_d_iq, n, g_stream);
+  RDSP_BIND_CHECK(rdsp_doConvolutionalProcessing(g_chain, nr, filt, lo, hi, g_d_iq, IN_STRIDE, n, g_d_out,
+                                                 OUT_STRIDE, g_stream));
+  play_audio(g_d_out, n * RDSP_BLOCK_SAMPLES / 4, g_stream);
+}
+
+/* the engine object keeps its call sites (RadioDSP_SDR_RX.ino:117-139,177) */
+enum { AGCoff = RDSP_AGC_OFF, AGCfast = RDSP_AGC_FAST, AGCmedium = RDSP_AGC_MEDIUM, AGCslow = RDSP_AGC_SLOW };
+enum { LSBmode = RDSP_DEMOD_LSB, USBmode = RDSP_DEMOD_USB, CW_LSBmode = RDSP_DEMOD_CW_LSB,
+       CW_USBmode = RDSP_DEMOD_CW_USB, AMmode = RDSP_DEMOD_AM, SAMmode = RDSP_DEMOD_SAM };
+enum { audioCW = RDSP_AUDIO_CW, audio2100 = RDSP_AUDIO_2100, audio2700 = RDSP_AUDIO_2700, audio3100 = RDSP_AUDIO_3100,
+       audioAM = RDSP_AUDIO_AM, audioWSPR = RDSP_AUDIO_WSPR };
+#define preProcessor_startAutoI2SerrorDetection() RDSP_BIND_CHECK(rdsp_pre_startAutoI2SerrorDetection(g_chain))
+#define preProcessor_swapIQ(b)      RDSP_BIND_CHECK(rdsp_pre_swapIQ(g_chain, (b)))
+#define SDR_enableAGC()             RDSP_BIND_CHECK(rdsp_sdr_enableAGC(g_chain))
+#define SDR_setAGCmode(m)           RDSP_BIND_CHECK(rdsp_sdr_setAGCmode(g_chain, (m)))
+#define SDR_disableALSfilter()      RDSP_BIND_CHECK(rdsp_sdr_disableALSfilter(g_chain))
+#define SDR_disableNoiseBlanker()   RDSP_BIND_CHECK(rdsp_sdr_disableNoiseBlanker(g_chain))
+#define SDR_setInputGain(g)         RDSP_BIND_CHECK(rdsp_sdr_setInputGain(g_chain, (g)))
+#define SDR_setOutputGain(g)        RDSP_BIND_CHECK(rdsp_sdr_setOutputGain(g_chain, (g)))
+#define SDR_setIQgainBalance(g)     RDSP_BIND_CHECK(rdsp_sdr_setIQgainBalance(g_chain, (g)))
+#define SDR_enableAudioFilter()     RDSP_BIND_CHECK(rdsp_sdr_enableAudioFilter(g_chain))
+#define SDR_setAudioFilter(f)       RDSP_BIND_CHECK(rdsp_sdr_setAudioFilter(g_chain, (f), g_stream))
+/* TuningOffset = SDR.setDemodMode(LSBmode);   .ino:139 */
+#define SDR_setDemodMode(m)         rdsp_sdr_setDemodMode(g_chain, (m), g_stream)
+#define SDR_setMute(b)              RDSP_BIND_CHECK(rdsp_sdr_setMute(g_chain, (b)))
+
+#endif
