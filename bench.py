@@ -302,7 +302,7 @@ def main():
     if os.environ.get("RDSP_PRIO"):  # A/B runs: "front_fir_prio,tail_prio"
         fpr, tpr = (int(x) for x in os.environ["RDSP_PRIO"].split(","))
         assert chain.lib.rdsp_chain_set_priorities(chain.h, fpr, tpr) == 0
-    if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 packed-FMA FIR, 1 matrix FIR
+    if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 direct-form decimator, 2 frequency domain (default: automatic)
         chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]
@@ -361,11 +361,15 @@ def main():
         # sample, the chain's own figure) unless the tail kernel -- 4 B in + 4 B out per OUTPUT sample --
         # runs clearly longer; in pipelined mode both run for the whole step, within a few percent
         if tail_avg > 1.10 * front_avg:
-            dom, dom_ms, B_dom = "rdsp_tail_kernel", tail_avg, 8.0 / decim
+            dom, dom_ms, B_own = "rdsp_tail_kernel", tail_avg, 8.0 / decim
         else:
-            dom, dom_ms, B_dom = "rdsp_front_kernel", front_avg, B
-        bytes_per_launch = B_dom * nch * n_samples
+            dom, dom_ms, B_own = "rdsp_front_kernel", front_avg, B
+        # roofline.achieved: SURVEY 8(d)'s figure (B = 5 bytes per input IQ sample of the chain) x the
+        # samples one launch processes / the dominant kernel's average duration; the kernel's own
+        # algorithmic bytes (the tail kernel only moves 4 B in + 4 B out per OUTPUT sample) go beside it
+        bytes_per_launch = B * nch * n_samples
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        own = B_own * nch * n_samples / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # counters of a committed PMC pass of this configuration (tests/profile_round.sh ->
         # profiles/counters.json): HBM bytes and VALU busy fraction per launch of each kernel
         ctr = {}
@@ -418,6 +422,7 @@ def main():
             # fraction of the dominant kernel from the committed PMC pass.
             "roofline": {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_own": {"algorithmic_bytes_per_sample": B_own, "achieved": own, "frac": own / HBM_PEAK_GBS},
                          "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved_tf / FP32_PEAK_TFLOPS,
                                   "flop_per_sample_model": FLOP_PER_SAMPLE.get(args.config),

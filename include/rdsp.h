@@ -229,10 +229,16 @@ int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
-/* decimating FIR variant: 0 packed FMAs (the product).  EXPERIMENTAL=1 builds: 1 matrix-core
- * GEMM slices (+10 % at K2, outside the north-star's "no MFMA"), -1 matrix unless the tail stage
- * shares the SIMDs */
-int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix);
+/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]): -1 (default) evaluates it in the
+ * frequency domain -- polyphase overlap-save: four low-rate transforms, branch spectra, one inverse
+ *  -- where that kernel exists (decim 4, fft_l <= 1024, noise blanker off) and in the
+ * direct form (packed FMAs) elsewhere; 0 the direct form always; 2 the frequency domain
+ * (RDSP_ERR_UNSUPPORTED where it does not exist).  Both are the same exact linear convolution with
+ * the same taps.  The frequency-domain frames are anchored at each call's first sample, so with it
+ * a stream cut into calls differently differs in rounding (~2e-7); with the direct form any call
+ * split gives the same bits.  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless
+ * the tail stage shares the SIMDs. */
+int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant);
 /* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row,
  * DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: lanes per channel 16 or 8;
  * matrix_reduce 0: delay line shifted by DPP (experimental/rdsp_tail_shift.hip), 2: row / half-row

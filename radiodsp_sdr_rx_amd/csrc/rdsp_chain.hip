@@ -85,6 +85,7 @@ struct rdsp_chain {
   hipEvent_t ev_fence = nullptr;      /* after the most recent front launch */
   bool fence_valid = false;
   float *d_fir_hc = nullptr;
+  float2 *d_fd_mask = nullptr; /* [4][N] branch spectra of the frequency-domain decimator (one wave per channel: N <= 1024) */
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
   float *d_scal = nullptr;
@@ -119,7 +120,9 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto (= full), 0 full-register front kernel, 1 lean */
-  int fir_mode = 0;   /* 0 packed-FMA FIR (default: the north-star path has no MFMA), 1 matrix FIR, -1 matrix unless the tail shares the SIMDs */
+  int fir_mode = -1;  /* -1 auto: frequency-domain decimator where it exists, else the direct form; 0 direct form
+                         (packed FMAs); 2 frequency domain; EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix
+                         unless the tail stage shares the SIMDs */
   int front_fir_prio = 2, tail_prio = 2; /* wave priorities while both kernels share the SIMDs (measured balance) */
   /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
    * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
@@ -381,6 +384,15 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
       return RDSP_ERR_INVALID;
     }
     HIP_TRY(hipMemcpy(c->d_fir_hc, hc.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
+    if (c->N / rdsp_plan_radix(c->N) == 64) {
+      std::vector<float> img(2 * 4 * (size_t)c->N);
+      if (rdsp_fd_decimator_image(c->fir_nat.data(), c->N, img.data()) != 0) {
+        rdsp_set_error("decimator spectra failed");
+        return RDSP_ERR_INVALID;
+      }
+      HIP_TRY(hipMalloc((void **)&c->d_fd_mask, img.size() * sizeof(float)));
+      HIP_TRY(hipMemcpy(c->d_fd_mask, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   /* boot order of the sketch: doConvolutionalInitialize (INO:180, mask from the
    * still-zero taps) then reInitializeFilter (INO:183) */
@@ -393,7 +405,7 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_fd_mask, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
@@ -605,7 +617,11 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
    * its waves and a tail wave fit one SIMD, and the lean variant's twiddle chains only cost */
   fp.lean = (c->lean_mode < 0) ? 0 : c->lean_mode;
   fp.front_prio = piped ? c->front_fir_prio : 0;
-  fp.fir_matrix = (c->fir_mode < 0) ? (piped ? 0 : 1) : c->fir_mode;
+  fp.fir_matrix = (c->fir_mode == 3) ? (piped ? 0 : 1) : (c->fir_mode == 1);
+  /* frequency-domain decimator: one-wave kernels only; the noise blanker works on the direct
+   * form's chunk windows, so a chain with the blanker on keeps the direct form */
+  fp.fir_fd = ((c->fir_mode == 2 || c->fir_mode == -1) && c->d_fd_mask && !c->nb_on) ? 1 : 0;
+  fp.fd_mask = c->d_fd_mask;
   fp.mid_q = c->d_mid_q[0];
   if (piped) {
     fp.mid = slot ? c->d_midx[slot - 1] : c->d_mid;
@@ -1075,20 +1091,26 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   c->tail_prio = tail_prio;
   return RDSP_OK;
 }
-/* decimating FIR of the front kernel: 0 = packed FMAs (default), 1 = v_mfma GEMM slices,
- * -1 = matrix unless the tail stage runs concurrently (where it loses).  Same taps and
- * products; the sums associate differently (~1e-7).  Opt-in: the north-star defines the path
- * without MFMA, and the measurement agrees that there is no idle pipe to win. */
-extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int matrix) {
+/* stage A3 of the front kernel.  -1 (default): in the frequency domain where that kernel exists
+ * (decim 4, fft_l <= 1024, noise blanker off), else the direct form; 0: direct form (packed FMAs)
+ * always -- the one whose results do not depend on how a stream is cut into calls, bit for bit;
+ * 2: frequency domain (RDSP_ERR_UNSUPPORTED where it does not exist).  Same taps, same linear
+ * convolution; the sums associate differently (~2e-7).  EXPERIMENTAL=1 builds: 1 = v_mfma GEMM
+ * slices, 3 = the same unless the tail stage runs concurrently. */
+extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   NEED(c);
-  if (matrix < -1 || matrix > 1) return RDSP_ERR_INVALID;
+  if (variant < -1 || variant > 3) return RDSP_ERR_INVALID;
+  if (variant == 2 && !c->d_fd_mask) {
+    rdsp_set_error("the frequency-domain decimator needs decim = 4 and fft_l <= 1024");
+    return RDSP_ERR_UNSUPPORTED;
+  }
 #ifndef RDSP_EXPERIMENTAL
-  if (matrix != 0) {
+  if (variant == 1 || variant == 3) {
     rdsp_set_error("the matrix-core FIR is only in EXPERIMENTAL=1 builds of the library");
     return RDSP_ERR_UNSUPPORTED;
   }
 #endif
-  c->fir_mode = matrix;
+  c->fir_mode = variant;
   return RDSP_OK;
 }
 /* tail-kernel variant: 16 lanes per channel with the DPP reduction (rdsp_tail.hip), or 16 / 8

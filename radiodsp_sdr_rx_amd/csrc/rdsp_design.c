@@ -178,6 +178,39 @@ int rdsp_design_decimator(int ntaps, double cut_hz, double fs, int window, float
   return 0;
 }
 
+/* Spectra of the decimator's polyphase branches for the frequency-domain decimator
+ * (rdsp_front_fd_kernel): g_r[k] = h[4k - r], k = 0..64 (zero outside the 256 taps), N-point
+ * DFT in double precision, scaled by 1/N, stored like the filter mask (digit-reversed,
+ * thread-major: element e of thread t at e*NT + t), branch r at image + 2*r*N floats. */
+int rdsp_fd_decimator_image(const float *h_nat, int fft_l, float *image) {
+  const int P = rdsp_plan_radix(fft_l);
+  if (P == 0 || fft_l < 128) return -1;
+  const int nt = fft_l / P;
+  const double inv_n = 1.0 / (double)fft_l;
+  for (int r = 0; r < 4; r++) {
+    double g[65];
+    for (int k = 0; k <= 64; k++) {
+      const int t = 4 * k - r;
+      g[k] = (t >= 0 && t < 256) ? (double)h_nat[t] : 0.0;
+    }
+    for (int t = 0; t < nt; t++)
+      for (int e = 0; e < P; e++) {
+        const int bin = rdsp_bin_of_pos(fft_l, t * P + e);
+        double re = 0.0, im = 0.0;
+        for (int k = 0; k <= 64; k++) {
+          const int m = (int)(((long long)bin * k) % fft_l);
+          const double a = -2.0 * kPi * (double)m / (double)fft_l;
+          re += g[k] * cos(a);
+          im += g[k] * sin(a);
+        }
+        const size_t o = (size_t)r * (size_t)fft_l + (size_t)e * (size_t)nt + (size_t)t;
+        image[2 * o] = (float)(re * inv_n);
+        image[2 * o + 1] = (float)(im * inv_n);
+      }
+  }
+  return 0;
+}
+
 /* NCO: phase increment in turns*2^32; constant rotations for k samples */
 uint32_t rdsp_nco_dphi(double hz, double fs) {
   const double turns = hz / fs;

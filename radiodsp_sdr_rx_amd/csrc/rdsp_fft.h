@@ -58,6 +58,32 @@ RDSP_HD float2 cmul_uniform(float2 a, float2 b) {
   return cmul(a, b);
 #endif
 }
+/* acc + a * b: two packed FMAs */
+RDSP_HD float2 cmac(float2 acc, float2 a, float2 b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y}, cv = {acc.x, acc.y};
+  rdsp_v2f t, r;
+  /* t = (acc.x - a.y b.y, acc.y + a.y b.x) */
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(av), "v"(bv), "v"(cv));
+  /* r = (a.x b.x + t.x, a.x b.y + t.y) */
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  return make_float2(r.x, r.y);
+#else
+  return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, acc.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, acc.y)));
+#endif
+}
+/* a * conj(b) with a wave-uniform b in scalar registers */
+RDSP_HD float2 cmulc_uniform(float2 a, float2 b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
+  rdsp_v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "s"(bv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "s"(bv), "v"(t));
+  return make_float2(r.x, r.y);
+#else
+  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(-a.x, b.y, a.y * b.x));
+#endif
+}
 RDSP_HD float2 cmulc(float2 a, float2 b) { /* a * conj(b) */
 #ifdef __HIP_DEVICE_COMPILE__
   const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};

@@ -53,7 +53,10 @@ struct RdspFrontParams {
   int vad_lo, vad_hi;      /* inclusive natural bin range                    */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
   int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */
-  int fir_matrix;          /* 1: decimating FIR as v_mfma GEMM slices (not beside a tail wave) */
+  int fir_matrix;          /* 1: decimating FIR as v_mfma GEMM slices (EXPERIMENTAL builds)    */
+  int fir_fd;              /* 1: decimator in the frequency domain (rdsp_front_fd_kernel)      */
+  const float2 *fd_mask;   /* [4][N] spectra of the polyphase branches g_r[k] = h[4k - r], /N,
+                              digit-reversed thread-major like the filter masks               */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
   int agc_on;
   float agc_attack, agc_decay;

@@ -48,6 +48,202 @@ struct FrontLds {
   static constexpr int TAPS_N = (DECIM == 4) ? (FM ? RDSP_HZ_N / 2 : 128) : 0;
   static constexpr size_t BYTES = (size_t)(XS_N + HB_N + WB_N + TAPS_N) * sizeof(float2) + 64 * sizeof(float);
 };
+/* ---- A5/A6 + epilogue: one overlap-save frame of H = N/2 new samples ------------------
+ * Shared by the front kernels (direct-form and FFT-domain decimator).  fetch(i) returns new
+ * sample i of the hop from wherever the producer left it in LDS. */
+template <int N, int P, bool WALIAS, typename TW, typename FETCH>
+__device__ __forceinline__ void front_frame(const RdspFrontParams &p, const RdspGroup &G, const TW &tw,
+                                            const LdsBases<N, P, WALIAS> &lb, float2 *wb, float *red,
+                                            const float2 (&mreg)[P], uint32_t vadbits, float vad_inv,
+                                            float2 (&vprev)[P / 2], float &nfloor, float &agc_g, float &am_dc,
+                                            int &frame_idx, size_t ch, int tid, FETCH fetch) {
+  using PL = FftPlan<N, P>;
+  constexpr int NT = PL::NT;
+  constexpr int NW = NT / 64;
+  constexpr int H = N / 2;
+  constexpr int PH = P / 2;
+  constexpr int NB = H / RDSP_BLOCK; /* 128-blocks per hop */
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  {
+  float2 v[P];
+  /* CONV:267-285: [previous hop | current hop]; CONV:274-278: the current hop is
+   * the next frame's previous hop (this thread's elements stay in its registers) */
+#pragma unroll
+  for (int j = 0; j < PH; j++) {
+    v[j] = vprev[j];
+    v[j + PH] = fetch(tid + j * NT);
+    vprev[j] = v[j + PH];
+  }
+  auto sync = []() { __syncthreads(); };
+  {
+    float2 twp[P - 1];
+    tw.template get<0>(twp);
+    fwd_pass0_store<N, P>(lb, v, wb, twp); /* CONV:291 */
+  }
+  __syncthreads();
+  fwd_mid_all<N, P, 1, PL::NP - 1, WALIAS>(lb, wb, tw, sync);
+  fwd_pass_last<N, P>(lb, v, wb);
+
+  if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
+    float mag[P], rmag[P];
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      /* |X| and 1/|X| from one v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt and a
+       * division per bin; the floor keeps rsq finite on empty bins, where |X| = 0 * r = 0 */
+      const float pw = v[e].x * v[e].x + v[e].y * v[e].y;
+      rmag[e] = __builtin_amdgcn_rsqf(fmaxf(pw, 1e-30f));
+      mag[e] = pw * rmag[e];                              /* SPEC:182 */
+      part += ((vadbits >> e) & 1u) ? mag[e] : 0.f;       /* SPEC:194-197 */
+    }
+    float tot = wave_sum(part);
+    if constexpr (NW > 1) {
+      if (lane == 0) red[wave] = tot;
+      __syncthreads();
+      tot = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
+    }
+    float th = tot * vad_inv;                      /* SPEC:200 */
+    th = th * p.spectral_k;                        /* SPEC:202 */
+    nfloor += (th - nfloor) * 0.65f;               /* SPEC:205 */
+    nfloor = nfloor > 0.f ? nfloor : 0.f;          /* SPEC:206 */
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      /* SPEC:213-217, 226-235: X * mag'/mag with mag' = 0.2 mag at or under the floor and
+       * mag - floor above it, i.e. a gain of 0.2 or 1 - floor/mag (an empty bin stays 0) */
+      const float sc = (mag[e] <= nfloor) ? 0.2f : fmaf(-nfloor, rmag[e], 1.f);
+      v[e].x *= sc;
+      v[e].y *= sc;
+    }
+  }
+  /* CONV:301: spectrum x mask */
+#pragma unroll
+  for (int e = 0; e < P; e++) v[e] = cmul(v[e], mreg[e]);
+
+  inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
+  __syncthreads();
+  inv_mid_all<N, P, PL::NP - 2, WALIAS>(lb, wb, tw, sync);
+  {
+    float2 twp[P - 1];
+    tw.template get<0>(twp);
+    inv_pass0_load<N, P>(lb, v, wb, twp);
+  }
+  __syncthreads(); /* wb is free again (next frame / taps / FIR partials) */
+
+  /* CONV:314-318: keep the second half.  v[PH + jj] = y[N/2 + tid + jj*NT] */
+  float L[PH], R[PH];
+#pragma unroll
+  for (int jj = 0; jj < PH; jj++) {
+    L[jj] = v[PH + jj].x;
+    R[jj] = v[PH + jj].y;
+  }
+
+  /* helper: per-128-block sums of a per-thread value over the workgroup */
+  float bs[NB];
+  auto block_sums = [&](const float(&pv)[PH]) {
+#pragma unroll
+    for (int jj = 0; jj < PH; jj++) {
+      float s = wave_sum(pv[jj]);
+      if (lane == 0) red[wave * PH + jj] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+#pragma unroll
+        for (int jj = 0; jj < PH; jj++)
+          if (((jj * NT + w * 64) >> 7) == b) s += red[w * PH + jj];
+      bs[b] = s;
+    }
+    __syncthreads();
+  };
+
+  if (G.demod == RDSP_K_DEMOD_REAL) {
+#pragma unroll
+    for (int jj = 0; jj < PH; jj++) R[jj] = L[jj];
+  } else if (G.demod == RDSP_K_DEMOD_AM) {
+    float a[PH];
+#pragma unroll
+    for (int jj = 0; jj < PH; jj++) a[jj] = __builtin_amdgcn_sqrtf(L[jj] * L[jj] + R[jj] * R[jj]);
+    block_sums(a);
+    float d0[NB], d1[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      float m = bs[b] / (float)RDSP_BLOCK;
+      float dn = am_dc + 0.25f * (m - am_dc);
+      d0[b] = am_dc;
+      d1[b] = dn;
+      am_dc = dn;
+    }
+#pragma unroll
+    for (int jj = 0; jj < PH; jj++) {
+      const int b0 = (jj * NT) >> 7;
+      float s0 = d0[b0], s1 = d1[b0];
+      if constexpr (NT == 256) {
+        if (tid >= 128) { s0 = d0[b0 + 1]; s1 = d1[b0 + 1]; }
+      }
+      int i = (tid + jj * NT) & 127;
+      float dc = s0 + (s1 - s0) * ((float)(i + 1) / (float)RDSP_BLOCK);
+      L[jj] = a[jj] - dc;
+      R[jj] = L[jj];
+    }
+  }
+
+  const size_t tout = (size_t)frame_idx * H;
+  if (p.to_mid) {
+#pragma unroll
+    for (int jj = 0; jj < PH; jj++) p.mid[ch * p.mid_stride + tout + tid + jj * NT] = L[jj];
+    if (G.demod == RDSP_K_DEMOD_SAM) { /* the PLL stage needs the quadrature part too */
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) p.mid_q[ch * p.mid_stride + tout + tid + jj * NT] = R[jj];
+    }
+  } else {
+    if (p.agc_on) {
+      float pw[PH];
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) pw[jj] = L[jj] * L[jj] + R[jj] * R[jj];
+      block_sums(pw);
+      float g0[NB], g1[NB];
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        float pp = bs[b] / (float)(2 * RDSP_BLOCK);
+        float rms = __builtin_amdgcn_sqrtf(pp); /* 1 ulp; the loop gain is a contraction */
+        float gt = 0.25f * __builtin_amdgcn_rcpf(rms + 1e-6f);
+        gt = fminf(gt, 100.0f);
+        float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
+        float gn = agc_g + coef * (gt - agc_g);
+        g0[b] = agc_g;
+        g1[b] = gn;
+        agc_g = gn;
+      }
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) {
+        const int b0 = (jj * NT) >> 7;
+        float s0 = g0[b0], s1 = g1[b0];
+        if constexpr (NT == 256) {
+          if (tid >= 128) { s0 = g0[b0 + 1]; s1 = g1[b0 + 1]; }
+        }
+        int i = (tid + jj * NT) & 127;
+        float g = s0 + (s1 - s0) * ((float)(i + 1) / (float)RDSP_BLOCK);
+        L[jj] *= g;
+        R[jj] *= g;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < PH; jj++) {
+      float l = L[jj] * p.out_gain, r = R[jj] * p.out_gain;
+      size_t o = ch * p.out_stride + tout + tid + jj * NT;
+      p.out_i16[o] = pack_lr(l, r); /* CONV:346-347 */
+      if (p.out_f32) p.out_f32[o] = make_float2(l, r);
+    }
+  }
+  frame_idx++;
+  }
+}
+
 /* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
  * mask slice re-read per chunk).  It pays at radix 16, where it buys the second wave per
  * SIMD.  At radix 8 it was what let two front waves and a tail wave share the 512-register
@@ -71,7 +267,6 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
   constexpr int CH_IN = CH_OUT * DECIM;
   constexpr int FPC = (H >= CH_OUT) ? 1 : CH_OUT / H; /* frames per chunk */
   constexpr int CPF = (H >= CH_OUT) ? H / CH_OUT : 1; /* chunks per frame */
-  constexpr int NB = H / RDSP_BLOCK;                  /* 128-blocks per hop */
   using LY = FrontLds<N, P, DECIM, FMX>;
   constexpr bool ALIAS = LY::ALIAS;
   constexpr bool FM = LY::FM;
@@ -364,181 +559,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
 #pragma unroll 1
     for (int f = 0; f < FPC; f++) {
       const float2 *hnew = hb + f * H;
-      float2 v[P];
-      /* CONV:267-285: [previous hop | current hop]; CONV:274-278: the current hop is
-       * the next frame's previous hop (this thread's elements stay in its registers) */
-#pragma unroll
-      for (int j = 0; j < PH; j++) {
-        v[j] = vprev[j];
-        v[j + PH] = hnew[tid + j * NT];
-        vprev[j] = v[j + PH];
-      }
-      auto sync = []() { __syncthreads(); };
-      {
-        float2 twp[P - 1];
-        tw.template get<0>(twp);
-        fwd_pass0_store<N, P>(lb, v, wb, twp); /* CONV:291 */
-      }
-      __syncthreads();
-      fwd_mid_all<N, P, 1, PL::NP - 1, WALIAS>(lb, wb, tw, sync);
-      fwd_pass_last<N, P>(lb, v, wb);
-
-      if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum */
-        float mag[P], rmag[P];
-        float part = 0.f;
-#pragma unroll
-        for (int e = 0; e < P; e++) {
-          /* |X| and 1/|X| from one v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt and a
-           * division per bin; the floor keeps rsq finite on empty bins, where |X| = 0 * r = 0 */
-          const float pw = v[e].x * v[e].x + v[e].y * v[e].y;
-          rmag[e] = __builtin_amdgcn_rsqf(fmaxf(pw, 1e-30f));
-          mag[e] = pw * rmag[e];                              /* SPEC:182 */
-          part += ((vadbits >> e) & 1u) ? mag[e] : 0.f;       /* SPEC:194-197 */
-        }
-        float tot = wave_sum(part);
-        if constexpr (NW > 1) {
-          if (lane == 0) red[wave] = tot;
-          __syncthreads();
-          tot = (red[0] + red[1]) + (red[2] + red[3]);
-          __syncthreads();
-        }
-        float th = tot * vad_inv;                      /* SPEC:200 */
-        th = th * p.spectral_k;                        /* SPEC:202 */
-        nfloor += (th - nfloor) * 0.65f;               /* SPEC:205 */
-        nfloor = nfloor > 0.f ? nfloor : 0.f;          /* SPEC:206 */
-#pragma unroll
-        for (int e = 0; e < P; e++) {
-          /* SPEC:213-217, 226-235: X * mag'/mag with mag' = 0.2 mag at or under the floor and
-           * mag - floor above it, i.e. a gain of 0.2 or 1 - floor/mag (an empty bin stays 0) */
-          const float sc = (mag[e] <= nfloor) ? 0.2f : fmaf(-nfloor, rmag[e], 1.f);
-          v[e].x *= sc;
-          v[e].y *= sc;
-        }
-      }
-      /* CONV:301: spectrum x mask */
-#pragma unroll
-      for (int e = 0; e < P; e++) v[e] = cmul(v[e], mreg[e]);
-
-      inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
-      __syncthreads();
-      inv_mid_all<N, P, PL::NP - 2, WALIAS>(lb, wb, tw, sync);
-      {
-        float2 twp[P - 1];
-        tw.template get<0>(twp);
-        inv_pass0_load<N, P>(lb, v, wb, twp);
-      }
-      __syncthreads(); /* wb is free again (next frame / taps / FIR partials) */
-
-      /* CONV:314-318: keep the second half.  v[PH + jj] = y[N/2 + tid + jj*NT] */
-      float L[PH], R[PH];
-#pragma unroll
-      for (int jj = 0; jj < PH; jj++) {
-        L[jj] = v[PH + jj].x;
-        R[jj] = v[PH + jj].y;
-      }
-
-      /* helper: per-128-block sums of a per-thread value over the workgroup */
-      float bs[NB];
-      auto block_sums = [&](const float(&pv)[PH]) {
-#pragma unroll
-        for (int jj = 0; jj < PH; jj++) {
-          float s = wave_sum(pv[jj]);
-          if (lane == 0) red[wave * PH + jj] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-          float s = 0.f;
-#pragma unroll
-          for (int w = 0; w < NW; w++)
-#pragma unroll
-            for (int jj = 0; jj < PH; jj++)
-              if (((jj * NT + w * 64) >> 7) == b) s += red[w * PH + jj];
-          bs[b] = s;
-        }
-        __syncthreads();
-      };
-
-      if (G.demod == RDSP_K_DEMOD_REAL) {
-#pragma unroll
-        for (int jj = 0; jj < PH; jj++) R[jj] = L[jj];
-      } else if (G.demod == RDSP_K_DEMOD_AM) {
-        float a[PH];
-#pragma unroll
-        for (int jj = 0; jj < PH; jj++) a[jj] = __builtin_amdgcn_sqrtf(L[jj] * L[jj] + R[jj] * R[jj]);
-        block_sums(a);
-        float d0[NB], d1[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-          float m = bs[b] / (float)RDSP_BLOCK;
-          float dn = am_dc + 0.25f * (m - am_dc);
-          d0[b] = am_dc;
-          d1[b] = dn;
-          am_dc = dn;
-        }
-#pragma unroll
-        for (int jj = 0; jj < PH; jj++) {
-          const int b0 = (jj * NT) >> 7;
-          float s0 = d0[b0], s1 = d1[b0];
-          if constexpr (NT == 256) {
-            if (tid >= 128) { s0 = d0[b0 + 1]; s1 = d1[b0 + 1]; }
-          }
-          int i = (tid + jj * NT) & 127;
-          float dc = s0 + (s1 - s0) * ((float)(i + 1) / (float)RDSP_BLOCK);
-          L[jj] = a[jj] - dc;
-          R[jj] = L[jj];
-        }
-      }
-
-      const size_t tout = (size_t)frame_idx * H;
-      if (p.to_mid) {
-#pragma unroll
-        for (int jj = 0; jj < PH; jj++) p.mid[ch * p.mid_stride + tout + tid + jj * NT] = L[jj];
-        if (G.demod == RDSP_K_DEMOD_SAM) { /* the PLL stage needs the quadrature part too */
-#pragma unroll
-          for (int jj = 0; jj < PH; jj++) p.mid_q[ch * p.mid_stride + tout + tid + jj * NT] = R[jj];
-        }
-      } else {
-        if (p.agc_on) {
-          float pw[PH];
-#pragma unroll
-          for (int jj = 0; jj < PH; jj++) pw[jj] = L[jj] * L[jj] + R[jj] * R[jj];
-          block_sums(pw);
-          float g0[NB], g1[NB];
-#pragma unroll
-          for (int b = 0; b < NB; b++) {
-            float pp = bs[b] / (float)(2 * RDSP_BLOCK);
-            float rms = __builtin_amdgcn_sqrtf(pp); /* 1 ulp; the loop gain is a contraction */
-            float gt = 0.25f * __builtin_amdgcn_rcpf(rms + 1e-6f);
-            gt = fminf(gt, 100.0f);
-            float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
-            float gn = agc_g + coef * (gt - agc_g);
-            g0[b] = agc_g;
-            g1[b] = gn;
-            agc_g = gn;
-          }
-#pragma unroll
-          for (int jj = 0; jj < PH; jj++) {
-            const int b0 = (jj * NT) >> 7;
-            float s0 = g0[b0], s1 = g1[b0];
-            if constexpr (NT == 256) {
-              if (tid >= 128) { s0 = g0[b0 + 1]; s1 = g1[b0 + 1]; }
-            }
-            int i = (tid + jj * NT) & 127;
-            float g = s0 + (s1 - s0) * ((float)(i + 1) / (float)RDSP_BLOCK);
-            L[jj] *= g;
-            R[jj] *= g;
-          }
-        }
-#pragma unroll
-        for (int jj = 0; jj < PH; jj++) {
-          float l = L[jj] * p.out_gain, r = R[jj] * p.out_gain;
-          size_t o = ch * p.out_stride + tout + tid + jj * NT;
-          p.out_i16[o] = pack_lr(l, r); /* CONV:346-347 */
-          if (p.out_f32) p.out_f32[o] = make_float2(l, r);
-        }
-      }
-      frame_idx++;
+      front_frame<N, P, WALIAS>(p, G, tw, lb, wb, red, mreg, vadbits, vad_inv, vprev, nfloor, agc_g, am_dc, frame_idx,
+                                ch, tid, [&](int i) { return hnew[i]; }); /* advances frame_idx */
     }
   }
 
@@ -560,6 +582,208 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     p.st_scal[ch * 4 + 2] = am_dc;
     p.st_scal[ch * 4 + 3] = nb_level;
   }
+}
+
+/* ---- front kernel with the decimator in the frequency domain -----------------------------
+ * Same chain as rdsp_front_kernel<N, P, 4, ...>; stage A3 (y[m] = sum_{k<256} h[k] x[4m - k]) is
+ * evaluated as a polyphase overlap-save convolution instead of 1024 packed FMAs per chunk and lane:
+ *     x[4q + r] = X_r[q]  (r = 0..3: the four int16 pairs of one aligned 16-byte load),
+ *     y[m] = sum_r sum_{k<=64} g_r[k] X_r[m - k],   g_r[k] = h[4k - r]  (zero outside 0..255),
+ * i.e. four N-point forward transforms of the mixed input at the LOW rate, a multiply-accumulate
+ * with the branch spectra G_r (host-computed, /N, digit-reversed like the filter mask) and ONE
+ * inverse transform: N - 64 valid outputs per frame.  That is the 4N-point overlap-save decimator
+ * with its first two radix-2 levels folded into the masks (only N of the 4N bins survive the
+ * fold by 4).  Per frame and lane at N = 512: 4 x 183 + 64 + 183 = 980 VALU instructions for
+ * 1792 input samples, against 1792 packed FMAs in the direct form.
+ *
+ * Layout: one wave per channel; lane t owns window quads t + 64 j (j < P), exactly the
+ * x[t + j NT] the first FFT pass wants, so the input goes from the 16-byte global loads straight
+ * into the transform's registers -- no polyphase planes in LDS.  Consecutive windows overlap by 64
+ * quads (the 256 raw samples of the FIR history): the j = P-1 quads of one frame are the j = 0
+ * quads of the next and stay in registers; HBM is still read exactly once.  Decimated samples go
+ * into a ring in LDS from which the overlap-save frames (front_frame) take N/2 at a time.
+ *
+ * Frames are anchored at the call's first sample and the last one of a call is partial (inputs
+ * past the end of the call are zeros; every output depends on inputs at or before its own time
+ * only, so the valid ones are exact).  State is the same 256 raw samples as the direct form.
+ * A stream cut into calls differently rounds differently (the frame grid moves): bitwise
+ * identity across call splits holds for the direct form only; everything else (pipelining,
+ * sub-batches, channel partition) stays bit-identical. */
+template <int N, int P, bool LEAN, bool PRE>
+__global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
+  using PL = FftPlan<N, P>;
+  constexpr int NT = PL::NT;
+  constexpr int H = N / 2;
+  constexpr int PH = P / 2;
+  constexpr int VAL = N - 64; /* valid outputs per decimator frame */
+  constexpr int RING = 2 * N; /* >= (H - 1) + VAL, power of two */
+  static_assert(NT == 64, "one wave per channel");
+  static_assert(VAL == 64 * (P - 1), "the last quad column of a frame is the first of the next");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *ring = reinterpret_cast<float2 *>(smem_raw);
+  float2 *wb = ring + RING;
+  float *red = reinterpret_cast<float *>(wb + PL::WB);
+
+  const bool SWAP_IQ = PRE && p.swap_iq != 0;
+  const int tid = threadIdx.x;
+  const size_t ch = (size_t)p.ch_base + blockIdx.x;
+  const uint32_t *iq = p.iq + ch * p.in_stride;
+  RdspGroup G;
+  {
+    const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
+    const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
+    uint32_t r[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) r[i] = (i < 24) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gw[i]) : 0u;
+    G = __builtin_bit_cast(RdspGroup, r);
+  }
+  const int total = p.n_chunks * 256; /* outputs = input quads of this call */
+
+  /* raw quads of frame 0: column 0 is the FIR history (the 64 quads before the call) */
+  uint4 rq[P];
+  rq[0] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * tid);
+#pragma unroll
+  for (int j = 1; j < P; j++) {
+    const int q = tid + 64 * (j - 1);
+    rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  Twiddles<N, P, LEAN> tw;
+  tw.init(tid);
+  LdsBases<N, P, false> lb;
+  make_lds_bases<N, P, false>(tid, lb);
+  uint32_t vadbits = 0;
+#pragma unroll
+  for (int e = 0; e < P; e++) {
+    int k = bin_of_pos<N, P>(tid * P + e);
+    if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+  }
+  float nfloor = p.st_scal[ch * 4 + 0];
+  const float vad_inv = 1.0f / (float)(p.vad_hi - p.vad_lo);
+  float agc_g = p.st_scal[ch * 4 + 1];
+  float am_dc = p.st_scal[ch * 4 + 2];
+  float2 vprev[PH];
+#pragma unroll
+  for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
+  int frame_idx = 0;
+  int produced = 0, consumed = 0;
+  auto sync = []() { __syncthreads(); };
+
+#pragma unroll 1
+  for (int fr = 0; produced < total; fr++) {
+    /* ---- A2: phasors of this lane's P quad columns (sample 4 q + r of a quad follows by rot_r) */
+    const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + tid); /* absolute index of column 0 */
+    float2 pj[P];
+    {
+      float2 b1 = make_float2(1.f, 0.f);
+      if (G.dphi != 0u) b1 = nco_phasor_alu((nq + 256u) * G.dphi);
+      pj[1] = b1;
+      if constexpr (P > 2) pj[2] = cmul_pinned_u(b1, G.rotp1);
+      if constexpr (P > 3) pj[3] = cmul_pinned_u(b1, G.rotp2);
+#pragma unroll
+      for (int j = 4; j < P; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotp3);
+      /* column 0: history of the previous call in frame 0 (mixed with the increment it came in
+       * with), else one column before b1 */
+      if (fr == 0) pj[0] = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
+      else pj[0] = cmulc_uniform(b1, G.rotp1);
+    }
+    const bool hist = (fr == 0);
+
+    /* ---- A1 + A3: four branch transforms, multiply-accumulate with the branch spectra ------- */
+    float2 acc[P];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float2 gm[P]; /* G_r slice of this lane: L2-resident, lands behind the transform */
+      {
+        const float2 *mp = p.fd_mask + (size_t)r * N;
+        asm volatile("" : "+s"(mp));
+#pragma unroll
+        for (int e = 0; e < P; e++) gm[e] = mp[e * NT + tid];
+      }
+      float2 v[P];
+#pragma unroll
+      for (int j = 0; j < P; j++) {
+        uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
+        if (SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
+        float2 x = unpack_iq(w, p.scale_i, p.scale_q);
+        float2 ph = pj[j];
+        if (r > 0) {
+          const float2 rr = (r == 1) ? G.rot1 : (r == 2) ? G.rot2 : G.rot3;
+          const float2 rh = (r == 1) ? G.roth1 : (r == 2) ? G.roth2 : G.roth3;
+          ph = (j == 0 && hist) ? cmul_pinned_u(ph, rh) : cmul_pinned_u(ph, rr);
+        }
+        v[j] = cmul_pinned(x, ph);
+      }
+      if (r == 3) { /* the raw registers are free: next frame's loads land behind the transforms */
+        rq[0] = rq[P - 1];
+#pragma unroll
+        for (int j = 1; j < P; j++) {
+          const int q = (fr + 1) * VAL + tid + 64 * (j - 1);
+          rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+      {
+        float2 twp[P - 1];
+        tw.template get<0>(twp);
+        fwd_pass0_store<N, P>(lb, v, wb, twp);
+      }
+      __syncthreads();
+      fwd_mid_all<N, P, 1, PL::NP - 1, false>(lb, wb, tw, sync);
+      fwd_pass_last<N, P>(lb, v, wb);
+      __syncthreads(); /* wb is rewritten by the next branch */
+#pragma unroll
+      for (int e = 0; e < P; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
+    }
+    inv_pass_last<N, P>(lb, acc, wb);
+    __syncthreads();
+    inv_mid_all<N, P, PL::NP - 2, false>(lb, wb, tw, sync);
+    {
+      float2 twp[P - 1];
+      tw.template get<0>(twp);
+      inv_pass0_load<N, P>(lb, acc, wb, twp);
+    }
+    /* acc[j] = y at window index tid + 64 j; index 64 (j = 1) is output fr*VAL of the call */
+#pragma unroll
+    for (int j = 1; j < P; j++) {
+      const int m = fr * VAL + tid + 64 * (j - 1);
+      if (m < total) ring[m & (RING - 1)] = acc[j];
+    }
+    produced = (fr + 1) * VAL < total ? (fr + 1) * VAL : total;
+    __syncthreads();
+
+    /* ---- A5/A6: overlap-save frames over what the ring holds ------------------------------ */
+#pragma unroll 1
+    while (produced - consumed >= H) {
+      float2 mreg[P];
+      {
+        const float2 *mp = p.mask_pool + G.mask_off;
+        asm volatile("" : "+s"(mp));
+#pragma unroll
+        for (int e = 0; e < P; e++) mreg[e] = mp[e * NT + tid];
+      }
+      const int base = consumed;
+      front_frame<N, P, false>(p, G, tw, lb, wb, red, mreg, vadbits, vad_inv, vprev, nfloor, agc_g, am_dc, frame_idx, ch,
+                               tid, [&](int i) { return ring[(base + i) & (RING - 1)]; });
+      consumed += H;
+    }
+  }
+
+  /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
+#pragma unroll
+  for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
+  *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
+      *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
+  if (tid == 0) {
+    p.st_scal[ch * 4 + 0] = nfloor;
+    if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
+    p.st_scal[ch * 4 + 2] = am_dc;
+  }
+}
+
+template <int N, int P>
+constexpr size_t front_fd_lds() {
+  return (size_t)(2 * N + FftPlan<N, P>::WB) * sizeof(float2) + 64 * sizeof(float);
 }
 
 /* one group record, rewritten in stream order (32 threads, one dword each) */
@@ -604,8 +828,18 @@ int launch_front_x(const RdspFrontParams *p, int n_channels, hipStream_t stream)
   hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
 }
+template <int N, int P, bool LEAN, bool PRE>
+int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  constexpr size_t lds = front_fd_lds<N, P>();
+  static_assert(lds <= 48 * 1024, "default dynamic LDS limit");
+  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE>), dim3(n_channels), dim3(64), lds, stream, *p);
+  return (int)hipGetLastError();
+}
 template <int N, int P, int DECIM, bool LEAN, bool PRE>
 int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  if constexpr (DECIM == 4 && N / P == 64) {
+    if (p->fir_fd) return launch_front_fd<N, P, LEAN, PRE>(p, n_channels, stream);
+  }
 #ifdef RDSP_EXPERIMENTAL
   if constexpr (DECIM == 4) {
     if (p->fir_matrix) return launch_front_x<N, P, DECIM, LEAN, PRE, true>(p, n_channels, stream);

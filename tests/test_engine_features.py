@@ -95,7 +95,6 @@ def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, tor
         ch.set_pipelined(pipelined)
         if lean:
             ch.set_front_variant(0)
-            ch.set_fir_variant(0)      # what pipelined mode runs
         step = iq.shape[1] // n_calls
         outs = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * step:(k + 1) * step])).cuda())
                 for k in range(n_calls)]

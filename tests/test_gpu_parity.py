@@ -53,7 +53,7 @@ def torch_cuda():
     return torch
 
 
-def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None):
+def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None, fir=None):
     """tail: None or "16r" (the product's tail kernel); "16", "8r", "16m", "8m": experimental layouts"""
     from radiodsp_sdr_rx_amd.chain import Chain
     nch, n = iq.shape[0], iq.shape[1]
@@ -65,6 +65,8 @@ def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None):
     elif tail:          # "16": rdsp_tail.hip; "16m" / "8m": matrix-pipe reduction
         ch.set_tail_variant(int(tail.rstrip("m")), int(tail.endswith("m")))
     apply_setup(ch, setup)
+    if fir is not None:   # stage A3: 0 direct form, 2 frequency domain (default: automatic)
+        ch.set_fir_variant(fir)
     o16, o32 = [], []
     step = n // calls
     for k in range(calls):
@@ -197,6 +199,33 @@ def test_matrix_fir_variant_matches_oracle(rdsp, oracle, torch_cuda, name):
     assert normwise(got, r32) <= TOL
 
 
+@pytest.mark.parametrize("name", ["k1_one_channel", "k2_usb_256", "usb_512", "usb_1024", "spectral_512", "spectral_256_level3",
+                                  "agc_fast_slow", "am_agc", "iq_gains", "odd_nco"])
+@pytest.mark.parametrize("calls", [1, 4])
+def test_frequency_domain_decimator_matches_oracle(rdsp, oracle, torch_cuda, name, calls):
+    """rdsp_chain_set_fir_variant(2): stage A3 as a polyphase overlap-save convolution (four
+    low-rate transforms, branch spectra, one inverse) instead of the direct form.  Same taps, exact
+    linear convolution: TOL against the oracle, whatever the call split (the frame grid is
+    anchored at each call's first sample; a call of one granule is a single partial frame)."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg, nch, nblk, cw = FF_CASES[name]
+    nblk = max(nblk, 64)          # four calls of at least one granule (8 or 16 blocks)
+    iq = synth_iq(nch, nblk * 128, cw=cw)
+    ch = Chain(nch, max_blocks_per_call=nblk // calls, **cfg)
+    ch.set_fir_variant(2)
+    step = nblk // calls * 128
+    outs = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * step:(k + 1) * step])).cuda(), want_f32=True)
+            for k in range(calls)]
+    torch.cuda.synchronize()
+    o16 = np.concatenate([o[0].cpu().numpy() for o in outs], 1)
+    o32 = np.concatenate([o[1].cpu().numpy() for o in outs], 1)
+    r16, r32 = oracle_run(oracle, iq, cfg)
+    err = normwise(o32, r32)
+    assert err <= TOL, f"{name}: normwise err {err:.3e}"
+    assert check_i16(o16, r16) < 0.02 * o16.size
+
+
 @pytest.mark.parametrize("name", sorted(FF_CASES))
 def test_feed_forward_chain_matches_oracle(rdsp, oracle, torch_cuda, name):
     from radiodsp_sdr_rx_amd.chain import synth_iq
@@ -321,17 +350,23 @@ def test_chain_with_nlms_is_as_close_to_float64_truth_as_the_oracle(rdsp, oracle
 @pytest.mark.parametrize("name,cfg,nblk", [("k2", K1, 64), ("k3", K3, 64), ("k4", K4, 256)])
 def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, cfg, nblk):
     """State (FIR history, overlap block, NFloor, AGC, NLMS) is carried in HBM across
-    launches: any call split gives the same bits."""
+    launches: with the direct-form decimator any call split gives the same bits.  The
+    frequency-domain decimator (the default where it exists: k2, k3) anchors its frames at each
+    call's first sample, so there a different split rounds differently: same result to TOL."""
     from radiodsp_sdr_rx_amd.chain import synth_iq
     iq = synth_iq(3, nblk * 128, cw=(name == "k4"))
-    a16, a32, _ = gpu_run(torch_cuda, iq, cfg, calls=1)
+    a16, a32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, fir=0)
     calls = 4 if name != "k4" else 2
-    b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
+    b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, fir=0)
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
+    if name != "k4":
+        _, f1, _ = gpu_run(torch_cuda, iq, cfg, calls=1)
+        _, f4, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
+        assert normwise(f4, f1) <= TOL and normwise(f1, a32) <= TOL
     if name == "k3":  # the other tail kernels carry the same state
         for tail in TAILS:
-            c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail=tail)
-            d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail=tail)
+            c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail=tail, fir=0)
+            d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail=tail, fir=0)
             assert np.array_equal(c16, d16) and np.array_equal(c32, d32)
             assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
@@ -354,8 +389,6 @@ def test_pipelined_mode_is_bitwise_identical(rdsp, torch_cuda, name, cfg, nch, n
     parts = [torch.from_numpy(np.ascontiguousarray(iq[:, k * nblk * 128:(k + 1) * nblk * 128])).cuda()
              for k in range(calls)]
     ref_chain = Chain(nch, max_blocks_per_call=nblk, **K3)
-    ref_chain.set_front_variant(-1)  # the same (automatic) kernel choice as the pipelined chain
-    ref_chain.set_fir_variant(0)     # ... with the packed-FMA FIR
     ref = [ref_chain.process(p).cpu().numpy() for p in parts]
     ch = Chain(nch, max_blocks_per_call=nblk, **K3)
     ch.set_pipelined(True)
@@ -437,7 +470,8 @@ def test_front_kernel_variants_agree(rdsp, oracle, torch_cuda):
     cfg = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, agc_mode="medium")
     iq = synth_iq(4, 32 * 128)
     _, r32 = oracle_run(oracle, iq, cfg)
-    for lean, fir in ((0, 0), (1, 0)) + (((0, 1), (1, 1)) if EXPERIMENTAL else ()):   # register-lean x (packed-FMA | matrix) FIR
+    # register-lean x stage A3 (0 direct form, 2 frequency domain, 1 matrix cores)
+    for lean, fir in ((0, 0), (1, 0), (0, 2), (1, 2)) + (((0, 1), (1, 1)) if EXPERIMENTAL else ()):
         ch = Chain(4, max_blocks_per_call=32, **cfg)
         ch.set_front_variant(lean)
         ch.set_fir_variant(fir)

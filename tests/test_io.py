@@ -136,9 +136,6 @@ def test_files_through_the_runner_match_resident_processing_and_oracle(rdsp, ora
     assert got.shape == (nch, exp_blocks * 32, 2)
     # the same samples resident in HBM, one call per batch of `per` blocks + the tail batch
     ref_chain = Chain(nch, max_blocks_per_call=per, **cfg)
-    if pipelined:
-        ref_chain.set_front_variant(0)   # pipelined mode runs the full-register front kernel
-        ref_chain.set_fir_variant(0)     # with the packed-FMA FIR
     parts, pos = [], 0
     while pos < exp_blocks:
         take = min(per, exp_blocks - pos)
@@ -162,8 +159,17 @@ def test_memory_runner_and_callbacks(rdsp, torch_cuda):
     nch, nblk, per = 4, 64, 8
     iq = synth_iq(nch, nblk * 128)
     out, st = stream_memory(Chain(nch, max_blocks_per_call=per, **K1), iq, per)
-    ref = Chain(nch, max_blocks_per_call=nblk, **K1).process(torch.from_numpy(iq).cuda()).cpu().numpy()
+    # the same samples resident in HBM, in the runner's batches (the frequency-domain decimator
+    # anchors its frames at each call's first sample: same batches, same bits)
+    rc = Chain(nch, max_blocks_per_call=per, **K1)
+    ref = np.concatenate([rc.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * per * 128:(k + 1) * per * 128])).cuda()).cpu().numpy()
+                          for k in range(nblk // per)], axis=1)
     assert st["blocks"] == nblk and np.array_equal(out, ref)
+    # ... and one call over everything with the direct-form decimator (split-invariant), +-1 LSB
+    one = Chain(nch, max_blocks_per_call=nblk, **K1)
+    one.set_fir_variant(0)
+    whole = one.process(torch.from_numpy(iq).cuda()).cpu().numpy()
+    assert np.abs(out.astype(np.int32) - whole.astype(np.int32)).max() <= 1
     # page-locked arrays at both ends: the zero-copy path (DMA straight from / to the user's memory)
     pin = torch.from_numpy(iq).pin_memory()
     out_p, st = stream_memory(Chain(nch, max_blocks_per_call=per, **K1), pin, per)
