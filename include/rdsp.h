@@ -68,7 +68,9 @@ typedef struct {
   double fhi_hz;        /* FHiCut, CONV:68                                           */
   int32_t filter_on;    /* bFilterEnabled, CONV:228,300                              */
   int32_t demod;        /* rdsp_demod_t                                              */
-  int32_t spectral_nr;  /* spectral-subtraction NR on/off, SPEC:112                  */
+  int32_t spectral_nr;  /* spectral-subtraction NR: 0 off, 1 SPEC:112-269, 2 the older
+                           variant of backup/RadioDSP_SDR_RX_Conv.ino:1520-1669 (bins
+                           60..120, /60, x3, no smoothing; the sketch runs it at nrndx == 3) */
   float spectral_level; /* iNRLevel of SPEC:112,202                                  */
   int32_t lms_nr;       /* nr_level: 0 off, else DSP-NR strength, CONV:326, NR:35    */
   int32_t als_mode;     /* rdsp_als_t                                                */
@@ -176,7 +178,7 @@ uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream);
 int rdsp_sdr_setMute(rdsp_chain_t *c, int mute);                  /* INO:177 */
 int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of CTL:447 */
 int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, GEN:111, CTL:237-297 */
-int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* SPEC:112 iNRLevel */
+int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* on: 0, 1 (SPEC:112 iNRLevel), 2 (older variant, level unused) */
 
 /* ---- receiver groups: per-group retune / PBT / mode tables -------
  * The sketch has one receiver, so one filter mask, one tuning offset and one

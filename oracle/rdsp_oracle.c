@@ -518,7 +518,30 @@ static void conv_frame(orc_chain_t *c) {
   }
   orc_cfft_f32(F, N, 0); /* CONV:291 */
 
-  if (c->cfg.spectral_nr) {
+  if (c->cfg.spectral_nr == 2) {
+    /* the older variant, backup/RadioDSP_SDR_RX_Conv.ino:1586-1630 (BK_INO): threshold =
+     * sum of bins 60..120 (61 terms) / 60 * 3, no smoothing, no state; active when the sketch
+     * sets TH_VALUE = 0.8 (nrndx == 3, BK_INO:1346-1350), spectral_level is not read.  Bins
+     * scale with FFT_L like the VAD bins of the newer variant; loop limits restated as j < FFT_L;
+     * BK_INO:1631-1634 has the mask multiply commented out -- as for the newer variant the build
+     * keeps the CONV:301 multiply after it. */
+    float *mag = c->mag;
+    orc_cmplx_mag_f32(F, mag, N); /* BK_INO:1589 */
+    int lo = (int)(60u * N / 256u), hi = (int)(120u * N / 256u);
+    float specVal = 0.0f;
+    for (int m = lo; m <= hi; m++) specVal = specVal + mag[m]; /* BK_INO:1594 */
+    float TH = specVal / (float)(hi - lo);                     /* BK_INO:1595 */
+    TH = TH * 3;                                               /* BK_INO:1596 */
+    c->NFloor = TH; /* kept only so that the state read-back shows the threshold in use */
+    for (uint32_t j = 0; j < N; j++) {                         /* BK_INO:1601-1609 */
+      float m0 = mag[j], m1;
+      if (m0 <= TH) m1 = (float)((double)m0 * 0.2);
+      else m1 = m0 - TH;
+      float sc = (m0 > 0.0f) ? (m1 / m0) : 0.0f;               /* BK_INO:1614-1628 */
+      F[2 * j] = F[2 * j] * sc;
+      F[2 * j + 1] = F[2 * j + 1] * sc;
+    }
+  } else if (c->cfg.spectral_nr) {
     /* SPEC:182-238, with the out-of-bounds loop limits restated as j < FFT_L
      *  and VAD bins scaled with FFT_L (SPEC:34-35 are for 256). */
     float *mag = c->mag;

@@ -65,7 +65,8 @@ typedef struct {
   double fhi_hz;       /* FHiCut (CONV:68)                                    */
   int32_t filter_on;   /* bFilterEnabled (CONV:300)                           */
   int32_t demod;       /* ORC_DEMOD_*                                         */
-  int32_t spectral_nr; /* 0/1: spectral subtraction (SPEC:112-269)            */
+  int32_t spectral_nr; /* 0 off, 1: spectral subtraction (SPEC:112-269), 2: the older
+                          variant of backup/RadioDSP_SDR_RX_Conv.ino:1520-1669        */
   float spectral_level;/* iNRLevel of SPEC:112 (0..3)                         */
   int32_t lms_nr;      /* 0 = off, else DSP-NR strength (NR:35; 15,20..50)    */
   int32_t als_mode;    /* ORC_ALS_* : LMS auto-notch / peak                   */

@@ -591,10 +591,16 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.groups = c->d_groups;
   fp.group_of = c->d_group_of;
   fp.mask_pool = c->d_mask_pool;
-  fp.spectral_on = cf.spectral_nr ? 1 : 0;
-  fp.spectral_k = (float)((double)cf.spectral_level * 1.5);
-  fp.vad_lo = 30 * c->N / 256; /* STATING_BIN_VAD_ANALISYS, SPEC:34, scaled with FFT_L */
-  fp.vad_hi = 180 * c->N / 256;
+  fp.spectral_on = cf.spectral_nr == 2 ? 2 : (cf.spectral_nr ? 1 : 0);
+  if (cf.spectral_nr == 2) { /* older variant, backup/RadioDSP_SDR_RX_Conv.ino:1594-1596: bins 60..120, x3 */
+    fp.spectral_k = 3.0f;
+    fp.vad_lo = 60 * c->N / 256;
+    fp.vad_hi = 120 * c->N / 256;
+  } else {
+    fp.spectral_k = (float)((double)cf.spectral_level * 1.5);
+    fp.vad_lo = 30 * c->N / 256; /* STATING_BIN_VAD_ANALISYS, SPEC:34, scaled with FFT_L */
+    fp.vad_hi = 180 * c->N / 256;
+  }
   fp.to_mid = tail ? 1 : 0;
   fp.agc_on = cf.agc_mode != RDSP_AGC_OFF;
   fp.agc_attack = attack;
@@ -870,7 +876,13 @@ extern "C" int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz) {
   return RDSP_OK;
 }
 extern "C" int rdsp_set_nr_level(rdsp_chain_t *c, int lvl) { NEED(c); c->cfg.lms_nr = lvl; return RDSP_OK; }
-extern "C" int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level) { NEED(c); c->cfg.spectral_nr = on ? 1 : 0; c->cfg.spectral_level = level; return RDSP_OK; }
+extern "C" int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level) {
+  NEED(c);
+  if (on < 0 || on > 2) return RDSP_ERR_INVALID;
+  c->cfg.spectral_nr = on;
+  c->cfg.spectral_level = level;
+  return RDSP_OK;
+}
 
 /* pass bands per audio filter and mode (CTL:149-191 names; Appendix C of the
  * survey: 150 Hz .. 2.1/2.7/3.1/3.9 kHz; CW 500 Hz wide around the 700 Hz pitch) */

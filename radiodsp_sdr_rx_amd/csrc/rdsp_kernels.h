@@ -48,8 +48,9 @@ struct RdspFrontParams {
   float nb_thr;            /* blanking threshold as a power ratio            */
   const float *fir_hc;     /* [4][64] decimator taps, hc[c][k'] = h[4k'+c]   */
   const float2 *mask_pool; /* [n_groups][2][N] masks/N, digit-reversed, thread-major (double-buffered) */
-  int spectral_on;
-  float spectral_k;        /* (float)(level*1.5)                             */
+  int spectral_on;         /* 1: SPEC:112-269 (smoothed floor); 2: the older variant of
+                              backup/RadioDSP_SDR_RX_Conv.ino:1586-1630 (floor = threshold) */
+  float spectral_k;        /* (float)(level*1.5); 3 for the older variant    */
   int vad_lo, vad_hi;      /* inclusive natural bin range                    */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
   int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */

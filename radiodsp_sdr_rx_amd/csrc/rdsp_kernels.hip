@@ -106,8 +106,12 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
     }
     float th = tot * vad_inv;                      /* SPEC:200 */
     th = th * p.spectral_k;                        /* SPEC:202 */
-    nfloor += (th - nfloor) * 0.65f;               /* SPEC:205 */
-    nfloor = nfloor > 0.f ? nfloor : 0.f;          /* SPEC:206 */
+    if (p.spectral_on == 2) {
+      nfloor = th;                                 /* BK_INO:1595-1596: no smoothing */
+    } else {
+      nfloor += (th - nfloor) * 0.65f;             /* SPEC:205 */
+      nfloor = nfloor > 0.f ? nfloor : 0.f;        /* SPEC:206 */
+    }
 #pragma unroll
     for (int e = 0; e < P; e++) {
       /* SPEC:213-217, 226-235: X * mag'/mag with mag' = 0.2 mag at or under the floor and

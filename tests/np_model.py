@@ -137,7 +137,15 @@ class Model:
             cur, self.pend = self.pend[:self.H], self.pend[self.H:]
             X = np.fft.fft(np.concatenate([self.prev, cur]))
             self.prev = cur
-            if c["spectral_nr"]:
+            if c["spectral_nr"] == 2:   # older variant, backup/RadioDSP_SDR_RX_Conv.ino:1586-1630
+                mag = np.abs(X)
+                lo, hi = 60 * self.N // 256, 120 * self.N // 256
+                th = mag[lo:hi + 1].sum() / (hi - lo) * 3.0
+                self.nfloor = th
+                m1 = np.where(mag <= th, mag * 0.2, mag - th)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    X = np.where(mag > 0, X * (m1 / mag), 0.0)
+            elif c["spectral_nr"]:
                 mag = np.abs(X)
                 lo, hi = 30 * self.N // 256, 180 * self.N // 256
                 th = mag[lo:hi + 1].sum() / (hi - lo) * (np.float32(c["spectral_level"]) * 1.5)

@@ -175,6 +175,12 @@ FF_CASES = {
     "k4_cw_4096_agc": (K4, 3, 128, True),
     "spectral_512": (dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0), 4, 32, False),
     "spectral_256_level3": (dict(fft_l=256, demod="USB", spectral_nr=1, spectral_level=3.0), 3, 32, False),
+    "spectral_old_512": (dict(fft_l=512, demod="USB", spectral_nr=2), 4, 32, False),        # BK_INO:1586-1630
+    "spectral_old_256_agc": (dict(fft_l=256, demod="USB", spectral_nr=2, agc_mode="medium"), 3, 32, False),
+    "window2_512": (dict(fft_l=512, demod="USB", window=2), 2, 32, False),                 # CONV:159-179: the other
+    "window3_256": (dict(fft_l=256, demod="LSB", flo_hz=-2700.0, fhi_hz=-300.0, window=3), 2, 32, False),  # window ids
+    "window4_1024": (dict(fft_l=1024, demod="USB", window=4), 2, 32, False),
+    "window5_512_agc": (dict(fft_l=512, demod="USB", window=5, agc_mode="fast"), 2, 32, False),
     "agc_fast_slow": (dict(fft_l=512, demod="USB", agc_mode="slow", output_gain=0.5), 4, 64, False),
     "am_agc": (dict(fft_l=512, demod="AM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="medium"), 3, 32, False),
     "iq_gains": (dict(fft_l=512, demod="IQ", agc_mode="fast", input_gain=0.7, iq_balance=1.02, output_gain=0.5), 3, 32, False),
@@ -199,7 +205,7 @@ def test_matrix_fir_variant_matches_oracle(rdsp, oracle, torch_cuda, name):
     assert normwise(got, r32) <= TOL
 
 
-@pytest.mark.parametrize("name", ["k1_one_channel", "k2_usb_256", "usb_512", "usb_1024", "spectral_512", "spectral_256_level3",
+@pytest.mark.parametrize("name", ["k1_one_channel", "k2_usb_256", "usb_512", "usb_1024", "spectral_512", "spectral_256_level3", "spectral_old_512",
                                   "agc_fast_slow", "am_agc", "iq_gains", "odd_nco"])
 @pytest.mark.parametrize("calls", [1, 4])
 def test_frequency_domain_decimator_matches_oracle(rdsp, oracle, torch_cuda, name, calls):

@@ -53,15 +53,16 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
 
 
+@pytest.mark.parametrize("window", [1, 2, 3, 4, 5])   # FIR_filter_window ids of CONV:152-179 (5 = the default branch)
 @pytest.mark.parametrize("fft_l,lo,hi,fs", [(256, 300.0, 4000.0, 44117.64706), (512, 300.0, 2700.0, 24000.0),
                                            (4096, 450.0, 950.0, 24000.0), (1024, -2700.0, -300.0, 24000.0)])
-def test_design_helpers_match_oracle(rdsp, oracle, fft_l, lo, hi, fs):
+def test_design_helpers_match_oracle(rdsp, oracle, fft_l, lo, hi, fs, window):
     from radiodsp_sdr_rx_amd.chain import calc_cplx_FIR_coeffs, init_filter_mask
-    ci, cq = calc_cplx_FIR_coeffs(fft_l // 2 + 1, lo, hi, fs, 1)
+    ci, cq = calc_cplx_FIR_coeffs(fft_l // 2 + 1, lo, hi, fs, window)
     lib = oracle.load()
     oi, oq = np.zeros_like(ci), np.zeros_like(cq)
     lib.orc_calc_cplx_FIR_coeffs(oi.ctypes.data_as(C.POINTER(C.c_double)), oq.ctypes.data_as(C.POINTER(C.c_double)),
-                                 len(ci), lo, hi, fs, 1)
+                                 len(ci), lo, hi, fs, window)
     assert np.abs(ci - oi).max() < 1e-15 and np.abs(cq - oq).max() < 1e-15
     m = init_filter_mask(ci, cq, fft_l)
     om = np.zeros(2 * fft_l, np.float32)

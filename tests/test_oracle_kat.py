@@ -190,12 +190,32 @@ def test_spectral_nr_reduces_noise_floor(oracle):
     assert (b[1024:] ** 2).sum() < 0.2 * (a[1024:] ** 2).sum()
 
 
+def test_older_spectral_variant_known_answers(oracle):
+    """backup/RadioDSP_SDR_RX_Conv.ino:1594-1609: threshold = sum(mag[60..120]) / 60 * 3, no
+    smoothing; a bin at or under it is scaled by 0.2, above it the threshold is subtracted."""
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    iq = synth_iq(1, 32 * 128)[0]
+    cfg = dict(CONV_LITERAL, filter_on=0)         # the spectral stage alone, at the sketch's FFT_L = 256
+    ch = oracle.OracleChain(**dict(cfg, spectral_nr=2))
+    b = ch.process(iq)[1]
+    a = oracle.OracleChain(**cfg).process(iq)[1]
+    # float64 evaluation of the last frame's threshold from the un-processed stream
+    x = (iq[:, 0] + 1j * iq[:, 1]) / 32768.0
+    X = np.abs(np.fft.fft(x[-256:]))
+    th = X[60:121].sum() / 60.0 * 3.0
+    assert abs(ch.nfloor() - th) < 1e-5 * th
+    # noise-only bins fall under the threshold: the stream loses most of its power, tones survive
+    assert 0.5 * (a ** 2).sum() < (b ** 2).sum() < 0.9 * (a ** 2).sum()
+
+
 FEED_FORWARD = {
     "conv_literal": (CONV_LITERAL, 16, False),
     "k1_k2": (K1, 32, False),
     "usb_1024": (dict(fft_l=1024, demod="USB"), 32, False),
     "lsb_2048": (dict(fft_l=2048, demod="LSB", nco_hz=14600.0, flo_hz=-2700.0, fhi_hz=-300.0), 64, False),
     "spectral_512": (dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0), 32, False),
+    "spectral_old_256": (dict(fft_l=256, demod="USB", spectral_nr=2), 32, False),   # BK_INO:1586-1630
+    "spectral_old_512": (dict(fft_l=512, demod="USB", spectral_nr=2), 32, False),
     "am_agc": (dict(fft_l=512, demod="AM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="slow"), 32, False),
     "iq_agc_gains": (dict(fft_l=512, demod="IQ", agc_mode="fast", input_gain=0.7, iq_balance=1.02,
                           output_gain=0.5), 32, False),
