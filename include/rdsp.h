@@ -384,6 +384,60 @@ int rdsp_spectrum_node_available(rdsp_node_t *n);            /* FFTIQ.h:62-68 */
 const uint16_t *rdsp_spectrum_node_output(rdsp_node_t *n);   /* FFTIQ.h:99, [n_channels][256] */
 int rdsp_spectrum_node_status(rdsp_node_t *n);
 
+/* ---- F3: biquad cascades (AudioFilterBiquad, INO:58-59,75-78,155-156; the engine's IIR audio
+ * filter bank, CTL:153-177 / SURVEY Appendix C) -------------------------------------------------
+ * Direct form 1 in float, up to four stages, y = b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2 with the
+ * feedback coefficients stored negated like arm_biquad_cascade_df1_f32 (build-defined: neither
+ * library is in the tree).  Design helpers (host): */
+void rdsp_biquad_design(int kind, double freq, double q, double fs, float *coef5); /* 0 LP, 1 HP, 2 BP, 3 notch */
+void rdsp_design_audio_iir(double f1, double f2, double fs, float *coef20);        /* 8th-order Butterworth band-pass */
+typedef struct rdsp_biquad rdsp_biquad_t; /* AudioFilterBiquad for n_channels streams */
+int rdsp_biquad_create(int n_channels, int device, double fs, rdsp_biquad_t **out);
+void rdsp_biquad_destroy(rdsp_biquad_t *b);
+/* setCoefficients(stage, {b0, b1, b2, a1, a2}) with H = (b0 + b1/z + b2/z^2) / (1 + a1/z + a2/z^2) */
+int rdsp_biquad_setCoefficients(rdsp_biquad_t *b, int stage, const double *coefficients);
+int rdsp_biquad_setLowpass(rdsp_biquad_t *b, int stage, float frequency, float q);
+int rdsp_biquad_setHighpass(rdsp_biquad_t *b, int stage, float frequency, float q);  /* INO:155-156 */
+int rdsp_biquad_setBandpass(rdsp_biquad_t *b, int stage, float frequency, float q);
+int rdsp_biquad_setNotch(rdsp_biquad_t *b, int stage, float frequency, float q);
+int rdsp_biquad_get_coeffs(const rdsp_biquad_t *b, float *out20);
+/* n_blocks update() ticks: int16 [n_channels][stride] samples read / written every `step` int16
+ * (1: planar mono blocks; 2: one side of interleaved pairs, e.g. the I or the Q of an IQ stream) */
+int rdsp_biquad_update(rdsp_biquad_t *b, const int16_t *d_in, size_t in_stride, int in_step, int n_blocks,
+                       int16_t *d_out, size_t out_stride, int out_step, void *stream);
+rdsp_node_t *rdsp_biquad_node_create(rdsp_graph_t *g, rdsp_biquad_t *b); /* 1 input, 1 output */
+int rdsp_biquad_node_status(rdsp_node_t *n);
+/* Implementation of the engine's audio filter (SDR.enableAudioFilter / setAudioFilter):
+ * RDSP_AUDIO_KIND_MASK (default): the pass band is the overlap-save mask (CONV:209-224).
+ * RDSP_AUDIO_KIND_IIR: the mask keeps only the side-band selection (50 Hz ... 4 kHz on the
+ * demodulator's side) and the selected audio filter is an 8th-order band-pass of four biquads on
+ * the demodulated audio, between the overlap-save filter and the NR / notch / AGC stages. */
+enum { RDSP_AUDIO_KIND_MASK = 0, RDSP_AUDIO_KIND_IIR = 1 };
+int rdsp_sdr_setAudioFilterKind(rdsp_chain_t *c, int kind, void *stream);
+int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out20);
+
+/* ---- AudioAnalyzeFFT1024 (Teensy Audio library; `AudioAnalyzeFFT1024 AudioFFT` on Q_out_L,
+ * INO:57,87): 1024-point frames of the audio stream with hop 512 (blocks collected eight at a time,
+ * four kept), q15 window, fixed-point radix-4 FFT of the real samples, output[i] = |X_i| for the
+ * 512 bins from DC up (integer, bit-exact against the test restatement; the library itself is not
+ * in the tree, so the rounding of the FFT and of the square root are build-defined as for F1).
+ * window_id: 0 none, 1 Hann, 2 Blackman-Harris. */
+typedef struct rdsp_fft1024 rdsp_fft1024_t;
+void rdsp_window_q15_n(int window_id, int n, int16_t *w);
+int rdsp_fft1024_create(int n_channels, int device, int window_id, rdsp_fft1024_t **out);
+void rdsp_fft1024_destroy(rdsp_fft1024_t *s);
+int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id);
+int rdsp_fft1024_outputs_for(const rdsp_fft1024_t *s, int n_blocks);
+/* n_blocks update() ticks; d_audio int16 [n_channels][in_stride] samples taken every in_step int16
+ * (2 with an offset pointer picks L or R of the chain's interleaved output); d_out uint16
+ * [n_channels][out_stride][512] receives the spectra completed in this call */
+int rdsp_fft1024_update(rdsp_fft1024_t *s, const int16_t *d_audio, size_t in_stride, int in_step, int n_blocks,
+                        uint16_t *d_out, size_t out_stride, int *n_outputs, void *stream);
+rdsp_node_t *rdsp_fft1024_node_create(rdsp_graph_t *g, rdsp_fft1024_t *s); /* 1 input, no outputs */
+int rdsp_fft1024_node_available(rdsp_node_t *n);
+const uint16_t *rdsp_fft1024_node_output(rdsp_node_t *n); /* [n_channels][512] */
+int rdsp_fft1024_node_status(rdsp_node_t *n);
+
 /* ---- deterministic synthetic IQ generator (host) -------------------*/
 typedef struct {
   double fs;        /* 96000 */

@@ -240,6 +240,115 @@ static void lms_noise_reduction(orc_lms_t *s, int n, float *nrbuffer, float *err
 /* ------------------------------------------------------------------------ */
 /* chain object: the reference's globals (CONV:34-80, NR:18-32, SPEC:109)    */
 /* ------------------------------------------------------------------------ */
+/* ======================================================================== */
+/* F3: biquad cascades.  arm_biquad_cascade_df1_f32 role (the engine's audio filter bank,
+ * {b0,b1,b2,a1,a2} x 4 stages in the firmware image) and Teensy's
+ * AudioFilterBiquad (INO:58-59,155-156).  Neither library is in the tree: build-defined as
+ * direct form 1 in float, per stage
+ *     y = fma(a2, y2, fma(a1, y1, fma(b2, x2, fma(b1, x1, b0 * x))))
+ * with the CMSIS sign convention (feedback terms are added).                              */
+/* ======================================================================== */
+void orc_biquad_init(orc_biquad_t *b, int n_stages, const float *coef5) {
+  memset(b, 0, sizeof(*b));
+  b->n_stages = n_stages < 0 ? 0 : (n_stages > ORC_BIQUAD_MAX_STAGES ? ORC_BIQUAD_MAX_STAGES : n_stages);
+  for (int s = 0; s < ORC_BIQUAD_MAX_STAGES; s++) {
+    float *c = b->coef + 5 * s;
+    if (s < b->n_stages && coef5) memcpy(c, coef5 + 5 * s, 5 * sizeof(float));
+    else { c[0] = 1.0f; c[1] = c[2] = c[3] = c[4] = 0.0f; } /* pass-through */
+  }
+}
+void orc_biquad_set_stage(orc_biquad_t *b, int stage, const float *coef5) {
+  if (stage < 0 || stage >= ORC_BIQUAD_MAX_STAGES) return;
+  memcpy(b->coef + 5 * stage, coef5, 5 * sizeof(float));
+  if (stage >= b->n_stages) b->n_stages = stage + 1;
+}
+void orc_biquad_run(orc_biquad_t *b, float *x, int n) {
+  for (int i = 0; i < n; i++) {
+    float v = x[i];
+    for (int s = 0; s < ORC_BIQUAD_MAX_STAGES; s++) {
+      const float *c = b->coef + 5 * s;
+      float *st = b->state + 4 * s; /* x1, x2, y1, y2 */
+      float y = c[0] * v;
+      y = fmaf(c[1], st[0], y);
+      y = fmaf(c[2], st[1], y);
+      y = fmaf(c[3], st[2], y);
+      y = fmaf(c[4], st[3], y);
+      st[1] = st[0]; st[0] = v;
+      st[3] = st[2]; st[2] = y;
+      v = y;
+    }
+    x[i] = v;
+  }
+}
+/* AudioFilterBiquad::setLowpass/setHighpass/setBandpass/setNotch (Teensy filter_biquad.h; not in
+ * the tree: the published RBJ audio-EQ formulas that library documents), double design narrowed
+ * to float, feedback coefficients stored negated like CMSIS.  kind: 0 LP, 1 HP, 2 BP, 3 notch. */
+void orc_biquad_design(int kind, double freq, double q, double fs, float *coef5) {
+  const double w0 = freq * (2.0 * 3.14159265358979323846 / fs);
+  const double sinW0 = sin(w0), alpha = sinW0 / (q * 2.0), cosW0 = cos(w0);
+  const double scale = 1.0 / (1.0 + alpha);
+  double b0, b1, b2;
+  switch (kind) {
+    case 0: b0 = ((1.0 - cosW0) / 2.0) * scale; b1 = (1.0 - cosW0) * scale; b2 = b0; break;
+    case 1: b0 = ((1.0 + cosW0) / 2.0) * scale; b1 = -(1.0 + cosW0) * scale; b2 = b0; break;
+    case 2: b0 = alpha * scale; b1 = 0.0; b2 = -alpha * scale; break;
+    default: b0 = scale; b1 = (-2.0 * cosW0) * scale; b2 = b0; break;
+  }
+  coef5[0] = (float)b0; coef5[1] = (float)b1; coef5[2] = (float)b2;
+  coef5[3] = (float)(-((-2.0 * cosW0) * scale));
+  coef5[4] = (float)(-((1.0 - alpha) * scale));
+}
+/* 8th-order Butterworth band-pass f1..f2 as four biquads (the shape SURVEY Appendix C reads out
+ * of the firmware image: -3 dB at 150 Hz and at 2.1 ... 3.9 kHz): analog 4th-order prototype,
+ * LP -> BP, bilinear transform with pre-warped edges; each section has one zero at z = 1 and one
+ * at z = -1; the cascade is normalised to unit gain at sqrt(f1 f2) with the gain spread evenly. */
+void orc_design_butter_bp8(double f1, double f2, double fs, float *coef20) {
+  const double pi = 3.14159265358979323846;
+  const double w1 = 2.0 * fs * tan(pi * f1 / fs), w2 = 2.0 * fs * tan(pi * f2 / fs);
+  const double bw = w2 - w1, w0sq = w1 * w2;
+  double pr[4], pi_[4]; /* one pole of each conjugate pair in the z plane */
+  int np = 0;
+  for (int k = 0; k < 2; k++) { /* prototype poles in the upper half plane: k = 0, 1 */
+    const double th = pi * (2.0 * k + 1.0 + 4.0) / 8.0;
+    const double ar = cos(th) * bw * 0.5, ai = sin(th) * bw * 0.5; /* p * bw / 2 */
+    /* s = a +- sqrt(a^2 - w0^2) */
+    const double dr = ar * ar - ai * ai - w0sq, di = 2.0 * ar * ai;
+    const double mag = sqrt(sqrt(dr * dr + di * di)), ang = 0.5 * atan2(di, dr);
+    const double sr = mag * cos(ang), si = mag * sin(ang);
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      double xr = ar + sgn * sr, xi = ai + sgn * si; /* analog pole */
+      if (xi < 0) xi = -xi;                            /* keep the upper-half representative */
+      /* z = (2 fs + s) / (2 fs - s) */
+      const double nr = 2.0 * fs + xr, ni = xi, dr2 = 2.0 * fs - xr, di2 = -xi;
+      const double den = dr2 * dr2 + di2 * di2;
+      pr[np] = (nr * dr2 + ni * di2) / den;
+      pi_[np] = (ni * dr2 - nr * di2) / den;
+      np++;
+    }
+  }
+  /* gain of the un-normalised cascade at the centre frequency */
+  const double wc = 2.0 * pi * sqrt(f1 * f2) / fs;
+  double gr = 1.0, gi = 0.0;
+  for (int s = 0; s < 4; s++) {
+    const double a1 = -2.0 * pr[s], a2 = pr[s] * pr[s] + pi_[s] * pi_[s];
+    /* H = (1 - z^-2) / (1 + a1 z^-1 + a2 z^-2) at z = e^{j wc} */
+    const double c1 = cos(wc), s1 = -sin(wc), c2 = cos(2 * wc), s2 = -sin(2 * wc);
+    const double nr = 1.0 - c2, ni = -s2, dr = 1.0 + a1 * c1 + a2 * c2, di = a1 * s1 + a2 * s2;
+    const double den = dr * dr + di * di;
+    const double hr = (nr * dr + ni * di) / den, hi = (ni * dr - nr * di) / den;
+    const double tr = gr * hr - gi * hi, ti = gr * hi + gi * hr;
+    gr = tr; gi = ti;
+  }
+  const double g = pow(1.0 / sqrt(gr * gr + gi * gi), 0.25);
+  for (int s = 0; s < 4; s++) {
+    coef20[5 * s + 0] = (float)g;
+    coef20[5 * s + 1] = 0.0f;
+    coef20[5 * s + 2] = (float)(-g);
+    coef20[5 * s + 3] = (float)(2.0 * pr[s]);                             /* -a1 */
+    coef20[5 * s + 4] = (float)(-(pr[s] * pr[s] + pi_[s] * pi_[s]));      /* -a2 */
+  }
+}
+
 struct orc_chain {
   orc_config_t cfg;
   uint32_t fft_l, hop; /* FFT_length, BUFFER_SIZE*N_BLOCKS */
@@ -272,6 +381,9 @@ struct orc_chain {
   /* F3: SAM demodulator (PLL) */
   float sam_g1, sam_g2, sam_wmin, sam_wmax;
   float sam_phs, sam_omega, sam_fil, sam_dc;
+  /* F3: the engine's IIR audio filter bank (build-defined) */
+  int iir_on;
+  orc_biquad_t iir;
 };
 
 uint32_t orc_demod_tuning_offset(int demod) {
@@ -373,6 +485,17 @@ static void sam_block(orc_chain_t *c, float *L, float *R) {
 /* ---- F2: retune / PBT / mode table (the callers of CONV:209) ------------------- */
 /* run-time changes of the engine settings a mode switch touches */
 void orc_set_demod(orc_chain_t *c, int demod) { c->cfg.demod = demod; }
+/* IIR implementation of the audio filter: 8th-order band-pass f1..f2 at the decimated rate;
+ * filter state is cleared like arm_biquad_cascade_df1_init_f32 does */
+void orc_set_audio_iir(orc_chain_t *c, int on, double f1, double f2) {
+  c->iir_on = on;
+  if (on) {
+    float coef[20];
+    orc_design_butter_bp8(f1, f2, c->fs_out, coef);
+    orc_biquad_init(&c->iir, 4, coef);
+  }
+}
+const float *orc_chain_iir_coeffs(const orc_chain_t *c) { return c->iir.coef; }
 void orc_set_nco_hz(orc_chain_t *c, double hz) {
   c->cfg.nco_hz = hz;
   c->dphi = (uint32_t)(unsigned long long)llround(hz / c->cfg.fs_in * 4294967296.0);
@@ -597,6 +720,12 @@ static void post_block(orc_chain_t *c, float *L, float *R) {
   } else if (cf->demod == ORC_DEMOD_SAM) {
     sam_block(c, L, R);
   } else if (cf->demod != ORC_DEMOD_IQ) {
+    for (int i = 0; i < ORC_BLOCK; i++) R[i] = L[i];
+  }
+  /* the engine's IIR audio filter (SDR.setAudioFilter, CTL:153-177) when that implementation of
+   * the audio filter is selected: mono audio through the biquad cascade */
+  if (c->iir_on && cf->demod != ORC_DEMOD_IQ) {
+    orc_biquad_run(&c->iir, L, ORC_BLOCK);
     for (int i = 0; i < ORC_BLOCK; i++) R[i] = L[i];
   }
   /* CONV:326-337 (applied per 128-block: deviation from the N_BLOCKS>1 bug) */
@@ -892,6 +1021,101 @@ int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *bi, const int16_t *bq)
   memcpy(s->prev_i, bi, sizeof(s->prev_i)); /* FFTIQ.cpp:114-117 */
   memcpy(s->prev_q, bq, sizeof(s->prev_q));
   return fresh;
+}
+
+/* ======================================================================== */
+/* AudioAnalyzeFFT1024 (Teensy Audio library; `AudioAnalyzeFFT1024 AudioFFT` fed from Q_out_L,    */
+/* INO:57,87, read by the display).  Not in the tree: restated from the library's published      */
+/* update(): blocks are collected eight at a time with four kept (1024-sample frames, hop 512),  */
+/* real samples with zero imaginary parts, q15 window (x*w)>>15, arm_cfft_radix4_q15 (here the   */
+/* same build-defined fixed-point radix-4 as F1, five stages), output[i] = sqrt(re^2 + im^2)     */
+/* for the 512 bins at and above DC; no averaging.                                               */
+/* ======================================================================== */
+void orc_window_q15_n(int window_id, int n, int16_t *w) {
+  for (int i = 0; i < n; i++) {
+    double t = ORC_TWO_PI * (double)i / (double)n, v;
+    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
+    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
+    else v = 1.0;
+    long q = lround(32767.0 * v);
+    w[i] = (int16_t)(q > 32767 ? 32767 : q);
+  }
+}
+/* n = 4^stages points, interleaved re/im int16, natural order in and out */
+void orc_cfft_radix4_q15_n(int16_t *buf, int n) {
+  int32_t *re = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n), *im = re + n;
+  for (int i = 0; i < n; i++) { re[i] = buf[2 * i]; im[i] = buf[2 * i + 1]; }
+  int stages = 0;
+  for (int L = n / 4; L >= 1; L >>= 2) {
+    stages++;
+    for (int g = 0; g < n; g += 4 * L) {
+      for (int j = 0; j < L; j++) {
+        int i0 = g + j, i1 = i0 + L, i2 = i0 + 2 * L, i3 = i0 + 3 * L;
+        int32_t s0r = re[i0] + re[i2], s0i = im[i0] + im[i2];
+        int32_t s1r = re[i0] - re[i2], s1i = im[i0] - im[i2];
+        int32_t s2r = re[i1] + re[i3], s2i = im[i1] + im[i3];
+        int32_t s3r = re[i1] - re[i3], s3i = im[i1] - im[i3];
+        int32_t yr[4], yi[4];
+        yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
+        yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2;
+        yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
+        yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2;
+        for (int k = 0; k < 4; k++) {
+          int m = (k * j * (n / (4 * L))) % n; /* W_n^m */
+          int32_t wr = (int32_t)lround(32767.0 * cos(ORC_TWO_PI * m / (double)n));
+          int32_t wi = (int32_t)lround(-32767.0 * sin(ORC_TWO_PI * m / (double)n));
+          int32_t pr = (yr[k] * wr - yi[k] * wi) >> 15;
+          int32_t pi = (yr[k] * wi + yi[k] * wr) >> 15;
+          re[g + j + k * L] = sat16(pr);
+          im[g + j + k * L] = sat16(pi);
+        }
+      }
+    }
+  }
+  for (int p = 0; p < n; p++) { /* position p holds bin digit-reverse_4(p) */
+    int k = 0, q = p;
+    for (int d = 0; d < stages; d++) { k = (k << 2) | (q & 3); q >>= 2; }
+    buf[2 * k] = (int16_t)re[p];
+    buf[2 * k + 1] = (int16_t)im[p];
+  }
+  free(re);
+}
+
+struct orc_fft1024 {
+  int16_t window[1024];
+  int has_window;
+  int16_t blocks[8][128]; /* blocklist[8] */
+  int state;
+  uint16_t output[512];
+};
+orc_fft1024_t *orc_fft1024_create(int window_id) {
+  orc_fft1024_t *s = (orc_fft1024_t *)calloc(1, sizeof(*s));
+  s->has_window = window_id != 0;
+  orc_window_q15_n(window_id, 1024, s->window);
+  return s;
+}
+void orc_fft1024_destroy(orc_fft1024_t *s) { free(s); }
+const uint16_t *orc_fft1024_output(const orc_fft1024_t *s) { return s->output; }
+/* one update() tick with one 128-sample block; 1 when output[] is fresh */
+int orc_fft1024_update(orc_fft1024_t *s, const int16_t *block) {
+  memcpy(s->blocks[s->state], block, 128 * sizeof(int16_t));
+  if (s->state < 7) { s->state++; return 0; }
+  int16_t buf[2048];
+  for (int b = 0; b < 8; b++)
+    for (int i = 0; i < 128; i++) {
+      int32_t v = s->blocks[b][i];
+      if (s->has_window) v = (v * s->window[b * 128 + i]) >> 15;
+      buf[2 * (b * 128 + i)] = (int16_t)v;
+      buf[2 * (b * 128 + i) + 1] = 0;
+    }
+  orc_cfft_radix4_q15_n(buf, 1024);
+  for (int i = 0; i < 512; i++) {
+    int32_t r = buf[2 * i], q = buf[2 * i + 1];
+    s->output[i] = (uint16_t)orc_sqrt_uint32((uint32_t)(r * r + q * q));
+  }
+  for (int b = 0; b < 4; b++) memcpy(s->blocks[b], s->blocks[b + 4], 128 * sizeof(int16_t));
+  s->state = 4;
+  return 1;
 }
 
 /* many channels of the F1 analyser (cpu_baseline leg); returns a checksum of the

@@ -171,6 +171,25 @@ void orc_fft256iq_destroy(orc_fft256iq_t *s);
 /* one update() tick with a 128-sample I block and Q block; returns 1 when output[] was refreshed */
 int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *block_i, const int16_t *block_q);
 const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s); /* uint16 output[256], FFTIQ.h:99 */
+/* AudioAnalyzeFFT1024 (Teensy Audio library; INO:57,87), restated like F1 */
+typedef struct orc_fft1024 orc_fft1024_t;
+void orc_window_q15_n(int window_id, int n, int16_t *w);
+void orc_cfft_radix4_q15_n(int16_t *buf, int n);
+orc_fft1024_t *orc_fft1024_create(int window_id);
+void orc_fft1024_destroy(orc_fft1024_t *s);
+int orc_fft1024_update(orc_fft1024_t *s, const int16_t *block);
+const uint16_t *orc_fft1024_output(const orc_fft1024_t *s); /* uint16 output[512] */
+/* biquad cascades (engine audio filter bank, AudioFilterBiquad): DF1, float, CMSIS coefficient
+ * order {b0, b1, b2, a1, a2} per stage with the feedback terms added */
+#define ORC_BIQUAD_MAX_STAGES 4
+typedef struct { int n_stages; float coef[5 * ORC_BIQUAD_MAX_STAGES]; float state[4 * ORC_BIQUAD_MAX_STAGES]; } orc_biquad_t;
+void orc_biquad_init(orc_biquad_t *b, int n_stages, const float *coef5);
+void orc_biquad_set_stage(orc_biquad_t *b, int stage, const float *coef5);
+void orc_biquad_run(orc_biquad_t *b, float *x, int n);
+void orc_biquad_design(int kind, double freq, double q, double fs, float *coef5); /* 0 LP 1 HP 2 BP 3 notch */
+void orc_design_butter_bp8(double f1, double f2, double fs, float *coef20);
+void orc_set_audio_iir(orc_chain_t *c, int on, double f1, double f2);
+const float *orc_chain_iir_coeffs(const orc_chain_t *c);
 uint64_t orc_fft256iq_multi(int naverage, int window_id, int n_ch, const int16_t *iq, int n_blocks, int n_threads);
 #ifdef __cplusplus
 }

@@ -194,6 +194,31 @@ SYMBOLS = [
     ("rdsp_sdr_node_status", _i, [_vp]),
     ("rdsp_chain_decim", _i, [_vp]),
     ("rdsp_window_q15", None, [_i, _i16p]),
+    ("rdsp_biquad_design", None, [_i, _d, _d, _d, _f32p]),
+    ("rdsp_design_audio_iir", None, [_d, _d, _d, _f32p]),
+    ("rdsp_biquad_create", _i, [_i, _i, _d, C.POINTER(_vp)]),
+    ("rdsp_biquad_destroy", None, [_vp]),
+    ("rdsp_biquad_setCoefficients", _i, [_vp, _i, _f64p]),
+    ("rdsp_biquad_setLowpass", _i, [_vp, _i, _f, _f]),
+    ("rdsp_biquad_setHighpass", _i, [_vp, _i, _f, _f]),
+    ("rdsp_biquad_setBandpass", _i, [_vp, _i, _f, _f]),
+    ("rdsp_biquad_setNotch", _i, [_vp, _i, _f, _f]),
+    ("rdsp_biquad_get_coeffs", _i, [_vp, _f32p]),
+    ("rdsp_biquad_update", _i, [_vp, _vp, _sz, _i, _i, _vp, _sz, _i, _vp]),
+    ("rdsp_biquad_node_create", _vp, [_vp, _vp]),
+    ("rdsp_biquad_node_status", _i, [_vp]),
+    ("rdsp_sdr_setAudioFilterKind", _i, [_vp, _i, _vp]),
+    ("rdsp_chain_get_iir_coeffs", _i, [_vp, _i, _f32p]),
+    ("rdsp_window_q15_n", None, [_i, _i, _i16p]),
+    ("rdsp_fft1024_create", _i, [_i, _i, _i, C.POINTER(_vp)]),
+    ("rdsp_fft1024_destroy", None, [_vp]),
+    ("rdsp_fft1024_windowFunction", _i, [_vp, _i]),
+    ("rdsp_fft1024_outputs_for", _i, [_vp, _i]),
+    ("rdsp_fft1024_update", _i, [_vp, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(C.c_int), _vp]),
+    ("rdsp_fft1024_node_create", _vp, [_vp, _vp]),
+    ("rdsp_fft1024_node_available", _i, [_vp]),
+    ("rdsp_fft1024_node_output", C.POINTER(C.c_uint16), [_vp]),
+    ("rdsp_fft1024_node_status", _i, [_vp]),
     ("rdsp_spectrum_create", _i, [_i, _i, _i, _i, C.POINTER(_vp)]),
     ("rdsp_spectrum_destroy", None, [_vp]),
     ("rdsp_spectrum_averageTogether", _i, [_vp, _i]),

@@ -119,6 +119,15 @@ class Chain:
     def enableAudioFilter(self): _lib.check(self.lib.rdsp_sdr_enableAudioFilter(self.h))
     def setAudioFilter(self, f, stream=None):
         _lib.check(self.lib.rdsp_sdr_setAudioFilter(self.h, int(f), _stream_ptr(stream)))
+    def setAudioFilterKind(self, kind, stream=None):
+        """0: SDR.setAudioFilter() filters are overlap-save masks; 1: 8th-order IIR band-passes (biquads)"""
+        _lib.check(self.lib.rdsp_sdr_setAudioFilterKind(self.h, int(kind), _stream_ptr(stream)))
+
+    def iir_coeffs(self, group=0):
+        a = np.zeros(20, np.float32)
+        _lib.check(self.lib.rdsp_chain_get_iir_coeffs(self.h, int(group), a.ctypes.data_as(_lib._f32p)))
+        return a
+
     def setDemodMode(self, mode, stream=None):
         return int(self.lib.rdsp_sdr_setDemodMode(self.h, int(mode), _stream_ptr(stream)))
     def setMute(self, m): _lib.check(self.lib.rdsp_sdr_setMute(self.h, int(bool(m))))

@@ -64,6 +64,8 @@ struct GroupState {
   uint32_t dev_dphi = 0;
   hipEvent_t ev_copy = nullptr;
   float *staging = nullptr; /* pinned, N float2 */
+  float iir[20];            /* the group's audio band-pass as four biquads (RDSP_AUDIO_KIND_IIR) */
+  bool iir_dirty = true;
 };
 
 struct rdsp_chain {
@@ -129,6 +131,11 @@ struct rdsp_chain {
    * with the reduction on the matrix pipe */
   int tail_lpc = 100;
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
+  /* the engine's IIR audio filter bank (RDSP_AUDIO_KIND_IIR): coefficient sets per group, DF1
+   * state per channel; allocated by rdsp_sdr_setAudioFilterKind */
+  int audio_kind = RDSP_AUDIO_KIND_MASK;
+  float *d_iir_coef = nullptr, *d_iir_state = nullptr;
+  int iir_sets = 0;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
   int nb_on = 0;              /* SDR.enableNoiseBlanker, BK_INO:1259 */
   float nb_threshold_db = 10.0f;
@@ -137,6 +144,7 @@ struct rdsp_chain {
 static int drain_tail_fwd(rdsp_chain_t *c);
 static int ensure_sam(rdsp_chain_t *c);
 static int ensure_sub_batch_events(rdsp_chain_t *c);
+static void passband(int filter, int demod, double *lo, double *hi);
 static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_channels, int device,
                        int max_blocks_per_call, int decim);
 static int check_device(rdsp_chain_t *c) {
@@ -194,7 +202,9 @@ static int groups_resize(rdsp_chain_t *c, int n) {
       const GroupState &g0 = c->groups[0];
       g.lo = g0.lo; g.hi = g0.hi; g.nco_hz = g0.nco_hz; g.demod = g0.demod; g.audio_filter = g0.audio_filter;
       g.coef_I = g0.coef_I; g.coef_Q = g0.coef_Q; g.mask_nat = g0.mask_nat;
+      memcpy(g.iir, g0.iir, sizeof(g.iir));
     } else {
+      for (int st = 0; st < 4; st++) { g.iir[5 * st] = 1.0f; g.iir[5 * st + 1] = g.iir[5 * st + 2] = g.iir[5 * st + 3] = g.iir[5 * st + 4] = 0.0f; }
       g.coef_I.assign(c->hop + 1, 0.0);
       g.coef_Q.assign(c->hop + 1, 0.0);
       g.mask_nat.assign(2 * (size_t)c->N, 0.0f);
@@ -405,7 +415,7 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_fd_mask, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_mid};
   for (void *p : ptrs)
@@ -465,6 +475,7 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   c->nr_mu = rdsp_lms_mu(15);
   for (auto &g : c->groups) { g.has_dev_dphi = false; g.dirty = true; }
   if (c->d_sam) HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch));
+  if (c->d_iir_state) HIP_TRY(hipMemset(c->d_iir_state, 0, sizeof(float) * 16 * nch));
   return RDSP_OK;
 }
 
@@ -571,7 +582,12 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     rdsp_set_error("SAM group without PLL buffers (internal)");
     return RDSP_ERR_INVALID;
   }
-  const bool tail = sam || (cf.lms_nr > 0) || (cf.als_mode != RDSP_ALS_OFF);
+  const bool iir = c->audio_kind == RDSP_AUDIO_KIND_IIR && cf.filter_on;
+  if (iir && (!c->d_iir_coef || c->iir_sets < (int)c->groups.size())) {
+    rdsp_set_error("IIR audio filter without its buffers (internal)");
+    return RDSP_ERR_INVALID;
+  }
+  const bool tail = sam || iir || (cf.lms_nr > 0) || (cf.als_mode != RDSP_ALS_OFF);
   float attack, decay;
   agc_params(cf.agc_mode, &attack, &decay);
   const float og = cf.mute ? 0.0f : cf.output_gain;
@@ -701,6 +717,34 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     int es = rdsp_launch_sam(&sp, tstream);
     if (es != 0) {
       rdsp_set_error("SAM kernel launch failed: %s", hipGetErrorString((hipError_t)es));
+      return RDSP_ERR_HIP;
+    }
+  }
+  if (iir) { /* SDR.setAudioFilter as a biquad cascade on the demodulated audio, before NR / notch / AGC */
+    for (size_t gi = 0; gi < c->groups.size(); gi++) {
+      GroupState &g = c->groups[gi];
+      if (!g.iir_dirty) continue;
+      int eb = rdsp_launch_biquad_coef_store(c->d_iir_coef + 20 * gi, g.iir, tstream);
+      if (eb != 0) {
+        rdsp_set_error("IIR coefficient store failed: %s", hipGetErrorString((hipError_t)eb));
+        return RDSP_ERR_HIP;
+      }
+      g.iir_dirty = false;
+    }
+    RdspBiquadParams bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.buf = fp.mid;
+    bp.stride = c->mid_stride;
+    bp.n_channels = c->n_channels;
+    bp.n_samples = (int)n_out;
+    bp.coef = c->d_iir_coef;
+    bp.set_of = c->d_group_of;
+    bp.state = c->d_iir_state;
+    if (nsb > 1) /* sub-batched fronts: the cascade covers all channels, after the last of them */
+      for (int k = 0; k < nsb; k++) HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front_sb[slot][k], 0));
+    int eb = rdsp_launch_biquad(&bp, tstream);
+    if (eb != 0) {
+      rdsp_set_error("biquad kernel launch failed: %s", hipGetErrorString((hipError_t)eb));
       return RDSP_ERR_HIP;
     }
   }
@@ -901,14 +945,64 @@ static void passband(int filter, int demod, double *lo, double *hi) {
   else if (demod == RDSP_DEMOD_AM || demod == RDSP_DEMOD_SAM) { *lo = -b; *hi = b; }
   else { *lo = a; *hi = b; }
 }
+/* the group's pass band under the current implementation of the audio filter: the mask carries
+ * it (MASK), or the mask only selects the side band (50 Hz ... 4 kHz on the demodulator's side;
+ * both sides for AM / SAM) and the band-pass is the group's biquad cascade (IIR) */
+static int group_apply_audio_filter(rdsp_chain_t *c, int group, void *stream) {
+  GroupState &g = c->groups[(size_t)group];
+  double lo, hi;
+  passband(g.audio_filter, g.demod, &lo, &hi);
+  if (c->audio_kind == RDSP_AUDIO_KIND_IIR) {
+    const double a = fabs(lo) < fabs(hi) ? fabs(lo) : fabs(hi), b = fabs(lo) < fabs(hi) ? fabs(hi) : fabs(lo);
+    const double f1 = (g.demod == RDSP_DEMOD_AM || g.demod == RDSP_DEMOD_SAM) ? 150.0 : a;
+    rdsp_design_audio_iir(f1, b, c->cfg.fs_in / (double)c->decim, g.iir);
+    g.iir_dirty = true;
+    if (g.demod == RDSP_DEMOD_LSB || g.demod == RDSP_DEMOD_CW_LSB) { lo = -4000.0; hi = -50.0; }
+    else if (g.demod == RDSP_DEMOD_AM || g.demod == RDSP_DEMOD_SAM) { lo = -4000.0; hi = 4000.0; }
+    else { lo = 50.0; hi = 4000.0; }
+  }
+  return rdsp_group_reInitializeFilter(c, group, lo, hi, stream);
+}
 extern "C" int rdsp_group_setAudioFilter(rdsp_chain_t *c, int group, int filter, void *stream) {
   if (check_group(c, group) != RDSP_OK) return RDSP_ERR_INVALID;
   if (filter < RDSP_AUDIO_CW || filter > RDSP_AUDIO_WSPR) return RDSP_ERR_INVALID;
-  GroupState &g = c->groups[(size_t)group];
-  g.audio_filter = filter;
-  double lo, hi;
-  passband(filter, g.demod, &lo, &hi);
-  return rdsp_group_reInitializeFilter(c, group, lo, hi, stream);
+  c->groups[(size_t)group].audio_filter = filter;
+  return group_apply_audio_filter(c, group, stream);
+}
+/* which implementation SDR.setAudioFilter() selects filters of; re-applies every group's
+ * current audio filter.  A control-path call: allocates the cascade's buffers on first use and
+ * drains the tail stream (the cascade's state belongs to it). */
+extern "C" int rdsp_sdr_setAudioFilterKind(rdsp_chain_t *c, int kind, void *stream) {
+  NEED(c);
+  if (kind != RDSP_AUDIO_KIND_MASK && kind != RDSP_AUDIO_KIND_IIR) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (drain_tail_fwd(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (kind == RDSP_AUDIO_KIND_IIR) {
+    const size_t nch = (size_t)c->n_channels, ng = c->groups.size();
+    if (!c->d_iir_state) {
+      HIP_TRY(hipMalloc((void **)&c->d_iir_state, sizeof(float) * 16 * nch));
+      HIP_TRY(hipMemset(c->d_iir_state, 0, sizeof(float) * 16 * nch));
+    }
+    if (c->iir_sets < (int)ng) {
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      if (c->d_iir_coef) (void)hipFree(c->d_iir_coef);
+      c->d_iir_coef = nullptr;
+      HIP_TRY(hipMalloc((void **)&c->d_iir_coef, sizeof(float) * 20 * ng));
+      c->iir_sets = (int)ng;
+      for (auto &g : c->groups) g.iir_dirty = true;
+    }
+  }
+  c->audio_kind = kind;
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    int rc = group_apply_audio_filter(c, (int)i, stream);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
+}
+extern "C" int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out20) {
+  if (check_group(c, group) != RDSP_OK || !out20) return RDSP_ERR_INVALID;
+  memcpy(out20, c->groups[(size_t)group].iir, sizeof(float) * 20);
+  return RDSP_OK;
 }
 extern "C" int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream) {
   NEED(c);
@@ -924,9 +1018,7 @@ extern "C" uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode
   if (mode == RDSP_DEMOD_SAM && ensure_sam(c) != RDSP_OK) return 0;
   g.demod = mode;
   if (group == 0) c->cfg.demod = mode;
-  double lo, hi;
-  passband(g.audio_filter, mode, &lo, &hi);
-  (void)rdsp_group_reInitializeFilter(c, group, lo, hi, stream);
+  (void)group_apply_audio_filter(c, group, stream);
   return demod_tuning_offset(mode);
 }
 extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream) {
@@ -968,6 +1060,7 @@ extern "C" int rdsp_chain_set_groups(rdsp_chain_t *c, int n_groups, const uint16
     rc = group_stage(c, g);
     if (rc != RDSP_OK) return rc;
   }
+  if (c->audio_kind == RDSP_AUDIO_KIND_IIR) return rdsp_sdr_setAudioFilterKind(c, RDSP_AUDIO_KIND_IIR, nullptr);
   return RDSP_OK;
 }
 

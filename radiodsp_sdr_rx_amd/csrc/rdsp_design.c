@@ -211,6 +211,65 @@ int rdsp_fd_decimator_image(const float *h_nat, int fft_l, float *image) {
   return 0;
 }
 
+/* ---- biquad design -------------------------------------------------------
+ * AudioFilterBiquad::setLowpass / setHighpass / setBandpass / setNotch (INO:155-156 calls
+ * setHighpass(0, 500, 0.5)): the RBJ audio-EQ cookbook sections the Teensy library documents.
+ * kind 0 LP, 1 HP, 2 BP (constant peak gain), 3 notch.  Output in the cascade kernel's order
+ * {b0, b1, b2, -a1, -a2} (feedback terms are added, as arm_biquad_cascade_df1_f32 stores them). */
+void rdsp_biquad_design(int kind, double freq, double q, double fs, float *coef5) {
+  const double w0 = 2.0 * kPi * freq / fs;
+  const double cs = cos(w0), alpha = sin(w0) / (2.0 * q);
+  const double a0 = 1.0 + alpha;
+  double num[3];
+  if (kind == 0) { num[1] = 1.0 - cs; num[0] = num[2] = 0.5 * num[1]; }
+  else if (kind == 1) { num[1] = -(1.0 + cs); num[0] = num[2] = -0.5 * num[1]; }
+  else if (kind == 2) { num[0] = alpha; num[1] = 0.0; num[2] = -alpha; }
+  else { num[0] = num[2] = 1.0; num[1] = -2.0 * cs; }
+  for (int i = 0; i < 3; i++) coef5[i] = (float)(num[i] / a0);
+  coef5[3] = (float)(2.0 * cs / a0);
+  coef5[4] = (float)(-(1.0 - alpha) / a0);
+}
+
+/* The engine's audio filter bank (SDR.setAudioFilter, CTL:153-177): SURVEY Appendix C reads
+ * 8th-order band-passes, -3 dB at 150 Hz and at 2.1 ... 3.9 kHz, out of the firmware's
+ * coefficient table.  Here: Butterworth, 4th-order low-pass prototype -> band-pass -> bilinear
+ * transform with pre-warped edges, four sections each with zeros at z = +1 and z = -1, unit gain
+ * at the geometric centre, the gain shared equally by the sections.  Complex arithmetic in
+ * double; the float coefficients are what the kernel and the state read-back use. */
+#include <complex.h>
+void rdsp_design_audio_iir(double f1, double f2, double fs, float *coef20) {
+  const double k = 2.0 * fs;
+  const double wa = k * tan(kPi * f1 / fs), wb = k * tan(kPi * f2 / fs);
+  const double bw = wb - wa, w0sq = wa * wb;
+  double complex zp[4];
+  int n = 0;
+  for (int m = 0; m < 2; m++) { /* the two prototype poles of the upper half plane */
+    const double complex p = cexp(I * kPi * (2.0 * m + 5.0) / 8.0);
+    const double complex hb = 0.5 * bw * p, root = csqrt(hb * hb - w0sq);
+    const double complex sp[2] = {hb - root, hb + root};
+    for (int i = 0; i < 2; i++) {
+      double complex sa = sp[i];
+      if (cimag(sa) < 0.0) sa = conj(sa);
+      zp[n++] = (k + sa) / (k - sa);
+    }
+  }
+  const double complex zc = cexp(-I * 2.0 * kPi * sqrt(f1 * f2) / fs); /* z^-1 at the centre */
+  double complex h = 1.0;
+  for (int i = 0; i < 4; i++) {
+    const double a1 = -2.0 * creal(zp[i]), a2 = creal(zp[i] * conj(zp[i]));
+    h *= (1.0 - zc * zc) / (1.0 + a1 * zc + a2 * zc * zc);
+  }
+  const double g = pow(cabs(h), -0.25);
+  for (int i = 0; i < 4; i++) {
+    float *c = coef20 + 5 * i;
+    c[0] = (float)g;
+    c[1] = 0.0f;
+    c[2] = (float)-g;
+    c[3] = (float)(2.0 * creal(zp[i]));
+    c[4] = (float)(-creal(zp[i] * conj(zp[i])));
+  }
+}
+
 /* NCO: phase increment in turns*2^32; constant rotations for k samples */
 uint32_t rdsp_nco_dphi(double hz, double fs) {
   const double turns = hz / fs;

@@ -116,9 +116,31 @@ struct RdspTailParams {
   float2 *out_f32;
 };
 
+/* biquad cascades (rdsp_biquad.hip): four DF1 stages per channel, one stage per lane of a quad.
+ * Float mode: `buf` [ch][stride] in place (the chain's mono intermediate).  int16 mode (in16 /
+ * out16 non-null): samples taken / written every step16 / ostep16 int16 of [ch][stride16] rows. */
+struct RdspBiquadParams {
+  float *buf;
+  size_t stride;
+  const int16_t *in16;
+  size_t stride16;
+  int step16;
+  int16_t *out16;
+  size_t ostride16;
+  int ostep16;
+  int n_channels;          /* one past the last channel of this launch       */
+  int ch_base;
+  int n_samples;           /* multiple of 128                                */
+  const float *coef;       /* [n_sets][20]: {b0,b1,b2,a1,a2} x 4, feedback terms added */
+  const uint16_t *set_of;  /* [ch] coefficient set of each channel; NULL: set 0 */
+  float *state;            /* [ch][4 stages][x1,x2,y1,y2]                    */
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int rdsp_launch_biquad(const RdspBiquadParams *p, hipStream_t stream);
+int rdsp_launch_biquad_coef_store(float *dst, const float *coef20, hipStream_t stream);
 /* returns hipError_t as int */
 int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_channels,
                       hipStream_t stream);

@@ -72,6 +72,22 @@ class Graph:
         self._keep.append(analyser)
         return SpectrumNode(self, C.c_void_p(h))
 
+    def biquad_node(self, biquad):
+        """AudioFilterBiquad as a node (INO:58-59,75-78): one input, one output"""
+        h = self.lib.rdsp_biquad_node_create(self.h, biquad.h)
+        if not h:
+            raise _lib.RdspError(-1, self.lib.rdsp_last_error().decode())
+        self._keep.append(biquad)
+        return BiquadNode(self, C.c_void_p(h))
+
+    def fft1024_node(self, analyser):
+        """AudioAnalyzeFFT1024 as a node (INO:57,87): one input; available()/output like the library"""
+        h = self.lib.rdsp_fft1024_node_create(self.h, analyser.h)
+        if not h:
+            raise _lib.RdspError(-1, self.lib.rdsp_last_error().decode())
+        self._keep.append(analyser)
+        return Fft1024Node(self, C.c_void_p(h))
+
     def AudioConnection(self, src, src_port, dst, dst_port):
         _lib.check(self.lib.rdsp_connect(src.h, src_port, dst.h, dst_port))
 
@@ -137,6 +153,23 @@ class SpectrumNode(Node):
 
     def status(self):
         return self.g.lib.rdsp_spectrum_node_status(self.h)
+
+
+class BiquadNode(Node):
+    def status(self):
+        return self.g.lib.rdsp_biquad_node_status(self.h)
+
+
+class Fft1024Node(Node):
+    def available(self):
+        return bool(self.g.lib.rdsp_fft1024_node_available(self.h))
+
+    def output(self):     # uint16 [n_channels, 512]
+        p = self.g.lib.rdsp_fft1024_node_output(self.h)
+        return np.ctypeslib.as_array(p, (self.g.n_channels, 512)).copy()
+
+    def status(self):
+        return self.g.lib.rdsp_fft1024_node_status(self.h)
 
 
 class InputNode(Node):

@@ -85,8 +85,15 @@ class Nlms64:
 class Model:
     """One channel, float64.  Same configuration keys as the oracle."""
 
-    def __init__(self, **kw):
+    def __init__(self, iir_coef=None, **kw):
+        """iir_coef: the engine's IIR audio filter as 20 floats ({b0, b1, b2, -a1, -a2} x 4), applied
+        to the demodulated audio in float64 (SciPy's sosfilt: the same difference equations)"""
         from oracle_lib import DEFAULTS, DEMOD, AGC, ALS
+        self.iir_sos = None
+        if iir_coef is not None:
+            q = np.asarray(iir_coef, np.float64).reshape(4, 5)
+            self.iir_sos = np.stack([q[:, 0], q[:, 1], q[:, 2], np.ones(4), -q[:, 3], -q[:, 4]], axis=1)
+            self.iir_zi = np.zeros((4, 2))
         c = dict(DEFAULTS)
         c.update(kw)
         for k, tab in (("demod", DEMOD), ("agc_mode", AGC), ("als_mode", ALS)):
@@ -171,6 +178,10 @@ class Model:
             R = L.copy()
             self.dc = dn
         elif c["demod"] != 0:
+            R = L.copy()
+        if self.iir_sos is not None and c["demod"] != 0:
+            from scipy import signal
+            L, self.iir_zi = signal.sosfilt(self.iir_sos, L, zi=self.iir_zi)
             R = L.copy()
         if c["lms_nr"] > 0:
             if c["lms_nr"] != self.old_nr:

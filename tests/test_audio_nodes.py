@@ -1,0 +1,338 @@
+"""SURVEY 8f row F3 (rest) and the graph's second analyser:
+  * AudioFilterBiquad (`biquad1.setHighpass(0, 500, 0.5)` in front of the panadapter,
+    RadioDSP_SDR_RX.ino:58-59,75-78,155-156) and the engine's IIR audio filter bank
+    (SDR.setAudioFilter, RDSP_controls.h:153-177) -- csrc/rdsp_biquad.hip;
+  * AudioAnalyzeFFT1024 on Q_out_L (RadioDSP_SDR_RX.ino:57,87) -- csrc/rdsp_fft1024.hip.
+Both libraries are outside the tree: the oracle states the build-defined arithmetic; the design
+formulas are anchored on SciPy (float64, this container only).  CPU tests: design and oracle
+known answers.  GPU tests: bit-exact (integer FFT; int16-in/int16-out biquad) or TOL (chain)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cases import K1, TOL
+
+F32P, I16P = C.POINTER(C.c_float), C.POINTER(C.c_int16)
+
+
+def _bind(lib):
+    lib.orc_design_butter_bp8.argtypes = [C.c_double, C.c_double, C.c_double, F32P]
+    lib.orc_biquad_design.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, F32P]
+    lib.orc_cfft_radix4_q15_n.argtypes = [I16P, C.c_int]
+    lib.orc_fft1024_create.restype = C.c_void_p
+    lib.orc_fft1024_create.argtypes = [C.c_int]
+    lib.orc_fft1024_destroy.argtypes = [C.c_void_p]
+    lib.orc_fft1024_update.argtypes = [C.c_void_p, I16P]
+    lib.orc_fft1024_update.restype = C.c_int
+    lib.orc_fft1024_output.argtypes = [C.c_void_p]
+    lib.orc_fft1024_output.restype = C.POINTER(C.c_uint16)
+    lib.orc_set_audio_iir.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    lib.orc_chain_iir_coeffs.argtypes = [C.c_void_p]
+    lib.orc_chain_iir_coeffs.restype = F32P
+    return lib
+
+
+class OrcBiquad(C.Structure):
+    _fields_ = [("n_stages", C.c_int), ("coef", C.c_float * 20), ("state", C.c_float * 16)]
+
+
+def oracle_biquad(lib, coef20, x):
+    """float DF1 cascade of the oracle over a float array (fresh state)"""
+    b = OrcBiquad()
+    lib.orc_biquad_init.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_biquad_run.argtypes = [C.POINTER(OrcBiquad), F32P, C.c_int]
+    c = np.ascontiguousarray(coef20, np.float32)
+    lib.orc_biquad_init(C.byref(b), 4, c.ctypes.data_as(F32P))
+    y = np.ascontiguousarray(x, np.float32).copy()
+    lib.orc_biquad_run(C.byref(b), y.ctypes.data_as(F32P), len(y))
+    return y
+
+
+def oracle_fft1024(lib, x, window):
+    s = lib.orc_fft1024_create(window)
+    outs = []
+    for b in range(len(x) // 128):
+        blk = np.ascontiguousarray(x[b * 128:(b + 1) * 128], np.int16)
+        if lib.orc_fft1024_update(s, blk.ctypes.data_as(I16P)):
+            outs.append(np.ctypeslib.as_array(lib.orc_fft1024_output(s), (512,)).copy())
+    lib.orc_fft1024_destroy(s)
+    return np.stack(outs) if outs else np.zeros((0, 512), np.uint16)
+
+
+# ---- CPU: designs and oracle known answers ------------------------------------------------------
+@pytest.mark.parametrize("f2", [2100.0, 2700.0, 3100.0, 3900.0])
+def test_audio_iir_design_is_the_butterworth_bandpass(rdsp, oracle, f2):
+    """8th-order band-passes 150 Hz .. 2.1/2.7/3.1/3.9 kHz.  Product design,
+    oracle design and SciPy's Butterworth agree; -3 dB sits on the two edges."""
+    from scipy import signal
+    from radiodsp_sdr_rx_amd.filters import design_audio_iir
+    lib = _bind(oracle.load())
+    fs = 24000.0
+    mine = design_audio_iir(150.0, f2, fs)
+    ref = np.zeros(20, np.float32)
+    lib.orc_design_butter_bp8(150.0, f2, fs, ref.ctypes.data_as(F32P))
+    assert np.abs(mine - ref).max() <= 2e-6          # two independently written designs
+    w = np.concatenate([np.linspace(20, 11900, 600), [150.0, f2, np.sqrt(150.0 * f2)]])
+
+    def resp(c):
+        sos = np.array([[c[5 * s], c[5 * s + 1], c[5 * s + 2], 1.0, -c[5 * s + 3], -c[5 * s + 4]] for s in range(4)], np.float64)
+        return np.abs(signal.sosfreqz(sos, worN=w, fs=fs)[1])
+
+    h = resp(mine)
+    h_ref = np.abs(signal.sosfreqz(signal.butter(4, [150.0, f2], btype="band", fs=fs, output="sos"), worN=w, fs=fs)[1])
+    assert np.abs(h - h_ref).max() < 1e-4
+    assert abs(20 * np.log10(h[-3]) + 3.0103) < 0.01 and abs(20 * np.log10(h[-2]) + 3.0103) < 0.01
+    assert abs(h[-1] - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("kind,btype", [(0, "lowpass"), (1, "highpass")])
+def test_rbj_sections_known_answers(rdsp, oracle, kind, btype):
+    """setLowpass / setHighpass at q = 0.7071 are 2nd-order Butterworth sections (RBJ cookbook);
+    setBandpass peaks at 1 at the centre; setNotch is zero there; INO:155 (500 Hz, q 0.5)."""
+    from scipy import signal
+    from radiodsp_sdr_rx_amd.filters import biquad_design
+    lib = _bind(oracle.load())
+    fs = 44117.64706
+    c = biquad_design(kind, 1000.0, np.sqrt(0.5), fs)
+    o = np.zeros(5, np.float32)
+    lib.orc_biquad_design(kind, 1000.0, float(np.sqrt(0.5)), fs, o.ctypes.data_as(F32P))
+    assert np.abs(c - o).max() <= 1e-7
+    b, a = signal.butter(2, 1000.0, btype=btype, fs=fs)
+    assert np.abs(c[:3] - b).max() < 1e-6 and abs(c[3] + a[1]) < 1e-6 and abs(c[4] + a[2]) < 1e-6
+    for k, want in ((2, 1.0), (3, 0.0)):
+        cc = biquad_design(k, 1000.0, 2.0, fs).astype(np.float64)
+        z = np.exp(-2j * np.pi * 1000.0 / fs)
+        hc = (cc[0] + cc[1] * z + cc[2] * z * z) / (1.0 - cc[3] * z - cc[4] * z * z)
+        assert abs(abs(hc) - want) < 1e-6
+    hp = biquad_design(1, 500.0, 0.5, fs).astype(np.float64)   # biquad1.setHighpass(0, 500, 0.5)
+    assert abs((hp[0] + hp[1] + hp[2]) / (1.0 - hp[3] - hp[4])) < 1e-6          # no DC
+    assert abs(abs((hp[0] - hp[1] + hp[2]) / (1.0 + hp[3] - hp[4])) - 1.0) < 1e-5  # unity at fs/2
+
+
+def test_oracle_biquad_cascade_matches_scipy(oracle):
+    from scipy import signal
+    lib = _bind(oracle.load())
+    coef = np.zeros(20, np.float32)
+    lib.orc_design_butter_bp8(150.0, 2700.0, 24000.0, coef.ctypes.data_as(F32P))
+    rng = np.random.default_rng(3)
+    x = (0.3 * rng.standard_normal(4096)).astype(np.float32)
+    y = oracle_biquad(lib, coef, x)
+    c = coef.astype(np.float64)
+    sos = np.array([[c[5 * s], c[5 * s + 1], c[5 * s + 2], 1.0, -c[5 * s + 3], -c[5 * s + 4]] for s in range(4)])
+    ref = signal.sosfilt(sos, x.astype(np.float64))
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-5   # float32 recursion against float64
+
+
+def test_oracle_fft1024_known_answers(oracle):
+    """frames after 8 blocks then every 4; a full-scale-ish tone on bin 37 shows up there with the
+    magnitude the 1/1024 scaling of the radix-4 passes gives; Hann spreads it over three bins."""
+    lib = _bind(oracle.load())
+    n = np.arange(20 * 128)
+    x = np.round(16000 * np.cos(2 * np.pi * 37 * n / 1024)).astype(np.int16)
+    out = oracle_fft1024(lib, x, 0)
+    assert out.shape == (4, 512)                     # 20 blocks: frames at 8, 12, 16, 20
+    assert out[0].argmax() == 37 and abs(int(out[0, 37]) - 8000) <= 12
+    assert np.delete(out[0], 37).max() <= 12         # fixed-point noise floor
+    hann = oracle_fft1024(lib, x, 1)
+    assert hann[1].argmax() == 37 and abs(int(hann[1, 37]) - 4000) <= 12
+    assert abs(int(hann[1, 36]) - 2000) <= 12 and abs(int(hann[1, 38]) - 2000) <= 12
+    # the generic radix-4 routine at 256 points is the F1 routine
+    rng = np.random.default_rng(2)
+    buf = (rng.standard_normal(512) * 4000).astype(np.int16)
+    a, b = buf.copy(), buf.copy()
+    lib.orc_cfft_radix4_q15_n(a.ctypes.data_as(I16P), 256)
+    lib.orc_cfft_radix4_q15_256.argtypes = [I16P]
+    lib.orc_cfft_radix4_q15_256(b.ctypes.data_as(I16P))
+    assert np.array_equal(a, b)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", ["none", "AudioWindowHanning1024", "AudioWindowBlackmanHarris1024"])
+def test_gpu_fft1024_is_bit_exact(rdsp, oracle, window):
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.filters import WINDOWS, AnalyzeFFT1024
+    lib = _bind(oracle.load())
+    nch, nblk = 5, 44
+    audio = synth_iq(nch, nblk * 128)[..., 0].copy()          # any int16 stream will do
+    want = [oracle_fft1024(lib, audio[c], WINDOWS[window]) for c in range(nch)]
+    dev = torch.from_numpy(audio).cuda()
+    an = AnalyzeFFT1024(nch, window=window)
+    one = an.update(dev).cpu().numpy().view(np.uint16)
+    assert one.shape == (nch, 10, 512)
+    for c in range(nch):
+        assert np.array_equal(one[c], want[c])
+    # split calls (3, 5, 1, 7, 12, 16 blocks): the buffered blocks live on the device
+    an2 = AnalyzeFFT1024(nch, window=window)
+    got, pos = [], 0
+    for k in (3, 5, 1, 7, 12, 16):
+        got.append(an2.update(dev[:, pos * 128:(pos + k) * 128]).cpu().numpy().view(np.uint16))
+        pos += k
+    assert np.array_equal(np.concatenate(got, axis=1), one)
+    assert an2.available() and not an2.available()
+
+
+@pytest.mark.gpu
+def test_gpu_fft1024_on_the_chain_output_like_the_sketch(rdsp, oracle):
+    """`AudioConnection c7(Q_out_L, 0, AudioFFT, 0)` (INO:87): the analyser reads the L side of the
+    chain's interleaved int16 audio in place (sample stride 2)."""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024
+    lib = _bind(oracle.load())
+    nch, nblk = 3, 128
+    iq = synth_iq(nch, nblk * 128)
+    out = Chain(nch, max_blocks_per_call=nblk, **K1).process(torch.from_numpy(iq).cuda())
+    torch.cuda.synchronize()
+    an = AnalyzeFFT1024(nch, window="AudioWindowHanning1024")
+    spec = an.update(out[..., 0]).cpu().numpy().view(np.uint16)
+    L = out[..., 0].cpu().numpy()
+    for c in range(nch):
+        assert np.array_equal(spec[c], oracle_fft1024(lib, L[c], 1))
+    # the USB tones of the synthetic input (700 Hz, 1900 Hz, interferer 1000 Hz) at 24 kHz / 1024 per bin
+    peak = spec[0, -1].astype(int)
+    for f in (700.0, 1000.0, 1900.0):
+        k = int(round(f / (24000.0 / 1024)))
+        assert peak[k - 1:k + 2].max() > 8 * np.median(peak[:128])
+
+
+@pytest.mark.gpu
+def test_gpu_biquad_is_bit_exact_and_streams(rdsp, oracle):
+    """AudioFilterBiquad on int16 audio: same float operations as the oracle in the same order,
+    so the int16 output is identical; state carries across calls; ragged last wave (21 channels)."""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.filters import FilterBiquad
+    lib = _bind(oracle.load())
+    nch, nblk = 21, 24
+    iq = synth_iq(nch, nblk * 128)
+    x = iq[..., 0].copy()
+    bq = FilterBiquad(nch, fs=44117.64706)
+    bq.setHighpass(0, 500, 0.5)                      # INO:155
+    bq.setLowpass(1, 3000, 0.7071)
+    bq.setNotch(3, 1000, 4.0)                        # stage 2 left as pass-through
+    dev = torch.from_numpy(x).cuda()
+    y = torch.cat([bq.update(dev[:, :5 * 128]), bq.update(dev[:, 5 * 128:])], dim=1).cpu().numpy()
+    coef = bq.coeffs()
+    assert np.array_equal(coef[10:15], np.array([1, 0, 0, 0, 0], np.float32))
+    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
+    for c in range(nch):
+        ref = oracle_biquad(lib, coef, x[c].astype(np.float32) / np.float32(32768.0))
+        r16 = np.zeros(len(ref), np.int16)
+        lib.orc_float_to_q15(ref.ctypes.data_as(F32P), r16.ctypes.data_as(I16P), len(ref))
+        assert np.array_equal(y[c], r16), c
+    # the Q side of the interleaved stream through a second object (biquad2 of the sketch)
+    bq2 = FilterBiquad(nch, fs=44117.64706)
+    bq2.setHighpass(0, 500, 0.5)
+    iqd = torch.from_numpy(iq).cuda()
+    yq = bq2.update(iqd[..., 1]).cpu().numpy()
+    ref = oracle_biquad(lib, bq2.coeffs(), iq[3, :, 1].astype(np.float32) / np.float32(32768.0))
+    r16 = np.zeros(len(ref), np.int16)
+    lib.orc_float_to_q15(ref.ctypes.data_as(F32P), r16.ctypes.data_as(I16P), len(ref))
+    assert np.array_equal(yq[3], r16)
+
+
+@pytest.mark.gpu
+def test_iqinput_biquad_fft_wiring_of_the_sketch(rdsp, oracle):
+    """INO:75-78: IQinput -> biquad1 / biquad2 (high-pass 500 Hz) -> FFT (AudioAnalyzeFFT256IQ):
+    the panadapter path as graph nodes, against the oracle's biquad + analyser restatements."""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.filters import FilterBiquad
+    from radiodsp_sdr_rx_amd.graph import Graph
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    from test_spectrum import _olib, oracle_spectra
+    lib = _bind(_olib(oracle))
+    nch, nblk = 2, 40
+    iq = synth_iq(nch, nblk * 128)
+    g = Graph(nch)
+    g.AudioMemory(40)                                               # INO:151
+    IQinput = g.input_node()                                        # INO:52
+    b1, b2 = FilterBiquad(nch), FilterBiquad(nch)                   # INO:58-59
+    b1.setHighpass(0, 500, 0.5); b2.setHighpass(0, 500, 0.5)        # INO:155-156
+    biquad1, biquad2 = g.biquad_node(b1), g.biquad_node(b2)
+    fft = AnalyzeFFT256IQ(nch, naverage=8, window="AudioWindowHanning256")
+    FFT = g.spectrum_node(fft)                                      # INO:57
+    g.AudioConnection(IQinput, 0, biquad1, 0)                       # INO:75
+    g.AudioConnection(IQinput, 1, biquad2, 0)                       # INO:76
+    g.AudioConnection(biquad1, 0, FFT, 0)                           # INO:77
+    g.AudioConnection(biquad2, 0, FFT, 1)                           # INO:78
+    spectra = []
+    for b in range(nblk):
+        blk = np.ascontiguousarray(iq[:, b * 128:(b + 1) * 128])
+        IQinput.push(np.ascontiguousarray(blk[..., 0]), np.ascontiguousarray(blk[..., 1]))
+        assert g.update_all() == 0
+        if FFT.available():
+            spectra.append(FFT.output())
+    assert biquad1.status() == 0 and biquad2.status() == 0 and FFT.status() == 0 and len(spectra) == 4
+    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
+    coef = b1.coeffs()
+    for c in range(nch):
+        filt = np.zeros((nblk * 128, 2), np.int16)
+        for side in (0, 1):
+            y = oracle_biquad(lib, coef, iq[c, :, side].astype(np.float32) / np.float32(32768.0))
+            q = np.zeros(len(y), np.int16)
+            lib.orc_float_to_q15(y.ctypes.data_as(F32P), q.ctypes.data_as(I16P), len(y))
+            filt[:, side] = q
+        want = np.stack(oracle_spectra(lib, filt, 8, 1))
+        assert np.array_equal(np.stack([s[c] for s in spectra]), want)
+
+
+IIR_CASES = {
+    "usb_2700": (dict(fft_l=256, demod="USB"), 2),               # audio2700
+    "lsb_2100_agc": (dict(fft_l=512, demod="LSB", agc_mode="medium"), 1),
+    "cw_agc": (dict(fft_l=256, demod="CW_USB", agc_mode="fast", output_gain=0.5), 0),           # audioCW
+    "am_3900": (dict(fft_l=512, demod="AM"), 4),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(IIR_CASES))
+def test_engine_audio_filter_as_iir_bank_matches_oracle(rdsp, oracle, name):
+    """rdsp_sdr_setAudioFilterKind(IIR): the mask keeps the side band only, SDR.setAudioFilter picks
+    an 8th-order band-pass of four biquads on the demodulated audio.  Oracle: same mask band, same
+    float coefficients (read back from the chain; the designs are compared in the CPU test)."""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    lib = _bind(oracle.load())
+    lib.orc_biquad_init.argtypes = [C.c_void_p, C.c_int, F32P]
+    cfg, filt = IIR_CASES[name]
+    nch, nblk = 19, 64
+    iq = synth_iq(nch, nblk * 128, cw=name.startswith("cw"))
+    if name.startswith("cw"):
+        cfg = dict(cfg, nco_hz=12000.0)
+    ch = Chain(nch, max_blocks_per_call=nblk // 2, **cfg)
+    ch.setAudioFilterKind(1)
+    ch.setAudioFilter(filt)
+    ch.set_pipelined(True)
+    outs = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * (nblk // 2) * 128:(k + 1) * (nblk // 2) * 128])).cuda(),
+                       want_f32=True) for k in range(2)]
+    ch.flush()
+    torch.cuda.synchronize()
+    got = np.concatenate([o[1].cpu().numpy() for o in outs], axis=1)
+    coef = ch.iir_coeffs(0)
+    lo, hi = oracle.passband(filt, rdsp.DEMOD[cfg["demod"]])
+    f1, f2 = sorted((abs(lo), abs(hi)))
+    if cfg["demod"] == "AM":
+        f1, band = 150.0, (-4000.0, 4000.0)
+    else:
+        band = (-4000.0, -50.0) if cfg["demod"] == "LSB" else (50.0, 4000.0)
+    from radiodsp_sdr_rx_amd.filters import design_audio_iir
+    assert np.array_equal(coef, design_audio_iir(f1, f2, 24000.0))
+    import np_model
+    from test_gpu_parity import assert_truth_anchored
+    ocfg = dict(cfg, flo_hz=band[0], fhi_hz=band[1])
+    ref, f64 = [], []
+    for c in range(nch):
+        oc = oracle.OracleChain(**ocfg)
+        lib.orc_set_audio_iir(oc.h, 1, f1, f2)
+        # the chain's own float coefficients, so that the comparison is about the arithmetic
+        dst = np.ctypeslib.as_array(lib.orc_chain_iir_coeffs(oc.h), (20,))
+        dst[:] = coef
+        ref.append(oc.process(iq[c])[1])
+        f64.append(np_model.Model(iir_coef=coef, **ocfg).process(iq[c]))
+    # a recursive filter behind the chain (and, for AM, one that removes most of the envelope's
+    # amplitude): truth-anchored like the NLMS chains -- err(gpu, f64) <= max(TOL, 1.5 err(oracle, f64))
+    assert_truth_anchored(got, np.stack(ref), np.stack(f64), name)
