@@ -1224,6 +1224,11 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
 extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce) {
   NEED(c);
   if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce)) return RDSP_ERR_INVALID;
+  if (lanes_per_channel == 16 && matrix_reduce == 3) { /* the one-reduction-per-step kernel of round 1 (A/B runs) */
+    if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
+    c->tail_lpc = 102;
+    return RDSP_OK;
+  }
 #ifndef RDSP_EXPERIMENTAL
   if (!(lanes_per_channel == 16 && matrix_reduce == 2)) {
     rdsp_set_error("tail-kernel layouts other than the 16-lane row are only in EXPERIMENTAL=1 builds of the library");

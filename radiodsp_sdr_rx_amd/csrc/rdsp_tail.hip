@@ -334,7 +334,132 @@ struct NlmsM {
   }
 };
 
-template <int COLS, bool DUAL>
+/* ---- two steps per reduction: the product's NLMS (16-lane row, 6 taps per lane) -------------
+ * With W the weights after update n0-1, two consecutive outputs are
+ *     y_{n0}   = W.X_{n0}                         = A_0
+ *     y_{n0+1} = W.X_{n0+1} + g_{n0} (X_{n0}.X_{n0+1}) = A_1 + g_{n0} B_{n0+1},
+ * so the two dot products share the weights and are evaluated together: the accumulator is the
+ * packed pair (A_0, A_1), every tap one v_pk_fma of the tap (broadcast to both halves by op_sel)
+ * with the sample pair (x[m], x[m+1]) -- no horizontal add at the end -- and the 16-lane
+ * reduction runs once per two steps: lanes 0-7 send their A_1 partial across (row_ror:8) and keep
+ * A_0, lanes 8-15 the other way round, then three butterfly stages inside each half; the
+ * consumers read A_0 / A_1 with row_newbcast.  Both tap updates use the same sample pairs with
+ * the halves swapped (op_sel again).  Per two steps: 7 + 6 + 5 + 6 = 24 VALU instructions where
+ * the one-step form (NlmsM above) takes 28 plus two horizontal adds, and one pair of LDS reads
+ * (the next two sample pairs) instead of four single reads.
+ * Sample pairs live in an 8-slot register ring, Pair(m) = (mine[m], mine[m+1]) at slot m & 7
+ * (mine[m] = x[m - 6 sub]: the newest of this lane's six samples of X_m); a block at n0 uses
+ * Pair(n0-5 .. n0) and the two new ones are read one block ahead. */
+struct NlmsB {
+  static constexpr int TPL = 6, GS = 32, SCR = 3 * GS;
+  v2f w2[TPL / 2];
+  v2f P[8];
+  float energy;
+
+  static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) {
+    /* m even: one aligned ds_read_b64; m odd: two dwords (the compiler pairs them as ds_read2_b32) */
+    return v2f{mine[m], mine[m + 1]};
+  }
+  __device__ __forceinline__ void load(const float *wst, const float *prev, const float *est, size_t ch, int sub) {
+    (void)prev;
+#pragma unroll
+    for (int t = 0; t < TPL; t++) w2[t >> 1][t & 1] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))];
+    energy = est[ch];
+  }
+  __device__ __forceinline__ void store(float *wst, float *est, size_t ch, int sub) {
+#pragma unroll
+    for (int t = 0; t < TPL; t++) wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))] = w2[t >> 1][t & 1];
+    if (sub == 0) est[ch] = energy;
+  }
+
+  template <bool OUT_E>
+  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr,
+                                        int sub, int ci, float tri) {
+    const float *cur = ring + RDSP_BLOCK;
+    const float *dsrc = first ? cur : ring; /* NR:69-79 */
+    const float *mine = cur - TPL * sub;
+    float bb = 0.f; /* B_{-1} = X_{-2}.X_{-1} */
+#pragma unroll
+    for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
+    float b_base = chan_sum<16>(bb);
+    float e_base = energy;
+    NlmsM<16>::prepare(cur, 0, sub, ci, tri, mu, e_base, b_base, scr);
+#pragma unroll
+    for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld(mine, m);
+    v2f pn1 = pair_ld(mine, 1), pn2 = pair_ld(mine, 2);
+    const bool lo_half = ci < 8;
+#pragma unroll 1
+    for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
+      const float *sc = scr + ((s0 / GS) & 1) * SCR;
+      __syncthreads();
+      float4 gq = *reinterpret_cast<const float4 *>(sc);
+      float4 bq = *reinterpret_cast<const float4 *>(sc + GS);
+      float4 dq = *reinterpret_cast<const float4 *>(dsrc + s0);
+      e_base = sc[2 * GS + GS - 1];
+      b_base = sc[GS + GS - 1];
+      if (s0 + GS < RDSP_BLOCK)
+        NlmsM<16>::prepare(cur, s0 + GS, sub, ci, tri, mu, e_base, b_base, scr + (((s0 / GS) + 1) & 1) * SCR);
+#pragma unroll
+      for (int q = 0; q < GS / 4; q++) {
+        const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, bn[4] = {bq.x, bq.y, bq.z, bq.w};
+        const float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+        if (q < GS / 4 - 1) {
+          gq = *reinterpret_cast<const float4 *>(sc + 4 * (q + 1));
+          bq = *reinterpret_cast<const float4 *>(sc + GS + 4 * (q + 1));
+          dq = *reinterpret_cast<const float4 *>(dsrc + s0 + 4 * (q + 1));
+        }
+        float o4[4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int n = 4 * q + 2 * h; /* block start inside the group; s0 is a multiple of 8 */
+          /* (A_0, A_1) lane parts: taps k = 0..5 against Pair(n - k), two chains */
+          v2f aa = v2f{w2[0][0], w2[0][0]} * P[n & 7];
+          v2f ab = v2f{w2[0][1], w2[0][1]} * P[(n - 1) & 7];
+          aa = __builtin_elementwise_fma(v2f{w2[1][0], w2[1][0]}, P[(n - 2) & 7], aa);
+          ab = __builtin_elementwise_fma(v2f{w2[1][1], w2[1][1]}, P[(n - 3) & 7], ab);
+          aa = __builtin_elementwise_fma(v2f{w2[2][0], w2[2][0]}, P[(n - 4) & 7], aa);
+          ab = __builtin_elementwise_fma(v2f{w2[2][1], w2[2][1]}, P[(n - 5) & 7], ab);
+          const v2f acc = aa + ab;
+          /* one reduction for both: halves swap their partner's value across the row */
+          const float keep = lo_half ? acc[0] : acc[1], send = lo_half ? acc[1] : acc[0];
+          float t = keep + dpp_f<0x128>(send); /* row_ror:8 */
+          t += dpp_f<0x141>(t);                /* row_half_mirror */
+          t += dpp_f<0x4E>(t);                 /* quad_perm [2,3,0,1] */
+          t += dpp_f<0xB1>(t);                 /* quad_perm [1,0,3,2] */
+          /* lanes 0-7 hold A_0, lanes 8-15 A_1 */
+          const float dA0 = dd[2 * h] - dpp_f<0x150>(t);     /* row_newbcast:0 */
+          const float dA1 = dd[2 * h + 1] - dpp_f<0x158>(t); /* row_newbcast:8 */
+          const float g0 = dA0 * gi[2 * h];                  /* e_{n0} = d - A_0 */
+          const float e1 = fmaf(-g0, bn[2 * h + 1], dA1);    /* d - (A_1 + g_{n0} B_{n0+1}) */
+          const float g1 = e1 * gi[2 * h + 1];
+          o4[2 * h] = OUT_E ? dA0 : dd[2 * h] - dA0;
+          o4[2 * h + 1] = OUT_E ? e1 : dd[2 * h + 1] - e1;
+          /* W += g_{n0} X_{n0} + g_{n0+1} X_{n0+1}: tap pair kk against the swapped sample pairs */
+          const v2f gg0 = {g0, g0}, gg1 = {g1, g1};
+#pragma unroll
+          for (int kk = 0; kk < TPL / 2; kk++) {
+            const v2f p0 = P[(n - 2 * kk - 1) & 7], p1 = P[(n - 2 * kk) & 7];
+            w2[kk] = __builtin_elementwise_fma(gg0, __builtin_shufflevector(p0, p0, 1, 0), w2[kk]);
+            w2[kk] = __builtin_elementwise_fma(gg1, __builtin_shufflevector(p1, p1, 1, 0), w2[kk]);
+          }
+          /* the ring moves on two samples; the pairs after these are requested now */
+          P[(n + 1) & 7] = pn1;
+          P[(n + 2) & 7] = pn2;
+          const bool more = (n + 4 < GS) || (s0 + GS < RDSP_BLOCK); /* Pair(n0 + 3), Pair(n0 + 4) exist */
+          if (more) {
+            pn1 = pair_ld(mine, s0 + n + 3);
+            pn2 = pair_ld(mine, s0 + n + 4);
+          }
+        }
+        *reinterpret_cast<float4 *>(out + s0 + 4 * q) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    energy = e_base;
+  }
+};
+
+template <int COLS, bool DUAL, typename NL = NlmsM<COLS>>
 __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   using G = Geo<COLS>;
   constexpr int CPW = G::CPW, SPL = G::SPL;
@@ -368,7 +493,7 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   const int o_first = one_is_nr ? p.nr_first : p.als_first;
   const int o_mode = one_is_nr ? p.nr_mode : p.als_mode; /* 0: 1.1*y, 1: e, 2: y */
 
-  NlmsM<COLS> nr, als; /* !DUAL: `als` is the one instance */
+  NL nr, als; /* !DUAL: `als` is the one instance */
   if constexpr (DUAL) {
     nr.load(p.nr_w, p.nr_prev, p.nr_energy, ch, sub);
     als.load(p.als_w, p.als_prev, p.als_energy, ch, sub);
@@ -508,14 +633,18 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
 }
 
 /* two NLMS instances (DSP-NR feeding the ALS filter) */
-__global__ void __launch_bounds__(64) rdsp_tail_dual_kernel(RdspTailParams p) { tailm_body<16, true>(p); }
+__global__ void __launch_bounds__(64) rdsp_tail_dual_kernel(RdspTailParams p) { tailm_body<16, true, NlmsB>(p); }
 
 /* The default (one NLMS instance) with its registers capped at 112: in pipelined mode it shares
- * a SIMD's 512 VGPRs with two waves of the front kernel (2 x 200), and a tail wave that does
- * not fit waits for a front wave to retire (measured: 1.8 -> 2.4 ms per K3 step at 122
- * registers).  amdgpu_num_vgpr counts half of the unified file on gfx950; the cap costs four
- * dwords of scratch outside the step loop. */
+ * a SIMD's 512 VGPRs with two waves of the front kernel, and a tail wave that does not fit waits
+ * for a front wave to retire (measured in round 1: 1.8 -> 2.4 ms per K3 step at 122 registers).
+ * amdgpu_num_vgpr counts half of the unified file on gfx950. */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(56))) rdsp_tail_kernel(RdspTailParams p) {
+  tailm_body<16, false, NlmsB>(p);
+}
+/* the one-step form of round 1 (one reduction per step), kept selectable for A/B runs */
+__global__ void __launch_bounds__(64) rdsp_tail1_dual_kernel(RdspTailParams p) { tailm_body<16, true>(p); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(56))) rdsp_tail1_kernel(RdspTailParams p) {
   tailm_body<16, false>(p);
 }
 
@@ -542,10 +671,16 @@ extern "C" int rdsp_launch_tail_shift(const RdspTailParams *p, hipStream_t strea
  * DPP, experimental/rdsp_tail_shift.hip), 101 (half a row per channel), 116 / 108 (16 / 8 lanes
  * with the reduction on the matrix pipe). */
 extern "C" int rdsp_launch_tail(const RdspTailParams *p, int variant, hipStream_t stream) {
-  if (variant == 100) {
+  if (variant == 100 || variant == 102) {
     const int grid = (p->n_channels - p->ch_base + 3) / 4;
-    if (p->nr_on && p->als_mode) hipLaunchKernelGGL(rdsp_tail_dual_kernel, dim3(grid), dim3(64), 0, stream, *p);
-    else hipLaunchKernelGGL(rdsp_tail_kernel, dim3(grid), dim3(64), 0, stream, *p);
+    const bool dual = p->nr_on && p->als_mode;
+    if (variant == 100) {
+      if (dual) hipLaunchKernelGGL(rdsp_tail_dual_kernel, dim3(grid), dim3(64), 0, stream, *p);
+      else hipLaunchKernelGGL(rdsp_tail_kernel, dim3(grid), dim3(64), 0, stream, *p);
+    } else { /* 102: one reduction per step (round 1) */
+      if (dual) hipLaunchKernelGGL(rdsp_tail1_dual_kernel, dim3(grid), dim3(64), 0, stream, *p);
+      else hipLaunchKernelGGL(rdsp_tail1_kernel, dim3(grid), dim3(64), 0, stream, *p);
+    }
     return (int)hipGetLastError();
   }
 #ifdef RDSP_EXPERIMENTAL
