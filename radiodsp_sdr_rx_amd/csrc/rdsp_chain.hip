@@ -87,7 +87,7 @@ struct rdsp_chain {
   hipEvent_t ev_fence = nullptr;      /* after the most recent front launch */
   bool fence_valid = false;
   float *d_fir_hc = nullptr;
-  float2 *d_fd_mask = nullptr; /* [4][N] branch spectra of the frequency-domain decimator (one wave per channel: N <= 1024) */
+  float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (one wave per channel: N <= 1024) */
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
   float *d_scal = nullptr;
@@ -395,8 +395,8 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
     }
     HIP_TRY(hipMemcpy(c->d_fir_hc, hc.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
     if (c->N / rdsp_plan_radix(c->N) == 64) {
-      std::vector<float> img(2 * 4 * (size_t)c->N);
-      if (rdsp_fd_decimator_image(c->fir_nat.data(), c->N, img.data()) != 0) {
+      std::vector<float> img(2 * 4 * (size_t)RDSP_FD_N);
+      if (rdsp_fd_decimator_image(c->fir_nat.data(), RDSP_FD_N, img.data()) != 0) {
         rdsp_set_error("decimator spectra failed");
         return RDSP_ERR_INVALID;
       }

@@ -10,6 +10,8 @@
 
 #define RDSP_BLOCK 128
 #define RDSP_LMS_TAPS 96
+#define RDSP_FD_N 512 /* transform size of the frequency-domain decimator (rdsp_front_fd_kernel) */
+#define RDSP_FD_P 8
 #define RDSP_XP 84 /* entries per polyphase sub-plane in LDS (81 used, 84 keeps
                       the sub-plane stride at 8 banks mod 32) */
 
@@ -56,8 +58,8 @@ struct RdspFrontParams {
   int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */
   int fir_matrix;          /* 1: decimating FIR as v_mfma GEMM slices (EXPERIMENTAL builds)    */
   int fir_fd;              /* 1: decimator in the frequency domain (rdsp_front_fd_kernel)      */
-  const float2 *fd_mask;   /* [4][N] spectra of the polyphase branches g_r[k] = h[4k - r], /N,
-                              digit-reversed thread-major like the filter masks               */
+  const float2 *fd_mask;   /* [4][RDSP_FD_N] spectra of the polyphase branches g_r[k] = h[4k - r],
+                              /RDSP_FD_N, digit-reversed thread-major like the filter masks    */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
   int agc_on;
   float agc_attack, agc_decay;

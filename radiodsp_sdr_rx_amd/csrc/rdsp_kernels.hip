@@ -593,9 +593,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * evaluated as a polyphase overlap-save convolution instead of 1024 packed FMAs per chunk and lane:
  *     x[4q + r] = X_r[q]  (r = 0..3: the four int16 pairs of one aligned 16-byte load),
  *     y[m] = sum_r sum_{k<=64} g_r[k] X_r[m - k],   g_r[k] = h[4k - r]  (zero outside 0..255),
- * i.e. four N-point forward transforms of the mixed input at the LOW rate, a multiply-accumulate
- * with the branch spectra G_r (host-computed, /N, digit-reversed like the filter mask) and ONE
- * inverse transform: N - 64 valid outputs per frame.  That is the 4N-point overlap-save decimator
+ * i.e. four 512-point forward transforms of the mixed input at the LOW rate (512 whatever FFT_L is:
+ * 448 of 512 outputs are valid, and the radix-8 passes are the cheapest per point), a
+ * multiply-accumulate with the branch spectra G_r (host-computed, /512, digit-reversed like the
+ * filter mask) and ONE inverse transform: 448 valid outputs per frame.  That is the 4N-point overlap-save decimator
  * with its first two radix-2 levels folded into the masks (only N of the 4N bins survive the
  * fold by 4).  Per frame and lane at N = 512: 4 x 183 + 64 + 183 = 980 VALU instructions for
  * 1792 input samples, against 1792 packed FMAs in the direct form.
@@ -615,19 +616,23 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * sub-batches, channel partition) stays bit-identical. */
 template <int N, int P, bool LEAN, bool PRE>
 __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
-  using PL = FftPlan<N, P>;
+  using PL = FftPlan<N, P>;              /* the overlap-save filter's transform (FFT_L)     */
+  constexpr int ND = RDSP_FD_N, PD = RDSP_FD_P; /* the decimator's: 512 points whatever FFT_L is  */
+  using PLD = FftPlan<ND, PD>;
   constexpr int NT = PL::NT;
   constexpr int H = N / 2;
   constexpr int PH = P / 2;
-  constexpr int VAL = N - 64; /* valid outputs per decimator frame */
-  constexpr int RING = 2 * N; /* >= (H - 1) + VAL, power of two */
-  static_assert(NT == 64, "one wave per channel");
-  static_assert(VAL == 64 * (P - 1), "the last quad column of a frame is the first of the next");
+  constexpr int VAL = ND - 64; /* valid outputs per decimator frame */
+  constexpr int RING = 1024;   /* >= (H - 1) + VAL for FFT_L <= 1024, power of two */
+  constexpr bool SAME = (N == ND && P == PD); /* one plan: twiddles and LDS bases are shared */
+  static_assert(NT == 64 && PLD::NT == 64, "one wave per channel");
+  static_assert(VAL == 64 * (PD - 1), "the last quad column of a frame is the first of the next");
+  static_assert(H - 1 + VAL <= RING, "ring holds a frame's outputs behind an unfinished hop");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *ring = reinterpret_cast<float2 *>(smem_raw);
   float2 *wb = ring + RING;
-  float *red = reinterpret_cast<float *>(wb + PL::WB);
+  float *red = reinterpret_cast<float *>(wb + (PL::WB > PLD::WB ? PL::WB : PLD::WB));
 
   const bool SWAP_IQ = PRE && p.swap_iq != 0;
   const int tid = threadIdx.x;
@@ -645,10 +650,10 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   const int total = p.n_chunks * 256; /* outputs = input quads of this call */
 
   /* raw quads of frame 0: column 0 is the FIR history (the 64 quads before the call) */
-  uint4 rq[P];
+  uint4 rq[PD];
   rq[0] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * tid);
 #pragma unroll
-  for (int j = 1; j < P; j++) {
+  for (int j = 1; j < PD; j++) {
     const int q = tid + 64 * (j - 1);
     rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
   }
@@ -657,6 +662,15 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   tw.init(tid);
   LdsBases<N, P, false> lb;
   make_lds_bases<N, P, false>(tid, lb);
+  /* the decimator's plan: its own twiddles and LDS bases unless it is the filter's plan */
+  Twiddles<ND, PD, false> twd_own;
+  LdsBases<ND, PD, false> lbd_own;
+  if constexpr (!SAME) {
+    twd_own.init(tid);
+    make_lds_bases<ND, PD, false>(tid, lbd_own);
+  }
+  const auto &twd = [&]() -> const auto & { if constexpr (SAME) return tw; else return twd_own; }();
+  const auto &lbd = [&]() -> const auto & { if constexpr (SAME) return lb; else return lbd_own; }();
   uint32_t vadbits = 0;
 #pragma unroll
   for (int e = 0; e < P; e++) {
@@ -678,15 +692,15 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   for (int fr = 0; produced < total; fr++) {
     /* ---- A2: phasors of this lane's P quad columns (sample 4 q + r of a quad follows by rot_r) */
     const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + tid); /* absolute index of column 0 */
-    float2 pj[P];
+    float2 pj[PD];
     {
       float2 b1 = make_float2(1.f, 0.f);
       if (G.dphi != 0u) b1 = nco_phasor_alu((nq + 256u) * G.dphi);
       pj[1] = b1;
-      if constexpr (P > 2) pj[2] = cmul_pinned_u(b1, G.rotp1);
-      if constexpr (P > 3) pj[3] = cmul_pinned_u(b1, G.rotp2);
+      if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotp1);
+      if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotp2);
 #pragma unroll
-      for (int j = 4; j < P; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotp3);
+      for (int j = 4; j < PD; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotp3);
       /* column 0: history of the previous call in frame 0 (mixed with the increment it came in
        * with), else one column before b1 */
       if (fr == 0) pj[0] = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
@@ -695,19 +709,19 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
     const bool hist = (fr == 0);
 
     /* ---- A1 + A3: four branch transforms, multiply-accumulate with the branch spectra ------- */
-    float2 acc[P];
+    float2 acc[PD];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      float2 gm[P]; /* G_r slice of this lane: L2-resident, lands behind the transform */
+      float2 gm[PD]; /* G_r slice of this lane: L2-resident, lands behind the transform */
       {
-        const float2 *mp = p.fd_mask + (size_t)r * N;
+        const float2 *mp = p.fd_mask + (size_t)r * ND;
         asm volatile("" : "+s"(mp));
 #pragma unroll
-        for (int e = 0; e < P; e++) gm[e] = mp[e * NT + tid];
+        for (int e = 0; e < PD; e++) gm[e] = mp[e * NT + tid];
       }
-      float2 v[P];
+      float2 v[PD];
 #pragma unroll
-      for (int j = 0; j < P; j++) {
+      for (int j = 0; j < PD; j++) {
         uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
         if (SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
         float2 x = unpack_iq(w, p.scale_i, p.scale_q);
@@ -720,36 +734,36 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
         v[j] = cmul_pinned(x, ph);
       }
       if (r == 3) { /* the raw registers are free: next frame's loads land behind the transforms */
-        rq[0] = rq[P - 1];
+        rq[0] = rq[PD - 1];
 #pragma unroll
-        for (int j = 1; j < P; j++) {
+        for (int j = 1; j < PD; j++) {
           const int q = (fr + 1) * VAL + tid + 64 * (j - 1);
           rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
         }
       }
       {
-        float2 twp[P - 1];
-        tw.template get<0>(twp);
-        fwd_pass0_store<N, P>(lb, v, wb, twp);
+        float2 twp[PD - 1];
+        twd.template get<0>(twp);
+        fwd_pass0_store<ND, PD>(lbd, v, wb, twp);
       }
       __syncthreads();
-      fwd_mid_all<N, P, 1, PL::NP - 1, false>(lb, wb, tw, sync);
-      fwd_pass_last<N, P>(lb, v, wb);
+      fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lbd, wb, twd, sync);
+      fwd_pass_last<ND, PD>(lbd, v, wb);
       __syncthreads(); /* wb is rewritten by the next branch */
 #pragma unroll
-      for (int e = 0; e < P; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
+      for (int e = 0; e < PD; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
     }
-    inv_pass_last<N, P>(lb, acc, wb);
+    inv_pass_last<ND, PD>(lbd, acc, wb);
     __syncthreads();
-    inv_mid_all<N, P, PL::NP - 2, false>(lb, wb, tw, sync);
+    inv_mid_all<ND, PD, PLD::NP - 2, false>(lbd, wb, twd, sync);
     {
-      float2 twp[P - 1];
-      tw.template get<0>(twp);
-      inv_pass0_load<N, P>(lb, acc, wb, twp);
+      float2 twp[PD - 1];
+      twd.template get<0>(twp);
+      inv_pass0_load<ND, PD>(lbd, acc, wb, twp);
     }
     /* acc[j] = y at window index tid + 64 j; index 64 (j = 1) is output fr*VAL of the call */
 #pragma unroll
-    for (int j = 1; j < P; j++) {
+    for (int j = 1; j < PD; j++) {
       const int m = fr * VAL + tid + 64 * (j - 1);
       if (m < total) ring[m & (RING - 1)] = acc[j];
     }
@@ -787,7 +801,8 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
 
 template <int N, int P>
 constexpr size_t front_fd_lds() {
-  return (size_t)(2 * N + FftPlan<N, P>::WB) * sizeof(float2) + 64 * sizeof(float);
+  constexpr int wbn = FftPlan<N, P>::WB > FftPlan<RDSP_FD_N, RDSP_FD_P>::WB ? FftPlan<N, P>::WB : FftPlan<RDSP_FD_N, RDSP_FD_P>::WB;
+  return (size_t)(1024 + wbn) * sizeof(float2) + 64 * sizeof(float);
 }
 
 /* one group record, rewritten in stream order (32 threads, one dword each) */
