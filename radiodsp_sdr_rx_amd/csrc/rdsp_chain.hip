@@ -261,6 +261,9 @@ static void group_record(const rdsp_chain_t *c, const GroupState &g, int gi, int
   rdsp_nco_rot(r->dphi, 4 * nt, t); r->rotp1 = make_float2(t[0], t[1]);
   rdsp_nco_rot(r->dphi, 8 * nt, t); r->rotp2 = make_float2(t[0], t[1]);
   rdsp_nco_rot(r->dphi, 12 * nt, t); r->rotp3 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 256, t); r->rotq1 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 512, t); r->rotq2 = make_float2(t[0], t[1]);
+  rdsp_nco_rot(r->dphi, 768, t); r->rotq3 = make_float2(t[0], t[1]);
   r->mask_off = (uint32_t)(((size_t)gi * 2 + (size_t)buf) * (size_t)c->N);
   /* the FIR history was mixed with the increment of the launch that brought it in */
   r->dphi_hist = g.has_dev_dphi ? g.dev_dphi : r->dphi;
@@ -394,7 +397,7 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
       return RDSP_ERR_INVALID;
     }
     HIP_TRY(hipMemcpy(c->d_fir_hc, hc.data(), sizeof(float) * 256, hipMemcpyHostToDevice));
-    if (c->N / rdsp_plan_radix(c->N) == 64) {
+    {
       std::vector<float> img(2 * 4 * (size_t)RDSP_FD_N);
       if (rdsp_fd_decimator_image(c->fir_nat.data(), RDSP_FD_N, img.data()) != 0) {
         rdsp_set_error("decimator spectra failed");
@@ -1206,7 +1209,7 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   NEED(c);
   if (variant < -1 || variant > 3) return RDSP_ERR_INVALID;
   if (variant == 2 && !c->d_fd_mask) {
-    rdsp_set_error("the frequency-domain decimator needs decim = 4 and fft_l <= 1024");
+    rdsp_set_error("the frequency-domain decimator needs decim = 4");
     return RDSP_ERR_UNSUPPORTED;
   }
 #ifndef RDSP_EXPERIMENTAL

@@ -31,7 +31,9 @@ struct RdspGroup {
                           from dphi only in the first call after a tuning change   */
   float2 roth1, roth2, roth3; /* rot1..3 for dphi_hist                            */
   float2 rothp3;       /* rotp3 for dphi_hist                                      */
-  uint32_t pad[8];
+  float2 rotq1, rotq2, rotq3; /* the same for 256 k samples: one quad column of the
+                                 frequency-domain decimator's frame (rdsp_front_fd_kernel)   */
+  uint32_t pad[2];
 };
 
 /* front kernel: A1 unpack, A2 mixer, A3 decimator, A5 overlap-save filter,

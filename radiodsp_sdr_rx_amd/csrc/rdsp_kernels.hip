@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * identity across call splits holds for the direct form only; everything else (pipelining,
  * sub-batches, channel partition) stays bit-identical. */
 template <int N, int P, bool LEAN, bool PRE>
-__global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
+__global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;              /* the overlap-save filter's transform (FFT_L)     */
   constexpr int ND = RDSP_FD_N, PD = RDSP_FD_P; /* the decimator's: 512 points whatever FFT_L is  */
   using PLD = FftPlan<ND, PD>;
@@ -623,19 +623,24 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   constexpr int H = N / 2;
   constexpr int PH = P / 2;
   constexpr int VAL = ND - 64; /* valid outputs per decimator frame */
-  constexpr int RING = 1024;   /* >= (H - 1) + VAL for FFT_L <= 1024, power of two */
-  constexpr bool SAME = (N == ND && P == PD); /* one plan: twiddles and LDS bases are shared */
-  static_assert(NT == 64 && PLD::NT == 64, "one wave per channel");
+  /* FFT_L >= 2048 runs four waves per channel: every wave takes its own decimator frame (four
+   * frames per round, no sums across waves), then all of them share the overlap-save frames */
+  constexpr int NW = NT / 64;
+  constexpr int RING = (NW == 1) ? 1024 : 4096; /* >= (H - 1) + NW * VAL, power of two */
+  constexpr bool SAME = (N == ND && P == PD);   /* one plan: twiddles and LDS bases are shared */
+  static_assert((NT == 64 || NT == 256) && PLD::NT == 64, "one or four waves per channel, one per decimator frame");
   static_assert(VAL == 64 * (PD - 1), "the last quad column of a frame is the first of the next");
-  static_assert(H - 1 + VAL <= RING, "ring holds a frame's outputs behind an unfinished hop");
+  static_assert(H - 1 + NW * VAL <= RING, "ring holds a round's outputs behind an unfinished hop");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *ring = reinterpret_cast<float2 *>(smem_raw);
   float2 *wb = ring + RING;
-  float *red = reinterpret_cast<float *>(wb + (PL::WB > PLD::WB ? PL::WB : PLD::WB));
+  float *red = reinterpret_cast<float *>(wb + (PL::WB > NW * PLD::WB ? PL::WB : NW * PLD::WB));
 
   const bool SWAP_IQ = PRE && p.swap_iq != 0;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  float2 *wbd = wb + wave * PLD::WB; /* this wave's decimator work buffer (inside the filter's) */
   const size_t ch = (size_t)p.ch_base + blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
   RdspGroup G;
@@ -644,18 +649,19 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
     const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
     uint32_t r[32];
 #pragma unroll
-    for (int i = 0; i < 32; i++) r[i] = (i < 24) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gw[i]) : 0u;
+    for (int i = 0; i < 32; i++) r[i] = (i < 30) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gw[i]) : 0u;
     G = __builtin_bit_cast(RdspGroup, r);
   }
   const int total = p.n_chunks * 256; /* outputs = input quads of this call */
 
-  /* raw quads of frame 0: column 0 is the FIR history (the 64 quads before the call) */
+  /* raw quads of this wave's first frame (frame `wave`): column j holds quads
+   * fr*VAL - 64 + lane + 64 j; for frame 0 column 0 is the FIR history (the 64 quads before the call) */
   uint4 rq[PD];
-  rq[0] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * tid);
 #pragma unroll
-  for (int j = 1; j < PD; j++) {
-    const int q = tid + 64 * (j - 1);
-    rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+  for (int j = 0; j < PD; j++) {
+    const int q = wave * VAL - 64 + lane + 64 * j;
+    if (q < 0) rq[j] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * lane);
+    else rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
   }
 
   Twiddles<N, P, LEAN> tw;
@@ -666,8 +672,8 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   Twiddles<ND, PD, false> twd_own;
   LdsBases<ND, PD, false> lbd_own;
   if constexpr (!SAME) {
-    twd_own.init(tid);
-    make_lds_bases<ND, PD, false>(tid, lbd_own);
+    twd_own.init(lane);
+    make_lds_bases<ND, PD, false>(lane, lbd_own);
   }
   const auto &twd = [&]() -> const auto & { if constexpr (SAME) return tw; else return twd_own; }();
   const auto &lbd = [&]() -> const auto & { if constexpr (SAME) return lb; else return lbd_own; }();
@@ -689,22 +695,23 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   auto sync = []() { __syncthreads(); };
 
 #pragma unroll 1
-  for (int fr = 0; produced < total; fr++) {
+  for (int round = 0; produced < total; round++) {
+    const int fr = round * NW + wave; /* this wave's frame; past the end of the call it works on zeros */
     /* ---- A2: phasors of this lane's P quad columns (sample 4 q + r of a quad follows by rot_r) */
-    const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + tid); /* absolute index of column 0 */
+    const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + lane); /* absolute index of column 0 */
     float2 pj[PD];
     {
       float2 b1 = make_float2(1.f, 0.f);
       if (G.dphi != 0u) b1 = nco_phasor_alu((nq + 256u) * G.dphi);
       pj[1] = b1;
-      if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotp1);
-      if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotp2);
+      if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotq1);
+      if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotq2);
 #pragma unroll
-      for (int j = 4; j < PD; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotp3);
+      for (int j = 4; j < PD; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
       /* column 0: history of the previous call in frame 0 (mixed with the increment it came in
        * with), else one column before b1 */
       if (fr == 0) pj[0] = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
-      else pj[0] = cmulc_uniform(b1, G.rotp1);
+      else pj[0] = cmulc_uniform(b1, G.rotq1);
     }
     const bool hist = (fr == 0);
 
@@ -717,7 +724,7 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
         const float2 *mp = p.fd_mask + (size_t)r * ND;
         asm volatile("" : "+s"(mp));
 #pragma unroll
-        for (int e = 0; e < PD; e++) gm[e] = mp[e * NT + tid];
+        for (int e = 0; e < PD; e++) gm[e] = mp[e * 64 + lane];
       }
       float2 v[PD];
 #pragma unroll
@@ -733,41 +740,41 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
         }
         v[j] = cmul_pinned(x, ph);
       }
-      if (r == 3) { /* the raw registers are free: next frame's loads land behind the transforms */
-        rq[0] = rq[PD - 1];
+      if (r == 3) { /* the raw registers are free: the next frame's loads land behind the transforms */
+        if constexpr (NW == 1) rq[0] = rq[PD - 1]; /* consecutive frames share a column */
 #pragma unroll
-        for (int j = 1; j < PD; j++) {
-          const int q = (fr + 1) * VAL + tid + 64 * (j - 1);
+        for (int j = (NW == 1 ? 1 : 0); j < PD; j++) {
+          const int q = (fr + NW) * VAL - 64 + lane + 64 * j; /* >= 0: this is frame 1 or later */
           rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
         }
       }
       {
         float2 twp[PD - 1];
         twd.template get<0>(twp);
-        fwd_pass0_store<ND, PD>(lbd, v, wb, twp);
+        fwd_pass0_store<ND, PD>(lbd, v, wbd, twp);
       }
       __syncthreads();
-      fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lbd, wb, twd, sync);
-      fwd_pass_last<ND, PD>(lbd, v, wb);
+      fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lbd, wbd, twd, sync);
+      fwd_pass_last<ND, PD>(lbd, v, wbd);
       __syncthreads(); /* wb is rewritten by the next branch */
 #pragma unroll
       for (int e = 0; e < PD; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
     }
-    inv_pass_last<ND, PD>(lbd, acc, wb);
+    inv_pass_last<ND, PD>(lbd, acc, wbd);
     __syncthreads();
-    inv_mid_all<ND, PD, PLD::NP - 2, false>(lbd, wb, twd, sync);
+    inv_mid_all<ND, PD, PLD::NP - 2, false>(lbd, wbd, twd, sync);
     {
       float2 twp[PD - 1];
       twd.template get<0>(twp);
-      inv_pass0_load<ND, PD>(lbd, acc, wb, twp);
+      inv_pass0_load<ND, PD>(lbd, acc, wbd, twp);
     }
-    /* acc[j] = y at window index tid + 64 j; index 64 (j = 1) is output fr*VAL of the call */
+    /* acc[j] = y at window index lane + 64 j; index 64 (j = 1) is output fr*VAL of the call */
 #pragma unroll
     for (int j = 1; j < PD; j++) {
-      const int m = fr * VAL + tid + 64 * (j - 1);
+      const int m = fr * VAL + lane + 64 * (j - 1);
       if (m < total) ring[m & (RING - 1)] = acc[j];
     }
-    produced = (fr + 1) * VAL < total ? (fr + 1) * VAL : total;
+    produced = (round + 1) * NW * VAL < total ? (round + 1) * NW * VAL : total;
     __syncthreads();
 
     /* ---- A5/A6: overlap-save frames over what the ring holds ------------------------------ */
@@ -790,8 +797,9 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
   /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
 #pragma unroll
   for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
-  *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
-      *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
+  if (tid < 64)
+    *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
+        *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
   if (tid == 0) {
     p.st_scal[ch * 4 + 0] = nfloor;
     if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
@@ -801,8 +809,10 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fd_kernel(RdspFrontParams p)
 
 template <int N, int P>
 constexpr size_t front_fd_lds() {
-  constexpr int wbn = FftPlan<N, P>::WB > FftPlan<RDSP_FD_N, RDSP_FD_P>::WB ? FftPlan<N, P>::WB : FftPlan<RDSP_FD_N, RDSP_FD_P>::WB;
-  return (size_t)(1024 + wbn) * sizeof(float2) + 64 * sizeof(float);
+  constexpr int nw = N / P / 64;
+  constexpr int wbd = nw * FftPlan<RDSP_FD_N, RDSP_FD_P>::WB;
+  constexpr int wbn = FftPlan<N, P>::WB > wbd ? FftPlan<N, P>::WB : wbd;
+  return (size_t)((nw == 1 ? 1024 : 4096) + wbn) * sizeof(float2) + 64 * sizeof(float);
 }
 
 /* one group record, rewritten in stream order (32 threads, one dword each) */
@@ -847,16 +857,35 @@ int launch_front_x(const RdspFrontParams *p, int n_channels, hipStream_t stream)
   hipLaunchKernelGGL((rdsp_front_kernel<N, P, DECIM, LEAN, PRE, FMX>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
 }
+/* the raised dynamic-LDS limit is a per-device property of a kernel function: one bit per device,
+ * set under a lock (chains on several devices may launch from several host threads) */
+template <auto Kernel> /* one flag set per kernel instance */
+int ensure_lds_limit(size_t lds) {
+  static std::mutex mu;
+  static uint64_t done = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return (int)hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!((done >> dev) & 1u)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    done |= (uint64_t)1 << dev;
+  }
+  return 0;
+}
 template <int N, int P, bool LEAN, bool PRE>
 int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   constexpr size_t lds = front_fd_lds<N, P>();
-  static_assert(lds <= 48 * 1024, "default dynamic LDS limit");
-  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE>), dim3(n_channels), dim3(64), lds, stream, *p);
+  if constexpr (lds > 48 * 1024) {
+    int e = ensure_lds_limit<&rdsp_front_fd_kernel<N, P, LEAN, PRE>>(lds);
+    if (e != 0) return e;
+  }
+  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
 }
 template <int N, int P, int DECIM, bool LEAN, bool PRE>
 int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  if constexpr (DECIM == 4 && N / P == 64) {
+  if constexpr (DECIM == 4) {
     if (p->fir_fd) return launch_front_fd<N, P, LEAN, PRE>(p, n_channels, stream);
   }
 #ifdef RDSP_EXPERIMENTAL
