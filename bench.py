@@ -22,9 +22,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic flops per input IQ sample: direct 256-tap /4 FIR 256, mixer ~14,
-# overlap-save FFT pair + mask 42-62, spectral NR ~8, NLMS 96, AGC/pack ~2
-FLOP_PER_SAMPLE = {"K2": 256 + 14 + 42 + 2, "K3": 256 + 14 + 47 + 8 + 96 + 2, "K4": 256 + 14 + 62 + 2, "K5": 256 + 14 + 47 + 8 + 96 + 2}
+# flops per input IQ sample of the chain AS RUN (SURVEY Appendix D conventions: FMA = 2, complex FFT
+# 5 N log2 N): the decimator in the frequency domain -- four 512-point transforms, 4 x 512 complex
+# multiply-accumulates and one inverse per 1792 input samples, 73 flop per sample where the direct
+# 256-tap form is 256 -- mixer ~14, overlap-save FFT pair + mask 42-62, spectral NR ~8, NLMS 96, AGC/pack ~2
+FLOP_FD = (5 * 5 * 512 * 9 + 8 * 4 * 512) / 1792.0
+FLOP_PER_SAMPLE = {"K2": FLOP_FD + 14 + 42 + 2, "K3": FLOP_FD + 14 + 47 + 8 + 96 + 2, "K4": FLOP_FD + 14 + 62 + 2,
+                   "K5": FLOP_FD + 14 + 47 + 8 + 96 + 2}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3
 

@@ -426,7 +426,8 @@ typedef struct rdsp_fft1024 rdsp_fft1024_t;
 void rdsp_window_q15_n(int window_id, int n, int16_t *w);
 int rdsp_fft1024_create(int n_channels, int device, int window_id, rdsp_fft1024_t **out);
 void rdsp_fft1024_destroy(rdsp_fft1024_t *s);
-int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id);
+int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id); /* INO:147 */
+int rdsp_fft1024_averageTogether(rdsp_fft1024_t *s, int n);       /* INO:148: a no-op in the library too */
 int rdsp_fft1024_outputs_for(const rdsp_fft1024_t *s, int n_blocks);
 /* n_blocks update() ticks; d_audio int16 [n_channels][in_stride] samples taken every in_step int16
  * (2 with an offset pointer picks L or R of the chain's interleaved output); d_out uint16

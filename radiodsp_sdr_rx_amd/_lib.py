@@ -213,6 +213,7 @@ SYMBOLS = [
     ("rdsp_fft1024_create", _i, [_i, _i, _i, C.POINTER(_vp)]),
     ("rdsp_fft1024_destroy", None, [_vp]),
     ("rdsp_fft1024_windowFunction", _i, [_vp, _i]),
+    ("rdsp_fft1024_averageTogether", _i, [_vp, _i]),
     ("rdsp_fft1024_outputs_for", _i, [_vp, _i]),
     ("rdsp_fft1024_update", _i, [_vp, _vp, _sz, _i, _i, _vp, _sz, C.POINTER(C.c_int), _vp]),
     ("rdsp_fft1024_node_create", _vp, [_vp, _vp]),

@@ -239,6 +239,12 @@ extern "C" int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id) {
   s->window_id = window_id;
   return fft1024_upload_window(s);
 }
+/* AudioFFT.averageTogether(30) (INO:148): the library's 1024-point analyser declares it and does
+ * nothing with it ("not implemented yet"); accepted and ignored here too */
+extern "C" int rdsp_fft1024_averageTogether(rdsp_fft1024_t *s, int n) {
+  (void)n;
+  return s ? RDSP_OK : RDSP_ERR_INVALID;
+}
 /* frames the next update over n_blocks completes: the first after 8 blocks, then one per 4 */
 extern "C" int rdsp_fft1024_outputs_for(const rdsp_fft1024_t *s, int n_blocks) {
   if (!s || n_blocks <= 0) return 0;

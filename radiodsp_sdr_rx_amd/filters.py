@@ -111,6 +111,9 @@ class AnalyzeFFT1024:
     def windowFunction(self, window):
         _lib.check(self.lib.rdsp_fft1024_windowFunction(self.h, WINDOWS[window]))
 
+    def averageTogether(self, n):   # INO:148; the library ignores it
+        _lib.check(self.lib.rdsp_fft1024_averageTogether(self.h, int(n)))
+
     def update(self, audio, stream=None):
         """audio: int16 cuda tensor [n_channels, n_blocks*128], sample stride 1 or 2 (e.g. the L side
         out[..., 0] of the chain's interleaved output).  Returns int16-storage [n_channels, n_out, 512]

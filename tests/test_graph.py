@@ -195,3 +195,93 @@ def test_k1_one_channel_through_the_graph_matches_oracle(rdsp, oracle):
     d = np.abs(np.stack([L, R], 1).astype(np.int32) - r16.astype(np.int32))
     assert d.max() <= 1
     assert g.memory_usage()[1] <= 40
+
+
+@pytest.mark.gpu
+def test_the_whole_graph_of_the_sketch(rdsp, oracle):
+    """Every AudioConnection of RadioDSP_SDR_RX.ino:71-89 and the set-up calls of :144-156:
+    IQinput -> preProcessor -> SDR -> Q_in_L/R -(loop)-> Q_out_L/R -> audio_out, the panadapter
+    branch IQinput -> biquad1/2 -> FFT, and AudioFFT on Q_out_L.  The audio that reaches audio_out
+    is the chain's (oracle, +-1 LSB); both analysers produce spectra from what flowed past them."""
+    import torch
+    from cases import K1
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024, FilterBiquad
+    from radiodsp_sdr_rx_amd.graph import Graph
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    assert torch.cuda.is_available()
+    nblk = 96
+    iq = synth_iq(1, nblk * 128)
+    chain = Chain(1, max_blocks_per_call=8, **K1)
+    g = Graph(1)
+    g.AudioMemory(40)                                            # INO:151
+    IQinput = g.input_node()                                     # INO:52
+
+    def pre_update(n):                                           # AudioSDRpreProcessor: pass-through
+        bi, bq = n.receiveReadOnly(0), n.receiveReadOnly(1)
+        if bi is not None and bq is not None:
+            n.transmit(bi, 0); n.transmit(bq, 1)
+        n.release(bi); n.release(bq)
+
+    preProcessor = g.node(2, pre_update)                         # INO:53
+    SDR = g.sdr_node(chain)                                      # INO:54
+    fft = AnalyzeFFT256IQ(1, naverage=30, window="AudioWindowHanning256")   # INO:57,144-145
+    FFT = g.spectrum_node(fft)
+    afft = AnalyzeFFT1024(1, window="AudioWindowHanning1024")    # INO:58,147
+    afft.averageTogether(30)                                     # INO:148
+    AudioFFT = g.fft1024_node(afft)
+    b1, b2 = FilterBiquad(1), FilterBiquad(1)                    # INO:59-60
+    b1.setHighpass(0, 500, 0.5); b2.setHighpass(0, 500, 0.5)     # INO:155-156
+    biquad1, biquad2 = g.biquad_node(b1), g.biquad_node(b2)
+    Q_in_L, Q_in_R = g.record_queue(), g.record_queue()          # INO:64-65
+    Q_out_L, Q_out_R = g.play_queue(), g.play_queue()            # INO:66-67
+    heard = []
+
+    def out_update(n):                                           # AudioOutputI2S audio_out
+        l, r = n.receiveReadOnly(0), n.receiveReadOnly(1)
+        if l is not None and r is not None:
+            heard.append(np.stack([l.data()[0].copy(), r.data()[0].copy()], axis=1))
+        n.release(l); n.release(r)
+
+    audio_out = g.node(2, out_update)                            # INO:55
+    g.AudioConnection(IQinput, 0, preProcessor, 0)               # c1
+    g.AudioConnection(IQinput, 1, preProcessor, 1)               # c2
+    g.AudioConnection(IQinput, 0, biquad1, 0)                    # c2f1
+    g.AudioConnection(IQinput, 1, biquad2, 0)                    # c2f2
+    g.AudioConnection(biquad1, 0, FFT, 0)                        # c2f11
+    g.AudioConnection(biquad2, 0, FFT, 1)                        # c2f22
+    g.AudioConnection(preProcessor, 0, SDR, 0)                   # a3
+    g.AudioConnection(preProcessor, 1, SDR, 1)                   # a4
+    g.AudioConnection(SDR, 0, Q_in_L, 0)                         # c5
+    g.AudioConnection(SDR, 1, Q_in_R, 0)                         # c6
+    g.AudioConnection(Q_out_L, 0, AudioFFT, 0)                   # c6a
+    g.AudioConnection(Q_out_L, 0, audio_out, 0)                  # c7
+    g.AudioConnection(Q_out_R, 0, audio_out, 1)                  # c8
+    Q_in_L.begin(); Q_in_R.begin()                               # CONV:205-206
+    rf, af = 0, 0
+    for b in range(nblk + 10):
+        if b < nblk:
+            blk = iq[0, b * 128:(b + 1) * 128]
+            IQinput.push(blk[None, :, 0], blk[None, :, 1])
+        assert g.update_all() == 0
+        # loop(): the convolutional stage lives in the engine node here, so the queues just hand over
+        while Q_in_L.available() > 0 and Q_in_R.available() > 0:
+            l, r = Q_in_L.readBuffer().copy(), Q_in_R.readBuffer().copy()
+            Q_in_L.freeBuffer(); Q_in_R.freeBuffer()
+            ol, orr = Q_out_L.getBuffer(), Q_out_R.getBuffer()
+            ol[:] = l; orr[:] = r
+            assert Q_out_L.playBuffer() == 0 and Q_out_R.playBuffer() == 0
+            assert g.update_all() == 0                           # the ISR tick that plays the pair
+        rf += FFT.available()
+        af += AudioFFT.available()
+    for node in (SDR, FFT, AudioFFT, biquad1, biquad2):
+        assert node.status() == 0
+    got = np.concatenate(heard)
+    r16, _ = oracle.OracleChain(**K1).process(iq[0])
+    assert got.shape == r16.shape and np.abs(got.astype(np.int32) - r16.astype(np.int32)).max() <= 1
+    assert rf >= 3 and af >= 3                                   # 96 IQ ticks / 30; 24 audio blocks: frames at 8, 12, ...
+    spec = AudioFFT.output()[0].astype(int)
+    for f in (700.0, 1000.0, 1900.0):                            # the USB tones of the synthetic input, 24 kHz / 1024 per bin
+        k = int(round(f / (24000.0 / 1024)))
+        assert spec[k - 1:k + 2].max() > 8 * np.median(spec[:128])
+    assert g.memory_usage()[0] == 0 and g.memory_usage()[1] <= 40
