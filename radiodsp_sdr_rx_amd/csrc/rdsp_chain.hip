@@ -125,7 +125,11 @@ struct rdsp_chain {
   int fir_mode = -1;  /* -1 auto: frequency-domain decimator where it exists, else the direct form; 0 direct form
                          (packed FMAs); 2 frequency domain; EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix
                          unless the tail stage shares the SIMDs */
-  int front_fir_prio = 2, tail_prio = 2; /* wave priorities while both kernels share the SIMDs (measured balance) */
+  /* wave priorities while both kernels share the SIMDs.  Round 2: with the frequency-domain front
+   * kernel (which never raises its priority) tail priority 0 / 1 / 2 / 3 measured 1.197 / 1.208 /
+   * 1.211 / 1.211 ms per K3 step on one box; the direct-form front kernel raises its own to
+   * front_fir_prio during the FIR */
+  int front_fir_prio = 2, tail_prio = 0;
   /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
    * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
    * with the reduction on the matrix pipe */

@@ -349,7 +349,8 @@ struct NlmsM {
  * (the next two sample pairs) instead of four single reads.
  * Sample pairs live in an 8-slot register ring, Pair(m) = (mine[m], mine[m+1]) at slot m & 7
  * (mine[m] = x[m - 6 sub]: the newest of this lane's six samples of X_m); a block at n0 uses
- * Pair(n0-5 .. n0) and the two new ones are read one block ahead. */
+ * Pair(n0-5 .. n0) and the two new ones are read one block ahead, into the slots of the two
+ * pairs that went out of use two blocks earlier. */
 struct NlmsB {
   static constexpr int TPL = 6, GS = 32, SCR = 3 * GS;
   v2f w2[TPL / 2];
@@ -386,7 +387,6 @@ struct NlmsB {
     NlmsM<16>::prepare(cur, 0, sub, ci, tri, mu, e_base, b_base, scr);
 #pragma unroll
     for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld(mine, m);
-    v2f pn1 = pair_ld(mine, 1), pn2 = pair_ld(mine, 2);
     const bool lo_half = ci < 8;
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
@@ -412,6 +412,12 @@ struct NlmsB {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int n = 4 * q + 2 * h; /* block start inside the group; s0 is a multiple of 8 */
+          /* the two pairs the block after this one adds go straight into the slots that died two
+           * blocks ago (Pair(n-7), Pair(n-6)): a whole block of time for the LDS reads to land */
+          if ((n + 3 < GS) || (s0 + GS < RDSP_BLOCK)) {
+            P[(n + 1) & 7] = pair_ld(mine, s0 + n + 1);
+            P[(n + 2) & 7] = pair_ld(mine, s0 + n + 2);
+          }
           /* (A_0, A_1) lane parts: taps k = 0..5 against Pair(n - k), two chains */
           v2f aa = v2f{w2[0][0], w2[0][0]} * P[n & 7];
           v2f ab = v2f{w2[0][1], w2[0][1]} * P[(n - 1) & 7];
@@ -441,14 +447,6 @@ struct NlmsB {
             const v2f p0 = P[(n - 2 * kk - 1) & 7], p1 = P[(n - 2 * kk) & 7];
             w2[kk] = __builtin_elementwise_fma(gg0, __builtin_shufflevector(p0, p0, 1, 0), w2[kk]);
             w2[kk] = __builtin_elementwise_fma(gg1, __builtin_shufflevector(p1, p1, 1, 0), w2[kk]);
-          }
-          /* the ring moves on two samples; the pairs after these are requested now */
-          P[(n + 1) & 7] = pn1;
-          P[(n + 2) & 7] = pn2;
-          const bool more = (n + 4 < GS) || (s0 + GS < RDSP_BLOCK); /* Pair(n0 + 3), Pair(n0 + 4) exist */
-          if (more) {
-            pn1 = pair_ld(mine, s0 + n + 3);
-            pn2 = pair_ld(mine, s0 + n + 4);
           }
         }
         *reinterpret_cast<float4 *>(out + s0 + 4 * q) = make_float4(o4[0], o4[1], o4[2], o4[3]);
