@@ -129,7 +129,8 @@ struct rdsp_chain {
    * kernel (which never raises its priority) tail priority 0 / 1 / 2 / 3 measured 1.197 / 1.208 /
    * 1.211 / 1.211 ms per K3 step on one box; the direct-form front kernel raises its own to
    * front_fir_prio during the FIR */
-  int front_fir_prio = 2, tail_prio = 0;
+  int front_fir_prio = 2, tail_prio = 2;
+  bool prio_user = false; /* rdsp_chain_set_priorities was called: its values hold for both front kernels */
   /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
    * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
    * with the reduction on the matrix pipe */
@@ -775,7 +776,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.agc_decay = decay;
     tp.out_gain = og;
     tp.st_scal = c->d_scal;
-    tp.prio = piped ? c->tail_prio : 0;
+    tp.prio = piped ? ((fp.fir_fd && !c->prio_user) ? 0 : c->tail_prio) : 0;
     tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
@@ -1201,6 +1202,7 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   if (front_fir_prio < 0 || front_fir_prio > 3 || tail_prio < 0 || tail_prio > 3) return RDSP_ERR_INVALID;
   c->front_fir_prio = front_fir_prio;
   c->tail_prio = tail_prio;
+  c->prio_user = true;
   return RDSP_OK;
 }
 /* stage A3 of the front kernel.  -1 (default): in the frequency domain where that kernel exists
