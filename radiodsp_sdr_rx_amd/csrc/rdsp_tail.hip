@@ -351,6 +351,32 @@ struct NlmsM {
  * (mine[m] = x[m - 6 sub]: the newest of this lane's six samples of X_m); a block at n0 uses
  * Pair(n0-5 .. n0) and the two new ones are read one block ahead, into the slots of the two
  * pairs that went out of use two blocks earlier. */
+/* The reduction of NlmsB: a0 / a1 are a lane's parts of A_0 / A_1.  Lanes 0-7 of the row end up
+ * with A_0 (the sum of a0 over the 16 lanes), lanes 8-15 with A_1.  The first stage merges the two
+ * values with write masks -- `v_add_f32_dpp ... bank_mask` writes the enabled banks only, the other
+ * lanes keep the destination -- which the compiler's DPP combiner cannot express (it folds a
+ * masked `update_dpp` into the add only when the disabled lanes may take an identity), so it is
+ * written out, hazard wait states included: a VALU result read through DPP needs two wait states.
+ * The hazard recognizer does not look into inline asm: the sources coming in get their two wait
+ * states here (it adds at most one in front of an asm statement); for `t` going out it does treat
+ * the statement as a VALU write and puts the two wait states before a DPP consumer itself
+ * (checked over all instances in the generated code). */
+__device__ __forceinline__ float reduce_halves(float a0, float a1) {
+  float t;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(t)
+      : "v"(a0), "v"(a1));
+  return t;
+}
+
 struct NlmsB {
   static constexpr int TPL = 6, GS = 32, SCR = 3 * GS;
   v2f w2[TPL / 2];
@@ -387,7 +413,6 @@ struct NlmsB {
     NlmsM<16>::prepare(cur, 0, sub, ci, tri, mu, e_base, b_base, scr);
 #pragma unroll
     for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld(mine, m);
-    const bool lo_half = ci < 8;
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
       const float *sc = scr + ((s0 / GS) & 1) * SCR;
@@ -419,19 +444,14 @@ struct NlmsB {
             P[(n + 2) & 7] = pair_ld(mine, s0 + n + 2);
           }
           /* (A_0, A_1) lane parts: taps k = 0..5 against Pair(n - k), two chains */
-          v2f aa = v2f{w2[0][0], w2[0][0]} * P[n & 7];
-          v2f ab = v2f{w2[0][1], w2[0][1]} * P[(n - 1) & 7];
-          aa = __builtin_elementwise_fma(v2f{w2[1][0], w2[1][0]}, P[(n - 2) & 7], aa);
-          ab = __builtin_elementwise_fma(v2f{w2[1][1], w2[1][1]}, P[(n - 3) & 7], ab);
-          aa = __builtin_elementwise_fma(v2f{w2[2][0], w2[2][0]}, P[(n - 4) & 7], aa);
-          ab = __builtin_elementwise_fma(v2f{w2[2][1], w2[2][1]}, P[(n - 5) & 7], ab);
-          const v2f acc = aa + ab;
-          /* one reduction for both: halves swap their partner's value across the row */
-          const float keep = lo_half ? acc[0] : acc[1], send = lo_half ? acc[1] : acc[0];
-          float t = keep + dpp_f<0x128>(send); /* row_ror:8 */
-          t += dpp_f<0x141>(t);                /* row_half_mirror */
-          t += dpp_f<0x4E>(t);                 /* quad_perm [2,3,0,1] */
-          t += dpp_f<0xB1>(t);                 /* quad_perm [1,0,3,2] */
+          v2f acc = v2f{w2[0][0], w2[0][0]} * P[n & 7];
+          acc = __builtin_elementwise_fma(v2f{w2[0][1], w2[0][1]}, P[(n - 1) & 7], acc);
+          acc = __builtin_elementwise_fma(v2f{w2[1][0], w2[1][0]}, P[(n - 2) & 7], acc);
+          acc = __builtin_elementwise_fma(v2f{w2[1][1], w2[1][1]}, P[(n - 3) & 7], acc);
+          acc = __builtin_elementwise_fma(v2f{w2[2][0], w2[2][0]}, P[(n - 4) & 7], acc);
+          acc = __builtin_elementwise_fma(v2f{w2[2][1], w2[2][1]}, P[(n - 5) & 7], acc);
+          /* one reduction for both: lanes 0-7 take their partner's A_0 part, lanes 8-15 the A_1 part */
+          const float t = reduce_halves(acc[0], acc[1]);
           /* lanes 0-7 hold A_0, lanes 8-15 A_1 */
           const float dA0 = dd[2 * h] - dpp_f<0x150>(t);     /* row_newbcast:0 */
           const float dA1 = dd[2 * h + 1] - dpp_f<0x158>(t); /* row_newbcast:8 */
