@@ -613,7 +613,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * only, so the valid ones are exact).  State is the same 256 raw samples as the direct form.
  * A stream cut into calls differently rounds differently (the frame grid moves): bitwise
  * identity across call splits holds for the direct form only; everything else (pipelining,
- * sub-batches, channel partition) stays bit-identical. */
+ * sub-batches, channel partition) stays bit-identical.  The pre-processor's IQ swap and the noise
+ * blanker are compiled in with PRE (the blanker in the one-wave kernels). */
 template <int N, int P, bool LEAN, bool PRE>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;              /* the overlap-save filter's transform (FFT_L)     */
@@ -638,6 +639,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   float *red = reinterpret_cast<float *>(wb + (PL::WB > NW * PLD::WB ? PL::WB : NW * PLD::WB));
 
   const bool SWAP_IQ = PRE && p.swap_iq != 0;
+  /* the noise blanker needs the quad columns in stream order: one-wave kernels only (with four
+   * waves per channel the frames of a round run side by side; the launch code keeps the direct
+   * form for such chains) */
+  const bool NB_ON = PRE && (N / P == 64) && p.nb_on != 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   float2 *wbd = wb + wave * PLD::WB; /* this wave's decimator work buffer (inside the filter's) */
@@ -687,6 +692,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   const float vad_inv = 1.0f / (float)(p.vad_hi - p.vad_lo);
   float agc_g = p.st_scal[ch * 4 + 1];
   float am_dc = p.st_scal[ch * 4 + 2];
+  float nb_level = p.st_scal[ch * 4 + 3], nb_acc = 0.f;
+  uint4 hist_save = make_uint4(0u, 0u, 0u, 0u); /* the call's last 64 quads as they entered the decimator */
   float2 vprev[PH];
 #pragma unroll
   for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
@@ -697,6 +704,37 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
 #pragma unroll 1
   for (int round = 0; produced < total; round++) {
     const int fr = round * NW + wave; /* this wave's frame; past the end of the call it works on zeros */
+    if (NB_ON) {
+      /* noise blanker (engine feature, build-defined): decision windows of 1024 input samples =
+       * four quad columns; a frame brings seven new columns (j = 1..7), taken in stream order.  A
+       * sample whose power exceeds the reference level x threshold is zeroed in the raw word, so it
+       * stays blanked in the next frame's column 0 and in the FIR history; the level moves at the
+       * end of every window from the mean post-blanking power (one wave reduction) */
+#pragma unroll
+      for (int j = 1; j < PD; j++) {
+        const int c = (PD - 1) * fr + (j - 1); /* column of the call */
+        if (64 * c < total) {
+          const float thr = nb_level * p.nb_thr;
+          uint32_t w[4] = {rq[j].x, rq[j].y, rq[j].z, rq[j].w};
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const uint32_t ww = SWAP_IQ ? __builtin_amdgcn_alignbit(w[r], w[r], 16) : w[r];
+            const float2 x = unpack_iq(ww, p.scale_i, p.scale_q);
+            const float pw = x.x * x.x + x.y * x.y;
+            const bool blanked = nb_level > 0.f && pw > thr;
+            w[r] = blanked ? 0u : w[r];
+            nb_acc += blanked ? 0.f : pw;
+          }
+          rq[j] = make_uint4(w[0], w[1], w[2], w[3]);
+          if ((c & 3) == 3) {
+            const float mean = wave_sum(nb_acc) / 1024.0f;
+            nb_level = (nb_level > 0.f) ? nb_level + 0.2f * (mean - nb_level) : mean;
+            nb_acc = 0.f;
+          }
+          if (64 * (c + 1) == total) hist_save = rq[j];
+        }
+      }
+    }
     /* ---- A2: phasors of this lane's P quad columns (sample 4 q + r of a quad follows by rot_r) */
     const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + lane); /* absolute index of column 0 */
     float2 pj[PD];
@@ -799,11 +837,12 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
   if (tid < 64)
     *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
-        *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
+        NB_ON ? hist_save : *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
   if (tid == 0) {
     p.st_scal[ch * 4 + 0] = nfloor;
     if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
     p.st_scal[ch * 4 + 2] = am_dc;
+    if (NB_ON) p.st_scal[ch * 4 + 3] = nb_level;
   }
 }
 

@@ -88,11 +88,12 @@ def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, tor
     for k in range(1, calls):
         iq[:, k * per * 128 - 2:k * per * 128 + 1] = 30000
 
-    def run(n_calls, pipelined, lean):
+    def run(n_calls, pipelined, lean, fir=0):
         ch = Chain(nch, max_blocks_per_call=per * calls // n_calls, **K3)
         ch.enableNoiseBlanker()
         ch.setNoiseBlankerThresholdDb(8.0)
         ch.set_pipelined(pipelined)
+        ch.set_fir_variant(fir)     # 0: direct-form decimator, the one that does not depend on the call split
         if lean:
             ch.set_front_variant(0)
         step = iq.shape[1] // n_calls
@@ -105,6 +106,11 @@ def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, tor
     one = run(1, False, True)
     assert np.array_equal(one, run(calls, False, True))
     assert np.array_equal(one, run(calls, True, False))
+    # the frequency-domain decimator (default) with the blanker compiled in: the same split,
+    # pipelined or not, gives the same bits; another split frames and rounds differently
+    fd = run(calls, False, False, fir=-1)
+    assert np.array_equal(fd, run(calls, True, False, fir=-1))
+    assert np.abs(fd.astype(np.int32) - one.astype(np.int32)).max() <= 64 and (fd != one).mean() < 0.3
 
 
 # ---- SAM: PLL synchronous detector (CTL:384-391; build-defined arithmetic) ---------------
