@@ -1208,7 +1208,7 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   return RDSP_OK;
 }
 /* stage A3 of the front kernel.  -1 (default): in the frequency domain where that kernel exists
- * (decim 4, fft_l <= 1024, noise blanker off), else the direct form; 0: direct form (packed FMAs)
+ * (decim 4; with the noise blanker on, fft_l <= 1024), else the direct form; 0: direct form (packed FMAs)
  * always -- the one whose results do not depend on how a stream is cut into calls, bit for bit;
  * 2: frequency domain (RDSP_ERR_UNSUPPORTED where it does not exist).  Same taps, same linear
  * convolution; the sums associate differently (~2e-7).  EXPERIMENTAL=1 builds: 1 = v_mfma GEMM
