@@ -15,7 +15,7 @@
  *        y_n = W_{n-1}.X_n + g_{n-1} (X_{n-1}.X_n) = A_n + g_{n-1} B_n,
  * which takes the reduction (A_n) off the g -> g chain (what stays loop-carried is fma, sub,
  * mul) and moves the energy E_n and the lag-1 correlation B_n, which depend on the input only,
- * into two DPP prefix scans per 32 steps.  Taps and delay line are <2 x float> values (packed
+ * into two DPP prefix scans per 64 steps.  Taps and delay line are <2 x float> values (packed
  * FMAs); the delay line is not shifted between lanes: every lane reads its next sample
  * x[n+1-TPL*sub] from the input ring in LDS (one ds_read_b32 per step and ring copy).
  *
@@ -378,7 +378,8 @@ __device__ __forceinline__ float reduce_halves(float a0, float a1) {
 }
 
 struct NlmsB {
-  static constexpr int TPL = 6, GS = 32, SCR = 3 * GS;
+  /* 64 steps per group of scalars: the two prefix scans (8 DPP operations) serve four steps per lane */
+  static constexpr int TPL = 6, GS = 64, SCR = 3 * GS;
   v2f w2[TPL / 2];
   v2f P[8];
   float energy;
@@ -399,9 +400,46 @@ struct NlmsB {
     if (sub == 0) est[ch] = energy;
   }
 
+  /* the 16 lanes of a channel prepare the 64 steps of a group, four consecutive steps each: E_n and
+   * B_n by prefix sums of their increments (x_n^2 - x_{n-96}^2, x_n x_{n-1} - x_{n-96} x_{n-97}),
+   * step size mu / (E_n + eps); dst = [step size x 64 | B x 64 | E x 64] */
+  static __device__ __forceinline__ void prepare(const float *cur, int s0, int sub, float mu, float e_base,
+                                                 float b_base, float *dst) {
+    const float *x = cur + s0 + 4 * sub; /* the previous block sits right below the current one */
+    const float xm = x[-1], qm = x[-97];
+    const float4 xv = *reinterpret_cast<const float4 *>(x), qv = *reinterpret_cast<const float4 *>(x - 96);
+    const float xs[5] = {xm, xv.x, xv.y, xv.z, xv.w}, qs[5] = {qm, qv.x, qv.y, qv.z, qv.w};
+    float ea[4], ba[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float de = fmaf(xs[k + 1], xs[k + 1], -(qs[k + 1] * qs[k + 1]));
+      const float db = fmaf(xs[k + 1], xs[k], -(qs[k + 1] * qs[k]));
+      ea[k] = (k == 0) ? de : ea[k - 1] + de;
+      ba[k] = (k == 0) ? db : ba[k - 1] + db;
+    }
+    float ie = ea[3], ib = ba[3]; /* inclusive scans of the lane totals over the row: row_shr 1, 2, 4, 8 */
+    ie += dpp0_f<0x111>(ie); ib += dpp0_f<0x111>(ib);
+    ie += dpp0_f<0x112>(ie); ib += dpp0_f<0x112>(ib);
+    ie += dpp0_f<0x114>(ie); ib += dpp0_f<0x114>(ib);
+    ie += dpp0_f<0x118>(ie); ib += dpp0_f<0x118>(ib);
+    const float oe = e_base + (ie - ea[3]), ob = b_base + (ib - ba[3]); /* everything before this lane */
+    float e[4], g[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      e[k] = oe + ea[k];
+      b[k] = ob + ba[k];
+      g[k] = mu * __builtin_amdgcn_rcpf(e[k] + 0.000000119209289f);
+    }
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    d4[sub] = make_float4(g[0], g[1], g[2], g[3]);
+    d4[GS / 4 + sub] = make_float4(b[0], b[1], b[2], b[3]);
+    d4[GS / 2 + sub] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+
   template <bool OUT_E>
   __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr,
                                         int sub, int ci, float tri) {
+    (void)ci; (void)tri;
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;
@@ -410,7 +448,7 @@ struct NlmsB {
     for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
     float b_base = chan_sum<16>(bb);
     float e_base = energy;
-    NlmsM<16>::prepare(cur, 0, sub, ci, tri, mu, e_base, b_base, scr);
+    prepare(cur, 0, sub, mu, e_base, b_base, scr);
 #pragma unroll
     for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld(mine, m);
 #pragma unroll 1
@@ -422,8 +460,7 @@ struct NlmsB {
       float4 dq = *reinterpret_cast<const float4 *>(dsrc + s0);
       e_base = sc[2 * GS + GS - 1];
       b_base = sc[GS + GS - 1];
-      if (s0 + GS < RDSP_BLOCK)
-        NlmsM<16>::prepare(cur, s0 + GS, sub, ci, tri, mu, e_base, b_base, scr + (((s0 / GS) + 1) & 1) * SCR);
+      if (s0 + GS < RDSP_BLOCK) prepare(cur, s0 + GS, sub, mu, e_base, b_base, scr + (((s0 / GS) + 1) & 1) * SCR);
 #pragma unroll
       for (int q = 0; q < GS / 4; q++) {
         const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, bn[4] = {bq.x, bq.y, bq.z, bq.w};
@@ -483,7 +520,7 @@ __device__ __forceinline__ void tailm_body(const RdspTailParams &p) {
   constexpr int CPW = G::CPW, SPL = G::SPL;
   constexpr int RINGS = DUAL ? 2 : 1;
   /* +4: consecutive channels start four LDS banks apart */
-  constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * G::SCR + 4;
+  constexpr int PER_CH = (2 * RINGS + 1) * RDSP_BLOCK + 2 * NL::SCR + 4;
   __shared__ __attribute__((aligned(16))) float lds[CPW][PER_CH];
   if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
