@@ -318,6 +318,9 @@ def main():
             chain.set_tail_variant(int(v[:-1]), 2)
         else:
             chain.set_tail_variant(int(v.rstrip("m")), int(v.endswith("m")))
+    if os.environ.get("RDSP_AUDIO_IIR"):   # A/B runs: SDR.setAudioFilter() as the 8th-order IIR bank instead of the mask
+        chain.setAudioFilterKind(1)
+        chain.setAudioFilter(int(os.environ["RDSP_AUDIO_IIR"]))
     if os.environ.get("RDSP_SUB_BATCH"):  # A/B runs: channels per launch in pipelined mode (0 = off)
         chain.set_sub_batch(int(os.environ["RDSP_SUB_BATCH"]))
     if os.environ.get("RDSP_FRONT_VARIANT"):  # A/B runs: force the full (0) or lean (1) front kernel
