@@ -60,7 +60,7 @@ def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None, fir=None):
     ch = Chain(nch, max_blocks_per_call=n // 128 // calls, **cfg)
     if tail == "16r":
         pass
-    elif tail == "8r":  # half-row layout of rdsp_tailm.hip
+    elif tail == "8r":  # half-row layout (EXPERIMENTAL builds)
         ch.set_tail_variant(8, 2)
     elif tail:          # "16": rdsp_tail.hip; "16m" / "8m": matrix-pipe reduction
         ch.set_tail_variant(int(tail.rstrip("m")), int(tail.endswith("m")))
@@ -335,7 +335,7 @@ NLMS_CASES = {
 @pytest.mark.parametrize("tail", TAILS)
 @pytest.mark.parametrize("name", sorted(NLMS_CASES))
 def test_chain_with_nlms_is_as_close_to_float64_truth_as_the_oracle(rdsp, oracle, torch_cuda, name, tail):
-    """tail "16r": the product's tail kernel (row layout of rdsp_tailm.hip).  The experimental
+    """tail "16r": the product's tail kernel (row layout, two steps per reduction).  The experimental
     layouts ("16": delay line shifted by DPP; "8r": half a row; "16m", "8m": reduction on the
     matrix pipe) are only in the library when it is built with EXPERIMENTAL=1."""
     from radiodsp_sdr_rx_amd.chain import synth_iq
