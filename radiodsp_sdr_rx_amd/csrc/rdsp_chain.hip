@@ -87,7 +87,7 @@ struct rdsp_chain {
   hipEvent_t ev_fence = nullptr;      /* after the most recent front launch */
   bool fence_valid = false;
   float *d_fir_hc = nullptr;
-  float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (one wave per channel: N <= 1024) */
+  float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (decim 4 only) */
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
   float *d_scal = nullptr;

@@ -336,3 +336,41 @@ def test_engine_audio_filter_as_iir_bank_matches_oracle(rdsp, oracle, name):
     # a recursive filter behind the chain (and, for AM, one that removes most of the envelope's
     # amplitude): truth-anchored like the NLMS chains -- err(gpu, f64) <= max(TOL, 1.5 err(oracle, f64))
     assert_truth_anchored(got, np.stack(ref), np.stack(f64), name)
+
+
+@pytest.mark.gpu
+def test_argument_errors_are_loud(rdsp):
+    """the new entry points reject what they cannot do, with RDSP_ERR_* and a message"""
+    import ctypes as C
+    import torch
+    from radiodsp_sdr_rx_amd import RdspError
+    from radiodsp_sdr_rx_amd.chain import Chain
+    from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024, FilterBiquad
+    lib = rdsp.load()
+    bq = FilterBiquad(3)
+    with pytest.raises(RdspError):
+        bq.setHighpass(4, 500, 0.5)                     # AudioFilterBiquad has stages 0..3
+    with pytest.raises(RdspError):
+        bq.setLowpass(0, -1.0, 0.7)
+    x = torch.zeros((3, 256), dtype=torch.int16, device="cuda")
+    out = torch.zeros_like(x)
+    assert lib.rdsp_biquad_update(bq.h, C.c_void_p(x.data_ptr()), 128, 1, 2, C.c_void_p(out.data_ptr()), 256, 1, None) == -1
+    an = AnalyzeFFT1024(3)
+    spectra = torch.zeros((3, 1, 512), dtype=torch.int16, device="cuda")
+    got = C.c_int()
+    audio = torch.zeros((3, 16 * 128), dtype=torch.int16, device="cuda")   # 16 blocks complete 3 frames
+    assert lib.rdsp_fft1024_update(an.h, C.c_void_p(audio.data_ptr()), 16 * 128, 1, 16, C.c_void_p(spectra.data_ptr()), 1,
+                                   C.byref(got), None) == -1
+    assert b"3 needed" in lib.rdsp_last_error()
+    ch = Chain(2, max_blocks_per_call=8, decim=1, fs_in=24000.0, nco_hz=0.0, fft_l=256, demod="IQ")
+    with pytest.raises(RdspError) as e:
+        ch.set_fir_variant(2)                           # no decimator, no frequency-domain decimator
+    assert e.value.code == -5
+    with pytest.raises(RdspError):
+        ch.setAudioFilterKind(7)
+    with pytest.raises(RdspError):
+        ch.set_spectral_nr(3, 1.0)
+    if not lib.rdsp_experimental_build():
+        with pytest.raises(RdspError) as e:
+            ch.set_fir_variant(1)                       # matrix-core FIR: EXPERIMENTAL builds only
+        assert e.value.code == -5
