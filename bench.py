@@ -338,7 +338,7 @@ def main():
         torch.cuda.synchronize()
         f2, t2, n2 = chain.get_timing()
         chain.set_timing(False)
-        iso = {"rdsp_front_kernel": f2 / max(n2, 1), "rdsp_tail_kernel": t2 / max(n2, 1)}
+        iso = {chain.front_kernel_name(): f2 / max(n2, 1), "rdsp_tail_kernel": t2 / max(n2, 1)}
         chain.set_pipelined(True)
     for _ in range(args.warmup):
         chain.process(iq, out=out)
@@ -371,10 +371,11 @@ def main():
         # dominant kernel: the front kernel (it carries the IQ stream: 4 B in + 4/D B out per input
         # sample, the chain's own figure) unless the tail kernel -- 4 B in + 4 B out per OUTPUT sample --
         # runs clearly longer; in pipelined mode both run for the whole step, within a few percent
+        fname = chain.front_kernel_name()   # rdsp_front_fd_kernel (stage A3 in the frequency domain) or rdsp_front_kernel
         if tail_avg > 1.10 * front_avg:
             dom, dom_ms, B_own = "rdsp_tail_kernel", tail_avg, 8.0 / decim
         else:
-            dom, dom_ms, B_own = "rdsp_front_kernel", front_avg, B
+            dom, dom_ms, B_own = fname, front_avg, B
         # roofline.achieved: SURVEY 8(d)'s figure (B = 5 bytes per input IQ sample of the chain) x the
         # samples one launch processes / the dominant kernel's average duration; the kernel's own
         # algorithmic bytes (the tail kernel only moves 4 B in + 4 B out per OUTPUT sample) go beside it
@@ -391,7 +392,7 @@ def main():
             except Exception:
                 ctr = {}
         traffic = ctr.get(dom, {}).get("hbm_bytes")
-        chain_traffic = sum(v.get("hbm_bytes", 0.0) for k, v in ctr.items() if k in ("rdsp_front_kernel", "rdsp_tail_kernel")) or None
+        chain_traffic = sum(v.get("hbm_bytes", 0.0) for k, v in ctr.items() if k in (fname, "rdsp_tail_kernel")) or None
         flops = FLOP_PER_SAMPLE.get(args.config, 0) * float(nch) * n_samples   # per launch of the chain
         achieved_tf = flops / (elapsed / args.steps) / 1e12
         res = {
@@ -424,7 +425,7 @@ def main():
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
                           "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS,
                           "traffic_bytes_per_step": chain_traffic},
-            "kernels_ms_per_step": {"rdsp_front_kernel": front_avg, "rdsp_tail_kernel": tail_avg},
+            "kernels_ms_per_step": {fname: front_avg, "rdsp_tail_kernel": tail_avg},
             "kernels_ms_isolated": iso,
             # The north-star's roofline is HBM, and that is what `roofline` reports (algorithmic bytes of
             # the dominant kernel / its measured duration / 8 TB/s).  What binds first is the fp32 VALU
@@ -438,7 +439,7 @@ def main():
                                   "frac": achieved_tf / FP32_PEAK_TFLOPS,
                                   "flop_per_sample_model": FLOP_PER_SAMPLE.get(args.config),
                                   "busy_frac_pmc": {k: v.get("valu_busy_frac") for k, v in ctr.items()
-                                                    if k in ("rdsp_front_kernel", "rdsp_tail_kernel")} or None}},
+                                                    if k in (fname, "rdsp_tail_kernel")} or None}},
             "input_gen_s": gen_s,
         }
         if world == 1 and not args.no_host_io:

@@ -249,6 +249,9 @@ int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matr
 
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/
 int rdsp_chain_set_timing(rdsp_chain_t *c, int on);
+/* name of the front kernel the most recent call launched, as a profiler shows it without template
+ * arguments: "rdsp_front_fd_kernel" (stage A3 in the frequency domain) or "rdsp_front_kernel" */
+const char *rdsp_chain_front_kernel_name(const rdsp_chain_t *c);
 /* total milliseconds spent in the front and tail kernels over `calls` calls */
 int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *tail_ms, int *calls);
 

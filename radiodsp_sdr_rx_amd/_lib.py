@@ -79,6 +79,7 @@ SYMBOLS = [
     ("rdsp_last_error", C.c_char_p, []),
     ("rdsp_version", C.c_char_p, []),
     ("rdsp_experimental_build", _i, []),
+    ("rdsp_chain_front_kernel_name", C.c_char_p, [_vp]),
     ("rdsp_device_count", _i, []),
     ("rdsp_calc_cplx_FIR_coeffs", None, [_f64p, _f64p, _i, _d, _d, _d, _i]),
     ("rdsp_init_filter_mask", _i, [_f32p, _f64p, _f64p, _i]),

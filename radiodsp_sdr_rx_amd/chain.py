@@ -199,6 +199,9 @@ class Chain:
     def set_timing(self, on):
         _lib.check(self.lib.rdsp_chain_set_timing(self.h, int(bool(on))))
 
+    def front_kernel_name(self):
+        return self.lib.rdsp_chain_front_kernel_name(self.h).decode()
+
     def get_timing(self):
         f, t, n = C.c_double(), C.c_double(), C.c_int()
         _lib.check(self.lib.rdsp_chain_get_timing(self.h, C.byref(f), C.byref(t), C.byref(n)))

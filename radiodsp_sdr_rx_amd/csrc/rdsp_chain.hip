@@ -138,6 +138,7 @@ struct rdsp_chain {
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   /* the engine's IIR audio filter bank (RDSP_AUDIO_KIND_IIR): coefficient sets per group, DF1
    * state per channel; allocated by rdsp_sdr_setAudioFilterKind */
+  const char *front_name = "rdsp_front_kernel"; /* front kernel of the most recent call (measurement reports) */
   int audio_kind = RDSP_AUDIO_KIND_MASK;
   float *d_iir_coef = nullptr, *d_iir_state = nullptr;
   int iir_sets = 0;
@@ -654,6 +655,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   const bool one_wave = c->N / rdsp_plan_radix(c->N) == 64;
   fp.fir_fd = ((c->fir_mode == 2 || c->fir_mode == -1) && c->d_fd_mask && (!c->nb_on || one_wave)) ? 1 : 0;
   fp.fd_mask = c->d_fd_mask;
+  c->front_name = fp.fir_fd ? "rdsp_front_fd_kernel" : "rdsp_front_kernel";
   fp.mid_q = c->d_mid_q[0];
   if (piped) {
     fp.mid = slot ? c->d_midx[slot - 1] : c->d_mid;
@@ -1259,6 +1261,10 @@ extern "C" int rdsp_chain_flush(rdsp_chain_t *c, void *stream) {
   if (c->tail_slot >= 0) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ev_tail[c->tail_slot], 0));
   return RDSP_OK;
 }
+
+/* name of the front kernel the most recent rdsp_chain_process launched (as the profiler shows it,
+ * without template arguments): rdsp_front_fd_kernel or rdsp_front_kernel */
+extern "C" const char *rdsp_chain_front_kernel_name(const rdsp_chain_t *c) { return c ? c->front_name : ""; }
 
 /* ---- per-kernel timing with HIP events on the launch stream -------------------- */
 extern "C" int rdsp_chain_set_timing(rdsp_chain_t *c, int on) {

@@ -23,11 +23,9 @@ def newest(pattern):
 
 
 def short(name):
-    if "rdsp_front_fd_kernel" in name:   # the front stage with the frequency-domain decimator: same stage name
-        return "rdsp_front_kernel"
     if "rdsp_tail" in name:
         return "rdsp_tail_kernel"
-    for k in ("rdsp_front_kernel", "rdsp_tail_kernel", "rdsp_sam_kernel", "rdsp_spectrum_kernel", "rdsp_group_store_kernel"):
+    for k in ("rdsp_front_fd_kernel", "rdsp_front_kernel", "rdsp_tail_kernel", "rdsp_sam_kernel", "rdsp_spectrum_kernel", "rdsp_group_store_kernel"):
         if k in name:
             return k
     return None
