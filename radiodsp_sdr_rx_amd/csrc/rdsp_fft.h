@@ -37,9 +37,15 @@ typedef float rdsp_v2f __attribute__((ext_vector_type(2)));
 RDSP_HD float2 cmul(float2 a, float2 b) {
 #ifdef __HIP_DEVICE_COMPILE__
   const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
-  rdsp_v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  rdsp_v2f r;
+  /* one statement for the dependent pair, the product going through the result register: the hazard
+   * recognizer cannot see inside an asm statement and puts a wait state between two of them that
+   * touch the same register (a result read, or a scratch register written again); the hardware
+   * needs none between packed VALU operations (278 such s_nop per frame loop with two statements
+   * per product) */
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+      : "=&v"(r) : "v"(av), "v"(bv));
   return make_float2(r.x, r.y);
 #else
   return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
@@ -50,9 +56,10 @@ RDSP_HD float2 cmul(float2 a, float2 b) {
 RDSP_HD float2 cmul_uniform(float2 a, float2 b) {
 #ifdef __HIP_DEVICE_COMPILE__
   const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
-  rdsp_v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "s"(bv));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(av), "s"(bv), "v"(t));
+  rdsp_v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+      : "=&v"(r) : "v"(av), "s"(bv));
   return make_float2(r.x, r.y);
 #else
   return cmul(a, b);
@@ -61,12 +68,12 @@ RDSP_HD float2 cmul_uniform(float2 a, float2 b) {
 /* acc + a * b: two packed FMAs */
 RDSP_HD float2 cmac(float2 acc, float2 a, float2 b) {
 #ifdef __HIP_DEVICE_COMPILE__
-  const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y}, cv = {acc.x, acc.y};
-  rdsp_v2f t, r;
-  /* t = (acc.x - a.y b.y, acc.y + a.y b.x) */
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(av), "v"(bv), "v"(cv));
-  /* r = (a.x b.x + t.x, a.x b.y + t.y) */
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
+  rdsp_v2f r = {acc.x, acc.y};
+  /* r = (acc.x - a.y b.y, acc.y + a.y b.x);  r = (a.x b.x + r.x, a.x b.y + r.y) */
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+      : "+v"(r) : "v"(av), "v"(bv));
   return make_float2(r.x, r.y);
 #else
   return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, acc.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, acc.y)));
@@ -76,9 +83,10 @@ RDSP_HD float2 cmac(float2 acc, float2 a, float2 b) {
 RDSP_HD float2 cmulc_uniform(float2 a, float2 b) {
 #ifdef __HIP_DEVICE_COMPILE__
   const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
-  rdsp_v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "s"(bv));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "s"(bv), "v"(t));
+  rdsp_v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+      : "=&v"(r) : "v"(av), "s"(bv));
   return make_float2(r.x, r.y);
 #else
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(-a.x, b.y, a.y * b.x));
@@ -87,9 +95,10 @@ RDSP_HD float2 cmulc_uniform(float2 a, float2 b) {
 RDSP_HD float2 cmulc(float2 a, float2 b) { /* a * conj(b) */
 #ifdef __HIP_DEVICE_COMPILE__
   const rdsp_v2f av = {a.x, a.y}, bv = {b.x, b.y};
-  rdsp_v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  rdsp_v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+      : "=&v"(r) : "v"(av), "v"(bv));
   return make_float2(r.x, r.y);
 #else
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(-a.x, b.y, a.y * b.x));
