@@ -125,12 +125,12 @@ struct rdsp_chain {
   int fir_mode = -1;  /* -1 auto: frequency-domain decimator where it exists, else the direct form; 0 direct form
                          (packed FMAs); 2 frequency domain; EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix
                          unless the tail stage shares the SIMDs */
-  /* wave priorities while both kernels share the SIMDs.  Round 2: with the frequency-domain front
-   * kernel (which never raises its priority) tail priority 0 / 1 / 2 / 3 measured 1.197 / 1.208 /
-   * 1.211 / 1.211 ms per K3 step on one box; the direct-form front kernel raises its own to
-   * front_fir_prio during the FIR */
+  /* wave priorities while both kernels share the SIMDs: the direct-form front kernel raises its
+   * own to front_fir_prio during the FIR, the frequency-domain one never does; the tail kernel runs
+   * at tail_prio throughout.  Round 2, frequency-domain front kernel, tail priority 0 / 1 / 2 / 3:
+   * K3 1.191 / - / 1.188 / - ms, K5 2.72 / 2.36 / 2.34 / 2.36 ms per step (at equal priority the tail
+   * kernels of two sub-batches are starved by the front waves) */
   int front_fir_prio = 2, tail_prio = 2;
-  bool prio_user = false; /* rdsp_chain_set_priorities was called: its values hold for both front kernels */
   /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
    * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
    * with the reduction on the matrix pipe */
@@ -780,7 +780,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.agc_decay = decay;
     tp.out_gain = og;
     tp.st_scal = c->d_scal;
-    tp.prio = piped ? ((fp.fir_fd && !c->prio_user) ? 0 : c->tail_prio) : 0;
+    tp.prio = piped ? c->tail_prio : 0;
     tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
@@ -1206,7 +1206,6 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   if (front_fir_prio < 0 || front_fir_prio > 3 || tail_prio < 0 || tail_prio > 3) return RDSP_ERR_INVALID;
   c->front_fir_prio = front_fir_prio;
   c->tail_prio = tail_prio;
-  c->prio_user = true;
   return RDSP_OK;
 }
 /* stage A3 of the front kernel.  -1 (default): in the frequency domain where that kernel exists
