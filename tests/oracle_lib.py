@@ -88,7 +88,8 @@ def load(path=None):
     global _lib
     if path is None and _lib is not None:
         return _lib
-    so = path or os.path.join(ORACLE_DIR, "liboracle.so")
+    # RDSP_ORACLE_SO: another build of the same source (the sanitizer build of test_oracle_kat.py)
+    so = path or os.environ.get("RDSP_ORACLE_SO") or os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(so):
         build()
     lib = C.CDLL(so)

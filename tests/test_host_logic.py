@@ -116,6 +116,23 @@ def test_kernel_index_arithmetic_on_host(src, tmp_path):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_host_c_under_address_and_ub_sanitizers(tmp_path):
+    """rdsp_graph.c, rdsp_io.c and rdsp_design.c (no HIP in them) built with ASan + UBSan + LSan
+    and walked by tests/host/host_sanitize.c: pool exhaustion, teardown with blocks queued,
+    damaged WAV headers, every design routine at every size with exactly sized buffers."""
+    exe = str(tmp_path / "host_sanitize")
+    csrc = os.path.join(ROOT, "radiodsp_sdr_rx_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fopenmp",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host", "host_sanitize.c")]
+                          + [os.path.join(csrc, f) for f in ("rdsp_graph.c", "rdsp_io.c", "rdsp_design.c")]
+                          + ["-lm", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "host_sanitize OK" in out.stdout, out.stdout + out.stderr
+    assert "runtime error" not in out.stderr and "Sanitizer" not in out.stderr, out.stderr
+
+
 def test_bin_of_pos_is_a_permutation(rdsp):
     lib = C.CDLL(os.path.join(ROOT, "radiodsp_sdr_rx_amd", "librdsp_hip.so"))
     for n in (256, 512, 1024, 2048, 4096):
