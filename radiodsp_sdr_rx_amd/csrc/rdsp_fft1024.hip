@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "rdsp_host.h"
+#include "rdsp_q15.h"
 
 struct RdspFft1024Params {
   const int16_t *audio; /* [ch][in_stride] samples, every in_step int16 */
@@ -38,36 +39,7 @@ struct RdspFft1024Params {
 };
 
 namespace {
-__device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
-__device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
-__device__ __forceinline__ int hi16(uint32_t w) { return (int)(int16_t)(w >> 16); }
-__device__ __forceinline__ uint32_t pack16(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
-
-__device__ __forceinline__ void bfly(uint32_t *x, const uint32_t *tw) {
-  int ar = lo16(x[0]), ai = hi16(x[0]), br = lo16(x[1]), bi = hi16(x[1]);
-  int cr = lo16(x[2]), ci = hi16(x[2]), dr = lo16(x[3]), di = hi16(x[3]);
-  int s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
-  int s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
-  int yr[4], yi[4];
-  yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
-  yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2;
-  yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
-  yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    int wr = lo16(tw[k]), wi = hi16(tw[k]);
-    int pr = (__mul24(yr[k], wr) - __mul24(yi[k], wi)) >> 15;
-    int pi = (__mul24(yr[k], wi) + __mul24(yi[k], wr)) >> 15;
-    x[k] = pack16(sat16(pr), sat16(pi));
-  }
-}
-
-__device__ __forceinline__ uint32_t isqrt32(uint32_t x) {
-  uint32_t r = (uint32_t)sqrtf((float)x);
-  while ((unsigned long long)r * r > x) r--;
-  while ((unsigned long long)(r + 1) * (r + 1) <= x) r++;
-  return r;
-}
+using namespace rdsp_q15;
 
 /* sample `idx` of the channel's stream = [buffered history | this call's new samples] */
 __device__ __forceinline__ int sample_at(const RdspFft1024Params &p, size_t ch, int idx) {
@@ -77,10 +49,10 @@ __device__ __forceinline__ int sample_at(const RdspFft1024Params &p, size_t ch, 
 
 __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
   __shared__ uint32_t ex[1024];
-  __shared__ uint32_t tws[1024];
+  __shared__ Twiddle tws[1024]; /* W_1024^m as the two dot-product operands (rdsp_q15.h) */
   const int t = threadIdx.x;
   const size_t ch = blockIdx.x;
-  for (int i = t; i < 1024; i += 64) tws[i] = p.twid[i];
+  for (int i = t; i < 1024; i += 64) tws[i] = make_twiddle(p.twid[i]);
   __syncthreads();
 
   for (int f = 0; f < p.n_frames; f++) {
@@ -90,14 +62,15 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
 #pragma unroll
     for (int m = 0; m < 4; m++) {
       const int b = t + 64 * m;
-      uint32_t x[4], tw[4];
+      uint32_t x[4];
+      Twiddle tw[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int pos = b + 256 * k;
         int v = sample_at(p, ch, base + pos);
         if (p.use_window) v = __mul24(v, (int)p.window[pos]) >> 15;
         x[k] = pack16(v, 0);
-        tw[k] = tws[(k * b) & 1023]; /* j = b, n / (4 L) = 1 */
+        if (k) tw[k] = tws[(k * b) & 1023]; /* j = b, n / (4 L) = 1; k = 0 is W^0 */
       }
       bfly(x, tw);
 #pragma unroll
@@ -113,13 +86,14 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
       for (int m = 0; m < 4; m++) {
         const int b = t + 64 * m;
         const int g = (b / L) * 4 * L, j = b % L;
-        uint32_t tw[4];
+        Twiddle tw[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           y[m][k] = ex[g + j + k * L];
-          tw[k] = tws[(k * j * (256 / L)) & 1023];
+          if (k && L > 1) tw[k] = tws[(k * j * (256 / L)) & 1023];
         }
-        bfly(y[m], tw);
+        if (L > 1) bfly(y[m], tw);
+        else bfly_w0(y[m]); /* last stage: j = 0 */
       }
       __syncthreads();
 #pragma unroll

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "rdsp_host.h"
+#include "rdsp_q15.h"
 
 struct RdspSpecParams {
   const uint32_t *iq; /* [ch][in_stride] I | Q << 16 */
@@ -29,9 +30,10 @@ struct RdspSpecParams {
   int have_prev; /* 0: the very first block only primes prevblock (FFTIQ.cpp:73-77) */
   int count0;    /* `count` at entry (FFTIQ.h:105) */
   int naverage;
-  /* x / naverage without the ~30-instruction 32-bit division (4 per frame and lane):
-   * power of two -> shift; else q = (((x - t) >> 1) + t) >> div_shift, t = mulhi(div_magic, x)
-   * (round-up method with the 33-bit multiplier folded into the add; exact for every uint32) */
+  /* x / naverage without the ~30-instruction 32-bit division (4 per frame and lane): power of
+   * two -> shift; else q = mulhi(div_magic, x) >> div_shift with div_magic = ceil(2^(31+L) / d),
+   * L = ceil(log2 d), div_shift = L - 1.  Exact for every x < 2^31 (the error term x e / (d 2^(31+L))
+   * with e < d <= 2^L stays below 1/d), and re^2 + im^2 <= 2 * 32767^2 < 2^31. */
   uint32_t div_magic;
   int div_shift, div_pow2;
   int use_window;
@@ -44,39 +46,7 @@ struct RdspSpecParams {
 };
 
 namespace {
-__device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
-__device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
-__device__ __forceinline__ int hi16(uint32_t w) { return (int)(int16_t)(w >> 16); }
-__device__ __forceinline__ uint32_t pack16(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
-
-/* one fixed-point radix-4 butterfly: x[k] (packed) -> y[k] = ((sum) >> 2) * W^{m_k} >> 15, saturated */
-__device__ __forceinline__ void bfly(uint32_t *x, const uint32_t *tw) {
-  int ar = lo16(x[0]), ai = hi16(x[0]), br = lo16(x[1]), bi = hi16(x[1]);
-  int cr = lo16(x[2]), ci = hi16(x[2]), dr = lo16(x[3]), di = hi16(x[3]);
-  int s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
-  int s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
-  int yr[4], yi[4];
-  yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
-  yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2;
-  yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
-  yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    int wr = lo16(tw[k]), wi = hi16(tw[k]);
-    /* |y| <= 32768, |w| <= 32767: 24-bit operands, 32-bit exact results -> full-rate
-     * v_mul_i32_i24 / v_mad_i32_i24 instead of the quarter-rate 32-bit multiply */
-    int pr = (__mul24(yr[k], wr) - __mul24(yi[k], wi)) >> 15;
-    int pi = (__mul24(yr[k], wi) + __mul24(yi[k], wr)) >> 15;
-    x[k] = pack16(sat16(pr), sat16(pi));
-  }
-}
-
-__device__ __forceinline__ uint32_t isqrt32(uint32_t x) {
-  uint32_t r = (uint32_t)sqrtf((float)x);
-  while ((unsigned long long)r * r > x) r--;
-  while ((unsigned long long)(r + 1) * (r + 1) <= x) r++;
-  return r;
-}
+using namespace rdsp_q15;
 
 __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
   __shared__ uint32_t ex[256];
@@ -84,28 +54,29 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
   const size_t ch = blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
 
-  /* per-lane constants: twiddles of stages 1..3 (stage 4 has j = 0), window taps */
-  uint32_t tw[4][4];
+  /* per-lane constants: twiddles of stages 1..3 (k = 0 and the whole of stage 4 are W^0, which
+   * the butterfly knows), window taps doubled (see window_mul) */
+  Twiddle tw[3][4];
 #pragma unroll
-  for (int st = 0; st < 4; st++) {
+  for (int st = 0; st < 3; st++) {
     const int L = 64 >> (2 * st);
     const int j = t % L;
 #pragma unroll
-    for (int k = 0; k < 4; k++) tw[st][k] = p.twid[(k * j * (64 / L)) & 255];
+    for (int k = 1; k < 4; k++) tw[st][k] = make_twiddle(p.twid[(k * j * (64 / L)) & 255]);
   }
-  int win[4] = {32767, 32767, 32767, 32767};
+  int win2[4] = {0, 0, 0, 0};
   if (p.use_window) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) win[k] = p.window[t + 64 * k];
+    for (int k = 0; k < 4; k++) win2[k] = 2 * (int)p.window[t + 64 * k];
   }
   /* bin of the position 4t + k this lane ends with: base-4 digit reversal */
   const int rbase = ((t & 3) << 4) | (((t >> 2) & 3) << 2) | ((t >> 4) & 3);
 
   uint32_t prev0 = p.st_prev[ch * 128 + t], prev1 = p.st_prev[ch * 128 + 64 + t];
+  int count = p.count0;
   uint32_t sum[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) sum[k] = p.st_sum[ch * 256 + 4 * t + k];
-  int count = p.count0;
+  for (int k = 0; k < 4; k++) sum[k] = count ? p.st_sum[ch * 256 + 4 * t + k] : 0u; /* count == 0 restarts the sums, FFTIQ.cpp:88-93 */
   int n_out = 0;
   int b = 0;
   if (!p.have_prev && p.n_blocks > 0) { /* FFTIQ.cpp:73-77 */
@@ -125,8 +96,7 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
     }
     if (p.use_window) { /* FFTIQ.cpp:50-63 */
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        x[k] = pack16(__mul24(lo16(x[k]), win[k]) >> 15, __mul24(hi16(x[k]), win[k]) >> 15);
+      for (int k = 0; k < 4; k++) x[k] = window_mul(x[k], win2[k]);
     }
     /* four stages, span L = 64, 16, 4, 1; positions base + k*L */
     bfly(x, tw[0]);
@@ -155,21 +125,20 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) x[k] = ex[4 * t + k];
-    bfly(x, tw[3]);
+    int re[4], im[4];
+    bfly_w0_unpacked(x, re, im);
     __syncthreads();
     /* FFTIQ.cpp:86-98 */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int r = lo16(x[k]), q = hi16(x[k]);
-      uint32_t magsq = (uint32_t)(__mul24(r, r) + __mul24(q, q));
+      const uint32_t magsq = (uint32_t)(__mul24(re[k], re[k]) + __mul24(im[k], im[k]));
       uint32_t term; /* magsq / naverage, FFTIQ.cpp:90 */
       if (p.div_pow2) {
         term = magsq >> p.div_shift;
       } else {
-        const uint32_t tq = __umulhi(p.div_magic, magsq);
-        term = (((magsq - tq) >> 1) + tq) >> p.div_shift;
+        term = __umulhi(p.div_magic, magsq) >> p.div_shift;
       }
-      sum[k] = (count == 0) ? term : sum[k] + term;
+      sum[k] += term;
     }
     if (++count == p.naverage) { /* FFTIQ.cpp:99-113 */
       count = 0;
@@ -178,6 +147,7 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
       for (int k = 0; k < 4; k++) {
         const int bin = 64 * k + rbase;
         o[255 - (bin ^ 128)] = (uint16_t)isqrt32(sum[k]);
+        sum[k] = 0u;
       }
       n_out++;
     }
@@ -324,15 +294,12 @@ extern "C" int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, siz
     const uint32_t d = (uint32_t)s->naverage;
     int fl = 0;
     while ((2u << fl) <= d) fl++; /* floor(log2 d) */
-    p.div_shift = fl;
     p.div_pow2 = (d & (d - 1)) == 0;
+    p.div_shift = fl; /* power of two: the shift itself; else L - 1 with L = fl + 1 */
     p.div_magic = 0;
     if (!p.div_pow2) {
-      const unsigned long long n = 1ull << (32 + fl);
-      unsigned long long m = n / d, rem = n - m * d;
-      m += m;
-      if (rem + rem >= d) m += 1;
-      p.div_magic = (uint32_t)(m + 1); /* low 32 bits of the 33-bit multiplier */
+      const unsigned long long n = 1ull << (31 + fl + 1);
+      p.div_magic = (uint32_t)((n + d - 1) / d); /* < 2^32 because d > 2^fl */
     }
   }
   p.use_window = s->window_id != 0;

@@ -157,6 +157,9 @@ def test_gpu_fft1024_is_bit_exact(rdsp, oracle, window):
     lib = _bind(oracle.load())
     nch, nblk = 5, 44
     audio = synth_iq(nch, nblk * 128)[..., 0].copy()          # any int16 stream will do
+    rng = np.random.default_rng(21)                            # ... and rails, to drive the saturating paths
+    audio[3] = rng.choice(np.array([-32768, 32767], np.int16), size=audio.shape[1])
+    audio[4] = np.repeat(rng.choice(np.array([-32768, 32767], np.int16), size=audio.shape[1] // 128), 128)
     want = [oracle_fft1024(lib, audio[c], WINDOWS[window]) for c in range(nch)]
     dev = torch.from_numpy(audio).cuda()
     an = AnalyzeFFT1024(nch, window=window)

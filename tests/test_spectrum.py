@@ -78,10 +78,16 @@ def test_gpu_spectrum_is_bit_exact(rdsp, oracle, naverage, window, calls):
     from radiodsp_sdr_rx_amd.chain import synth_iq
     from radiodsp_sdr_rx_amd.spectrum import WINDOWS, AnalyzeFFT256IQ
     lib = _olib(oracle)
-    nch, nblk = 7, 96
+    nch, nblk = 10, 96
     iq = synth_iq(nch, nblk * 128)
     iq[3] = np.clip(iq[3].astype(np.int32) * 4, -32768, 32767).astype(np.int16)  # drive saturation paths
     iq[4, :, :] = -32768
+    # rail-to-rail data: butterfly outputs of +-32768 on both components meet 45-degree twiddles,
+    # the only way a product leaves the int16 range; and the whole int16 range uniformly
+    rng = np.random.default_rng(12)
+    iq[7] = rng.choice(np.array([-32768, 32767], np.int16), size=iq[7].shape)
+    iq[8] = rng.integers(-32768, 32768, size=iq[8].shape).astype(np.int16)
+    iq[9] = np.repeat(rng.choice(np.array([-32768, 32767], np.int16), size=(nblk * 128 // 64, 2)), 64, axis=0)
     fft = AnalyzeFFT256IQ(nch, naverage=naverage, window=window)
     got = []
     step = nblk // calls * 128
