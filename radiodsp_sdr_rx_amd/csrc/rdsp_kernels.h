@@ -87,7 +87,7 @@ struct RdspSamParams {
   const float *mid_q;      /* Im y                                           */
   size_t mid_stride;
   int n_channels;
-  int n_samples;           /* multiple of 4                                  */
+  int n_samples;           /* multiple of 32 (whole tiles)                   */
   const RdspGroup *groups;
   const uint16_t *group_of;
   float g1, g2, wmin, wmax;
