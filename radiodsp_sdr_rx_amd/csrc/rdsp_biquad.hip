@@ -32,6 +32,7 @@ namespace {
 
 constexpr int TS = 128; /* samples per LDS tile */
 constexpr int TP = TS + 4;
+typedef float bq_v4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int q15_trunc(float x) { /* arm_float_to_q15 (CONV:346-347): x*32768, truncate, saturate */
   float v = x * 32768.0f;
@@ -52,6 +53,14 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
   const float b0 = cf[0], b1 = cf[1], b2 = cf[2], a1 = cf[3], a2 = cf[4];
   float *st = p.state + (size_t)ch * 16 + 4 * s;
   float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+  /* float tiles: this lane's piece of rows (lane >> 5) + 2 it (rows past the last channel read a real one) */
+  size_t row_off[8];
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    int rch = ch0 + (lane >> 5) + 2 * it;
+    if (rch >= p.n_channels) rch = p.n_channels - 1;
+    row_off[it] = (size_t)rch * p.stride + 4 * (lane & 31);
+  }
 
 #pragma unroll 1
   for (int t0 = 0; t0 < p.n_samples; t0 += TS) {
@@ -66,18 +75,18 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
         tile[row][2 * c2 + 1] = (float)src[p.step16] * (1.0f / 32768.0f);
       }
     } else {
-      for (int idx = lane; idx < 16 * (TS / 4); idx += 64) {
-        const int row = idx / (TS / 4), c4 = idx % (TS / 4);
-        int rch = ch0 + row;
-        if (rch >= p.n_channels) rch = p.n_channels - 1;
-        const float4 v = *reinterpret_cast<const float4 *>(p.buf + (size_t)rch * p.stride + t0 + 4 * c4);
-        *reinterpret_cast<float4 *>(&tile[row][4 * c4]) = v;
-      }
+#pragma unroll
+      for (int it = 0; it < 8; it++) /* 32 lanes per row, two rows per pass */
+        *reinterpret_cast<bq_v4 *>(&tile[(lane >> 5) + 2 * it][4 * (lane & 31)]) =
+            *reinterpret_cast<const bq_v4 *>(p.buf + row_off[it] + t0);
     }
     __syncthreads();
+    /* skewed steps i = 0 .. TS + 2, lane s on sample n = i - s.  Steps 7 .. TS - 2 have every lane
+     * inside the tile: they run unmasked, four to a chunk (i = 4c + 3 .. 4c + 6, c = 1 .. TS/4 - 2), so
+     * that stage 3 finishes samples 4c .. 4c + 3 and stage 0 starts 4c + 3 .. 4c + 6 -- one 16-byte
+     * LDS read and one write per chunk; the ramps at both ends of the tile keep the general form */
     float yprev = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < TS + 3; i++) {
+    auto ramp_step = [&](int i) {
       const int n = i - s;
       const bool active = (n >= 0) && (n < TS);
       const float xin0 = tile[cl][i < TS ? i : TS - 1];
@@ -96,7 +105,37 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
         yprev = y;
         if (s == 3) tile[cl][n] = y;
       }
+    };
+#pragma unroll
+    for (int i = 0; i < 7; i++) ramp_step(i);
+    {
+      bq_v4 q = *reinterpret_cast<const bq_v4 *>(&tile[cl][4]);
+#pragma unroll 2
+      for (int c = 1; c <= TS / 4 - 2; c++) {
+        const bq_v4 qn = *reinterpret_cast<const bq_v4 *>(&tile[cl][4 * c + 4]);
+        const float xin[4] = {q[3], qn[0], qn[1], qn[2]};
+        bq_v4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float xup = __builtin_bit_cast(
+              float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yprev), 0x90, 0xF, 0xF, false));
+          const float x = (s == 0) ? xin[k] : xup;
+          float y = b0 * x;
+          y = fmaf(b1, x1, y);
+          y = fmaf(b2, x2, y);
+          y = fmaf(a1, y1, y);
+          y = fmaf(a2, y2, y);
+          x2 = x1; x1 = x;
+          y2 = y1; y1 = y;
+          yprev = y;
+          o[k] = y;
+        }
+        if (s == 3) *reinterpret_cast<bq_v4 *>(&tile[cl][4 * c]) = o;
+        q = qn;
+      }
     }
+#pragma unroll
+    for (int i = TS - 1; i < TS + 3; i++) ramp_step(i);
     __syncthreads();
     /* tile out */
     if (p.out16) {
@@ -110,13 +149,11 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
         }
       }
     } else {
-      for (int idx = lane; idx < 16 * (TS / 4); idx += 64) {
-        const int row = idx / (TS / 4), c4 = idx % (TS / 4);
-        const int rch = ch0 + row;
-        if (rch < p.n_channels)
-          *reinterpret_cast<float4 *>(p.buf + (size_t)rch * p.stride + t0 + 4 * c4) =
-              *reinterpret_cast<const float4 *>(&tile[row][4 * c4]);
-      }
+#pragma unroll
+      for (int it = 0; it < 8; it++)
+        if (ch0 + (lane >> 5) + 2 * it < p.n_channels)
+          *reinterpret_cast<bq_v4 *>(p.buf + row_off[it] + t0) =
+              *reinterpret_cast<const bq_v4 *>(&tile[(lane >> 5) + 2 * it][4 * (lane & 31)]);
     }
     __syncthreads();
   }
