@@ -146,6 +146,13 @@ def f1_main(args):
     samples = nch * nblk * 128
     value = samples * args.steps / elapsed / 1e6
     achieved = 4.0 * samples / (kms * 1e-3) / 1e9
+    traffic, valu = None, None   # PMC passes of tests/profile_round.sh (same workload), per launch
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))["F1"]["rdsp_spectrum_kernel"]
+        if (nch, nblk) == (4096, 512):
+            traffic, valu = ent.get("hbm_bytes"), {"insts_per_launch": ent.get("valu_insts"), "busy_frac_pmc": ent.get("valu_busy_frac")}
+    except Exception:
+        pass
     res = {"metric": "IQ Msamples/s through the IQ panadapter spectrum analyser (SURVEY 8f row F1)", "value": value,
            "unit": "IQ Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -153,8 +160,10 @@ def f1_main(args):
            "config": {"workload": f"F1: {nch} channels x {nblk} blocks of 128 int16 IQ samples per step; 256-pt q15 "
                                   "radix-4 FFT per block pair, Hann window, 30-frame power average, integer sqrt"},
            "roofline": {"bound": "hbm", "kernel": "rdsp_spectrum_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "note": "algorithmic bytes = 4 B per input sample (the spectra written are < 0.1 %)"}}
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "limiter": "valu",
+                        "valu": valu,
+                        "note": "algorithmic bytes = 4 B per input sample (the spectra written are < 0.1 %); "
+                                "integer VALU issue binds (about 210 instructions per 256-point frame and wave)"}}
     if not args.no_cpu_baseline:
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", "F1"],

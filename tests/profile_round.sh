@@ -18,7 +18,6 @@ for K in $CFGS; do
 done
 # PMC: one counter family per pass (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel trace only
 for K in $CFGS; do
-  [ $K = F1 ] && continue
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_${K}_$C -o pmc -- python3 $ROOT/bench.py --config $K $P > $OUT/pmc_${K}_$C.json 2> $OUT/pmc_${K}_$C.err) || { echo "pmc $K $C failed"; tail -5 $OUT/pmc_${K}_$C.err; }
   done

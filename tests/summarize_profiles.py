@@ -67,7 +67,7 @@ def main():
                 open(os.path.join(PROF, f"{rnd}_{cfg.lower()}_bench.json"), "w").write(lines[-1] + "\n")
     cpath = os.path.join(PROF, "counters.json")
     counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
-    for cfg in ("K2", "K3", "K4", "K5"):
+    for cfg in ("K2", "K3", "K4", "K5", "F1"):
         fetch, write, sq = (pmc_per_launch(f"{cfg}_{t}") for t in ("FETCH_SIZE", "WRITE_SIZE", "SQ"))
         if not (fetch or write or sq):
             continue
