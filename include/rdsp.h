@@ -166,6 +166,8 @@ int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c);                 /* BK_INO:1259
 int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c);                /* INO:131 */
 int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db); /* BK_INO:1260 */
 /* AudioSDRpreProcessor */
+/* swapIQ and the input-side gains take effect with the first sample of the next call (samples
+ * already inside the decimator's delay line keep what they came in with) */
 int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap);                   /* INO:118 */
 int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c);         /* INO:117: no I2S bus here, accepted and ignored */
 int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g);              /* INO:133 */
@@ -173,7 +175,10 @@ int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g);             /* INO:134 */
 int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g);          /* INO:135 */
 int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c);                  /* INO:137 */
 int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream); /* INO:138, CTL:153-177 */
-/* returns the tuning offset in Hz like the reference (INO:139, CTL:337-407) */
+/* returns the tuning offset in Hz like the reference (INO:139, CTL:337-407).  The engine's modes pick
+ * the side band the selected audio filter sits on, so the pass band is re-applied for the new mode
+ * (USB/CW_USB: +a..+b, LSB/CW_LSB: -b..-a, AM/SAM: -b..+b of setAudioFilter's a..b); a later
+ * rdsp_reInitializeFilter / PBT step overrides it, as RDSP_controls.h:569-612 does in the sketch. */
 uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream);
 int rdsp_sdr_setMute(rdsp_chain_t *c, int mute);                  /* INO:177 */
 int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of CTL:447 */

@@ -441,6 +441,15 @@ void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db) {
   c->nb_thr = (float)pow(10.0, (double)threshold_db / 10.0);
 }
 float orc_chain_nb_level(const orc_chain_t *c) { return c->nb_level; }
+/* SDR.setInputGain / setIQgainBalance / setOutputGain / setMute (INO:133-135,177) between calls:
+ * the input-side values apply to samples as they arrive (what is already in the decimator's delay
+ * line keeps the gains it came in with), the output-side ones from the next output sample on */
+void orc_set_gains(orc_chain_t *c, float input_gain, float iq_balance, float output_gain, int mute) {
+  c->cfg.input_gain = input_gain;
+  c->cfg.iq_balance = iq_balance;
+  c->cfg.output_gain = output_gain;
+  c->cfg.mute = mute ? 1 : 0;
+}
 
 /* SAMmode (CTL:384-391) is an AudioSDR demodulator; build-defined here as the
  * classic second-order PLL synchronous detector on the filtered base band y:

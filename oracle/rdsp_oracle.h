@@ -112,6 +112,7 @@ void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327
 void orc_set_swap_iq(orc_chain_t *c, int on);
 void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db);
 float orc_chain_nb_level(const orc_chain_t *c);
+void orc_set_gains(orc_chain_t *c, float input_gain, float iq_balance, float output_gain, int mute);
 /* SAM PLL loop constants at the decimated rate (build-defined, see rdsp_oracle.c) */
 void orc_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax);
 

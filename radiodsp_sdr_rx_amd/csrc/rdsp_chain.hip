@@ -143,6 +143,10 @@ struct rdsp_chain {
   float *d_iir_coef = nullptr, *d_iir_state = nullptr;
   int iir_sets = 0;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
+  /* swap flag and input scales of the previous call (its samples are this call's FIR history) */
+  bool hist_valid = false;
+  int hist_swap = 0;
+  float hist_scale_i = 0.f, hist_scale_q = 0.f;
   int nb_on = 0;              /* SDR.enableNoiseBlanker, BK_INO:1259 */
   float nb_threshold_db = 10.0f;
 };
@@ -479,6 +483,7 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   for (size_t i = 0; i < nch; i++) sc[4 * i + 1] = 1.0f;
   HIP_TRY(hipMemcpy(c->d_scal, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
   c->n_in = 0;
+  c->hist_valid = false;
   c->nr_calls = c->als_calls = 0;
   c->old_nr_level = 15;
   c->nr_mu = rdsp_lms_mu(15);
@@ -610,6 +615,9 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.scale_i = cf.iq_balance * cf.input_gain * (1.0f / 32768.0f);
   fp.scale_q = cf.input_gain * (1.0f / 32768.0f);
   fp.swap_iq = c->swap_iq;
+  fp.swap_hist = c->hist_valid ? c->hist_swap : fp.swap_iq;
+  fp.scale_i_hist = c->hist_valid ? c->hist_scale_i : fp.scale_i;
+  fp.scale_q_hist = c->hist_valid ? c->hist_scale_q : fp.scale_q;
   fp.nb_on = c->nb_on;
   fp.nb_thr = (float)pow(10.0, (double)c->nb_threshold_db / 10.0);
   fp.fir_hc = c->d_fir_hc;
@@ -809,6 +817,10 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   }
   c->call_idx++;
   c->n_in += n_in;
+  c->hist_valid = true;
+  c->hist_swap = fp.swap_iq;
+  c->hist_scale_i = fp.scale_i;
+  c->hist_scale_q = fp.scale_q;
   return RDSP_OK;
 }
 

@@ -48,6 +48,10 @@ struct RdspFrontParams {
   const uint16_t *group_of;  /* [ch] group of each channel; NULL: all group 0 */
   float scale_i, scale_q;  /* iq_balance*input_gain/32768, input_gain/32768  */
   int swap_iq;             /* preProcessor.swapIQ(true), INO:118             */
+  /* what the previous call ran with: the FIR history is kept as raw words, and the 256 samples in
+   * it went through the pre-processor and the input gains when they were new (like dphi_hist) */
+  float scale_i_hist, scale_q_hist;
+  int swap_hist;
   int nb_on;               /* noise blanker (engine feature, build-defined)  */
   float nb_thr;            /* blanking threshold as a power ratio            */
   const float *fir_hc;     /* [4][64] decimator taps, hc[c][k'] = h[4k'+c]   */

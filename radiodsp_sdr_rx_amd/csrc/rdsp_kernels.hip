@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     for (int i = tid; i < 64; i += NT) {
       uint4 w4 = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * i);
       uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-      if (SWAP_IQ) { /* preProcessor.swapIQ: the stored history is the raw stream */
+      if (PRE && p.swap_hist != 0) { /* the stored history is the raw stream: swapped as the call it came in with swapped */
 #pragma unroll
         for (int k = 0; k < 4; k++) w[k] = __builtin_amdgcn_alignbit(w[k], w[k], 16);
       }
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        float2 x = unpack_iq(w[k], p.scale_i, p.scale_q);
+        float2 x = unpack_iq(w[k], PRE ? p.scale_i_hist : p.scale_i, PRE ? p.scale_q_hist : p.scale_q); /* ... and the gains of that call */
         { /* the history keeps the mixing it went through when it was new (identity phasors when
            * the NCO was off: roth* are (1, -0) then and the products are exact) */
           float2 ph = (k == 0) ? ph0 : cmul_pinned_u(ph0, k == 1 ? G.roth1 : (k == 2 ? G.roth2 : G.roth3));
@@ -752,6 +752,11 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       else pj[0] = cmulc_uniform(b1, G.rotq1);
     }
     const bool hist = (fr == 0);
+    /* column 0 of the call's first frame is the previous call's samples: they keep the swap flag and
+     * the gains they came in with (uniform values, chosen once per frame).  Only the PRE kernels carry
+     * this: the launch code picks them for the one call after such a setting changed */
+    const float si0 = (PRE && hist) ? p.scale_i_hist : p.scale_i, sq0 = (PRE && hist) ? p.scale_q_hist : p.scale_q;
+    const bool swap0 = PRE && (hist ? p.swap_hist != 0 : p.swap_iq != 0);
 
     /* ---- A1 + A3: four branch transforms, multiply-accumulate with the branch spectra ------- */
     float2 acc[PD];
@@ -768,8 +773,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
 #pragma unroll
       for (int j = 0; j < PD; j++) {
         uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
-        if (SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
-        float2 x = unpack_iq(w, p.scale_i, p.scale_q);
+        if (j == 0 ? swap0 : SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
+        float2 x = unpack_iq(w, j == 0 ? si0 : p.scale_i, j == 0 ? sq0 : p.scale_q);
         float2 ph = pj[j];
         if (r > 0) {
           const float2 rr = (r == 1) ? G.rot1 : (r == 2) ? G.rot2 : G.rot3;
@@ -938,7 +943,9 @@ int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream)
 }
 template <int N, int P, int DECIM, bool LEAN>
 int launch_front_v(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  return (p->nb_on || p->swap_iq) ? launch_front_w<N, P, DECIM, LEAN, true>(p, n_channels, stream)
+  /* PRE: blanker, swap, or a FIR history that came in under another swap flag / other input gains */
+  const bool hist_differs = p->swap_hist != p->swap_iq || p->scale_i_hist != p->scale_i || p->scale_q_hist != p->scale_q;
+  return (p->nb_on || p->swap_iq || hist_differs) ? launch_front_w<N, P, DECIM, LEAN, true>(p, n_channels, stream)
                                   : launch_front_w<N, P, DECIM, LEAN, false>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM>

@@ -130,6 +130,7 @@ def load(path=None):
     lib.orc_demod_tuning_offset.restype = C.c_uint32
     lib.orc_set_swap_iq.argtypes = [vp, C.c_int]
     lib.orc_set_noise_blanker.argtypes = [vp, C.c_int, C.c_float]
+    lib.orc_set_gains.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int]
     lib.orc_chain_nb_level.argtypes = [vp]
     lib.orc_chain_nb_level.restype = C.c_float
     lib.orc_set_demod.argtypes = [vp, C.c_int]
@@ -207,6 +208,9 @@ class OracleChain:
 
     def nb_level(self):
         return float(self.lib.orc_chain_nb_level(self.h))
+
+    def set_gains(self, input_gain, iq_balance, output_gain, mute=False):
+        self.lib.orc_set_gains(self.h, C.c_float(input_gain), C.c_float(iq_balance), C.c_float(output_gain), int(bool(mute)))
 
     def set_demod(self, demod):
         self.lib.orc_set_demod(self.h, int(demod))

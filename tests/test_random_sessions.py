@@ -7,7 +7,7 @@ rewritten in stream order).  Same call split, same kernels: the int16 audio, the
 scalars and both NLMS coefficient sets must be bit-identical -- any missing stream dependency
 between a setter, a stage and the next call shows up as a difference.
 
-A third chain replays the script on a different channel partition (the first 64 channels only) and
+A third chain replays the script on a different channel partition (the first 63 channels only) and
 must reproduce those channels bit for bit: nothing may depend on which other channels share a launch.
 """
 import numpy as np
@@ -141,10 +141,135 @@ def test_random_control_session_plain_pipelined_and_repartitioned_agree_bitwise(
     plain = run_script(rdsp, torch, ops, iq, NCH, False, 0)
     piped = run_script(rdsp, torch, ops, iq, NCH, True, 64)      # 64 + 64 + 22 channels per stage launch
     names = ("audio", "scalars", "DSP-NR weights", "ALS weights")
+    # equal_nan: the reference's NLMS (arm_lms_norm_f32: energy by running difference) can blow up after
+    # a loud-to-quiet transition -- the literal CPU restatement does the same -- and a
+    # script that tunes a group off its signal produces exactly that; both chains must then blow up alike
     for name, a, b in zip(names, plain, piped):
-        assert np.array_equal(a, b), f"seed {seed}: {name} differ between the plain and the pipelined chain"
-    assert np.isfinite(plain[1]).all() and np.isfinite(plain[2]).all() and np.isfinite(plain[3]).all()
+        assert np.array_equal(a, b, equal_nan=True), f"seed {seed}: {name} differ between the plain and the pipelined chain"
+    assert np.isfinite(plain[1]).all()
     # 63 = 21 x 3 keeps the channel -> group map (c mod 3) of the first channels
     part = run_script(rdsp, torch, ops, iq, 63, True, 0)
     for name, a, b in zip(names, plain, part):
-        assert np.array_equal(a[:63], b), f"seed {seed}: {name} depend on the channel partition"
+        assert np.array_equal(a[:63], b, equal_nan=True), f"seed {seed}: {name} depend on the channel partition"
+
+
+# ---- the same idea against the oracle: feed-forward chains, 1e-5 -------------------------------
+def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
+    """per-group mode changes (tuningMode()'s pair: setAudioFilter + setDemodMode, CTL:330-423), retunes,
+    PBT steps and offsets, global swap / blanker / gains / mute, calls of random length.  Every op
+    carries what the oracle chain of a channel of that group has to be told."""
+    from radiodsp_sdr_rx_amd.chain import pbt_step
+    ops = []
+    band = [(300.0, 2700.0)] * n_groups
+    gains = dict(input_gain=1.0, iq_balance=1.0, output_gain=0.5, mute=False)
+    for _ in range(n_ops):
+        kind = str(rng.choice(["proc", "proc", "proc", "mode", "filt", "pbt", "nco", "swap", "nb", "gain"]))
+        g = int(rng.integers(0, n_groups))
+        if kind == "proc":
+            ops.append(("proc", granule * int(rng.integers(1, 4))))
+        elif kind == "mode":
+            filt, demod = int(rng.integers(0, 5)), str(rng.choice(["USB", "LSB", "CW_USB", "CW_LSB", "AM"]))
+            band[g] = oracle.passband(filt, rdsp.DEMOD[demod])
+            ops.append(("mode", g, filt, demod) + band[g])
+        elif kind == "filt":
+            lo = float(rng.choice([100.0, 300.0, 600.0]))
+            band[g] = (lo, lo + float(rng.choice([400.0, 1800.0, 2400.0])))
+            ops.append(("filt", g) + band[g])
+        elif kind == "pbt":
+            if band[g][0] < 0.0:      # the sketch steps its positive dFLoCut / dFHiCut (CTL:569-612)
+                continue
+            edge, d = int(rng.integers(0, 2)), int(rng.choice([-1, 1]))
+            band[g] = pbt_step(band[g][0], band[g][1], edge, d)
+            ops.append(("pbt", g, edge, d) + band[g])
+        elif kind == "nco":
+            ops.append(("nco", g, float(rng.choice([12000.0, 11300.0, 12650.0]))))
+        elif kind == "swap":
+            ops.append(("swap", bool(rng.integers(0, 2))))
+        elif kind == "nb":
+            ops.append(("nb", bool(rng.integers(0, 2)), float(rng.choice([8.0, 12.0]))))
+        elif kind == "gain":
+            which = str(rng.choice(["input_gain", "iq_balance", "output_gain", "mute"]))
+            gains[which] = {"input_gain": float(rng.choice([0.5, 1.0, 1.4])), "iq_balance": float(rng.choice([1.0, 1.02, 0.96])),
+                            "output_gain": float(rng.choice([0.25, 0.5, 1.0])), "mute": bool(rng.integers(0, 3) == 0)}[which]
+            ops.append(("gain", dict(gains)))
+    ops.append(("gain", dict(gains, mute=False)))
+    ops.append(("proc", 2 * granule))
+    return ops
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from cases import TOL
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    rng = np.random.default_rng(seed)
+    n_groups, nch = 3, 6
+    base = dict(fft_l=int(rng.choice([256, 512, 1024])), agc_mode=str(rng.choice(["off", "medium", "fast"])),
+                spectral_nr=int(rng.choice([0, 1])), spectral_level=2.0, output_gain=0.5,
+                window=int(rng.choice([1, 2, 4])))
+    granule = max(8, base["fft_l"] // 64)   # an overlap-save hop of FFT_L / 2 samples at 24 kHz and the front kernel's 1024-sample chunk, in 128-sample blocks
+    ops = _oracle_script(rng, oracle, rdsp, n_groups, granule)
+    total = sum(op[1] for op in ops if op[0] == "proc")
+    iq = synth_iq(nch, total * 128)
+    for c in range(nch):
+        for p in rng.integers(3000, iq.shape[1] - 4, 10):
+            iq[c, p:p + 3] = rng.choice([-30000, 30000])
+    group_of = (np.arange(nch) % n_groups).astype(np.uint16)
+    ch = Chain(nch, max_blocks_per_call=3 * granule, **base)
+    ch.set_groups(group_of)
+    ch.set_pipelined(bool(seed % 2))
+    if seed % 3 == 0:
+        ch.set_fir_variant(0)        # the direct-form decimator keeps its own copy of the history path
+    ocs = [oracle.OracleChain(**base) for _ in range(nch)]
+    dev = torch.from_numpy(iq).cuda()
+    got, ref, pos = [], [[] for _ in range(nch)], 0
+    for op in ops:
+        k = op[0]
+        mine = [c for c in range(nch) if k in ("mode", "filt", "pbt", "nco") and group_of[c] == op[1]]
+        if k == "proc":
+            n = op[1]
+            got.append(ch.process(dev[:, pos * 128:(pos + n) * 128], want_f32=True)[1])
+            for c in range(nch):
+                ref[c].append(ocs[c].process(iq[c, pos * 128:(pos + n) * 128])[1])
+            pos += n
+        elif k == "mode":
+            ch.group_setAudioFilter(op[1], op[2])
+            ch.group_setDemodMode(op[1], rdsp.DEMOD[op[3]])
+            for c in mine:
+                ocs[c].set_demod(rdsp.DEMOD[op[3]])
+                ocs[c].reinit_filter(op[4], op[5])
+        elif k == "filt":
+            ch.group_reInitializeFilter(op[1], op[2], op[3])
+            for c in mine:
+                ocs[c].reinit_filter(op[2], op[3])
+        elif k == "pbt":
+            ch.group_pbt(op[1], op[2], op[3])
+            for c in mine:
+                ocs[c].reinit_filter(op[4], op[5])
+        elif k == "nco":
+            ch.group_setTuningOffsetHz(op[1], op[2])
+            for c in mine:
+                ocs[c].set_nco_hz(op[2])
+        elif k == "swap":
+            ch.swapIQ(op[1])
+            for oc in ocs:
+                oc.set_swap_iq(op[1])
+        elif k == "nb":
+            ch.enableNoiseBlanker() if op[1] else ch.disableNoiseBlanker()
+            ch.setNoiseBlankerThresholdDb(op[2])
+            for oc in ocs:
+                oc.set_noise_blanker(op[1], op[2])
+        elif k == "gain":
+            gn = op[1]
+            ch.setInputGain(gn["input_gain"]); ch.setIQgainBalance(gn["iq_balance"])
+            ch.setOutputGain(gn["output_gain"]); ch.setMute(gn["mute"])
+            for oc in ocs:
+                oc.set_gains(gn["input_gain"], gn["iq_balance"], gn["output_gain"], gn["mute"])
+    ch.flush()
+    torch.cuda.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in got], 1)
+    for c in range(nch):
+        r = np.concatenate(ref[c])
+        err = np.abs(got[c] - r).max() / np.abs(r).max()
+        assert err <= TOL, f"seed {seed} ({base}), channel {c}: {err:.2e}\n{ops}"
