@@ -444,6 +444,13 @@ float orc_chain_nb_level(const orc_chain_t *c) { return c->nb_level; }
 /* SDR.setInputGain / setIQgainBalance / setOutputGain / setMute (INO:133-135,177) between calls:
  * the input-side values apply to samples as they arrive (what is already in the decimator's delay
  * line keeps the gains it came in with), the output-side ones from the next output sample on */
+/* SDR.setAGCmode / disableAGC (INO:120-121, CTL:196-232) and the spectral stage's switch and level
+ * (SPEC:112 iNRLevel; CTL:237-297) between calls: plain configuration, the states (gain, NFloor) stay */
+void orc_set_agc_mode(orc_chain_t *c, int mode) { c->cfg.agc_mode = mode; }
+void orc_set_spectral_nr(orc_chain_t *c, int on, float level) {
+  c->cfg.spectral_nr = on;
+  c->cfg.spectral_level = level;
+}
 void orc_set_gains(orc_chain_t *c, float input_gain, float iq_balance, float output_gain, int mute) {
   c->cfg.input_gain = input_gain;
   c->cfg.iq_balance = iq_balance;

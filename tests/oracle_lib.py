@@ -131,6 +131,8 @@ def load(path=None):
     lib.orc_set_swap_iq.argtypes = [vp, C.c_int]
     lib.orc_set_noise_blanker.argtypes = [vp, C.c_int, C.c_float]
     lib.orc_set_gains.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int]
+    lib.orc_set_agc_mode.argtypes = [vp, C.c_int]
+    lib.orc_set_spectral_nr.argtypes = [vp, C.c_int, C.c_float]
     lib.orc_chain_nb_level.argtypes = [vp]
     lib.orc_chain_nb_level.restype = C.c_float
     lib.orc_set_demod.argtypes = [vp, C.c_int]
@@ -211,6 +213,12 @@ class OracleChain:
 
     def set_gains(self, input_gain, iq_balance, output_gain, mute=False):
         self.lib.orc_set_gains(self.h, C.c_float(input_gain), C.c_float(iq_balance), C.c_float(output_gain), int(bool(mute)))
+
+    def set_agc_mode(self, mode):
+        self.lib.orc_set_agc_mode(self.h, int(mode))
+
+    def set_spectral_nr(self, on, level):
+        self.lib.orc_set_spectral_nr(self.h, int(on), float(level))
 
     def set_demod(self, demod):
         self.lib.orc_set_demod(self.h, int(demod))

@@ -163,7 +163,7 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
     band = [(300.0, 2700.0)] * n_groups
     gains = dict(input_gain=1.0, iq_balance=1.0, output_gain=0.5, mute=False)
     for _ in range(n_ops):
-        kind = str(rng.choice(["proc", "proc", "proc", "mode", "filt", "pbt", "nco", "swap", "nb", "gain"]))
+        kind = str(rng.choice(["proc", "proc", "proc", "mode", "filt", "pbt", "nco", "swap", "nb", "gain", "agc", "spec"]))
         g = int(rng.integers(0, n_groups))
         if kind == "proc":
             ops.append(("proc", granule * int(rng.integers(1, 4))))
@@ -187,6 +187,10 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
             ops.append(("swap", bool(rng.integers(0, 2))))
         elif kind == "nb":
             ops.append(("nb", bool(rng.integers(0, 2)), float(rng.choice([8.0, 12.0]))))
+        elif kind == "agc":
+            ops.append(("agc", str(rng.choice(["off", "fast", "medium", "slow"]))))
+        elif kind == "spec":
+            ops.append(("spec", int(rng.choice([0, 1, 2])), float(rng.choice([1.0, 2.0, 3.0]))))
         elif kind == "gain":
             which = str(rng.choice(["input_gain", "iq_balance", "output_gain", "mute"]))
             gains[which] = {"input_gain": float(rng.choice([0.5, 1.0, 1.4])), "iq_balance": float(rng.choice([1.0, 1.02, 0.96])),
@@ -197,7 +201,7 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
     return ops
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("seed", list(range(11, 27)))
 def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
@@ -260,6 +264,14 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
             ch.setNoiseBlankerThresholdDb(op[2])
             for oc in ocs:
                 oc.set_noise_blanker(op[1], op[2])
+        elif k == "agc":
+            ch.setAGCmode(rdsp.AGC[op[1]])
+            for oc in ocs:
+                oc.set_agc_mode(rdsp.AGC[op[1]])
+        elif k == "spec":
+            ch.set_spectral_nr(op[1], op[2])
+            for oc in ocs:
+                oc.set_spectral_nr(op[1], op[2])
         elif k == "gain":
             gn = op[1]
             ch.setInputGain(gn["input_gain"]); ch.setIQgainBalance(gn["iq_balance"])
