@@ -285,3 +285,76 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
         r = np.concatenate(ref[c])
         err = np.abs(got[c] - r).max() / np.abs(r).max()
         assert err <= TOL, f"seed {seed} ({base}), channel {c}: {err:.2e}\n{ops}"
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
+def test_random_nr_and_notch_switching_follows_the_oracle(rdsp, oracle, seed):
+    """The recursive stages switched at random between calls: ALS off / notch / peak, DSP-NR level
+    0 / 20 / 30 (a level change re-initialises the instance, CONV:327-331), AGC modes, the spectral stage.
+    Not a parity measurement (that is the truth-anchored tests' job: two float32 NLMS runs drift apart
+    by 1e-5 ... 1e-4 on their own) but a check of the switching semantics -- what keeps its state, what
+    is re-initialised, which call a change takes effect in: a wrong answer to any of those is an error
+    of order one, the bound is 3e-3 of full scale."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    rng = np.random.default_rng(seed)
+    nch = 4
+    base = dict(K3, fft_l=int(rng.choice([256, 512])))
+    ops = []
+    for _ in range(22):
+        kind = str(rng.choice(["proc", "proc", "als", "nr", "agc", "spec"]))
+        if kind == "proc":
+            ops.append(("proc", 8 * int(rng.integers(1, 4))))
+        elif kind == "als":
+            ops.append(("als", str(rng.choice(["off", "notch", "peak"]))))
+        elif kind == "nr":
+            ops.append(("nr", int(rng.choice([0, 20, 30]))))
+        elif kind == "agc":
+            ops.append(("agc", str(rng.choice(["off", "fast", "medium", "slow"]))))
+        else:
+            ops.append(("spec", int(rng.choice([0, 1])), float(rng.choice([1.0, 2.0]))))
+    ops.append(("proc", 16))
+    total = sum(op[1] for op in ops if op[0] == "proc")
+    iq = synth_iq(nch, total * 128)
+    ch = Chain(nch, max_blocks_per_call=24, **base)
+    ch.set_pipelined(bool(seed % 2))
+    ocs = [oracle.OracleChain(**base) for _ in range(nch)]
+    dev = torch.from_numpy(iq).cuda()
+    got, ref, pos = [], [[] for _ in range(nch)], 0
+    for op in ops:
+        k = op[0]
+        if k == "proc":
+            n = op[1]
+            got.append(ch.process(dev[:, pos * 128:(pos + n) * 128], want_f32=True)[1])
+            for c in range(nch):
+                ref[c].append(ocs[c].process(iq[c, pos * 128:(pos + n) * 128])[1])
+            pos += n
+        elif k == "als":
+            if op[1] == "off":
+                ch.disableALSfilter()
+            else:
+                ch.enableALSfilter()
+                ch.setALSfilterNotch() if op[1] == "notch" else ch.setALSfilterPeak()
+            for oc in ocs:
+                oc.set_als_mode(rdsp.ALS[op[1]])
+        elif k == "nr":
+            ch.set_nr_level(op[1])
+            for oc in ocs:
+                oc.set_nr_level(op[1])
+        elif k == "agc":
+            ch.setAGCmode(rdsp.AGC[op[1]])
+            for oc in ocs:
+                oc.set_agc_mode(rdsp.AGC[op[1]])
+        elif k == "spec":
+            ch.set_spectral_nr(op[1], op[2])
+            for oc in ocs:
+                oc.set_spectral_nr(op[1], op[2])
+    ch.flush()
+    torch.cuda.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in got], 1)
+    for c in range(nch):
+        r = np.concatenate(ref[c])
+        assert np.isfinite(r).all() and np.isfinite(got[c]).all()
+        err = np.abs(got[c] - r).max() / np.abs(r).max()
+        assert err <= 3e-3, f"seed {seed}, channel {c}: {err:.2e}\n{ops}"
