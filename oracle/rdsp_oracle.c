@@ -1002,6 +1002,13 @@ orc_fft256iq_t *orc_fft256iq_create(int naverage, int window_id) {
   return s;
 }
 void orc_fft256iq_destroy(orc_fft256iq_t *s) { free(s); }
+/* averageTogether(uint8_t n), FFTIQ.h:88-91: count is left alone */
+void orc_fft256iq_averageTogether(orc_fft256iq_t *s, int n) { s->naverage = (uint8_t)(n <= 0 ? 1 : n); }
+/* windowFunction(const int16_t *w), FFTIQ.h:93-95 */
+void orc_fft256iq_windowFunction(orc_fft256iq_t *s, int window_id) {
+  s->has_window = window_id != 0;
+  orc_window_q15(window_id, s->window);
+}
 const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s) { return s->output; }
 
 int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *bi, const int16_t *bq) {

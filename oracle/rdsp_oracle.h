@@ -172,6 +172,8 @@ void orc_cfft_radix4_q15_256(int16_t *buf /* 512: re,im */); /* scaled by 1/256,
 uint32_t orc_sqrt_uint32(uint32_t x);
 orc_fft256iq_t *orc_fft256iq_create(int naverage, int window_id);
 void orc_fft256iq_destroy(orc_fft256iq_t *s);
+void orc_fft256iq_averageTogether(orc_fft256iq_t *s, int n);       /* FFTIQ.h:88-91 */
+void orc_fft256iq_windowFunction(orc_fft256iq_t *s, int window_id); /* FFTIQ.h:93-95 */
 /* one update() tick with a 128-sample I block and Q block; returns 1 when output[] was refreshed */
 int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *block_i, const int16_t *block_q);
 const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s); /* uint16 output[256], FFTIQ.h:99 */

@@ -140,7 +140,13 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
       }
       sum[k] += term;
     }
-    if (++count == p.naverage) { /* FFTIQ.cpp:99-113 */
+    count = (count + 1) & 255; /* `uint8_t count`, FFTIQ.h:105 */
+    if (count == 0) { /* wrapped (averageTogether set below the running count): the next frame finds count == 0
+                         and restarts the sums without an output, FFTIQ.cpp:88-93 */
+#pragma unroll
+      for (int k = 0; k < 4; k++) sum[k] = 0u;
+    }
+    if (count == p.naverage) { /* FFTIQ.cpp:99-113 */
       count = 0;
       uint16_t *o = p.out + (ch * p.out_stride + (size_t)n_out) * 256;
 #pragma unroll
@@ -259,11 +265,38 @@ extern "C" int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id) {
   return upload_window(s);
 }
 
+/* the reference's frame counter over `frames` frames: `if (++count == naverage) { output; count = 0; }`
+ * with `uint8_t count` (FFTIQ.h:105, FFTIQ.cpp:99-100) -- an averageTogether() below the running count
+ * lets it run on to the 8-bit wrap, exactly as on the Teensy */
+static void advance_count(int *count, int naverage, int frames, int *outputs) {
+  int c = *count, n = 0;
+  if (c < naverage) { /* the usual case in closed form */
+    const long long t = (long long)c + frames;
+    n = (int)(t / naverage);
+    c = (int)(t % naverage);
+  } else {
+    for (int f = 0; f < frames; f++) {
+      c = (c + 1) & 255;
+      if (c == naverage) { n++; c = 0; }
+      if (c < naverage) { /* back in the usual regime: finish in closed form */
+        const long long t = (long long)c + (frames - f - 1);
+        n += (int)(t / naverage);
+        c = (int)(t % naverage);
+        break;
+      }
+    }
+  }
+  *count = c;
+  if (outputs) *outputs = n;
+}
+
 /* number of spectra the next update over n_blocks will produce */
 extern "C" int rdsp_spectrum_outputs_for(const rdsp_spectrum_t *s, int n_blocks) {
   if (!s || n_blocks <= 0) return 0;
   const int frames = n_blocks - (s->have_prev ? 0 : 1);
-  return (s->count + frames) / s->naverage;
+  int count = s->count, n = 0;
+  advance_count(&count, s->naverage, frames, &n);
+  return n;
 }
 
 /* n_blocks update() ticks for every channel (FFTIQ.cpp:65-118).  d_iq: int16
@@ -316,7 +349,7 @@ extern "C" int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, siz
     return RDSP_ERR_HIP;
   }
   const int frames = n_blocks - (s->have_prev ? 0 : 1);
-  s->count = (s->count + frames) % s->naverage;
+  advance_count(&s->count, s->naverage, frames, nullptr);
   s->have_prev = 1;
   if (n_outputs) *n_outputs = nout;
   return RDSP_OK;

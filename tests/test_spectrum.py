@@ -18,6 +18,8 @@ def _olib(oracle):
     lib.orc_fft256iq_update.restype = C.c_int
     lib.orc_fft256iq_output.restype = C.POINTER(C.c_uint16)
     lib.orc_fft256iq_output.argtypes = [C.c_void_p]
+    lib.orc_fft256iq_averageTogether.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_fft256iq_windowFunction.argtypes = [C.c_void_p, C.c_int]
     lib.orc_cfft_radix4_q15_256.argtypes = [I16P]
     lib.orc_window_q15.argtypes = [C.c_int, I16P]
     lib.orc_sqrt_uint32.argtypes = [C.c_uint32]
@@ -141,3 +143,64 @@ def test_analyser_as_a_graph_node_like_the_sketch(rdsp, oracle):
         for k, r in enumerate(ref):
             assert np.array_equal(outs[k][c], r)
     assert fft.read(0, 10) == outs[-1][0, 10] / 16384.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_gpu_spectrum_random_sessions_are_bit_exact(rdsp, oracle, seed):
+    """update() calls of random length with averageTogether() / windowFunction() in between, against the
+    restatement block by block.  averageTogether below the running frame count lets the reference's
+    `uint8_t count` (FFTIQ.h:105) run on to its 8-bit wrap, with a silent restart of the sums there
+    (FFTIQ.cpp:88-93,99-100): script 1 forces that case; available()/outputs follow."""
+    import torch
+    assert torch.cuda.is_available()
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.spectrum import WINDOWS, AnalyzeFFT256IQ
+    lib = _olib(oracle)
+    rng = np.random.default_rng(seed)
+    names = list(WINDOWS)
+    nch = 3
+    ops = []
+    for _ in range(14):
+        kind = str(rng.choice(["update", "update", "avg", "win"]))
+        if kind == "update":
+            ops.append(("update", int(rng.integers(1, 40))))
+        elif kind == "avg":
+            ops.append(("avg", int(rng.choice([1, 2, 3, 5, 8, 30, 200]))))
+        else:
+            ops.append(("win", str(rng.choice(names))))
+    if seed == 1:   # 30 frames into an average of 200, then averageTogether(5): count = 30 > 5 runs to the wrap
+        ops = [("avg", 200), ("update", 31), ("avg", 5), ("update", 100), ("update", 140), ("update", 20)] + ops
+    ops.append(("update", 64))
+    total = sum(op[1] for op in ops if op[0] == "update")
+    iq = synth_iq(nch, total * 128)
+    iq[1] = rng.integers(-32768, 32768, size=iq[1].shape).astype(np.int16)
+    fft = AnalyzeFFT256IQ(nch, naverage=8, window=names[0])
+    ors = [lib.orc_fft256iq_create(8, WINDOWS[names[0]]) for _ in range(nch)]
+    dev = torch.from_numpy(iq).cuda()
+    pos = 0
+    for op in ops:
+        if op[0] == "update":
+            n = op[1]
+            got = fft.update(dev[:, pos * 128:(pos + n) * 128].contiguous()).cpu().numpy().view(np.uint16)
+            for c in range(nch):
+                want = []
+                i = np.ascontiguousarray(iq[c, pos * 128:(pos + n) * 128, 0])
+                q = np.ascontiguousarray(iq[c, pos * 128:(pos + n) * 128, 1])
+                for b in range(n):
+                    if lib.orc_fft256iq_update(ors[c], i[b * 128:].ctypes.data_as(I16P), q[b * 128:].ctypes.data_as(I16P)):
+                        want.append(np.ctypeslib.as_array(lib.orc_fft256iq_output(ors[c]), (256,)).copy())
+                assert got.shape[1] == len(want), (seed, op, got.shape, len(want))
+                if want:
+                    assert np.array_equal(got[c], np.stack(want)), (seed, op, c)
+            pos += n
+        elif op[0] == "avg":
+            fft.averageTogether(op[1])
+            for o in ors:
+                lib.orc_fft256iq_averageTogether(o, op[1])
+        else:
+            fft.windowFunction(op[1])
+            for o in ors:
+                lib.orc_fft256iq_windowFunction(o, WINDOWS[op[1]])
+    for o in ors:
+        lib.orc_fft256iq_destroy(o)
