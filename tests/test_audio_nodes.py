@@ -238,6 +238,60 @@ def test_gpu_biquad_is_bit_exact_and_streams(rdsp, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_gpu_biquad_random_sessions_are_bit_exact(rdsp, oracle, seed):
+    """update() calls of random length with setLowpass / setHighpass / setBandpass / setNotch on random
+    stages in between: a new section takes over with the next sample and inherits the stage's state, as
+    the oracle cascade does when a stage is rewritten; int16 in, int16 out, identical."""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.filters import FilterBiquad
+    lib = _bind(oracle.load())
+    lib.orc_biquad_init.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_biquad_run.argtypes = [C.POINTER(OrcBiquad), F32P, C.c_int]
+    lib.orc_biquad_set_stage.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
+    rng = np.random.default_rng(seed)
+    nch, fs = 5, 44117.64706
+    ops = []
+    for _ in range(12):
+        if rng.integers(0, 2):
+            ops.append(("update", int(rng.integers(1, 12))))
+        else:
+            ops.append(("set", int(rng.integers(0, 4)), int(rng.integers(0, 4)),
+                        float(rng.choice([300.0, 500.0, 1000.0, 3000.0])), float(rng.choice([0.5, 0.7071, 4.0]))))
+    ops.append(("update", 6))
+    total = sum(op[1] for op in ops if op[0] == "update")
+    x = synth_iq(nch, total * 128)[..., 0].copy()
+    x[2] = rng.integers(-32768, 32768, size=x.shape[1]).astype(np.int16)
+    bq = FilterBiquad(nch, fs=fs)
+    ors = [OrcBiquad() for _ in range(nch)]
+    for o in ors:
+        lib.orc_biquad_init(C.byref(o), 0, None)
+    dev = torch.from_numpy(x).cuda()
+    setters = [bq.setLowpass, bq.setHighpass, bq.setBandpass, bq.setNotch]
+    pos = 0
+    for op in ops:
+        if op[0] == "update":
+            n = op[1] * 128
+            got = bq.update(dev[:, pos:pos + n].contiguous()).cpu().numpy()
+            for c in range(nch):
+                y = x[c, pos:pos + n].astype(np.float32) / np.float32(32768.0)
+                lib.orc_biquad_run(C.byref(ors[c]), y.ctypes.data_as(F32P), n)
+                r16 = np.zeros(n, np.int16)
+                lib.orc_float_to_q15(y.ctypes.data_as(F32P), r16.ctypes.data_as(I16P), n)
+                assert np.array_equal(got[c], r16), (seed, op, c)
+            pos += n
+        else:
+            _, stage, kind, f, q = op
+            setters[kind](stage, f, q)
+            c5 = np.zeros(5, np.float32)
+            lib.orc_biquad_design(kind, f, q, fs, c5.ctypes.data_as(F32P))
+            for o in ors:
+                lib.orc_biquad_set_stage(C.byref(o), stage, c5.ctypes.data_as(F32P))
+
+
+@pytest.mark.gpu
 def test_iqinput_biquad_fft_wiring_of_the_sketch(rdsp, oracle):
     """INO:75-78: IQinput -> biquad1 / biquad2 (high-pass 500 Hz) -> FFT (AudioAnalyzeFFT256IQ):
     the panadapter path as graph nodes, against the oracle's biquad + analyser restatements."""
