@@ -102,6 +102,10 @@ struct rdsp_chain {
    * stage of call k+1 never waits for the tail stage of call k-1) */
   int pipe_on = 0;
   hipStream_t s_tail = nullptr;
+  /* the serial per-channel stages between front and tail stage (SAM PLL, IIR cascade) run on a stream
+   * of their own when pipelined: three stages in flight, the tail stage waits for ev_mid */
+  hipStream_t s_mid = nullptr;
+  hipEvent_t ev_mid[3] = {nullptr, nullptr, nullptr};
   /* three intermediate buffers: the front stage may run two calls ahead of the tail stage, so
    * neither stream waits on the other in steady state (with two, every call paid two
    * cross-stream event waits, ~0.1 ms of a 2 ms step) */
@@ -441,6 +445,11 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   }
   for (auto &g : c->groups) group_free(g);
   if (c->s_tail) {
+    if (c->s_mid) {
+      (void)hipStreamSynchronize(c->s_mid);
+      (void)hipStreamDestroy(c->s_mid);
+      for (int i = 0; i < 3; i++) (void)hipEventDestroy(c->ev_mid[i]);
+    }
     (void)hipStreamSynchronize(c->s_tail);
     (void)hipStreamDestroy(c->s_tail);
     for (int i = 0; i < 3; i++) { (void)hipEventDestroy(c->ev_front[i]); (void)hipEventDestroy(c->ev_tail[i]); }
@@ -652,6 +661,8 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   const bool piped = tail && c->pipe_on;
   const int slot = (int)(c->call_idx % 3);
   hipStream_t tstream = piped ? c->s_tail : stream;
+  const bool mid_stage = sam || iir;
+  hipStream_t mstream = (piped && mid_stage) ? c->s_mid : tstream; /* SAM PLL / IIR cascade */
   /* full-register front kernel in both modes: since its butterflies shrank to 199 VGPRs two of
    * its waves and a tail wave fit one SIMD, and the lean variant's twiddle chains only cost */
   fp.lean = (c->lean_mode < 0) ? 0 : c->lean_mode;
@@ -720,7 +731,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   }
   if (piped && nsb == 1) {
     HIP_TRY(hipEventRecord(c->ev_front[slot], stream));
-    HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front[slot], 0));
+    HIP_TRY(hipStreamWaitEvent(mid_stage ? c->s_mid : c->s_tail, c->ev_front[slot], 0));
   }
   if (sam) {
     RdspSamParams sp;
@@ -734,7 +745,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     sp.group_of = c->d_group_of;
     rdsp_sam_constants(cf.fs_in / (double)c->decim, &sp.g1, &sp.g2, &sp.wmin, &sp.wmax);
     sp.st_sam = c->d_sam;
-    int es = rdsp_launch_sam(&sp, tstream);
+    int es = rdsp_launch_sam(&sp, mstream);
     if (es != 0) {
       rdsp_set_error("SAM kernel launch failed: %s", hipGetErrorString((hipError_t)es));
       return RDSP_ERR_HIP;
@@ -744,7 +755,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     for (size_t gi = 0; gi < c->groups.size(); gi++) {
       GroupState &g = c->groups[gi];
       if (!g.iir_dirty) continue;
-      int eb = rdsp_launch_biquad_coef_store(c->d_iir_coef + 20 * gi, g.iir, tstream);
+      int eb = rdsp_launch_biquad_coef_store(c->d_iir_coef + 20 * gi, g.iir, mstream);
       if (eb != 0) {
         rdsp_set_error("IIR coefficient store failed: %s", hipGetErrorString((hipError_t)eb));
         return RDSP_ERR_HIP;
@@ -761,12 +772,16 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     bp.set_of = c->d_group_of;
     bp.state = c->d_iir_state;
     if (nsb > 1) /* sub-batched fronts: the cascade covers all channels, after the last of them */
-      for (int k = 0; k < nsb; k++) HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_front_sb[slot][k], 0));
-    int eb = rdsp_launch_biquad(&bp, tstream);
+      for (int k = 0; k < nsb; k++) HIP_TRY(hipStreamWaitEvent(mstream, c->ev_front_sb[slot][k], 0));
+    int eb = rdsp_launch_biquad(&bp, mstream);
     if (eb != 0) {
       rdsp_set_error("biquad kernel launch failed: %s", hipGetErrorString((hipError_t)eb));
       return RDSP_ERR_HIP;
     }
+  }
+  if (piped && mid_stage) { /* the tail stage of this call follows its PLL / cascade */
+    HIP_TRY(hipEventRecord(c->ev_mid[slot], c->s_mid));
+    HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_mid[slot], 0));
   }
   if (tail) {
     RdspTailParams tp;
@@ -1156,6 +1171,8 @@ extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
   if (on && !c->s_tail) {
     HIP_TRY(hipStreamCreateWithFlags(&c->s_tail, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_mid, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_mid[i], hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
       HIP_TRY(hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming));
