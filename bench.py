@@ -423,7 +423,9 @@ def main():
                             + {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
                                "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
                                "K4": "NCO mix + 256-tap polyphase /4 + 4096-pt overlap-save CW filter (2049 taps) + AGC",
-                               "K5": "K3 chain, 8192 channels/GPU"}[args.config],
+                               "K5": "K3 chain, 8192 channels/GPU"}[args.config]
+                            + (f" + audio filter {os.environ['RDSP_AUDIO_IIR']} as the 8th-order IIR bank (non-default option)"
+                               if os.environ.get("RDSP_AUDIO_IIR") else ""),
                 "channels_per_gpu": nch,
                 "blocks_per_step": nblk,
                 "sharding": f"channels x{world}, no collectives",

@@ -16,6 +16,12 @@ for K in $CFGS; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$K -o trace -- python3 $ROOT/bench.py --config $K $B > $OUT/prof_$K.json 2> $OUT/prof_$K.err) || { echo "rocprof $K failed"; tail -5 $OUT/prof_$K.err; }
   echo "trace $K done"
 done
+# the optional stages of row F3 at the K3 shape: SAM groups (tests/micro/f3_bench.py) and the IIR filter bank
+if [[ " $CFGS " == *" K3 "* ]]; then
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_F3SAM -o trace -- python3 $ROOT/tests/micro/f3_bench.py > $OUT/prof_F3SAM.log 2> $OUT/prof_F3SAM.err) || { echo "rocprof F3SAM failed"; tail -5 $OUT/prof_F3SAM.err; }
+  (cd /tmp && RDSP_AUDIO_IIR=2 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_K3IIR -o trace -- python3 $ROOT/bench.py --config K3 $B > $OUT/prof_K3IIR.json 2> $OUT/prof_K3IIR.err) || { echo "rocprof K3IIR failed"; tail -5 $OUT/prof_K3IIR.err; }
+  echo "trace F3 stages done"
+fi
 # PMC: one counter family per pass (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel trace only
 for K in $CFGS; do
   for C in FETCH_SIZE WRITE_SIZE; do

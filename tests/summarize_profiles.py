@@ -65,6 +65,16 @@ def main():
             lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
             if lines:
                 open(os.path.join(PROF, f"{rnd}_{cfg.lower()}_bench.json"), "w").write(lines[-1] + "\n")
+    for tag, name in (("F3SAM", "f3_sam"), ("K3IIR", "k3_iir")):   # optional stages of row F3 at the K3 shape
+        stats = newest(os.path.join(OUT, f"prof_{tag}", "**", "*kernel_stats.csv"))
+        if stats:
+            shutil.copy(stats, os.path.join(PROF, f"{rnd}_{name}_kernel_stats.csv"))
+        for ext in ("log", "json"):
+            f = os.path.join(OUT, f"prof_{tag}.{ext}")
+            if os.path.exists(f):
+                lines = [l for l in open(f).read().splitlines() if l.startswith("{") or l.startswith("K3 ")]
+                if lines:
+                    open(os.path.join(PROF, f"{rnd}_{name}_bench.{'json' if ext == 'json' else 'txt'}"), "w").write("\n".join(lines[-5:] if ext == "log" else lines[-1:]) + "\n")
     cpath = os.path.join(PROF, "counters.json")
     counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
     for cfg in ("K2", "K3", "K4", "K5", "F1"):
