@@ -24,6 +24,12 @@ GOLDEN_CASES["sam_agc_512"] = dict(channels=2, blocks=48,
                                             nco_hz=12950.0, agc_mode="slow"))   # the 13 kHz carrier sits 50 Hz off tune
 GOLDEN_CASES["blanker_swap_256"] = dict(channels=2, blocks=32, cfg=K1, impulses=True,
                                         setup=dict(noise_blanker_db=8.0, swap_iq=True))
+# the older spectral-NR variant of the A6 row (BK_INO:1586-1630) and a non-default design window
+# (CONV:159-179, id 3) on the negative side band with the 1024-point filter
+GOLDEN_CASES["spectral_old_256"] = dict(channels=2, blocks=32,
+                                        cfg=dict(fft_l=256, demod="USB", spectral_nr=2, agc_mode="fast", output_gain=0.5))
+GOLDEN_CASES["window3_lsb_1024"] = dict(channels=2, blocks=64,
+                                        cfg=dict(fft_l=1024, demod="LSB", flo_hz=-2700.0, fhi_hz=-300.0, window=3))
 
 
 def add_impulses(iq, every=1777, burst=3):

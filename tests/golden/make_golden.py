@@ -21,8 +21,73 @@ from cases import GOLDEN_CASES, add_impulses, apply_setup  # noqa: E402
 from radiodsp_sdr_rx_amd.chain import synth_iq  # noqa: E402
 
 
+def make_nodes():
+    """graph nodes beside the chain (integer analysers, int16 biquad): nodes.npz holds one input and what
+    the oracle's restatements give for it -- the panadapter analyser (naverage 5, Hann), the audio
+    analyser on the I side (Hann) and `setHighpass(0, 500, 0.5)` + a notch on the I side"""
+    import ctypes as C
+    lib = oracle_lib.load()
+    I16P, F32P = C.POINTER(C.c_int16), C.POINTER(C.c_float)
+    nch, nblk = 2, 40
+    iq = synth_iq(nch, nblk * 128)
+    iq[1] = np.clip(iq[1].astype(np.int32) * 4, -32768, 32767).astype(np.int16)
+    lib.orc_fft256iq_create.restype = C.c_void_p
+    lib.orc_fft256iq_create.argtypes = [C.c_int, C.c_int]
+    lib.orc_fft256iq_update.argtypes = [C.c_void_p, I16P, I16P]
+    lib.orc_fft256iq_output.restype = C.POINTER(C.c_uint16)
+    lib.orc_fft256iq_output.argtypes = [C.c_void_p]
+    lib.orc_fft256iq_destroy.argtypes = [C.c_void_p]
+    lib.orc_fft1024_create.restype = C.c_void_p
+    lib.orc_fft1024_create.argtypes = [C.c_int]
+    lib.orc_fft1024_update.argtypes = [C.c_void_p, I16P]
+    lib.orc_fft1024_output.restype = C.POINTER(C.c_uint16)
+    lib.orc_fft1024_output.argtypes = [C.c_void_p]
+    lib.orc_fft1024_destroy.argtypes = [C.c_void_p]
+    lib.orc_biquad_design.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, F32P]
+    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
+
+    class OrcBiquad(C.Structure):
+        _fields_ = [("n_stages", C.c_int), ("coef", C.c_float * 20), ("state", C.c_float * 16)]
+    lib.orc_biquad_init.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_biquad_run.argtypes = [C.POINTER(OrcBiquad), F32P, C.c_int]
+    lib.orc_biquad_set_stage.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    spec256, spec1024, bq = [], [], []
+    for c in range(nch):
+        i = np.ascontiguousarray(iq[c, :, 0])
+        q = np.ascontiguousarray(iq[c, :, 1])
+        s = lib.orc_fft256iq_create(5, 1)
+        outs = []
+        for b in range(nblk):
+            if lib.orc_fft256iq_update(s, i[b * 128:].ctypes.data_as(I16P), q[b * 128:].ctypes.data_as(I16P)):
+                outs.append(np.ctypeslib.as_array(lib.orc_fft256iq_output(s), (256,)).copy())
+        lib.orc_fft256iq_destroy(s)
+        spec256.append(np.stack(outs))
+        s = lib.orc_fft1024_create(1)
+        outs = []
+        for b in range(nblk):
+            if lib.orc_fft1024_update(s, i[b * 128:].ctypes.data_as(I16P)):
+                outs.append(np.ctypeslib.as_array(lib.orc_fft1024_output(s), (512,)).copy())
+        lib.orc_fft1024_destroy(s)
+        spec1024.append(np.stack(outs))
+        o = OrcBiquad()
+        lib.orc_biquad_init(C.byref(o), 0, None)
+        for stage, (kind, f, qq) in ((0, (1, 500.0, 0.5)), (2, (3, 1000.0, 4.0))):
+            c5 = np.zeros(5, np.float32)
+            lib.orc_biquad_design(kind, f, qq, 44117.64706, c5.ctypes.data_as(F32P))
+            lib.orc_biquad_set_stage(C.byref(o), stage, c5.ctypes.data_as(F32P))
+        y = i.astype(np.float32) / np.float32(32768.0)
+        lib.orc_biquad_run(C.byref(o), y.ctypes.data_as(F32P), len(y))
+        r16 = np.zeros(len(y), np.int16)
+        lib.orc_float_to_q15(y.ctypes.data_as(F32P), r16.ctypes.data_as(I16P), len(y))
+        bq.append(r16)
+    np.savez_compressed(os.path.join(HERE, "nodes.npz"), iq=iq, spectrum256=np.stack(spec256),
+                        fft1024=np.stack(spec1024), biquad=np.stack(bq))
+    print("nodes", iq.shape, np.stack(spec256).shape, np.stack(spec1024).shape)
+
+
 def main():
     oracle_lib.build()
+    make_nodes()
     for name, case in GOLDEN_CASES.items():
         iq = synth_iq(case["channels"], case["blocks"] * 128, cw=case.get("cw", False))
         if case.get("impulses"):

@@ -431,3 +431,55 @@ def test_argument_errors_are_loud(rdsp):
         with pytest.raises(RdspError) as e:
             ch.set_fir_variant(1)                       # matrix-core FIR: EXPERIMENTAL builds only
         assert e.value.code == -5
+
+
+# ---- committed fixture of the graph nodes (tests/golden/nodes.npz, made by make_golden.py) --------
+def _nodes_fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nodes.npz"))
+
+
+def test_oracle_reproduces_the_node_fixture(oracle):
+    """pins the integer analysers and the biquad cascade of the oracle against accidental change"""
+    from test_spectrum import _olib, oracle_spectra
+    lib = _bind(_olib(oracle))
+    lib.orc_biquad_set_stage.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_biquad_init.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_biquad_run.argtypes = [C.POINTER(OrcBiquad), F32P, C.c_int]
+    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
+    g = _nodes_fixture()
+    iq = g["iq"]
+    for c in range(iq.shape[0]):
+        assert np.array_equal(np.stack(oracle_spectra(lib, iq[c], 5, 1)), g["spectrum256"][c])
+        assert np.array_equal(oracle_fft1024(lib, np.ascontiguousarray(iq[c, :, 0]), 1), g["fft1024"][c])
+        o = OrcBiquad()
+        lib.orc_biquad_init(C.byref(o), 0, None)
+        for stage, (kind, f, q) in ((0, (1, 500.0, 0.5)), (2, (3, 1000.0, 4.0))):
+            c5 = np.zeros(5, np.float32)
+            lib.orc_biquad_design(kind, f, q, 44117.64706, c5.ctypes.data_as(F32P))
+            lib.orc_biquad_set_stage(C.byref(o), stage, c5.ctypes.data_as(F32P))
+        y = iq[c, :, 0].astype(np.float32) / np.float32(32768.0)
+        lib.orc_biquad_run(C.byref(o), y.ctypes.data_as(F32P), len(y))
+        r16 = np.zeros(len(y), np.int16)
+        lib.orc_float_to_q15(y.ctypes.data_as(F32P), r16.ctypes.data_as(I16P), len(y))
+        assert np.array_equal(r16, g["biquad"][c])
+
+
+@pytest.mark.gpu
+def test_gpu_nodes_match_the_fixture(rdsp):
+    """the three node kernels against the committed outputs, bit for bit (no oracle at run time)"""
+    import torch
+    from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024, FilterBiquad
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    g = _nodes_fixture()
+    iq = g["iq"]
+    nch = iq.shape[0]
+    dev = torch.from_numpy(iq).cuda()
+    s256 = AnalyzeFFT256IQ(nch, naverage=5, window="AudioWindowHanning256").update(dev).cpu().numpy().view(np.uint16)
+    assert np.array_equal(s256, g["spectrum256"])
+    s1024 = AnalyzeFFT1024(nch, window="AudioWindowHanning1024").update(dev[..., 0]).cpu().numpy().view(np.uint16)
+    assert np.array_equal(s1024, g["fft1024"])
+    bq = FilterBiquad(nch, fs=44117.64706)
+    bq.setHighpass(0, 500, 0.5)
+    bq.setNotch(2, 1000, 4.0)
+    assert np.array_equal(bq.update(dev[..., 0]).cpu().numpy(), g["biquad"])
