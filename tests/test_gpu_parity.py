@@ -668,10 +668,10 @@ def test_long_stream_many_calls_stays_on_the_oracle(rdsp, oracle, torch_cuda):
     got = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
     _, r32 = oracle_run(oracle, iq, cfg)
     per_call = np.abs(got - r32).max(axis=2).reshape(nch, calls, -1).max(axis=2) / np.abs(r32).max()
-    assert (per_call > TOL).mean() < 0.03 and per_call.max() < 5e-3  # stray spectral-threshold flips only
+    assert per_call.max() <= TOL   # measured 5.3e-7: no bin lands on the other side of the spectral threshold
     sc = ch.scalars()
     for c in range(nch):
         oc = oracle.OracleChain(**cfg)
         oc.process(iq[c])
-        assert abs(sc[c, 0] - oc.nfloor()) <= 5e-6 * oc.nfloor()
-        assert abs(sc[c, 1] - oc.agc_gain()) <= 1e-4 * oc.agc_gain()
+        assert abs(sc[c, 0] - oc.nfloor()) <= 2e-6 * oc.nfloor()       # measured <= 3.7e-7
+        assert abs(sc[c, 1] - oc.agc_gain()) <= 2e-6 * oc.agc_gain()   # measured <= 7.3e-8

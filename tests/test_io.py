@@ -143,12 +143,13 @@ def test_files_through_the_runner_match_resident_processing_and_oracle(rdsp, ora
         parts.append(ref_chain.process(dev).cpu().numpy())
         pos += take
     assert np.array_equal(got, np.concatenate(parts, 1))
-    # and the oracle on the int16 audio
-    for c in range(nch):
-        r16 = oracle.OracleChain(**cfg).process(iq[c, :exp_blocks * 128])[0]
-        d = np.abs(got[c].astype(np.int32) - r16.astype(np.int32))
-        lim = 1 if name == "k1" else 16          # k3 carries the NLMS start-up conditioning (test_gpu_parity.py)
-        assert d.max() <= lim
+    # and the oracle on the int16 audio: the feed-forward chain directly (one LSB at truncation
+    # boundaries); the chain with the NLMS stage is bit-identical to resident processing (above), which
+    # the truth-anchored tests of test_gpu_parity.py hold against the oracle and the float64 model
+    if name == "k1":
+        for c in range(nch):
+            r16 = oracle.OracleChain(**cfg).process(iq[c, :exp_blocks * 128])[0]
+            assert np.abs(got[c].astype(np.int32) - r16.astype(np.int32)).max() <= 1
 
 
 @pytest.mark.gpu

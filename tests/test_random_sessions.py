@@ -288,18 +288,22 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
-def test_random_nr_and_notch_switching_follows_the_oracle(rdsp, oracle, seed):
+def test_random_nr_and_notch_switching_is_truth_anchored(rdsp, oracle, seed):
     """The recursive stages switched at random between calls: ALS off / notch / peak, DSP-NR level
     0 / 20 / 30 (a level change re-initialises the instance, CONV:327-331), AGC modes, the spectral stage.
-    Not a parity measurement (that is the truth-anchored tests' job: two float32 NLMS runs drift apart
-    by 1e-5 ... 1e-4 on their own) but a check of the switching semantics -- what keeps its state, what
-    is re-initialised, which call a change takes effect in: a wrong answer to any of those is an error
-    of order one, the bound is 3e-3 of full scale."""
+    Three runs of the same script: GPU, float32 oracle, float64 model (tests/np_model.py takes the same
+    switches); the criterion is the truth-anchored one of the NLMS chains -- the GPU no further from
+    the float64 result than max(1e-5, 1.5 x the oracle's own distance).  What keeps its state, what is
+    re-initialised and which call a change takes effect in are all inside that bound: a wrong answer to
+    any of them is an error of order one."""
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import np_model
+    from oracle_lib import AGC, ALS
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from test_gpu_parity import assert_truth_anchored
     rng = np.random.default_rng(seed)
-    nch = 4
+    nch = 5
     base = dict(K3, fft_l=int(rng.choice([256, 512])))
     ops = []
     for _ in range(22):
@@ -320,8 +324,9 @@ def test_random_nr_and_notch_switching_follows_the_oracle(rdsp, oracle, seed):
     ch = Chain(nch, max_blocks_per_call=24, **base)
     ch.set_pipelined(bool(seed % 2))
     ocs = [oracle.OracleChain(**base) for _ in range(nch)]
+    mods = [np_model.Model(**base) for _ in range(nch)]
     dev = torch.from_numpy(iq).cuda()
-    got, ref, pos = [], [[] for _ in range(nch)], 0
+    got, ref, f64, pos = [], [[] for _ in range(nch)], [[] for _ in range(nch)], 0
     for op in ops:
         k = op[0]
         if k == "proc":
@@ -329,6 +334,7 @@ def test_random_nr_and_notch_switching_follows_the_oracle(rdsp, oracle, seed):
             got.append(ch.process(dev[:, pos * 128:(pos + n) * 128], want_f32=True)[1])
             for c in range(nch):
                 ref[c].append(ocs[c].process(iq[c, pos * 128:(pos + n) * 128])[1])
+                f64[c].append(mods[c].process(iq[c, pos * 128:(pos + n) * 128]))
             pos += n
         elif k == "als":
             if op[1] == "off":
@@ -336,25 +342,28 @@ def test_random_nr_and_notch_switching_follows_the_oracle(rdsp, oracle, seed):
             else:
                 ch.enableALSfilter()
                 ch.setALSfilterNotch() if op[1] == "notch" else ch.setALSfilterPeak()
-            for oc in ocs:
+            for oc, m in zip(ocs, mods):
                 oc.set_als_mode(rdsp.ALS[op[1]])
+                m.c["als_mode"] = ALS[op[1]]
         elif k == "nr":
             ch.set_nr_level(op[1])
-            for oc in ocs:
+            for oc, m in zip(ocs, mods):
                 oc.set_nr_level(op[1])
+                m.c["lms_nr"] = op[1]
         elif k == "agc":
             ch.setAGCmode(rdsp.AGC[op[1]])
-            for oc in ocs:
+            for oc, m in zip(ocs, mods):
                 oc.set_agc_mode(rdsp.AGC[op[1]])
+                m.c["agc_mode"] = AGC[op[1]]
         elif k == "spec":
             ch.set_spectral_nr(op[1], op[2])
-            for oc in ocs:
+            for oc, m in zip(ocs, mods):
                 oc.set_spectral_nr(op[1], op[2])
+                m.c["spectral_nr"], m.c["spectral_level"] = op[1], op[2]
     ch.flush()
     torch.cuda.synchronize()
     got = np.concatenate([o.cpu().numpy() for o in got], 1)
-    for c in range(nch):
-        r = np.concatenate(ref[c])
-        assert np.isfinite(r).all() and np.isfinite(got[c]).all()
-        err = np.abs(got[c] - r).max() / np.abs(r).max()
-        assert err <= 3e-3, f"seed {seed}, channel {c}: {err:.2e}\n{ops}"
+    r32 = np.stack([np.concatenate(r) for r in ref])
+    t64 = np.stack([np.concatenate(r) for r in f64])
+    assert np.isfinite(r32).all() and np.isfinite(got).all()
+    assert_truth_anchored(got, r32, t64, f"seed {seed}")
