@@ -668,11 +668,8 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.lean = (c->lean_mode < 0) ? 0 : c->lean_mode;
   fp.front_prio = piped ? c->front_fir_prio : 0;
   fp.fir_matrix = (c->fir_mode == 3) ? (piped ? 0 : 1) : (c->fir_mode == 1);
-  /* frequency-domain decimator; the noise blanker needs a channel's quad columns in stream order,
-   * which the four-wave kernels (fft_l >= 2048: four frames side by side) do not give: a chain of
-   * that size with the blanker on keeps the direct form */
-  const bool one_wave = c->N / rdsp_plan_radix(c->N) == 64;
-  fp.fir_fd = ((c->fir_mode == 2 || c->fir_mode == -1) && c->d_fd_mask && (!c->nb_on || one_wave)) ? 1 : 0;
+  /* frequency-domain decimator (default); the direct form stays selectable (fir_variant 0) */
+  fp.fir_fd = ((c->fir_mode == 2 || c->fir_mode == -1) && c->d_fd_mask) ? 1 : 0;
   fp.fd_mask = c->d_fd_mask;
   c->front_name = fp.fir_fd ? "rdsp_front_fd_kernel" : "rdsp_front_kernel";
   fp.mid_q = c->d_mid_q[0];

@@ -639,10 +639,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   float *red = reinterpret_cast<float *>(wb + (PL::WB > NW * PLD::WB ? PL::WB : NW * PLD::WB));
 
   const bool SWAP_IQ = PRE && p.swap_iq != 0;
-  /* the noise blanker needs the quad columns in stream order: one-wave kernels only (with four
-   * waves per channel the frames of a round run side by side; the launch code keeps the direct
-   * form for such chains) */
-  const bool NB_ON = PRE && (N / P == 64) && p.nb_on != 0;
+  /* the noise blanker takes the quad columns in stream order.  With four waves per channel the
+   * frames of a round run side by side, so the blanker's pre-pass goes round the waves in frame
+   * order before the transforms start: its state (level, per-lane window sums) and every frame's
+   * last column as blanked (the next frame's column 0) are handed on through LDS */
+  const bool NB_ON = PRE && p.nb_on != 0;
+  uint4 *nbcol = reinterpret_cast<uint4 *>(red + 64);   /* [NW][64] (four-wave kernels only) */
+  float *nbacc = reinterpret_cast<float *>(nbcol + NW * 64); /* [64] per-lane sums of the open window */
+  float *nbs = nbacc + 64;                              /* [0]: level */
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   float2 *wbd = wb + wave * PLD::WB; /* this wave's decimator work buffer (inside the filter's) */
@@ -700,6 +704,13 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   int frame_idx = 0;
   int produced = 0, consumed = 0;
   auto sync = []() { __syncthreads(); };
+  if constexpr (NW > 1) {
+    if (NB_ON) {
+      if (tid < 64) nbacc[tid] = 0.f;
+      if (tid == 0) nbs[0] = nb_level;
+      __syncthreads();
+    }
+  }
 
 #pragma unroll 1
   for (int round = 0; produced < total; round++) {
@@ -710,28 +721,50 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
        * sample whose power exceeds the reference level x threshold is zeroed in the raw word, so it
        * stays blanked in the next frame's column 0 and in the FIR history; the level moves at the
        * end of every window from the mean post-blanking power (one wave reduction) */
+      auto blank_frame = [&]() {
 #pragma unroll
-      for (int j = 1; j < PD; j++) {
-        const int c = (PD - 1) * fr + (j - 1); /* column of the call */
-        if (64 * c < total) {
-          const float thr = nb_level * p.nb_thr;
-          uint32_t w[4] = {rq[j].x, rq[j].y, rq[j].z, rq[j].w};
+        for (int j = 1; j < PD; j++) {
+          const int c = (PD - 1) * fr + (j - 1); /* column of the call */
+          if (64 * c < total) {
+            const float thr = nb_level * p.nb_thr;
+            uint32_t w[4] = {rq[j].x, rq[j].y, rq[j].z, rq[j].w};
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const uint32_t ww = SWAP_IQ ? __builtin_amdgcn_alignbit(w[r], w[r], 16) : w[r];
-            const float2 x = unpack_iq(ww, p.scale_i, p.scale_q);
-            const float pw = x.x * x.x + x.y * x.y;
-            const bool blanked = nb_level > 0.f && pw > thr;
-            w[r] = blanked ? 0u : w[r];
-            nb_acc += blanked ? 0.f : pw;
+            for (int r = 0; r < 4; r++) {
+              const uint32_t ww = SWAP_IQ ? __builtin_amdgcn_alignbit(w[r], w[r], 16) : w[r];
+              const float2 x = unpack_iq(ww, p.scale_i, p.scale_q);
+              const float pw = x.x * x.x + x.y * x.y;
+              const bool blanked = nb_level > 0.f && pw > thr;
+              w[r] = blanked ? 0u : w[r];
+              nb_acc += blanked ? 0.f : pw;
+            }
+            rq[j] = make_uint4(w[0], w[1], w[2], w[3]);
+            if ((c & 3) == 3) {
+              const float mean = wave_sum(nb_acc) / 1024.0f;
+              nb_level = (nb_level > 0.f) ? nb_level + 0.2f * (mean - nb_level) : mean;
+              nb_acc = 0.f;
+            }
+            if (64 * (c + 1) == total) {
+              if constexpr (NW == 1) hist_save = rq[j];
+              else *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * lane) = rq[j]; /* the call's last 64 quads */
+            }
           }
-          rq[j] = make_uint4(w[0], w[1], w[2], w[3]);
-          if ((c & 3) == 3) {
-            const float mean = wave_sum(nb_acc) / 1024.0f;
-            nb_level = (nb_level > 0.f) ? nb_level + 0.2f * (mean - nb_level) : mean;
-            nb_acc = 0.f;
+        }
+      };
+      if constexpr (NW == 1) {
+        blank_frame();
+      } else {
+#pragma unroll 1
+        for (int w = 0; w < NW; w++) {
+          if (wave == w) {
+            nb_level = nbs[0];
+            nb_acc = nbacc[lane];
+            if (fr > 0) rq[0] = nbcol[(w + NW - 1) % NW * 64 + lane]; /* the frame before, as blanked */
+            blank_frame();
+            nbcol[w * 64 + lane] = rq[PD - 1];
+            nbacc[lane] = nb_acc;
+            if (lane == 0) nbs[0] = nb_level;
           }
-          if (64 * (c + 1) == total) hist_save = rq[j];
+          __syncthreads();
         }
       }
     }
@@ -840,14 +873,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
 #pragma unroll
   for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
-  if (tid < 64)
+  if (tid < 64 && !(NB_ON && NW > 1)) /* four waves with the blanker: stored by the wave that blanked them */
     *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
         NB_ON ? hist_save : *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
   if (tid == 0) {
     p.st_scal[ch * 4 + 0] = nfloor;
     if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
     p.st_scal[ch * 4 + 2] = am_dc;
-    if (NB_ON) p.st_scal[ch * 4 + 3] = nb_level;
+    if (NB_ON) p.st_scal[ch * 4 + 3] = (NW > 1) ? nbs[0] : nb_level;
   }
 }
 
@@ -856,7 +889,9 @@ constexpr size_t front_fd_lds() {
   constexpr int nw = N / P / 64;
   constexpr int wbd = nw * FftPlan<RDSP_FD_N, RDSP_FD_P>::WB;
   constexpr int wbn = FftPlan<N, P>::WB > wbd ? FftPlan<N, P>::WB : wbd;
-  return (size_t)((nw == 1 ? 1024 : 4096) + wbn) * sizeof(float2) + 64 * sizeof(float);
+  /* + the blanker's hand-over area of the four-wave kernels: [nw][64] quads, 64 sums, the level */
+  return (size_t)((nw == 1 ? 1024 : 4096) + wbn) * sizeof(float2) + 64 * sizeof(float) +
+         (nw > 1 ? (size_t)nw * 64 * sizeof(uint4) + 64 * sizeof(float) + 16 : 0);
 }
 
 /* one group record, rewritten in stream order (32 threads, one dword each) */

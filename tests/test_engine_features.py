@@ -46,13 +46,16 @@ def test_swap_iq_matches_oracle_and_is_a_pure_relabelling(rdsp, oracle, torch_cu
     assert np.array_equal(got16.cpu().numpy(), plain.cpu().numpy())
 
 
-@pytest.mark.parametrize("name,cfg", [("k1", K1), ("k3_front", dict(K3, als_mode="off")), ("literal", None)])
+@pytest.mark.parametrize("name,cfg", [("k1", K1), ("k3_front", dict(K3, als_mode="off")), ("literal", None),
+                                      # four waves per channel: the blanker's pre-pass goes round the waves in frame order
+                                      ("usb_2048", dict(fft_l=2048, demod="USB", agc_mode="medium", output_gain=0.5)),
+                                      ("k4_4096", "K4")])
 def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, name, cfg):
     torch = torch_cuda
-    from cases import CONV_LITERAL
+    from cases import CONV_LITERAL, K4
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
-    cfg = CONV_LITERAL if cfg is None else cfg
-    nch, nblk = 4, 64
+    cfg = CONV_LITERAL if cfg is None else (K4 if cfg == "K4" else cfg)
+    nch, nblk = 4, (128 if cfg.get("fft_l", 256) >= 2048 else 64)
     clean = synth_iq(nch, nblk * 128)
     iq = _impulses(clean)
     ch = Chain(nch, max_blocks_per_call=nblk, **cfg)
@@ -60,6 +63,8 @@ def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, name, cfg):
     ch.setNoiseBlankerThresholdDb(8.0)
     dev = torch.from_numpy(iq).cuda()
     got = ch.process(dev, want_f32=True)[1].cpu().numpy()
+    if cfg.get("decim", 4) == 4:      # the default decimator, whatever FFT_L: no fall-back to the direct form
+        assert ch.front_kernel_name() == "rdsp_front_fd_kernel"
     levels = ch.scalars()[:, 3]
     off = Chain(nch, max_blocks_per_call=nblk, **cfg).process(dev, want_f32=True)[1].cpu().numpy()
     ref_clean = Chain(nch, max_blocks_per_call=nblk, **cfg).process(torch.from_numpy(clean).cuda(), want_f32=True)[1].cpu().numpy()
@@ -111,6 +116,45 @@ def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, tor
     fd = run(calls, False, False, fir=-1)
     assert np.array_equal(fd, run(calls, True, False, fir=-1))
     assert np.abs(fd.astype(np.int32) - one.astype(np.int32)).max() <= 64 and (fd != one).mean() < 0.3
+
+
+def test_noise_blanker_four_wave_kernels_split_and_pipelined(rdsp, oracle, torch_cuda):
+    """FFT_L 2048 (four waves per channel): bursts at call boundaries and inside the column a frame
+    shares with the next one; the same split pipelined or not gives the same bits, a blanked sample
+    stays blanked as FIR history, and every call follows the oracle."""
+    torch = torch_cuda
+    from cases import TOL
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg = dict(fft_l=2048, demod="LSB", flo_hz=-2700.0, fhi_hz=-300.0, agc_mode="fast", output_gain=0.5)
+    nch, per, calls = 3, 32, 4
+    iq = _impulses(synth_iq(nch, per * calls * 128), per_channel=60)
+    for k in range(1, calls):
+        iq[:, k * per * 128 - 2:k * per * 128 + 1] = 30000
+    for f in range(1, 6):            # the shared column of consecutive decimator frames (1792-sample hop)
+        iq[:, f * 1792 - 100:f * 1792 - 97] = -30000
+
+    def run(pipelined):
+        ch = Chain(nch, max_blocks_per_call=per, **cfg)
+        ch.enableNoiseBlanker()
+        ch.setNoiseBlankerThresholdDb(8.0)
+        ch.set_pipelined(pipelined)
+        outs = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * per * 128:(k + 1) * per * 128])).cuda(),
+                           want_f32=True)[1] for k in range(calls)]
+        ch.flush()
+        torch.cuda.synchronize()
+        assert ch.front_kernel_name() == "rdsp_front_fd_kernel"
+        return np.concatenate([o.cpu().numpy() for o in outs], 1), ch.scalars()
+
+    a, sa = run(False)
+    b, sb = run(True)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    for c in range(nch):
+        oc = oracle.OracleChain(**cfg)
+        oc.set_noise_blanker(True, 8.0)
+        ref = np.concatenate([oc.process(iq[c, k * per * 128:(k + 1) * per * 128])[1] for k in range(calls)])
+        err = np.abs(a[c] - ref).max() / np.abs(ref).max()
+        assert err <= TOL, f"channel {c}: {err:.2e}"
+        assert abs(sa[c, 3] - oc.nb_level()) <= 1e-5 * oc.nb_level()
 
 
 # ---- SAM: PLL synchronous detector (CTL:384-391; build-defined arithmetic) ---------------
