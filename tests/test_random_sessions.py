@@ -20,14 +20,14 @@ pytestmark = pytest.mark.gpu
 NCH, MAXBLK, NGROUPS = 150, 32, 3
 
 
-def make_script(rng, n_ops=40):
+def make_script(rng, n_ops=40, granule=8):
     ops = []
     for _ in range(n_ops):
         kind = rng.choice(["proc", "proc", "proc", "als", "nr", "spec", "agc", "gdemod", "gfilt", "gpbt", "goff", "gaf",
                            "nb", "swap", "mute", "ogain", "igain", "bal", "afk"])
         g = int(rng.integers(0, NGROUPS))
         if kind == "proc":
-            ops.append(("proc", int(rng.choice([8, 16, 24, 32]))))
+            ops.append(("proc", granule * int(rng.integers(1, 32 // granule + 1))))
         elif kind == "als":
             ops.append(("als", str(rng.choice(["off", "notch", "peak"]))))
         elif kind == "nr":
@@ -61,14 +61,14 @@ def make_script(rng, n_ops=40):
             ops.append(("bal", float(rng.choice([1.0, 1.02, 0.97]))))
         elif kind == "afk":
             ops.append(("afk", int(rng.integers(0, 2))))
-    ops.append(("proc", 16))
-    ops.append(("proc", 8))
+    ops.append(("proc", 2 * granule if granule <= 16 else granule))
+    ops.append(("proc", granule))
     return ops
 
 
-def run_script(rdsp, torch, ops, iq, n_channels, pipelined, sub_batch):
+def run_script(rdsp, torch, ops, iq, n_channels, pipelined, sub_batch, cfg=K3):
     from radiodsp_sdr_rx_amd.chain import Chain
-    ch = Chain(n_channels, max_blocks_per_call=MAXBLK, **K3)
+    ch = Chain(n_channels, max_blocks_per_call=MAXBLK, **cfg)
     ch.set_groups((np.arange(n_channels) % NGROUPS).astype(np.uint16))
     ch.set_pipelined(pipelined)
     if sub_batch:
@@ -125,21 +125,23 @@ def run_script(rdsp, torch, ops, iq, n_channels, pipelined, sub_batch):
     return out.cpu().numpy(), ch.scalars(), ch.lms_coeffs(0), ch.lms_coeffs(1)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_random_control_session_plain_pipelined_and_repartitioned_agree_bitwise(rdsp, seed):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from radiodsp_sdr_rx_amd.chain import synth_iq
     rng = np.random.default_rng(seed)
-    ops = make_script(rng)
+    # seeds 9, 10: the four-wave front kernels (FFT_L 2048: a call is a multiple of 32 blocks)
+    cfg = dict(K3, fft_l=2048) if seed >= 9 else K3
+    ops = make_script(rng, n_ops=40 if seed < 9 else 30, granule=32 if seed >= 9 else 8)
     total = sum(op[1] for op in ops if op[0] == "proc")
     iq = synth_iq(NCH, total * 128)
     # a few rail-to-rail bursts so that an enabled blanker has something to do
     for c in range(0, NCH, 7):
         for p in rng.integers(2000, iq.shape[1] - 4, 12):
             iq[c, p:p + 3] = 30000
-    plain = run_script(rdsp, torch, ops, iq, NCH, False, 0)
-    piped = run_script(rdsp, torch, ops, iq, NCH, True, 64)      # 64 + 64 + 22 channels per stage launch
+    plain = run_script(rdsp, torch, ops, iq, NCH, False, 0, cfg)
+    piped = run_script(rdsp, torch, ops, iq, NCH, True, 64, cfg)      # 64 + 64 + 22 channels per stage launch
     names = ("audio", "scalars", "DSP-NR weights", "ALS weights")
     # equal_nan: the reference's NLMS (arm_lms_norm_f32: energy by running difference) can blow up after
     # a loud-to-quiet transition -- the literal CPU restatement does the same -- and a
@@ -148,7 +150,7 @@ def test_random_control_session_plain_pipelined_and_repartitioned_agree_bitwise(
         assert np.array_equal(a, b, equal_nan=True), f"seed {seed}: {name} differ between the plain and the pipelined chain"
     assert np.isfinite(plain[1]).all()
     # 63 = 21 x 3 keeps the channel -> group map (c mod 3) of the first channels
-    part = run_script(rdsp, torch, ops, iq, 63, True, 0)
+    part = run_script(rdsp, torch, ops, iq, 63, True, 0, cfg)
     for name, a, b in zip(names, plain, part):
         assert np.array_equal(a[:63], b, equal_nan=True), f"seed {seed}: {name} depend on the channel partition"
 
@@ -209,7 +211,7 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
     rng = np.random.default_rng(seed)
     n_groups, nch = 3, 6
-    base = dict(fft_l=int(rng.choice([256, 512, 1024])), agc_mode=str(rng.choice(["off", "medium", "fast"])),
+    base = dict(fft_l=int(rng.choice([256, 512, 1024, 2048])), agc_mode=str(rng.choice(["off", "medium", "fast"])),
                 spectral_nr=int(rng.choice([0, 1])), spectral_level=2.0, output_gain=0.5,
                 window=int(rng.choice([1, 2, 4])))
     granule = max(8, base["fft_l"] // 64)   # an overlap-save hop of FFT_L / 2 samples at 24 kHz and the front kernel's 1024-sample chunk, in 128-sample blocks
@@ -281,10 +283,21 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
     ch.flush()
     torch.cuda.synchronize()
     got = np.concatenate([o.cpu().numpy() for o in got], 1)
+    hop = base["fft_l"] // 2
     for c in range(nch):
         r = np.concatenate(ref[c])
-        err = np.abs(got[c] - r).max() / np.abs(r).max()
-        assert err <= TOL, f"seed {seed} ({base}), channel {c}: {err:.2e}\n{ops}"
+        e = np.abs(got[c] - r).max(axis=1) / np.abs(r).max()
+        per_hop = e[:len(e) // hop * hop].reshape(-1, hop).max(axis=1)
+        bad = per_hop > TOL
+        if base["spectral_nr"] or any(op[0] == "spec" and op[1] for op in ops):
+            # the spectral stage is discontinuous at its threshold (SPEC:213-217: 0.2 mag below NFloor,
+            # mag - NFloor above): a bin within rounding of NFloor lands on either side, which moves one
+            # bin of one frame by 0.2 NFloor, i.e. one hop of output by ~1e-4 of full scale.  2048 bins x
+            # every frame x every channel make that a one-in-ten event per session; it is confined to
+            # that hop (every output sample comes from exactly one frame).  Everything else is at 1e-5.
+            assert bad.sum() <= 2 and per_hop.max() <= 1e-3, f"seed {seed} ({base}), channel {c}: {per_hop[bad]}\n{ops}"
+        else:
+            assert not bad.any(), f"seed {seed} ({base}), channel {c}: {per_hop.max():.2e}\n{ops}"
 
 
 @pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
