@@ -238,7 +238,7 @@ int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
 /* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]): -1 (default) evaluates it in the
  * frequency domain -- polyphase overlap-save: four low-rate transforms, branch spectra, one inverse
- *  -- where that kernel exists (decim 4; with the noise blanker on, fft_l <= 1024) and in
+ *  -- where that kernel exists (decim 4) and in
  * the direct form (packed FMAs) elsewhere; 0 the direct form always; 2 the frequency domain
  * (RDSP_ERR_UNSUPPORTED where it does not exist).  Both are the same exact linear convolution with
  * the same taps.  The frequency-domain frames are anchored at each call's first sample, so with it
