@@ -23,8 +23,8 @@ namespace {
  *    depends on the detector of sample n-1, not n: the recursion is two interleaved chains
  *    (even and odd samples) joined only by the three-operation omega update, and the eight
  *    samples of a loop body give the scheduler both chains to overlap;
- *  - the detector is a short arctangent with one reciprocal (the fold above tan(pi/8) selects
- *    numerator and denominator before the division), 2e-7;
+ *  - the detector is an arctangent without a range fold: one reciprocal, an eight-term odd polynomial
+ *    on [0, 1], three selects for the octant, 1.5e-7;
  *  - the unit-modulus correction of the phasor (once per eight samples) takes its norm from the
  *    previous sample's phasor, off the chain;
  *  - samples reach the lanes through LDS tiles: the global accesses are 16-byte and
@@ -35,16 +35,15 @@ namespace {
 __device__ __forceinline__ float sam_atan2(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
-  /* atan(t), t = mn / mx in [0, 1]: above tan(pi/8) fold with atan(t) = pi/4 + atan((t - 1)/(t + 1))
-   * = pi/4 + atan((mn - mx)/(mn + mx)) */
-  const bool hi = mn > 0.41421356237f * mx;
-  const float num = hi ? mn - mx : mn, den = hi ? mn + mx : mx;
-  const float u = num * __builtin_amdgcn_rcpf(den);
+  /* atan(u), u = mn / mx in [0, 1], as u P(u^2) with an eight-term polynomial (weighted least squares
+   * towards the minimax fit, 1.5e-7 in float): no range fold, so no selects and one reciprocal */
+  const float u = mn * __builtin_amdgcn_rcpf(mx);
   const float z = u * u;
-  float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
-  p = fmaf(p, z, 1.99777106478e-1f);
-  p = fmaf(p, z, -3.33329491539e-1f);
-  float r = fmaf(p * z, u, u) + (hi ? 0.78539816339744831f : 0.0f);
+  constexpr float c[8] = {9.999993356e-01f, -3.332986079e-01f, 1.994656566e-01f, -1.390862957e-01f, 9.642197347e-02f, -5.591232664e-02f, 2.186295759e-02f, -4.054567096e-03f};
+  float p = c[7];
+#pragma unroll
+  for (int k = 6; k >= 0; k--) p = fmaf(p, z, c[k]);
+  float r = p * u;
   r = (ay > ax) ? 1.57079632679489662f - r : r;
   r = (x < 0.0f) ? 3.14159265358979324f - r : r;
   return (y < 0.0f) ? -r : r;
