@@ -14,11 +14,11 @@ CFG = dict(fft_l=256, demod="LSB", flo_hz=300.0, fhi_hz=4000.0, agc_mode="medium
            iq_balance=1.02)   # what setup() of binding_check.c leaves the engine in
 
 
-def build(tmp_path):
-    exe = str(tmp_path / "binding_check")
-    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__",
+def build(tmp_path, name="binding_check"):
+    exe = str(tmp_path / name)
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-D__HIP_PLATFORM_AMD__",
                            "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
-                           os.path.join(HOST, "binding_check.c"), "-o", exe,
+                           os.path.join(HOST, name + ".c"), "-o", exe,
                            "-L", os.path.join(ROOT, "radiodsp_sdr_rx_amd"), "-lrdsp_hip",
                            "-L", "/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + os.path.join(ROOT, "radiodsp_sdr_rx_amd"), "-Wl,-rpath,/opt/rocm/lib"])
@@ -51,3 +51,19 @@ def test_k1_through_the_c_binding_matches_ctypes_path_and_oracle(rdsp, oracle, t
     assert np.array_equal(got, ref)
     r16, _ = oracle.OracleChain(**CFG).process(iq[0])
     assert np.abs(got.astype(np.int32) - r16.astype(np.int32)).max() <= 1
+
+
+def test_sharding_host_in_c_compiles_and_links(rdsp, tmp_path):
+    exe = build(tmp_path, "shard_threads")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 64 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_channel_shards_on_threads_match_one_bucket_bitwise(rdsp, tmp_path):
+    """SURVEY 8(e) in C: one host thread + chain + stream per contiguous channel range (device k % n_devices),
+    three shards running concurrently against the same channels as one bucket: K3, pipelined, bit for bit."""
+    exe = build(tmp_path, "shard_threads")
+    r = subprocess.run([exe, "3", "37", "5", "16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of" in r.stdout and "3 shards x 37 channels" in r.stdout
