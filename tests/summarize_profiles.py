@@ -72,9 +72,9 @@ def main():
         for ext in ("log", "json"):
             f = os.path.join(OUT, f"prof_{tag}.{ext}")
             if os.path.exists(f):
-                lines = [l for l in open(f).read().splitlines() if l.startswith("{") or l.startswith("K3 ")]
+                lines = [l for l in open(f).read().splitlines() if l.startswith("{") or l.startswith("K3 ") or l.startswith("K4 ")]
                 if lines:
-                    open(os.path.join(PROF, f"{rnd}_{name}_bench.{'json' if ext == 'json' else 'txt'}"), "w").write("\n".join(lines[-5:] if ext == "log" else lines[-1:]) + "\n")
+                    open(os.path.join(PROF, f"{rnd}_{name}_bench.{'json' if ext == 'json' else 'txt'}"), "w").write("\n".join(lines[-8:] if ext == "log" else lines[-1:]) + "\n")
     cpath = os.path.join(PROF, "counters.json")
     counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
     for cfg in ("K2", "K3", "K4", "K5", "F1"):
