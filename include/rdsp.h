@@ -270,6 +270,19 @@ int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void 
 int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out);
 int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);
 
+/* ---- per-channel state as data (the reference's DSP state is a set of globals,
+ * CONV:50-57,77-80, NR:26-32, SPEC:109; here an explicit per-channel record) ------------------------
+ * Checkpoint / resume and moving channels between chains or GPUs: the state of channels
+ * first_channel .. first_channel + n_channels - 1 (FIR history, overlap block, NFloor / AGC gain / AM DC /
+ * blanker level, both NLMS instances, SAM PLL, IIR cascade) as one host blob.  Settings (modes, filters,
+ * gains, groups) are configuration and are re-applied by the caller; FFT_L and decimation must match.
+ * Loading into a chain that has not processed anything also restores the stream position and call
+ * history (resume: the next call continues the stream bit for bit); a chain that has must be at the
+ * same stream position.  Control-path calls: both wait for everything queued so far. */
+size_t rdsp_chain_state_bytes(const rdsp_chain_t *c, int n_channels);
+int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_channels, void *host_buf, size_t bytes, void *stream);
+int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const void *host_buf, size_t bytes, void *stream);
+
 /* ---- recorded IQ in, audio out ----------------------------------
  * The ends of the sketch's graph are an I2S bus and a codec (AudioInputI2S IQinput,
  * AudioOutputI2S audio_out, AudioControlSGTL5000 codec: INO:52,55,159-169).  A

@@ -207,6 +207,21 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_get_timing(self.h, C.byref(f), C.byref(t), C.byref(n)))
         return f.value, t.value, n.value
 
+    # ---- per-channel state as data (checkpoint / resume, channels moved between chains) ------
+    def save_state(self, first_channel=0, n_channels=None, stream=None):
+        """uint8 array holding the DSP state of channels first_channel .. first_channel + n_channels - 1"""
+        n = self.n_channels - first_channel if n_channels is None else n_channels
+        size = self.lib.rdsp_chain_state_bytes(self.h, n)
+        buf = np.zeros(size, np.uint8)
+        _lib.check(self.lib.rdsp_chain_save_state(self.h, first_channel, n, buf.ctypes.data_as(C.c_void_p), size,
+                                                  _stream_ptr(stream)))
+        return buf
+
+    def load_state(self, blob, first_channel=0, stream=None):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        _lib.check(self.lib.rdsp_chain_load_state(self.h, first_channel, blob.ctypes.data_as(C.c_void_p), blob.size,
+                                                  _stream_ptr(stream)))
+
     # ---- state read-back ------------------------------------------------------
     def scalars(self, stream=None):
         a = np.zeros((self.n_channels, 4), np.float32)

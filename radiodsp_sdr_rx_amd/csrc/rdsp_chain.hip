@@ -1328,6 +1328,136 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
   return RDSP_OK;
 }
 
+/* ---- per-channel state as data: checkpoint / resume, channels moved between chains or GPUs ------
+ * The reference keeps its DSP state in globals (CONV:50-57,77-80; NR:26-32; SPEC:109) and has no
+ * persistence; here the state is an explicit per-channel record, so a range of
+ * channels can be written out and read back into the same range of another chain -- same FFT_L and
+ * decimation, same settings (modes, filters and gains are configuration: the caller re-applies them).
+ * Blob: header, then the arrays of DESIGN.md 3 for the n channels, each [n][...]. */
+namespace {
+struct StateHeader {
+  uint32_t magic, version; /* "RDSP", 1 */
+  int32_t n_channels, fft_l, decim;
+  int32_t has_sam, has_iir;
+  int32_t old_nr_level;
+  uint64_t n_in;
+  int64_t nr_calls, als_calls;
+  float nr_mu, als_mu;
+  int32_t hist_valid, hist_swap;
+  float hist_scale_i, hist_scale_q;
+};
+constexpr uint32_t kStateMagic = 0x50534452u; /* 'R' 'D' 'S' 'P' */
+struct StatePart { void *dev; size_t per_channel; };
+/* the per-channel arrays in blob order; optional ones (SAM, IIR) only when present */
+std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir) {
+  std::vector<StatePart> v = {
+      {c->d_hist, sizeof(uint32_t) * 256},
+      {c->d_prev, sizeof(float2) * (size_t)(c->N / 2)},
+      {c->d_scal, sizeof(float) * 4},
+      {c->d_nr_w, sizeof(float) * RDSP_LMS_TAPS}, {c->d_nr_prev, sizeof(float) * RDSP_BLOCK}, {c->d_nr_energy, sizeof(float)},
+      {c->d_als_w, sizeof(float) * RDSP_LMS_TAPS}, {c->d_als_prev, sizeof(float) * RDSP_BLOCK}, {c->d_als_energy, sizeof(float)},
+  };
+  if (sam) v.push_back({c->d_sam, sizeof(float) * 4});
+  if (iir) v.push_back({c->d_iir_state, sizeof(float) * 16});
+  return v;
+}
+size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir) {
+  size_t b = sizeof(StateHeader);
+  for (const auto &p : state_parts(c, sam, iir)) b += p.per_channel * (size_t)n;
+  return b;
+}
+}  // namespace
+
+extern "C" size_t rdsp_chain_state_bytes(const rdsp_chain_t *c, int n_channels) {
+  if (!c || n_channels <= 0 || n_channels > c->n_channels) return 0;
+  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr);
+}
+
+/* everything queued so far has finished when the copy is taken (a control-path call) */
+extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_channels, void *host_buf, size_t bytes,
+                                     void *stream) {
+  NEED(c);
+  if (!host_buf || first_channel < 0 || n_channels <= 0 || first_channel + n_channels > c->n_channels ||
+      bytes < rdsp_chain_state_bytes(c, n_channels)) {
+    rdsp_set_error("rdsp_chain_save_state: bad argument (channels %d..%d of %d, %zu bytes, %zu needed)", first_channel,
+                   first_channel + n_channels, c->n_channels, bytes, rdsp_chain_state_bytes(c, n_channels));
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  StateHeader h;
+  memset(&h, 0, sizeof(h));
+  h.magic = kStateMagic; h.version = 1;
+  h.n_channels = n_channels; h.fft_l = c->N; h.decim = c->decim;
+  h.has_sam = c->d_sam != nullptr; h.has_iir = c->d_iir_state != nullptr;
+  h.old_nr_level = c->old_nr_level; h.n_in = c->n_in;
+  h.nr_calls = c->nr_calls; h.als_calls = c->als_calls;
+  h.nr_mu = c->nr_mu; h.als_mu = c->als_mu;
+  h.hist_valid = c->hist_valid; h.hist_swap = c->hist_swap;
+  h.hist_scale_i = c->hist_scale_i; h.hist_scale_q = c->hist_scale_q;
+  unsigned char *dst = (unsigned char *)host_buf;
+  memcpy(dst, &h, sizeof(h));
+  dst += sizeof(h);
+  for (const auto &p : state_parts(c, h.has_sam, h.has_iir)) {
+    const size_t n = p.per_channel * (size_t)n_channels;
+    HIP_TRY(hipMemcpy(dst, (const unsigned char *)p.dev + p.per_channel * (size_t)first_channel, n, hipMemcpyDeviceToHost));
+    dst += n;
+  }
+  return RDSP_OK;
+}
+
+/* the blob's channels become channels first_channel .. of this chain.  A chain that has not processed
+ * anything yet also takes the stream position and the call history (resume); one that has must be at
+ * the same stream position (channels moved between shards of one stream). */
+extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const void *host_buf, size_t bytes, void *stream) {
+  NEED(c);
+  StateHeader h;
+  if (!host_buf || bytes < sizeof(h)) {
+    rdsp_set_error("rdsp_chain_load_state: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  memcpy(&h, host_buf, sizeof(h));
+  if (h.magic != kStateMagic || h.version != 1 || h.fft_l != c->N || h.decim != c->decim || h.n_channels <= 0 ||
+      first_channel < 0 || first_channel + h.n_channels > c->n_channels) {
+    rdsp_set_error("rdsp_chain_load_state: blob of %d channels, FFT_L %d, decimation %d does not fit channels %d.. of a chain "
+                   "of %d channels, FFT_L %d, decimation %d", h.n_channels, h.fft_l, h.decim, first_channel, c->n_channels,
+                   c->N, c->decim);
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (h.has_sam && ensure_sam(c) != RDSP_OK) return RDSP_ERR_HIP;
+  const bool take_iir = h.has_iir && c->d_iir_state != nullptr; /* the cascade's state exists once the IIR bank was selected */
+  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0)) {
+    rdsp_set_error("rdsp_chain_load_state: blob truncated");
+    return RDSP_ERR_INVALID;
+  }
+  const bool fresh = c->n_in == 0 && c->call_idx == 0;
+  if (!fresh && c->n_in != h.n_in) {
+    rdsp_set_error("rdsp_chain_load_state: the chain is at input sample %llu, the blob at %llu", (unsigned long long)c->n_in,
+                   (unsigned long long)h.n_in);
+    return RDSP_ERR_INVALID;
+  }
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const unsigned char *src = (const unsigned char *)host_buf + sizeof(h);
+  for (const auto &p : state_parts(c, h.has_sam != 0, h.has_iir != 0)) {
+    const size_t n = p.per_channel * (size_t)h.n_channels;
+    if (p.dev && (p.dev != (void *)c->d_iir_state || take_iir))
+      HIP_TRY(hipMemcpy((unsigned char *)p.dev + p.per_channel * (size_t)first_channel, src, n, hipMemcpyHostToDevice));
+    src += n;
+  }
+  if (fresh) {
+    c->n_in = h.n_in;
+    c->old_nr_level = h.old_nr_level;
+    c->nr_calls = (long)h.nr_calls; c->als_calls = (long)h.als_calls;
+    c->nr_mu = h.nr_mu; c->als_mu = h.als_mu;
+    c->hist_valid = h.hist_valid != 0; c->hist_swap = h.hist_swap;
+    c->hist_scale_i = h.hist_scale_i; c->hist_scale_q = h.hist_scale_q;
+  }
+  return RDSP_OK;
+}
+
 /* ---- state read-back ------------------------------------------------------- */
 extern "C" int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream) {
   NEED(c);

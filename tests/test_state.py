@@ -1,0 +1,102 @@
+"""the per-channel DSP state as data.  The reference keeps it in globals
+(RDSP_convolutional.h:50-57,77-80; RDSP_noise_reduction.h:26-32; RDSP_convolutional_spec.h:109) and has no
+persistence; rdsp_chain_save_state / rdsp_chain_load_state write a range of channels out and read it back
+into another chain: resume after a restart, channels moved between shards or GPUs.  Everything here is
+bit-exact: a stream continued from a blob is the uninterrupted stream."""
+import numpy as np
+import pytest
+
+from cases import K1, K3
+
+pytestmark = pytest.mark.gpu
+
+
+def _parts(iq, per):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(iq[:, k * per * 128:(k + 1) * per * 128])).cuda()
+            for k in range(iq.shape[1] // (per * 128))]
+
+
+def _setup(ch, kind):
+    if kind == "sam_iir":           # the optional arrays: SAM PLL state, IIR cascade state
+        ch.setAudioFilterKind(1)
+        ch.setAudioFilter(4)
+        ch.setDemodMode(6)          # SAM
+    elif kind == "k3_nr":           # both NLMS instances, blanker level, swap / gains carried as history parameters
+        ch.set_nr_level(20)
+        ch.enableNoiseBlanker()
+        ch.swapIQ(True)
+        ch.setInputGain(0.8)
+
+
+@pytest.mark.parametrize("kind,cfg", [("k3", K3), ("k3_nr", K3), ("sam_iir", dict(fft_l=512, agc_mode="slow", output_gain=0.5)),
+                                      ("k1", K1), ("cw_2048", dict(fft_l=2048, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0,
+                                                                    nco_hz=11300.0, agc_mode="fast"))])
+def test_resume_and_channel_move_are_bit_exact(rdsp, kind, cfg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, per = 11, (32 if cfg.get("fft_l", 256) >= 2048 else 16)
+    iq = synth_iq(nch, per * 4 * 128)
+    parts = _parts(iq, per)
+
+    def new(n):
+        ch = Chain(n, max_blocks_per_call=per, **cfg)
+        _setup(ch, kind)
+        ch.set_pipelined(True)
+        return ch
+
+    def run(ch, ps):                               # pipelined: the audio is complete at flush()
+        outs = [ch.process(p) for p in ps]
+        ch.flush()
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in outs]
+
+    a = new(nch)                                   # the uninterrupted stream
+    ref = run(a, parts)
+    b = new(nch)                                   # stops after two calls
+    for p in parts[:2]:
+        b.process(p)
+    blob = b.save_state()
+    assert blob.size == rdsp.load().rdsp_chain_state_bytes(b.h, nch)
+    part = b.save_state(3, 4)                      # channels 3..6 only
+    c = new(nch)                                   # restart: a fresh chain, same settings
+    c.load_state(blob)
+    for g, r in zip(run(c, parts[2:]), ref[2:]):
+        assert np.array_equal(g, r)
+    assert np.array_equal(c.scalars(), a.scalars()) and np.array_equal(c.lms_coeffs(1), a.lms_coeffs(1))
+    assert np.array_equal(c.save_state(), a.save_state())      # the whole record, not only what the getters show
+    d = new(4)                                     # those four channels on another chain (another shard / GPU)
+    d.load_state(part)
+    for g, r in zip(run(d, [p[3:7].contiguous() for p in parts[2:]]), ref[2:]):
+        assert np.array_equal(g, r[3:7])
+    # ... and back into a running chain at the same stream position, other channels untouched
+    e = new(nch)
+    for p in parts[:2]:
+        e.process(p)
+    e.load_state(part, first_channel=3)
+    assert np.array_equal(e.save_state(), blob)
+
+
+def test_state_argument_errors_are_loud(rdsp):
+    import torch
+    assert torch.cuda.is_available()
+    from radiodsp_sdr_rx_amd import RdspError
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    a = Chain(4, max_blocks_per_call=8, **K1)
+    blob = a.save_state()
+    with pytest.raises(RdspError):
+        Chain(4, max_blocks_per_call=8, **dict(K1, fft_l=512)).load_state(blob)       # another FFT_L
+    with pytest.raises(RdspError):
+        Chain(3, max_blocks_per_call=8, **K1).load_state(blob)                         # does not fit
+    with pytest.raises(RdspError):
+        a.load_state(blob[:-8])                                                        # truncated
+    bad = blob.copy(); bad[0] ^= 0xFF
+    with pytest.raises(RdspError):
+        a.load_state(bad)                                                              # not a state blob
+    with pytest.raises(RdspError):
+        a.save_state(2, 3)                                                             # range past the end
+    b = Chain(4, max_blocks_per_call=8, **K1)
+    b.process(torch.from_numpy(synth_iq(4, 8 * 128)).cuda())
+    with pytest.raises(RdspError):
+        b.load_state(blob)                                                             # a running chain at another stream position
