@@ -62,8 +62,14 @@ struct GroupState {
   bool dirty = true; /* the device record must be rewritten before the next launch */
   bool has_dev_dphi = false; /* dev_dphi: increment the last launch mixed with */
   uint32_t dev_dphi = 0;
-  hipEvent_t ev_copy = nullptr;
-  float *staging = nullptr; /* pinned, N float2 */
+  /* two pinned images of the mask (N float2 each) with the event of the upload that last read each:
+   * a retune fills the one whose upload is two retunes old, so the host never overwrites an image
+   * an earlier, still queued upload has yet to read (the processing stream only waits for uploads
+   * on the device; the host does not know when one has run) */
+  hipEvent_t ev_copy[2] = {nullptr, nullptr};
+  float *staging[2] = {nullptr, nullptr};
+  bool issued[2] = {false, false};
+  int stage_next = 0, stage_last = 0;
   float iir[20];            /* the group's audio band-pass as four biquads (RDSP_AUDIO_KIND_IIR) */
   bool iir_dirty = true;
 };
@@ -192,10 +198,13 @@ static void group_design(rdsp_chain_t *c, GroupState &g) { /* CONV:209-224 witho
 }
 
 static void group_free(GroupState &g) {
-  if (g.ev_copy) (void)hipEventDestroy(g.ev_copy);
-  if (g.staging) (void)hipHostFree(g.staging);
-  g.ev_copy = nullptr;
-  g.staging = nullptr;
+  for (int i = 0; i < 2; i++) {
+    if (g.ev_copy[i]) (void)hipEventDestroy(g.ev_copy[i]);
+    if (g.staging[i]) (void)hipHostFree(g.staging[i]);
+    g.ev_copy[i] = nullptr;
+    g.staging[i] = nullptr;
+    g.issued[i] = false;
+  }
 }
 
 /* (re)allocate the device side for n groups; existing groups keep their settings,
@@ -223,8 +232,10 @@ static int groups_resize(rdsp_chain_t *c, int n) {
       g.coef_Q.assign(c->hop + 1, 0.0);
       g.mask_nat.assign(2 * (size_t)c->N, 0.0f);
     }
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_copy, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void **)&g.staging, sizeof(float2) * (size_t)c->N, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) {
+      HIP_TRY(hipEventCreateWithFlags(&g.ev_copy[i], hipEventDisableTiming));
+      HIP_TRY(hipHostMalloc((void **)&g.staging[i], sizeof(float2) * (size_t)c->N, hipHostMallocDefault));
+    }
   }
   if (c->d_groups) (void)hipFree(c->d_groups);
   if (c->d_mask_pool) (void)hipFree(c->d_mask_pool);
@@ -248,14 +259,20 @@ static int groups_resize(rdsp_chain_t *c, int n) {
  * processing stream (the reference does this under AudioNoInterrupts, CONV:211-222) */
 static int group_stage(rdsp_chain_t *c, int gi) {
   GroupState &g = c->groups[(size_t)gi];
-  if (g.staged >= 0) HIP_TRY(hipEventSynchronize(g.ev_copy)); /* the pinned image is ours again */
-  rdsp_mask_device_image(c->cfg.filter_on ? g.mask_nat.data() : nullptr, c->N, g.staging);
+  const int si = g.stage_next;
+  /* the upload that last read this image is two retunes old: almost always long done; if not
+   * (a burst of retunes of one group while the device is calls behind) the host waits for it */
+  if (g.issued[si]) HIP_TRY(hipEventSynchronize(g.ev_copy[si]));
+  rdsp_mask_device_image(c->cfg.filter_on ? g.mask_nat.data() : nullptr, c->N, g.staging[si]);
   const int target = (g.staged >= 0) ? g.staged : (1 - g.applied);
   /* front kernels launched so far may still read `target` (it was live before the last switch) */
   if (c->fence_valid) HIP_TRY(hipStreamWaitEvent(c->s_copy, c->ev_fence, 0));
   float2 *dst = c->d_mask_pool + ((size_t)gi * 2 + (size_t)target) * (size_t)c->N;
-  HIP_TRY(hipMemcpyAsync(dst, g.staging, sizeof(float2) * (size_t)c->N, hipMemcpyHostToDevice, c->s_copy));
-  HIP_TRY(hipEventRecord(g.ev_copy, c->s_copy));
+  HIP_TRY(hipMemcpyAsync(dst, g.staging[si], sizeof(float2) * (size_t)c->N, hipMemcpyHostToDevice, c->s_copy));
+  HIP_TRY(hipEventRecord(g.ev_copy[si], c->s_copy));
+  g.issued[si] = true;
+  g.stage_last = si;
+  g.stage_next = si ^ 1;
   g.staged = target;
   g.dirty = true;
   return RDSP_OK;
@@ -294,7 +311,7 @@ static int groups_commit(rdsp_chain_t *c, hipStream_t stream) {
     if (!g.dirty) continue;
     int buf = g.applied;
     if (g.staged >= 0) {
-      HIP_TRY(hipStreamWaitEvent(stream, g.ev_copy, 0));
+      HIP_TRY(hipStreamWaitEvent(stream, g.ev_copy[g.stage_last], 0));
       buf = g.staged;
     }
     RdspGroup r;

@@ -195,3 +195,37 @@ def test_group_argument_errors_are_loud(rdsp, torch_cuda):
         ch.group_pbt(2, 0, 1)
     ch.set_groups(None)
     assert ch.n_groups == 1
+
+
+@pytest.mark.gpu
+def test_back_to_back_retunes_while_the_device_is_calls_behind(rdsp, torch_cuda):
+    """Two retunes of the same group one call apart, issued while the device is still working on
+    earlier calls: the first retune's upload is queued behind those calls when the second retune
+    arrives, and must still carry the first mask (its pinned image is not the second one's).  Found by
+    the randomised sessions: the call between the two retunes ran with the second mask.  The reference
+    run synchronises before every retune; both must give the same bits."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, per, calls = 1024, 32, 8
+    iq = torch.from_numpy(synth_iq(nch, per * 128)).cuda()       # every call gets the same block of input
+    group_of = (np.arange(nch) % 3).astype(np.uint16)
+    bands = [(300.0, 2100.0), (500.0, 1000.0), (100.0, 3400.0), (300.0, 2700.0), (600.0, 2400.0)]
+
+    def run(sync_before_retune):
+        ch = Chain(nch, max_blocks_per_call=per, **K1)
+        ch.set_groups(group_of)
+        outs = []
+        for k in range(calls):
+            if k >= 3:                                # the device is three calls behind by now
+                if sync_before_retune:
+                    torch.cuda.synchronize()
+                ch.group_reInitializeFilter(1, *bands[k - 3])
+            outs.append(ch.process(iq))
+        torch.cuda.synchronize()
+        return np.stack([o.cpu().numpy() for o in outs])
+
+    ref = run(True)
+    for _ in range(3):
+        got = run(False)
+        assert np.array_equal(got, ref)
+    assert not np.array_equal(ref[4][1], ref[5][1])      # the retunes do change group 1 from call to call
