@@ -41,3 +41,17 @@ for seed in range(first, first + count):
     if (seed - first) % 10 == 9:
         print("seeds", first, "..", seed, "done,", bad, "mismatches", flush=True)
 print("soak:", count, "sessions,", bad, "mismatches")
+
+# the oracle-checked sessions and the truth-anchored switching sessions over the same seed range
+import oracle_lib
+oracle_lib.build()
+fails = {"oracle": [], "switching": []}
+for seed in range(first, first + count):
+    for name, fn in (("oracle", m.test_random_retune_session_matches_oracle),
+                     ("switching", m.test_random_nr_and_notch_switching_is_truth_anchored)):
+        try:
+            fn(R, oracle_lib, seed)
+        except AssertionError as e:
+            fails[name].append(seed)
+            print("FAIL", name, "seed", seed, str(e)[:300].replace("\n", " "), flush=True)
+print("soak oracle / switching:", count, "sessions each, failures", fails)
