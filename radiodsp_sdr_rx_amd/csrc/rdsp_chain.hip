@@ -1362,6 +1362,8 @@ struct StateHeader {
   float nr_mu, als_mu;
   int32_t hist_valid, hist_swap;
   float hist_scale_i, hist_scale_q;
+  int32_t n_groups, pad; /* followed by n_groups x {has_dev_dphi, dev_dphi}: the NCO increment each group's FIR
+                            history was mixed with (a tuning change right before the checkpoint) */
 };
 constexpr uint32_t kStateMagic = 0x50534452u; /* 'R' 'D' 'S' 'P' */
 struct StatePart { void *dev; size_t per_channel; };
@@ -1378,8 +1380,8 @@ std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir) {
   if (iir) v.push_back({c->d_iir_state, sizeof(float) * 16});
   return v;
 }
-size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir) {
-  size_t b = sizeof(StateHeader);
+size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir, size_t n_groups) {
+  size_t b = sizeof(StateHeader) + 2 * sizeof(uint32_t) * n_groups;
   for (const auto &p : state_parts(c, sam, iir)) b += p.per_channel * (size_t)n;
   return b;
 }
@@ -1387,7 +1389,7 @@ size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir) {
 
 extern "C" size_t rdsp_chain_state_bytes(const rdsp_chain_t *c, int n_channels) {
   if (!c || n_channels <= 0 || n_channels > c->n_channels) return 0;
-  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr);
+  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr, c->groups.size());
 }
 
 /* everything queued so far has finished when the copy is taken (a control-path call) */
@@ -1413,9 +1415,15 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
   h.nr_mu = c->nr_mu; h.als_mu = c->als_mu;
   h.hist_valid = c->hist_valid; h.hist_swap = c->hist_swap;
   h.hist_scale_i = c->hist_scale_i; h.hist_scale_q = c->hist_scale_q;
+  h.n_groups = (int32_t)c->groups.size();
   unsigned char *dst = (unsigned char *)host_buf;
   memcpy(dst, &h, sizeof(h));
   dst += sizeof(h);
+  for (const auto &g : c->groups) {
+    const uint32_t w[2] = {g.has_dev_dphi ? 1u : 0u, g.dev_dphi};
+    memcpy(dst, w, sizeof(w));
+    dst += sizeof(w);
+  }
   for (const auto &p : state_parts(c, h.has_sam, h.has_iir)) {
     const size_t n = p.per_channel * (size_t)n_channels;
     HIP_TRY(hipMemcpy(dst, (const unsigned char *)p.dev + p.per_channel * (size_t)first_channel, n, hipMemcpyDeviceToHost));
@@ -1435,7 +1443,7 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
     return RDSP_ERR_INVALID;
   }
   memcpy(&h, host_buf, sizeof(h));
-  if (h.magic != kStateMagic || h.version != 1 || h.fft_l != c->N || h.decim != c->decim || h.n_channels <= 0 ||
+  if (h.magic != kStateMagic || h.version != 1 || h.fft_l != c->N || h.decim != c->decim || h.n_channels <= 0 || h.n_groups < 1 ||
       first_channel < 0 || first_channel + h.n_channels > c->n_channels) {
     rdsp_set_error("rdsp_chain_load_state: blob of %d channels, FFT_L %d, decimation %d does not fit channels %d.. of a chain "
                    "of %d channels, FFT_L %d, decimation %d", h.n_channels, h.fft_l, h.decim, first_channel, c->n_channels,
@@ -1445,7 +1453,7 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   if (h.has_sam && ensure_sam(c) != RDSP_OK) return RDSP_ERR_HIP;
   const bool take_iir = h.has_iir && c->d_iir_state != nullptr; /* the cascade's state exists once the IIR bank was selected */
-  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0)) {
+  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0, (size_t)h.n_groups)) {
     rdsp_set_error("rdsp_chain_load_state: blob truncated");
     return RDSP_ERR_INVALID;
   }
@@ -1458,6 +1466,8 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   const unsigned char *src = (const unsigned char *)host_buf + sizeof(h);
+  const unsigned char *gsrc = src;
+  src += 2 * sizeof(uint32_t) * (size_t)h.n_groups;
   for (const auto &p : state_parts(c, h.has_sam != 0, h.has_iir != 0)) {
     const size_t n = p.per_channel * (size_t)h.n_channels;
     if (p.dev && (p.dev != (void *)c->d_iir_state || take_iir))
@@ -1471,6 +1481,15 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
     c->nr_mu = h.nr_mu; c->als_mu = h.als_mu;
     c->hist_valid = h.hist_valid != 0; c->hist_swap = h.hist_swap;
     c->hist_scale_i = h.hist_scale_i; c->hist_scale_q = h.hist_scale_q;
+    if ((size_t)h.n_groups == c->groups.size()) /* same partition: the increments the histories came in with */
+      for (auto &g : c->groups) {
+        uint32_t w[2];
+        memcpy(w, gsrc, sizeof(w));
+        gsrc += sizeof(w);
+        g.has_dev_dphi = w[0] != 0;
+        g.dev_dphi = w[1];
+        g.dirty = true;
+      }
   }
   return RDSP_OK;
 }

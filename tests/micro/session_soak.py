@@ -51,13 +51,14 @@ print("soak:", count, "sessions,", bad, "mismatches")
 # the oracle-checked sessions and the truth-anchored switching sessions over the same seed range
 import oracle_lib
 oracle_lib.build()
-fails = {"oracle": [], "switching": []}
+fails = {"oracle": [], "switching": [], "resume": []}
 for seed in range(first, first + count):
     for name, fn in (("oracle", m.test_random_retune_session_matches_oracle),
-                     ("switching", m.test_random_nr_and_notch_switching_is_truth_anchored)):
+                     ("switching", m.test_random_nr_and_notch_switching_is_truth_anchored),
+                     ("resume", m.test_random_session_resumed_from_a_checkpoint_is_bit_exact)):
         try:
-            fn(R, oracle_lib, seed)
+            fn(R, seed) if name == "resume" else fn(R, oracle_lib, seed)
         except AssertionError as e:
             fails[name].append(seed)
             print("FAIL", name, "seed", seed, str(e)[:300].replace("\n", " "), flush=True)
-print("soak oracle / switching:", count, "sessions each, failures", fails)
+print("soak oracle / switching / resume:", count, "sessions each, failures", fails)

@@ -66,63 +66,121 @@ def make_script(rng, n_ops=40, granule=8):
     return ops
 
 
-def run_script(rdsp, torch, ops, iq, n_channels, pipelined, sub_batch, cfg=K3):
+def make_chain(n_channels, pipelined, sub_batch, cfg=K3):
     from radiodsp_sdr_rx_amd.chain import Chain
     ch = Chain(n_channels, max_blocks_per_call=MAXBLK, **cfg)
     ch.set_groups((np.arange(n_channels) % NGROUPS).astype(np.uint16))
     ch.set_pipelined(pipelined)
     if sub_batch:
         ch.set_sub_batch(sub_batch)
-    total = sum(op[1] for op in ops if op[0] == "proc")
-    out = torch.zeros((n_channels, total * 32, 2), dtype=torch.int16, device="cuda")
-    dev = torch.from_numpy(np.ascontiguousarray(iq[:n_channels])).cuda()
-    pos = 0
+    return ch
+
+
+def apply_setter(ch, rdsp, op):
+    k = op[0]
+    if k == "als":
+        if op[1] == "off":
+            ch.disableALSfilter()
+        else:
+            ch.enableALSfilter()
+            ch.setALSfilterNotch() if op[1] == "notch" else ch.setALSfilterPeak()
+    elif k == "nr":
+        ch.set_nr_level(op[1])
+    elif k == "spec":
+        ch.set_spectral_nr(op[1], op[2])
+    elif k == "agc":
+        ch.setAGCmode(rdsp.AGC[op[1]])
+    elif k == "gdemod":
+        ch.group_setDemodMode(op[1], rdsp.DEMOD[op[2]])
+    elif k == "gfilt":
+        ch.group_reInitializeFilter(op[1], op[2], op[3])
+    elif k == "gpbt":
+        ch.group_pbt(op[1], op[2], op[3])
+    elif k == "goff":
+        ch.group_setTuningOffsetHz(op[1], op[2])
+    elif k == "gaf":
+        ch.group_setAudioFilter(op[1], op[2])
+    elif k == "nb":
+        ch.enableNoiseBlanker() if op[1] else ch.disableNoiseBlanker()
+        ch.setNoiseBlankerThresholdDb(op[2])
+    elif k == "swap":
+        ch.swapIQ(op[1])
+    elif k == "mute":
+        ch.setMute(op[1])
+    elif k == "ogain":
+        ch.setOutputGain(op[1])
+    elif k == "igain":
+        ch.setInputGain(op[1])
+    elif k == "bal":
+        ch.setIQgainBalance(op[1])
+    elif k == "afk":
+        ch.setAudioFilterKind(op[1])
+    else:
+        raise ValueError(op)
+
+
+def run_ops(ch, rdsp, torch, ops, dev, out, pos=0):
+    """ops on one chain; audio of the calls into `out` at the stream position; returns the new position"""
     for op in ops:
-        k = op[0]
-        if k == "proc":
+        if op[0] == "proc":
             n = op[1]
             ch.process(dev[:, pos * 128:(pos + n) * 128], out=out[:, pos * 32:(pos + n) * 32])
             pos += n
-        elif k == "als":
-            if op[1] == "off":
-                ch.disableALSfilter()
-            else:
-                ch.enableALSfilter()
-                ch.setALSfilterNotch() if op[1] == "notch" else ch.setALSfilterPeak()
-        elif k == "nr":
-            ch.set_nr_level(op[1])
-        elif k == "spec":
-            ch.set_spectral_nr(op[1], op[2])
-        elif k == "agc":
-            ch.setAGCmode(rdsp.AGC[op[1]])
-        elif k == "gdemod":
-            ch.group_setDemodMode(op[1], rdsp.DEMOD[op[2]])
-        elif k == "gfilt":
-            ch.group_reInitializeFilter(op[1], op[2], op[3])
-        elif k == "gpbt":
-            ch.group_pbt(op[1], op[2], op[3])
-        elif k == "goff":
-            ch.group_setTuningOffsetHz(op[1], op[2])
-        elif k == "gaf":
-            ch.group_setAudioFilter(op[1], op[2])
-        elif k == "nb":
-            ch.enableNoiseBlanker() if op[1] else ch.disableNoiseBlanker()
-            ch.setNoiseBlankerThresholdDb(op[2])
-        elif k == "swap":
-            ch.swapIQ(op[1])
-        elif k == "mute":
-            ch.setMute(op[1])
-        elif k == "ogain":
-            ch.setOutputGain(op[1])
-        elif k == "igain":
-            ch.setInputGain(op[1])
-        elif k == "bal":
-            ch.setIQgainBalance(op[1])
-        elif k == "afk":
-            ch.setAudioFilterKind(op[1])
+        else:
+            apply_setter(ch, rdsp, op)
+    return pos
+
+
+def run_script(rdsp, torch, ops, iq, n_channels, pipelined, sub_batch, cfg=K3):
+    ch = make_chain(n_channels, pipelined, sub_batch, cfg)
+    total = sum(op[1] for op in ops if op[0] == "proc")
+    out = torch.zeros((n_channels, total * 32, 2), dtype=torch.int16, device="cuda")
+    dev = torch.from_numpy(np.ascontiguousarray(iq[:n_channels])).cuda()
+    run_ops(ch, rdsp, torch, ops, dev, out)
     ch.flush()
     torch.cuda.synchronize()
     return out.cpu().numpy(), ch.scalars(), ch.lms_coeffs(0), ch.lms_coeffs(1)
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43, 44, 45, 46])
+def test_random_session_resumed_from_a_checkpoint_is_bit_exact(rdsp, seed):
+    """A script cut at a random call: the first part on one chain, rdsp_chain_save_state, then a fresh chain
+    that is given the same settings (the setters of the first part, no calls), rdsp_chain_load_state and
+    the rest of the script -- against the uninterrupted run: audio of the rest and the final state blob,
+    bit for bit.  Whatever the record leaves out (a tuning change right before the cut, a blanker level,
+    the swap flag the history came in with) shows up here."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    rng = np.random.default_rng(seed)
+    ops = make_script(rng)
+    procs = [i for i, op in enumerate(ops) if op[0] == "proc"]
+    cut = procs[int(rng.integers(1, len(procs) - 1))] + 1      # right after a call; setters may follow before the next one
+    total = sum(op[1] for op in ops if op[0] == "proc")
+    nch = 40
+    iq = synth_iq(nch, total * 128)
+    dev = torch.from_numpy(iq).cuda()
+    piped = bool(seed % 2)
+
+    def fresh_out():
+        return torch.zeros((nch, total * 32, 2), dtype=torch.int16, device="cuda")
+
+    a, out_a = make_chain(nch, piped, 0), fresh_out()
+    run_ops(a, rdsp, torch, ops, dev, out_a)
+    a.flush()
+    b, out_b = make_chain(nch, piped, 0), fresh_out()
+    pos = run_ops(b, rdsp, torch, ops[:cut], dev, out_b)
+    blob = b.save_state()
+    c, out_c = make_chain(nch, piped, 0), fresh_out()
+    for op in ops[:cut]:
+        if op[0] != "proc":
+            apply_setter(c, rdsp, op)
+    c.load_state(blob)
+    run_ops(c, rdsp, torch, ops[cut:], dev, out_c, pos)
+    c.flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(out_c.cpu().numpy()[:, pos * 32:], out_a.cpu().numpy()[:, pos * 32:])
+    assert np.array_equal(c.save_state(), a.save_state())
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
