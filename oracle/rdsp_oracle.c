@@ -447,6 +447,8 @@ float orc_chain_nb_level(const orc_chain_t *c) { return c->nb_level; }
 /* SDR.setAGCmode / disableAGC (INO:120-121, CTL:196-232) and the spectral stage's switch and level
  * (SPEC:112 iNRLevel; CTL:237-297) between calls: plain configuration, the states (gain, NFloor) stay */
 void orc_set_agc_mode(orc_chain_t *c, int mode) { c->cfg.agc_mode = mode; }
+/* bFilterEnabled of doConvolutionalProcessing (CONV:228,300): read by every frame */
+void orc_set_filter_on(orc_chain_t *c, int on) { c->cfg.filter_on = on ? 1 : 0; }
 /* SDR.enableALSfilter / disableALSfilter / setALSfilterNotch / setALSfilterPeak (CTL:250-261): which
  * of the instance's two outputs is taken, or none; the instance's weights and delay line stay */
 void orc_set_als_mode(orc_chain_t *c, int mode) { c->cfg.als_mode = mode; }

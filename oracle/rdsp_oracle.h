@@ -114,6 +114,7 @@ void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db);
 float orc_chain_nb_level(const orc_chain_t *c);
 void orc_set_gains(orc_chain_t *c, float input_gain, float iq_balance, float output_gain, int mute);
 void orc_set_agc_mode(orc_chain_t *c, int mode);
+void orc_set_filter_on(orc_chain_t *c, int on);
 void orc_set_als_mode(orc_chain_t *c, int mode);
 void orc_set_spectral_nr(orc_chain_t *c, int on, float level);
 /* SAM PLL loop constants at the decimated rate (build-defined, see rdsp_oracle.c) */

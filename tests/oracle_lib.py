@@ -132,6 +132,7 @@ def load(path=None):
     lib.orc_set_noise_blanker.argtypes = [vp, C.c_int, C.c_float]
     lib.orc_set_gains.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int]
     lib.orc_set_agc_mode.argtypes = [vp, C.c_int]
+    lib.orc_set_filter_on.argtypes = [vp, C.c_int]
     lib.orc_set_als_mode.argtypes = [vp, C.c_int]
     lib.orc_set_spectral_nr.argtypes = [vp, C.c_int, C.c_float]
     lib.orc_chain_nb_level.argtypes = [vp]
@@ -217,6 +218,9 @@ class OracleChain:
 
     def set_agc_mode(self, mode):
         self.lib.orc_set_agc_mode(self.h, int(mode))
+
+    def set_filter_on(self, on):
+        self.lib.orc_set_filter_on(self.h, int(bool(on)))
 
     def set_als_mode(self, mode):
         self.lib.orc_set_als_mode(self.h, int(mode))

@@ -223,10 +223,12 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
     band = [(300.0, 2700.0)] * n_groups
     gains = dict(input_gain=1.0, iq_balance=1.0, output_gain=0.5, mute=False)
     for _ in range(n_ops):
-        kind = str(rng.choice(["proc", "proc", "proc", "mode", "filt", "pbt", "nco", "swap", "nb", "gain", "agc", "spec"]))
+        kind = str(rng.choice(["proc", "proc", "proc", "dcp", "mode", "filt", "pbt", "nco", "swap", "nb", "gain", "agc", "spec"]))
         g = int(rng.integers(0, n_groups))
         if kind == "proc":
             ops.append(("proc", granule * int(rng.integers(1, 4))))
+        elif kind == "dcp":     # the reference-shaped call, bFilterEnabled per call (CONV:228,300)
+            ops.append(("dcp", granule * int(rng.integers(1, 3)), bool(rng.integers(0, 2))))
         elif kind == "mode":
             filt, demod = int(rng.integers(0, 5)), str(rng.choice(["USB", "LSB", "CW_USB", "CW_LSB", "AM"]))
             band[g] = oracle.passband(filt, rdsp.DEMOD[demod])
@@ -274,7 +276,7 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
                 window=int(rng.choice([1, 2, 4])))
     granule = max(8, base["fft_l"] // 64)   # an overlap-save hop of FFT_L / 2 samples at 24 kHz and the front kernel's 1024-sample chunk, in 128-sample blocks
     ops = _oracle_script(rng, oracle, rdsp, n_groups, granule)
-    total = sum(op[1] for op in ops if op[0] == "proc")
+    total = sum(op[1] for op in ops if op[0] in ("proc", "dcp"))
     iq = synth_iq(nch, total * 128)
     for c in range(nch):
         for p in rng.integers(3000, iq.shape[1] - 4, 10):
@@ -296,6 +298,20 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
             got.append(ch.process(dev[:, pos * 128:(pos + n) * 128], want_f32=True)[1])
             for c in range(nch):
                 ref[c].append(ocs[c].process(iq[c, pos * 128:(pos + n) * 128])[1])
+            pos += n
+        elif k == "dcp":        # doConvolutionalProcessing(nr_level, bFilterEnabled, lo, hi): int16 audio only
+            n, f = op[1], op[2]
+            o16 = ch.doConvolutionalProcessing(0, f, 0.0, 0.0, dev[:, pos * 128:(pos + n) * 128])
+            ch.flush()
+            torch.cuda.synchronize()
+            o16 = o16.cpu().numpy()
+            for c in range(nch):
+                ocs[c].set_filter_on(f)
+                r16, r32 = ocs[c].process(iq[c, pos * 128:(pos + n) * 128])
+                d = np.abs(o16[c].astype(np.int32) - r16.astype(np.int32)).max()
+                assert d <= max(1, int(np.ceil(2 * TOL * 32768 * np.abs(r32).max()))), (seed, op, c, d)
+                ref[c].append(r32)
+            got.append(torch.zeros((nch, n * 128 // 4, 2), dtype=torch.float32, device="cuda") + float("nan"))
             pos += n
         elif k == "mode":
             ch.group_setAudioFilter(op[1], op[2])
@@ -345,6 +361,7 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
     for c in range(nch):
         r = np.concatenate(ref[c])
         e = np.abs(got[c] - r).max(axis=1) / np.abs(r).max()
+        e = np.where(np.isnan(e), 0.0, e)      # the reference-shaped calls were checked on their int16 audio
         per_hop = e[:len(e) // hop * hop].reshape(-1, hop).max(axis=1)
         bad = per_hop > TOL
         if base["spectral_nr"] or any(op[0] == "spec" and op[1] for op in ops):
