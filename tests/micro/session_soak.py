@@ -1,5 +1,9 @@
 """Soak run of the randomised control sessions (tests/test_random_sessions.py) over many seeds:
-python tests/micro/session_soak.py <first_seed> <count> [channels].  Not part of the suite."""
+python tests/micro/session_soak.py <first_seed> <count> [channels].  Not part of the suite.
+The bitwise kinds (plain / pipelined / re-partitioned, checkpoint / resume) must never fail.  The two
+that compare float32 implementations have statistical tails: in 400 sessions each, one oracle session had a
+spectral-threshold hop of 1.9e-3, and two switching sessions missed the truth-anchored criterion by a hair
+(worst channel 1.44e-5 against 1.5 x 9.46e-6; one channel at 3.9 x its own oracle distance)."""
 import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import radiodsp_sdr_rx_amd as R
