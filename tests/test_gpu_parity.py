@@ -169,6 +169,10 @@ FF_CASES = {
     "conv_literal_256": (CONV_LITERAL, 3, 16, False),
     "conv_literal_512": (dict(CONV_LITERAL, fft_l=512), 2, 16, False),
     "conv_literal_4096": (dict(CONV_LITERAL, fft_l=4096), 2, 64, False),
+    # the spectral-NR variant of the in-tree loop as the file has it (SPEC:112-269: native rate, FFT_L 256,
+    # no filter mask, iNRLevel 2) and the older one (BK_INO:1520-1669) at the native rate
+    "spec_literal_256": (dict(CONV_LITERAL, filter_on=0, spectral_nr=1, spectral_level=2.0), 3, 32, False),
+    "spec_old_literal_256": (dict(CONV_LITERAL, spectral_nr=2), 2, 32, False),
     "k1_one_channel": (K1, 1, 16, False),
     "k2_usb_256": (K1, 5, 32, False),
     "usb_512": (dict(fft_l=512, demod="USB"), 4, 32, False),
