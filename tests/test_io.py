@@ -198,3 +198,41 @@ def test_runner_argument_errors(rdsp, torch_cuda):
     iq = synth_iq(2, 16 * 128)
     with pytest.raises(RdspError):
         stream_memory(Chain(2, max_blocks_per_call=16, **K1), iq, 12)     # not a granule multiple
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_memory_runner_random_shapes_match_resident_processing(rdsp, torch_cuda, seed):
+    """the runner's three streams and two slots over random batch sizes, stream lengths (a ragged last batch,
+    trailing blocks short of a granule), channel counts and chains, pipelined or not, pageable or page-locked
+    arrays: bit-identical to the same batches processed resident in HBM"""
+    torch = torch_cuda
+    from cases import K3
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.io import stream_memory
+    rng = np.random.default_rng(seed)
+    cfg = [K1, K3, dict(fft_l=1024, demod="LSB", flo_hz=-2700.0, fhi_hz=-300.0, agc_mode="fast")][seed % 3]
+    gran = max(8, cfg["fft_l"] // 64)
+    nch = int(rng.integers(1, 40))
+    per = gran * int(rng.integers(1, 5))
+    nblk = int(rng.integers(per, 9 * per)) + int(rng.integers(0, gran))     # not a multiple of anything in general
+    piped = bool(rng.integers(0, 2))
+    iq = synth_iq(nch, nblk * 128)
+    src = torch.from_numpy(iq).pin_memory() if seed % 2 else iq
+    ch = Chain(nch, max_blocks_per_call=per, **cfg)
+    ch.set_pipelined(piped)
+    out, st = stream_memory(ch, src, per)
+    out = out.numpy() if hasattr(out, "numpy") else out
+    exp = nblk // gran * gran
+    assert st["blocks"] == exp and st["samples_out"] == exp * 32
+    out = out[:, :exp * 32]            # the array is sized for the whole input; trailing blocks short of a granule are not processed
+    rc = Chain(nch, max_blocks_per_call=per, **cfg)
+    rc.set_pipelined(piped)
+    parts, pos = [], 0
+    while pos < exp:
+        take = min(per, exp - pos)
+        parts.append(rc.process(torch.from_numpy(np.ascontiguousarray(iq[:, pos * 128:(pos + take) * 128])).cuda()))
+        pos += take
+    rc.flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(out, np.concatenate([p.cpu().numpy() for p in parts], 1))
