@@ -52,6 +52,14 @@ for seed in range(first, first + count):
         print("seeds", first, "..", seed, "done,", bad, "mismatches", flush=True)
 print("soak:", count, "sessions,", bad, "mismatches")
 
+if len(sys.argv) > 4 and sys.argv[4] == "bitwise":   # only the kinds that must never fail
+    for seed in range(first, first + count):
+        try:
+            m.test_random_session_resumed_from_a_checkpoint_is_bit_exact(R, seed)
+        except AssertionError as e:
+            print("FAIL resume seed", seed, flush=True)
+    print("soak resume:", count, "sessions done")
+    sys.exit(0)
 # the oracle-checked sessions and the truth-anchored switching sessions over the same seed range
 import oracle_lib
 oracle_lib.build()
