@@ -382,6 +382,7 @@ int rdsp_input_node_push(rdsp_node_t *n, const int16_t *i_tile, const int16_t *q
 rdsp_node_t *rdsp_sdr_node_create(rdsp_graph_t *g, rdsp_chain_t *chain);
 int rdsp_sdr_node_status(rdsp_node_t *n);
 int rdsp_chain_decim(const rdsp_chain_t *c);
+int rdsp_chain_device(const rdsp_chain_t *c);   /* the device index given to rdsp_chain_create */
 
 /* ---- F1: IQ panadapter spectrum analyser (AudioAnalyzeFFT256IQ, FFTIQ.h:52-110) ----
  * Integer q15 path batched over channels; bit-exact against the oracle.  window_id:
@@ -391,6 +392,7 @@ typedef struct rdsp_spectrum rdsp_spectrum_t;
 void rdsp_window_q15(int window_id, int16_t *w256);
 int rdsp_spectrum_create(int n_channels, int device, int naverage, int window_id, rdsp_spectrum_t **out);
 void rdsp_spectrum_destroy(rdsp_spectrum_t *s);
+int rdsp_spectrum_device(const rdsp_spectrum_t *s);
 int rdsp_spectrum_averageTogether(rdsp_spectrum_t *s, int n);      /* FFTIQ.h:88 */
 int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id); /* FFTIQ.h:93 */
 int rdsp_spectrum_outputs_for(const rdsp_spectrum_t *s, int n_blocks);

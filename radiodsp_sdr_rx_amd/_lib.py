@@ -126,6 +126,8 @@ SYMBOLS = [
     ("rdsp_chain_set_timing", _i, [_vp, _i]),
     ("rdsp_chain_get_timing", _i, [_vp, _f64p, _f64p, C.POINTER(C.c_int)]),
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
+    ("rdsp_chain_device", _i, [_vp]),
+    ("rdsp_spectrum_device", _i, [_vp]),
     ("rdsp_chain_state_bytes", C.c_size_t, [_vp, _i]),
     ("rdsp_chain_save_state", _i, [_vp, _i, _i, _vp, C.c_size_t, _vp]),
     ("rdsp_chain_load_state", _i, [_vp, _i, _vp, C.c_size_t, _vp]),

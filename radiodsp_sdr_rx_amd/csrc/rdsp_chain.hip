@@ -480,6 +480,7 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
 
 extern "C" int rdsp_chain_channels(const rdsp_chain_t *c) { return c ? c->n_channels : 0; }
 extern "C" int rdsp_chain_decim(const rdsp_chain_t *c) { return c ? c->decim : 0; }
+extern "C" int rdsp_chain_device(const rdsp_chain_t *c) { return c ? c->device : -1; }
 
 extern "C" int rdsp_chain_granule_blocks(const rdsp_chain_t *c) {
   if (!c) return 0;

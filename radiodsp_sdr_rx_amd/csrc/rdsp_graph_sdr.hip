@@ -26,12 +26,14 @@ struct SdrNode {
   std::vector<int16_t> h_out; /* [ch][gran*128/decim][2] */
   int16_t *d_iq = nullptr, *d_out = nullptr;
   hipStream_t stream = nullptr;
+  int device = 0;
   std::deque<std::vector<int16_t>> out_l, out_r; /* audio tiles waiting for a tick */
   int status = RDSP_OK;
 };
 
 void sdr_destroy(void *u) {
   SdrNode *s = static_cast<SdrNode *>(u);
+  (void)hipSetDevice(s->device);
   if (s->d_iq) (void)hipFree(s->d_iq);
   if (s->d_out) (void)hipFree(s->d_out);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -61,8 +63,9 @@ void sdr_update(rdsp_node_t *n, void *u) {
   if (s->have == s->gran) {
     const size_t in_row = (size_t)s->gran * RDSP_BLOCK_SAMPLES;
     const size_t out_row = in_row / (size_t)s->decim;
-    hipError_t e = hipMemcpyAsync(s->d_iq, s->h_iq.data(), s->h_iq.size() * sizeof(int16_t),
-                                  hipMemcpyHostToDevice, s->stream);
+    hipError_t e = hipSetDevice(s->device);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(s->d_iq, s->h_iq.data(), s->h_iq.size() * sizeof(int16_t), hipMemcpyHostToDevice, s->stream);
     int rc = RDSP_OK;
     if (e == hipSuccess)
       rc = rdsp_chain_process(s->chain, s->d_iq, in_row, s->gran, s->d_out, out_row, nullptr, s->stream);
@@ -123,7 +126,9 @@ extern "C" rdsp_node_t *rdsp_sdr_node_create(rdsp_graph_t *g, rdsp_chain_t *chai
   const size_t in_n = (size_t)s->n_channels * s->gran * RDSP_BLOCK_SAMPLES * 2;
   s->h_iq.assign(in_n, 0);
   s->h_out.assign(in_n / s->decim, 0);
-  if (hipMalloc((void **)&s->d_iq, in_n * sizeof(int16_t)) != hipSuccess ||
+  s->device = rdsp_chain_device(chain); /* the node's buffers and stream live where the chain does */
+  if (hipSetDevice(s->device) != hipSuccess ||
+      hipMalloc((void **)&s->d_iq, in_n * sizeof(int16_t)) != hipSuccess ||
       hipMalloc((void **)&s->d_out, in_n / s->decim * sizeof(int16_t)) != hipSuccess ||
       hipStreamCreate(&s->stream) != hipSuccess) {
     rdsp_set_error("rdsp_sdr_node_create: device allocation failed");
@@ -159,12 +164,14 @@ struct SpectrumNode {
   int16_t *d_iq = nullptr;
   uint16_t *d_out = nullptr;
   hipStream_t stream = nullptr;
+  int device = 0;
   int outputflag = 0;             /* FFTIQ.h:63 */
   int status = RDSP_OK;
 };
 
 void spectrum_destroy(void *u) {
   SpectrumNode *s = static_cast<SpectrumNode *>(u);
+  (void)hipSetDevice(s->device);
   if (s->d_iq) (void)hipFree(s->d_iq);
   if (s->d_out) (void)hipFree(s->d_out);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -191,7 +198,9 @@ void spectrum_update(rdsp_node_t *n, void *u) {
   rdsp_release(bi); /* FFTIQ.cpp:114-115 (the previous block lives on the device) */
   rdsp_release(bq);
   int n_out = 0;
-  hipError_t e = hipMemcpyAsync(s->d_iq, s->h_iq.data(), s->h_iq.size() * sizeof(int16_t), hipMemcpyHostToDevice, s->stream);
+  hipError_t e = hipSetDevice(s->device);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(s->d_iq, s->h_iq.data(), s->h_iq.size() * sizeof(int16_t), hipMemcpyHostToDevice, s->stream);
   int rc = RDSP_OK;
   if (e == hipSuccess)
     rc = rdsp_spectrum_update(s->spec, s->d_iq, RDSP_BLOCK_SAMPLES, 1, s->d_out, 1, &n_out, s->stream);
@@ -217,7 +226,9 @@ extern "C" rdsp_node_t *rdsp_spectrum_node_create(rdsp_graph_t *g, rdsp_spectrum
   s->n_channels = rdsp_graph_channels(g);
   s->h_iq.assign((size_t)s->n_channels * RDSP_BLOCK_SAMPLES * 2, 0);
   s->h_out.assign((size_t)s->n_channels * 256, 0);
-  if (hipMalloc((void **)&s->d_iq, s->h_iq.size() * sizeof(int16_t)) != hipSuccess ||
+  s->device = rdsp_spectrum_device(spec);
+  if (hipSetDevice(s->device) != hipSuccess ||
+      hipMalloc((void **)&s->d_iq, s->h_iq.size() * sizeof(int16_t)) != hipSuccess ||
       hipMalloc((void **)&s->d_out, s->h_out.size() * sizeof(uint16_t)) != hipSuccess ||
       hipStreamCreate(&s->stream) != hipSuccess) {
     rdsp_set_error("rdsp_spectrum_node_create: device allocation failed");

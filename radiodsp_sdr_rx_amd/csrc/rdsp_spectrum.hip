@@ -242,6 +242,7 @@ extern "C" int rdsp_spectrum_create(int n_channels, int device, int naverage, in
   return RDSP_OK;
 }
 
+extern "C" int rdsp_spectrum_device(const rdsp_spectrum_t *s) { return s ? s->device : -1; }
 extern "C" void rdsp_spectrum_destroy(rdsp_spectrum_t *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);

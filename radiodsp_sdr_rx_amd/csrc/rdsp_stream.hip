@@ -42,6 +42,12 @@ extern "C" int rdsp_stream_run(rdsp_chain_t *c, rdsp_source_fn source, void *sou
     rdsp_set_error("blocks_per_call %d is not a multiple of the granule %d", blocks_per_call, gran);
     return RDSP_ERR_NOT_READY;
   }
+  /* the runner's buffers, streams and events live on the chain's device, whatever the calling thread had
+   * selected (a host that drives several GPUs from one process) */
+  if (hipSetDevice(rdsp_chain_device(c)) != hipSuccess) {
+    rdsp_set_error("hipSetDevice(%d) failed", rdsp_chain_device(c));
+    return RDSP_ERR_HIP;
+  }
   const int nch = rdsp_chain_channels(c);
   const int decim = rdsp_chain_decim(c);
   const size_t in_stride = (size_t)blocks_per_call * RDSP_BLOCK_SAMPLES; /* IQ pairs per channel row */
@@ -267,6 +273,10 @@ static int stream_pinned(rdsp_chain_t *c, const int16_t *host_iq, size_t in_stri
   if (blocks_per_call <= 0 || blocks_per_call % gran != 0) {
     rdsp_set_error("blocks_per_call %d is not a multiple of the granule %d", blocks_per_call, gran);
     return RDSP_ERR_NOT_READY;
+  }
+  if (hipSetDevice(rdsp_chain_device(c)) != hipSuccess) {
+    rdsp_set_error("hipSetDevice(%d) failed", rdsp_chain_device(c));
+    return RDSP_ERR_HIP;
   }
   const int nch = rdsp_chain_channels(c), decim = rdsp_chain_decim(c);
   const size_t d_in = (size_t)blocks_per_call * RDSP_BLOCK_SAMPLES, d_out = d_in / (size_t)decim;
