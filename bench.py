@@ -321,8 +321,10 @@ def main():
         chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]
-        if v == "1step":      # round 1's tail kernel: one reduction per step
+        if v == "1step":      # round 1's tail kernel: one reduction per step (EXPERIMENTAL builds)
             chain.set_tail_variant(16, 3)
+        elif v == "lookahead":  # round 3: weights one block stale (EXPERIMENTAL builds)
+            chain.set_tail_variant(16, 4)
         elif v.endswith("r"):   # row layouts: "16r", "8r"
             chain.set_tail_variant(int(v[:-1]), 2)
         else:

@@ -246,10 +246,10 @@ int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio
  * split gives the same bits.  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless
  * the tail stage shares the SIMDs. */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant);
-/* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row,
- * DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: lanes per channel 16 or 8;
- * matrix_reduce 0: delay line shifted by DPP (experimental/rdsp_tail_shift.hip), 2: row / half-row
- * layout, 1: cross-lane sums on the matrix pipe */
+/* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row, two
+ * steps per DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: (16, 4) weights one block
+ * stale with a hand-interleaved issue order, (16, 3) one reduction per step, (8, 2) half a row per
+ * channel, (16 | 8, 1) cross-lane sums on the matrix pipe, (16, 0) delay line shifted by DPP */
 int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce);
 
 /* ---- per-kernel timing (HIP events on the launch stream; measurement only) ---*/

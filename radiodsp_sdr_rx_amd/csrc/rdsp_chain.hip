@@ -1274,27 +1274,31 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   c->fir_mode = variant;
   return RDSP_OK;
 }
-/* tail-kernel variant: 16 lanes per channel with the DPP reduction (rdsp_tail.hip), or 16 / 8
- * lanes with the reduction on the matrix pipe (rdsp_tailm.hip); all compute the same
- * recursion, the sums associate differently */
+/* tail-kernel variant.  (16, 2) is the product (rdsp_tail.hip: a channel per 16-lane DPP row, two
+ * steps per reduction).  EXPERIMENTAL=1 builds: (16, 4) weights one block stale with a hand-interleaved
+ * issue order (round 3), (16, 3) one reduction per step (round 1), (8, 2) half a row per channel,
+ * (16 | 8, 1) the reduction on the matrix pipe, (16, 0) the delay line shifted by DPP.  All compute
+ * the same recursion; the sums associate differently. */
 extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce) {
   NEED(c);
-  if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce)) return RDSP_ERR_INVALID;
-  if (lanes_per_channel == 16 && matrix_reduce == 3) { /* the one-reduction-per-step kernel of round 1 (A/B runs) */
-    if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
-    c->tail_lpc = 102;
-    return RDSP_OK;
-  }
+  if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce) ||
+      matrix_reduce < 0 || matrix_reduce > 4 || (lanes_per_channel == 8 && matrix_reduce > 2))
+    return RDSP_ERR_INVALID;
+  int v;
+  if (lanes_per_channel == 16 && matrix_reduce == 2) v = 100;
+  else {
 #ifndef RDSP_EXPERIMENTAL
-  if (!(lanes_per_channel == 16 && matrix_reduce == 2)) {
-    rdsp_set_error("tail-kernel layouts other than the 16-lane row are only in EXPERIMENTAL=1 builds of the library");
+    rdsp_set_error("tail-kernel variants other than the product's are only in EXPERIMENTAL=1 builds of the library");
     return RDSP_ERR_UNSUPPORTED;
-  }
+#else
+    if (matrix_reduce == 4) v = 104;
+    else if (matrix_reduce == 3) v = 102;
+    else if (matrix_reduce == 2) v = 101;
+    else v = lanes_per_channel + (matrix_reduce ? 100 : 0);
 #endif
+  }
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
-  /* matrix_reduce 2: the row layouts of rdsp_tailm.hip (DPP reduction, delay line fed from LDS):
-   * a whole DPP row of 16 lanes per channel, or half a row */
-  c->tail_lpc = (matrix_reduce == 2) ? (lanes_per_channel == 8 ? 101 : 100) : lanes_per_channel + (matrix_reduce ? 100 : 0);
+  c->tail_lpc = v;
   return RDSP_OK;
 }
 /* `stream` waits for every call issued so far (outputs complete after it) */
