@@ -323,6 +323,8 @@ def main():
         v = os.environ["RDSP_TAIL_VARIANT"]
         if v == "1step":      # round 1's tail kernel: one reduction per step (EXPERIMENTAL builds)
             chain.set_tail_variant(16, 3)
+        elif v == "4step":      # round 3: four steps per reduction (EXPERIMENTAL builds)
+            chain.set_tail_variant(16, 5)
         elif v == "lookahead":  # round 3: weights one block stale (EXPERIMENTAL builds)
             chain.set_tail_variant(16, 4)
         elif v.endswith("r"):   # row layouts: "16r", "8r"

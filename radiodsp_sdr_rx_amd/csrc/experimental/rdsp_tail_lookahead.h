@@ -8,6 +8,13 @@
  * correlations) plus four more instructions per block cost more than the shorter chain saves:
  * 1.008 ms alone against 0.912 ms, pipelined K3 1.39 ms against 1.21 ms (same box).
  * Included by ../rdsp_tail.hip in EXPERIMENTAL=1 builds (variant 104).
+ *
+ * NlmsQ below (variant 105): four steps per reduction -- one transposing 16-lane reduction of depth 4
+ * per four steps.  Its step loop is 21 % shorter than NlmsB's (tests/micro/lone_wave.hip: 355 cycles
+ * per four steps against 2 x 225), but it needs the same four prefix scans as NlmsL, and those plus
+ * the exact restart of the three correlations cost 2 900 cycles per 128-step block outside the loop
+ * (s_memtime phases, tests/micro/tail_phases.sh): 0.927 ms alone against 0.901 ms, 2.39e8 VALU
+ * instructions per launch against 2.18e8, pipelined K3 1.24 ms against 1.17 ms.  MEASURED, NOT ADOPTED.
  */
 /* ---- NlmsL: weights one block stale, hand-interleaved issue order (the product) ---------------
  * Lane layout and sample pairs as NlmsB; the pair ring has 16 slots because a block's update runs
@@ -219,6 +226,209 @@ struct NlmsL {
   static __device__ __forceinline__ float4 out4(const float *, const float *scr, int i) {
     const v2f a = *reinterpret_cast<const v2f *>(scr + 4 * i + 6), b = *reinterpret_cast<const v2f *>(scr + 4 * i + 14);
     return make_float4(a[0], a[1], b[0], b[1]);
+  }
+};
+
+
+/* ---- NlmsQ: four steps per reduction ----------------------------------------------------------
+ * With W the weights after update n-1, four consecutive outputs are
+ *     y_n     = W.X_n
+ *     y_{n+1} = W.X_{n+1} + g_n R1(n+1)
+ *     y_{n+2} = W.X_{n+2} + g_n R2(n+2) + g_{n+1} R1(n+2)
+ *     y_{n+3} = W.X_{n+3} + g_n R3(n+3) + g_{n+1} R2(n+3) + g_{n+2} R1(n+3),     R_L(m) = X_{m-L}.X_m,
+ * so the four dot products share the weights: two packed accumulators (A_n, A_{n+1}), (A_{n+2},
+ * A_{n+3}) and ONE transposing 16-lane reduction of depth 4 per four steps (8 DPP adds: lanes 0-3
+ * end up with A_n, 4-7 with A_{n+2}, 8-11 with A_{n+1}, 12-15 with A_{n+3}) where NlmsB runs its
+ * 5-deep one every two steps -- a dependent DPP costs a lone wave 16.4 cycles, and the reduction
+ * was 40 % of NlmsB's dependency chain.  The energy E and the lag-1..3 correlations come from four
+ * DPP prefix scans per 128 steps (prepare).  Per four steps: 12 + 8 + 4 + 10 + 12 = 46 VALU
+ * instructions against 2 x 25.5, 8 LDS instructions against 8.6. */
+__device__ __forceinline__ float reduce_quarters(v2f a, v2f b) {
+  float ta, tb, u;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t" /* lanes 0-3, 8-11 take lane + 4 */
+      "v_add_f32_dpp %2, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"  /* lanes 4-7, 12-15 take lane - 4 */
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(ta), "=&v"(tb), "=&v"(u)
+      : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+  return u;
+}
+
+struct NlmsQ {
+  static constexpr int TPL = 6, REC = 12;              /* floats per four-step record */
+  static constexpr int SCR = REC * (RDSP_BLOCK / 4);   /* one 128-step block of records */
+  static constexpr int LDS_SCR = SCR + REC;            /* + one record: the last block's look-ahead reads */
+  static constexpr bool OUT_IN_SCR = false;
+  v2f w2[TPL / 2];
+  v2f P[16]; /* Pair(m) = (mine[m], mine[m+1]) at slot m & 15; a block at n uses Pair(n-5 .. n+2) */
+  float energy;
+
+  static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) { return v2f{mine[m], mine[m + 1]}; }
+  __device__ __forceinline__ void load(const float *wst, const float *est, size_t ch, int sub) {
+#pragma unroll
+    for (int t = 0; t < TPL; t++) w2[t >> 1][t & 1] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))];
+    energy = est[ch];
+  }
+  __device__ __forceinline__ void store(float *wst, float *est, size_t ch, int sub) {
+#pragma unroll
+    for (int t = 0; t < TPL; t++) wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))] = w2[t >> 1][t & 1];
+    if (sub == 0) est[ch] = energy;
+  }
+
+  /* the 16 lanes of a channel prepare the 128 steps of a block, eight consecutive steps (two
+   * records) each: E, R1, R2, R3 by prefix sums of their increments  x_n x_{n-L} - x_{n-96} x_{n-96-L}
+   * (inside the lane, then one DPP scan of the lane totals over the row each).  Record of the block
+   * at n:  { c_n .. c_{n+3} | R1(n+1) R1(n+2) R1(n+3) R2(n+2) | R2(n+3) R3(n+3) - - },  c = mu / (E + eps).
+   * Returns E_127. */
+  static __device__ __forceinline__ float prepare(const float *cur, int sub, float mu, const float (&base)[4],
+                                                  float *scr) {
+    const float *x = cur + 8 * sub; /* the previous block sits right below the current one */
+    float xs[11], qs[11];           /* xs[3 + k] = x[k], k = -3..7; qs likewise 96 samples earlier */
+    {
+      const float4 a = *reinterpret_cast<const float4 *>(x - 4), b = *reinterpret_cast<const float4 *>(x),
+                   c = *reinterpret_cast<const float4 *>(x + 4);
+      const float4 d = *reinterpret_cast<const float4 *>(x - 100), e = *reinterpret_cast<const float4 *>(x - 96),
+                   f = *reinterpret_cast<const float4 *>(x - 92);
+      xs[0] = a.y; xs[1] = a.z; xs[2] = a.w; xs[3] = b.x; xs[4] = b.y; xs[5] = b.z; xs[6] = b.w;
+      xs[7] = c.x; xs[8] = c.y; xs[9] = c.z; xs[10] = c.w;
+      qs[0] = d.y; qs[1] = d.z; qs[2] = d.w; qs[3] = e.x; qs[4] = e.y; qs[5] = e.z; qs[6] = e.w;
+      qs[7] = f.x; qs[8] = f.y; qs[9] = f.z; qs[10] = f.w;
+    }
+    float val[4][8];
+#pragma unroll
+    for (int L = 0; L < 4; L++) {
+      float a[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float d = fmaf(xs[3 + k], xs[3 + k - L], -(qs[3 + k] * qs[3 + k - L]));
+        a[k] = (k == 0) ? d : a[k - 1] + d;
+      }
+      float in = a[7]; /* inclusive scan of the lane totals over the row: row_shr 1, 2, 4, 8 */
+      in += dpp0_f<0x111>(in);
+      in += dpp0_f<0x112>(in);
+      in += dpp0_f<0x114>(in);
+      in += dpp0_f<0x118>(in);
+      const float off = base[L] + (in - a[7]); /* everything before this lane */
+#pragma unroll
+      for (int k = 0; k < 8; k++) val[L][k] = off + a[k];
+    }
+    float4 *rec = reinterpret_cast<float4 *>(scr) + 6 * sub; /* records 2 sub, 2 sub + 1 */
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      float c[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) c[k] = mu * __builtin_amdgcn_rcpf(val[0][4 * b + k] + 0.000000119209289f);
+      rec[3 * b] = make_float4(c[0], c[1], c[2], c[3]);
+      rec[3 * b + 1] = make_float4(val[1][4 * b + 1], val[1][4 * b + 2], val[1][4 * b + 3], val[2][4 * b + 2]);
+      rec[3 * b + 2] = make_float4(val[2][4 * b + 3], val[3][4 * b + 3], 0.f, 0.f);
+    }
+    return dpp_f<0x15F>(val[0][7]); /* row_newbcast:15: E_127 to every lane of the channel */
+  }
+
+  template <bool OUT_E>
+  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr, int sub) {
+    const float *cur = ring + RDSP_BLOCK;
+    const float *dsrc = first ? cur : ring; /* NR:69-79 */
+    const float *mine = cur - TPL * sub;
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    const float *mine_b = mine + zero; /* an opaque copy: the even pairs are read through it, or the
+                                          compiler shares dwords between overlapping pair reads and
+                                          glues the pairs with v_mov (VALU work on the chain) */
+    {
+      /* R_L(-1) = X_{-1-L}.X_{-1} recomputed exactly at every block (only E is a running sum over
+       * the whole stream, like the energy of arm_lms_norm_f32) */
+      float m[9];
+#pragma unroll
+      for (int t = 0; t < 9; t++) m[t] = mine[-1 - t];
+      float b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+      for (int t = 0; t < TPL; t++) {
+        b1 = fmaf(m[t], m[t + 1], b1);
+        b2 = fmaf(m[t], m[t + 2], b2);
+        b3 = fmaf(m[t], m[t + 3], b3);
+      }
+      const float base[4] = {energy, row_allsum(b1), row_allsum(b2), row_allsum(b3)};
+      energy = prepare(cur, sub, mu, base, scr);
+    }
+#pragma unroll
+    for (int m = -5; m <= 2; m++) P[m & 15] = pair_ld((m & 1) ? mine : mine_b, m);
+    __syncthreads();
+    const float4 *rp = reinterpret_cast<const float4 *>(scr);
+    float4 ra = rp[0], rb = rp[1], rc = rp[2];
+    float4 dq = *reinterpret_cast<const float4 *>(dsrc);
+#pragma unroll 1
+    for (int c = 0; c < RDSP_BLOCK / 16; c++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int n = 4 * i;      /* block start mod 16 (the ring slots repeat every 16 steps) */
+        const int s = 16 * c + n; /* block start inside the 128-sample block */
+        const float cc[4] = {ra.x, ra.y, ra.z, ra.w}, dd[4] = {dq.x, dq.y, dq.z, dq.w};
+        const float r1_1 = rb.x, r1_2 = rb.y, r1_3 = rb.z, r2_2 = rb.w, r2_3 = rc.x, r3_3 = rc.y;
+        /* look-ahead reads: the next record and desired samples, the four pairs the next block adds
+         * (into the slots of Pair(n-13 .. n-10), long dead) */
+        const float4 na = rp[3 * (s >> 2) + 3], nb = rp[3 * (s >> 2) + 4], nc = rp[3 * (s >> 2) + 5];
+        const float4 nd = *reinterpret_cast<const float4 *>(dsrc + s + 4);
+        P[(n + 3) & 15] = pair_ld(mine, s + 3);
+        P[(n + 4) & 15] = pair_ld(mine_b, s + 4);
+        P[(n + 5) & 15] = pair_ld(mine, s + 5);
+        P[(n + 6) & 15] = pair_ld(mine_b, s + 6);
+        /* (A_n, A_{n+1}) and (A_{n+2}, A_{n+3}) lane parts: taps k = 0..5 against Pair(n - k), Pair(n + 2 - k) */
+        v2f accA = v2f{w2[0][0], w2[0][0]} * P[n & 15];
+        v2f accB = v2f{w2[0][0], w2[0][0]} * P[(n + 2) & 15];
+        accA = __builtin_elementwise_fma(v2f{w2[0][1], w2[0][1]}, P[(n - 1) & 15], accA);
+        accB = __builtin_elementwise_fma(v2f{w2[0][1], w2[0][1]}, P[(n + 1) & 15], accB);
+        accA = __builtin_elementwise_fma(v2f{w2[1][0], w2[1][0]}, P[(n - 2) & 15], accA);
+        accB = __builtin_elementwise_fma(v2f{w2[1][0], w2[1][0]}, P[n & 15], accB);
+        accA = __builtin_elementwise_fma(v2f{w2[1][1], w2[1][1]}, P[(n - 3) & 15], accA);
+        accB = __builtin_elementwise_fma(v2f{w2[1][1], w2[1][1]}, P[(n - 1) & 15], accB);
+        accA = __builtin_elementwise_fma(v2f{w2[2][0], w2[2][0]}, P[(n - 4) & 15], accA);
+        accB = __builtin_elementwise_fma(v2f{w2[2][0], w2[2][0]}, P[(n - 2) & 15], accB);
+        accA = __builtin_elementwise_fma(v2f{w2[2][1], w2[2][1]}, P[(n - 5) & 15], accA);
+        accB = __builtin_elementwise_fma(v2f{w2[2][1], w2[2][1]}, P[(n - 3) & 15], accB);
+        const float u = reduce_quarters(accA, accB);
+        const float dA0 = dd[0] - dpp_f<0x150>(u); /* row_newbcast:0  */
+        const float dA1 = dd[1] - dpp_f<0x158>(u); /* row_newbcast:8  */
+        const float dA2 = dd[2] - dpp_f<0x154>(u); /* row_newbcast:4  */
+        const float dA3 = dd[3] - dpp_f<0x15C>(u); /* row_newbcast:12 */
+        const float g0 = dA0 * cc[0];
+        const float e1 = fmaf(-g0, r1_1, dA1);
+        const float t2 = fmaf(-g0, r2_2, dA2);
+        const float t3 = fmaf(-g0, r3_3, dA3);
+        const float g1 = e1 * cc[1];
+        const float e2 = fmaf(-g1, r1_2, t2);
+        const float t3b = fmaf(-g1, r2_3, t3);
+        const float g2 = e2 * cc[2];
+        const float e3 = fmaf(-g2, r1_3, t3b);
+        const float g3 = e3 * cc[3];
+        *reinterpret_cast<float4 *>(out + s) = OUT_E ? make_float4(dA0, e1, e2, e3)
+                                                     : make_float4(dd[0] - dA0, dd[1] - e1, dd[2] - e2, dd[3] - e3);
+        /* W += sum_j g_{n+j} X_{n+j}: tap pair kk of step j against the swapped Pair(n + j - 2 kk - 1) */
+        const float gj[4] = {g0, g1, g2, g3};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const v2f gg = {gj[j], gj[j]};
+#pragma unroll
+          for (int kk = 0; kk < TPL / 2; kk++) {
+            const v2f pp = P[(n + j - 2 * kk - 1) & 15];
+            w2[kk] = __builtin_elementwise_fma(gg, __builtin_shufflevector(pp, pp, 1, 0), w2[kk]);
+          }
+        }
+        ra = na; rb = nb; rc = nc; dq = nd;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  static __device__ __forceinline__ float4 out4(const float *out, const float *, int i) {
+    return *reinterpret_cast<const float4 *>(out + i);
   }
 };
 

@@ -1276,13 +1276,13 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
 }
 /* tail-kernel variant.  (16, 2) is the product (rdsp_tail.hip: a channel per 16-lane DPP row, two
  * steps per reduction).  EXPERIMENTAL=1 builds: (16, 4) weights one block stale with a hand-interleaved
- * issue order (round 3), (16, 3) one reduction per step (round 1), (8, 2) half a row per channel,
+ * issue order, (16, 5) four steps per reduction (both round 3), (16, 3) one reduction per step (round 1), (8, 2) half a row per channel,
  * (16 | 8, 1) the reduction on the matrix pipe, (16, 0) the delay line shifted by DPP.  All compute
  * the same recursion; the sums associate differently. */
 extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channel, int matrix_reduce) {
   NEED(c);
   if ((lanes_per_channel != 8 && lanes_per_channel != 16) || (lanes_per_channel == 8 && !matrix_reduce) ||
-      matrix_reduce < 0 || matrix_reduce > 4 || (lanes_per_channel == 8 && matrix_reduce > 2))
+      matrix_reduce < 0 || matrix_reduce > 5 || (lanes_per_channel == 8 && matrix_reduce > 2))
     return RDSP_ERR_INVALID;
   int v;
   if (lanes_per_channel == 16 && matrix_reduce == 2) v = 100;
@@ -1291,7 +1291,8 @@ extern "C" int rdsp_chain_set_tail_variant(rdsp_chain_t *c, int lanes_per_channe
     rdsp_set_error("tail-kernel variants other than the product's are only in EXPERIMENTAL=1 builds of the library");
     return RDSP_ERR_UNSUPPORTED;
 #else
-    if (matrix_reduce == 4) v = 104;
+    if (matrix_reduce == 5) v = 105;
+    else if (matrix_reduce == 4) v = 104;
     else if (matrix_reduce == 3) v = 102;
     else if (matrix_reduce == 2) v = 101;
     else v = lanes_per_channel + (matrix_reduce ? 100 : 0);

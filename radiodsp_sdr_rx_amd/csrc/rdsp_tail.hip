@@ -141,6 +141,13 @@ struct NlmsB {
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;
+    /* an opaque copy of the pointer for the even pairs: consecutive pairs overlap by a sample, and
+     * through one pointer the compiler reads the shared dword once and glues the pairs together with
+     * v_mov instructions that wait for the LDS right behind the reads (PMC, round 3: 37 % of the
+     * kernel's wave-cycles were spent in s_waitcnt) */
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    const float *mine_b = mine + zero;
     float bb = 0.f; /* B_{-1} = X_{-2}.X_{-1} */
 #pragma unroll
     for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
@@ -148,7 +155,7 @@ struct NlmsB {
     float e_base = energy;
     prepare(cur, 0, sub, mu, e_base, b_base, scr);
 #pragma unroll
-    for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld(mine, m);
+    for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld((m & 1) ? mine : mine_b, m);
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
       const float *sc = scr + ((s0 / GS) & 1) * SCR;
@@ -175,8 +182,8 @@ struct NlmsB {
           /* the two pairs the block after this one adds go straight into the slots that died two
            * blocks ago (Pair(n-7), Pair(n-6)): a whole block of time for the LDS reads to land */
           if ((n + 3 < GS) || (s0 + GS < RDSP_BLOCK)) {
-            P[(n + 1) & 7] = pair_ld(mine, s0 + n + 1);
-            P[(n + 2) & 7] = pair_ld(mine, s0 + n + 2);
+            P[(n + 1) & 7] = pair_ld(mine, s0 + n + 1);   /* odd: two dwords */
+            P[(n + 2) & 7] = pair_ld(mine_b, s0 + n + 2); /* even */
           }
           /* (A_0, A_1) lane parts: taps k = 0..5 against Pair(n - k) */
           v2f acc = v2f{w2[0][0], w2[0][0]} * P[n & 7];
@@ -219,8 +226,17 @@ struct NlmsB {
 #include "experimental/rdsp_tail_lookahead.h"
 #endif
 
+#ifdef RDSP_TAIL_PROFILE /* measurement builds only (tests/micro/tail_phases.sh): s_memtime around the phases */
+#define RDSP_TP(i) do { const long long tp_now = __builtin_readcyclecounter(); tp_acc[i] += tp_now - tp_last; tp_last = tp_now; } while (0)
+#else
+#define RDSP_TP(i) do { } while (0)
+#endif
+
 template <bool DUAL, typename NL>
 __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
+#ifdef RDSP_TAIL_PROFILE
+  long long tp_acc[4] = {0, 0, 0, 0}, tp_last = __builtin_readcyclecounter();
+#endif
   constexpr int CPW = 4, SPL = RDSP_BLOCK / 16; /* channels per wave, samples per lane per block */
   constexpr int RINGS = DUAL ? 2 : 1;
   constexpr int FIN = NL::OUT_IN_SCR ? 0 : RDSP_BLOCK;
@@ -295,6 +311,7 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
 #pragma unroll 1
   for (int b = 0; b < p.n_blocks; b++) {
     __syncthreads();
+    RDSP_TP(0);
     if constexpr (DUAL) { /* CONV:326-337, then the ALS filter */
       float *o = ringB + RDSP_BLOCK;
       nr.template block<false>(ringA, p.nr_first && b == 0, p.nr_mu, o, scr, sub);
@@ -311,6 +328,7 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
       else als.template block<false>(ringA, o_first && b == 0, o_mu, fin, scr, sub);
     }
     __syncthreads();
+    RDSP_TP(1);
     /* A9 AGC + output gain + A10 pack: lane handles SPL consecutive samples */
     float L[SPL];
 #pragma unroll
@@ -340,6 +358,7 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
         nx1 = n4[1];
       }
     }
+    RDSP_TP(2);
     if (p.raw_out) { /* LMS_NoiseReduction(n, nrbuffer) in isolation, NR:66 */
       if (valid) {
 #pragma unroll
@@ -385,7 +404,13 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
       }
     }
     __syncthreads();
+    RDSP_TP(3);
   }
+#ifdef RDSP_TAIL_PROFILE
+  if (p.out_f32 == nullptr && blockIdx.x == 0 && threadIdx.x == 0) /* phases: top of block | NLMS block() | ring rotation | AGC, pack, stores */
+    printf("tail phases (cycles per 128-step block): top %lld  nlms %lld  rotate %lld  agc/pack %lld\n", tp_acc[0] / p.n_blocks,
+           tp_acc[1] / p.n_blocks, tp_acc[2] / p.n_blocks, tp_acc[3] / p.n_blocks);
+#endif
 
   if (valid) { /* the last block processed is the upper half of the ring */
     if constexpr (DUAL) {
@@ -417,9 +442,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(56))) rdsp_
   tail_body<false, NlmsB>(p);
 }
 #ifdef RDSP_EXPERIMENTAL
-/* weights one block stale (experimental/rdsp_tail_lookahead.h): measured, not adopted */
+/* weights one block stale / four steps per reduction (experimental/rdsp_tail_lookahead.h): measured, not adopted */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(64))) rdsp_tail_lookahead_kernel(RdspTailParams p) {
   tail_body<false, NlmsL>(p);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(64))) rdsp_tail_four_kernel(RdspTailParams p) {
+  tail_body<false, NlmsQ>(p);
 }
 #endif
 
@@ -430,7 +458,8 @@ extern "C" int rdsp_launch_tail_shift(const RdspTailParams *p, hipStream_t strea
 extern "C" int rdsp_launch_tail_layouts(const RdspTailParams *p, int variant, hipStream_t stream); /* experimental/rdsp_tail_layouts.hip */
 #endif
 
-/* variant 100: the product's kernel.  EXPERIMENTAL=1 builds also know 104 (weights one block stale),
+/* variant 100: the product's kernel.  EXPERIMENTAL=1 builds also know 104 (weights one block stale), 105 (four
+ * steps per reduction),
  * 16 (delay line shifted by DPP), 102 (one reduction per step), 101 (half a row per channel),
  * 116 / 108 (16 / 8 lanes with the reduction on the matrix pipe). */
 extern "C" int rdsp_launch_tail(const RdspTailParams *p, int variant, hipStream_t stream) {
@@ -442,9 +471,10 @@ extern "C" int rdsp_launch_tail(const RdspTailParams *p, int variant, hipStream_
     return (int)hipGetLastError();
   }
 #ifdef RDSP_EXPERIMENTAL
-  if (variant == 104) {
+  if (variant == 104 || variant == 105) {
     if (dual) hipLaunchKernelGGL(rdsp_tail_dual_kernel, dim3(grid), dim3(64), 0, stream, *p);
-    else hipLaunchKernelGGL(rdsp_tail_lookahead_kernel, dim3(grid), dim3(64), 0, stream, *p);
+    else if (variant == 104) hipLaunchKernelGGL(rdsp_tail_lookahead_kernel, dim3(grid), dim3(64), 0, stream, *p);
+    else hipLaunchKernelGGL(rdsp_tail_four_kernel, dim3(grid), dim3(64), 0, stream, *p);
     return (int)hipGetLastError();
   }
   if (variant == 16) return rdsp_launch_tail_shift(p, stream);

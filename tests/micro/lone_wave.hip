@@ -182,6 +182,93 @@ __global__ void __launch_bounds__(64) k(float *out, long long *cyc, int iters, f
         ao = an;
       }
       p[0] = an; p[1] = w0; p[2] = w1; p[3] = w2; v[14] += n0[0] + n1[1] + ra.x + rb.y + dd[0];
+    } else if (MODE == 16 || MODE == 17) {
+      // NlmsQ's four-step block as compiled (rdsp_tail.hip): DOT 12 pk, RED 8 DPP + nops, 4 bcast subs,
+      // REC 10, UPD 12 pk.  17: the same plus 9 LDS instructions
+      extern __shared__ float sm[];
+      const int la = (int)(threadIdx.x * 16);
+      v2f w0 = p[1], w1 = p[2], w2 = p[3], aA, aB;
+      float ta, tb, u, d0, d1, d2, d3, g0, g1, g2, g3, e1, e2, e3, t2, t3;
+      float4 ra = *(float4 *)&sm[threadIdx.x * 4], rb = ra, rc = ra, dq = ra;
+      v2f n0 = q[4], n1 = q[3], n2 = q[2], n3 = q[1];
+      for (int rr = 0; rr < 1; rr++) {
+        if (MODE == 17) {
+          asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(ra) : "v"(la));
+          asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(rb) : "v"(la));
+          asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(rc) : "v"(la));
+          asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(dq) : "v"(la));
+          asm volatile("ds_read2_b32 %0, %1 offset0:4 offset1:5" : "=v"(n0) : "v"(la));
+          asm volatile("ds_read2_b32 %0, %1 offset0:6 offset1:7" : "=v"(n1) : "v"(la));
+          asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:9" : "=v"(n2) : "v"(la));
+          asm volatile("ds_read2_b32 %0, %1 offset0:10 offset1:11" : "=v"(n3) : "v"(la));
+          asm volatile("ds_write_b64 %0, %1 offset:8192" ::"v"(la), "v"(n0));
+          asm volatile("s_waitcnt lgkmcnt(8)");
+        }
+        asm volatile(
+            "v_pk_mul_f32 %[aA], %[p0], %[w0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %[aB], %[p2], %[w0] op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %[aA], %[w0], %[p1], %[aA] op_sel:[1,0,0]\n\t"
+            "v_pk_fma_f32 %[aB], %[w0], %[p3], %[aB] op_sel:[1,0,0]\n\t"
+            "v_pk_fma_f32 %[aA], %[w1], %[p4], %[aA] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[aB], %[w1], %[p0], %[aB] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[aA], %[w1], %[p5], %[aA] op_sel:[1,0,0]\n\t"
+            "v_pk_fma_f32 %[aB], %[w1], %[p1], %[aB] op_sel:[1,0,0]\n\t"
+            "v_pk_fma_f32 %[aA], %[w2], %[p6], %[aA] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[aB], %[w2], %[p4], %[aB] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[aA], %[w2], %[p7], %[aA] op_sel:[1,0,0]\n\t"
+            "v_pk_fma_f32 %[aB], %[w2], %[p5], %[aB] op_sel:[1,0,0]"
+            : [aA] "=&v"(aA), [aB] "=&v"(aB)
+            : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [p0] "v"(r[0]), [p1] "v"(r[1]), [p2] "v"(r[2]), [p3] "v"(r[3]),
+              [p4] "v"(r[4]), [p5] "v"(r[5]), [p6] "v"(r[6]), [p7] "v"(r[7]));
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[ta], %[a0], %[a0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %[tb], %[b0], %[b0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %[ta], %[a1], %[a1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %[tb], %[b1], %[b1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[u], %[ta], %[ta] row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %[u], %[tb], %[tb] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[u], %[u], %[u] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[u], %[u], %[u] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_subrev_f32_dpp %[d0], %[u], %[x0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_subrev_f32_dpp %[d1], %[u], %[x1] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mul_f32 %[g0], %[c0], %[d0]\n\t"
+            "v_subrev_f32_dpp %[d2], %[u], %[x2] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fma_f32 %[e1], -%[g0], %[r11], %[d1]\n\t"
+            "v_subrev_f32_dpp %[d3], %[u], %[x3] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fma_f32 %[t2], -%[g0], %[r22], %[d2]\n\t"
+            "v_mul_f32 %[g1], %[c1], %[e1]\n\t"
+            "v_fma_f32 %[t3], -%[g0], %[r33], %[d3]\n\t"
+            "v_fma_f32 %[e2], -%[g1], %[r12], %[t2]\n\t"
+            "v_fma_f32 %[t3], -%[g1], %[r23], %[t3]\n\t"
+            "v_mul_f32 %[g2], %[c2], %[e2]\n\t"
+            "v_fma_f32 %[e3], -%[g2], %[r13], %[t3]\n\t"
+            "v_mul_f32 %[g3], %[c3], %[e3]"
+            : [ta] "=&v"(ta), [tb] "=&v"(tb), [u] "=&v"(u), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3),
+              [g0] "=&v"(g0), [g1] "=&v"(g1), [g2] "=&v"(g2), [g3] "=&v"(g3), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3),
+              [t2] "=&v"(t2), [t3] "=&v"(t3)
+            : [a0] "v"(aA[0]), [a1] "v"(aA[1]), [b0] "v"(aB[0]), [b1] "v"(aB[1]), [x0] "v"(dq.x), [x1] "v"(dq.y), [x2] "v"(dq.z),
+              [x3] "v"(dq.w), [c0] "v"(ra.x), [c1] "v"(ra.y), [c2] "v"(ra.z), [c3] "v"(ra.w), [r11] "v"(rb.x), [r12] "v"(rb.y),
+              [r13] "v"(rb.z), [r22] "v"(rb.w), [r23] "v"(rc.x), [r33] "v"(rc.y));
+        {
+          v2f G0, G1, G2, G3; G0[0] = g0; G1[0] = g1; G2[0] = g2; G3[0] = g3;
+#define U " op_sel:[0,1,0] op_sel_hi:[0,0,1]\n\t"
+          asm volatile(
+              "v_pk_fma_f32 %[w0], %[G0], %[p1], %[w0]" U "v_pk_fma_f32 %[w1], %[G0], %[p5], %[w1]" U "v_pk_fma_f32 %[w2], %[G0], %[p7], %[w2]" U
+              "v_pk_fma_f32 %[w0], %[G1], %[p0], %[w0]" U "v_pk_fma_f32 %[w1], %[G1], %[p4], %[w1]" U "v_pk_fma_f32 %[w2], %[G1], %[p6], %[w2]" U
+              "v_pk_fma_f32 %[w0], %[G2], %[p3], %[w0]" U "v_pk_fma_f32 %[w1], %[G2], %[p1], %[w1]" U "v_pk_fma_f32 %[w2], %[G2], %[p5], %[w2]" U
+              "v_pk_fma_f32 %[w0], %[G3], %[p2], %[w0]" U "v_pk_fma_f32 %[w1], %[G3], %[p0], %[w1]" U "v_pk_fma_f32 %[w2], %[G3], %[p4], %[w2]"
+              : [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2)
+              : [G0] "v"(G0), [G1] "v"(G1), [G2] "v"(G2), [G3] "v"(G3), [p0] "v"(r[0]), [p1] "v"(r[1]), [p2] "v"(r[2]), [p3] "v"(r[3]),
+                [p4] "v"(r[4]), [p5] "v"(r[5]), [p6] "v"(r[6]), [p7] "v"(r[7]));
+#undef U
+        }
+      }
+      p[1] = w0; p[2] = w1; p[3] = w2; v[14] += n0[0] + n1[1] + n2[0] + n3[1] + e1 + e2 + e3 + d0;
     }
   }
   const long long t1 = __builtin_readcyclecounter();
@@ -237,5 +324,7 @@ int main() {
   run<13>("NlmsL blocks A+B (per 2-step iteration)", 2);
   run<14>("NlmsL blocks + 6 LDS instructions", 2);
   run<15>("NlmsL blocks + LDS + 2 s_nop", 2);
+  run<16>("NlmsQ four-step block as compiled (per block)", 1);
+  run<17>("NlmsQ block + 9 LDS instructions", 1);
   return 0;
 }

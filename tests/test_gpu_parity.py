@@ -43,7 +43,7 @@ def _experimental():
 
 
 EXPERIMENTAL = _experimental()
-TAILS = ["16r"] + (["16", "8r", "16m", "8m", "16l"] if EXPERIMENTAL else [])
+TAILS = ["16r"] + (["16", "8r", "16m", "8m", "16l", "16q"] if EXPERIMENTAL else [])
 
 
 @pytest.fixture(scope="module")
@@ -64,6 +64,8 @@ def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None, fir=None):
         ch.set_tail_variant(8, 2)
     elif tail == "16l":  # weights one block stale, hand-interleaved issue order (EXPERIMENTAL builds)
         ch.set_tail_variant(16, 4)
+    elif tail == "16q":  # four steps per reduction (EXPERIMENTAL builds)
+        ch.set_tail_variant(16, 5)
     elif tail:          # "16": rdsp_tail.hip; "16m" / "8m": matrix-pipe reduction
         ch.set_tail_variant(int(tail.rstrip("m")), int(tail.endswith("m")))
     apply_setup(ch, setup)
