@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="K3", choices=["K2", "K3", "K4", "K5", "F1"])
+    ap.add_argument("--config", default="K3", choices=["K1", "K2", "K3", "K4", "K5", "F1"])
     ap.add_argument("--channels-per-gpu", type=int, default=0)
     ap.add_argument("--blocks", type=int, default=512, help="128-sample input blocks per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,6 +81,39 @@ def launch_ranks(args):
         sys.exit(r.returncode or 1)
     print(lines[-1])
     sys.exit(0)
+
+
+def lib_sha():
+    """Hash of the sources librdsp_hip.so is built from: profiles/counters.json carries the hash of the
+    library its PMC passes were taken on, and the bench line only quotes those counters for the same
+    sources (otherwise roofline.traffic and busy_frac_pmc are null and `counters_note` says why)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "radiodsp_sdr_rx_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) +
+                   glob.glob(os.path.join(base, "*.c")) + [os.path.join(base, "Makefile")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_counters(config):
+    """(per-kernel counters of `config`, note) from profiles/counters.json, or ({}, reason)"""
+    cpath = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(cpath):
+        return {}, "no profiles/counters.json"
+    try:
+        allc = json.load(open(cpath))
+    except Exception as e:
+        return {}, f"profiles/counters.json unreadable: {e}"
+    ent = allc.get(config, {})
+    have, want = ent.get("lib_sha"), lib_sha()
+    if have != want:
+        return {}, (f"profiles/counters.json[{config}] was taken on library sources {have}, this run is {want}: "
+                    "PMC constants not quoted (re-run tests/profile_round.sh + tests/summarize_profiles.py)")
+    return {k: v for k, v in ent.items() if isinstance(v, dict)}, None
 
 
 def algorithmic_bytes_per_sample(decim):
@@ -146,13 +179,11 @@ def f1_main(args):
     samples = nch * nblk * 128
     value = samples * args.steps / elapsed / 1e6
     achieved = 4.0 * samples / (kms * 1e-3) / 1e9
-    traffic, valu = None, None   # PMC passes of tests/profile_round.sh (same workload), per launch
-    try:
-        ent = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))["F1"]["rdsp_spectrum_kernel"]
-        if (nch, nblk) == (4096, 512):
-            traffic, valu = ent.get("hbm_bytes"), {"insts_per_launch": ent.get("valu_insts"), "busy_frac_pmc": ent.get("valu_busy_frac")}
-    except Exception:
-        pass
+    traffic, valu = None, None   # PMC passes of tests/profile_round.sh (same workload, same sources), per launch
+    ctr, ctr_note = load_counters("F1")
+    ent = ctr.get("rdsp_spectrum_kernel")
+    if ent and (nch, nblk) == (4096, 512):
+        traffic, valu = ent.get("hbm_bytes"), {"insts_per_launch": ent.get("valu_insts"), "busy_frac_pmc": ent.get("valu_busy_frac")}
     res = {"metric": "IQ Msamples/s through the IQ panadapter spectrum analyser (SURVEY 8f row F1)", "value": value,
            "unit": "IQ Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -161,7 +192,7 @@ def f1_main(args):
                                   "radix-4 FFT per block pair, Hann window, 30-frame power average, integer sqrt"},
            "roofline": {"bound": "hbm", "kernel": "rdsp_spectrum_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "limiter": "valu",
-                        "valu": valu,
+                        "valu": valu, "counters_note": ctr_note,
                         "note": "algorithmic bytes = 4 B per input sample (the spectra written are < 0.1 %); "
                                 "integer VALU issue binds (about 210 instructions per 256-point frame and wave)"}}
     if not args.no_cpu_baseline:
@@ -172,6 +203,92 @@ def f1_main(args):
         except Exception as e:
             res["cpu_baseline"] = {"value": None, "unit": "IQ Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     print(json.dumps(res))
+
+
+def k1_main(args):
+    """BASELINE.json configs[0] / BASELINE.md K1: 1 channel, 96 kHz IQ, 128-sample blocks, USB, NR / notch
+    off -- the CPU reference path (plumbing, no GPU).  The sketch's graph (INO:71-89) on the host block
+    graph (rdsp_graph.c): IQinput -> engine node -> record queues -> loop() -> play queues, with the
+    oracle's chain (the CPU restatement of the reference) as the engine node's update(); one tick per
+    128-sample block like the audio interrupt.  Reported like a cpu_baseline (n_gpus 0): it is the
+    reference-shaped path timed, never the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    import radiodsp_sdr_rx_amd as R
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.graph import Graph
+
+    cfg = dict(R.K_CONFIGS["K1"]["cfg"])
+    lib = oracle_lib.load(oracle_lib.build(native=True, out_dir="/tmp"))
+    nblk = max(64, (min(args.blocks, 512) // 4) * 4)
+    iq = synth_iq(1, nblk * 128)[0]                      # [n, 2] int16
+    chain = oracle_lib.OracleChain(lib=lib, **cfg)
+    g = Graph(n_channels=1)
+    g.AudioMemory(40)                                    # INO:151
+    src = g.input_node()
+    held, produced = [], []
+
+    def engine_update(n):                                # preProcessor + SDR of the sketch as one node
+        bi, bq = n.receiveReadOnly(0), n.receiveReadOnly(1)
+        if bi is None or bq is None:                     # FFTIQ.cpp:72: silent early return
+            n.release(bi); n.release(bq)
+            return
+        held.append(np.stack([bi.data()[0], bq.data()[0]], axis=1))
+        n.release(bi); n.release(bq)
+        if len(held) == 4:                               # 4 input blocks = one 128-sample audio block at fs/4
+            o16, _ = chain.process(np.concatenate(held, axis=0))
+            held.clear()
+            if len(o16) == 128:
+                bl, br = n.allocate(), n.allocate()
+                if bl is not None and br is not None:
+                    bl.data()[0, :] = o16[:, 0]; br.data()[0, :] = o16[:, 1]
+                    n.transmit(bl, 0); n.transmit(br, 1)
+                n.release(bl); n.release(br)
+
+    eng = g.node(2, engine_update)
+    ql, qr = g.record_queue(), g.record_queue()
+    g.AudioConnection(src, 0, eng, 0); g.AudioConnection(src, 1, eng, 1)     # INO:81-82
+    g.AudioConnection(eng, 0, ql, 0); g.AudioConnection(eng, 1, qr, 0)       # INO:85-86
+    ql.begin(); qr.begin()
+
+    def run_once():
+        chain_blocks = 0
+        t = time.perf_counter()
+        for b in range(nblk):
+            blk = iq[b * 128:(b + 1) * 128]
+            src.push(np.ascontiguousarray(blk[None, :, 0]), np.ascontiguousarray(blk[None, :, 1]))
+            g.update_all()
+            while ql.available() > 0 and qr.available() > 0:               # loop(): CONV:231-244
+                produced.append(ql.readBuffer()[0].copy()); ql.freeBuffer()
+                qr.readBuffer(); qr.freeBuffer()
+                chain_blocks += 1
+        return time.perf_counter() - t, chain_blocks
+
+    run_once()                                           # warm-up
+    best, nout = None, 0
+    for _ in range(max(1, min(args.steps, 5))):
+        dt, nout = run_once()
+        best = dt if best is None else min(best, dt)
+    # the oracle alone, same blocks, no graph (what the plumbing costs on top)
+    c2 = oracle_lib.OracleChain(lib=lib, **cfg)
+    t = time.perf_counter()
+    for b in range(0, nblk, 4):
+        c2.process(iq[b * 128:(b + 4) * 128])
+    alone = time.perf_counter() - t
+    print(json.dumps({
+        "metric": "IQ Msamples/s through full SSB+NR chain; achieved HBM GB/s vs peak",
+        "value": nblk * 128 / best / 1e6, "unit": "IQ Msamples/s", "n_gpus": 0, "steps": nblk, "warmup": nblk,
+        "ms_per_step": best / nblk * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"K1: 1 channel x {nblk} blocks of 128 int16 IQ samples @96 kHz, one graph tick per block; "
+                               "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter, NR / notch off",
+                   "path": "CPU reference path: oracle chain as the engine node of the host block graph (no GPU)"},
+        "roofline": None,
+        "cpu_baseline": {"value": nblk * 128 / alone / 1e6, "unit": "IQ Msamples/s", "cores": 1, "kind": "port",
+                         "sample": f"the same {nblk} blocks through the oracle chain alone (no graph), 4 blocks per call, "
+                                   "gcc -O3 -march=native, one thread"},
+        "audio_blocks_out": nout, "realtime_factor": nblk * 128 / best / 96000.0}))
 
 
 def cpu_baseline_worker(args):
@@ -237,11 +354,15 @@ def dry_run(args, rank, world, dist):
         elapsed = float(tt.item())
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "dry run of the launcher (no device work)", "value": None, "unit": "IQ Msamples/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": elapsed / args.steps * 1e3, "data": "dry-run",
-                          "config": {"workload": f"{args.config}: {kc_channels} channels/GPU (not run)",
-                                     "sharding": f"channels x{world}, no collectives"}}))
+        line = {"metric": "dry run of the launcher (no device work)", "value": None, "unit": "IQ Msamples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "data": "dry-run",
+                "config": {"workload": f"{args.config}: {kc_channels} channels/GPU (not run)",
+                           "sharding": f"channels x{world}, no collectives"}}
+        if world > 1 and args.config == "K3":   # the shape of the second leg of a real N > 1 run
+            line["k5"] = {"config": "K5", "channels_per_gpu": 8192, "channels_total": 8192 * world, "steps": 0,
+                          "ms_per_step": None, "value": None, "unit": "IQ Msamples/s", "note": "dry run"}
+        print(json.dumps(line))
 
 
 def main():
@@ -250,6 +371,8 @@ def main():
         return f1_cpu_baseline(args) if args.config == "F1" else cpu_baseline_worker(args)
     if args.config == "F1":
         return f1_main(args)
+    if args.config == "K1":
+        return k1_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)   # before any torch / HIP call in this process
 
@@ -374,6 +497,39 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # N > 1 with the default workload: a second, separately timed leg at BASELINE.json configs[4]'s shape
+    # (K5: 8192 channels per GPU, full chain), so that the driver's `--gpus 8` form also yields the
+    # 65 536-channel figure; the headline `value` stays the K3 per-GPU workload for every N
+    k5_leg = None
+    if world > 1 and args.config == "K3" and not args.channels_per_gpu and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
+        del iq, out, chain
+        torch.cuda.empty_cache()
+        k5c = R.K_CONFIGS["K5"]
+        n5 = k5c["channels"]
+        iq5 = torch.from_numpy(synth_iq(n5, n_samples, ch0=rank * n5, n_threads=threads)).to(dev)
+        out5 = torch.empty((n5, n_samples // decim, 2), dtype=torch.int16, device=dev)
+        ch5 = Chain(n5, max_blocks_per_call=nblk, device=local_rank, **dict(k5c["cfg"]))
+        ch5.set_pipelined(not args.no_pipeline)
+        steps5 = max(10, min(args.steps, 60))
+        for _ in range(min(args.warmup, 10)):
+            ch5.process(iq5, out=out5)
+        ch5.flush()
+        barrier()
+        t5 = time.perf_counter()
+        for _ in range(steps5):
+            ch5.process(iq5, out=out5)
+        ch5.flush()
+        torch.cuda.synchronize()
+        e5 = time.perf_counter() - t5
+        barrier()
+        tt = torch.tensor([e5], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e5 = float(tt.item())
+        k5_leg = {"config": "K5", "channels_per_gpu": n5, "channels_total": n5 * world, "steps": steps5,
+                  "ms_per_step": e5 / steps5 * 1e3, "value": float(world) * n5 * n_samples * steps5 / e5 / 1e6,
+                  "unit": "IQ Msamples/s", "note": "BASELINE.json configs[4]: full chain, 8192 channels per GPU, "
+                                                   "timed after the headline leg with the same barrier / max-over-ranks protocol"}
+
     if rank == 0:
         total_samples = float(world) * nch * n_samples * args.steps
         value = total_samples / elapsed / 1e6  # IQ Msamples/s, whole job
@@ -397,13 +553,9 @@ def main():
         own = B_own * nch * n_samples / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # counters of a committed PMC pass of this configuration (tests/profile_round.sh ->
         # profiles/counters.json): HBM bytes and VALU busy fraction per launch of each kernel
-        ctr = {}
-        cpath = os.path.join(ROOT, "profiles", "counters.json")
-        if os.path.exists(cpath):
-            try:
-                ctr = json.load(open(cpath)).get(args.config, {})
-            except Exception:
-                ctr = {}
+        ctr, ctr_note = load_counters(args.config)
+        if (nch, nblk) != (kc["channels"], 512):
+            ctr, ctr_note = {}, "PMC constants are for the default shape of the configuration only"
         traffic = ctr.get(dom, {}).get("hbm_bytes")
         chain_traffic = sum(v.get("hbm_bytes", 0.0) for k, v in ctr.items() if k in (fname, "rdsp_tail_kernel")) or None
         flops = FLOP_PER_SAMPLE.get(args.config, 0) * float(nch) * n_samples   # per launch of the chain
@@ -449,6 +601,7 @@ def main():
             # fraction of the dominant kernel from the committed PMC pass.
             "roofline": {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "counters_note": ctr_note,
                          "kernel_own": {"algorithmic_bytes_per_sample": B_own, "achieved": own, "frac": own / HBM_PEAK_GBS},
                          "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved_tf / FP32_PEAK_TFLOPS,
@@ -457,6 +610,8 @@ def main():
                                                     if k in (fname, "rdsp_tail_kernel")} or None}},
             "input_gen_s": gen_s,
         }
+        if k5_leg is not None:
+            res["k5"] = k5_leg
         if world == 1 and not args.no_host_io:
             # extra, un-timed for `value`: the same chain fed from and drained to host memory through
             # rdsp_stream_run_memory (pinned double buffers, upload / kernels / download overlapped)

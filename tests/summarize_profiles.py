@@ -82,6 +82,9 @@ def main():
         if not (fetch or write or sq):
             continue
         counters[cfg] = {"round": rnd}
+        shaf = os.path.join(OUT, f"prof_{cfg}.sha")   # hash of the library sources the passes ran on (bench.lib_sha)
+        if os.path.exists(shaf):
+            counters[cfg]["lib_sha"] = open(shaf).read().strip()
         lines = [f"{cfg} per-launch PMC (rocprofv3, separate passes; FETCH_SIZE doubled per the gfx950 note in "
                  "MI355X_MICROARCH.md, WRITE_SIZE as read; units of both: KB):"]
         for k in sorted(set(fetch) | set(write) | set(sq)):

@@ -187,7 +187,43 @@ def test_bench_gpus_2_launches_two_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["data"] == "dry-run"
     assert d["ms_per_step"] >= 2.0                     # the MAX over ranks: rank 1 sleeps 2 ms per step
+    # N > 1 with the default workload carries the second leg at BASELINE.json configs[4]'s shape
+    assert d["k5"]["channels_per_gpu"] == 8192 and d["k5"]["channels_total"] == 16384 and d["k5"]["unit"] == d["unit"]
     # a worker whose world size disagrees with --gpus refuses to run
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                          text=True, env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_bench_quotes_pmc_constants_only_for_the_sources_they_were_taken_on(tmp_path, monkeypatch):
+    """profiles/counters.json carries, per configuration, the hash of the library sources its PMC passes
+    ran on; bench.load_counters returns nothing (and says why) when the tree's sources differ."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    sha = bench.lib_sha()
+    assert len(sha) == 16 and sha == bench.lib_sha()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "lib_sha", lambda: sha)
+    (prof / "counters.json").write_text(json.dumps({"K3": {"round": "r03", "lib_sha": sha, "rdsp_tail_kernel": {"hbm_bytes": 5.0}},
+                                                    "K2": {"round": "r02", "rdsp_front_fd_kernel": {"hbm_bytes": 1.0}}}))
+    ctr, note = bench.load_counters("K3")
+    assert note is None and ctr == {"rdsp_tail_kernel": {"hbm_bytes": 5.0}}
+    ctr, note = bench.load_counters("K2")               # no hash recorded: stale by definition
+    assert ctr == {} and "not quoted" in note
+    ctr, note = bench.load_counters("K4")
+    assert ctr == {} and note
+
+
+def test_bench_k1_line_on_the_host(tmp_path):
+    """`bench.py --config K1`: BASELINE.json configs[0], the CPU reference path through the block graph"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "K1", "--blocks", "64", "--steps", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 0 and d["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and d["roofline"] is None
+    assert d["audio_blocks_out"] == 16 and d["config"]["workload"].startswith("K1")
