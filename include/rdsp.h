@@ -169,7 +169,21 @@ int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db); /* BK_INO:12
 /* swapIQ and the input-side gains take effect with the first sample of the next call (samples
  * already inside the decimator's delay line keep what they came in with) */
 int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap);                   /* INO:118 */
-int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c);         /* INO:117: no I2S bus here, accepted and ignored */
+int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c);         /* INO:117: accepted; there is no I2S bus to watch at run time */
+/* What INO:117 guards against is an I2S fault that leaves one rail of the codec stream a sample behind
+ * the other; a RECORDING made through such a front end carries it (the image rejection of the
+ * quadrature pair is gone).  rdsp_estimate_iq_slip finds it in a recording (host, no GPU),
+ * rdsp_pre_setIQslip corrects it: slip +1 pairs I[n-1] with Q[n] (delays the I rail by one sample),
+ * -1 pairs I[n] with Q[n-1], 0 switches the correction off.  It acts on the raw words in a pass of
+ * its own in front of the front kernel (8 bytes of HBM traffic per input sample while it is on), before
+ * swapIQ and the input gains, on samples as they arrive from the next call on.  The first non-zero
+ * value allocates the corrected-input buffer (n_channels x max_blocks_per_call x 128 words): a set-up
+ * call.  Build-defined (the AudioSDR pre-processor is not in the reference tree). */
+int rdsp_pre_setIQslip(rdsp_chain_t *c, int slip);
+/* iq: n_samples interleaved int16 I,Q pairs of ONE channel (host memory).  *slip: the value to pass to
+ * rdsp_pre_setIQslip; rejection_db (optional, 3 values): image rejection of the strongest line with the
+ * slip undone as 0, +1, -1.  Needs a dominant one-sided line in the first 2^k samples (k <= 14). */
+int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double *rejection_db);
 int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g);              /* INO:133 */
 int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g);             /* INO:134 */
 int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g);          /* INO:135 */
@@ -266,6 +280,17 @@ int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *stream);
 /* which: 0 = DSP-NR instance (NR:31), 1 = ALS instance; float[n_channels][96] in
  * CMSIS coefficient order */
 int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void *stream);
+/* Per-channel health word, host_out[n_channels].  The reference's NLMS keeps its window energy as a
+ * running difference (RDSP_noise_reduction.h:73 -> arm_lms_norm_f32): after a loud-to-quiet transition
+ * the residue can leave energy + 1.19e-7 at or below zero, the step size turns negative or infinite
+ * and the channel's weights run away to +-inf -- the reference's own behaviour, reproduced here.  The
+ * tail kernel records it per channel: bits are sticky until rdsp_Init_LMS_NR (DSP-NR instance) or
+ * rdsp_chain_reset (both), the arithmetic is untouched.  Synchronises `stream` and the tail stream. */
+#define RDSP_STATUS_NR_ENERGY 0x01u     /* DSP-NR: divided by energy + eps <= 0 */
+#define RDSP_STATUS_NR_NONFINITE 0x02u  /* DSP-NR: a weight or the energy is inf / NaN */
+#define RDSP_STATUS_ALS_ENERGY 0x10u    /* ALS notch / peak instance, likewise */
+#define RDSP_STATUS_ALS_NONFINITE 0x20u
+int rdsp_chain_get_status(rdsp_chain_t *c, uint32_t *host_out, void *stream);
 /* natural-order filter mask currently in use, float[2*fft_l] (CONV:77) */
 int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out);
 int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);

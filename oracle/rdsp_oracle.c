@@ -373,6 +373,8 @@ struct orc_chain {
   float am_dc;
   /* F3 (build-defined): pre-processor IQ swap, noise blanker */
   int swap_iq;
+  int iq_slip;            /* +1: the I rail is taken one sample late, -1: the Q rail (I2S channel slip) */
+  int16_t slip_i, slip_q; /* the previous raw sample */
   int nb_on;
   float nb_thr;   /* threshold as a power ratio, 10^(dB/10) */
   float nb_level; /* reference power: smoothed mean |x|^2 of the past windows */
@@ -436,6 +438,11 @@ void orc_reInitializeFilter(orc_chain_t *c, double lo, double hi) {
  * (alpha 0.2) mean post-blanking power of the previous windows, so every decision
  * inside a window uses state from before the window. */
 void orc_set_swap_iq(orc_chain_t *c, int on) { c->swap_iq = on ? 1 : 0; }
+/* preProcessor.startAutoI2SerrorDetection() (INO:117) guards against the I2S fault that leaves one
+ * rail of the codec stream a sample behind the other; a recording made through such a front end
+ * carries it.  Build-defined correction: slip +1 pairs I[n-1] with Q[n] (delays the I rail by one
+ * sample), slip -1 pairs I[n] with Q[n-1]; applied to the raw words, before swapIQ and the gains. */
+void orc_set_iq_slip(orc_chain_t *c, int slip) { c->iq_slip = slip > 0 ? 1 : (slip < 0 ? -1 : 0); }
 void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db) {
   c->nb_on = on ? 1 : 0;
   c->nb_thr = (float)pow(10.0, (double)threshold_db / 10.0);
@@ -805,7 +812,12 @@ int orc_chain_process(orc_chain_t *c, const int16_t *iq, int n_blocks,
   int produced = 0;
   for (int b = 0; b < n_blocks; b++) {
     for (int i = 0; i < ORC_BLOCK; i++) {
-      const int16_t *s = &iq[2 * ((size_t)b * ORC_BLOCK + (size_t)i)];
+      const int16_t *raw = &iq[2 * ((size_t)b * ORC_BLOCK + (size_t)i)];
+      int16_t s[2] = {raw[0], raw[1]};
+      if (c->iq_slip > 0) s[0] = c->slip_i;      /* orc_set_iq_slip */
+      else if (c->iq_slip < 0) s[1] = c->slip_q;
+      c->slip_i = raw[0];
+      c->slip_q = raw[1];
       /* arm_q15_to_float, CONV:241-242 */
       float xr = (float)s[c->swap_iq ? 1 : 0] / 32768.0f; /* preProcessor.swapIQ, INO:118 */
       float xi = (float)s[c->swap_iq ? 0 : 1] / 32768.0f;

@@ -110,6 +110,7 @@ void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327
 /* F3 (build-defined engine features): preProcessor.swapIQ (INO:118), noise blanker
  * (BK_INO:1259-1260, INO:131) */
 void orc_set_swap_iq(orc_chain_t *c, int on);
+void orc_set_iq_slip(orc_chain_t *c, int slip); /* INO:117: +1 delays the I rail by one sample, -1 the Q rail */
 void orc_set_noise_blanker(orc_chain_t *c, int on, float threshold_db);
 float orc_chain_nb_level(const orc_chain_t *c);
 void orc_set_gains(orc_chain_t *c, float input_gain, float iq_balance, float output_gain, int mute);

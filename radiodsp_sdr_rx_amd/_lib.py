@@ -109,6 +109,8 @@ SYMBOLS = [
     ("rdsp_sdr_setNoiseBlankerThresholdDb", _i, [_vp, _f]),
     ("rdsp_pre_swapIQ", _i, [_vp, _i]),
     ("rdsp_pre_startAutoI2SerrorDetection", _i, [_vp]),
+    ("rdsp_pre_setIQslip", _i, [_vp, _i]),
+    ("rdsp_estimate_iq_slip", _i, [C.POINTER(C.c_int16), C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("rdsp_sdr_setInputGain", _i, [_vp, _f]),
     ("rdsp_sdr_setOutputGain", _i, [_vp, _f]),
     ("rdsp_sdr_setIQgainBalance", _i, [_vp, _f]),
@@ -132,6 +134,7 @@ SYMBOLS = [
     ("rdsp_chain_save_state", _i, [_vp, _i, _i, _vp, C.c_size_t, _vp]),
     ("rdsp_chain_load_state", _i, [_vp, _i, _vp, C.c_size_t, _vp]),
     ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
+    ("rdsp_chain_get_status", _i, [_vp, C.POINTER(C.c_uint32), _vp]),
     ("rdsp_chain_get_mask", _i, [_vp, _f32p]),
     ("rdsp_iq_reader_open", _i, [C.c_char_p, _i, C.POINTER(_vp)]),
     ("rdsp_iq_reader_sample_rate", _d, [_vp]),

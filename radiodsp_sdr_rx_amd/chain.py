@@ -113,6 +113,7 @@ class Chain:
     def setNoiseBlankerThresholdDb(self, db): _lib.check(self.lib.rdsp_sdr_setNoiseBlankerThresholdDb(self.h, float(db)))
     def swapIQ(self, on): _lib.check(self.lib.rdsp_pre_swapIQ(self.h, int(bool(on))))
     def startAutoI2SerrorDetection(self): _lib.check(self.lib.rdsp_pre_startAutoI2SerrorDetection(self.h))
+    def setIQslip(self, slip): _lib.check(self.lib.rdsp_pre_setIQslip(self.h, int(slip)))
     def setInputGain(self, g): _lib.check(self.lib.rdsp_sdr_setInputGain(self.h, float(g)))
     def setOutputGain(self, g): _lib.check(self.lib.rdsp_sdr_setOutputGain(self.h, float(g)))
     def setIQgainBalance(self, g): _lib.check(self.lib.rdsp_sdr_setIQgainBalance(self.h, float(g)))
@@ -233,6 +234,15 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_get_lms_coeffs(self.h, which, a.ctypes.data_as(_lib._f32p), _stream_ptr(stream)))
         return a
 
+    STATUS_NR_ENERGY, STATUS_NR_NONFINITE, STATUS_ALS_ENERGY, STATUS_ALS_NONFINITE = 0x01, 0x02, 0x10, 0x20
+
+    def get_status(self, stream=None):
+        """per-channel NLMS health words (include/rdsp.h RDSP_STATUS_*), uint32 [n_channels]"""
+        import ctypes as C
+        a = np.zeros(self.n_channels, np.uint32)
+        _lib.check(self.lib.rdsp_chain_get_status(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), _stream_ptr(stream)))
+        return a
+
     def mask(self):
         a = np.zeros(2 * self.fft_l, np.float32)
         _lib.check(self.lib.rdsp_chain_get_mask(self.h, a.ctypes.data_as(_lib._f32p)))
@@ -280,3 +290,15 @@ def init_filter_mask(coef_I, coef_Q, fft_l):
                                    np.ascontiguousarray(coef_Q).ctypes.data_as(_lib._f64p), fft_l)
     _lib.check(rc)
     return m
+
+
+def estimate_iq_slip(iq):
+    """I2S channel-slip estimate of one recorded channel (int16 [n, 2], host): (slip, rejection_db[3]);
+    pass `slip` to Chain.setIQslip.  include/rdsp.h rdsp_estimate_iq_slip."""
+    import ctypes as C
+    lib = _lib.load()
+    a = np.ascontiguousarray(iq, dtype=np.int16)
+    assert a.ndim == 2 and a.shape[1] == 2
+    slip, rej = C.c_int(0), (C.c_double * 3)()
+    _lib.check(lib.rdsp_estimate_iq_slip(a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[0], C.byref(slip), rej))
+    return slip.value, [rej[0], rej[1], rej[2]]

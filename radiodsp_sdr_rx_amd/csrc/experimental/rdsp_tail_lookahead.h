@@ -30,6 +30,7 @@ struct NlmsL {
   v2f w2[TPL / 2];
   v2f P[16];
   float energy;
+  float emin = __builtin_inff(); /* health word (see NlmsB): not tracked by the experimental forms */
 
   static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) { return v2f{mine[m], mine[m + 1]}; }
   __device__ __forceinline__ void load(const float *wst, const float *est, size_t ch, int sub) {
@@ -270,6 +271,7 @@ struct NlmsQ {
   v2f w2[TPL / 2];
   v2f P[16]; /* Pair(m) = (mine[m], mine[m+1]) at slot m & 15; a block at n uses Pair(n-5 .. n+2) */
   float energy;
+  float emin = __builtin_inff(); /* health word (see NlmsB): not tracked by the experimental forms */
 
   static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) { return v2f{mine[m], mine[m + 1]}; }
   __device__ __forceinline__ void load(const float *wst, const float *est, size_t ch, int sub) {

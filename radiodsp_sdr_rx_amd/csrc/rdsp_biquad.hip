@@ -298,9 +298,11 @@ struct BiquadNode {
   int16_t *d_in = nullptr, *d_out = nullptr;
   hipStream_t stream = nullptr;
   int status = RDSP_OK;
+  int device = 0; /* the object's device: selected in update and destroy (a process may drive several GPUs) */
 };
 void biquad_node_destroy(void *u) {
   BiquadNode *s = static_cast<BiquadNode *>(u);
+  (void)hipSetDevice(s->device); /* the node's buffers and stream live on its object's device */
   if (s->d_in) (void)hipFree(s->d_in);
   if (s->d_out) (void)hipFree(s->d_out);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -310,6 +312,7 @@ void biquad_node_update(rdsp_node_t *n, void *u) {
   BiquadNode *s = static_cast<BiquadNode *>(u);
   rdsp_block_t *in = rdsp_receive_readonly(n, 0);
   if (!in) return; /* no input this tick: nothing is transmitted */
+  (void)hipSetDevice(s->device);
   rdsp_block_t *out = rdsp_allocate(n);
   if (!out) { rdsp_release(in); return; }
   const size_t bytes = (size_t)s->n_channels * RDSP_BLOCK_SAMPLES * sizeof(int16_t);
@@ -337,6 +340,7 @@ extern "C" rdsp_node_t *rdsp_biquad_node_create(rdsp_graph_t *g, rdsp_biquad_t *
   BiquadNode *s = new BiquadNode();
   s->bq = bq;
   s->n_channels = bq->n_channels;
+  s->device = bq->device;
   const size_t bytes = (size_t)s->n_channels * RDSP_BLOCK_SAMPLES * sizeof(int16_t);
   if (hipSetDevice(bq->device) != hipSuccess || hipMalloc((void **)&s->d_in, bytes) != hipSuccess ||
       hipMalloc((void **)&s->d_out, bytes) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess) {

@@ -99,6 +99,7 @@ struct rdsp_chain {
   float *d_scal = nullptr;
   float *d_nr_w = nullptr, *d_nr_prev = nullptr, *d_nr_energy = nullptr;
   float *d_als_w = nullptr, *d_als_prev = nullptr, *d_als_energy = nullptr;
+  uint32_t *d_status = nullptr; /* [2][n_channels] sticky NLMS health words: DSP-NR instance, ALS instance */
   float *d_mid = nullptr;
   size_t mid_stride = 0;
   /* SAM groups: quadrature part of the base band (three buffers, like d_mid), PLL state */
@@ -153,6 +154,11 @@ struct rdsp_chain {
   float *d_iir_coef = nullptr, *d_iir_state = nullptr;
   int iir_sets = 0;
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
+  int iq_slip = 0;            /* rdsp_pre_setIQslip: +1 delays the I rail by one sample, -1 the Q rail */
+  uint32_t *d_slip_buf = nullptr;      /* [n_channels][max_blocks * 128] corrected words of a call */
+  uint32_t *d_slip_carry[2] = {nullptr, nullptr}; /* [n_channels] last raw word of the previous / this call */
+  int slip_phase = 0;
+  bool slip_prev_on = false;  /* the previous call ran with the correction (its history words are corrected ones) */
   /* swap flag and input scales of the previous call (its samples are this call's FIR history) */
   bool hist_valid = false;
   int hist_swap = 0;
@@ -412,6 +418,7 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
   ALLOC_ZERO(c->d_als_w, sizeof(float) * RDSP_LMS_TAPS * nch);
   ALLOC_ZERO(c->d_als_prev, sizeof(float) * RDSP_BLOCK * nch);
   ALLOC_ZERO(c->d_als_energy, sizeof(float) * nch);
+  ALLOC_ZERO(c->d_status, sizeof(uint32_t) * 2 * nch);
   c->mid_stride = (size_t)max_blocks_per_call * RDSP_BLOCK / decim;
   ALLOC_ZERO(c->d_mid, sizeof(float) * c->mid_stride * nch);
 #undef ALLOC_ZERO
@@ -451,7 +458,7 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   (void)hipSetDevice(c->device);
   void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
-                  c->d_als_energy, c->d_mid};
+                  c->d_als_energy, c->d_status, c->d_mid, c->d_slip_buf, c->d_slip_carry[0], c->d_slip_carry[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -506,6 +513,8 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   HIP_TRY(hipMemset(c->d_als_w, 0, sizeof(float) * RDSP_LMS_TAPS * nch));
   HIP_TRY(hipMemset(c->d_als_prev, 0, sizeof(float) * RDSP_BLOCK * nch));
   HIP_TRY(hipMemset(c->d_als_energy, 0, sizeof(float) * nch));
+  HIP_TRY(hipMemset(c->d_status, 0, sizeof(uint32_t) * 2 * nch));
+  c->slip_prev_on = false;
   std::vector<float> sc(4 * nch, 0.0f);
   for (size_t i = 0; i < nch; i++) sc[4 * i + 1] = 1.0f;
   HIP_TRY(hipMemcpy(c->d_scal, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -576,6 +585,7 @@ extern "C" int rdsp_Init_LMS_NR(rdsp_chain_t *c, int strength, void *stream_) {
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail)); /* the tail stage owns these arrays */
   HIP_TRY(hipMemsetAsync(c->d_nr_prev, 0, sizeof(float) * RDSP_BLOCK * nch, stream));
   HIP_TRY(hipMemsetAsync(c->d_nr_energy, 0, sizeof(float) * nch, stream));
+  HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t) * nch, stream)); /* the DSP-NR instance's health words */
   if (c->s_tail) {
     HIP_TRY(hipEventRecord(c->ev_misc, stream));
     HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_misc, 0));
@@ -637,6 +647,22 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   memset(&fp, 0, sizeof(fp));
   fp.iq = reinterpret_cast<const uint32_t *>(d_iq);
   fp.in_stride = in_stride;
+  if (c->iq_slip != 0) {
+    /* the word in front of this call's first sample: the previous pass's carry, or -- when the previous
+     * call ran without the correction -- the last word of the FIR history, which is raw then */
+    const size_t sstride = (size_t)c->max_blocks * RDSP_BLOCK;
+    const uint32_t *cin = c->slip_prev_on ? c->d_slip_carry[c->slip_phase] : c->d_hist + 255;
+    int e = rdsp_launch_iq_slip(fp.iq, in_stride, c->d_slip_buf, sstride, cin, c->slip_prev_on ? 1 : 256,
+                                c->d_slip_carry[c->slip_phase ^ 1], (int)n_in, c->iq_slip, c->n_channels, stream);
+    if (e != 0) {
+      rdsp_set_error("slip kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      return RDSP_ERR_HIP;
+    }
+    fp.iq = c->d_slip_buf;
+    fp.in_stride = sstride;
+    c->slip_phase ^= 1;
+  }
+  c->slip_prev_on = c->iq_slip != 0;
   fp.n_chunks = (int)(n_in / (size_t)(256 * c->decim));
   fp.n0 = (uint32_t)c->n_in;
   fp.scale_i = cf.iq_balance * cf.input_gain * (1.0f / 32768.0f);
@@ -818,6 +844,8 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.agc_decay = decay;
     tp.out_gain = og;
     tp.st_scal = c->d_scal;
+    tp.st_status = c->d_status;
+    tp.st_status_stride = (size_t)c->n_channels;
     tp.prio = piped ? c->tail_prio : 0;
     tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
     tp.out_stride = out_stride;
@@ -878,6 +906,8 @@ extern "C" int rdsp_LMS_NoiseReduction(rdsp_chain_t *c, int n_samples, float *d_
   tp.nr_first = (c->nr_calls == 0);
   tp.nr_w = c->d_nr_w; tp.nr_prev = c->d_nr_prev; tp.nr_energy = c->d_nr_energy;
   tp.st_scal = c->d_scal;
+  tp.st_status = c->d_status;
+  tp.st_status_stride = (size_t)c->n_channels;
   int e = rdsp_launch_tail(&tp, c->tail_lpc, (hipStream_t)stream_);
   if (e != 0) {
     rdsp_set_error("tail kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -946,8 +976,30 @@ extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) {
 }
 /* AudioSDRpreProcessor (INO:117-118) */
 extern "C" int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap) { NEED(c); c->swap_iq = swap ? 1 : 0; return RDSP_OK; }
-/* the I2S slip it guards against is a Teensy bus fault; recorded streams have none */
+/* INO:117 guards against a Teensy I2S bus fault that leaves one rail of the codec stream a sample
+ * behind the other.  There is no bus here, so there is nothing to watch at run time; a RECORDING made
+ * through such a front end carries the fault: rdsp_estimate_iq_slip finds it, rdsp_pre_setIQslip
+ * corrects it. */
 extern "C" int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c) { NEED(c); return RDSP_OK; }
+/* slip +1: pair I[n-1] with Q[n] (delay the I rail by one sample); -1: pair I[n] with Q[n-1]; 0: off.
+ * Applies to samples as they arrive, from the next call on (what is already in the FIR history keeps
+ * the pairing it came in with).  A set-up call: the first non-zero value allocates the corrected-input
+ * buffer ([n_channels][max_blocks_per_call * 128] words). */
+extern "C" int rdsp_pre_setIQslip(rdsp_chain_t *c, int slip) {
+  NEED(c);
+  if (slip < -1 || slip > 1) return RDSP_ERR_INVALID;
+  if (slip != 0 && !c->d_slip_buf) {
+    if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+    const size_t nch = (size_t)c->n_channels;
+    HIP_TRY(hipMalloc((void **)&c->d_slip_buf, sizeof(uint32_t) * nch * (size_t)c->max_blocks * RDSP_BLOCK));
+    for (auto &p : c->d_slip_carry) {
+      HIP_TRY(hipMalloc((void **)&p, sizeof(uint32_t) * nch));
+      HIP_TRY(hipMemset(p, 0, sizeof(uint32_t) * nch));
+    }
+  }
+  c->iq_slip = slip;
+  return RDSP_OK;
+}
 extern "C" int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.input_gain = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.output_gain = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g) { NEED(c); c->cfg.iq_balance = g; return RDSP_OK; }
@@ -1101,6 +1153,10 @@ extern "C" int rdsp_chain_set_groups(rdsp_chain_t *c, int n_groups, const uint16
         return RDSP_ERR_INVALID;
       }
   if (drain_tail_fwd(c) != RDSP_OK) return RDSP_ERR_HIP;
+  /* documented as synchronising: the caller's processing stream is not known here and may be a
+   * non-blocking one (no null-stream sync covers it), and the group tables below are freed and
+   * reallocated -- every kernel that may still read them has finished after this */
+  HIP_TRY(hipDeviceSynchronize());
   int rc = groups_resize(c, n_groups);
   if (rc != RDSP_OK) return rc;
   if (c->d_group_of) { (void)hipFree(c->d_group_of); c->d_group_of = nullptr; }
@@ -1110,11 +1166,13 @@ extern "C" int rdsp_chain_set_groups(rdsp_chain_t *c, int n_groups, const uint16
     HIP_TRY(hipMalloc((void **)&c->d_group_of, sizeof(uint16_t) * (size_t)c->n_channels));
     HIP_TRY(hipMemcpy(c->d_group_of, c->group_of.data(), sizeof(uint16_t) * (size_t)c->n_channels, hipMemcpyHostToDevice));
   }
+  /* with the IIR bank selected, re-selecting it stages every group's mask (side-band selector) and
+   * coefficient set; otherwise the masks alone */
+  if (c->audio_kind == RDSP_AUDIO_KIND_IIR) return rdsp_sdr_setAudioFilterKind(c, RDSP_AUDIO_KIND_IIR, nullptr);
   for (int g = 0; g < n_groups; g++) {
     rc = group_stage(c, g);
     if (rc != RDSP_OK) return rc;
   }
-  if (c->audio_kind == RDSP_AUDIO_KIND_IIR) return rdsp_sdr_setAudioFilterKind(c, RDSP_AUDIO_KIND_IIR, nullptr);
   return RDSP_OK;
 }
 
@@ -1359,7 +1417,7 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
  * Blob: header, then the arrays of DESIGN.md 3 for the n channels, each [n][...]. */
 namespace {
 struct StateHeader {
-  uint32_t magic, version; /* "RDSP", 1 */
+  uint32_t magic, version; /* "RDSP", 2 */
   int32_t n_channels, fft_l, decim;
   int32_t has_sam, has_iir;
   int32_t old_nr_level;
@@ -1368,34 +1426,38 @@ struct StateHeader {
   float nr_mu, als_mu;
   int32_t hist_valid, hist_swap;
   float hist_scale_i, hist_scale_q;
-  int32_t n_groups, pad; /* followed by n_groups x {has_dev_dphi, dev_dphi}: the NCO increment each group's FIR
+  int32_t n_groups;      /* followed by n_groups x {has_dev_dphi, dev_dphi}: the NCO increment each group's FIR
                             history was mixed with (a tuning change right before the checkpoint) */
+  int32_t has_slip;      /* the last call ran with the I2S slip correction: its carry word travels too */
 };
+constexpr uint32_t kStateVersion = 2;
 constexpr uint32_t kStateMagic = 0x50534452u; /* 'R' 'D' 'S' 'P' */
 struct StatePart { void *dev; size_t per_channel; };
-/* the per-channel arrays in blob order; optional ones (SAM, IIR) only when present */
-std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir) {
+/* the per-channel arrays in blob order; optional ones (SAM, IIR, slip carry) only when present */
+std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir, bool slip = false) {
   std::vector<StatePart> v = {
       {c->d_hist, sizeof(uint32_t) * 256},
       {c->d_prev, sizeof(float2) * (size_t)(c->N / 2)},
       {c->d_scal, sizeof(float) * 4},
       {c->d_nr_w, sizeof(float) * RDSP_LMS_TAPS}, {c->d_nr_prev, sizeof(float) * RDSP_BLOCK}, {c->d_nr_energy, sizeof(float)},
       {c->d_als_w, sizeof(float) * RDSP_LMS_TAPS}, {c->d_als_prev, sizeof(float) * RDSP_BLOCK}, {c->d_als_energy, sizeof(float)},
+      {c->d_status, sizeof(uint32_t)}, {c->d_status + c->n_channels, sizeof(uint32_t)}, /* health words: DSP-NR, ALS */
   };
   if (sam) v.push_back({c->d_sam, sizeof(float) * 4});
   if (iir) v.push_back({c->d_iir_state, sizeof(float) * 16});
+  if (slip) v.push_back({c->d_slip_carry[c->slip_phase], sizeof(uint32_t)});
   return v;
 }
-size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir, size_t n_groups) {
+size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir, bool slip, size_t n_groups) {
   size_t b = sizeof(StateHeader) + 2 * sizeof(uint32_t) * n_groups;
-  for (const auto &p : state_parts(c, sam, iir)) b += p.per_channel * (size_t)n;
+  for (const auto &p : state_parts(c, sam, iir, slip)) b += p.per_channel * (size_t)n;
   return b;
 }
 }  // namespace
 
 extern "C" size_t rdsp_chain_state_bytes(const rdsp_chain_t *c, int n_channels) {
   if (!c || n_channels <= 0 || n_channels > c->n_channels) return 0;
-  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr, c->groups.size());
+  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr, c->slip_prev_on, c->groups.size());
 }
 
 /* everything queued so far has finished when the copy is taken (a control-path call) */
@@ -1413,7 +1475,8 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   StateHeader h;
   memset(&h, 0, sizeof(h));
-  h.magic = kStateMagic; h.version = 1;
+  h.magic = kStateMagic; h.version = kStateVersion;
+  h.has_slip = c->slip_prev_on ? 1 : 0;
   h.n_channels = n_channels; h.fft_l = c->N; h.decim = c->decim;
   h.has_sam = c->d_sam != nullptr; h.has_iir = c->d_iir_state != nullptr;
   h.old_nr_level = c->old_nr_level; h.n_in = c->n_in;
@@ -1430,7 +1493,7 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
     memcpy(dst, w, sizeof(w));
     dst += sizeof(w);
   }
-  for (const auto &p : state_parts(c, h.has_sam, h.has_iir)) {
+  for (const auto &p : state_parts(c, h.has_sam, h.has_iir, h.has_slip)) {
     const size_t n = p.per_channel * (size_t)n_channels;
     HIP_TRY(hipMemcpy(dst, (const unsigned char *)p.dev + p.per_channel * (size_t)first_channel, n, hipMemcpyDeviceToHost));
     dst += n;
@@ -1449,37 +1512,65 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
     return RDSP_ERR_INVALID;
   }
   memcpy(&h, host_buf, sizeof(h));
-  if (h.magic != kStateMagic || h.version != 1 || h.fft_l != c->N || h.decim != c->decim || h.n_channels <= 0 || h.n_groups < 1 ||
-      first_channel < 0 || first_channel + h.n_channels > c->n_channels) {
-    rdsp_set_error("rdsp_chain_load_state: blob of %d channels, FFT_L %d, decimation %d does not fit channels %d.. of a chain "
-                   "of %d channels, FFT_L %d, decimation %d", h.n_channels, h.fft_l, h.decim, first_channel, c->n_channels,
-                   c->N, c->decim);
+  if (h.magic != kStateMagic || h.version != kStateVersion || h.fft_l != c->N || h.decim != c->decim || h.n_channels <= 0 ||
+      h.n_groups < 1 || first_channel < 0 || first_channel + h.n_channels > c->n_channels) {
+    rdsp_set_error("rdsp_chain_load_state: blob (version %u) of %d channels, FFT_L %d, decimation %d does not fit channels %d.. "
+                   "of a chain of %d channels, FFT_L %d, decimation %d (blob version %u)", h.version, h.n_channels, h.fft_l,
+                   h.decim, first_channel, c->n_channels, c->N, c->decim, kStateVersion);
     return RDSP_ERR_INVALID;
   }
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  /* A stream continued from a blob is the uninterrupted stream bit for bit, or the call fails: nothing
+   * is restored in part.  Optional state the blob carries must have a place in this chain. */
+  if (h.has_iir && !c->d_iir_state) {
+    rdsp_set_error("rdsp_chain_load_state: the blob carries the IIR audio filter's state; select it first "
+                   "(rdsp_sdr_setAudioFilterKind(chain, RDSP_AUDIO_KIND_IIR))");
+    return RDSP_ERR_INVALID;
+  }
+  if (h.has_slip && !c->d_slip_buf) {
+    rdsp_set_error("rdsp_chain_load_state: the blob was taken with the I2S slip correction on; call rdsp_pre_setIQslip first");
+    return RDSP_ERR_INVALID;
+  }
   if (h.has_sam && ensure_sam(c) != RDSP_OK) return RDSP_ERR_HIP;
-  const bool take_iir = h.has_iir && c->d_iir_state != nullptr; /* the cascade's state exists once the IIR bank was selected */
-  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0, (size_t)h.n_groups)) {
+  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0, h.has_slip != 0, (size_t)h.n_groups)) {
     rdsp_set_error("rdsp_chain_load_state: blob truncated");
     return RDSP_ERR_INVALID;
   }
+  const unsigned char *gsrc = (const unsigned char *)host_buf + sizeof(h);
   const bool fresh = c->n_in == 0 && c->call_idx == 0;
-  if (!fresh && c->n_in != h.n_in) {
-    rdsp_set_error("rdsp_chain_load_state: the chain is at input sample %llu, the blob at %llu", (unsigned long long)c->n_in,
-                   (unsigned long long)h.n_in);
-    return RDSP_ERR_INVALID;
+  if ((size_t)h.n_groups != c->groups.size()) { /* another partition: fine unless a history increment would be lost */
+    for (int g = 0; g < h.n_groups; g++) {
+      uint32_t w[2];
+      memcpy(w, gsrc + 2 * sizeof(uint32_t) * (size_t)g, sizeof(w));
+      if (w[0]) {
+        rdsp_set_error("rdsp_chain_load_state: the blob has %d receiver groups with a tuning change pending in a FIR history, "
+                       "the chain %zu groups: set the same groups first", h.n_groups, c->groups.size());
+        return RDSP_ERR_INVALID;
+      }
+    }
+  }
+  if (!fresh) { /* channels moved between shards of one stream: both sides must be at the same point of it */
+    const bool same = c->n_in == h.n_in && (c->nr_calls == 0) == (h.nr_calls == 0) && (c->als_calls == 0) == (h.als_calls == 0) &&
+                      c->hist_valid == (h.hist_valid != 0) && c->hist_swap == h.hist_swap && c->hist_scale_i == h.hist_scale_i &&
+                      c->hist_scale_q == h.hist_scale_q && c->old_nr_level == h.old_nr_level && c->slip_prev_on == (h.has_slip != 0);
+    if (!same) {
+      rdsp_set_error("rdsp_chain_load_state: the chain (input sample %llu) and the blob (input sample %llu) are not at the same "
+                     "point of the stream / call history", (unsigned long long)c->n_in, (unsigned long long)h.n_in);
+      return RDSP_ERR_INVALID;
+    }
   }
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  const unsigned char *src = (const unsigned char *)host_buf + sizeof(h);
-  const unsigned char *gsrc = src;
-  src += 2 * sizeof(uint32_t) * (size_t)h.n_groups;
-  for (const auto &p : state_parts(c, h.has_sam != 0, h.has_iir != 0)) {
+  const unsigned char *src = gsrc + 2 * sizeof(uint32_t) * (size_t)h.n_groups;
+  for (const auto &p : state_parts(c, h.has_sam != 0, h.has_iir != 0, h.has_slip != 0)) {
     const size_t n = p.per_channel * (size_t)h.n_channels;
-    if (p.dev && (p.dev != (void *)c->d_iir_state || take_iir))
-      HIP_TRY(hipMemcpy((unsigned char *)p.dev + p.per_channel * (size_t)first_channel, src, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((unsigned char *)p.dev + p.per_channel * (size_t)first_channel, src, n, hipMemcpyHostToDevice));
     src += n;
   }
+  /* optional state the chain has and the blob does not starts from zero for these channels, like a fresh chain's */
+  if (!h.has_sam && c->d_sam) HIP_TRY(hipMemset(c->d_sam + 4 * (size_t)first_channel, 0, sizeof(float) * 4 * (size_t)h.n_channels));
+  if (!h.has_iir && c->d_iir_state)
+    HIP_TRY(hipMemset(c->d_iir_state + 16 * (size_t)first_channel, 0, sizeof(float) * 16 * (size_t)h.n_channels));
   if (fresh) {
     c->n_in = h.n_in;
     c->old_nr_level = h.old_nr_level;
@@ -1487,6 +1578,7 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
     c->nr_mu = h.nr_mu; c->als_mu = h.als_mu;
     c->hist_valid = h.hist_valid != 0; c->hist_swap = h.hist_swap;
     c->hist_scale_i = h.hist_scale_i; c->hist_scale_q = h.hist_scale_q;
+    c->slip_prev_on = h.has_slip != 0;
     if ((size_t)h.n_groups == c->groups.size()) /* same partition: the increments the histories came in with */
       for (auto &g : c->groups) {
         uint32_t w[2];
@@ -1507,6 +1599,19 @@ extern "C" int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *st
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   HIP_TRY(hipMemcpy(host_out, c->d_scal, sizeof(float) * 4 * (size_t)c->n_channels, hipMemcpyDeviceToHost));
+  return RDSP_OK;
+}
+/* per-channel health word: RDSP_STATUS_* bits, sticky until rdsp_Init_LMS_NR (DSP-NR bits) / rdsp_chain_reset */
+extern "C" int rdsp_chain_get_status(rdsp_chain_t *c, uint32_t *host_out, void *stream) {
+  NEED(c);
+  if (!host_out) return RDSP_ERR_INVALID;
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const size_t nch = (size_t)c->n_channels;
+  std::vector<uint32_t> w(2 * nch);
+  HIP_TRY(hipMemcpy(w.data(), c->d_status, sizeof(uint32_t) * 2 * nch, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nch; i++) host_out[i] = (w[i] & 3u) | ((w[nch + i] & 3u) << 4);
   return RDSP_OK;
 }
 extern "C" int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void *stream) {

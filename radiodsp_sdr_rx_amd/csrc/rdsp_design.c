@@ -69,7 +69,7 @@ static void mask_time_image(double *re, double *im, const double *coef_I, const 
  * design constant, so it is evaluated in double and narrowed once -- and in n log n, because a
  * retune is a host call on the control path of every receiver group: the direct
  * sum this replaces took 0.3 ms at n = 256 and 5 ... 20 ms at n = 4096. */
-static void mask_fft(double *re, double *im, int n) {
+void rdsp_host_fft(double *re, double *im, int n) {
   for (int i = 1, j = 0; i < n; i++) { /* bit reversal */
     int bit = n >> 1;
     for (; j & bit; bit >>= 1) j ^= bit;
@@ -107,7 +107,7 @@ int rdsp_init_filter_mask(float *mask, const double *coef_I, const double *coef_
   if (!buf) return -6;
   double *re = buf, *im = buf + n;
   mask_time_image(re, im, coef_I, coef_Q, n);
-  mask_fft(re, im, n);
+  rdsp_host_fft(re, im, n);
   for (int k = 0; k < n; k++) {
     mask[2 * k] = (float)re[k];
     mask[2 * k + 1] = (float)im[k];

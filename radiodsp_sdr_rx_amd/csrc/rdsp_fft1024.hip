@@ -274,9 +274,11 @@ struct Fft1024Node {
   uint16_t *d_out = nullptr;
   hipStream_t stream = nullptr;
   int outputflag = 0, status = RDSP_OK;
+  int device = 0; /* the object's device: selected in update and destroy (a process may drive several GPUs) */
 };
 void fft1024_node_destroy(void *u) {
   Fft1024Node *s = static_cast<Fft1024Node *>(u);
+  (void)hipSetDevice(s->device); /* the node's buffers and stream live on its object's device */
   if (s->d_in) (void)hipFree(s->d_in);
   if (s->d_out) (void)hipFree(s->d_out);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -286,6 +288,7 @@ void fft1024_node_update(rdsp_node_t *n, void *u) {
   Fft1024Node *s = static_cast<Fft1024Node *>(u);
   rdsp_block_t *b = rdsp_receive_readonly(n, 0);
   if (!b) return;
+  (void)hipSetDevice(s->device);
   const size_t bytes = (size_t)s->n_channels * RDSP_BLOCK_SAMPLES * sizeof(int16_t);
   int n_out = 0;
   hipError_t e = hipMemcpyAsync(s->d_in, rdsp_block_data(b), bytes, hipMemcpyHostToDevice, s->stream);
@@ -312,6 +315,7 @@ extern "C" rdsp_node_t *rdsp_fft1024_node_create(rdsp_graph_t *g, rdsp_fft1024_t
   Fft1024Node *s = new Fft1024Node();
   s->an = an;
   s->n_channels = an->n_channels;
+  s->device = an->device;
   s->h_out.assign((size_t)s->n_channels * 512, 0);
   if (hipSetDevice(an->device) != hipSuccess ||
       hipMalloc((void **)&s->d_in, (size_t)s->n_channels * RDSP_BLOCK_SAMPLES * sizeof(int16_t)) != hipSuccess ||

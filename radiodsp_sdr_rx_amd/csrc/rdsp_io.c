@@ -14,6 +14,7 @@
  */
 #include "rdsp_host.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -212,4 +213,54 @@ int rdsp_audio_writer_close(rdsp_audio_writer_t *w) {
   if (fclose(w->f) != 0) rc = RDSP_ERR_INVALID;
   free(w);
   return rc;
+}
+
+
+/* ---- I2S channel-slip estimate for a recording (INO:117, rdsp_pre_setIQslip) --------------------
+ * A front end with the fault delivers one rail a sample behind the other.  On a stream with a dominant
+ * one-sided line (a carrier, a tone: what a receiver's IQ stream normally holds) the misalignment shows
+ * as a loss of image rejection: the line at +f leaks to -f by tan(pi f / fs).  The three hypotheses
+ * (no slip, I late, Q late) are undone in turn on the first 2^k samples (Hann window, one transform
+ * each); the one with the best rejection of the strongest line's image wins.  Returns RDSP_OK and the
+ * value to pass to rdsp_pre_setIQslip in *slip; rejection_db[3] (optional) gets the rejection under
+ * slip 0, +1, -1. */
+int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double *rejection_db) {
+  if (!iq || !slip || n_samples < 258) {
+    rdsp_set_error("rdsp_estimate_iq_slip: bad argument (at least 258 samples)");
+    return RDSP_ERR_INVALID;
+  }
+  int n = 256;
+  while ((size_t)(2 * n) + 2 <= n_samples && n < 16384) n *= 2;
+  double *re = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+  if (!re) return RDSP_ERR_INVALID;
+  double *im = re + n;
+  static const int hyp[3] = {0, 1, -1};
+  double best = -1.0;
+  *slip = 0;
+  for (int h = 0; h < 3; h++) {
+    for (int i = 0; i < n; i++) { /* sample i + 1 of the recording, so that its predecessor exists */
+      const double w = 0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * (double)i / (double)n);
+      const int ii = (hyp[h] > 0) ? i : i + 1, qi = (hyp[h] < 0) ? i : i + 1;
+      re[i] = w * (double)iq[2 * ii];
+      im[i] = w * (double)iq[2 * qi + 1];
+    }
+    rdsp_host_fft(re, im, n);
+    int kmax = 3;
+    double pmax = -1.0;
+    for (int k = 3; k < n - 2; k++) { /* strongest line away from DC */
+      const double pw = re[k] * re[k] + im[k] * im[k];
+      if (pw > pmax) { pmax = pw; kmax = k; }
+    }
+    double pimg = 0.0;
+    for (int d = -2; d <= 2; d++) { /* its image, main lobe of the window included */
+      const int k = ((n - kmax) + d + n) % n;
+      const double pw = re[k] * re[k] + im[k] * im[k];
+      if (pw > pimg) pimg = pw;
+    }
+    const double rej = pmax / (pimg + 1e-30);
+    if (rejection_db) rejection_db[h] = 10.0 * log10(rej);
+    if (rej > best) { best = rej; *slip = hyp[h]; }
+  }
+  free(re);
+  return RDSP_OK;
 }

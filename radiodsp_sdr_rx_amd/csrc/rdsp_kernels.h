@@ -122,6 +122,12 @@ struct RdspTailParams {
   uint32_t *out_i16;
   size_t out_stride;
   float2 *out_f32;
+  /* per-channel health words, sticky (OR-ed in at the end of a launch): [0 .. n) for the DSP-NR
+   * instance, [n .. 2n) for the ALS instance, n = n_channels of the chain (st_status_stride);
+   * bit 0: energy + eps <= 0 was seen (the step size of arm_lms_norm_f32 goes negative or infinite),
+   * bit 1: a weight or the energy is not finite.  May be null. */
+  uint32_t *st_status;
+  size_t st_status_stride;
 };
 
 /* biquad cascades (rdsp_biquad.hip): four DF1 stages per channel, one stage per lane of a quad.
@@ -155,6 +161,8 @@ int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_chan
 int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream);
 int rdsp_launch_sam(const RdspSamParams *p, hipStream_t stream);
 int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hipStream_t stream);
+int rdsp_launch_iq_slip(const uint32_t *in, size_t in_stride, uint32_t *out, size_t out_stride, const uint32_t *carry_in,
+                        size_t carry_stride, uint32_t *carry_out, int n_samples, int slip, int n_channels, hipStream_t stream);
 int rdsp_launch_q15_to_float(const int16_t *src, float *dst, size_t n, hipStream_t stream);
 int rdsp_launch_float_to_q15(const float *src, int16_t *dst, size_t n, hipStream_t stream);
 size_t rdsp_front_lds_bytes(int fft_l, int decim);

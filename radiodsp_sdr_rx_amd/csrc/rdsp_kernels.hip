@@ -898,6 +898,35 @@ constexpr size_t front_fd_lds() {
 struct RdspGroupWords { uint32_t w[32]; };
 __global__ void rdsp_group_store_kernel(uint32_t *dst, RdspGroupWords v) { dst[threadIdx.x] = v.w[threadIdx.x]; }
 
+/* ---- pre-processor: I2S channel-slip correction (rdsp_pre_setIQslip) -------------------------
+ * One rail of the stream is a sample behind the other: the corrected word pairs this sample's half
+ * of one rail with the previous sample's half of the other (slip +1: I[n-1] | Q[n], slip -1:
+ * I[n] | Q[n-1]).  A pass of its own in front of the front kernel, over the raw words: 8 bytes of HBM
+ * traffic per input sample while the correction is on, nothing when it is off; the front kernels and
+ * the 256-sample FIR history see corrected words only.  carry_in[ch * carry_stride]: the last raw word
+ * of the previous call -- the chain's FIR history when that call ran without the correction, else the
+ * word the previous pass left in carry_out (two arrays, alternating: every thread's predecessor word
+ * is read before any carry is written). */
+__global__ void __launch_bounds__(256) rdsp_iq_slip_kernel(const uint32_t *in, size_t in_stride, uint32_t *out,
+                                                           size_t out_stride, const uint32_t *carry_in, size_t carry_stride,
+                                                           uint32_t *carry_out, int n_quads, int slip) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const size_t ch = blockIdx.y;
+  if (q >= n_quads) return;
+  const uint32_t *src = in + ch * in_stride;
+  const uint4 w = *reinterpret_cast<const uint4 *>(src + 4 * (size_t)q);
+  const uint32_t p = (q == 0) ? carry_in[ch * carry_stride] : src[4 * (size_t)q - 1];
+  const uint32_t lo = 0x0000FFFFu;
+  uint4 r;
+  if (slip > 0) { /* I of the previous sample, Q of this one */
+    r.x = (p & lo) | (w.x & ~lo); r.y = (w.x & lo) | (w.y & ~lo); r.z = (w.y & lo) | (w.z & ~lo); r.w = (w.z & lo) | (w.w & ~lo);
+  } else {        /* I of this sample, Q of the previous one */
+    r.x = (w.x & lo) | (p & ~lo); r.y = (w.y & lo) | (w.x & ~lo); r.z = (w.z & lo) | (w.y & ~lo); r.w = (w.w & lo) | (w.z & ~lo);
+  }
+  *reinterpret_cast<uint4 *>(out + ch * out_stride + 4 * (size_t)q) = r;
+  if (q == n_quads - 1) carry_out[ch] = w.w;
+}
+
 /* ---- standalone A1 / A10 (bit-exact tests of the int16 <-> float edges) ---- */
 __global__ void rdsp_q15_to_float_kernel(const int16_t *src, float *dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1023,6 +1052,15 @@ extern "C" int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hip
   RdspGroupWords v;
   memcpy(&v, val, sizeof(v));
   hipLaunchKernelGGL(rdsp_group_store_kernel, dim3(1), dim3(32), 0, stream, reinterpret_cast<uint32_t *>(dst), v);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rdsp_launch_iq_slip(const uint32_t *in, size_t in_stride, uint32_t *out, size_t out_stride,
+                                   const uint32_t *carry_in, size_t carry_stride, uint32_t *carry_out, int n_samples,
+                                   int slip, int n_channels, hipStream_t stream) {
+  const int nq = n_samples / 4;
+  hipLaunchKernelGGL(rdsp_iq_slip_kernel, dim3((nq + 255) / 256, n_channels), dim3(256), 0, stream, in, in_stride, out,
+                     out_stride, carry_in, carry_stride, carry_out, nq, slip);
   return (int)hipGetLastError();
 }
 

@@ -82,6 +82,7 @@ struct NlmsB {
   v2f w2[TPL / 2];
   v2f P[8];
   float energy;
+  float emin; /* smallest energy + eps this lane has divided by (health word: <= 0 means a blow-up) */
 
   static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) {
     /* m even: one aligned ds_read_b64; m odd: two dwords (the compiler pairs them as ds_read2_b32) */
@@ -91,6 +92,7 @@ struct NlmsB {
 #pragma unroll
     for (int t = 0; t < TPL; t++) w2[t >> 1][t & 1] = wst[ch * RDSP_LMS_TAPS + (95 - (TPL * sub + t))];
     energy = est[ch];
+    emin = __builtin_inff();
   }
   __device__ __forceinline__ void store(float *wst, float *est, size_t ch, int sub) {
 #pragma unroll
@@ -102,7 +104,7 @@ struct NlmsB {
    * B_n by prefix sums of their increments (x_n^2 - x_{n-96}^2, x_n x_{n-1} - x_{n-96} x_{n-97}),
    * step size mu / (E_n + eps); dst = [step size x 64 | B x 64 | E x 64] */
   static __device__ __forceinline__ void prepare(const float *cur, int s0, int sub, float mu, float e_base,
-                                                 float b_base, float *dst) {
+                                                 float b_base, float *dst, float &emin) {
     const float *x = cur + s0 + 4 * sub; /* the previous block sits right below the current one */
     const float xm = x[-1], qm = x[-97];
     const float4 xv = *reinterpret_cast<const float4 *>(x), qv = *reinterpret_cast<const float4 *>(x - 96);
@@ -126,7 +128,9 @@ struct NlmsB {
     for (int k = 0; k < 4; k++) {
       e[k] = oe + ea[k];
       b[k] = ob + ba[k];
-      g[k] = mu * __builtin_amdgcn_rcpf(e[k] + 0.000000119209289f);
+      const float den = e[k] + 0.000000119209289f;
+      g[k] = mu * __builtin_amdgcn_rcpf(den);
+      emin = fminf(emin, den);
     }
     float4 *d4 = reinterpret_cast<float4 *>(dst);
     d4[sub] = make_float4(g[0], g[1], g[2], g[3]);
@@ -153,7 +157,7 @@ struct NlmsB {
     for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
     float b_base = row_allsum(bb);
     float e_base = energy;
-    prepare(cur, 0, sub, mu, e_base, b_base, scr);
+    prepare(cur, 0, sub, mu, e_base, b_base, scr, emin);
 #pragma unroll
     for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld((m & 1) ? mine : mine_b, m);
 #pragma unroll 1
@@ -165,7 +169,7 @@ struct NlmsB {
       float4 dq = *reinterpret_cast<const float4 *>(dsrc + s0);
       e_base = sc[2 * GS + GS - 1];
       b_base = sc[GS + GS - 1];
-      if (s0 + GS < RDSP_BLOCK) prepare(cur, s0 + GS, sub, mu, e_base, b_base, scr + (((s0 / GS) + 1) & 1) * SCR);
+      if (s0 + GS < RDSP_BLOCK) prepare(cur, s0 + GS, sub, mu, e_base, b_base, scr + (((s0 / GS) + 1) & 1) * SCR, emin);
 #pragma unroll
       for (int q = 0; q < GS / 4; q++) {
         const float gi[4] = {gq.x, gq.y, gq.z, gq.w}, bn[4] = {bq.x, bq.y, bq.z, bq.w};
@@ -225,6 +229,19 @@ struct NlmsB {
 #ifdef RDSP_EXPERIMENTAL
 #include "experimental/rdsp_tail_lookahead.h"
 #endif
+
+/* health word of one NLMS instance at the end of a launch (kernel params, st_status): bit 0 when some
+ * lane of the channel divided by energy + eps <= 0, bit 1 when a weight or the energy is not finite
+ * (0 * x is NaN exactly for those; the row sum carries it to every lane) */
+template <typename NL>
+__device__ __forceinline__ uint32_t nlms_health(const NL &f) {
+  float z = f.energy * 0.f;
+#pragma unroll
+  for (int k = 0; k < NL::TPL / 2; k++) z = fmaf(f.w2[k][0], 0.f, fmaf(f.w2[k][1], 0.f, z));
+  const float bad_e = row_allsum(f.emin <= 0.f ? 1.f : 0.f);
+  const float nf = row_allsum(z);
+  return (bad_e > 0.f ? 1u : 0u) | (nf == 0.f ? 0u : 2u);
+}
 
 #ifdef RDSP_TAIL_PROFILE /* measurement builds only (tests/micro/tail_phases.sh): s_memtime around the phases */
 #define RDSP_TP(i) do { const long long tp_now = __builtin_readcyclecounter(); tp_acc[i] += tp_now - tp_last; tp_last = tp_now; } while (0)
@@ -412,6 +429,21 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
            tp_acc[1] / p.n_blocks, tp_acc[2] / p.n_blocks, tp_acc[3] / p.n_blocks);
 #endif
 
+  if (p.st_status && has_inst) { /* sticky health words (rdsp_chain_get_status) */
+    uint32_t h_nr = 0, h_als = 0;
+    if constexpr (DUAL) {
+      h_nr = nlms_health(nr);
+      h_als = nlms_health(als);
+    } else if (one_is_nr) {
+      h_nr = nlms_health(als);
+    } else {
+      h_als = nlms_health(als);
+    }
+    if (valid && sub == 0) {
+      if (h_nr) p.st_status[ch] |= h_nr;
+      if (h_als) p.st_status[p.st_status_stride + ch] |= h_als;
+    }
+  }
   if (valid) { /* the last block processed is the upper half of the ring */
     if constexpr (DUAL) {
       nr.store(p.nr_w, p.nr_energy, ch, sub);

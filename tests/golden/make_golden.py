@@ -101,8 +101,8 @@ def main():
             o32.append(b)
         extra = {}
         cfg = case["cfg"]
-        if cfg.get("lms_nr", 0) > 0 or cfg.get("als_mode", "off") != "off":
-            # NLMS chains: the float64 evaluation of the same chain (tests/np_model.py) travels with
+        if cfg.get("lms_nr", 0) > 0 or cfg.get("als_mode", "off") != "off" or cfg.get("demod") == "SAM":
+            # recursive stages (NLMS, SAM PLL): the float64 evaluation of the same chain (tests/np_model.py) travels with
             # the fixture; the GPU test anchors its tolerance on it (truth), not on the float32 oracle
             extra["out_f64"] = np.stack([np_model.Model(**cfg).process(iq[c]) for c in range(case["channels"])])
         np.savez_compressed(os.path.join(HERE, name + ".npz"), iq=iq, out_i16=np.stack(o16),

@@ -83,6 +83,7 @@ enum { audioCW = RDSP_AUDIO_CW, audio2100 = RDSP_AUDIO_2100, audio2700 = RDSP_AU
        audioAM = RDSP_AUDIO_AM, audioWSPR = RDSP_AUDIO_WSPR };
 #define preProcessor_startAutoI2SerrorDetection() RDSP_BIND_CHECK(rdsp_pre_startAutoI2SerrorDetection(g_chain))
 #define preProcessor_swapIQ(b)      RDSP_BIND_CHECK(rdsp_pre_swapIQ(g_chain, (b)))
+#define preProcessor_setIQslip(s)   RDSP_BIND_CHECK(rdsp_pre_setIQslip(g_chain, (s)))   /* build-defined: correction for recordings */
 #define SDR_enableAGC()             RDSP_BIND_CHECK(rdsp_sdr_enableAGC(g_chain))
 #define SDR_setAGCmode(m)           RDSP_BIND_CHECK(rdsp_sdr_setAGCmode(g_chain, (m)))
 #define SDR_disableALSfilter()      RDSP_BIND_CHECK(rdsp_sdr_disableALSfilter(g_chain))

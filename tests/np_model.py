@@ -117,6 +117,14 @@ class Model:
         self.nfloor = 0.0
         self.g = 1.0
         self.dc = 0.0
+        # SAM (engine feature, build-defined: oracle/rdsp_oracle.c orc_sam_constants / sam_block): loop
+        # constants for zeta = 0.65, omegaN = 200 rad/s at the decimated rate, narrowed to float like there
+        zeta, wn = 0.65, 200.0
+        a = 1.0 - np.exp(-2.0 * wn * zeta / self.fs_out)
+        b = -a + 2.0 * (1.0 - np.exp(-wn * zeta / self.fs_out) * np.cos(wn / self.fs_out * np.sqrt(1.0 - zeta * zeta)))
+        self.sam_g1, self.sam_g2 = float(np.float32(a)), float(np.float32(b))
+        self.sam_wmax = float(np.float32(2.0 * np.pi * 2000.0 / self.fs_out))
+        self.sam_phs = self.sam_omega = self.sam_fil = self.sam_dc = 0.0
         self.nr = Nlms64(15)
         self.old_nr = 15
         self.als = Nlms64(c["als_strength"] if c["als_strength"] > 0 else 15)
@@ -177,6 +185,21 @@ class Model:
             L = a - (self.dc + (dn - self.dc) * ramp)
             R = L.copy()
             self.dc = dn
+        elif c["demod"] == 6:   # SAM: second-order PLL synchronous detector, serial per sample
+            eps = float(np.float32(1e-6))
+            for i in range(BLOCK):
+                sn, cs = np.sin(self.sam_phs), np.cos(self.sam_phs)
+                corr0 = L[i] * cs + R[i] * sn
+                corr1 = R[i] * cs - L[i] * sn
+                mag2 = corr0 * corr0 + corr1 * corr1
+                det = np.arctan2(corr1, corr0) * (mag2 / (mag2 + eps))
+                del_out = self.sam_fil
+                self.sam_omega = min(max(self.sam_omega + self.sam_g2 * det, -self.sam_wmax), self.sam_wmax)
+                self.sam_fil = self.sam_g1 * det + self.sam_omega
+                self.sam_phs = (self.sam_phs + del_out) % (2.0 * np.pi)
+                self.sam_dc += (corr0 - self.sam_dc) * (1.0 / 512.0)
+                L[i] = corr0 - self.sam_dc
+            R = L.copy()
         elif c["demod"] != 0:
             R = L.copy()
         if self.iir_sos is not None and c["demod"] != 0:

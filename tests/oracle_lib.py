@@ -129,6 +129,7 @@ def load(path=None):
     lib.orc_demod_tuning_offset.argtypes = [C.c_int]
     lib.orc_demod_tuning_offset.restype = C.c_uint32
     lib.orc_set_swap_iq.argtypes = [vp, C.c_int]
+    lib.orc_set_iq_slip.argtypes = [vp, C.c_int]
     lib.orc_set_noise_blanker.argtypes = [vp, C.c_int, C.c_float]
     lib.orc_set_gains.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int]
     lib.orc_set_agc_mode.argtypes = [vp, C.c_int]
@@ -206,6 +207,9 @@ class OracleChain:
 
     def set_swap_iq(self, on):
         self.lib.orc_set_swap_iq(self.h, int(bool(on)))
+
+    def set_iq_slip(self, slip):
+        self.lib.orc_set_iq_slip(self.h, int(slip))
 
     def set_noise_blanker(self, on, threshold_db=10.0):
         self.lib.orc_set_noise_blanker(self.h, int(bool(on)), float(threshold_db))

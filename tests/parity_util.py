@@ -1,0 +1,55 @@
+"""Parity criteria shared by the GPU tests (test infrastructure).
+
+normwise: the north-star's relative float tolerance, per channel against the float32 oracle.
+assert_truth_anchored: chains whose last stages are recursive (NLMS, IIR bank, SAM PLL), where two
+float32 implementations cannot agree to 1e-5 with each other but each can be measured against the
+float64 evaluation of the same chain (tests/np_model.py)."""
+import os
+
+import numpy as np
+
+from cases import TOL
+
+PER_CHANNEL_RATIO = 4.5   # observed maximum 4.0 + one eighth (assert_truth_anchored)
+
+
+def normwise(y, ref):
+    """max over channels of max|y - ref| / max|ref|"""
+    return max(np.abs(y[c] - ref[c]).max() / max(np.abs(ref[c]).max(), 1e-30) for c in range(len(ref)))
+
+
+def model_run(iq, cfg):
+    """float64 evaluation of the same chain (tests/np_model.py), one channel at a time"""
+    import np_model
+    return np.stack([np_model.Model(**cfg).process(iq[c]) for c in range(iq.shape[0])])
+
+
+def q15_of(x64):
+    """arm_float_to_q15 of the float64 result (truncate, saturate; CONV:346-347)"""
+    return np.clip(np.trunc(x64 * 32768.0), -32768, 32767).astype(np.int32)
+
+
+def assert_truth_anchored(g32, r32, f64, what, g16=None, r16=None):
+    """NLMS chains: the GPU is no further from the float64 result than max(TOL, 1.5 x the float32
+    oracle's own distance) -- for the worst channel and for the median channel of the set; int16
+    likewise, in LSB.  The yardstick is taken over the channel set because the oracle's distance
+    is itself a draw of float32 rounding with a 7x spread between channels (als_notch, measured:
+    oracle 1.5e-5 .. 1.1e-4, GPU 2.5e-5 .. 2.9e-5 on the same five channels), so a channel where
+    the oracle happens to land close says nothing about the arithmetic; no single channel may
+    exceed 4.5 x its own oracle distance either: the largest such ratio observed over some 2000
+    channel-runs of the session soak and of the cases here is 4.0 (twice, on channels where the oracle
+    sat at 0.3 of its typical distance), plus a margin of one eighth."""
+    den = np.array([max(np.abs(f64[c]).max(), 1e-30) for c in range(len(f64))])
+    eg = np.array([np.abs(g32[c] - f64[c]).max() for c in range(len(f64))]) / den
+    eo = np.array([np.abs(r32[c] - f64[c]).max() for c in range(len(f64))]) / den
+    if os.environ.get("RDSP_SHOW_ERR"):
+        for c in range(len(f64)):
+            print(f"  {what} ch {c}: gpu {eg[c]:.3e} oracle {eo[c]:.3e}")
+    assert eg.max() <= max(TOL, 1.5 * eo.max()), f"{what}: worst channel err(gpu,f64) {eg.max():.3e} vs oracle {eo.max():.3e}"
+    assert np.median(eg) <= max(TOL, 1.5 * np.median(eo)), f"{what}: median err(gpu,f64) {np.median(eg):.3e} vs oracle {np.median(eo):.3e}"
+    assert (eg <= np.maximum(TOL, PER_CHANNEL_RATIO * eo)).all(), f"{what}: gpu {eg} oracle {eo}"
+    if g16 is not None:
+        lg = np.array([np.abs(g16[c].astype(np.int32) - q15_of(f64[c])).max() for c in range(len(f64))])
+        lo = np.array([np.abs(r16[c].astype(np.int32) - q15_of(f64[c])).max() for c in range(len(f64))])
+        assert lg.max() <= max(1, int(np.ceil(1.5 * lo.max()))), f"{what}: {lg} LSB vs oracle {lo} LSB from the float64 result"
+    return float(eg.max() / max(eo.max(), 1e-30))

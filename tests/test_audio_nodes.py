@@ -379,7 +379,7 @@ def test_engine_audio_filter_as_iir_bank_matches_oracle(rdsp, oracle, name):
     from radiodsp_sdr_rx_amd.filters import design_audio_iir
     assert np.array_equal(coef, design_audio_iir(f1, f2, 24000.0))
     import np_model
-    from test_gpu_parity import assert_truth_anchored
+    from parity_util import assert_truth_anchored
     ocfg = dict(cfg, flo_hz=band[0], fhi_hz=band[1])
     ref, f64 = [], []
     for c in range(nch):

@@ -28,6 +28,7 @@ import numpy as np
 import pytest
 
 from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4, TOL, apply_setup
+from parity_util import assert_truth_anchored, model_run, normwise, q15_of  # noqa: F401 (re-exported)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -91,46 +92,6 @@ def oracle_run(oracle, iq, cfg):
     return np.stack(o16), np.stack(o32)
 
 
-def normwise(y, ref):
-    """max over channels of max|y - ref| / max|ref|"""
-    return max(np.abs(y[c] - ref[c]).max() / max(np.abs(ref[c]).max(), 1e-30) for c in range(len(ref)))
-
-
-def model_run(iq, cfg):
-    """float64 evaluation of the same chain (tests/np_model.py), one channel at a time"""
-    import np_model
-    return np.stack([np_model.Model(**cfg).process(iq[c]) for c in range(iq.shape[0])])
-
-
-def q15_of(x64):
-    """arm_float_to_q15 of the float64 result (truncate, saturate; CONV:346-347)"""
-    return np.clip(np.trunc(x64 * 32768.0), -32768, 32767).astype(np.int32)
-
-
-def assert_truth_anchored(g32, r32, f64, what, g16=None, r16=None):
-    """NLMS chains: the GPU is no further from the float64 result than max(TOL, 1.5 x the float32
-    oracle's own distance) -- for the worst channel and for the median channel of the set; int16
-    likewise, in LSB.  The yardstick is taken over the channel set because the oracle's distance
-    is itself a draw of float32 rounding with a 7x spread between channels (als_notch, measured:
-    oracle 1.5e-5 .. 1.1e-4, GPU 2.5e-5 .. 2.9e-5 on the same five channels), so a channel where
-    the oracle happens to land close says nothing about the arithmetic; no single channel may
-    exceed 5 x its own oracle distance either (over some 2000 channel-runs of the session soak and of
-    the cases here the largest such ratio was 4.0, twice; with 3 x those two runs failed on a channel
-    where the oracle sat at 0.3 of its typical distance)."""
-    den = np.array([max(np.abs(f64[c]).max(), 1e-30) for c in range(len(f64))])
-    eg = np.array([np.abs(g32[c] - f64[c]).max() for c in range(len(f64))]) / den
-    eo = np.array([np.abs(r32[c] - f64[c]).max() for c in range(len(f64))]) / den
-    if os.environ.get("RDSP_SHOW_ERR"):
-        for c in range(len(f64)):
-            print(f"  {what} ch {c}: gpu {eg[c]:.3e} oracle {eo[c]:.3e}")
-    assert eg.max() <= max(TOL, 1.5 * eo.max()), f"{what}: worst channel err(gpu,f64) {eg.max():.3e} vs oracle {eo.max():.3e}"
-    assert np.median(eg) <= max(TOL, 1.5 * np.median(eo)), f"{what}: median err(gpu,f64) {np.median(eg):.3e} vs oracle {np.median(eo):.3e}"
-    assert (eg <= np.maximum(TOL, 5.0 * eo)).all(), f"{what}: gpu {eg} oracle {eo}"
-    if g16 is not None:
-        lg = np.array([np.abs(g16[c].astype(np.int32) - q15_of(f64[c])).max() for c in range(len(f64))])
-        lo = np.array([np.abs(r16[c].astype(np.int32) - q15_of(f64[c])).max() for c in range(len(f64))])
-        assert lg.max() <= max(1, int(np.ceil(1.5 * lo.max()))), f"{what}: {lg} LSB vs oracle {lo} LSB from the float64 result"
-    return float(eg.max() / max(eo.max(), 1e-30))
 
 
 def check_i16(o16, r16):
@@ -282,14 +243,14 @@ def test_golden_vectors(rdsp, torch_cuda, name):
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
     o16, o32, _ = gpu_run(torch_cuda, g["iq"], case["cfg"], setup=case.get("setup"))
-    nlms = case["cfg"].get("lms_nr", 0) > 0 or case["cfg"].get("als_mode", "off") != "off"
-    if nlms:   # truth-anchored (module docstring): the fixture carries the float64 result too
+    recursive = (case["cfg"].get("lms_nr", 0) > 0 or case["cfg"].get("als_mode", "off") != "off"
+                 or case["cfg"].get("demod") == "SAM")
+    if recursive:   # truth-anchored (module docstring): the fixture carries the float64 result too
         assert_truth_anchored(o32, g["out_f32"], g["out_f64"], name, o16, g["out_i16"])
+        if name == "k3_full_512":   # the metric configuration also meets the north-star's 1e-5 against the oracle
+            assert normwise(o32, g["out_f32"]) <= TOL
         return
-    tol = TOL
-    if case["cfg"].get("demod") == "SAM":
-        tol = 2e-5               # PLL feedback (tests/test_engine_features.py)
-    assert normwise(o32, g["out_f32"]) <= tol
+    assert normwise(o32, g["out_f32"]) <= TOL
     d = np.abs(o16.astype(np.int32) - g["out_i16"].astype(np.int32))
     assert d.max() <= 1
 
@@ -332,6 +293,56 @@ def test_lms_noise_reduction_isolated(rdsp, oracle, torch_cuda):
         assert np.abs(got[c] - ref).max() / np.abs(ref).max() <= TOL
         w = oc.lms_coeffs(0)
         assert np.abs(wg[c] - w).max() <= 2e-5 * np.abs(w).max()
+
+
+def test_nlms_health_word_flags_the_channels_that_blow_up(rdsp, oracle, torch_cuda):
+    """The reference's NLMS keeps its window energy as a running difference (NR:73 -> arm_lms_norm_f32):
+    after a loud-to-quiet transition the residue can leave energy + 1.19e-7 at or below zero and the
+    channel's weights run away -- in the CPU restatement and on the GPU alike.  The tail
+    kernel records it per channel (rdsp_chain_get_status): the non-finite bit is set for exactly the
+    channels whose weights are not finite, every such channel also carries the energy bit (the cause),
+    quiet channels carry nothing, and Init_LMS_NR clears the words.  The arithmetic is untouched: the
+    same script through the oracle blows up too (not necessarily in the same channels: which residue
+    lands below zero is a draw of float32 rounding)."""
+    import ctypes as C
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain
+    nch, loud, quiet = 640, 768, 1792
+    rng = np.random.default_rng(2024)
+    x = np.concatenate([0.3 * rng.standard_normal((nch, loud)), 1e-4 * rng.standard_normal((nch, quiet))], axis=1).astype(np.float32)
+    x[::2, loud:] = (0.3 * rng.standard_normal((nch // 2, quiet))).astype(np.float32)   # every second channel stays loud: the control group
+    ch = Chain(nch, **K1)
+    ch.Init_LMS_NR(20)
+    assert not ch.get_status().any()
+    buf = torch.from_numpy(x.copy()).cuda()
+    ch.LMS_NoiseReduction(buf[:, :loud].contiguous())
+    assert not ch.get_status().any()             # nothing happens while the input is loud
+    ch.LMS_NoiseReduction(buf[:, loud:].contiguous())
+    torch.cuda.synchronize()
+    st = ch.get_status()
+    w = ch.lms_coeffs(0)
+    dead = ~np.isfinite(w).all(axis=1)
+    assert ((st & ch.STATUS_NR_NONFINITE) != 0).tolist() == dead.tolist()
+    assert ((st[dead] & ch.STATUS_NR_ENERGY) != 0).all()
+    assert not (st & (ch.STATUS_ALS_ENERGY | ch.STATUS_ALS_NONFINITE)).any()
+    assert not st[::2].any() and not dead[::2].any()   # the control group
+    # the same script through the CPU restatement: the phenomenon is the reference's
+    lib = oracle.load()
+    odead = np.zeros(nch, bool)
+    for c in range(nch):
+        oc = oracle.OracleChain(**K1)
+        lib.orc_Init_LMS_NR(oc.h, 20)
+        for k in range((loud + quiet) // 128):
+            blk = x[c, k * 128:(k + 1) * 128].copy()
+            lib.orc_LMS_NoiseReduction(oc.h, 128, blk.ctypes.data_as(C.POINTER(C.c_float)))
+        odead[c] = not np.isfinite(oc.lms_coeffs(0)).all()
+    print(f"blow-ups: gpu {int(dead.sum())} (energy flag on {int(((st & 1) != 0).sum())}), oracle {int(odead.sum())} of {nch // 2} transitions")
+    assert dead.any() and odead.any() and not odead[::2].any()
+    # sticky until Init_LMS_NR; the run-away weights are the caller's to clear (NR:62 leaves them)
+    ch.LMS_NoiseReduction(buf[:, :128].contiguous())
+    assert (ch.get_status() == st).all()
+    ch.Init_LMS_NR(20)
+    assert not ch.get_status().any()
 
 
 NLMS_CASES = {
@@ -603,6 +614,9 @@ def test_full_size_k3_sampled_channels(rdsp, oracle, torch_cuda):
     r16, r32 = oracle_run(oracle, iq[sample], K3)
     assert_truth_anchored(o32[sample].cpu().numpy(), r32, model_run(iq[sample], K3), "K3 full size",
                           o16[sample].cpu().numpy(), r16)
+    # the metric configuration meets the north-star's tolerance against the float32 oracle directly
+    # (measured 3e-6 .. 6e-6: the spectral stage's floor and the AGC keep the notch's start-up small)
+    assert normwise(o32[sample].cpu().numpy(), r32) <= TOL
     # every channel produced finite, non-trivial audio under AGC
     pw = o32[..., 0].float().pow(2).mean(dim=1)
     assert bool(torch.isfinite(pw).all()) and float(pw.min()) > 1e-6

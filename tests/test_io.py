@@ -236,3 +236,19 @@ def test_memory_runner_random_shapes_match_resident_processing(rdsp, torch_cuda,
     rc.flush()
     torch.cuda.synchronize()
     assert np.array_equal(out, np.concatenate([p.cpu().numpy() for p in parts], 1))
+
+
+def test_iq_slip_estimate_of_a_recording(rdsp):
+    """rdsp_estimate_iq_slip (host C, no GPU): a stream with a dominant one-sided line loses its image
+    rejection when one rail is a sample late; the estimate names the correction for rdsp_pre_setIQslip."""
+    from radiodsp_sdr_rx_amd.chain import estimate_iq_slip, synth_iq
+    from radiodsp_sdr_rx_amd import RdspError
+    iq = synth_iq(2, 6000)
+    for c in range(2):
+        slip, rej = estimate_iq_slip(iq[c])
+        assert slip == 0 and rej[0] > 30.0 and max(rej[1:]) < 15.0
+        q_late = iq[c].copy(); q_late[1:, 1] = iq[c, :-1, 1]
+        i_late = iq[c].copy(); i_late[1:, 0] = iq[c, :-1, 0]
+        assert estimate_iq_slip(q_late)[0] == 1 and estimate_iq_slip(i_late)[0] == -1
+    with pytest.raises(RdspError):
+        estimate_iq_slip(iq[0, :100])

@@ -27,10 +27,12 @@ def _setup(ch, kind):
         ch.enableNoiseBlanker()
         ch.swapIQ(True)
         ch.setInputGain(0.8)
+    elif kind == "k1_slip":         # the I2S slip correction: its carry word (the last raw sample) travels too
+        ch.setIQslip(1)
 
 
 @pytest.mark.parametrize("kind,cfg", [("k3", K3), ("k3_nr", K3), ("sam_iir", dict(fft_l=512, agc_mode="slow", output_gain=0.5)),
-                                      ("k1", K1), ("cw_2048", dict(fft_l=2048, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0,
+                                      ("k1", K1), ("k1_slip", K1), ("cw_2048", dict(fft_l=2048, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0,
                                                                     nco_hz=11300.0, agc_mode="fast"))])
 def test_resume_and_channel_move_are_bit_exact(rdsp, kind, cfg):
     import torch
@@ -100,3 +102,17 @@ def test_state_argument_errors_are_loud(rdsp):
     b.process(torch.from_numpy(synth_iq(4, 8 * 128)).cuda())
     with pytest.raises(RdspError):
         b.load_state(blob)                                                             # a running chain at another stream position
+    # nothing is restored in part: optional state in the blob needs its place in the chain
+    s = Chain(4, max_blocks_per_call=8, **K1)
+    s.setIQslip(-1)
+    s.process(torch.from_numpy(synth_iq(4, 8 * 128)).cuda())
+    with pytest.raises(RdspError):
+        Chain(4, max_blocks_per_call=8, **K1).load_state(s.save_state())               # slip carry without setIQslip
+    i = Chain(4, max_blocks_per_call=8, **K1)
+    i.setAudioFilterKind(1)
+    i.process(torch.from_numpy(synth_iq(4, 8 * 128)).cuda())
+    with pytest.raises(RdspError):
+        Chain(4, max_blocks_per_call=8, **K1).load_state(i.save_state())               # IIR cascade state without the IIR bank
+    ok = Chain(4, max_blocks_per_call=8, **K1)
+    ok.setAudioFilterKind(1)
+    ok.load_state(i.save_state())
