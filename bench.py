@@ -440,7 +440,7 @@ def main():
     if os.environ.get("RDSP_PRIO"):  # A/B runs: "front_fir_prio,tail_prio"
         fpr, tpr = (int(x) for x in os.environ["RDSP_PRIO"].split(","))
         assert chain.lib.rdsp_chain_set_priorities(chain.h, fpr, tpr) == 0
-    if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 direct-form decimator, 2 frequency domain (default: automatic)
+    if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 direct-form decimator, 2 frequency domain, 4 folded front stage (default: automatic)
         chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]

@@ -256,9 +256,13 @@ int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio
  * the direct form (packed FMAs) elsewhere; 0 the direct form always; 2 the frequency domain
  * (RDSP_ERR_UNSUPPORTED where it does not exist).  Both are the same exact linear convolution with
  * the same taps.  The frequency-domain frames are anchored at each call's first sample, so with it
- * a stream cut into calls differently differs in rounding (~2e-7); with the direct form any call
- * split gives the same bits.  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless
- * the tail stage shares the SIMDs. */
+ * a stream cut into calls differently differs in rounding (2.6e-7 of the output's peak over random
+ * splits, 2.8e-6 through K3's recursive stages: tests/test_gpu_parity.py pins both); with the direct
+ * form any call split gives the same bits.  4: the folded front stage (decimator and overlap-save filter
+ * as one filter in 1024-point frames; decim 4, FFT_L 256 / 512, up to 32 receiver groups, no spectral
+ * stage / blanker / swap: entered at the start of a stream, left for the two-stage kernels at the first
+ * call that does not qualify; measured slower than those as built).
+ * EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the tail stage shares the SIMDs. */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant);
 /* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row, two
  * steps per DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: (16, 4) weights one block

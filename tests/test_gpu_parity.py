@@ -402,6 +402,72 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
             assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
 
+FOLD_CASES = {
+    "k2_usb_256": K1,
+    "lsb_512": dict(fft_l=512, demod="LSB", flo_hz=-2700.0, fhi_hz=-300.0),
+    "iq_256_agc": dict(fft_l=256, demod="IQ", agc_mode="fast", output_gain=0.5),       # blocks of 128 through the ring
+    "am_512_agc": dict(fft_l=512, demod="AM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="slow"),
+    "usb_256_filter_off": dict(fft_l=256, demod="USB", filter_on=0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FOLD_CASES))
+def test_folded_front_stage_matches_oracle(rdsp, oracle, torch_cuda, name):
+    """rdsp_chain_set_fir_variant(chain, 4): decimator and overlap-save filter as ONE frequency-domain pass
+    (1024-point frames).  The same taps, exact linear convolution: TOL against the oracle in
+    one call and in three, int16 within 1 LSB; split calls carry the 1280-sample raw history."""
+    cfg = FOLD_CASES[name]
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    iq = synth_iq(4, 48 * 128)
+    r16, r32 = oracle_run(oracle, iq, cfg)
+    for calls in (1, 3):
+        o16, o32, ch = gpu_run(torch_cuda, iq, cfg, calls=calls, fir=4)
+        assert ch.front_kernel_name() == "rdsp_front_fold_kernel"
+        assert normwise(o32, r32) <= TOL, (name, calls, normwise(o32, r32))
+        assert np.abs(o16.astype(np.int32) - r16).max() <= 1
+
+
+def test_folded_front_stage_is_left_and_kept_as_the_settings_demand(rdsp, oracle, torch_cuda):
+    """The folded form starts with a stream and is left for the two-stage kernels at the first call that
+    does not qualify; the previous hop those continue from is rebuilt from the raw history
+    (rdsp_fold_leave_kernel).  Script: two folded calls, a PBT retune (stays folded: new spectra), a tuning
+    offset change with calls as long as the history window (stays folded, history mixed with the old
+    increment), the spectral stage on (leaves), off again (stays in the two-stage form until reset).
+    Every call follows the oracle at TOL; a second script changes the offset with calls shorter than the
+    window, which leaves the folded form at the change."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch = 3
+    for fft_l, per, expect in ((256, 16, ["fold", "fold", "fold", "fold", "fd", "fd"]),
+                               (512, 8, ["fold", "fold", "fold", "fd", "fd", "fd"])):   # 1024-sample calls < the 1280-sample window
+        iq = synth_iq(nch, 6 * per * 128)
+        cfg = dict(K1, fft_l=fft_l)
+        ch = Chain(nch, max_blocks_per_call=per, **cfg)
+        ch.set_fir_variant(4)
+        ocs = [oracle.OracleChain(**cfg) for _ in range(nch)]
+        names, worst = [], 0.0
+        for k in range(6):
+            if k == 2:
+                ch.reInitializeFilter(350.0, 2600.0)
+                for oc in ocs:
+                    oc.reinit_filter(350.0, 2600.0)
+            if k == 3:
+                ch.setTuningOffsetHz(12150.0)
+                for oc in ocs:
+                    oc.set_nco_hz(12150.0)
+            if k in (4, 5):
+                ch.set_spectral_nr(1 if k == 4 else 0, 2.0)
+                for oc in ocs:
+                    oc.set_spectral_nr(1 if k == 4 else 0, 2.0)
+            part = iq[:, k * per * 128:(k + 1) * per * 128]
+            got = ch.process(torch.from_numpy(np.ascontiguousarray(part)).cuda(), want_f32=True)[1].cpu().numpy()
+            names.append("fold" if ch.front_kernel_name() == "rdsp_front_fold_kernel" else "fd")
+            ref = np.stack([oc.process(part[c])[1] for c, oc in enumerate(ocs)])
+            worst = max(worst, normwise(got, ref))
+            assert normwise(got, ref) <= TOL, (per, k, names, normwise(got, ref))
+        assert names == expect, (per, names)
+
+
 @pytest.mark.parametrize("name,cfg,bound", [("k2", K1, 1e-6), ("k3", K3, TOL)])
 def test_frequency_domain_decimator_call_split_sensitivity_is_pinned(rdsp, torch_cuda, name, cfg, bound):
     """The default decimator (frequency domain) anchors its frames at each call's first sample: the same
