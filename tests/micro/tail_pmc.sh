@@ -1,8 +1,9 @@
 #!/bin/bash
-# PMC passes of the tail kernel alone (tests/micro/tail_bench), product (100) and round-2 form (103).
-# usage (GPU box, repository root): bash tests/micro/tail_pmc.sh
+# PMC passes of the tail kernel alone (tests/micro/tail_bench): the product (variant 100); with an EXPERIMENTAL=1
+# build of the library also 104 (weights one block stale) and 105 (four steps per reduction).
+# usage (GPU box, repository root): bash tests/micro/tail_pmc.sh [variants...]
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r3/tailpmc; mkdir -p $OUT; export TMPDIR=/tmp
-for V in 100 103; do
+for V in ${@:-100}; do
   (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/a_$V -o pmc -- $ROOT/tests/micro/tail_bench 4096 $V > $OUT/a_$V.log 2>&1) || echo "pass a $V failed"
   (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU -d $OUT/b_$V -o pmc -- $ROOT/tests/micro/tail_bench 4096 $V > $OUT/b_$V.log 2>&1) || echo "pass b $V failed"
 done
