@@ -500,6 +500,7 @@ def main():
     # N > 1 with the default workload: a second, separately timed leg at BASELINE.json configs[4]'s shape
     # (K5: 8192 channels per GPU, full chain), so that the driver's `--gpus 8` form also yields the
     # 65 536-channel figure; the headline `value` stays the K3 per-GPU workload for every N
+    fname = chain.front_kernel_name()   # rdsp_front_fd_kernel (stage A3 in the frequency domain) or rdsp_front_kernel
     k5_leg = None
     if world > 1 and args.config == "K3" and not args.channels_per_gpu and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
         del iq, out, chain
@@ -540,7 +541,6 @@ def main():
         # dominant kernel: the front kernel (it carries the IQ stream: 4 B in + 4/D B out per input
         # sample, the chain's own figure) unless the tail kernel -- 4 B in + 4 B out per OUTPUT sample --
         # runs clearly longer; in pipelined mode both run for the whole step, within a few percent
-        fname = chain.front_kernel_name()   # rdsp_front_fd_kernel (stage A3 in the frequency domain) or rdsp_front_kernel
         if tail_avg > 1.10 * front_avg:
             dom, dom_ms, B_own = "rdsp_tail_kernel", tail_avg, 8.0 / decim
         else:
