@@ -829,6 +829,9 @@ int orc_chain_process(orc_chain_t *c, const int16_t *iq, int n_blocks,
         if (c->nb_level > 0.0f && pw > c->nb_level * c->nb_thr) {
           xr = 0.0f;
           xi = 0.0f;
+          /* what the chain keeps of a sample is the blanked word: a slip correction switched on at the
+           * next call pairs its first sample with that (while the correction runs it works on raw words) */
+          if (c->iq_slip == 0) c->slip_i = c->slip_q = 0;
         } else {
           c->nb_acc += pw;
         }

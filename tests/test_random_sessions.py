@@ -24,7 +24,7 @@ def make_script(rng, n_ops=40, granule=8):
     ops = []
     for _ in range(n_ops):
         kind = rng.choice(["proc", "proc", "proc", "als", "nr", "spec", "agc", "gdemod", "gfilt", "gpbt", "goff", "gaf",
-                           "nb", "swap", "mute", "ogain", "igain", "bal", "afk"])
+                           "nb", "swap", "slip", "mute", "ogain", "igain", "bal", "afk"])
         g = int(rng.integers(0, NGROUPS))
         if kind == "proc":
             ops.append(("proc", granule * int(rng.integers(1, 32 // granule + 1))))
@@ -51,6 +51,8 @@ def make_script(rng, n_ops=40, granule=8):
             ops.append(("nb", bool(rng.integers(0, 2)), float(rng.choice([6.0, 10.0, 20.0]))))
         elif kind == "swap":
             ops.append(("swap", bool(rng.integers(0, 2))))
+        elif kind == "slip":
+            ops.append(("slip", int(rng.choice([-1, 0, 0, 1]))))
         elif kind == "mute":
             ops.append(("mute", bool(rng.integers(0, 4) == 0)))
         elif kind == "ogain":
@@ -105,6 +107,8 @@ def apply_setter(ch, rdsp, op):
         ch.setNoiseBlankerThresholdDb(op[2])
     elif k == "swap":
         ch.swapIQ(op[1])
+    elif k == "slip":
+        ch.setIQslip(op[1])
     elif k == "mute":
         ch.setMute(op[1])
     elif k == "ogain":
@@ -223,7 +227,7 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
     band = [(300.0, 2700.0)] * n_groups
     gains = dict(input_gain=1.0, iq_balance=1.0, output_gain=0.5, mute=False)
     for _ in range(n_ops):
-        kind = str(rng.choice(["proc", "proc", "proc", "dcp", "mode", "filt", "pbt", "nco", "swap", "nb", "gain", "agc", "spec"]))
+        kind = str(rng.choice(["proc", "proc", "proc", "dcp", "mode", "filt", "pbt", "nco", "swap", "slip", "nb", "gain", "agc", "spec"]))
         g = int(rng.integers(0, n_groups))
         if kind == "proc":
             ops.append(("proc", granule * int(rng.integers(1, 4))))
@@ -247,6 +251,8 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
             ops.append(("nco", g, float(rng.choice([12000.0, 11300.0, 12650.0]))))
         elif kind == "swap":
             ops.append(("swap", bool(rng.integers(0, 2))))
+        elif kind == "slip":
+            ops.append(("slip", int(rng.choice([-1, 0, 1]))))
         elif kind == "nb":
             ops.append(("nb", bool(rng.integers(0, 2)), float(rng.choice([8.0, 12.0]))))
         elif kind == "agc":
@@ -343,6 +349,10 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
             ch.swapIQ(op[1])
             for oc in ocs:
                 oc.set_swap_iq(op[1])
+        elif k == "slip":
+            ch.setIQslip(op[1])
+            for oc in ocs:
+                oc.set_iq_slip(op[1])
         elif k == "nb":
             ch.enableNoiseBlanker() if op[1] else ch.disableNoiseBlanker()
             ch.setNoiseBlankerThresholdDb(op[2])
