@@ -295,6 +295,12 @@ int rdsp_chain_get_lms_coeffs(rdsp_chain_t *c, int which, float *host_out, void 
 #define RDSP_STATUS_ALS_ENERGY 0x10u    /* ALS notch / peak instance, likewise */
 #define RDSP_STATUS_ALS_NONFINITE 0x20u
 int rdsp_chain_get_status(rdsp_chain_t *c, uint32_t *host_out, void *stream);
+/* Recovery for the channels the health words name: arm_lms_norm_init_f32 leaves the coefficients
+ * (RDSP_noise_reduction.h:62), so Init_LMS_NR does not clear weights that have run away, and the sketch's
+ * only cure is a power cycle.  which 0: the DSP-NR instance, 1: the ALS instance; weights, delay block,
+ * energy and health word of channels [first_channel, first_channel + n_channels) go back to their boot
+ * values, in stream order behind what is queued; every other channel continues bit for bit. */
+int rdsp_chain_reset_nlms_channels(rdsp_chain_t *c, int which, int first_channel, int n_channels, void *stream);
 /* natural-order filter mask currently in use, float[2*fft_l] (CONV:77) */
 int rdsp_chain_get_mask(rdsp_chain_t *c, float *host_out);
 int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);

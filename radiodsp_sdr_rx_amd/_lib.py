@@ -135,6 +135,7 @@ SYMBOLS = [
     ("rdsp_chain_load_state", _i, [_vp, _i, _vp, C.c_size_t, _vp]),
     ("rdsp_chain_get_lms_coeffs", _i, [_vp, _i, _f32p, _vp]),
     ("rdsp_chain_get_status", _i, [_vp, C.POINTER(C.c_uint32), _vp]),
+    ("rdsp_chain_reset_nlms_channels", _i, [_vp, _i, _i, _i, _vp]),
     ("rdsp_chain_get_mask", _i, [_vp, _f32p]),
     ("rdsp_iq_reader_open", _i, [C.c_char_p, _i, C.POINTER(_vp)]),
     ("rdsp_iq_reader_sample_rate", _d, [_vp]),

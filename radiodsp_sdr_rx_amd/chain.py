@@ -243,6 +243,11 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_get_status(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), _stream_ptr(stream)))
         return a
 
+    def reset_nlms_channels(self, which, first_channel, n_channels=1, stream=None):
+        """boot values for the NLMS instance (0 DSP-NR, 1 ALS) of a range of channels: the cure for a channel
+        the health words name (include/rdsp.h rdsp_chain_reset_nlms_channels)"""
+        _lib.check(self.lib.rdsp_chain_reset_nlms_channels(self.h, int(which), int(first_channel), int(n_channels), _stream_ptr(stream)))
+
     def mask(self):
         a = np.zeros(2 * self.fft_l, np.float32)
         _lib.check(self.lib.rdsp_chain_get_mask(self.h, a.ctypes.data_as(_lib._f32p)))

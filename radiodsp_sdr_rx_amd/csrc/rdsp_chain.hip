@@ -1718,6 +1718,32 @@ extern "C" int rdsp_chain_get_scalars(rdsp_chain_t *c, float *host_out, void *st
   HIP_TRY(hipMemcpy(host_out, c->d_scal, sizeof(float) * 4 * (size_t)c->n_channels, hipMemcpyDeviceToHost));
   return RDSP_OK;
 }
+/* A channel whose NLMS instance has run away (rdsp_chain_get_status) stays dead: arm_lms_norm_init_f32
+ * leaves the coefficients (NR:62), so Init_LMS_NR does not clear infinite weights, and the sketch's only
+ * cure is a power cycle.  With thousands of receivers the host clears just the ones that need it: the
+ * instance's weights, delay block, energy and health word of channels [first, first + count) go back to
+ * their boot values, in stream order behind everything queued so far; no other channel is touched. */
+extern "C" int rdsp_chain_reset_nlms_channels(rdsp_chain_t *c, int which, int first_channel, int n_channels, void *stream_) {
+  NEED(c);
+  if ((which != 0 && which != 1) || first_channel < 0 || n_channels <= 0 || first_channel + n_channels > c->n_channels) {
+    rdsp_set_error("rdsp_chain_reset_nlms_channels: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail)); /* the tail stage owns these arrays */
+  const size_t f = (size_t)first_channel, n = (size_t)n_channels, nch = (size_t)c->n_channels;
+  float *w = which ? c->d_als_w : c->d_nr_w, *prev = which ? c->d_als_prev : c->d_nr_prev, *en = which ? c->d_als_energy : c->d_nr_energy;
+  HIP_TRY(hipMemsetAsync(w + RDSP_LMS_TAPS * f, 0, sizeof(float) * RDSP_LMS_TAPS * n, stream));
+  HIP_TRY(hipMemsetAsync(prev + RDSP_BLOCK * f, 0, sizeof(float) * RDSP_BLOCK * n, stream));
+  HIP_TRY(hipMemsetAsync(en + f, 0, sizeof(float) * n, stream));
+  HIP_TRY(hipMemsetAsync(c->d_status + (which ? nch : 0) + f, 0, sizeof(uint32_t) * n, stream));
+  if (c->s_tail) {
+    HIP_TRY(hipEventRecord(c->ev_misc, stream));
+    HIP_TRY(hipStreamWaitEvent(c->s_tail, c->ev_misc, 0));
+  }
+  return RDSP_OK;
+}
 /* per-channel health word: RDSP_STATUS_* bits, sticky until rdsp_Init_LMS_NR (DSP-NR bits) / rdsp_chain_reset */
 extern "C" int rdsp_chain_get_status(rdsp_chain_t *c, uint32_t *host_out, void *stream) {
   NEED(c);

@@ -301,7 +301,8 @@ def test_nlms_health_word_flags_the_channels_that_blow_up(rdsp, oracle, torch_cu
     channel's weights run away -- in the CPU restatement and on the GPU alike.  The tail
     kernel records it per channel (rdsp_chain_get_status): the non-finite bit is set for exactly the
     channels whose weights are not finite, every such channel also carries the energy bit (the cause),
-    quiet channels carry nothing, and Init_LMS_NR clears the words.  The arithmetic is untouched: the
+    quiet channels carry nothing, rdsp_chain_reset_nlms_channels cures the named channels and no other, and
+    Init_LMS_NR clears the words.  The arithmetic is untouched: the
     same script through the oracle blows up too (not necessarily in the same channels: which residue
     lands below zero is a draw of float32 rounding)."""
     import ctypes as C
@@ -338,9 +339,27 @@ def test_nlms_health_word_flags_the_channels_that_blow_up(rdsp, oracle, torch_cu
         odead[c] = not np.isfinite(oc.lms_coeffs(0)).all()
     print(f"blow-ups: gpu {int(dead.sum())} (energy flag on {int(((st & 1) != 0).sum())}), oracle {int(odead.sum())} of {nch // 2} transitions")
     assert dead.any() and odead.any() and not odead[::2].any()
-    # sticky until Init_LMS_NR; the run-away weights are the caller's to clear (NR:62 leaves them)
-    ch.LMS_NoiseReduction(buf[:, :128].contiguous())
-    assert (ch.get_status() == st).all()
+    # sticky; and Init_LMS_NR would not cure a dead channel (NR:62 leaves the coefficients): the host
+    # resets just the channels the words name, every other channel continues bit for bit
+    more = torch.from_numpy((1e-4 * rng.standard_normal((nch, 256))).astype(np.float32)).cuda()
+    ref = Chain(nch, **K1)                      # the same stream without the cure
+    ref.Init_LMS_NR(20)
+    rb = torch.from_numpy(x.copy()).cuda()
+    ref.LMS_NoiseReduction(rb[:, :loud].contiguous())
+    ref.LMS_NoiseReduction(rb[:, loud:].contiguous())
+    a, b = more.clone(), more.clone()
+    ch.LMS_NoiseReduction(a[:, :128].contiguous())
+    st2 = ch.get_status()
+    assert ((st2 & st) == st).all()             # sticky: bits are only ever added
+    st, dead = st2, (st2 & ch.STATUS_NR_NONFINITE) != 0
+    for c in np.where(dead)[0]:
+        ch.reset_nlms_channels(0, int(c))
+    assert not (ch.get_status()[dead]).any() and (ch.get_status()[~dead] == st[~dead]).all()
+    oa = ch.LMS_NoiseReduction(a[:, 128:].contiguous()).cpu().numpy()
+    ref.LMS_NoiseReduction(b[:, :128].contiguous())
+    ob = ref.LMS_NoiseReduction(b[:, 128:].contiguous()).cpu().numpy()
+    assert np.isfinite(oa[dead]).all() and np.isfinite(ch.lms_coeffs(0)[dead]).all() and not ch.get_status()[dead].any()
+    assert np.array_equal(oa[~dead], ob[~dead], equal_nan=True)   # (a channel that dies in this very block dies in both)
     ch.Init_LMS_NR(20)
     assert not ch.get_status().any()
 
