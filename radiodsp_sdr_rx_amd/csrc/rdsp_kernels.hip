@@ -404,8 +404,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     {
       const float2 *mp = p.mask_pool + G.mask_off;
       if constexpr (LEAN) asm volatile("" : "+s"(mp));
+      const auto gp = as_global(mp);
 #pragma unroll
-      for (int e = 0; e < P; e++) mreg[e] = mp[e * NT + tid];
+      for (int e = 0; e < P; e++) mreg[e] = gp[e * NT + tid];
     }
     float2 ph_base = make_float2(1.f, 0.f);
     if (G.dphi != 0u)
@@ -799,8 +800,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       {
         const float2 *mp = p.fd_mask + (size_t)r * ND;
         asm volatile("" : "+s"(mp));
+        const auto gp = as_global(mp);
 #pragma unroll
-        for (int e = 0; e < PD; e++) gm[e] = mp[e * 64 + lane];
+        for (int e = 0; e < PD; e++) gm[e] = gp[e * 64 + lane];
       }
       float2 v[PD];
 #pragma unroll
@@ -860,8 +862,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       {
         const float2 *mp = p.mask_pool + G.mask_off;
         asm volatile("" : "+s"(mp));
+        const auto gp = as_global(mp);
 #pragma unroll
-        for (int e = 0; e < P; e++) mreg[e] = mp[e * NT + tid];
+        for (int e = 0; e < P; e++) mreg[e] = gp[e * NT + tid];
       }
       const int base = consumed;
       front_frame<N, P, false>(p, G, tw, lb, wb, red, mreg, vadbits, vad_inv, vprev, nfloor, agc_g, am_dc, frame_idx, ch,
@@ -1012,9 +1015,10 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
       {
         const float2 *mp = fimg + (size_t)r * ND;
         asm volatile("" : "+s"(mp));
+        const auto gp = as_global(mp);
 #pragma unroll
         for (int e = 0; e < PD; e++) {
-          const float2 gm = mp[e * 64 + lane];
+          const float2 gm = gp[e * 64 + lane];
           acc[e] = (r == 0) ? cmul(v[e], gm) : cmac(acc[e], v[e], gm);
         }
       }

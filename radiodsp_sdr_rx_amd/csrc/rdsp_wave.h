@@ -8,6 +8,22 @@
 
 namespace {
 
+/* A pointer that went through an `asm volatile("" : "+s"(p))` (to keep a table's loads inside a loop)
+ * has lost its provenance: the compiler can no longer prove it global and emits FLAT loads, which
+ * count on lgkmcnt as well as vmcnt -- every `s_waitcnt lgkmcnt(0)` of an LDS exchange behind them
+ * then waits out the table's L2 round trip.  Saying "global" again gives `global_load ... s[base]`. */
+struct GlobalF2 {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  const __attribute__((address_space(1))) v2 *p;
+  __device__ __forceinline__ float2 operator[](int i) const {
+    const v2 v = p[i];
+    return make_float2(v[0], v[1]);
+  }
+};
+__device__ __forceinline__ GlobalF2 as_global(const float2 *p) {
+  return GlobalF2{(const __attribute__((address_space(1))) GlobalF2::v2 *)p};
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(
