@@ -84,9 +84,16 @@ struct NlmsB {
   float energy;
   float emin; /* smallest energy + eps this lane has divided by (health word: <= 0 means a blow-up) */
 
-  static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) {
-    /* m even: one aligned ds_read_b64; m odd: two dwords (the compiler pairs them as ds_read2_b32) */
-    return v2f{mine[m], mine[m + 1]};
+  /* m odd: two dwords (the compiler pairs them as ds_read2_b32: 4 LDS cycles, and the two channels of a
+   * 32-lane group -- lane addresses m - 6 sub, all of one parity -- collide whatever 16-byte-aligned
+   * offset lies between them: 8).  m even: ONE aligned ds_read_b64 (2 LDS cycles; conflict-free with
+   * the channels 32 dwords apart mod 64, see PER_CH) -- volatile, so that it is neither split into
+   * dwords nor paired into a ds_read2_b64 (8 cycles).  In pipelined K3 the tail kernel's LDS cycles are
+   * more than the front kernel's (PMC, round 3) and these reads were 60 % of them. */
+  static __device__ __forceinline__ v2f pair_ld(const float *mine, int m) { return v2f{mine[m], mine[m + 1]}; }
+  static __device__ __forceinline__ v2f pair_ld_even(const float *mine, int m) {
+    typedef const volatile __attribute__((address_space(3))) v2f *LP;
+    return *(LP)(mine + m);
   }
   __device__ __forceinline__ void load(const float *wst, const float *est, size_t ch, int sub) {
 #pragma unroll
@@ -145,13 +152,9 @@ struct NlmsB {
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;
-    /* an opaque copy of the pointer for the even pairs: consecutive pairs overlap by a sample, and
-     * through one pointer the compiler reads the shared dword once and glues the pairs together with
-     * v_mov instructions that wait for the LDS right behind the reads (PMC, round 3: 37 % of the
-     * kernel's wave-cycles were spent in s_waitcnt) */
-    int zero = 0;
-    asm volatile("" : "+v"(zero));
-    const float *mine_b = mine + zero;
+    /* (the even pairs are read by instructions of their own: consecutive pairs overlap by a sample, and
+     * left to itself the compiler reads the shared dword once and glues the pairs together with v_mov
+     * instructions that wait for the LDS right behind the reads) */
     float bb = 0.f; /* B_{-1} = X_{-2}.X_{-1} */
 #pragma unroll
     for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
@@ -159,7 +162,7 @@ struct NlmsB {
     float e_base = energy;
     prepare(cur, 0, sub, mu, e_base, b_base, scr, emin);
 #pragma unroll
-    for (int m = -5; m <= 0; m++) P[m & 7] = pair_ld((m & 1) ? mine : mine_b, m);
+    for (int m = -5; m <= 0; m++) P[m & 7] = (m & 1) ? pair_ld(mine, m) : pair_ld_even(mine, m);
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
       const float *sc = scr + ((s0 / GS) & 1) * SCR;
@@ -187,7 +190,7 @@ struct NlmsB {
            * blocks ago (Pair(n-7), Pair(n-6)): a whole block of time for the LDS reads to land */
           if ((n + 3 < GS) || (s0 + GS < RDSP_BLOCK)) {
             P[(n + 1) & 7] = pair_ld(mine, s0 + n + 1);   /* odd: two dwords */
-            P[(n + 2) & 7] = pair_ld(mine_b, s0 + n + 2); /* even */
+            P[(n + 2) & 7] = pair_ld_even(mine, s0 + n + 2);
           }
           /* (A_0, A_1) lane parts: taps k = 0..5 against Pair(n - k) */
           v2f acc = v2f{w2[0][0], w2[0][0]} * P[n & 7];
@@ -257,8 +260,11 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
   constexpr int CPW = 4, SPL = RDSP_BLOCK / 16; /* channels per wave, samples per lane per block */
   constexpr int RINGS = DUAL ? 2 : 1;
   constexpr int FIN = NL::OUT_IN_SCR ? 0 : RDSP_BLOCK;
-  /* +4: consecutive channels start four LDS banks apart */
-  constexpr int PER_CH = 2 * RINGS * RDSP_BLOCK + FIN + NL::LDS_SCR + 4;
+  /* consecutive channels start 32 dwords apart mod 64: the even sample pairs of the two channels of a
+   * 32-lane group (float2 index -3 sub each) then fall on disjoint halves of the 64 banks */
+  constexpr int PER_CH0 = 2 * RINGS * RDSP_BLOCK + FIN + NL::LDS_SCR;
+  constexpr int PER_CH = PER_CH0 + (96 - PER_CH0 % 64) % 64;
+  static_assert(PER_CH % 64 == 32 && PER_CH % 4 == 0, "channel pitch in LDS");
   static_assert(!(DUAL && NL::OUT_IN_SCR), "the two-instance kernel hands a block on through `out`");
   __shared__ __attribute__((aligned(16))) float lds[CPW][PER_CH];
   if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
