@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include <complex>
+#include <type_traits>
 #include "rdsp_fft.h"
 using namespace rdsp;
 
@@ -44,10 +45,33 @@ double check() {
     for (int j = 0; j < P; j++) v[j] = x[t + j * NT];
     fwd_pass0_store<N, P>(lb[t], v, wb.data(), tw[t][0]);
   }
-  // middle passes: must be emulated pass by pass over all threads
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 1, ALIAS>(lb[t], wb.data(), tw[t][1]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 2, ALIAS>(lb[t], wb.data(), tw[t][2]);
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, 3, ALIAS>(lb[t], wb.data(), tw[t][3]);
+  // middle passes: emulated pass by pass over all threads.  The one-wave plans read under the map of one
+  // exchange and write under the next one's (every lane of the wave has read before any writes): all
+  // loads of a pass first, then all stores.  The four-wave plans run in place, thread after thread.
+  static float2 regs[NT][P];
+  auto fwd_mid = [&](auto pidx) {
+    constexpr int PIDX = decltype(pidx)::value;
+    if constexpr (PL::PERX) {
+      for (int t = 0; t < NT; t++) fwd_mid_load<N, P, PIDX, ALIAS>(lb[t], regs[t], wb.data());
+      for (auto &e : wb) if (!ALIAS) e = make_float2(7e33f, 7e33f);  // nothing of the old image may be read again
+      for (int t = 0; t < NT; t++) fwd_mid_store<N, P, PIDX, ALIAS>(lb[t], regs[t], wb.data(), tw[t][PIDX]);
+    } else {
+      for (int t = 0; t < NT; t++) fwd_pass_mid<N, P, PIDX, ALIAS>(lb[t], wb.data(), tw[t][PIDX]);
+    }
+  };
+  auto inv_mid = [&](auto pidx) {
+    constexpr int PIDX = decltype(pidx)::value;
+    if constexpr (PL::PERX) {
+      for (int t = 0; t < NT; t++) inv_mid_load<N, P, PIDX, ALIAS>(lb[t], regs[t], wb.data());
+      for (auto &e : wb) if (!ALIAS) e = make_float2(7e33f, 7e33f);
+      for (int t = 0; t < NT; t++) inv_mid_store<N, P, PIDX, ALIAS>(lb[t], regs[t], wb.data(), tw[t][PIDX]);
+    } else {
+      for (int t = 0; t < NT; t++) inv_pass_mid<N, P, PIDX, ALIAS>(lb[t], wb.data(), tw[t][PIDX]);
+    }
+  };
+  if constexpr (PL::NP >= 3) fwd_mid(std::integral_constant<int, 1>());
+  if constexpr (PL::NP >= 4) fwd_mid(std::integral_constant<int, 2>());
+  if constexpr (PL::NP >= 5) fwd_mid(std::integral_constant<int, 3>());
   static_assert(PL::NP <= 5, "extend harness");
   std::vector<float2> spec(N);
   double emax = 0, xmax = 0;
@@ -69,9 +93,9 @@ double check() {
     for (int e = 0; e < P; e++) v[e] = spec[t * P + e];
     inv_pass_last<N, P>(lb[t], v, wb.data());
   }
-  if constexpr (PL::NP >= 5) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 3, ALIAS>(lb[t], wb.data(), tw[t][3]);
-  if constexpr (PL::NP >= 4) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 2, ALIAS>(lb[t], wb.data(), tw[t][2]);
-  if constexpr (PL::NP >= 3) for (int t = 0; t < NT; t++) inv_pass_mid<N, P, 1, ALIAS>(lb[t], wb.data(), tw[t][1]);
+  if constexpr (PL::NP >= 5) inv_mid(std::integral_constant<int, 3>());
+  if constexpr (PL::NP >= 4) inv_mid(std::integral_constant<int, 2>());
+  if constexpr (PL::NP >= 3) inv_mid(std::integral_constant<int, 1>());
   double imax = 0;
   for (int t = 0; t < NT; t++) {
     float2 v[P];
