@@ -775,6 +775,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
     {
       float2 b1 = make_float2(1.f, 0.f);
       if (G.dphi != 0u) b1 = nco_phasor_alu((nq + 256u) * G.dphi);
+      /* Without PRE the launch code guarantees one gain for I and Q, history included: it rides on the
+       * phasors (two packed multiplies per frame) instead of on every sample (32); x (g ph) = (x g) ph
+       * to the bit when g is a power of two -- unit input gain -- and to an ulp otherwise */
+      if constexpr (!PRE) b1 = make_float2(b1.x * p.scale_i, b1.y * p.scale_i);
       pj[1] = b1;
       if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotq1);
       if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotq2);
@@ -782,8 +786,12 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       for (int j = 4; j < PD; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
       /* column 0: history of the previous call in frame 0 (mixed with the increment it came in
        * with), else one column before b1 */
-      if (fr == 0) pj[0] = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
-      else pj[0] = cmulc_uniform(b1, G.rotq1);
+      if (fr == 0) {
+        pj[0] = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
+        if constexpr (!PRE) pj[0] = make_float2(pj[0].x * p.scale_i, pj[0].y * p.scale_i);
+      } else {
+        pj[0] = cmulc_uniform(b1, G.rotq1);
+      }
     }
     const bool hist = (fr == 0);
     /* column 0 of the call's first frame is the previous call's samples: they keep the swap flag and
@@ -809,7 +817,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       for (int j = 0; j < PD; j++) {
         uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
         if (j == 0 ? swap0 : SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
-        float2 x = unpack_iq(w, j == 0 ? si0 : p.scale_i, j == 0 ? sq0 : p.scale_q);
+        float2 x;
+        if constexpr (PRE) x = unpack_iq(w, j == 0 ? si0 : p.scale_i, j == 0 ? sq0 : p.scale_q);
+        else x = make_float2((float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16));
         float2 ph = pj[j];
         if (r > 0) {
           const float2 rr = (r == 1) ? G.rot1 : (r == 2) ? G.rot2 : G.rot3;
@@ -1283,7 +1293,8 @@ template <int N, int P, int DECIM, bool LEAN>
 int launch_front_v(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   /* PRE: blanker, swap, or a FIR history that came in under another swap flag / other input gains */
   const bool hist_differs = p->swap_hist != p->swap_iq || p->scale_i_hist != p->scale_i || p->scale_q_hist != p->scale_q;
-  return (p->nb_on || p->swap_iq || hist_differs) ? launch_front_w<N, P, DECIM, LEAN, true>(p, n_channels, stream)
+  /* ... or different gains on I and Q (iq_balance): the kernels without PRE fold the one gain into the mixer */
+  return (p->nb_on || p->swap_iq || hist_differs || p->scale_i != p->scale_q) ? launch_front_w<N, P, DECIM, LEAN, true>(p, n_channels, stream)
                                   : launch_front_w<N, P, DECIM, LEAN, false>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM>
