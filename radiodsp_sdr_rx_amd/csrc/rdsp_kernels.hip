@@ -91,9 +91,10 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
 #pragma unroll
     for (int e = 0; e < P; e++) {
       /* |X| and 1/|X| from one v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt and a
-       * division per bin; the floor keeps rsq finite on empty bins, where |X| = 0 * r = 0 */
-      const float pw = v[e].x * v[e].x + v[e].y * v[e].y;
-      rmag[e] = __builtin_amdgcn_rsqf(fmaxf(pw, 1e-30f));
+       * division per bin; the floor keeps rsq finite on empty bins (|X| = 1e-15 there; it is
+       * absorbed by any power above 1e-22) */
+      const float pw = fmaf(v[e].y, v[e].y, fmaf(v[e].x, v[e].x, 1e-30f)); /* the floor rides in the sum */
+      rmag[e] = __builtin_amdgcn_rsqf(pw);
       mag[e] = pw * rmag[e];                              /* SPEC:182 */
       part += ((vadbits >> e) & 1u) ? mag[e] : 0.f;       /* SPEC:194-197 */
     }

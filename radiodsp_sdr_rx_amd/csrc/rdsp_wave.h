@@ -37,14 +37,19 @@ __device__ __forceinline__ float row_allsum(float v) {
   v += dpp_f<0x140>(v); /* row_mirror */
   return v;
 }
-/* sum over the 64-lane wave, wave-uniform result */
+/* sum over the 64-lane wave, wave-uniform result: the row sums, then row_bcast:15 into rows 1 and 3
+ * and row_bcast:31 into rows 2 and 3 leave (r2 + r3) + (r0 + r1) in the last row -- the same pairs
+ * as four v_readlane and three adds, to the bit, in 7 vector instructions instead of 13 */
 __device__ __forceinline__ float wave_sum(float v) {
   v = row_allsum(v);
-  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  return (a + b) + (c + d);
+  /* masked adds (rows outside row_mask keep their value): the compiler's DPP combiner does not fold a
+   * row-masked update_dpp into the add, so they are written out, wait states for the DPP reads included */
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 /* `float_buffer_L[i] * 1.1` of CONV:334: the literal is a double, so the product is formed in
