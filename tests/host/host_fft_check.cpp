@@ -116,7 +116,17 @@ double check() {
   return fwd_err > imax ? fwd_err : imax;
 }
 
-int main() {
+template <int N, int P>
+void print_maps() {
+  using PL = FftPlan<N, P>;
+  for (int x = 0; x < PL::NP - 1; x++) printf("map %d %d %d %d %d %d\n", N, P, x, PL::xshift(x), PL::xmul(x), PL::WB);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) { /* the LDS maps of the plans, for tests/micro/lds_model.py (test_host_logic.py) */
+    print_maps<256, 4>(); print_maps<512, 8>(); print_maps<1024, 16>(); print_maps<2048, 8>(); print_maps<4096, 16>();
+    return 0;
+  }
   double w = 0;
   w = fmax(w, check<256, 4, false>());
   w = fmax(w, check<512, 8, false>());

@@ -162,6 +162,39 @@ def test_kernel_index_arithmetic_on_host(src, tmp_path):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_fft_lds_maps_are_bank_conflict_free_under_the_lds_model(tmp_path):
+    """The per-exchange LDS maps compiled into FftPlan (printed by the host harness) against the bank model
+    of tests/micro/lds_model.py (ds_write_b64: 16 contiguous lanes over 32 banks; ds_read_b64: 32 lanes
+    over 64 banks): every exchange of the one-wave plans costs exactly the conflict-free cycles for both of
+    its lane patterns, as written and as read, and fits the work buffer; the four-wave plans keep phi."""
+    import importlib.util
+    exe = str(tmp_path / "host_fft_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", "-I",
+                           os.path.join(ROOT, "radiodsp_sdr_rx_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", "host_fft_check.cpp"), "-o", exe])
+    out = subprocess.run([exe, "maps"], capture_output=True, text=True, check=True).stdout
+    spec = importlib.util.spec_from_file_location("lds_model", os.path.join(ROOT, "tests", "micro", "lds_model.py"))
+    lm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lm)
+    seen = 0
+    for line in out.splitlines():
+        f = line.split()
+        if not f or f[0] != "map":
+            continue
+        N, P, x, shift, mul, wb = (int(v) for v in f[1:])
+        A = lambda i: i + mul * (i >> shift)
+        assert A(N - 1) + 1 <= wb, (N, P, x)
+        nt, pats = lm.plan(N, P)
+        if nt == 64:
+            for pat in (pats[x], pats[x + 1]):
+                assert lm.pattern_cost(N, P, A, pat) == (1.0, 1.0), (N, P, x)
+            assert (shift, mul) == lm.PERX[(N, P)][x]
+        else:
+            assert (1 << shift, mul) == (P, 1)
+        seen += 1
+    assert seen == 3 + 2 + 2 + 3 + 2
+
+
 def test_host_c_under_address_and_ub_sanitizers(tmp_path):
     """rdsp_graph.c, rdsp_io.c and rdsp_design.c (no HIP in them) built with ASan + UBSan + LSan
     and walked by tests/host/host_sanitize.c: pool exhaustion, teardown with blocks queued,
