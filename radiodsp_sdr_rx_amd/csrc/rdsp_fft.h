@@ -9,9 +9,9 @@
  * digit-reversed position; the filter mask is stored in that order, so no
  * reordering pass exists.  Inverse = the exact transpose (decimation-in-time)
  * and lands in natural time order.  Between passes the data goes through LDS
- * at phi(i) = i + i/P, which keeps every pass within 1.33x of conflict-free
- * (measured offline over all lane patterns).  Per-thread twiddles live in
- * registers for the whole kernel.
+ * under one address map per exchange (FftPlan::xshift / xmul): bank-conflict-free
+ * for the one-wave plans, phi(i) = i + i/P for the four-wave ones.  Per-thread
+ * twiddles live in registers for the whole kernel.
  *
  * Everything here is __host__ __device__ so tests/host_fft_check.cpp can run
  * the same code thread by thread on the CPU.
@@ -432,11 +432,11 @@ RDSP_HD void make_twiddle_bases(int t, float2 *w1) {
 }
 
 /* LDS addressing.  A thread touches, in pass p, the positions base_p + j*s_p
- * (j = 0..P-1); through the padded map phi(i) = i + i/P that is
- *     phi(base_p) + j*s_p + (j*s_p)/P        (s_p and P are powers of two, so
- * the offset inside the span never carries), i.e. a per-thread constant that is
- * computed once per kernel plus a compile-time offset the assembler folds into
- * the ds_read/ds_write immediate.
+ * (j = 0..P-1); through a padded map A(i) = i + c (i >> a) that is
+ *     A(base_p) + j*s_p + c ((j*s_p) >> a)   (base_p has no bits in j's field and
+ * s_p is a power of two, so nothing carries across the shift), i.e. a per-thread
+ * constant that is computed once per kernel plus a compile-time offset the
+ * assembler folds into the ds_read/ds_write immediate.
  *
  * ALIAS = true places the work buffer inside the polyphase planes of the FIR
  * (rdsp_front.h): after the FIR of a chunk only the first 17 entries of each of
