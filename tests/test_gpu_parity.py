@@ -155,6 +155,9 @@ FF_CASES = {
     "agc_fast_slow": (dict(fft_l=512, demod="USB", agc_mode="slow", output_gain=0.5), 4, 64, False),
     "am_agc": (dict(fft_l=512, demod="AM", flo_hz=-3900.0, fhi_hz=3900.0, agc_mode="medium"), 3, 32, False),
     "iq_gains": (dict(fft_l=512, demod="IQ", agc_mode="fast", input_gain=0.7, iq_balance=1.02, output_gain=0.5), 3, 32, False),
+    # one gain for I and Q that is not a power of two: the kernels without PRE carry it on the mixer phasors
+    "input_gain_0p7_usb": (dict(fft_l=512, demod="USB", input_gain=0.7, agc_mode="medium"), 3, 32, False),
+    "input_gain_1p3_cw_4096": (dict(K4, input_gain=1.3), 2, 128, True),
     "nco_off_filter_off": (dict(fft_l=256, demod="IQ", nco_hz=0.0, filter_on=0), 2, 16, False),
     "odd_nco": (dict(fft_l=256, demod="USB", nco_hz=12345.678), 3, 32, False),
 }
