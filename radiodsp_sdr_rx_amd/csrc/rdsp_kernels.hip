@@ -667,12 +667,23 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
 
   /* raw quads of this wave's first frame (frame `wave`): column j holds quads
    * fr*VAL - 64 + lane + 64 j; for frame 0 column 0 is the FIR history (the 64 quads before the call) */
+  /* The call's input of this channel as a raw buffer: a quad past the end of the call reads as zeros by the
+   * buffer's range check -- no compare, no exec-mask branch and no zeroed registers per load, and the
+   * loads are unconditional, so the waits for the table loads issued before them are counted exactly
+   * (behind a conditional load the compiler has to assume it was not issued, and every wait for an
+   * older load became a wait for the whole prefetch: an HBM round trip inside the frame) */
+  const __amdgpu_buffer_rsrc_t iq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(iq), 0, 16 * total, 0x00020000);
+  auto ld_quad = [&](int q) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, 0);
+    return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+  };
   uint4 rq[PD];
 #pragma unroll
   for (int j = 0; j < PD; j++) {
     const int q = wave * VAL - 64 + lane + 64 * j;
     if (q < 0) rq[j] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * lane);
-    else rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+    else rq[j] = ld_quad(q);
   }
 
   Twiddles<N, P, LEAN> tw;
@@ -834,7 +845,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
 #pragma unroll
         for (int j = (NW == 1 ? 1 : 0); j < PD; j++) {
           const int q = (fr + NW) * VAL - 64 + lane + 64 * j; /* >= 0: this is frame 1 or later */
-          rq[j] = (q < total) ? *reinterpret_cast<const uint4 *>(iq + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+          rq[j] = ld_quad(q);
         }
       }
       {
@@ -859,9 +870,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
     }
     /* acc[j] = y at window index lane + 64 j; index 64 (j = 1) is output fr*VAL of the call */
 #pragma unroll
-    for (int j = 1; j < PD; j++) {
+    for (int j = 1; j < PD; j++) { /* past the end of the call: slots nobody consumes (`produced` stops at total) */
       const int m = fr * VAL + lane + 64 * (j - 1);
-      if (m < total) ring[m & (RING - 1)] = acc[j];
+      ring[m & (RING - 1)] = acc[j];
     }
     produced = (round + 1) * NW * VAL < total ? (round + 1) * NW * VAL : total;
     __syncthreads();
