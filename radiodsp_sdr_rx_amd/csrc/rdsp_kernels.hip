@@ -75,13 +75,13 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
     v[j + PH] = fetch(tid + j * NT);
     vprev[j] = v[j + PH];
   }
-  auto sync = []() { __syncthreads(); };
+  auto sync = []() { wg_sync<NW>(); };
   {
     float2 twp[P - 1];
     tw.template get<0>(twp);
     fwd_pass0_store<N, P>(lb, v, wb, twp); /* CONV:291 */
   }
-  __syncthreads();
+  wg_sync<NW>();
   fwd_mid_all<N, P, 1, PL::NP - 1, WALIAS>(lb, wb, tw, sync);
   fwd_pass_last<N, P>(lb, v, wb);
 
@@ -101,9 +101,9 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
     float tot = wave_sum(part);
     if constexpr (NW > 1) {
       if (lane == 0) red[wave] = tot;
-      __syncthreads();
+      wg_sync<NW>();
       tot = (red[0] + red[1]) + (red[2] + red[3]);
-      __syncthreads();
+      wg_sync<NW>();
     }
     float th = tot * vad_inv;                      /* SPEC:200 */
     th = th * p.spectral_k;                        /* SPEC:202 */
@@ -127,14 +127,14 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
   for (int e = 0; e < P; e++) v[e] = cmul(v[e], mreg[e]);
 
   inv_pass_last<N, P>(lb, v, wb); /* CONV:309 */
-  __syncthreads();
+  wg_sync<NW>();
   inv_mid_all<N, P, PL::NP - 2, WALIAS>(lb, wb, tw, sync);
   {
     float2 twp[P - 1];
     tw.template get<0>(twp);
     inv_pass0_load<N, P>(lb, v, wb, twp);
   }
-  __syncthreads(); /* wb is free again (next frame / taps / FIR partials) */
+  wg_sync<NW>(); /* wb is free again (next frame / taps / FIR partials) */
 
   /* CONV:314-318: keep the second half.  v[PH + jj] = y[N/2 + tid + jj*NT] */
   float L[PH], R[PH];
@@ -152,7 +152,7 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
       float s = wave_sum(pv[jj]);
       if (lane == 0) red[wave * PH + jj] = s;
     }
-    __syncthreads();
+    wg_sync<NW>();
 #pragma unroll
     for (int b = 0; b < NB; b++) {
       float s = 0.f;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
           if (((jj * NT + w * 64) >> 7) == b) s += red[w * PH + jj];
       bs[b] = s;
     }
-    __syncthreads();
+    wg_sync<NW>();
   };
 
   if (G.demod == RDSP_K_DEMOD_REAL) {
@@ -716,12 +716,12 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
   int frame_idx = 0;
   int produced = 0, consumed = 0;
-  auto sync = []() { __syncthreads(); };
+  auto sync = []() { wg_sync<NW>(); };
   if constexpr (NW > 1) {
     if (NB_ON) {
       if (tid < 64) nbacc[tid] = 0.f;
       if (tid == 0) nbs[0] = nb_level;
-      __syncthreads();
+      wg_sync<NW>();
     }
   }
 
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
             nbacc[lane] = nb_acc;
             if (lane == 0) nbs[0] = nb_level;
           }
-          __syncthreads();
+          wg_sync<NW>();
         }
       }
     }
@@ -853,15 +853,15 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
         twd.template get<0>(twp);
         fwd_pass0_store<ND, PD>(lbd, v, wbd, twp);
       }
-      __syncthreads();
+      wg_sync<NW>();
       fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lbd, wbd, twd, sync);
       fwd_pass_last<ND, PD>(lbd, v, wbd);
-      __syncthreads(); /* wb is rewritten by the next branch */
+      wg_sync<NW>(); /* wb is rewritten by the next branch */
 #pragma unroll
       for (int e = 0; e < PD; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
     }
     inv_pass_last<ND, PD>(lbd, acc, wbd);
-    __syncthreads();
+    wg_sync<NW>();
     inv_mid_all<ND, PD, PLD::NP - 2, false>(lbd, wbd, twd, sync);
     {
       float2 twp[PD - 1];
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       ring[m & (RING - 1)] = acc[j];
     }
     produced = (round + 1) * NW * VAL < total ? (round + 1) * NW * VAL : total;
-    __syncthreads();
+    wg_sync<NW>();
 
     /* ---- A5/A6: overlap-save frames over what the ring holds ------------------------------ */
 #pragma unroll 1

@@ -166,7 +166,7 @@ struct NlmsB {
 #pragma unroll 1
     for (int s0 = 0; s0 < RDSP_BLOCK; s0 += GS) {
       const float *sc = scr + ((s0 / GS) & 1) * SCR;
-      __syncthreads();
+      wg_sync<1>();
       float4 gq = *reinterpret_cast<const float4 *>(sc);
       float4 bq = *reinterpret_cast<const float4 *>(sc + GS);
       float4 dq = *reinterpret_cast<const float4 *>(dsrc + s0);
@@ -252,6 +252,8 @@ __device__ __forceinline__ uint32_t nlms_health(const NL &f) {
 #define RDSP_TP(i) do { } while (0)
 #endif
 
+/* One wave per workgroup throughout: wg_sync<1>() (rdsp_wave.h) orders the lanes' LDS traffic without the
+ * `s_waitcnt lgkmcnt(0)` a __syncthreads() leaves behind. */
 template <bool DUAL, typename NL>
 __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
 #ifdef RDSP_TAIL_PROFILE
@@ -333,16 +335,16 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
 
 #pragma unroll 1
   for (int b = 0; b < p.n_blocks; b++) {
-    __syncthreads();
+    wg_sync<1>();
     RDSP_TP(0);
     if constexpr (DUAL) { /* CONV:326-337, then the ALS filter */
       float *o = ringB + RDSP_BLOCK;
       nr.template block<false>(ringA, p.nr_first && b == 0, p.nr_mu, o, scr, sub);
-      __syncthreads();
+      wg_sync<1>();
       if (p.nr_mode == 0) { /* CONV:334 */
 #pragma unroll
         for (int k = 0; k < SPL; k++) o[sub * SPL + k] = mul_1p1(o[sub * SPL + k]);
-        __syncthreads();
+        wg_sync<1>();
       }
       if (p.als_mode == 1) als.template block<true>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub);
       else als.template block<false>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub);
@@ -350,7 +352,7 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
       if (o_mode == 1) als.template block<true>(ringA, o_first && b == 0, o_mu, fin, scr, sub);
       else als.template block<false>(ringA, o_first && b == 0, o_mu, fin, scr, sub);
     }
-    __syncthreads();
+    wg_sync<1>();
     RDSP_TP(1);
     /* A9 AGC + output gain + A10 pack: lane handles SPL consecutive samples */
     float L[SPL];
@@ -388,7 +390,7 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
         for (int k = 0; k < SPL; k++)
           p.raw_out[ch * p.mid_stride + (size_t)b * RDSP_BLOCK + sub * SPL + k] = L[k];
       }
-      __syncthreads();
+      wg_sync<1>();
       continue;
     }
     if (p.agc_on) {
@@ -426,7 +428,7 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
         }
       }
     }
-    __syncthreads();
+    wg_sync<1>();
     RDSP_TP(3);
   }
 #ifdef RDSP_TAIL_PROFILE
