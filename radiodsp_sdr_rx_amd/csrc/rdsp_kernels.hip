@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
   int frame_idx = 0;
   int produced = 0, consumed = 0;
-  auto sync = []() { wg_sync<NW>(); };
+  auto wsync = []() { wg_sync<1>(); };
   if constexpr (NW > 1) {
     if (NB_ON) {
       if (tid < 64) nbacc[tid] = 0.f;
@@ -853,16 +853,19 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
         twd.template get<0>(twp);
         fwd_pass0_store<ND, PD>(lbd, v, wbd, twp);
       }
-      wg_sync<NW>();
-      fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lbd, wbd, twd, sync);
+      /* the decimator's transforms run in a work buffer of the wave's own (wbd), also with four waves per
+       * channel: the lanes of ONE wave are all that has to be ordered here.  Between waves the barriers are the
+       * one behind the ring writes below and the one that ends every overlap-save frame ("wb is free again") */
+      wg_sync<1>();
+      fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lbd, wbd, twd, wsync);
       fwd_pass_last<ND, PD>(lbd, v, wbd);
-      wg_sync<NW>(); /* wb is rewritten by the next branch */
+      wg_sync<1>(); /* wbd is rewritten by the next branch */
 #pragma unroll
       for (int e = 0; e < PD; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
     }
     inv_pass_last<ND, PD>(lbd, acc, wbd);
-    wg_sync<NW>();
-    inv_mid_all<ND, PD, PLD::NP - 2, false>(lbd, wbd, twd, sync);
+    wg_sync<1>();
+    inv_mid_all<ND, PD, PLD::NP - 2, false>(lbd, wbd, twd, wsync);
     {
       float2 twp[PD - 1];
       twd.template get<0>(twp);
