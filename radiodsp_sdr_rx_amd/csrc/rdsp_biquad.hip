@@ -27,6 +27,7 @@
 
 #include "rdsp_host.h"
 #include "rdsp_kernels.h"
+#include "rdsp_sync.h"
 
 namespace {
 
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
         *reinterpret_cast<bq_v4 *>(&tile[(lane >> 5) + 2 * it][4 * (lane & 31)]) =
             *reinterpret_cast<const bq_v4 *>(p.buf + row_off[it] + t0);
     }
-    __syncthreads();
+    wg_sync<1>();
     /* skewed steps i = 0 .. TS + 2, lane s on sample n = i - s.  Steps 7 .. TS - 2 have every lane
      * inside the tile: they run unmasked, four to a chunk (i = 4c + 3 .. 4c + 6, c = 1 .. TS/4 - 2), so
      * that stage 3 finishes samples 4c .. 4c + 3 and stage 0 starts 4c + 3 .. 4c + 6 -- one 16-byte
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
     }
 #pragma unroll
     for (int i = TS - 1; i < TS + 3; i++) ramp_step(i);
-    __syncthreads();
+    wg_sync<1>();
     /* tile out */
     if (p.out16) {
       for (int idx = lane; idx < 16 * (TS / 2); idx += 64) {
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
           *reinterpret_cast<bq_v4 *>(p.buf + row_off[it] + t0) =
               *reinterpret_cast<const bq_v4 *>(&tile[(lane >> 5) + 2 * it][4 * (lane & 31)]);
     }
-    __syncthreads();
+    wg_sync<1>();
   }
   if (valid) { st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2; }
 }

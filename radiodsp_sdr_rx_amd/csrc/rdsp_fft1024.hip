@@ -21,6 +21,7 @@
 
 #include "rdsp_host.h"
 #include "rdsp_q15.h"
+#include "rdsp_sync.h"
 
 struct RdspFft1024Params {
   const int16_t *audio; /* [ch][in_stride] samples, every in_step int16 */
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
   const int t = threadIdx.x;
   const size_t ch = blockIdx.x;
   for (int i = t; i < 1024; i += 64) tws[i] = make_twiddle(p.twid[i]);
-  __syncthreads();
+  wg_sync<1>();
 
   for (int f = 0; f < p.n_frames; f++) {
     const int base = 512 * f;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
 #pragma unroll
       for (int k = 0; k < 4; k++) ex[b + 256 * k] = x[k];
     }
-    __syncthreads();
+    wg_sync<1>();
     /* stages 2..5: span L = 64, 16, 4, 1 */
 #pragma unroll
     for (int st = 1; st < 5; st++) {
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
         if (L > 1) bfly(y[m], tw);
         else bfly_w0(y[m]); /* last stage: j = 0 */
       }
-      __syncthreads();
+      wg_sync<1>();
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const int b = t + 64 * m;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
 #pragma unroll
         for (int k = 0; k < 4; k++) ex[g + j + k * L] = y[m][k];
       }
-      __syncthreads();
+      wg_sync<1>();
     }
     /* position q holds bin digit-reverse_4(q) (five base-4 digits); bins 0..511 go out */
     uint16_t *o = p.out + (ch * p.out_stride + (size_t)f) * 512;
@@ -117,14 +118,14 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
         o[bin] = (uint16_t)isqrt32((uint32_t)(__mul24(re, re) + __mul24(im, im)));
       }
     }
-    __syncthreads();
+    wg_sync<1>();
   }
   /* the last `keep` samples of the stream stay buffered for the next call */
   const int total = p.have + p.n_new;
   int16_t tmp[14];
   int n_tmp = 0;
   for (int i = t; i < p.keep; i += 64) tmp[n_tmp++] = (int16_t)sample_at(p, ch, total - p.keep + i);
-  __syncthreads(); /* every lane has read the old history before anyone overwrites it */
+  wg_sync<1>(); /* every lane has read the old history before anyone overwrites it */
   n_tmp = 0;
   for (int i = t; i < p.keep; i += 64) p.st_hist[ch * 896 + i] = tmp[n_tmp++];
 }

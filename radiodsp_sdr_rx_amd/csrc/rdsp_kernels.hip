@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     }
   }
   int frame_idx = 0;
-  __syncthreads();
+  wg_sync<NW>();
 
   for (int chunk = 0; chunk < p.n_chunks; chunk++) {
     /* ---- A1 + A2: unpack, gains, mix; scatter into the polyphase planes ----
@@ -470,9 +470,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       float tot = wave_sum(nb_acc);
       if constexpr (NW > 1) {
         if (lane == 0) red[wave] = tot;
-        __syncthreads();
+        wg_sync<NW>();
         tot = (red[0] + red[1]) + (red[2] + red[3]);
-        __syncthreads();
+        wg_sync<NW>();
       }
       const float mean = tot / (float)CH_IN;
       nb_level = (nb_level > 0.f) ? nb_level + 0.2f * (mean - nb_level) : mean;
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
           raw[k] = *reinterpret_cast<const uint4 *>(iq + (size_t)(chunk + 1) * CH_IN + 4 * idx);
       }
     }
-    __syncthreads();
+    wg_sync<NW>();
 
     /* ---- A3: polyphase decimating FIR ------------------------------------ */
     if constexpr (DECIM == 4 && FM) {
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int r = 0; r < 4; r++) hb[(chunk % CPF) * CH_OUT + 64 * mk + 16 * r + mi] = make_float2(dre[r], dim[r]);
-        __syncthreads();
+        wg_sync<NW>();
       } else {
         /* four waves: wave w takes a quarter of the K-slices; partials summed via LDS */
         if (wave == 0) fir_matrix<0, 20>(lane, xs, hz, dre, dim);
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         else fir_matrix<60, 80>(lane, xs, hz, dre, dim);
 #pragma unroll
         for (int r = 0; r < 4; r++) wb[wave * CH_OUT + 64 * mk + 16 * r + mi] = make_float2(dre[r], dim[r]);
-        __syncthreads();
+        wg_sync<NW>();
         {
           float2 s0 = wb[tid], s1 = wb[CH_OUT + tid], s2 = wb[2 * CH_OUT + tid], s3 = wb[3 * CH_OUT + tid];
           float2 s = cadd(cadd(s0, s1), cadd(s2, s3));
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
       }
       /* the last 256 samples of the chunk are the next chunk's history */
       for (int t = tid; t < 256; t += NT) xs[xl_pos(t - 256)] = xs[xl_pos(768 + t)];
-      __syncthreads();
+      wg_sync<NW>();
     } else if constexpr (DECIM == 4) {
       float2 acc[4];
 #pragma unroll
@@ -535,13 +535,13 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
         if (p.front_prio > 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int r = 0; r < 4; r++) hb[(chunk % CPF) * CH_OUT + 4 * lane + r] = acc[r];
-        __syncthreads();
+        wg_sync<NW>();
       } else {
         /* four waves: wave w takes polyphase branch w; partials summed via LDS */
         fir_lane<(P >= 8)>(lane, wave, wave + 1, xs, taps_lds, acc);
 #pragma unroll
         for (int r = 0; r < 4; r++) wb[wave * CH_OUT + 4 * lane + r] = acc[r];
-        __syncthreads();
+        wg_sync<NW>();
         {
           float2 s0 = wb[tid], s1 = wb[CH_OUT + tid], s2 = wb[2 * CH_OUT + tid], s3 = wb[3 * CH_OUT + tid];
           float2 s = cadd(cadd(s0, s1), cadd(s2, s3));
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
           xs4[sp * RDSP_XP + e] = xs4[sp * RDSP_XP + 64 + e];
         }
       }
-      __syncthreads();
+      wg_sync<NW>();
     }
 
     if ((chunk + 1) % CPF != 0) continue;
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
   make_lds_bases<ND, PD, false>(lane, lb);
   float agc_g = p.st_scal[ch * 4 + 1];
   float am_dc = p.st_scal[ch * 4 + 2];
-  auto sync = []() { __syncthreads(); };
+  auto sync = []() { wg_sync<1>(); };
   /* blocks of 128 outputs go through the ring only when something needs block sums (AGC, the AM
    * detector's DC tracking); otherwise a frame's outputs are packed straight from its registers */
   const bool blocked = (!p.to_mid && p.agc_on) || G.demod == RDSP_K_DEMOD_AM;
@@ -1033,10 +1033,10 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
         tw.template get<0>(twp);
         fwd_pass0_store<ND, PD>(lb, v, wb, twp);
       }
-      __syncthreads();
+      wg_sync<1>();
       fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lb, wb, tw, sync);
       fwd_pass_last<ND, PD>(lb, v, wb);
-      __syncthreads(); /* wb is rewritten by the next branch */
+      wg_sync<1>(); /* wb is rewritten by the next branch */
       {
         const float2 *mp = fimg + (size_t)r * ND;
         asm volatile("" : "+s"(mp));
@@ -1049,7 +1049,7 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
       }
     }
     inv_pass_last<ND, PD>(lb, acc, wb);
-    __syncthreads();
+    wg_sync<1>();
     inv_mid_all<ND, PD, PLD::NP - 2, false>(lb, wb, tw, sync);
     {
       float2 twp[PD - 1];
@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
         if (m < total) ring[m & (RING - 1)] = acc[j];
       }
       produced = (base + VAL < total) ? base + VAL : total;
-      __syncthreads();
+      wg_sync<1>();
 #pragma unroll 1
       while (produced - consumed >= RDSP_BLOCK) {
         const float2 y0 = ring[(consumed + lane) & (RING - 1)], y1 = ring[(consumed + 64 + lane) & (RING - 1)];
@@ -1122,7 +1122,7 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
         }
         consumed += RDSP_BLOCK;
       }
-      __syncthreads(); /* the next frame writes the ring */
+      wg_sync<1>(); /* the next frame writes the ring */
     }
   }
 
@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams 
       const int src = nw - 1280 + w;               /* the same word counted from the start of the call */
       keep[k] = (src >= 0) ? *reinterpret_cast<const uint4 *>(iq + src) : *reinterpret_cast<const uint4 *>(hl + 1280 + src);
     }
-    __syncthreads();
+    wg_sync<1>();
     uint32_t *hw = p.st_hist_long + ch * 1280;
 #pragma unroll
     for (int k = 0; k < 5; k++) *reinterpret_cast<uint4 *>(hw + 4 * (lane + 64 * k)) = keep[k];

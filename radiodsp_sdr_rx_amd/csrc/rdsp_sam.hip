@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64) rdsp_sam_kernel(RdspSamParams p) {
       *reinterpret_cast<sam_v4 *>(ti + (row0 + 8 * j) * SAM_ROW + 4 * piece) = ri[j];
       *reinterpret_cast<sam_v4 *>(tq + (row0 + 8 * j) * SAM_ROW + 4 * piece) = rq[j];
     }
-    __syncthreads();
+    wg_sync<1>();
     if (n0 + SAM_TILE < p.n_samples) { /* the next tile lands during this tile's arithmetic */
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) rdsp_sam_kernel(RdspSamParams p) {
       *reinterpret_cast<float4 *>(mine_i + m) = make_float4(o[0], o[1], o[2], o[3]);
       *reinterpret_cast<float4 *>(mine_i + m + 4) = make_float4(o[4], o[5], o[6], o[7]);
     }
-    __syncthreads();
+    wg_sync<1>();
     { /* audio of the SAM channels back in place; rows of other demodulators keep their base band */
       const int n = n0 + 4 * piece;
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64) rdsp_sam_kernel(RdspSamParams p) {
               *reinterpret_cast<const float4 *>(ti + r * SAM_ROW + 4 * piece);
       }
     }
-    __syncthreads();
+    wg_sync<1>();
   }
   if (is_sam) {
     float phs = atan2f(sn, cs);

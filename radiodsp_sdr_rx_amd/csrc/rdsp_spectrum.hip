@@ -22,6 +22,7 @@
 
 #include "rdsp_host.h"
 #include "rdsp_q15.h"
+#include "rdsp_sync.h"
 
 struct RdspSpecParams {
   const uint32_t *iq; /* [ch][in_stride] I | Q << 16 */
@@ -102,32 +103,32 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
     bfly(x, tw[0]);
 #pragma unroll
     for (int k = 0; k < 4; k++) ex[t + 64 * k] = x[k];
-    __syncthreads();
+    wg_sync<1>();
     {
       const int base = (t / 16) * 64 + (t % 16);
 #pragma unroll
       for (int k = 0; k < 4; k++) x[k] = ex[base + 16 * k];
       bfly(x, tw[1]);
-      __syncthreads();
+      wg_sync<1>();
 #pragma unroll
       for (int k = 0; k < 4; k++) ex[base + 16 * k] = x[k];
     }
-    __syncthreads();
+    wg_sync<1>();
     {
       const int base = (t / 4) * 16 + (t % 4);
 #pragma unroll
       for (int k = 0; k < 4; k++) x[k] = ex[base + 4 * k];
       bfly(x, tw[2]);
-      __syncthreads();
+      wg_sync<1>();
 #pragma unroll
       for (int k = 0; k < 4; k++) ex[base + 4 * k] = x[k];
     }
-    __syncthreads();
+    wg_sync<1>();
 #pragma unroll
     for (int k = 0; k < 4; k++) x[k] = ex[4 * t + k];
     int re[4], im[4];
     bfly_w0_unpacked(x, re, im);
-    __syncthreads();
+    wg_sync<1>();
     /* FFTIQ.cpp:86-98 */
 #pragma unroll
     for (int k = 0; k < 4; k++) {

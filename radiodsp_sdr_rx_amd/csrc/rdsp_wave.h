@@ -5,6 +5,7 @@
 #define RDSP_WAVE_H
 
 #include "rdsp_front.h"
+#include "rdsp_sync.h"
 
 namespace {
 
@@ -22,24 +23,6 @@ struct GlobalF2 {
 };
 __device__ __forceinline__ GlobalF2 as_global(const float2 *p) {
   return GlobalF2{(const __attribute__((address_space(1))) GlobalF2::v2 *)p};
-}
-
-/* Workgroup barrier of a kernel whose workgroup is NW waves.  ONE wave needs no instruction at all: its LDS
- * operations execute in order, so a read issued behind a write sees it, and the lanes are synchronised by
- * program order; what remains is to keep the compiler from moving memory accesses across the point, which a
- * wavefront-scope fence does at no cost (LLVM's AMDGPU memory model: no wait for that scope).
- * __syncthreads() in a one-wave workgroup drops the s_barrier but keeps the workgroup-scope fence, an
- * `s_waitcnt lgkmcnt(0)` -- between the writes of a transform pass and the reads of the next one that is a full
- * LDS round trip, 17 times per decimator frame. */
-template <int NW>
-__device__ __forceinline__ void wg_sync() {
-  if constexpr (NW == 1) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  } else {
-    __syncthreads();
-  }
 }
 
 template <int CTRL>
