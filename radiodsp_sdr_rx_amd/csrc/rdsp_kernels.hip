@@ -872,10 +872,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       inv_pass0_load<ND, PD>(lbd, acc, wbd, twp);
     }
     /* acc[j] = y at window index lane + 64 j; index 64 (j = 1) is output fr*VAL of the call */
+    {
+      /* a frame's outputs start at a multiple of 64 in the ring, so a column of 64 never wraps: the wrap is
+       * scalar arithmetic per column, one vector add per store (past the end of the call: slots nobody
+       * consumes, `produced` stops at total) */
+      const int m0 = __builtin_amdgcn_readfirstlane(fr * VAL);
+      static_assert(VAL % 64 == 0 && RING % 64 == 0, "ring columns");
 #pragma unroll
-    for (int j = 1; j < PD; j++) { /* past the end of the call: slots nobody consumes (`produced` stops at total) */
-      const int m = fr * VAL + lane + 64 * (j - 1);
-      ring[m & (RING - 1)] = acc[j];
+      for (int j = 1; j < PD; j++) ring[((m0 + 64 * (j - 1)) & (RING - 1)) + lane] = acc[j];
     }
     produced = (round + 1) * NW * VAL < total ? (round + 1) * NW * VAL : total;
     wg_sync<NW>();
@@ -891,9 +895,11 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
 #pragma unroll
         for (int e = 0; e < P; e++) mreg[e] = gp[e * NT + tid];
       }
-      const int base = consumed;
+      /* hops start at multiples of H in a ring of a multiple of H: the hop is contiguous */
+      static_assert(RING % H == 0, "a hop never wraps");
+      const float2 *hop = ring + (consumed & (RING - 1));
       front_frame<N, P, false>(p, G, tw, lb, wb, red, mreg, vadbits, vad_inv, vprev, nfloor, agc_g, am_dc, frame_idx, ch,
-                               tid, [&](int i) { return ring[(base + i) & (RING - 1)]; });
+                               tid, [&](int i) { return hop[i]; });
       consumed += H;
     }
   }
