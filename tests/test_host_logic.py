@@ -195,6 +195,58 @@ def test_fft_lds_maps_are_bank_conflict_free_under_the_lds_model(tmp_path):
     assert seen == 3 + 2 + 2 + 3 + 2
 
 
+def _device_disassembly(tmp_path):
+    """gfx950 disassembly of every code object linked into librdsp_hip.so, by kernel name"""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "radiodsp_sdr_rx_amd", "librdsp_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    sec = str(tmp_path / "fatbin.bin")
+    subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + sec, lib, str(tmp_path / "unused.so")])
+    blob = open(sec, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in __import__("re").finditer(magic, blob)]
+    kernels = {}
+    for n, a in enumerate(starts):
+        b = starts[n + 1] if n + 1 < len(starts) else len(blob)
+        part, co = str(tmp_path / f"b{n}.bin"), str(tmp_path / f"b{n}.co")
+        open(part, "wb").write(blob[a:b])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        name = None
+        for line in subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True,
+                                   text=True, check=True).stdout.splitlines():
+            if line[:1].isdigit() and line.rstrip().endswith(">:"):
+                name = line.split("<", 1)[1][:-2]
+                kernels[name] = []
+            elif name and line.startswith("\t"):
+                kernels[name].append(line.split()[0])
+    return kernels
+
+
+def test_generated_code_keeps_the_instruction_forms_the_measurements_rest_on(tmp_path):
+    """What round 3 found in the generated code, pinned (DESIGN.md 4.1 'LDS', 'No barriers inside a wave'): a
+    compiler that goes back to any of these forms costs 2-13 % per step without failing a parity test.
+    Frequency-domain front kernels: no FLAT loads in the frame loop (at most the one pointer select of the PRE
+    prologue), no ds_read2_b64 (LDS reads are single ds_read_b64), input quads through buffer loads; the
+    one-wave kernels contain no s_barrier at all."""
+    k = _device_disassembly(tmp_path)
+    fd = {n: v for n, v in k.items() if "rdsp_front_fd_kernel" in n}
+    assert len(fd) >= 16
+    for n, ins in fd.items():
+        assert ins.count("flat_load_dwordx2") == 0 and sum(i.startswith("flat_load") for i in ins) <= 1, n
+        assert "ds_read2_b64" not in ins and ins.count("ds_read_b64") >= 16, n
+        assert ins.count("buffer_load_dwordx4") >= 7, n
+        one_wave = any(t in n for t in ("ILi256ELi4E", "ILi512ELi8E", "ILi1024ELi16E"))
+        assert ("s_barrier" in ins) != one_wave, n
+    for name in ("rdsp_tail_kernel", "rdsp_tail_dual_kernel", "rdsp_spectrum_kernel", "rdsp_fft1024_kernel",
+                 "rdsp_biquad_kernel", "rdsp_sam_kernel"):
+        hit = [v for n, v in k.items() if name in n]
+        assert hit and all("s_barrier" not in v for v in hit), name
+    tail = [v for n, v in k.items() if "rdsp_tail_kernel" in n][0]
+    assert tail.count("ds_read_b64") >= 32   # the even sample pairs
+
+
 def test_host_c_under_address_and_ub_sanitizers(tmp_path):
     """rdsp_graph.c, rdsp_io.c and rdsp_design.c (no HIP in them) built with ASan + UBSan + LSan
     and walked by tests/host/host_sanitize.c: pool exhaustion, teardown with blocks queued,
