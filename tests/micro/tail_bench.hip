@@ -1,7 +1,7 @@
 // Times the tail kernel alone (ALS notch instance, 4096 channels by default).
 // hipcc -O3 --offload-arch=gfx950 -std=c++17 -I radiodsp_sdr_rx_amd/csrc tests/micro/tail_bench.hip \
 //       -L radiodsp_sdr_rx_amd -lrdsp_hip -Wl,-rpath,$PWD/radiodsp_sdr_rx_amd -o tests/micro/tail_bench
-// usage: tail_bench [channels] [variant]   variant 100 row layout (default), 16 rdsp_tail.hip, 116 / 108 matrix pipe
+// usage: tail_bench [channels] [variant] [iterations]   variant 100 the product kernel (default; others: EXPERIMENTAL=1 builds)
 #include "rdsp_kernels.h"
 #include <cstdio>
 #include <cstring>
@@ -26,7 +26,8 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   rdsp_launch_tail(&p, variant, 0); hipDeviceSynchronize();
   float best = 1e9;
-  for (int it = 0; it < 5; it++) {
+  const int iters = argc > 3 ? atoi(argv[3]) : 5; /* many iterations: a run long enough to sample clock and power beside it */
+  for (int it = 0; it < iters; it++) {
     hipEventRecord(e0); rdsp_launch_tail(&p, variant, 0); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }
