@@ -241,7 +241,7 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
     for (int jj = 0; jj < PH; jj++) {
       float l = L[jj] * p.out_gain, r = R[jj] * p.out_gain;
       size_t o = ch * p.out_stride + tout + tid + jj * NT;
-      p.out_i16[o] = pack_lr(l, r); /* CONV:346-347 */
+      __builtin_nontemporal_store(pack_lr(l, r), p.out_i16 + o); /* CONV:346-347; written once, read by nobody here */
       if (p.out_f32) p.out_f32[o] = make_float2(l, r);
     }
   }
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   const __amdgpu_buffer_rsrc_t iq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(iq), 0, 16 * total, 0x00020000);
   auto ld_quad = [&](int q) {
     typedef int v4i __attribute__((ext_vector_type(4)));
-    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, 0);
+    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, 2);
     return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
   };
   uint4 rq[PD];
