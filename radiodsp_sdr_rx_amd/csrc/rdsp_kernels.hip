@@ -675,7 +675,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   const __amdgpu_buffer_rsrc_t iq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(iq), 0, 16 * total, 0x00020000);
   auto ld_quad = [&](int q) {
     typedef int v4i __attribute__((ext_vector_type(4)));
-    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, 2);
+    /* aux 2 = nt: the stream passes once (one wave per channel).  Four waves per channel re-read each other's
+     * frame overlap, which they should find in L2: default policy there */
+    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, NW == 1 ? 2 : 0);
     return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
   };
   uint4 rq[PD];
