@@ -159,7 +159,9 @@ def test_random_session_resumed_from_a_checkpoint_is_bit_exact(rdsp, seed):
     rng = np.random.default_rng(seed)
     ops = make_script(rng)
     procs = [i for i, op in enumerate(ops) if op[0] == "proc"]
-    cut = procs[int(rng.integers(1, len(procs) - 1))] + 1      # right after a call; setters may follow before the next one
+    if len(procs) < 3:                                         # (a soak seed with two calls: cut between them)
+        pytest.skip("script with fewer than three calls") if len(procs) < 2 else None
+    cut = procs[int(rng.integers(1, max(2, len(procs) - 1)))] + 1  # right after a call; setters may follow before the next one
     total = sum(op[1] for op in ops if op[0] == "proc")
     nch = 40
     iq = synth_iq(nch, total * 128)
