@@ -1,3 +1,4 @@
+# 25 000 K3 steps with clock, package power and temperatures sampled once a second (is the step time steady?)
 ( while true; do rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|Power|Temperature \(Sensor (junction|memory)" | tr '\n' ' '; echo; sleep 1; done ) > gpurun_out/long_samples.txt &
 SP=$!
 python bench.py --config K3 --steps 25000 --warmup 20 --no-cpu-baseline --no-host-io --no-iso --no-kernel-timing > gpurun_out/long_k3.json 2> gpurun_out/long_k3.err
