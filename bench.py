@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra PCIe-inclusive leg (host memory -> chain -> host memory)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
+    ap.add_argument("--lib", default=os.environ.get("RDSP_BENCH_LIB"),
+                    help="A/B runs: another build of librdsp_hip.so (default: the in-tree one); named in the JSON line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction / JSON plumbing only, no device work (CPU-side test of --gpus N)")
     return ap.parse_args()
@@ -367,6 +369,9 @@ def dry_run(args, rank, world, dist):
 
 def main():
     args = parse()
+    if args.lib:   # A/B harness: another build of the library (no torch / HIP touched by this import)
+        from radiodsp_sdr_rx_amd import _lib
+        _lib.use_library(args.lib)
     if args.cpu_baseline_worker:
         return f1_cpu_baseline(args) if args.config == "F1" else cpu_baseline_worker(args)
     if args.config == "F1":
@@ -423,7 +428,10 @@ def main():
     out = torch.empty((nch, n_samples // decim, 2), dtype=torch.int16, device=dev)
     gen_s = time.perf_counter() - t0
 
-    chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, **cfg)
+    # stage A3 in the frequency domain (rdsp_chain_set_fir_variant 2): the library's default is the direct
+    # form, whose bits do not depend on how a stream is cut into calls; a bench step is one fixed-size call
+    fir_variant = int(os.environ.get("RDSP_FIR_VARIANT", "2"))   # A/B runs: 0 = the direct form
+    chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **cfg)
     chain.set_pipelined(not args.no_pipeline)
     if args.groups > 1:
         import numpy as np
@@ -440,8 +448,6 @@ def main():
     if os.environ.get("RDSP_PRIO"):  # A/B runs: "front_fir_prio,tail_prio"
         fpr, tpr = (int(x) for x in os.environ["RDSP_PRIO"].split(","))
         assert chain.lib.rdsp_chain_set_priorities(chain.h, fpr, tpr) == 0
-    if os.environ.get("RDSP_FIR_VARIANT"):  # A/B runs: 0 direct-form decimator, 2 frequency domain, 4 folded front stage (default: automatic)
-        chain.set_fir_variant(int(os.environ["RDSP_FIR_VARIANT"]))
     if os.environ.get("RDSP_TAIL_VARIANT"):  # A/B runs: "16" (DPP), "16m" / "8m" (matrix-pipe reduction)
         v = os.environ["RDSP_TAIL_VARIANT"]
         if v == "1step":      # round 1's tail kernel: one reduction per step (EXPERIMENTAL builds)
@@ -509,7 +515,7 @@ def main():
         n5 = k5c["channels"]
         iq5 = torch.from_numpy(synth_iq(n5, n_samples, ch0=rank * n5, n_threads=threads)).to(dev)
         out5 = torch.empty((n5, n_samples // decim, 2), dtype=torch.int16, device=dev)
-        ch5 = Chain(n5, max_blocks_per_call=nblk, device=local_rank, **dict(k5c["cfg"]))
+        ch5 = Chain(n5, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **dict(k5c["cfg"]))
         ch5.set_pipelined(not args.no_pipeline)
         steps5 = max(10, min(args.steps, 60))
         for _ in range(min(args.warmup, 10)):
@@ -586,6 +592,7 @@ def main():
                 "blocks_per_step": nblk,
                 "sharding": f"channels x{world}, no collectives",
                 "pipelined": not args.no_pipeline,
+                "decimator": "frequency domain (rdsp_chain_set_fir_variant 2)" if fir_variant == 2 else "direct form (library default)",
                 "groups": args.groups,
                 "retune_every_steps": args.retune_every,
             },
@@ -610,6 +617,8 @@ def main():
                                                     if k in (fname, "rdsp_tail_kernel")} or None}},
             "input_gen_s": gen_s,
         }
+        if args.lib:
+            res["library"] = os.path.abspath(args.lib)   # an A/B run, not the in-tree build
         if k5_leg is not None:
             res["k5"] = k5_leg
         if world == 1 and not args.no_host_io:

@@ -182,7 +182,9 @@ int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c);         /* INO:117: ac
 int rdsp_pre_setIQslip(rdsp_chain_t *c, int slip);
 /* iq: n_samples interleaved int16 I,Q pairs of ONE channel (host memory).  *slip: the value to pass to
  * rdsp_pre_setIQslip; rejection_db (optional, 3 values): image rejection of the strongest line with the
- * slip undone as 0, +1, -1.  Needs a dominant one-sided line in the first 2^k samples (k <= 14). */
+ * slip undone as 0, +1, -1.  Needs a dominant one-sided line in the first 2^k samples (k <= 14); without
+ * one (noise, a real-valued or double-side-band signal: all three rejections near 0 dB) *slip is 0 -- a
+ * correction is only recommended when it rejects the image by 15 dB at least and beats "no slip" by 10 dB. */
 int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double *rejection_db);
 int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g);              /* INO:133 */
 int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g);             /* INO:134 */
@@ -250,19 +252,17 @@ int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
-/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]): -1 (default) evaluates it in the
- * frequency domain -- polyphase overlap-save: four low-rate transforms, branch spectra, one inverse
- *  -- where that kernel exists (decim 4) and in
- * the direct form (packed FMAs) elsewhere; 0 the direct form always; 2 the frequency domain
- * (RDSP_ERR_UNSUPPORTED where it does not exist).  Both are the same exact linear convolution with
- * the same taps.  The frequency-domain frames are anchored at each call's first sample, so with it
- * a stream cut into calls differently differs in rounding (2.6e-7 of the output's peak over random
- * splits, 2.8e-6 through K3's recursive stages: tests/test_gpu_parity.py pins both); with the direct
- * form any call split gives the same bits.  4: the folded front stage (decimator and overlap-save filter
- * as one filter in 1024-point frames; decim 4, FFT_L 256 / 512, up to 32 receiver groups, no spectral
- * stage / blanker / swap: entered at the start of a stream, left for the two-stage kernels at the first
- * call that does not qualify; measured slower than those as built).
- * EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the tail stage shares the SIMDs. */
+/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]).  -1 (default) and 0: the direct form (packed
+ * FMAs): every output is a function of the absolute sample position only, so a stream gives the same
+ * bits however it is cut into calls -- the property the reference has by construction (fixed 128-sample
+ * blocks, CONV:231-245).  2: in the frequency domain -- polyphase overlap-save: four low-rate transforms,
+ * branch spectra, one inverse; decim 4 only (RDSP_ERR_UNSUPPORTED elsewhere).  The same
+ * exact linear convolution with the same taps at about twice the throughput of the front kernel, for
+ * callers who do not need split-invariant bits: its frames start at each call's first sample, so with it
+ * a stream cut into calls differently differs in rounding (2.6e-7 of the output's peak over random splits,
+ * 2.8e-6 through K3's recursive stages: tests/test_gpu_parity.py pins both).  bench.py selects 2 and says
+ * so in its `config`.  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the tail stage
+ * shares the SIMDs. */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant);
 /* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row, two
  * steps per DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: (16, 4) weights one block
@@ -313,7 +313,11 @@ int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out);
  * gains, groups) are configuration and are re-applied by the caller; FFT_L and decimation must match.
  * Loading into a chain that has not processed anything also restores the stream position and call
  * history (resume: the next call continues the stream bit for bit); a chain that has must be at the
- * same stream position.  Control-path calls: both wait for everything queued so far. */
+ * same stream position.  Control-path calls: both wait for everything queued so far.
+ * rdsp_chain_state_bytes is an upper bound for every later rdsp_chain_save_state of that many channels; it
+ * grows only with set-up calls that allocate optional state (a SAM group, RDSP_AUDIO_KIND_IIR, the first
+ * non-zero rdsp_pre_setIQslip, rdsp_chain_set_groups): size the buffer after set-up.  Blobs carry a
+ * version (4 in this library); a blob of another version is refused (RDSP_ERR_INVALID), nothing is restored. */
 size_t rdsp_chain_state_bytes(const rdsp_chain_t *c, int n_channels);
 int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_channels, void *host_buf, size_t bytes, void *stream);
 int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const void *host_buf, size_t bytes, void *stream);

@@ -8,8 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RDSP_LIB_PATH selects another build of the same library (A/B runs of kernel variants)
-LIB_PATH = os.environ.get("RDSP_LIB_PATH") or os.path.join(_HERE, "librdsp_hip.so")
+# the in-tree build, and nothing else: no environment variable can put another library under the tests or
+# under a caller.  Measurement harnesses that compare builds call use_library() themselves (bench.py --lib).
+LIB_PATH = os.path.join(_HERE, "librdsp_hip.so")
 
 RDSP_OK = 0
 ERRORS = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "NOT_READY", -5: "UNSUPPORTED", -6: "NOMEM"}
@@ -238,6 +239,15 @@ SYMBOLS = [
     ("rdsp_spectrum_update", _i, [_vp, _vp, _sz, _i, _vp, _sz, C.POINTER(C.c_int), _vp]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
+
+
+def use_library(path):
+    """A/B harness only (bench.py --lib): load another build of the same library instead of the in-tree one.
+    Must be called before the first load()."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() after the library was loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def load():

@@ -21,7 +21,12 @@ def _stream_ptr(stream=None):
 
 
 class Chain:
-    def __init__(self, n_channels, max_blocks_per_call=512, device=0, **cfg):
+    # stage A3 of chains made without an explicit choice: None = the library's default (the direct form, whose
+    # bits do not depend on the call split); 2 = the frequency-domain decimator on decim-4 chains (what
+    # bench.py runs).  The GPU test modules run under both (tests/conftest.py `front_form`).
+    default_fir_variant = None
+
+    def __init__(self, n_channels, max_blocks_per_call=512, device=0, fir_variant=None, **cfg):
         self.lib = _lib.load()
         self.cfg = make_config(**cfg)
         self.n_channels = int(n_channels)
@@ -33,6 +38,10 @@ class Chain:
                                               int(max_blocks_per_call), C.byref(h)))
         self.h = h
         self.granule_blocks = self.lib.rdsp_chain_granule_blocks(self.h)
+        if fir_variant is None and self.decim == 4:
+            fir_variant = self.default_fir_variant
+        if fir_variant is not None:
+            self.set_fir_variant(fir_variant)
 
     def close(self):
         if getattr(self, "h", None):
@@ -185,8 +194,9 @@ class Chain:
     def set_front_variant(self, lean):
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 
-    def set_fir_variant(self, matrix):
-        _lib.check(self.lib.rdsp_chain_set_fir_variant(self.h, int(matrix)))
+    def set_fir_variant(self, variant):
+        """stage A3: 0 / -1 the direct form (split-invariant bits, default), 2 in the frequency domain"""
+        _lib.check(self.lib.rdsp_chain_set_fir_variant(self.h, int(variant)))
 
     def set_tail_variant(self, lanes_per_channel, matrix_reduce=None):
         if matrix_reduce is None:

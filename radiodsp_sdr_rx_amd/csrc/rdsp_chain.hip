@@ -52,7 +52,6 @@ extern "C" int rdsp_device_count(void) {
  * The device sees it as one RdspGroup record plus two mask buffers; a retune fills
  * the buffer the record does not point to (copy stream) and the record is rewritten
  * in stream order at the next processing call. */
-#define RDSP_FOLD_MAX_GROUPS 32
 
 struct GroupState {
   double lo = 0.0, hi = 0.0, nco_hz = 0.0;
@@ -135,8 +134,8 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto (= full), 0 full-register front kernel, 1 lean */
-  int fir_mode = -1;  /* -1 auto: frequency-domain decimator where it exists, else the direct form; 0 direct form
-                         (packed FMAs); 2 frequency domain; EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix
+  int fir_mode = -1;  /* stage A3: -1 / 0 direct form (packed FMAs; split-invariant bits, the default); 2 frequency
+                         domain (rdsp_chain_set_fir_variant; bench.py); EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix
                          unless the tail stage shares the SIMDs */
   /* wave priorities while both kernels share the SIMDs: the direct-form front kernel raises its
    * own to front_fir_prio during the FIR, the frequency-domain one never does; the tail kernel runs
@@ -144,9 +143,8 @@ struct rdsp_chain {
    * K3 1.191 / - / 1.188 / - ms, K5 2.72 / 2.36 / 2.34 / 2.36 ms per step (at equal priority the tail
    * kernels of two sub-batches are starved by the front waves) */
   int front_fir_prio = 2, tail_prio = 2;
-  /* tail kernel: 100 = rdsp_tailm.hip row layout (16 lanes/channel, DPP reduction, delay line fed
-   * from LDS; default), 16 = rdsp_tail.hip (delay line shifted by DPP), 116 / 108 = 16 / 8 lanes
-   * with the reduction on the matrix pipe */
+  /* tail kernel: 100 = the product's (rdsp_tail.hip: a channel per 16-lane DPP row, two steps per reduction);
+   * other values select the EXPERIMENTAL=1 variants (rdsp_launch_tail) */
   int tail_lpc = 100;
   int saved_agc_mode = RDSP_AGC_MEDIUM, saved_als_mode = RDSP_ALS_NOTCH;
   /* the engine's IIR audio filter bank (RDSP_AUDIO_KIND_IIR): coefficient sets per group, DF1
@@ -155,18 +153,6 @@ struct rdsp_chain {
   int audio_kind = RDSP_AUDIO_KIND_MASK;
   float *d_iir_coef = nullptr, *d_iir_state = nullptr;
   int iir_sets = 0;
-  /* folded front stage (rdsp_front_fold_kernel): decimator and overlap-save filter in one pass for
-   * chains without a non-linear stage in the spectrum.  Entered at the start of a stream, left (for
-   * good, until rdsp_chain_reset) when a setting needs the two-stage kernels: the pre-processor features,
-   * the spectral stage, a tuning or input-gain change that reaches into the history, many groups */
-  enum { FOLD_FRESH = 0, FOLD_ACTIVE = 1, FOLD_LEFT = 2 };
-  int fold_state = FOLD_FRESH;
-  bool fold_leaving = false;
-  uint64_t hist_change_n = 0; /* stream position of the last tuning / input-gain / swap change */
-  bool hist_change_seen = false;  /* the next launch first rebuilds the two-stage kernels' previous hop */
-  bool fold_capable = false;  /* decimation 4, FFT_L 256 / 512: the pool carries the folded spectra */
-  size_t pool_stride = 0;     /* float2 per mask buffer in the pool: N, + 4 x 1024 when fold_capable */
-  uint32_t *d_hist_long = nullptr; /* [n_channels][1280] last raw samples (folded stage only) */
   int swap_iq = 0;            /* preProcessor.swapIQ, INO:118 */
   int iq_slip = 0;            /* rdsp_pre_setIQslip: +1 delays the I rail by one sample, -1 the Q rail */
   uint32_t *d_slip_buf = nullptr;      /* [n_channels][max_blocks * 128] corrected words of a call */
@@ -236,20 +222,6 @@ static int groups_resize(rdsp_chain_t *c, int n) {
     HIP_TRY(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
   }
-  /* the folded front stage reads one image of 4 x 1024 spectra per group behind the mask: with
-   * many groups that gather would cost more HBM traffic than the IQ stream itself, so only chains
-   * of up to RDSP_FOLD_MAX_GROUPS groups carry (and use) it */
-  c->fold_capable = c->decim == 4 && (c->N == 256 || c->N == 512) && n <= RDSP_FOLD_MAX_GROUPS;
-  const size_t stride = (size_t)c->N + (c->fold_capable ? 4 * (size_t)RDSP_FOLD_N : 0);
-  if (stride != c->pool_stride) {
-    for (auto &g : c->groups)
-      for (int i = 0; i < 2; i++) {
-        if (g.staging[i]) (void)hipHostFree(g.staging[i]);
-        g.staging[i] = nullptr;
-        g.issued[i] = false;
-      }
-    c->pool_stride = stride;
-  }
   const size_t old = c->groups.size();
   for (size_t i = (size_t)n; i < old; i++) group_free(c->groups[i]);
   c->groups.resize((size_t)n);
@@ -270,7 +242,7 @@ static int groups_resize(rdsp_chain_t *c, int n) {
     }
     for (int k = 0; k < 2; k++) {
       if (!g.ev_copy[k]) HIP_TRY(hipEventCreateWithFlags(&g.ev_copy[k], hipEventDisableTiming));
-      if (!g.staging[k]) HIP_TRY(hipHostMalloc((void **)&g.staging[k], sizeof(float2) * c->pool_stride, hipHostMallocDefault));
+      if (!g.staging[k]) HIP_TRY(hipHostMalloc((void **)&g.staging[k], sizeof(float2) * (size_t)c->N, hipHostMallocDefault));
     }
   }
   if (c->d_groups) (void)hipFree(c->d_groups);
@@ -279,8 +251,8 @@ static int groups_resize(rdsp_chain_t *c, int n) {
   c->d_mask_pool = nullptr;
   HIP_TRY(hipMalloc((void **)&c->d_groups, sizeof(RdspGroup) * (size_t)n));
   HIP_TRY(hipMemset(c->d_groups, 0, sizeof(RdspGroup) * (size_t)n));
-  HIP_TRY(hipMalloc((void **)&c->d_mask_pool, sizeof(float2) * 2 * c->pool_stride * (size_t)n));
-  HIP_TRY(hipMemset(c->d_mask_pool, 0, sizeof(float2) * 2 * c->pool_stride * (size_t)n));
+  HIP_TRY(hipMalloc((void **)&c->d_mask_pool, sizeof(float2) * 2 * (size_t)c->N * (size_t)n));
+  HIP_TRY(hipMemset(c->d_mask_pool, 0, sizeof(float2) * 2 * (size_t)c->N * (size_t)n));
   for (auto &g : c->groups) { /* pool contents are gone: every group restages */
     g.applied = 0;
     g.staged = -1;
@@ -300,19 +272,11 @@ static int group_stage(rdsp_chain_t *c, int gi) {
    * (a burst of retunes of one group while the device is calls behind) the host waits for it */
   if (g.issued[si]) HIP_TRY(hipEventSynchronize(g.ev_copy[si]));
   rdsp_mask_device_image(c->cfg.filter_on ? g.mask_nat.data() : nullptr, c->N, g.staging[si]);
-  size_t img = (size_t)c->N;
-  if (c->fold_capable && c->fir_mode == 4 && c->fold_state != rdsp_chain::FOLD_LEFT) { /* the folded stage's spectra travel with the mask */
-    if (rdsp_fold_image(c->fir_nat.data(), g.coef_I.data(), g.coef_Q.data(), c->hop + 1, c->cfg.filter_on,
-                        g.staging[si] + 2 * (size_t)c->N) != 0) {
-      rdsp_set_error("folded filter spectra failed");
-      return RDSP_ERR_INVALID;
-    }
-    img = c->pool_stride;
-  }
+  const size_t img = (size_t)c->N;
   const int target = (g.staged >= 0) ? g.staged : (1 - g.applied);
   /* front kernels launched so far may still read `target` (it was live before the last switch) */
   if (c->fence_valid) HIP_TRY(hipStreamWaitEvent(c->s_copy, c->ev_fence, 0));
-  float2 *dst = c->d_mask_pool + ((size_t)gi * 2 + (size_t)target) * c->pool_stride;
+  float2 *dst = c->d_mask_pool + ((size_t)gi * 2 + (size_t)target) * (size_t)c->N;
   HIP_TRY(hipMemcpyAsync(dst, g.staging[si], sizeof(float2) * img, hipMemcpyHostToDevice, c->s_copy));
   HIP_TRY(hipEventRecord(g.ev_copy[si], c->s_copy));
   g.issued[si] = true;
@@ -340,7 +304,7 @@ static void group_record(const rdsp_chain_t *c, const GroupState &g, int gi, int
   rdsp_nco_rot(r->dphi, 256, t); r->rotq1 = make_float2(t[0], t[1]);
   rdsp_nco_rot(r->dphi, 512, t); r->rotq2 = make_float2(t[0], t[1]);
   rdsp_nco_rot(r->dphi, 768, t); r->rotq3 = make_float2(t[0], t[1]);
-  r->mask_off = (uint32_t)(((size_t)gi * 2 + (size_t)buf) * c->pool_stride);
+  r->mask_off = (uint32_t)(((size_t)gi * 2 + (size_t)buf) * (size_t)c->N);
   /* the FIR history was mixed with the increment of the launch that brought it in */
   r->dphi_hist = g.has_dev_dphi ? g.dev_dphi : r->dphi;
   rdsp_nco_rot(r->dphi_hist, 1, t); r->roth1 = make_float2(t[0], t[1]);
@@ -449,7 +413,6 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
   } while (0)
   ALLOC_ZERO(c->d_fir_hc, sizeof(float) * 256);
   ALLOC_ZERO(c->d_hist, sizeof(uint32_t) * 256 * nch);
-  if (c->decim == 4 && c->N <= 512) ALLOC_ZERO(c->d_hist_long, sizeof(uint32_t) * 1280 * nch);
   ALLOC_ZERO(c->d_prev, sizeof(float2) * c->hop * nch);
   ALLOC_ZERO(c->d_scal, sizeof(float) * 4 * nch);
   ALLOC_ZERO(c->d_nr_w, sizeof(float) * RDSP_LMS_TAPS * nch);
@@ -498,7 +461,7 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   (void)hipSetDevice(c->device);
   void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
-                  c->d_als_energy, c->d_status, c->d_mid, c->d_slip_buf, c->d_slip_carry[0], c->d_slip_carry[1], c->d_hist_long};
+                  c->d_als_energy, c->d_status, c->d_mid, c->d_slip_buf, c->d_slip_carry[0], c->d_slip_carry[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -546,7 +509,6 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   c->tail_slot = -1;
   HIP_TRY(hipStreamSynchronize(stream));
   HIP_TRY(hipMemset(c->d_hist, 0, sizeof(uint32_t) * 256 * nch));
-  if (c->d_hist_long) HIP_TRY(hipMemset(c->d_hist_long, 0, sizeof(uint32_t) * 1280 * nch));
   HIP_TRY(hipMemset(c->d_prev, 0, sizeof(float2) * c->hop * nch));
   HIP_TRY(hipMemset(c->d_nr_w, 0, sizeof(float) * RDSP_LMS_TAPS * nch));
   HIP_TRY(hipMemset(c->d_nr_prev, 0, sizeof(float) * RDSP_BLOCK * nch));
@@ -565,16 +527,6 @@ extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
   c->old_nr_level = 15;
   c->nr_mu = rdsp_lms_mu(15);
   for (auto &g : c->groups) { g.has_dev_dphi = false; g.dirty = true; }
-  if (c->fold_state == rdsp_chain::FOLD_LEFT && c->fold_capable) { /* a new stream may fold again: its spectra restage */
-    c->fold_state = rdsp_chain::FOLD_FRESH;
-    for (size_t i = 0; i < c->groups.size(); i++) {
-      int rc = group_stage(c, (int)i);
-      if (rc != RDSP_OK) return rc;
-    }
-  }
-  c->fold_state = rdsp_chain::FOLD_FRESH;
-  c->hist_change_n = 0;
-  c->hist_change_seen = false;
   if (c->d_sam) HIP_TRY(hipMemset(c->d_sam, 0, sizeof(float) * 4 * nch));
   if (c->d_iir_state) HIP_TRY(hipMemset(c->d_iir_state, 0, sizeof(float) * 16 * nch));
   return RDSP_OK;
@@ -763,43 +715,12 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.lean = (c->lean_mode < 0) ? 0 : c->lean_mode;
   fp.front_prio = piped ? c->front_fir_prio : 0;
   fp.fir_matrix = (c->fir_mode == 3) ? (piped ? 0 : 1) : (c->fir_mode == 1);
-  /* frequency-domain decimator (default); the direct form stays selectable (fir_variant 0) */
-  fp.fir_fd = ((c->fir_mode == 2 || c->fir_mode == -1 || c->fir_mode == 4) && c->d_fd_mask) ? 1 : 0;
+  /* stage A3: the direct form unless the caller selected the frequency-domain decimator
+   * (rdsp_chain_set_fir_variant(chain, 2): same taps, ~2x the throughput, but its frames start at each call's
+   * first sample, so the bits depend on how the stream is cut into calls; bench.py selects it) */
+  fp.fir_fd = (c->fir_mode == 2 && c->d_fd_mask) ? 1 : 0;
   fp.fd_mask = c->d_fd_mask;
-  /* The folded stage (one pass instead of decimator + overlap-save filter; opt-in, fir_variant 4: measured
-   * slower than the two-stage kernels as built) runs while nothing needs the two-stage
-   * kernels: no spectral stage, no pre-processor feature, every
-   * sample of the 1280-sample history taken with the settings of this call (no tuning offset, gain or
-   * swap change reaching back).  It starts with a stream and is left for good at the first call that
-   * does not qualify (rdsp_chain_reset starts a new stream). */
-  bool fold = false;
-  {
-    /* settings the FIR history is interpreted with: a change takes effect at this call's first sample */
-    bool pending = fp.scale_i_hist != fp.scale_i || fp.scale_q_hist != fp.scale_q || fp.swap_hist != fp.swap_iq;
-    for (const auto &g : c->groups)
-      pending = pending || (g.has_dev_dphi && g.dev_dphi != rdsp_nco_dphi(g.nco_hz, cf.fs_in));
-    /* the folded stage's history window (768 / 1280 samples) must lie entirely behind the previous such
-     * change: its first frame mixes and scales all of it with the previous call's settings (*_hist) */
-    const uint64_t need = (c->N == 256) ? 768 : 1280;
-    const bool window_clean = !c->hist_change_seen || c->n_in - c->hist_change_n >= need; /* (silence before the stream) */
-    if (c->fold_state != rdsp_chain::FOLD_LEFT) {
-      const bool ok = c->fold_capable && c->d_hist_long && c->fir_mode == 4 && fp.fir_fd && !fp.spectral_on && !fp.nb_on &&
-                      !fp.swap_iq && !fp.swap_hist && window_clean && (!pending || n_in >= need);
-      /* (a changing call shorter than the window would leave two generations of settings in the next
-       * call's history: such a call leaves the folded form here, while its own history is still clean) */
-      if (ok) {
-        fold = true;
-        c->fold_state = rdsp_chain::FOLD_ACTIVE;
-      } else {
-        if (c->fold_state == rdsp_chain::FOLD_ACTIVE) c->fold_leaving = true; /* the previous hop is rebuilt below */
-        c->fold_state = rdsp_chain::FOLD_LEFT;
-      }
-    }
-    if (pending) { c->hist_change_n = c->n_in; c->hist_change_seen = true; }
-  }
-  fp.st_hist_long = c->d_hist_long;
-  fp.fold_off = (uint32_t)c->N;
-  c->front_name = fold ? "rdsp_front_fold_kernel" : (fp.fir_fd ? "rdsp_front_fd_kernel" : "rdsp_front_kernel");
+  c->front_name = fp.fir_fd ? "rdsp_front_fd_kernel" : "rdsp_front_kernel";
   fp.mid_q = c->d_mid_q[0];
   if (piped) {
     fp.mid = slot ? c->d_midx[slot - 1] : c->d_mid;
@@ -841,15 +762,10 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     }
   }
   int e = 0;
-  if (c->fold_leaving) { /* the two-stage kernels continue from the decimated stream's previous hop */
-    fp.ch_base = 0;
-    e = rdsp_launch_fold_leave(c->N, &fp, c->n_channels, stream);
-    c->fold_leaving = false;
-  }
   for (int k = 0; k < nsb && e == 0; k++) {
     fp.ch_base = k * sbn;
     const int count = (c->n_channels - fp.ch_base < sbn) ? c->n_channels - fp.ch_base : sbn;
-    e = fold ? rdsp_launch_front_fold(c->N, &fp, count, stream) : rdsp_launch_front(c->N, c->decim, &fp, count, stream);
+    e = rdsp_launch_front(c->N, c->decim, &fp, count, stream);
     if (nsb > 1 && e == 0) HIP_TRY(hipEventRecord(c->ev_front_sb[slot][k], stream));
   }
   if (timed) HIP_TRY(hipEventRecord(ev1, stream));
@@ -1399,21 +1315,20 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   c->tail_prio = tail_prio;
   return RDSP_OK;
 }
-/* stage A3 of the front kernel.  -1 (default): in the frequency domain where that kernel exists
- * (decim 4; with the noise blanker on, fft_l <= 1024), else the direct form; 0: direct form (packed FMAs)
- * always -- the one whose results do not depend on how a stream is cut into calls, bit for bit;
- * 2: frequency domain (RDSP_ERR_UNSUPPORTED where it does not exist).  Same taps, same linear
- * convolution; the sums associate differently (~2e-7).  EXPERIMENTAL=1 builds: 1 = v_mfma GEMM
- * slices, 3 = the same unless the tail stage runs concurrently. */
+/* stage A3 of the front kernel.  -1 (default) and 0: the direct form (packed FMAs) -- outputs are a function
+ * of the absolute sample position only, so a stream gives the same bits however it is cut into calls, like
+ * the reference's fixed 128-sample blocks (CONV:231-245).  2: in the frequency domain (decim 4 only, else
+ * RDSP_ERR_UNSUPPORTED): same taps, same linear convolution, ~2x the throughput of the whole front kernel,
+ * but its frames start at each call's first sample, so a different call split rounds differently (~3e-7;
+ * an absolute frame grid cannot help: the outputs at a call's end would come from a frame with zeros for
+ * the samples that have not arrived, and from the whole frame under another split -- DESIGN.md 4.1).
+ * bench.py selects 2.  EXPERIMENTAL=1 builds: 1 = v_mfma GEMM slices, 3 = the same unless the tail stage
+ * runs concurrently. */
 extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   NEED(c);
-  if (variant < -1 || variant > 4) return RDSP_ERR_INVALID;
+  if (variant < -1 || variant > 3) return RDSP_ERR_INVALID;
   if (variant == 2 && !c->d_fd_mask) {
     rdsp_set_error("the frequency-domain decimator needs decim = 4");
-    return RDSP_ERR_UNSUPPORTED;
-  }
-  if (variant == 4 && !(c->decim == 4 && (c->N == 256 || c->N == 512))) {
-    rdsp_set_error("the folded front stage exists for decim = 4 and FFT_L 256 / 512");
     return RDSP_ERR_UNSUPPORTED;
   }
 #ifndef RDSP_EXPERIMENTAL
@@ -1422,13 +1337,7 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
     return RDSP_ERR_UNSUPPORTED;
   }
 #endif
-  const bool restage = variant == 4 && c->fir_mode != 4;
   c->fir_mode = variant;
-  if (restage) /* the folded stage's spectra are staged with the masks from now on */
-    for (size_t i = 0; i < c->groups.size(); i++) {
-      int rc = group_stage(c, (int)i);
-      if (rc != RDSP_OK) return rc;
-    }
   return RDSP_OK;
 }
 /* tail-kernel variant.  (16, 2) is the product (rdsp_tail.hip: a channel per 16-lane DPP row, two
@@ -1516,7 +1425,7 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
  * Blob: header, then the arrays of DESIGN.md 3 for the n channels, each [n][...]. */
 namespace {
 struct StateHeader {
-  uint32_t magic, version; /* "RDSP", 3 */
+  uint32_t magic, version; /* "RDSP", 4 */
   int32_t n_channels, fft_l, decim;
   int32_t has_sam, has_iir;
   int32_t old_nr_level;
@@ -1528,15 +1437,14 @@ struct StateHeader {
   int32_t n_groups;      /* followed by n_groups x {has_dev_dphi, dev_dphi}: the NCO increment each group's FIR
                             history was mixed with (a tuning change right before the checkpoint) */
   int32_t has_slip;      /* the last call ran with the I2S slip correction: its carry word travels too */
-  int32_t fold_state;    /* folded front stage: fresh / active (its 1280-sample raw history travels too) / left */
-  int32_t hist_change_seen;
-  uint64_t hist_change_n; /* stream position of the last tuning / input-gain change */
+  int32_t fir_fd;        /* the last call ran the frequency-domain decimator (informative: both forms keep the
+                            same 256 raw samples, so a stream may be continued in either) */
 };
-constexpr uint32_t kStateVersion = 3;
+constexpr uint32_t kStateVersion = 4;
 constexpr uint32_t kStateMagic = 0x50534452u; /* 'R' 'D' 'S' 'P' */
 struct StatePart { void *dev; size_t per_channel; };
 /* the per-channel arrays in blob order; optional ones (SAM, IIR, slip carry) only when present */
-std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir, bool slip = false, bool fold = false) {
+std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir, bool slip = false) {
   std::vector<StatePart> v = {
       {c->d_hist, sizeof(uint32_t) * 256},
       {c->d_prev, sizeof(float2) * (size_t)(c->N / 2)},
@@ -1548,20 +1456,21 @@ std::vector<StatePart> state_parts(const rdsp_chain_t *c, bool sam, bool iir, bo
   if (sam) v.push_back({c->d_sam, sizeof(float) * 4});
   if (iir) v.push_back({c->d_iir_state, sizeof(float) * 16});
   if (slip) v.push_back({c->d_slip_carry[c->slip_phase], sizeof(uint32_t)});
-  if (fold) v.push_back({c->d_hist_long, sizeof(uint32_t) * 1280});
   return v;
 }
-size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir, bool slip, bool fold, size_t n_groups) {
+size_t state_bytes(const rdsp_chain_t *c, int n, bool sam, bool iir, bool slip, size_t n_groups) {
   size_t b = sizeof(StateHeader) + 2 * sizeof(uint32_t) * n_groups;
-  for (const auto &p : state_parts(c, sam, iir, slip, fold)) b += p.per_channel * (size_t)n;
+  for (const auto &p : state_parts(c, sam, iir, slip)) b += p.per_channel * (size_t)n;
   return b;
 }
 }  // namespace
 
 extern "C" size_t rdsp_chain_state_bytes(const rdsp_chain_t *c, int n_channels) {
   if (!c || n_channels <= 0 || n_channels > c->n_channels) return 0;
-  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr, c->slip_prev_on,
-                     c->fold_state == rdsp_chain::FOLD_ACTIVE, c->groups.size());
+  /* an upper bound that only set-up calls change: optional parts count once their buffers exist (the slip
+   * carry travels only when the last call ran corrected, but its place is reserved as soon as
+   * rdsp_pre_setIQslip has allocated it), so a buffer sized after set-up fits every later save */
+  return state_bytes(c, n_channels, c->d_sam != nullptr, c->d_iir_state != nullptr, c->d_slip_buf != nullptr, c->groups.size());
 }
 
 /* everything queued so far has finished when the copy is taken (a control-path call) */
@@ -1581,9 +1490,7 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
   memset(&h, 0, sizeof(h));
   h.magic = kStateMagic; h.version = kStateVersion;
   h.has_slip = c->slip_prev_on ? 1 : 0;
-  h.fold_state = c->fold_state;
-  h.hist_change_n = c->hist_change_n;
-  h.hist_change_seen = c->hist_change_seen ? 1 : 0;
+  h.fir_fd = c->fir_mode == 2 ? 1 : 0;
   h.n_channels = n_channels; h.fft_l = c->N; h.decim = c->decim;
   h.has_sam = c->d_sam != nullptr; h.has_iir = c->d_iir_state != nullptr;
   h.old_nr_level = c->old_nr_level; h.n_in = c->n_in;
@@ -1600,7 +1507,7 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
     memcpy(dst, w, sizeof(w));
     dst += sizeof(w);
   }
-  for (const auto &p : state_parts(c, h.has_sam, h.has_iir, h.has_slip, h.fold_state == rdsp_chain::FOLD_ACTIVE)) {
+  for (const auto &p : state_parts(c, h.has_sam, h.has_iir, h.has_slip)) {
     const size_t n = p.per_channel * (size_t)n_channels;
     HIP_TRY(hipMemcpy(dst, (const unsigned char *)p.dev + p.per_channel * (size_t)first_channel, n, hipMemcpyDeviceToHost));
     dst += n;
@@ -1638,14 +1545,8 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
     rdsp_set_error("rdsp_chain_load_state: the blob was taken with the I2S slip correction on; call rdsp_pre_setIQslip first");
     return RDSP_ERR_INVALID;
   }
-  const bool bfold = h.fold_state == rdsp_chain::FOLD_ACTIVE;
-  if (bfold && !(c->fold_capable && c->d_hist_long)) {
-    rdsp_set_error("rdsp_chain_load_state: the blob was taken in the folded front stage's form, which this chain cannot run "
-                   "(more than %d receiver groups?)", RDSP_FOLD_MAX_GROUPS);
-    return RDSP_ERR_INVALID;
-  }
   if (h.has_sam && ensure_sam(c) != RDSP_OK) return RDSP_ERR_HIP;
-  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0, h.has_slip != 0, bfold, (size_t)h.n_groups)) {
+  if (bytes < state_bytes(c, h.n_channels, h.has_sam != 0, h.has_iir != 0, h.has_slip != 0, (size_t)h.n_groups)) {
     rdsp_set_error("rdsp_chain_load_state: blob truncated");
     return RDSP_ERR_INVALID;
   }
@@ -1665,8 +1566,7 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
   if (!fresh) { /* channels moved between shards of one stream: both sides must be at the same point of it */
     const bool same = c->n_in == h.n_in && (c->nr_calls == 0) == (h.nr_calls == 0) && (c->als_calls == 0) == (h.als_calls == 0) &&
                       c->hist_valid == (h.hist_valid != 0) && c->hist_swap == h.hist_swap && c->hist_scale_i == h.hist_scale_i &&
-                      c->hist_scale_q == h.hist_scale_q && c->old_nr_level == h.old_nr_level && c->slip_prev_on == (h.has_slip != 0) &&
-                      c->fold_state == h.fold_state;
+                      c->hist_scale_q == h.hist_scale_q && c->old_nr_level == h.old_nr_level && c->slip_prev_on == (h.has_slip != 0);
     if (!same) {
       rdsp_set_error("rdsp_chain_load_state: the chain (input sample %llu) and the blob (input sample %llu) are not at the same "
                      "point of the stream / call history", (unsigned long long)c->n_in, (unsigned long long)h.n_in);
@@ -1676,7 +1576,7 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
   if (c->s_tail) HIP_TRY(hipStreamSynchronize(c->s_tail));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   const unsigned char *src = gsrc + 2 * sizeof(uint32_t) * (size_t)h.n_groups;
-  for (const auto &p : state_parts(c, h.has_sam != 0, h.has_iir != 0, h.has_slip != 0, bfold)) {
+  for (const auto &p : state_parts(c, h.has_sam != 0, h.has_iir != 0, h.has_slip != 0)) {
     const size_t n = p.per_channel * (size_t)h.n_channels;
     HIP_TRY(hipMemcpy((unsigned char *)p.dev + p.per_channel * (size_t)first_channel, src, n, hipMemcpyHostToDevice));
     src += n;
@@ -1693,9 +1593,6 @@ extern "C" int rdsp_chain_load_state(rdsp_chain_t *c, int first_channel, const v
     c->hist_valid = h.hist_valid != 0; c->hist_swap = h.hist_swap;
     c->hist_scale_i = h.hist_scale_i; c->hist_scale_q = h.hist_scale_q;
     c->slip_prev_on = h.has_slip != 0;
-    c->fold_state = h.fold_state; /* the resumed stream continues in the form it was cut in: the same bits */
-    c->hist_change_n = h.hist_change_n;
-    c->hist_change_seen = h.hist_change_seen != 0;
     if ((size_t)h.n_groups == c->groups.size()) /* same partition: the increments the histories came in with */
       for (auto &g : c->groups) {
         uint32_t w[2];

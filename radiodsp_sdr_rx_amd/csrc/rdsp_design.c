@@ -224,56 +224,6 @@ int rdsp_fd_decimator_image(const float *h_nat, int fft_l, float *image) {
   return 0;
 }
 
-/* Images for the folded front stage (rdsp_front_fold_kernel): decimator and overlap-save filter as ONE
- * filter.  c = h * (f upsampled by 4): h the 256 decimator taps, f the n_taps = FFT_L/2 + 1 complex taps
- * of the overlap-save filter exactly as the mask holds them (narrowed to float, last Q tap cleared,
- * CONV:96-105; a unit pulse when the filter is off), so the folded stage is the same linear convolution
- * as the two stages behind one another.  Branch r of its polyphase form: c_r[k] = c[4k - r],
- * k = 0 .. n_taps + 63; RDSP_FOLD_N-point spectra in double, / RDSP_FOLD_N, stored like the filter
- * masks (digit-reversed, thread-major: element e of thread t at e*64 + t), branch r at image + 2 r N. */
-int rdsp_fold_image(const float *h_nat, const double *coef_I, const double *coef_Q, int n_taps, int filter_on,
-                    float *image) {
-  const int n = 1024, P = 16, nt = n / P;
-  if (!h_nat || !image || n_taps < 2 || 256 + 4 * (n_taps - 1) > 4 * (n - 64)) return -1;
-  const int lc = 256 + 4 * (n_taps - 1); /* length of c */
-  double *cr = (double *)calloc(2 * (size_t)lc + 2 * (size_t)n, sizeof(double));
-  if (!cr) return -6;
-  double *ci = cr + lc, *re = ci + lc, *im = re + n;
-  for (int i = 0; i < n_taps; i++) {
-    double fr, fi;
-    if (filter_on) {
-      fr = (double)(float)coef_I[i];
-      fi = (i == n_taps - 1) ? 0.0 : (double)(float)coef_Q[i]; /* CONV:102-105: the zero fill starts one word early */
-    } else {
-      fr = (i == 0) ? 1.0 : 0.0;
-      fi = 0.0;
-    }
-    if (fr == 0.0 && fi == 0.0) continue;
-    for (int k = 0; k < 256; k++) {
-      cr[4 * i + k] += fr * (double)h_nat[k];
-      ci[4 * i + k] += fi * (double)h_nat[k];
-    }
-  }
-  const double inv_n = 1.0 / (double)n;
-  for (int r = 0; r < 4; r++) {
-    memset(re, 0, sizeof(double) * 2 * (size_t)n);
-    for (int k = 0; k < n; k++) {
-      const int t = 4 * k - r;
-      if (t >= 0 && t < lc) { re[k] = cr[t]; im[k] = ci[t]; }
-    }
-    rdsp_host_fft(re, im, n);
-    for (int t = 0; t < nt; t++)
-      for (int e = 0; e < P; e++) {
-        const int bin = rdsp_bin_of_pos(n, t * P + e);
-        const size_t o = (size_t)r * (size_t)n + (size_t)e * (size_t)nt + (size_t)t;
-        image[2 * o] = (float)(re[bin] * inv_n);
-        image[2 * o + 1] = (float)(im[bin] * inv_n);
-      }
-  }
-  free(cr);
-  return 0;
-}
-
 /* ---- biquad design -------------------------------------------------------
  * AudioFilterBiquad::setLowpass / setHighpass / setBandpass / setNotch (INO:155-156 calls
  * setHighpass(0, 500, 0.5)): the RBJ audio-EQ cookbook sections the Teensy library documents.

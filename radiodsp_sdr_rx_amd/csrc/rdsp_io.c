@@ -219,11 +219,17 @@ int rdsp_audio_writer_close(rdsp_audio_writer_t *w) {
 /* ---- I2S channel-slip estimate for a recording (INO:117, rdsp_pre_setIQslip) --------------------
  * A front end with the fault delivers one rail a sample behind the other.  On a stream with a dominant
  * one-sided line (a carrier, a tone: what a receiver's IQ stream normally holds) the misalignment shows
- * as a loss of image rejection: the line at +f leaks to -f by tan(pi f / fs).  The three hypotheses
- * (no slip, I late, Q late) are undone in turn on the first 2^k samples (Hann window, one transform
- * each); the one with the best rejection of the strongest line's image wins.  Returns RDSP_OK and the
- * value to pass to rdsp_pre_setIQslip in *slip; rejection_db[3] (optional) gets the rejection under
- * slip 0, +1, -1. */
+ * as a loss of image rejection: the line at +f leaks to -f by tan(pi f / fs).  The three hypotheses --
+ * slip 0 (rails aligned), +1 (pair I[n-1] with Q[n]: what corrects a LATE Q rail), -1 (pair I[n] with
+ * Q[n-1]: a late I rail) -- are applied in turn to the first 2^k samples (Hann window, one transform each)
+ * and the rejection of the strongest line's image is measured under each.  A correction is only
+ * recommended on evidence: the winner must reject the image by RDSP_SLIP_MIN_REJECTION_DB at least and beat
+ * "no slip" by RDSP_SLIP_MARGIN_DB -- on noise, a real-valued or a double-side-band signal all three sit
+ * near 0 dB, rounding would decide, and a spurious +-1 handed to rdsp_pre_setIQslip would destroy the image
+ * rejection of a healthy recording.  Returns RDSP_OK and the value to pass to rdsp_pre_setIQslip in *slip
+ * (0 without such evidence); rejection_db[3] (optional) gets the rejection under slip 0, +1, -1. */
+#define RDSP_SLIP_MIN_REJECTION_DB 15.0
+#define RDSP_SLIP_MARGIN_DB 10.0
 int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double *rejection_db) {
   if (!iq || !slip || n_samples < 258) {
     rdsp_set_error("rdsp_estimate_iq_slip: bad argument (at least 258 samples)");
@@ -232,10 +238,13 @@ int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double
   int n = 256;
   while ((size_t)(2 * n) + 2 <= n_samples && n < 16384) n *= 2;
   double *re = (double *)malloc(sizeof(double) * 2 * (size_t)n);
-  if (!re) return RDSP_ERR_INVALID;
+  if (!re) {
+    rdsp_set_error("rdsp_estimate_iq_slip: out of memory (%d-point transform)", n);
+    return RDSP_ERR_INVALID;
+  }
   double *im = re + n;
   static const int hyp[3] = {0, 1, -1};
-  double best = -1.0;
+  double db[3] = {0.0, 0.0, 0.0};
   *slip = 0;
   for (int h = 0; h < 3; h++) {
     for (int i = 0; i < n; i++) { /* sample i + 1 of the recording, so that its predecessor exists */
@@ -257,10 +266,11 @@ int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double
       const double pw = re[k] * re[k] + im[k] * im[k];
       if (pw > pimg) pimg = pw;
     }
-    const double rej = pmax / (pimg + 1e-30);
-    if (rejection_db) rejection_db[h] = 10.0 * log10(rej);
-    if (rej > best) { best = rej; *slip = hyp[h]; }
+    db[h] = 10.0 * log10(pmax / (pimg + 1e-30) + 1e-30);
+    if (rejection_db) rejection_db[h] = db[h];
   }
   free(re);
+  const int w = db[1] >= db[2] ? 1 : 2;
+  if (db[w] >= RDSP_SLIP_MIN_REJECTION_DB && db[w] >= db[0] + RDSP_SLIP_MARGIN_DB) *slip = hyp[w];
   return RDSP_OK;
 }

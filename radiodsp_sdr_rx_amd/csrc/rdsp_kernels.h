@@ -66,9 +66,6 @@ struct RdspFrontParams {
   int fir_fd;              /* 1: decimator in the frequency domain (rdsp_front_fd_kernel)      */
   const float2 *fd_mask;   /* [4][RDSP_FD_N] spectra of the polyphase branches g_r[k] = h[4k - r],
                               /RDSP_FD_N, digit-reversed thread-major like the filter masks    */
-  uint32_t fold_off;       /* float2 offset, behind a group's mask in the pool, of its folded branch spectra
-                              [4][1024] (rdsp_fold_image; rdsp_front_fold_kernel)                */
-  uint32_t *st_hist_long;  /* [ch][1280] last raw input samples (folded front stage)            */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
   int agc_on;
   float agc_attack, agc_decay;
@@ -162,9 +159,6 @@ int rdsp_launch_biquad_coef_store(float *dst, const float *coef20, hipStream_t s
 int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p, int n_channels,
                       hipStream_t stream);
 int rdsp_launch_tail(const RdspTailParams *p, int lanes_per_channel, hipStream_t stream);
-int rdsp_launch_front_fold(int fft_l, const RdspFrontParams *p, int n_channels, hipStream_t stream);
-int rdsp_launch_fold_leave(int fft_l, const RdspFrontParams *p, int n_channels, hipStream_t stream);
-size_t rdsp_front_fold_lds_bytes(void);
 int rdsp_launch_sam(const RdspSamParams *p, hipStream_t stream);
 int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hipStream_t stream);
 int rdsp_launch_iq_slip(const uint32_t *in, size_t in_stride, uint32_t *out, size_t out_stride, const uint32_t *carry_in,

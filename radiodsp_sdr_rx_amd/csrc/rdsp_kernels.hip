@@ -581,6 +581,10 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
     } else {
       if (tid >= NT - 64) *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * (tid - (NT - 64))) = raw[0];
     }
+  } else {
+    /* no FIR history at decim 1, but the call's last raw word still has a reader: the I2S slip correction,
+     * switched on between two calls, pairs the next call's first sample with it (rdsp_chain_process) */
+    if (tid == 0) p.st_hist[ch * 256 + 255] = iq[(size_t)p.n_chunks * CH_IN - 1];
   }
   if (tid == 0) {
     p.st_scal[ch * 4 + 0] = nfloor;
@@ -920,277 +924,6 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   }
 }
 
-/* ---- folded front stage: decimator and overlap-save filter as ONE frequency-domain pass ------
- * For chains whose stage A5 is only the mask multiply (no spectral NR), the 256-tap decimator h and
- * the FFT_L/2+1-tap overlap-save filter f (CONV:256-318) are one linear filter c = h * (f upsampled
- * by 4) followed by the decimation: its polyphase branches c_r[k] = c[4k - r] are 64 + FFT_L/2 + 1
- * taps long, and with 1024-point frames (RDSP_FOLD_N) the whole stage is four forward transforms at the
- * low rate, the multiply-accumulate with the branch spectra C_r (rdsp_fold_image) and ONE inverse
- * per frame -- no second transform pair, no ring of decimated samples: 832 valid outputs of 1024 at
- * FFT_L = 256 (OVC = 3 overlap columns), 704 at FFT_L = 512 (OVC = 5).  Same taps as the two-stage
- * form, exact linear convolution.
- * Layout as rdsp_front_fd_kernel: one wave per channel, lane t owns window quads t + 64 j (j < 16);
- * the last OVC columns of a frame are the first OVC of the next and stay in registers.  State: the
- * last 1280 raw samples (st_hist_long; the first frame of a call takes its overlap columns from it)
- * and the scalars; the two-stage kernels' previous hop is rebuilt by rdsp_fold_leave_kernel when a
- * chain leaves this form.  No pre-processor features here (swap, blanker: the launch code picks the
- * two-stage kernels for those). */
-template <int OVC>
-__global__ void __launch_bounds__(64, 2) rdsp_front_fold_kernel(RdspFrontParams p) {
-  constexpr int ND = 1024, PD = 16;
-  using PLD = FftPlan<ND, PD>;
-  constexpr int VALC = PD - OVC, VAL = 64 * VALC;
-  constexpr int RING = 1024; /* >= 127 + VAL */
-  static_assert(PLD::NT == 64 && OVC >= 1 && OVC < PD, "one wave per channel");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2 *ring = reinterpret_cast<float2 *>(smem_raw);
-  float2 *wb = ring + RING;
-  const int lane = threadIdx.x;
-  const size_t ch = (size_t)p.ch_base + blockIdx.x;
-  const uint32_t *iq = p.iq + ch * p.in_stride;
-  const uint4 *iq4 = reinterpret_cast<const uint4 *>(iq); /* uniform base + 32-bit lane offsets: no 64-bit address arithmetic per access */
-  uint32_t *out_ch = p.out_i16 + ch * p.out_stride;
-  float2 *outf_ch = p.out_f32 ? p.out_f32 + ch * p.out_stride : nullptr;
-  float *mid_ch = p.mid + ch * p.mid_stride, *midq_ch = p.mid_q ? p.mid_q + ch * p.mid_stride : nullptr;
-  RdspGroup G;
-  {
-    const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
-    const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
-    uint32_t r[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) r[i] = (i < 30) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gw[i]) : 0u;
-    G = __builtin_bit_cast(RdspGroup, r);
-  }
-  const int total = p.n_chunks * 256; /* outputs = input quads of this call */
-  const uint32_t *hl = p.st_hist_long + ch * 1280;
-
-  /* raw quads of frame 0: column j holds quads 64 (j - OVC) + lane; j < OVC is the history */
-  uint4 rq[PD];
-#pragma unroll
-  for (int j = 0; j < PD; j++) {
-    const int q = 64 * (j - OVC) + lane;
-    if (j < OVC) rq[j] = *reinterpret_cast<const uint4 *>(hl + 1280 + 4 * q);
-    else rq[j] = (q < total) ? iq4[(uint32_t)q] : make_uint4(0u, 0u, 0u, 0u);
-  }
-  Twiddles<ND, PD, true> tw;
-  tw.init(lane);
-  LdsBases<ND, PD, false> lb;
-  make_lds_bases<ND, PD, false>(lane, lb);
-  float agc_g = p.st_scal[ch * 4 + 1];
-  float am_dc = p.st_scal[ch * 4 + 2];
-  auto sync = []() { wg_sync<1>(); };
-  /* blocks of 128 outputs go through the ring only when something needs block sums (AGC, the AM
-   * detector's DC tracking); otherwise a frame's outputs are packed straight from its registers */
-  const bool blocked = (!p.to_mid && p.agc_on) || G.demod == RDSP_K_DEMOD_AM;
-  int produced = 0, consumed = 0;
-  const float2 *fimg = p.mask_pool + G.mask_off + p.fold_off;
-
-#pragma unroll 1
-  for (int fr = 0; produced < total; fr++) {
-    /* ---- A2: phasors of this lane's quad columns (sample 4 q + r of a quad follows by rot_r) */
-    const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 * OVC + lane); /* absolute index of column 0 */
-    float2 pj[PD];
-    pj[0] = (G.dphi != 0u) ? nco_phasor_alu(nq * G.dphi) : make_float2(1.f, 0.f);
-    pj[1] = cmul_pinned_u(pj[0], G.rotq1);
-    pj[2] = cmul_pinned_u(pj[0], G.rotq2);
-#pragma unroll
-    for (int j = 3; j < PD; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
-    /* the overlap columns of a call's first frame are the previous call's samples: they keep the NCO
-     * increment and the input gains they came in with (a tuning or gain change between two calls; the
-     * launch code only runs this kernel when the whole history was taken under those settings) */
-    const bool hist = (fr == 0);
-    if (hist && G.dphi_hist != G.dphi) {
-#pragma unroll
-      for (int j = 0; j < OVC; j++)
-        pj[j] = (G.dphi_hist != 0u) ? nco_phasor_alu((nq + 256u * (uint32_t)j) * G.dphi_hist) : make_float2(1.f, 0.f);
-    }
-    const rdsp_v2f scn = {p.scale_i, p.scale_q};
-    const rdsp_v2f sch = hist ? rdsp_v2f{p.scale_i_hist, p.scale_q_hist} : scn;
-
-    /* ---- A1 + A3 + A5: four branch transforms, multiply-accumulate with the folded branch spectra */
-    float2 acc[PD];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      float2 v[PD];
-#pragma unroll
-      for (int j = 0; j < PD; j++) {
-        const uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
-        /* arm_q15_to_float (CONV:241-242) and the input gains: one packed multiply per sample */
-        const rdsp_v2f xv = rdsp_v2f{(float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16)} * (j < OVC ? sch : scn);
-        const float2 x = make_float2(xv.x, xv.y);
-        float2 ph = pj[j];
-        if (r > 0) {
-          const float2 rr = (r == 1) ? G.rot1 : (r == 2) ? G.rot2 : G.rot3;
-          const float2 rh = (r == 1) ? G.roth1 : (r == 2) ? G.roth2 : G.roth3;
-          ph = (j < OVC && hist) ? cmul_pinned_u(ph, rh) : cmul_pinned_u(ph, rr);
-        }
-        v[j] = cmul_pinned(x, ph);
-      }
-      if (r == 3) { /* the raw registers are free: the next frame's loads land behind the transforms */
-#pragma unroll
-        for (int j = 0; j < OVC; j++) rq[j] = rq[j + VALC];
-#pragma unroll
-        for (int j = OVC; j < PD; j++) {
-          const int q = (fr + 1) * VAL + 64 * (j - OVC) + lane;
-          rq[j] = (q < total) ? iq4[(uint32_t)q] : make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
-      {
-        float2 twp[PD - 1];
-        tw.template get<0>(twp);
-        fwd_pass0_store<ND, PD>(lb, v, wb, twp);
-      }
-      wg_sync<1>();
-      fwd_mid_all<ND, PD, 1, PLD::NP - 1, false>(lb, wb, tw, sync);
-      fwd_pass_last<ND, PD>(lb, v, wb);
-      wg_sync<1>(); /* wb is rewritten by the next branch */
-      {
-        const float2 *mp = fimg + (size_t)r * ND;
-        asm volatile("" : "+s"(mp));
-        const auto gp = as_global(mp);
-#pragma unroll
-        for (int e = 0; e < PD; e++) {
-          const float2 gm = gp[e * 64 + lane];
-          acc[e] = (r == 0) ? cmul(v[e], gm) : cmac(acc[e], v[e], gm);
-        }
-      }
-    }
-    inv_pass_last<ND, PD>(lb, acc, wb);
-    wg_sync<1>();
-    inv_mid_all<ND, PD, PLD::NP - 2, false>(lb, wb, tw, sync);
-    {
-      float2 twp[PD - 1];
-      tw.template get<0>(twp);
-      inv_pass0_load<ND, PD>(lb, acc, wb, twp);
-    }
-    /* acc[j] = y at window index lane + 64 j; index 64 OVC (j = OVC) is output fr*VAL of the call */
-    const int base = fr * VAL;
-    if (!blocked) {
-#pragma unroll
-      for (int j = OVC; j < PD; j++) {
-        const int m = base + lane + 64 * (j - OVC);
-        if (m < total) {
-          const float L = acc[j].x, R = (G.demod == RDSP_K_DEMOD_REAL) ? L : acc[j].y; /* CONV:314-318 / demod select */
-          if (p.to_mid) {
-            mid_ch[(uint32_t)m] = L;
-            if (G.demod == RDSP_K_DEMOD_SAM) midq_ch[(uint32_t)m] = R;
-          } else {
-            const float l = L * p.out_gain, r = R * p.out_gain;
-            out_ch[(uint32_t)m] = pack_lr(l, r); /* CONV:346-347 */
-            if (outf_ch) outf_ch[(uint32_t)m] = make_float2(l, r);
-          }
-        }
-      }
-      produced = (base + VAL < total) ? base + VAL : total;
-    } else {
-#pragma unroll
-      for (int j = OVC; j < PD; j++) {
-        const int m = base + lane + 64 * (j - OVC);
-        if (m < total) ring[m & (RING - 1)] = acc[j];
-      }
-      produced = (base + VAL < total) ? base + VAL : total;
-      wg_sync<1>();
-#pragma unroll 1
-      while (produced - consumed >= RDSP_BLOCK) {
-        const float2 y0 = ring[(consumed + lane) & (RING - 1)], y1 = ring[(consumed + 64 + lane) & (RING - 1)];
-        float L0 = y0.x, R0 = y0.y, L1 = y1.x, R1 = y1.y;
-        const float i0 = (float)(lane + 1) / (float)RDSP_BLOCK, i1 = (float)(lane + 65) / (float)RDSP_BLOCK;
-        if (G.demod == RDSP_K_DEMOD_REAL) {
-          R0 = L0; R1 = L1;
-        } else if (G.demod == RDSP_K_DEMOD_AM) {
-          const float a0 = __builtin_amdgcn_sqrtf(L0 * L0 + R0 * R0), a1 = __builtin_amdgcn_sqrtf(L1 * L1 + R1 * R1);
-          const float m = wave_sum(a0 + a1) / (float)RDSP_BLOCK;
-          const float dn = am_dc + 0.25f * (m - am_dc);
-          L0 = a0 - (am_dc + (dn - am_dc) * i0); R0 = L0;
-          L1 = a1 - (am_dc + (dn - am_dc) * i1); R1 = L1;
-          am_dc = dn;
-        }
-        if (p.to_mid) {
-          mid_ch[(uint32_t)(consumed + lane)] = L0;
-          mid_ch[(uint32_t)(consumed + 64 + lane)] = L1;
-        } else {
-          if (p.agc_on) {
-            const float pw = wave_sum((L0 * L0 + R0 * R0) + (L1 * L1 + R1 * R1));
-            const float pp = pw / (float)(2 * RDSP_BLOCK);
-            const float rms = __builtin_amdgcn_sqrtf(pp);
-            float gt = 0.25f * __builtin_amdgcn_rcpf(rms + 1e-6f);
-            gt = fminf(gt, 100.0f);
-            const float coef = (gt < agc_g) ? p.agc_attack : p.agc_decay;
-            const float gn = agc_g + coef * (gt - agc_g);
-            const float g0 = agc_g + (gn - agc_g) * i0, g1 = agc_g + (gn - agc_g) * i1;
-            L0 *= g0; R0 *= g0; L1 *= g1; R1 *= g1;
-            agc_g = gn;
-          }
-          const uint32_t o = (uint32_t)(consumed + lane);
-          const float l0 = L0 * p.out_gain, r0 = R0 * p.out_gain, l1 = L1 * p.out_gain, r1 = R1 * p.out_gain;
-          out_ch[o] = pack_lr(l0, r0);
-          out_ch[o + 64u] = pack_lr(l1, r1);
-          if (outf_ch) { outf_ch[o] = make_float2(l0, r0); outf_ch[o + 64u] = make_float2(l1, r1); }
-        }
-        consumed += RDSP_BLOCK;
-      }
-      wg_sync<1>(); /* the next frame writes the ring */
-    }
-  }
-
-  /* ---- state out: the last 1280 raw samples (an L2 re-read; a call shorter than that keeps the
-   * tail of the old history in front), the last 256 of them also where the two-stage kernels look */
-  {
-    const int nw = 4 * total; /* words of this call */
-    uint4 keep[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const int w = 4 * (lane + 64 * k);           /* word of the new history */
-      const int src = nw - 1280 + w;               /* the same word counted from the start of the call */
-      keep[k] = (src >= 0) ? *reinterpret_cast<const uint4 *>(iq + src) : *reinterpret_cast<const uint4 *>(hl + 1280 + src);
-    }
-    wg_sync<1>();
-    uint32_t *hw = p.st_hist_long + ch * 1280;
-#pragma unroll
-    for (int k = 0; k < 5; k++) *reinterpret_cast<uint4 *>(hw + 4 * (lane + 64 * k)) = keep[k];
-    *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * lane) = keep[4];
-  }
-  if (lane == 0) {
-    if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
-    p.st_scal[ch * 4 + 2] = am_dc;
-  }
-}
-
-/* Leaving the folded form: the two-stage kernels continue from the previous hop of the DECIMATED
- * stream (st_prev, H = FFT_L/2 samples), which the folded kernel never forms.  Rebuilt here from the raw
- * history by the direct form: u[m] = sum_k h[k] x[4 m - k] for the last H outputs, the samples
- * unpacked and mixed as they were when they came in (scales, swap flag and NCO increment of the
- * previous call: *_hist).  One workgroup of 64 threads per channel, a control-path kernel. */
-__global__ void __launch_bounds__(64) rdsp_fold_leave_kernel(RdspFrontParams p, int H) {
-  __shared__ float2 xs[1280];
-  __shared__ float hs[256];
-  const int lane = threadIdx.x;
-  const size_t ch = (size_t)p.ch_base + blockIdx.x;
-  const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
-  const uint32_t dphi = p.groups[gi].dphi_hist;
-  const uint32_t *hl = p.st_hist_long + ch * 1280;
-  for (int i = lane; i < 256; i += 64) hs[i] = p.fir_hc[(i & 3) * 64 + (i >> 2)]; /* hc[c][k'] = h[4k' + c] */
-  for (int i = lane; i < 1280; i += 64) {
-    uint32_t w = hl[i];
-    if (p.swap_hist) w = (w >> 16) | (w << 16);
-    const float2 x = unpack_iq(w, p.scale_i_hist, p.scale_q_hist);
-    const uint32_t n = p.n0 - 1280u + (uint32_t)i; /* absolute index of this sample */
-    const float2 ph = (dphi != 0u) ? nco_phasor_alu(n * dphi) : make_float2(1.f, 0.f);
-    xs[i] = cmul(x, ph);
-  }
-  __syncthreads();
-  for (int o = lane; o < H; o += 64) { /* output m = M - H + o; its newest input is word 1280 - 4 (H - o) */
-    const int top = 1280 - 4 * (H - o);
-    float2 a = make_float2(0.f, 0.f);
-    for (int k = 0; k < 256; k++) {
-      const int idx = top - k;
-      if (idx >= 0) { a.x = fmaf(hs[k], xs[idx].x, a.x); a.y = fmaf(hs[k], xs[idx].y, a.y); }
-    }
-    p.st_prev[ch * H + o] = a;
-  }
-}
-
 template <int N, int P>
 constexpr size_t front_fd_lds() {
   constexpr int nw = N / P / 64;
@@ -1353,20 +1086,6 @@ extern "C" int rdsp_launch_front(int fft_l, int decim, const RdspFrontParams *p,
     case 4096: return d4 ? launch_front_t<4096, 16, 4>(p, n_channels, stream) : launch_front_t<4096, 16, 1>(p, n_channels, stream);
     default: return (int)hipErrorInvalidValue;
   }
-}
-
-/* the folded front stage (FFT_L 256 / 512, decimation 4) and the kernel that leaves it */
-extern "C" size_t rdsp_front_fold_lds_bytes(void) { return (size_t)(1024 + FftPlan<1024, 16>::WB) * sizeof(float2); }
-extern "C" int rdsp_launch_front_fold(int fft_l, const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  const size_t lds = rdsp_front_fold_lds_bytes();
-  if (fft_l == 256) hipLaunchKernelGGL((rdsp_front_fold_kernel<3>), dim3(n_channels), dim3(64), lds, stream, *p);
-  else if (fft_l == 512) hipLaunchKernelGGL((rdsp_front_fold_kernel<5>), dim3(n_channels), dim3(64), lds, stream, *p);
-  else return (int)hipErrorInvalidValue;
-  return (int)hipGetLastError();
-}
-extern "C" int rdsp_launch_fold_leave(int fft_l, const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  hipLaunchKernelGGL(rdsp_fold_leave_kernel, dim3(n_channels), dim3(64), 0, stream, *p, fft_l / 2);
-  return (int)hipGetLastError();
 }
 
 extern "C" int rdsp_launch_group_store(RdspGroup *dst, const RdspGroup *val, hipStream_t stream) {

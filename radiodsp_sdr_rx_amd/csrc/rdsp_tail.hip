@@ -155,11 +155,24 @@ struct NlmsB {
     /* (the even pairs are read by instructions of their own: consecutive pairs overlap by a sample, and
      * left to itself the compiler reads the shared dword once and glues the pairs together with v_mov
      * instructions that wait for the LDS right behind the reads) */
-    float bb = 0.f; /* B_{-1} = X_{-2}.X_{-1} */
+    /* B_{-1} = X_{-2}.X_{-1} and E_{-1} = |X_{-1}|^2, both as exact sums over the 96-sample window in front
+     * of the block.  arm_lms_norm_f32 carries the energy as a running difference for the whole stream
+     * (`energy -= x0 * x0; energy += in * in`): after a loud-to-quiet transition what is left is the
+     * rounding residue of everything that went through, of either sign and larger than the quiet window's
+     * true energy, and `energy + 1.19e-7` at or below zero turns the step size negative or infinite.  The
+     * prefix-scan form of the same sum (prepare) drew such residues MORE often than the sequential one
+     * (round 3: 90 of 320 transitions flagged, 8 channels dead, against 1 in the CPU restatement).  Started
+     * from the window sum at every block the residue lives for one block instead of for ever; between two
+     * anchors it is the reference's difference form.  In ordinary signals both differ by the reference's own
+     * accumulated rounding (~1e-6 relative). */
+    float bb = 0.f, ee = 0.f;
 #pragma unroll
-    for (int t = 0; t < TPL; t++) bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
+    for (int t = 0; t < TPL; t++) {
+      bb = fmaf(mine[-1 - t], mine[-2 - t], bb);
+      ee = fmaf(mine[-1 - t], mine[-1 - t], ee);
+    }
     float b_base = row_allsum(bb);
-    float e_base = energy;
+    float e_base = row_allsum(ee);
     prepare(cur, 0, sub, mu, e_base, b_base, scr, emin);
 #pragma unroll
     for (int m = -5; m <= 0; m++) P[m & 7] = (m & 1) ? pair_ld(mine, m) : pair_ld_even(mine, m);
@@ -473,12 +486,11 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
 /* two NLMS instances (DSP-NR feeding the ALS filter; the sketch's menu never enables both, CTL:240-296) */
 __global__ void __launch_bounds__(64) rdsp_tail_dual_kernel(RdspTailParams p) { tail_body<true, NlmsB>(p); }
 
-/* The default (one NLMS instance) with its registers capped at 112: in pipelined mode it shares a
- * SIMD's 512 VGPRs with two waves of the front kernel (176 each in the frequency-domain form, 192
- * in the direct form), and a tail wave that does not fit waits for a front wave to retire (measured
- * in round 1: 1.8 -> 2.4 ms per K3 step at 122 registers).  amdgpu_num_vgpr counts half of the
- * unified file on gfx950; the cap costs two dwords of scratch outside the step loop. */
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(56))) rdsp_tail_kernel(RdspTailParams p) {
+/* The default (one NLMS instance).  124 VGPRs, 128 allocated: in pipelined mode it shares a SIMD's 512 with
+ * two waves of the frequency-domain front kernel (176 allocated each: 480 in all); a tail wave that does
+ * not fit waits for a front wave to retire (measured in round 1: 1.8 -> 2.4 ms per K3 step).  The CPU suite
+ * reads both counts out of the built code object (test_generated_code_keeps_...). */
+__global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
   tail_body<false, NlmsB>(p);
 }
 #ifdef RDSP_EXPERIMENTAL

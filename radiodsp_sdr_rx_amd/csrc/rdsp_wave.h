@@ -45,10 +45,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   v = row_allsum(v);
   /* masked adds (rows outside row_mask keep their value): the compiler's DPP combiner does not fold a
    * row-masked update_dpp into the add, so they are written out, wait states for the DPP reads included */
+  /* ... and the wait state a v_readlane needs behind the VALU write of its source: the hazard recognizer
+   * does not look into inline asm for what it wrote last, so the statement ends with its own s_nop */
   asm("s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
       "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0"
       : "+v"(v));
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes of the front kernel in the bench configurations (instruction mix, wait breakdown, LDS):
 # usage (GPU box, repository root): bash tests/micro/front_pmc.sh [configs...]     (default K2 K3)
-# RDSP_LIB_PATH selects a library; results under gpurun_out/r3/frontpmc/, one summary line per kernel and pass.
+# RDSP_BENCH_LIB selects a library; results under gpurun_out/r3/frontpmc/, one summary line per kernel and pass.
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r3/frontpmc; mkdir -p $OUT; export TMPDIR=/tmp
 P="--steps 4 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing --no-iso --no-pipeline"
 for K in ${@:-K2 K3}; do

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Same-box A/B of built libraries: bash tests/micro/lib_ab.sh variants/a.so variants/b.so ...
-# (RDSP_LIB_PATH picks the library; configs via CONFIGS="K3 K2", extra bench flags via BFLAGS)
+# (RDSP_BENCH_LIB picks the library; configs via CONFIGS="K3 K2", extra bench flags via BFLAGS)
 mkdir -p gpurun_out
 for rep in 1 2; do for lib in "$@"; do for K in ${CONFIGS:-K3}; do
-  RDSP_LIB_PATH=$PWD/$lib python bench.py --config $K --steps ${STEPS:-10} --warmup ${WARMUP:-2} --no-cpu-baseline --no-host-io $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
+  RDSP_BENCH_LIB=$PWD/$lib python bench.py --config $K --steps ${STEPS:-10} --warmup ${WARMUP:-2} --no-cpu-baseline --no-host-io $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
   python - "$lib" "$K" <<PY
 import json,sys
 d=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])

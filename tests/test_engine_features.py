@@ -8,7 +8,7 @@ import pytest
 from cases import K1, K3, TOL
 from parity_util import assert_truth_anchored, model_run, normwise
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("front_form")]   # every test under both front kernels (conftest.py)
 
 
 @pytest.fixture(scope="module")
@@ -77,6 +77,23 @@ def test_iq_slip_correction_matches_oracle_and_undoes_a_slipped_recording(rdsp, 
     for c in range(nch):
         r = np.concatenate(ref[c])
         assert np.abs(got[c] - r).max() / np.abs(r).max() <= TOL
+    # the same script on a chain without the decimator (the literal CONV stage at its native rate): there is no
+    # FIR history there, and the word in front of a call's first sample must still be the previous call's last one
+    from cases import CONV_LITERAL
+    lit = Chain(nch, max_blocks_per_call=per, **CONV_LITERAL)
+    olit = [oracle.OracleChain(**CONV_LITERAL) for _ in range(nch)]
+    got, ref = [], [[] for _ in range(nch)]
+    for k, sl in enumerate(script):
+        part = iq[:, k * per * 128:(k + 1) * per * 128]
+        lit.setIQslip(sl)
+        got.append(lit.process(torch.from_numpy(np.ascontiguousarray(part)).cuda(), want_f32=True)[1].cpu().numpy())
+        for c, oc in enumerate(olit):
+            oc.set_iq_slip(sl)
+            ref[c].append(oc.process(part[c])[1])
+    got = np.concatenate(got, 1)
+    for c in range(nch):
+        r = np.concatenate(ref[c])
+        assert np.abs(got[c] - r).max() / np.abs(r).max() <= TOL, ("decim 1", c)
     # a recording with the fault: Q one sample late.  Corrected it is the clean stream delayed by one sample.
     late = iq.copy()
     late[:, 1:, 1] = iq[:, :-1, 1]
@@ -97,7 +114,6 @@ def test_iq_slip_correction_matches_oracle_and_undoes_a_slipped_recording(rdsp, 
     outs = [p.process(torch.from_numpy(np.ascontiguousarray(late[:, k * per * 128:(k + 1) * per * 128])).cuda()) for k in range(calls)]
     p.flush()
     torch.cuda.synchronize()
-    p.set_fir_variant(0)                                # (the split-invariant decimator form for the comparison chain)
     q = Chain(nch, max_blocks_per_call=per, **K3)
     q.set_fir_variant(0)
     q.setIQslip(1)
@@ -116,7 +132,7 @@ def test_iq_slip_correction_matches_oracle_and_undoes_a_slipped_recording(rdsp, 
                                       # four waves per channel: the blanker's pre-pass goes round the waves in frame order
                                       ("usb_2048", dict(fft_l=2048, demod="USB", agc_mode="medium", output_gain=0.5)),
                                       ("k4_4096", "K4")])
-def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, name, cfg):
+def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, front_form, name, cfg):
     torch = torch_cuda
     from cases import CONV_LITERAL, K4
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
@@ -130,7 +146,7 @@ def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, name, cfg):
     dev = torch.from_numpy(iq).cuda()
     got = ch.process(dev, want_f32=True)[1].cpu().numpy()
     if cfg.get("decim", 4) == 4:      # the default decimator, whatever FFT_L: no fall-back to the direct form
-        assert ch.front_kernel_name() == "rdsp_front_fd_kernel"
+        assert ch.front_kernel_name() == ("rdsp_front_fd_kernel" if front_form == "fd" else "rdsp_front_kernel")
     levels = ch.scalars()[:, 3]
     off = Chain(nch, max_blocks_per_call=nblk, **cfg).process(dev, want_f32=True)[1].cpu().numpy()
     ref_clean = Chain(nch, max_blocks_per_call=nblk, **cfg).process(torch.from_numpy(clean).cuda(), want_f32=True)[1].cpu().numpy()
@@ -177,14 +193,14 @@ def test_noise_blanker_split_calls_and_pipelined_are_bitwise_identical(rdsp, tor
     one = run(1, False, True)
     assert np.array_equal(one, run(calls, False, True))
     assert np.array_equal(one, run(calls, True, False))
-    # the frequency-domain decimator (default) with the blanker compiled in: the same split,
+    # the frequency-domain decimator (opt-in) with the blanker compiled in: the same split,
     # pipelined or not, gives the same bits; another split frames and rounds differently
-    fd = run(calls, False, False, fir=-1)
-    assert np.array_equal(fd, run(calls, True, False, fir=-1))
+    fd = run(calls, False, False, fir=2)
+    assert np.array_equal(fd, run(calls, True, False, fir=2))
     assert np.abs(fd.astype(np.int32) - one.astype(np.int32)).max() <= 64 and (fd != one).mean() < 0.3
 
 
-def test_noise_blanker_four_wave_kernels_split_and_pipelined(rdsp, oracle, torch_cuda):
+def test_noise_blanker_four_wave_kernels_split_and_pipelined(rdsp, oracle, torch_cuda, front_form):
     """FFT_L 2048 (four waves per channel): bursts at call boundaries and inside the column a frame
     shares with the next one; the same split pipelined or not gives the same bits, a blanked sample
     stays blanked as FIR history, and every call follows the oracle."""
@@ -208,7 +224,7 @@ def test_noise_blanker_four_wave_kernels_split_and_pipelined(rdsp, oracle, torch
                            want_f32=True)[1] for k in range(calls)]
         ch.flush()
         torch.cuda.synchronize()
-        assert ch.front_kernel_name() == "rdsp_front_fd_kernel"
+        assert ch.front_kernel_name() == ("rdsp_front_fd_kernel" if front_form == "fd" else "rdsp_front_kernel")
         return np.concatenate([o.cpu().numpy() for o in outs], 1), ch.scalars()
 
     a, sa = run(False)

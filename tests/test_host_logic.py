@@ -72,52 +72,6 @@ def test_design_helpers_match_oracle(rdsp, oracle, fft_l, lo, hi, fs, window):
     assert np.abs(m - om).max() < 2e-6
 
 
-@pytest.mark.parametrize("fft_l", [256, 512])
-def test_folded_stage_spectra_are_the_two_stages_as_one_filter(rdsp, fft_l):
-    """rdsp_fold_image (host C): branch r of the folded front stage is c_r[k] = c[4k - r] with
-    c = h * (f upsampled by 4) -- h the 256 decimator taps, f the overlap-save filter's taps as the mask holds
-    them (narrowed to float, last Q tap cleared).  Checked against NumPy: every stored spectrum value is the
-    1024-point DFT of its branch / 1024 at the bin rdsp_bin_of_pos assigns to that slot."""
-    from radiodsp_sdr_rx_amd import _lib
-    from radiodsp_sdr_rx_amd.chain import calc_cplx_FIR_coeffs
-    lib = _lib.load()
-    h = np.zeros(256, np.float32)
-    hc = np.zeros(256, np.float32)
-    f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
-    lib.rdsp_design_decimator.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, f32p, f32p]
-    assert lib.rdsp_design_decimator(256, 10000.0, 96000.0, 1, h.ctypes.data_as(f32p), hc.ctypes.data_as(f32p)) == 0
-    nt = fft_l // 2 + 1
-    ci, cq = calc_cplx_FIR_coeffs(nt, 300.0, 2700.0, 24000.0, 1)
-    img = np.zeros(2 * 4 * 1024, np.float32)
-    lib.rdsp_fold_image.argtypes = [f32p, f64p, f64p, C.c_int, C.c_int, f32p]
-    lib.rdsp_bin_of_pos.argtypes = [C.c_int, C.c_int]
-    assert lib.rdsp_fold_image(h.ctypes.data_as(f32p), ci.ctypes.data_as(f64p), cq.ctypes.data_as(f64p), nt, 1,
-                               img.ctypes.data_as(f32p)) == 0
-    f = ci.astype(np.float32).astype(np.float64) + 1j * cq.astype(np.float32).astype(np.float64)
-    f[-1] = f[-1].real                                   # CONV:102-105
-    up = np.zeros(4 * (nt - 1) + 1, np.complex128)
-    up[::4] = f
-    c = np.convolve(h.astype(np.float64), up)            # 256 + 4 (nt - 1) taps
-    z = img.reshape(4, 1024, 2)
-    for r in range(4):
-        br = np.zeros(1024, np.complex128)
-        k = np.arange(1024)
-        t = 4 * k - r
-        ok = (t >= 0) & (t < len(c))
-        br[ok] = c[t[ok]]
-        spec = np.fft.fft(br) / 1024.0
-        for thread in (0, 7, 63):
-            for e in range(16):
-                b = lib.rdsp_bin_of_pos(1024, thread * 16 + e)
-                got = z[r, e * 64 + thread, 0] + 1j * z[r, e * 64 + thread, 1]
-                assert abs(got - spec[b]) < 1e-9 + 2e-7 * abs(spec[b]), (r, thread, e)
-    # filter off: the unit pulse, i.e. the decimator alone
-    lib.rdsp_fold_image(h.ctypes.data_as(f32p), ci.ctypes.data_as(f64p), cq.ctypes.data_as(f64p), nt, 0, img.ctypes.data_as(f32p))
-    spec0 = np.fft.fft(np.r_[h[0::4].astype(np.float64), np.zeros(1024 - 64)]) / 1024.0
-    b = lib.rdsp_bin_of_pos(1024, 5 * 16 + 3)
-    assert abs((img.reshape(4, 1024, 2)[0, 3 * 64 + 5] @ np.array([1, 1j])) - spec0[b]) < 1e-9
-
-
 def test_synth_is_deterministic_and_shardable(rdsp):
     from radiodsp_sdr_rx_amd.chain import synth_iq
     a = synth_iq(6, 4096)
@@ -245,6 +199,29 @@ def test_generated_code_keeps_the_instruction_forms_the_measurements_rest_on(tmp
         assert hit and all("s_barrier" not in v for v in hit), name
     tail = [v for n, v in k.items() if "rdsp_tail_kernel" in n][0]
     assert tail.count("ds_read_b64") >= 32   # the even sample pairs
+
+
+def test_register_budget_of_the_two_kernels_that_share_a_simd(tmp_path):
+    """Pipelined K3 keeps two waves of the frequency-domain front kernel and one tail wave on a SIMD: 2 x 176 +
+    128 of its 512 registers.  Nothing in the source enforces that (an `amdgpu_num_vgpr`
+    attribute on the tail kernel turned out to be inert): read the counts out of the built code objects."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    _device_disassembly(tmp_path)            # leaves the unbundled code objects b<n>.co in tmp_path
+    vg = {}
+    for co in sorted(tmp_path.glob("b*.co")):
+        name = None
+        for line in subprocess.run([llvm + "/llvm-readelf", "--notes", str(co)], capture_output=True, text=True,
+                                   check=True).stdout.splitlines():
+            t = line.strip()
+            if t.startswith(".name:"):
+                name = t.split(":", 1)[1].strip()
+            elif t.startswith(".vgpr_count:") and name:
+                vg[name] = int(t.split(":", 1)[1])
+    tail = [v for n, v in vg.items() if "rdsp_tail_kernel" in n]
+    front = [v for n, v in vg.items() if "rdsp_front_fd_kernel" in n and "ILi512ELi8ELb0ELb0E" in n]
+    assert tail and front, sorted(vg)[:5]
+    alloc = lambda v: (v + 7) // 8 * 8        # gfx950 allocates VGPRs in blocks of 8
+    assert alloc(tail[0]) <= 128 and alloc(front[0]) <= 176 and 2 * alloc(front[0]) + alloc(tail[0]) <= 512, (tail, front)
 
 
 def test_host_c_under_address_and_ub_sanitizers(tmp_path):

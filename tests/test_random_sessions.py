@@ -15,7 +15,7 @@ import pytest
 
 from cases import K3
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("front_form")]   # every test under both front kernels (conftest.py)
 
 NCH, MAXBLK, NGROUPS = 150, 32, 3
 

@@ -8,7 +8,7 @@ import pytest
 
 from cases import K1, K3
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("front_form")]   # every test under both front kernels (conftest.py)
 
 
 def _parts(iq, per):
@@ -27,14 +27,12 @@ def _setup(ch, kind):
         ch.enableNoiseBlanker()
         ch.swapIQ(True)
         ch.setInputGain(0.8)
-    elif kind == "k1_fold":         # the folded front stage: its 1280-sample raw history and its form travel too
-        ch.set_fir_variant(4)
     elif kind == "k1_slip":         # the I2S slip correction: its carry word (the last raw sample) travels too
         ch.setIQslip(1)
 
 
 @pytest.mark.parametrize("kind,cfg", [("k3", K3), ("k3_nr", K3), ("sam_iir", dict(fft_l=512, agc_mode="slow", output_gain=0.5)),
-                                      ("k1", K1), ("k1_slip", K1), ("k1_fold", K1), ("cw_2048", dict(fft_l=2048, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0,
+                                      ("k1", K1), ("k1_slip", K1), ("cw_2048", dict(fft_l=2048, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0,
                                                                     nco_hz=11300.0, agc_mode="fast"))])
 def test_resume_and_channel_move_are_bit_exact(rdsp, kind, cfg):
     import torch
