@@ -54,6 +54,8 @@ def parse():
                     help="with --groups: re-tune one group (PBT step) every N timed steps, without synchronising")
     ap.add_argument("--no-host-io", action="store_true",
                     help="skip the extra PCIe-inclusive leg (host memory -> chain -> host memory)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the K2 / K4 / K5 legs that follow the headline leg of the default run")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
     ap.add_argument("--lib", default=os.environ.get("RDSP_BENCH_LIB"),
                     help="A/B runs: another build of librdsp_hip.so (default: the in-tree one); named in the JSON line")
@@ -367,6 +369,76 @@ def dry_run(args, rank, world, dist):
         print(json.dumps(line))
 
 
+WORKLOAD_TEXT = {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
+                 "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
+                 "K4": "NCO mix + 256-tap polyphase /4 + 4096-pt overlap-save CW filter (2049 taps) + AGC",
+                 "K5": "K3 chain, 8192 channels/GPU"}
+
+
+def dominant_kernel(fname, front_avg, tail_avg, decim):
+    """(name, avg ms, the kernel's own algorithmic bytes per input sample): the kernel of the step that runs
+    LONGER.  Every kernel of the chain is priced with the chain's 5 B per input sample in
+    `roofline.achieved`; what the kernel itself moves (the tail kernel: 4 B in + 4 B out per OUTPUT sample)
+    goes beside it as `kernel_own`."""
+    if tail_avg > front_avg:
+        return "rdsp_tail_kernel", tail_avg, 8.0 / decim
+    return fname, front_avg, algorithmic_bytes_per_sample(decim)
+
+
+def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant, barrier, iq=None):
+    """One more BASELINE.json configuration after the headline leg, timed the same way (inputs resident in HBM,
+    warm-up, barrier + synchronize on both sides, max over ranks, per-kernel HIP events): K2 / K4 / the K5
+    per-GPU shape, so that the driver's one run carries a number for every GPU configuration."""
+    kc = R.K_CONFIGS[name]
+    cfg = dict(kc["cfg"])
+    nch, nblk, decim = kc["channels"], args.blocks, cfg.get("decim", 4)
+    n_samples = nblk * 128
+    if iq is None or iq.shape[0] != nch:
+        host = synth_iq(nch, n_samples, ch0=rank * nch, cw=kc.get("cw", False), n_threads=host_cores(1))
+        iq = torch.from_numpy(host).to(dev)
+        del host
+    out = torch.empty((nch, n_samples // decim, 2), dtype=torch.int16, device=dev)
+    ch = Chain(nch, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **cfg)
+    ch.set_pipelined(not args.no_pipeline)
+    steps = max(20, min(args.steps, 60))
+    for _ in range(max(5, min(args.warmup, 10))):
+        ch.process(iq, out=out)
+    ch.flush()
+    barrier()
+    ch.set_timing(not args.no_kernel_timing)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ch.process(iq, out=out)
+    ch.flush()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    f_ms, t_ms, calls = ch.get_timing()
+    span, _ = ch.get_timing_span()
+    ch.set_timing(False)
+    fname = ch.front_kernel_name()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    f_avg, t_avg = f_ms / max(calls, 1), t_ms / max(calls, 1)
+    dom, dom_ms, b_own = dominant_kernel(fname, f_avg, t_avg, decim)
+    B = algorithmic_bytes_per_sample(decim)
+    ach = B * nch * n_samples / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
+    ctr, note = load_counters(name)
+    leg = {"config": name, "workload": f"{name}: {nch} channels/GPU x {nblk} blocks of 128 int16 IQ samples per step; {WORKLOAD_TEXT[name]}",
+           "channels_per_gpu": nch, "channels_total": nch * world, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "ms_per_step_steady": span / (calls - 1) if calls > 1 else None,
+           "value": float(world) * nch * n_samples * steps / elapsed / 1e6, "unit": "IQ Msamples/s",
+           "kernels_ms_per_step": {fname: f_avg, "rdsp_tail_kernel": t_avg} if t_avg > 0 else {fname: f_avg},
+           "roofline": {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": ctr.get(dom, {}).get("hbm_bytes"),
+                        "counters_note": note}}
+    del ch, out, iq
+    torch.cuda.empty_cache()
+    return leg
+
+
 def main():
     args = parse()
     if args.lib:   # A/B harness: another build of the library (no torch / HIP touched by this import)
@@ -497,45 +569,34 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     front_ms, tail_ms, calls = chain.get_timing()
+    span_ms, _ = chain.get_timing_span()
     chain.set_timing(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # N > 1 with the default workload: a second, separately timed leg at BASELINE.json configs[4]'s shape
-    # (K5: 8192 channels per GPU, full chain), so that the driver's `--gpus 8` form also yields the
-    # 65 536-channel figure; the headline `value` stays the K3 per-GPU workload for every N
+    # After the headline leg, the other GPU configurations of BASELINE.json, each timed the same way (extra_leg):
+    # N = 1: K2, K4 and the K5 per-GPU shape; N > 1: the K5 shape (8192 channels per GPU, 65 536 at N = 8).  The
+    # headline `value` / `config` stay the K3 per-GPU workload for every N.
     fname = chain.front_kernel_name()   # rdsp_front_fd_kernel (stage A3 in the frequency domain) or rdsp_front_kernel
+    legs = {}
+    default_shape = args.config == "K3" and not args.channels_per_gpu and args.groups == 1
+    if default_shape and not args.no_extra_legs and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
+        which = ["K5"] if world > 1 else ["K2", "K5", "K4"]
+        for name in which:
+            reuse = iq if name == "K2" else None      # K2 reads the headline leg's input (same generator, same channels)
+            try:
+                legs[name] = extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant,
+                                       barrier, iq=reuse)
+            except Exception as e:   # an extra leg never takes the headline down
+                if world > 1:
+                    raise
+                legs[name] = {"config": name, "value": None, "note": f"failed: {e}"}
     k5_leg = None
-    if world > 1 and args.config == "K3" and not args.channels_per_gpu and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
-        del iq, out, chain
-        torch.cuda.empty_cache()
-        k5c = R.K_CONFIGS["K5"]
-        n5 = k5c["channels"]
-        iq5 = torch.from_numpy(synth_iq(n5, n_samples, ch0=rank * n5, n_threads=threads)).to(dev)
-        out5 = torch.empty((n5, n_samples // decim, 2), dtype=torch.int16, device=dev)
-        ch5 = Chain(n5, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **dict(k5c["cfg"]))
-        ch5.set_pipelined(not args.no_pipeline)
-        steps5 = max(10, min(args.steps, 60))
-        for _ in range(min(args.warmup, 10)):
-            ch5.process(iq5, out=out5)
-        ch5.flush()
-        barrier()
-        t5 = time.perf_counter()
-        for _ in range(steps5):
-            ch5.process(iq5, out=out5)
-        ch5.flush()
-        torch.cuda.synchronize()
-        e5 = time.perf_counter() - t5
-        barrier()
-        tt = torch.tensor([e5], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        e5 = float(tt.item())
-        k5_leg = {"config": "K5", "channels_per_gpu": n5, "channels_total": n5 * world, "steps": steps5,
-                  "ms_per_step": e5 / steps5 * 1e3, "value": float(world) * n5 * n_samples * steps5 / e5 / 1e6,
-                  "unit": "IQ Msamples/s", "note": "BASELINE.json configs[4]: full chain, 8192 channels per GPU, "
-                                                   "timed after the headline leg with the same barrier / max-over-ranks protocol"}
+    if world > 1 and "K5" in legs:
+        k5_leg = dict(legs["K5"], note="BASELINE.json configs[4]: full chain, 8192 channels per GPU, timed after the headline "
+                                       "leg with the same barrier / max-over-ranks protocol")
 
     if rank == 0:
         total_samples = float(world) * nch * n_samples * args.steps
@@ -544,13 +605,8 @@ def main():
         # dominant kernel of the step and its roofline (bytes per launch / avg launch time)
         front_avg = front_ms / max(calls, 1)
         tail_avg = tail_ms / max(calls, 1)
-        # dominant kernel: the front kernel (it carries the IQ stream: 4 B in + 4/D B out per input
-        # sample, the chain's own figure) unless the tail kernel -- 4 B in + 4 B out per OUTPUT sample --
-        # runs clearly longer; in pipelined mode both run for the whole step, within a few percent
-        if tail_avg > 1.10 * front_avg:
-            dom, dom_ms, B_own = "rdsp_tail_kernel", tail_avg, 8.0 / decim
-        else:
-            dom, dom_ms, B_own = fname, front_avg, B
+        # dominant kernel: whichever runs longer (in pipelined mode both run for the whole step, within a few percent)
+        dom, dom_ms, B_own = dominant_kernel(fname, front_avg, tail_avg, decim)
         # roofline.achieved: SURVEY 8(d)'s figure (B = 5 bytes per input IQ sample of the chain) x the
         # samples one launch processes / the dominant kernel's average duration; the kernel's own
         # algorithmic bytes (the tail kernel only moves 4 B in + 4 B out per OUTPUT sample) go beside it
@@ -575,6 +631,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # what a long stream pays per step: the period between the ends of consecutive steps' last kernels
+            # (HIP events), i.e. without the pipeline's fill -- the first step's front kernel has no tail kernel
+            # to overlap with, ~0.6 ms once per timed region, 0.03 ms per step at --steps 20
+            "ms_per_step_steady": span_ms / (calls - 1) if calls > 1 else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -582,10 +642,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: {nch} channels/GPU x {nblk} blocks of 128 int16 IQ samples @96 kHz per step; "
-                            + {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
-                               "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
-                               "K4": "NCO mix + 256-tap polyphase /4 + 4096-pt overlap-save CW filter (2049 taps) + AGC",
-                               "K5": "K3 chain, 8192 channels/GPU"}[args.config]
+                            + WORKLOAD_TEXT[args.config]
                             + (f" + audio filter {os.environ['RDSP_AUDIO_IIR']} as the 8th-order IIR bank (non-default option)"
                                if os.environ.get("RDSP_AUDIO_IIR") else ""),
                 "channels_per_gpu": nch,
@@ -616,9 +673,19 @@ def main():
                                   "busy_frac_pmc": {k: v.get("valu_busy_frac") for k, v in ctr.items()
                                                     if k in (fname, "rdsp_tail_kernel")} or None}},
             "input_gen_s": gen_s,
+            # what "matches the reference's CPU path" means here (tests/parity_util.py; a deviation from the
+            # north-star's blanket 1e-5 for the bare-recursion chains, stated where the number is read)
+            "tolerance": {"int16_unpack_pack": "bit-exact",
+                          "feed_forward_chains_and_K3": "<= 1e-5 normwise per channel vs the float32 CPU oracle (K3 measured 3e-6..6e-6)",
+                          "bare_recursion_chains": "DSP-NR / ALS without spectral stage + AGC, IIR bank, SAM: truth-anchored -- "
+                                                   "err(gpu, float64 model) <= max(1e-5, 1.5 x err(oracle, float64 model)); gpu vs "
+                                                   "oracle up to 1.4e-4 there, the float32 oracle itself 4e-5..1.1e-4 from float64",
+                          "oracle": "parity unpinned: the reference holds no vectors and cannot be built here (DESIGN.md 2)"},
         }
         if args.lib:
             res["library"] = os.path.abspath(args.lib)   # an A/B run, not the in-tree build
+        if legs:
+            res["configs"] = legs      # K2 / K4 / K5-per-GPU legs of the same run (N > 1: K5 only)
         if k5_leg is not None:
             res["k5"] = k5_leg
         if world == 1 and not args.no_host_io:

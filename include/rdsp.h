@@ -277,6 +277,9 @@ int rdsp_chain_set_timing(rdsp_chain_t *c, int on);
 const char *rdsp_chain_front_kernel_name(const rdsp_chain_t *c);
 /* total milliseconds spent in the front and tail kernels over `calls` calls */
 int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *tail_ms, int *calls);
+/* milliseconds between the end of the first and of the last recorded call (calls - 1 steady-state periods
+ * of a pipelined sequence: what a long stream pays per call, without the pipeline's fill) */
+int rdsp_chain_get_timing_span(rdsp_chain_t *c, double *span_ms, int *calls);
 
 /* ---- state read-back (tests, checkpoint/resume) ------------------------------*/
 /* scal: float[n_channels][4] = NFloor (SPEC:109), AGC gain, AM DC, noise-blanker level */

@@ -128,6 +128,7 @@ SYMBOLS = [
     ("rdsp_chain_set_sub_batch", _i, [_vp, _i]),
     ("rdsp_chain_set_timing", _i, [_vp, _i]),
     ("rdsp_chain_get_timing", _i, [_vp, _f64p, _f64p, C.POINTER(C.c_int)]),
+    ("rdsp_chain_get_timing_span", _i, [_vp, _f64p, C.POINTER(C.c_int)]),
     ("rdsp_chain_get_scalars", _i, [_vp, _f32p, _vp]),
     ("rdsp_chain_device", _i, [_vp]),
     ("rdsp_spectrum_device", _i, [_vp]),

@@ -218,6 +218,12 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_get_timing(self.h, C.byref(f), C.byref(t), C.byref(n)))
         return f.value, t.value, n.value
 
+    def get_timing_span(self):
+        """(ms between the end of the first and of the last timed call, timed calls)"""
+        t, n = C.c_double(), C.c_int()
+        _lib.check(self.lib.rdsp_chain_get_timing_span(self.h, C.byref(t), C.byref(n)))
+        return t.value, n.value
+
     # ---- per-channel state as data (checkpoint / resume, channels moved between chains) ------
     def save_state(self, first_channel=0, n_channels=None, stream=None):
         """uint8 array holding the DSP state of channels first_channel .. first_channel + n_channels - 1"""

@@ -1417,6 +1417,25 @@ extern "C" int rdsp_chain_get_timing(rdsp_chain_t *c, double *front_ms, double *
   return RDSP_OK;
 }
 
+/* milliseconds from the end of the first recorded call's last kernel to the end of the last recorded call's:
+ * (calls - 1) steady-state periods of a pipelined sequence, without the pipeline's fill (the first call's
+ * front kernel has no tail kernel to overlap with) */
+extern "C" int rdsp_chain_get_timing_span(rdsp_chain_t *c, double *span_ms, int *calls) {
+  NEED(c);
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  const size_t n = c->ev_used;
+  float ms = 0.f;
+  if (n >= 2) {
+    hipEvent_t a = c->ev[4 * 0 + (c->ev_has_tail[0] ? 3 : 1)];
+    hipEvent_t b = c->ev[4 * (n - 1) + (c->ev_has_tail[n - 1] ? 3 : 1)];
+    HIP_TRY(hipEventSynchronize(b));
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  }
+  if (span_ms) *span_ms = ms;
+  if (calls) *calls = (int)n;
+  return RDSP_OK;
+}
+
 /* ---- per-channel state as data: checkpoint / resume, channels moved between chains or GPUs ------
  * The reference keeps its DSP state in globals (CONV:50-57,77-80; NR:26-32; SPEC:109) and has no
  * persistence; here the state is an explicit per-channel record, so a range of
