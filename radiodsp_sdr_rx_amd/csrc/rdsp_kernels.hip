@@ -249,6 +249,182 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
   }
 }
 
+/* ---- FFT_L = 256 behind the frequency-domain decimator: FOUR overlap-save frames per pass ----------
+ * 256 points over a whole wave are 4 points per lane: four radix-4 passes, three LDS exchanges each way,
+ * every pass a quarter-filled instruction stream -- the filter stage of K1 / K2 (the reference's own
+ * FFT_L, CONV:36) cost as many VALU instructions and more LDS cycles than the 256-tap decimator in front
+ * of it.  Overlap-save frames do not depend on each other (each is two consecutive hops of the decimated
+ * stream, which sits in the ring), so here a 16-lane DPP row takes one frame -- 16 points per lane, two
+ * radix-16 passes, ONE exchange each way -- and the wave takes four consecutive frames at once: a third
+ * of the LDS operations per frame and about half the instructions.  What IS sequential across frames
+ * (NFloor SPEC:205, the AGC gain, the AM detector's DC) depends on one number per frame: the four row
+ * sums are read out with v_readlane and the four steps of the recursion run on wave-uniform values.
+ * The mask is read from the same device image as the radix-4 plan's (digit-reversed for FftPlan<256, 4>):
+ * bin k = i + 16 e of lane i sits at 64 e1 + e0 + 16 i0 + 4 i1 (i = i0 + 4 i1, e = e0 + 4 e1).
+ * Ring: nine hops of 128, each padded by 16 float2 so that the two rows of a 32-lane group read disjoint
+ * halves of the 64 banks; the hop in front of the oldest unconsumed one is never overwritten (it is the
+ * first frame's overlap, CONV:267-271), so there is no previous-hop register file as in front_frame. */
+constexpr int QUAD_HOPS = 9, QUAD_PITCH = 128 + 16, QUAD_RING = QUAD_HOPS * QUAD_PITCH;
+constexpr int QUAD_WB = 4 * FftPlan<256, 16>::WB;
+
+template <typename F>
+__device__ __forceinline__ void quad_chain(float x, int g, int nf, float &state, float &before, float &after, F step) {
+  const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+  const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+  const float x2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 32));
+  const float x3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 48));
+  const float s0 = state, s1 = step(s0, x0), s2 = step(s1, x1), s3 = step(s2, x2), s4 = step(s3, x3);
+  before = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3));
+  after = g == 0 ? s1 : (g == 1 ? s2 : (g == 2 ? s3 : s4));
+  state = nf == 1 ? s1 : (nf == 2 ? s2 : (nf == 3 ? s3 : s4)); /* frames g >= nf are not there: their sums are never used */
+}
+
+template <typename TW>
+__device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const RdspGroup &G, const TW &tw,
+                                                 const LdsBases<256, 16, false> &lb, float2 *wbg, const float2 *ring,
+                                                 int rhop, int nf, int mbase, uint32_t vadbits, float vad_inv, float &nfloor,
+                                                 float &agc_g, float &am_dc, int frame_idx, size_t ch, int lane) {
+  constexpr int N = 256, P = 16;
+  const int g = lane >> 4, i = lane & 15;
+  int hc = rhop + g;
+  hc = hc >= QUAD_HOPS ? hc - QUAD_HOPS : hc;
+  const int hp = hc == 0 ? QUAD_HOPS - 1 : hc - 1;
+  const float2 *cur = ring + hc * QUAD_PITCH + i, *prv = ring + hp * QUAD_PITCH + i;
+  /* this lane's sixteen bins of the group's mask: L2-resident, land behind the forward transform */
+  float2 mreg[P];
+  {
+    const float2 *mp = p.mask_pool + G.mask_off;
+    asm volatile("" : "+s"(mp));
+    const auto gp = as_global(mp);
+#pragma unroll
+    for (int e = 0; e < P; e++) mreg[e] = gp[mbase + 64 * (e >> 2) + (e & 3)];
+  }
+  float2 v[P];
+#pragma unroll
+  for (int j = 0; j < P / 2; j++) { /* CONV:267-285: [previous hop | current hop], v[j] = x[i + 16 j] */
+    v[j] = lds_ld(prv + 16 * j);
+    v[j + P / 2] = lds_ld(cur + 16 * j);
+  }
+  {
+    float2 twp[P - 1];
+    tw.template get<0>(twp);
+    fwd_pass0_store<N, P>(lb, v, wbg, twp); /* CONV:291 */
+  }
+  wg_sync<1>();
+  fwd_pass_last<N, P>(lb, v, wbg);
+
+  if (p.spectral_on) { /* SPEC:182-235 on the un-masked spectrum, as front_frame */
+    float mag[P], rmag[P];
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      const float pw = fmaf(v[e].y, v[e].y, fmaf(v[e].x, v[e].x, 1e-30f));
+      rmag[e] = __builtin_amdgcn_rsqf(pw);
+      mag[e] = pw * rmag[e];                              /* SPEC:182 */
+      part += ((vadbits >> e) & 1u) ? mag[e] : 0.f;       /* SPEC:194-197 */
+    }
+    float th = row_allsum(part) * vad_inv;                /* SPEC:200 */
+    th = th * p.spectral_k;                               /* SPEC:202 */
+    float nf0, mine;
+    const int old_variant = p.spectral_on == 2;
+    quad_chain(th, g, nf, nfloor, nf0, mine, [&](float s, float t) {
+      float n = s + (t - s) * 0.65f;                      /* SPEC:205 */
+      n = n > 0.f ? n : 0.f;                              /* SPEC:206 */
+      return old_variant ? t : n;                         /* BK_INO:1595-1596: no smoothing */
+    });
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      const float sc = (mag[e] <= mine) ? 0.2f : fmaf(-mine, rmag[e], 1.f); /* SPEC:213-217, 226-235 */
+      v[e].x *= sc;
+      v[e].y *= sc;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < P; e++) v[e] = cmul(v[e], mreg[e]); /* CONV:301 */
+
+  inv_pass_last<N, P>(lb, v, wbg); /* CONV:309 */
+  wg_sync<1>();
+  {
+    float2 twp[P - 1];
+    tw.template get<0>(twp);
+    inv_pass0_load<N, P>(lb, v, wbg, twp);
+  }
+  wg_sync<1>();
+
+  /* CONV:314-318: keep the second half.  v[8 + j] = y[128 + i + 16 j]; sample o = i + 16 j of the hop */
+  constexpr int Q = P / 2;
+  float L[Q], R[Q], ramp[Q];
+#pragma unroll
+  for (int j = 0; j < Q; j++) {
+    L[j] = v[Q + j].x;
+    R[j] = v[Q + j].y;
+    ramp[j] = (float)(i + 16 * j + 1) / (float)RDSP_BLOCK;
+  }
+  if (G.demod == RDSP_K_DEMOD_REAL) {
+#pragma unroll
+    for (int j = 0; j < Q; j++) R[j] = L[j];
+  } else if (G.demod == RDSP_K_DEMOD_AM) {
+    float a[Q], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q; j++) {
+      a[j] = __builtin_amdgcn_sqrtf(L[j] * L[j] + R[j] * R[j]);
+      s += a[j];
+    }
+    float d0, d1;
+    quad_chain(row_allsum(s), g, nf, am_dc, d0, d1, [&](float dc, float sum) {
+      const float m = sum / (float)RDSP_BLOCK;
+      return dc + 0.25f * (m - dc);
+    });
+#pragma unroll
+    for (int j = 0; j < Q; j++) {
+      L[j] = a[j] - (d0 + (d1 - d0) * ramp[j]);
+      R[j] = L[j];
+    }
+  }
+  const bool valid = g < nf;
+  const size_t tout = (size_t)(frame_idx + g) * RDSP_BLOCK + (size_t)i;
+  if (p.to_mid) {
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < Q; j++) p.mid[ch * p.mid_stride + tout + 16 * j] = L[j];
+      if (G.demod == RDSP_K_DEMOD_SAM) {
+#pragma unroll
+        for (int j = 0; j < Q; j++) p.mid_q[ch * p.mid_stride + tout + 16 * j] = R[j];
+      }
+    }
+  } else {
+    if (p.agc_on) {
+      float pw = 0.f;
+#pragma unroll
+      for (int j = 0; j < Q; j++) pw += L[j] * L[j] + R[j] * R[j];
+      float g0, g1;
+      quad_chain(row_allsum(pw), g, nf, agc_g, g0, g1, [&](float gain, float sum) {
+        const float pp = sum / (float)(2 * RDSP_BLOCK);
+        const float rms = __builtin_amdgcn_sqrtf(pp);
+        float gt = 0.25f * __builtin_amdgcn_rcpf(rms + 1e-6f);
+        gt = fminf(gt, 100.0f);
+        const float coef = (gt < gain) ? p.agc_attack : p.agc_decay;
+        return gain + coef * (gt - gain);
+      });
+#pragma unroll
+      for (int j = 0; j < Q; j++) {
+        const float gg = g0 + (g1 - g0) * ramp[j];
+        L[j] *= gg;
+        R[j] *= gg;
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < Q; j++) {
+        const float l = L[j] * p.out_gain, r = R[j] * p.out_gain;
+        const size_t o = ch * p.out_stride + tout + 16 * j;
+        __builtin_nontemporal_store(pack_lr(l, r), p.out_i16 + o); /* CONV:346-347 */
+        if (p.out_f32) p.out_f32[o] = make_float2(l, r);
+      }
+    }
+  }
+}
+
 /* LEAN = true trades registers for a little recomputation (twiddle powers per pass,
  * mask slice re-read per chunk).  It pays at radix 16, where it buys the second wave per
  * SIMD.  At radix 8 it was what let two front waves and a tail wave share the 512-register
@@ -633,16 +809,21 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   /* FFT_L >= 2048 runs four waves per channel: every wave takes its own decimator frame (four
    * frames per round, no sums across waves), then all of them share the overlap-save frames */
   constexpr int NW = NT / 64;
-  constexpr int RING = (NW == 1) ? 1024 : 4096; /* >= (H - 1) + NW * VAL, power of two */
+  /* FFT_L 256: four overlap-save frames per pass, a 16-lane row each (front_frame_quad) */
+  constexpr bool QUAD = (N == 256);
+  constexpr int RING = QUAD ? QUAD_RING : ((NW == 1) ? 1024 : 4096); /* >= (H - 1) + NW * VAL, power of two (QUAD: nine padded hops) */
   constexpr bool SAME = (N == ND && P == PD);   /* one plan: twiddles and LDS bases are shared */
   static_assert((NT == 64 || NT == 256) && PLD::NT == 64, "one or four waves per channel, one per decimator frame");
   static_assert(VAL == 64 * (PD - 1), "the last quad column of a frame is the first of the next");
-  static_assert(H - 1 + NW * VAL <= RING, "ring holds a round's outputs behind an unfinished hop");
+  static_assert(QUAD || H - 1 + NW * VAL <= RING, "ring holds a round's outputs behind an unfinished hop");
+  static_assert(!QUAD || (H + 4 * H - 1) + VAL <= QUAD_HOPS * H, "the overlap hop and three and a bit unconsumed hops survive a frame's seven columns");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *ring = reinterpret_cast<float2 *>(smem_raw);
   float2 *wb = ring + RING;
-  float *red = reinterpret_cast<float *>(wb + (PL::WB > NW * PLD::WB ? PL::WB : NW * PLD::WB));
+  constexpr int WBN0 = PL::WB > NW * PLD::WB ? PL::WB : NW * PLD::WB;
+  constexpr int WBN = (QUAD && QUAD_WB > WBN0) ? QUAD_WB : WBN0;
+  float *red = reinterpret_cast<float *>(wb + WBN);
 
   const bool SWAP_IQ = PRE && p.swap_iq != 0;
   /* the noise blanker takes the quad columns in stream order.  With four waves per channel the
@@ -693,9 +874,19 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   }
 
   Twiddles<N, P, LEAN> tw;
-  tw.init(tid);
   LdsBases<N, P, false> lb;
-  make_lds_bases<N, P, false>(tid, lb);
+  if constexpr (!QUAD) {
+    tw.init(tid);
+    make_lds_bases<N, P, false>(tid, lb);
+  }
+  /* FFT_L 256: the 16-point-per-lane plan of front_frame_quad, a lane's place in its row */
+  Twiddles<256, 16, LEAN> tw16;
+  LdsBases<256, 16, false> lb16;
+  if constexpr (QUAD) {
+    tw16.init(lane & 15);
+    make_lds_bases<256, 16, false>(lane & 15, lb16);
+  }
+  const int mbase = 16 * (lane & 3) + 4 * ((lane >> 2) & 3); /* this lane's bins in the radix-4 plan's mask image */
   /* the decimator's plan: its own twiddles and LDS bases unless it is the filter's plan */
   Twiddles<ND, PD, false> twd_own;
   LdsBases<ND, PD, false> lbd_own;
@@ -706,10 +897,18 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   const auto &twd = [&]() -> const auto & { if constexpr (SAME) return tw; else return twd_own; }();
   const auto &lbd = [&]() -> const auto & { if constexpr (SAME) return lb; else return lbd_own; }();
   uint32_t vadbits = 0;
+  if constexpr (QUAD) {
 #pragma unroll
-  for (int e = 0; e < P; e++) {
-    int k = bin_of_pos<N, P>(tid * P + e);
-    if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+    for (int e = 0; e < 16; e++) {
+      const int k = (lane & 15) + 16 * e; /* bin_of_pos<256, 16>(16 i + e) */
+      if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      int k = bin_of_pos<N, P>(tid * P + e);
+      if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+    }
   }
   float nfloor = p.st_scal[ch * 4 + 0];
   const float vad_inv = 1.0f / (float)(p.vad_hi - p.vad_lo);
@@ -718,10 +917,16 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   float nb_level = p.st_scal[ch * 4 + 3], nb_acc = 0.f;
   uint4 hist_save = make_uint4(0u, 0u, 0u, 0u); /* the call's last 64 quads as they entered the decimator */
   float2 vprev[PH];
+  if constexpr (QUAD) { /* the previous hop goes in front of the ring's first one (hop 8 of 9) */
 #pragma unroll
-  for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
+    for (int j = 0; j < PH; j++) ring[(QUAD_HOPS - 1) * QUAD_PITCH + tid + j * NT] = p.st_prev[ch * H + tid + j * NT];
+  } else {
+#pragma unroll
+    for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
+  }
   int frame_idx = 0;
   int produced = 0, consumed = 0;
+  int rhop = 0; /* QUAD: ring hop of the oldest unconsumed sample */
   auto wsync = []() { wg_sync<1>(); };
   if constexpr (NW > 1) {
     if (NB_ON) {
@@ -882,15 +1087,40 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       /* a frame's outputs start at a multiple of 64 in the ring, so a column of 64 never wraps: the wrap is
        * scalar arithmetic per column, one vector add per store (past the end of the call: slots nobody
        * consumes, `produced` stops at total) */
-      const int m0 = __builtin_amdgcn_readfirstlane(fr * VAL);
-      static_assert(VAL % 64 == 0 && RING % 64 == 0, "ring columns");
+      if constexpr (QUAD) { /* eighteen columns of 64 in nine padded hops */
+        const int w0 = __builtin_amdgcn_readfirstlane((fr * (PD - 1)) % (2 * QUAD_HOPS));
 #pragma unroll
-      for (int j = 1; j < PD; j++) ring[((m0 + 64 * (j - 1)) & (RING - 1)) + lane] = acc[j];
+        for (int j = 1; j < PD; j++) {
+          int cw = w0 + (j - 1);
+          cw = cw >= 2 * QUAD_HOPS ? cw - 2 * QUAD_HOPS : cw;
+          ring[cw * 64 + (cw >> 1) * (QUAD_PITCH - 128) + lane] = acc[j];
+        }
+      } else {
+        const int m0 = __builtin_amdgcn_readfirstlane(fr * VAL);
+        static_assert(VAL % 64 == 0 && (QUAD || RING % 64 == 0), "ring columns");
+#pragma unroll
+        for (int j = 1; j < PD; j++) ring[((m0 + 64 * (j - 1)) & (RING - 1)) + lane] = acc[j];
+      }
     }
     produced = (round + 1) * NW * VAL < total ? (round + 1) * NW * VAL : total;
     wg_sync<NW>();
 
     /* ---- A5/A6: overlap-save frames over what the ring holds ------------------------------ */
+    if constexpr (QUAD) {
+      /* four at a time; at the end of the call whatever is left (frames are complete hops: the call is whole granules) */
+#pragma unroll 1
+      while (produced - consumed >= 4 * H || (produced == total && produced - consumed >= H)) {
+        int nf = (produced - consumed) / H;
+        nf = nf > 4 ? 4 : nf;
+        front_frame_quad(p, G, tw16, lb16, wb + (lane >> 4) * FftPlan<256, 16>::WB, ring, rhop, nf, mbase, vadbits, vad_inv,
+                         nfloor, agc_g, am_dc, frame_idx, ch, lane);
+        frame_idx += nf;
+        consumed += nf * H;
+        rhop += nf;
+        rhop = rhop >= QUAD_HOPS ? rhop - QUAD_HOPS : rhop;
+      }
+      continue;
+    }
 #pragma unroll 1
     while (produced - consumed >= H) {
       float2 mreg[P];
@@ -902,7 +1132,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
         for (int e = 0; e < P; e++) mreg[e] = gp[e * NT + tid];
       }
       /* hops start at multiples of H in a ring of a multiple of H: the hop is contiguous */
-      static_assert(RING % H == 0, "a hop never wraps");
+      static_assert(QUAD || RING % H == 0, "a hop never wraps");
       const float2 *hop = ring + (consumed & (RING - 1));
       front_frame<N, P, false>(p, G, tw, lb, wb, red, mreg, vadbits, vad_inv, vprev, nfloor, agc_g, am_dc, frame_idx, ch,
                                tid, [&](int i) { return hop[i]; });
@@ -911,8 +1141,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   }
 
   /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
+  if constexpr (QUAD) {
+    const int hp = rhop == 0 ? QUAD_HOPS - 1 : rhop - 1; /* the last hop consumed */
 #pragma unroll
-  for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
+    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = ring[hp * QUAD_PITCH + tid + j * NT];
+  } else {
+#pragma unroll
+    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
+  }
   if (tid < 64 && !(NB_ON && NW > 1)) /* four waves with the blanker: stored by the wave that blanked them */
     *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
         NB_ON ? hist_save : *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
@@ -928,9 +1164,10 @@ template <int N, int P>
 constexpr size_t front_fd_lds() {
   constexpr int nw = N / P / 64;
   constexpr int wbd = nw * FftPlan<RDSP_FD_N, RDSP_FD_P>::WB;
-  constexpr int wbn = FftPlan<N, P>::WB > wbd ? FftPlan<N, P>::WB : wbd;
+  constexpr int wbn0 = FftPlan<N, P>::WB > wbd ? FftPlan<N, P>::WB : wbd;
+  constexpr int wbn = (N == 256 && QUAD_WB > wbn0) ? QUAD_WB : wbn0;
   /* + the blanker's hand-over area of the four-wave kernels: [nw][64] quads, 64 sums, the level */
-  return (size_t)((nw == 1 ? 1024 : 4096) + wbn) * sizeof(float2) + 64 * sizeof(float) +
+  return (size_t)((N == 256 ? QUAD_RING : (nw == 1 ? 1024 : 4096)) + wbn) * sizeof(float2) + 64 * sizeof(float) +
          (nw > 1 ? (size_t)nw * 64 * sizeof(uint4) + 64 * sizeof(float) + 16 : 0);
 }
 
