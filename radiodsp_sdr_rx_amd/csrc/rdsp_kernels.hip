@@ -261,10 +261,18 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
  * sums are read out with v_readlane and the four steps of the recursion run on wave-uniform values.
  * The mask is read from the same device image as the radix-4 plan's (digit-reversed for FftPlan<256, 4>):
  * bin k = i + 16 e of lane i sits at 64 e1 + e0 + 16 i0 + 4 i1 (i = i0 + 4 i1, e = e0 + 4 e1).
- * Ring: nine hops of 128, each padded by 16 float2 so that the two rows of a 32-lane group read disjoint
- * halves of the 64 banks; the hop in front of the oldest unconsumed one is never overwritten (it is the
- * first frame's overlap, CONV:267-271), so there is no previous-hop register file as in front_frame. */
-constexpr int QUAD_HOPS = 9, QUAD_PITCH = 128 + 16, QUAD_RING = QUAD_HOPS * QUAD_PITCH;
+ * Ring: eight hops of 128, each padded by 16 float2 so that the two rows of a 32-lane group read disjoint
+ * halves of the 64 banks.  The hop in front of the oldest unconsumed one is never overwritten (it is the
+ * first frame's overlap, CONV:267-271: no previous-hop register file as in front_frame): a decimator frame adds
+ * 448 samples when at most 448 are unconsumed (a quad goes as soon as 512 are there, and the counts are
+ * multiples of 64), 128 + 448 + 448 = the ring.
+ * Cost of the shape: 226 VGPRs and 18 KiB of LDS per channel (the four rows' exchange buffers), where the
+ * one-frame form takes 187 and 12.9.  Alone that is still two waves per SIMD and eight channels per CU, and
+ * K2 runs 0.6775 -> 0.6115 ms per step (same-box A/B); beside a tail kernel (124 VGPRs, 12.5 KiB per four
+ * channels) it would be one wave per SIMD, so chains that hand their audio to the tail kernel keep the
+ * one-frame form (template Q4, chosen by the launch code).  Moving mask and twiddles to LDS instead
+ * (171 VGPRs, 22-23 KiB: seven or six channels per CU) measured 0.710 / 0.744 ms: occupancy is worth more. */
+constexpr int QUAD_HOPS = 8, QUAD_PITCH = 128 + 16, QUAD_RING = QUAD_HOPS * QUAD_PITCH;
 constexpr int QUAD_WB = 4 * FftPlan<256, 16>::WB;
 
 template <typename F>
@@ -797,7 +805,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * identity across call splits holds for the direct form only; everything else (pipelining,
  * sub-batches, channel partition) stays bit-identical.  The pre-processor's IQ swap and the noise
  * blanker are compiled in with PRE (the blanker in the one-wave kernels). */
-template <int N, int P, bool LEAN, bool PRE>
+template <int N, int P, bool LEAN, bool PRE, bool Q4 = false>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;              /* the overlap-save filter's transform (FFT_L)     */
   constexpr int ND = RDSP_FD_N, PD = RDSP_FD_P; /* the decimator's: 512 points whatever FFT_L is  */
@@ -810,13 +818,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
    * frames per round, no sums across waves), then all of them share the overlap-save frames */
   constexpr int NW = NT / 64;
   /* FFT_L 256: four overlap-save frames per pass, a 16-lane row each (front_frame_quad) */
-  constexpr bool QUAD = (N == 256);
-  constexpr int RING = QUAD ? QUAD_RING : ((NW == 1) ? 1024 : 4096); /* >= (H - 1) + NW * VAL, power of two (QUAD: nine padded hops) */
+  constexpr bool QUAD = Q4;
+  static_assert(!Q4 || N == 256, "the four-frame form exists for FFT_L 256");
+  constexpr int RING = QUAD ? QUAD_RING : ((NW == 1) ? 1024 : 4096); /* >= (H - 1) + NW * VAL, power of two (QUAD: eight padded hops) */
   constexpr bool SAME = (N == ND && P == PD);   /* one plan: twiddles and LDS bases are shared */
   static_assert((NT == 64 || NT == 256) && PLD::NT == 64, "one or four waves per channel, one per decimator frame");
   static_assert(VAL == 64 * (PD - 1), "the last quad column of a frame is the first of the next");
   static_assert(QUAD || H - 1 + NW * VAL <= RING, "ring holds a round's outputs behind an unfinished hop");
-  static_assert(!QUAD || (H + 4 * H - 1) + VAL <= QUAD_HOPS * H, "the overlap hop and three and a bit unconsumed hops survive a frame's seven columns");
+  static_assert(!QUAD || H + (4 * H - 64) + VAL <= QUAD_HOPS * H, "the overlap hop and what is unconsumed (< 4 hops, in steps of 64) survive a frame's seven columns");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *ring = reinterpret_cast<float2 *>(smem_raw);
@@ -917,7 +926,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   float nb_level = p.st_scal[ch * 4 + 3], nb_acc = 0.f;
   uint4 hist_save = make_uint4(0u, 0u, 0u, 0u); /* the call's last 64 quads as they entered the decimator */
   float2 vprev[PH];
-  if constexpr (QUAD) { /* the previous hop goes in front of the ring's first one (hop 8 of 9) */
+  if constexpr (QUAD) { /* the previous hop goes in front of the ring's first one (the last of the ring) */
 #pragma unroll
     for (int j = 0; j < PH; j++) ring[(QUAD_HOPS - 1) * QUAD_PITCH + tid + j * NT] = p.st_prev[ch * H + tid + j * NT];
   } else {
@@ -1087,7 +1096,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       /* a frame's outputs start at a multiple of 64 in the ring, so a column of 64 never wraps: the wrap is
        * scalar arithmetic per column, one vector add per store (past the end of the call: slots nobody
        * consumes, `produced` stops at total) */
-      if constexpr (QUAD) { /* eighteen columns of 64 in nine padded hops */
+      if constexpr (QUAD) { /* columns of 64 in padded hops */
         const int w0 = __builtin_amdgcn_readfirstlane((fr * (PD - 1)) % (2 * QUAD_HOPS));
 #pragma unroll
         for (int j = 1; j < PD; j++) {
@@ -1160,14 +1169,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   }
 }
 
-template <int N, int P>
+template <int N, int P, bool Q4 = false>
 constexpr size_t front_fd_lds() {
   constexpr int nw = N / P / 64;
   constexpr int wbd = nw * FftPlan<RDSP_FD_N, RDSP_FD_P>::WB;
   constexpr int wbn0 = FftPlan<N, P>::WB > wbd ? FftPlan<N, P>::WB : wbd;
-  constexpr int wbn = (N == 256 && QUAD_WB > wbn0) ? QUAD_WB : wbn0;
+  constexpr int wbn = (Q4 && QUAD_WB > wbn0) ? QUAD_WB : wbn0;
   /* + the blanker's hand-over area of the four-wave kernels: [nw][64] quads, 64 sums, the level */
-  return (size_t)((N == 256 ? QUAD_RING : (nw == 1 ? 1024 : 4096)) + wbn) * sizeof(float2) + 64 * sizeof(float) +
+  return (size_t)((Q4 ? QUAD_RING : (nw == 1 ? 1024 : 4096)) + wbn) * sizeof(float2) + 64 * sizeof(float) +
          (nw > 1 ? (size_t)nw * 64 * sizeof(uint4) + 64 * sizeof(float) + 16 : 0);
 }
 
@@ -1260,6 +1269,16 @@ int ensure_lds_limit(size_t lds) {
 }
 template <int N, int P, bool LEAN, bool PRE>
 int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  if constexpr (N == 256) {
+    /* FFT_L 256: four overlap-save frames per pass (front_frame_quad) unless the audio goes on to the tail
+     * kernel, which may share the SIMDs (pipelined mode) and leaves no room for that form's registers and LDS */
+    if (!p->to_mid) {
+      constexpr size_t lds4 = front_fd_lds<N, P, true>();
+      static_assert(lds4 <= 48 * 1024, "no raised dynamic-LDS limit needed");
+      hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, true>), dim3(n_channels), dim3(N / P), lds4, stream, *p);
+      return (int)hipGetLastError();
+    }
+  }
   constexpr size_t lds = front_fd_lds<N, P>();
   if constexpr (lds > 48 * 1024) {
     int e = ensure_lds_limit<&rdsp_front_fd_kernel<N, P, LEAN, PRE>>(lds);
