@@ -10,8 +10,8 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 CFGS=${@:-K3 K2 K4 K5 F1}
-B="--steps 100 --warmup 20 --no-cpu-baseline --no-host-io --no-iso"
-P="--steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing"
+B="--steps 100 --warmup 20 --no-cpu-baseline --no-host-io --no-iso --no-extra-legs"
+P="--steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing --no-extra-legs"
 for K in $CFGS; do
   python3 -c "import bench; print(bench.lib_sha())" > $OUT/prof_$K.sha   # the sources these counters belong to
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$K -o trace -- python3 $ROOT/bench.py --config $K $B > $OUT/prof_$K.json 2> $OUT/prof_$K.err) || { echo "rocprof $K failed"; tail -5 $OUT/prof_$K.err; }
