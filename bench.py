@@ -401,7 +401,7 @@ def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_ra
     ch = Chain(nch, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **cfg)
     ch.set_pipelined(not args.no_pipeline)
     steps = max(20, min(args.steps, 60))
-    for _ in range(max(5, min(args.warmup, 10))):
+    for _ in range(40):   # un-timed: the same settling as the headline leg gets (set-up + warm-up)
         ch.process(iq, out=out)
     ch.flush()
     barrier()
@@ -554,6 +554,13 @@ def main():
         chain.set_timing(False)
         iso = {chain.front_kernel_name(): f2 / max(n2, 1), "rdsp_tail_kernel": t2 / max(n2, 1)}
         chain.set_pipelined(True)
+    # set-up, un-timed: the package's power management needs ~15 steps of the PIPELINED load to settle (the two
+    # kernels together sit at the 1400 W cap; behind the lighter set-up above the first pipelined steps run
+    # 1.19, 1.18, 1.16, 1.15 ... ms before the clock finds its level at ~1.10: tests/micro/step_trace.py).  The
+    # timed region is a stream in flight, not a cold start; the count goes into the line (`setup_steps`).
+    settle = max(0, 40 - args.warmup)
+    for _ in range(settle):
+        chain.process(iq, out=out)
     for _ in range(args.warmup):
         chain.process(iq, out=out)
     chain.flush()
@@ -673,6 +680,8 @@ def main():
                                   "busy_frac_pmc": {k: v.get("valu_busy_frac") for k, v in ctr.items()
                                                     if k in (fname, "rdsp_tail_kernel")} or None}},
             "input_gen_s": gen_s,
+            "setup_steps": {"unpipelined_kernel_reference": 30 if iso is not None else 0, "settle_before_warmup": settle,
+                            "note": "un-timed, before the --warmup steps: clock / power settling of the GPU under this load"},
             # what "matches the reference's CPU path" means here (tests/parity_util.py; a deviation from the
             # north-star's blanket 1e-5 for the bare-recursion chains, stated where the number is read)
             "tolerance": {"int16_unpack_pack": "bit-exact",
