@@ -375,6 +375,7 @@ struct orc_chain {
   int swap_iq;
   int iq_slip;            /* +1: the I rail is taken one sample late, -1: the Q rail (I2S channel slip) */
   int16_t slip_i, slip_q; /* the previous raw sample */
+  int literal_resynthesis; /* SPEC:221-235 as written: atan2 + table-interpolated arm_cos_f32 / arm_sin_f32 */
   int nb_on;
   float nb_thr;   /* threshold as a power ratio, 10^(dB/10) */
   float nb_level; /* reference power: smoothed mean |x|^2 of the past windows */
@@ -463,6 +464,33 @@ void orc_set_spectral_nr(orc_chain_t *c, int on, float level) {
   c->cfg.spectral_nr = on;
   c->cfg.spectral_level = level;
 }
+/* SPEC:221-235 re-synthesises every bin as mag' * (arm_cos_f32(phi) + j arm_sin_f32(phi)), phi = atan2(im, re).
+ * In exact arithmetic that is X * mag'/mag, which is what this restatement (and the kernels) evaluate by
+ * default.  on = 1 evaluates it AS WRITTEN, with arm_sin_f32 / arm_cos_f32 restated from their published
+ * algorithm (CMSIS-DSP FastMathFunctions: 512-entry table of sin(2 pi k / 512), 513 entries, linear
+ * interpolation on the fractional index; cos = the same with the argument advanced by a quarter turn), so that
+ * the distance between the two forms -- the table's interpolation error, up to (2 pi / 512)^2 / 8 = 1.9e-5 of a
+ * bin's magnitude -- can be measured (tests/test_oracle_kat.py).  Test infrastructure only. */
+void orc_set_literal_resynthesis(orc_chain_t *c, int on) { c->literal_resynthesis = on ? 1 : 0; }
+static float orc_sin_table[513];
+static int orc_sin_table_ready = 0;
+static float orc_fast_sin_turns(float in) { /* in: the angle in turns (x / 2 pi), any sign */
+  if (!orc_sin_table_ready) {
+    for (int k = 0; k <= 512; k++) orc_sin_table[k] = (float)sin(2.0 * 3.14159265358979323846 * (double)k / 512.0);
+    orc_sin_table_ready = 1;
+  }
+  int32_t n = (int32_t)in;
+  if (in < 0.0f) n--;
+  in = in - (float)n; /* fractional part, [0, 1) */
+  float findex = 512.0f * in;
+  uint16_t index = (uint16_t)findex;
+  if (index >= 512) { index = 0; findex -= 512.0f; }
+  const float fract = findex - (float)index;
+  const float a = orc_sin_table[index], b = orc_sin_table[index + 1];
+  return (1.0f - fract) * a + fract * b;
+}
+float orc_arm_sin_f32(float x) { return orc_fast_sin_turns(x * 0.159154943092f); }
+float orc_arm_cos_f32(float x) { return orc_fast_sin_turns(x * 0.159154943092f + 0.25f); }
 void orc_set_gains(orc_chain_t *c, float input_gain, float iq_balance, float output_gain, int mute) {
   c->cfg.input_gain = input_gain;
   c->cfg.iq_balance = iq_balance;
@@ -709,6 +737,12 @@ static void conv_frame(orc_chain_t *c) {
       float m0 = mag[j], m1;
       if (m0 <= c->NFloor) m1 = (float)((double)m0 * 0.2);
       else m1 = m0 - c->NFloor;
+      if (c->literal_resynthesis) { /* SPEC:221-235 as written (orc_set_literal_resynthesis) */
+        const float phi = (float)atan2((double)F[2 * j + 1], (double)F[2 * j]); /* SPEC:229 */
+        F[2 * j] = m1 * orc_arm_cos_f32(phi);                                  /* SPEC:231 */
+        F[2 * j + 1] = m1 * orc_arm_sin_f32(phi);                              /* SPEC:232 */
+        continue;
+      }
       /* SPEC:226-235: mag' * (cos phi + j sin phi) == X * mag'/mag */
       float sc = (m0 > 0.0f) ? (m1 / m0) : 0.0f;
       F[2 * j] = F[2 * j] * sc;

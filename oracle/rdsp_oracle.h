@@ -118,6 +118,11 @@ void orc_set_agc_mode(orc_chain_t *c, int mode);
 void orc_set_filter_on(orc_chain_t *c, int on);
 void orc_set_als_mode(orc_chain_t *c, int mode);
 void orc_set_spectral_nr(orc_chain_t *c, int on, float level);
+/* SPEC:221-235 as written (atan2 + table-interpolated arm_cos_f32 / arm_sin_f32) instead of the equivalent
+ * X * mag'/mag: bounds how far the two forms are apart (test infrastructure) */
+void orc_set_literal_resynthesis(orc_chain_t *c, int on);
+float orc_arm_sin_f32(float x);
+float orc_arm_cos_f32(float x);
 /* SAM PLL loop constants at the decimated rate (build-defined, see rdsp_oracle.c) */
 void orc_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax);
 

@@ -136,6 +136,11 @@ def load(path=None):
     lib.orc_set_filter_on.argtypes = [vp, C.c_int]
     lib.orc_set_als_mode.argtypes = [vp, C.c_int]
     lib.orc_set_spectral_nr.argtypes = [vp, C.c_int, C.c_float]
+    lib.orc_set_literal_resynthesis.argtypes = [vp, C.c_int]
+    lib.orc_arm_sin_f32.restype = C.c_float
+    lib.orc_arm_sin_f32.argtypes = [C.c_float]
+    lib.orc_arm_cos_f32.restype = C.c_float
+    lib.orc_arm_cos_f32.argtypes = [C.c_float]
     lib.orc_chain_nb_level.argtypes = [vp]
     lib.orc_chain_nb_level.restype = C.c_float
     lib.orc_set_demod.argtypes = [vp, C.c_int]
@@ -231,6 +236,10 @@ class OracleChain:
 
     def set_spectral_nr(self, on, level):
         self.lib.orc_set_spectral_nr(self.h, int(on), float(level))
+
+    def set_literal_resynthesis(self, on):
+        """SPEC:221-235 as written (atan2 + table sin / cos) instead of X * mag'/mag"""
+        self.lib.orc_set_literal_resynthesis(self.h, int(bool(on)))
 
     def set_demod(self, demod):
         self.lib.orc_set_demod(self.h, int(demod))

@@ -331,3 +331,37 @@ def test_oracle_kats_pass_under_address_and_ub_sanitizers(tmp_path):
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_literal_resynthesis_bounds_the_equivalent_form(oracle):
+    """SPEC:221-235 re-synthesises every bin as mag' * (arm_cos_f32(phi) + j arm_sin_f32(phi)) with phi = atan2(im, re);
+    the oracle (and the kernels) evaluate the exact-arithmetic equivalent X * mag'/mag.  CMSIS' arm_sin_f32 /
+    arm_cos_f32 are a 512-entry table with linear interpolation (restated from the published algorithm in the
+    oracle): their error, up to (2 pi / 512)^2 / 8 = 1.9e-5, is what separates the two forms.  Measured here on the
+    reference's own configuration (SPEC: native rate, FFT_L 256, no mask) and on the K3 front end: the literal form
+    sits 1e-5 ... 3e-5 (normwise) from the equivalent one -- the size of its own table error, not a semantic
+    difference; the 1e-5 parity statements of this repository are about the equivalent form."""
+    import ctypes as C
+    from cases import CONV_LITERAL
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    lib = oracle.load()
+    # the table functions against libm
+    x = np.linspace(-7.0, 7.0, 20001).astype(np.float32)
+    es = max(abs(lib.orc_arm_sin_f32(C.c_float(float(v))) - np.sin(np.float64(v))) for v in x[::7])
+    ec = max(abs(lib.orc_arm_cos_f32(C.c_float(float(v))) - np.cos(np.float64(v))) for v in x[::7])
+    assert es <= 2.0e-5 and ec <= 2.0e-5 and max(es, ec) >= 1.0e-5, (es, ec)     # the interpolation error, no more, no less
+    worst = {}
+    for name, cfg in (("spec_literal_256", dict(CONV_LITERAL, filter_on=0, spectral_nr=1, spectral_level=2.0)),
+                      ("k3_front", dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0))):
+        iq = synth_iq(3, 64 * 128)
+        d = 0.0
+        for c in range(3):
+            a = oracle.OracleChain(**cfg)
+            b = oracle.OracleChain(**cfg)
+            b.set_literal_resynthesis(True)
+            ya, yb = a.process(iq[c])[1], b.process(iq[c])[1]
+            d = max(d, np.abs(ya - yb).max() / np.abs(ya).max())
+            assert abs(a.nfloor() - b.nfloor()) <= 1e-6 * a.nfloor()     # the threshold logic is the same code
+        worst[name] = d
+    print("literal re-synthesis vs X * mag'/mag, normwise:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert all(2e-6 <= v <= 5e-5 for v in worst.values()), worst
