@@ -224,6 +224,26 @@ def test_register_budget_of_the_two_kernels_that_share_a_simd(tmp_path):
     assert alloc(tail[0]) <= 128 and alloc(front[0]) <= 176 and 2 * alloc(front[0]) + alloc(tail[0]) <= 512, (tail, front)
 
 
+def test_quad_frame_mask_gather_matches_the_radix4_device_image(rdsp):
+    """front_frame_quad (FFT_L 256, four overlap-save frames per pass, 16 points per lane) reads its mask out of
+    the device image of the radix-4 plan, which both front kernels share: bin k = i + 16 e of lane i, element e sits
+    at 64 (e >> 2) + (e & 3) + 16 (i & 3) + 4 (i >> 2).  Checked against rdsp_mask_device_image for a labelled mask."""
+    lib = C.CDLL(os.path.join(ROOT, "radiodsp_sdr_rx_amd", "librdsp_hip.so"))
+    n = 256
+    nat = np.zeros(2 * n, np.float32)
+    nat[0::2] = np.arange(n) * n          # the image divides by N: entry k reads back as k
+    nat[1::2] = -np.arange(n) * n
+    img = np.zeros(2 * n, np.float32)
+    f32p = C.POINTER(C.c_float)
+    lib.rdsp_mask_device_image.argtypes = [f32p, C.c_int, f32p]
+    lib.rdsp_mask_device_image.restype = None
+    lib.rdsp_mask_device_image(nat.ctypes.data_as(f32p), n, img.ctypes.data_as(f32p))
+    for i in range(16):
+        for e in range(16):
+            idx = 64 * (e >> 2) + (e & 3) + 16 * (i & 3) + 4 * (i >> 2)
+            assert img[2 * idx] == i + 16 * e and img[2 * idx + 1] == -(i + 16 * e), (i, e, idx)
+
+
 def test_host_c_under_address_and_ub_sanitizers(tmp_path):
     """rdsp_graph.c, rdsp_io.c and rdsp_design.c (no HIP in them) built with ASan + UBSan + LSan
     and walked by tests/host/host_sanitize.c: pool exhaustion, teardown with blocks queued,
