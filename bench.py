@@ -500,9 +500,10 @@ def main():
     out = torch.empty((nch, n_samples // decim, 2), dtype=torch.int16, device=dev)
     gen_s = time.perf_counter() - t0
 
-    # stage A3 in the frequency domain (rdsp_chain_set_fir_variant 2): the library's default is the direct
-    # form, whose bits do not depend on how a stream is cut into calls; a bench step is one fixed-size call
-    fir_variant = int(os.environ.get("RDSP_FIR_VARIANT", "2"))   # A/B runs: 0 = the direct form
+    # stage A3 in the frequency domain with 448-sample frames (rdsp_chain_set_fir_variant 2): the library's default
+    # frames one granule at a time so that the bits do not depend on how a stream is cut into calls; a bench step
+    # is one fixed-size call
+    fir_variant = int(os.environ.get("RDSP_FIR_VARIANT", "2"))   # A/B runs: -1 = the library default, 0 = the direct form
     chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **cfg)
     chain.set_pipelined(not args.no_pipeline)
     if args.groups > 1:
@@ -656,7 +657,8 @@ def main():
                 "blocks_per_step": nblk,
                 "sharding": f"channels x{world}, no collectives",
                 "pipelined": not args.no_pipeline,
-                "decimator": "frequency domain (rdsp_chain_set_fir_variant 2)" if fir_variant == 2 else "direct form (library default)",
+                "decimator": {2: "frequency domain, 448-sample frames (rdsp_chain_set_fir_variant 2)", 0: "direct form (variant 0)"}.get(
+                    fir_variant, "frequency domain, one granule per frame (library default, split-invariant)"),
                 "groups": args.groups,
                 "retune_every_steps": args.retune_every,
             },

@@ -252,17 +252,19 @@ int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
-/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]).  -1 (default) and 0: the direct form (packed
- * FMAs): every output is a function of the absolute sample position only, so a stream gives the same
+/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]; decim 4).  -1 (default) and 4: in the frequency
+ * domain -- polyphase overlap-save: four low-rate transforms, branch spectra, one inverse -- with
+ * frames of ONE GRANULE (256 outputs, the rest of the 512-point window zeros): every call boundary is a frame
+ * boundary and every frame's input is a function of the absolute sample position, so a stream gives the same
  * bits however it is cut into calls -- the property the reference has by construction (fixed 128-sample
- * blocks, CONV:231-245).  2: in the frequency domain -- polyphase overlap-save: four low-rate transforms,
- * branch spectra, one inverse; decim 4 only (RDSP_ERR_UNSUPPORTED elsewhere).  The same
- * exact linear convolution with the same taps at about twice the throughput of the front kernel, for
- * callers who do not need split-invariant bits: its frames start at each call's first sample, so with it
- * a stream cut into calls differently differs in rounding (2.6e-7 of the output's peak over random splits,
- * 2.8e-6 through K3's recursive stages: tests/test_gpu_parity.py pins both).  bench.py selects 2 and says
- * so in its `config`.  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the tail stage
- * shares the SIMDs. */
+ * blocks, CONV:231-245).  0: the direct form (packed FMAs): split-invariant too, about 1.3x slower.  2: the
+ * frequency domain with 448-sample frames anchored at each call's first sample: 5 transforms per 448 outputs
+ * instead of per 256 (the front kernel ~1.4x faster), for callers who do not need split-invariant bits -- another
+ * call split frames and rounds differently (2.6e-7 of the output's peak over random splits, 2.8e-6 through K3's
+ * recursive stages: tests/test_gpu_parity.py pins both).  bench.py selects 2 and says so in its `config`.  All
+ * three are the same exact linear convolution with the same taps (RDSP_ERR_UNSUPPORTED for 2 / 4 on decim-1
+ * chains, which have no decimator).  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the
+ * tail stage shares the SIMDs. */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant);
 /* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row, two
  * steps per DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: (16, 4) weights one block

@@ -21,9 +21,10 @@ def _stream_ptr(stream=None):
 
 
 class Chain:
-    # stage A3 of chains made without an explicit choice: None = the library's default (the direct form, whose
-    # bits do not depend on the call split); 2 = the frequency-domain decimator on decim-4 chains (what
-    # bench.py runs).  The GPU test modules run under both (tests/conftest.py `front_form`).
+    # stage A3 of chains made without an explicit choice: None = the library's default (frequency domain with
+    # frames of one granule: the bits do not depend on the call split); 0 = the direct form; 2 = the
+    # frequency-domain decimator with 448-sample frames (what bench.py runs).  The GPU test modules run under
+    # all three (tests/conftest.py `front_form`).
     default_fir_variant = None
 
     def __init__(self, n_channels, max_blocks_per_call=512, device=0, fir_variant=None, **cfg):
@@ -195,7 +196,8 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 
     def set_fir_variant(self, variant):
-        """stage A3: 0 / -1 the direct form (split-invariant bits, default), 2 in the frequency domain"""
+        """stage A3: -1 / 4 frequency domain with granule frames (split-invariant bits, default), 0 the direct
+        form, 2 frequency domain with 448-sample frames (throughput; bits depend on the call split)"""
         _lib.check(self.lib.rdsp_chain_set_fir_variant(self.h, int(variant)))
 
     def set_tail_variant(self, lanes_per_channel, matrix_reduce=None):

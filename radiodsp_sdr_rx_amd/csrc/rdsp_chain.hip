@@ -134,9 +134,9 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto (= full), 0 full-register front kernel, 1 lean */
-  int fir_mode = -1;  /* stage A3: -1 / 0 direct form (packed FMAs; split-invariant bits, the default); 2 frequency
-                         domain (rdsp_chain_set_fir_variant; bench.py); EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix
-                         unless the tail stage shares the SIMDs */
+  int fir_mode = -1;  /* stage A3 (rdsp_chain_set_fir_variant): -1 / 4 frequency domain, one granule per frame (split-
+                         invariant bits, the default); 0 direct form; 2 frequency domain, 448-sample frames (bench.py);
+                         EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix unless the tail stage shares the SIMDs */
   /* wave priorities while both kernels share the SIMDs: the direct-form front kernel raises its
    * own to front_fir_prio during the FIR, the frequency-domain one never does; the tail kernel runs
    * at tail_prio throughout.  Round 2, frequency-domain front kernel, tail priority 0 / 1 / 2 / 3:
@@ -715,10 +715,11 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   fp.lean = (c->lean_mode < 0) ? 0 : c->lean_mode;
   fp.front_prio = piped ? c->front_fir_prio : 0;
   fp.fir_matrix = (c->fir_mode == 3) ? (piped ? 0 : 1) : (c->fir_mode == 1);
-  /* stage A3: the direct form unless the caller selected the frequency-domain decimator
-   * (rdsp_chain_set_fir_variant(chain, 2): same taps, ~2x the throughput, but its frames start at each call's
-   * first sample, so the bits depend on how the stream is cut into calls; bench.py selects it) */
-  fp.fir_fd = (c->fir_mode == 2 && c->d_fd_mask) ? 1 : 0;
+  /* stage A3 (rdsp_chain_set_fir_variant).  Default (-1) and 4: in the frequency domain with frames of one granule
+   * (256 outputs per 512-point window): every frame's input is a function of the absolute sample position, so the
+   * bits do not depend on how the stream is cut into calls -- like the direct form (0), at about two thirds of
+   * its cost.  2: 448-sample frames anchored at the call's first sample: the throughput form bench.py selects. */
+  fp.fir_fd = !c->d_fd_mask ? 0 : (c->fir_mode == 2 ? 1 : ((c->fir_mode == -1 || c->fir_mode == 4) ? 2 : 0));
   fp.fd_mask = c->d_fd_mask;
   c->front_name = fp.fir_fd ? "rdsp_front_fd_kernel" : "rdsp_front_kernel";
   fp.mid_q = c->d_mid_q[0];
@@ -1315,19 +1316,20 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   c->tail_prio = tail_prio;
   return RDSP_OK;
 }
-/* stage A3 of the front kernel.  -1 (default) and 0: the direct form (packed FMAs) -- outputs are a function
- * of the absolute sample position only, so a stream gives the same bits however it is cut into calls, like
- * the reference's fixed 128-sample blocks (CONV:231-245).  2: in the frequency domain (decim 4 only, else
- * RDSP_ERR_UNSUPPORTED): same taps, same linear convolution, ~2x the throughput of the whole front kernel,
- * but its frames start at each call's first sample, so a different call split rounds differently (~3e-7;
- * an absolute frame grid cannot help: the outputs at a call's end would come from a frame with zeros for
- * the samples that have not arrived, and from the whole frame under another split -- DESIGN.md 4.1).
- * bench.py selects 2.  EXPERIMENTAL=1 builds: 1 = v_mfma GEMM slices, 3 = the same unless the tail stage
- * runs concurrently. */
+/* stage A3 of the front kernel (decim 4; decim-1 chains have no decimator and always run rdsp_front_kernel).
+ * -1 (default) and 4: in the frequency domain -- polyphase overlap-save: four low-rate transforms, branch
+ * spectra, one inverse -- with frames of one granule (256 outputs; the rest of the 512-point window zeros): every
+ * call boundary is a frame boundary and every frame's input is a function of the absolute sample position, so a
+ * stream gives the same bits however it is cut into calls, like the reference's fixed 128-sample blocks
+ * (CONV:231-245).  0: the direct form (packed FMAs), split-invariant too, ~1.3x slower.  2: the frequency domain
+ * with 448-sample frames anchored at each call's first sample: 5 transforms per 448 outputs instead of per 256,
+ * but a different call split frames and rounds differently (~3e-7): the throughput form, what bench.py selects.
+ * Same taps and the same exact linear convolution in all three; the sums associate differently (~2e-7).
+ * EXPERIMENTAL=1 builds: 1 = v_mfma GEMM slices, 3 = the same unless the tail stage runs concurrently. */
 extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   NEED(c);
-  if (variant < -1 || variant > 3) return RDSP_ERR_INVALID;
-  if (variant == 2 && !c->d_fd_mask) {
+  if (variant < -1 || variant > 4) return RDSP_ERR_INVALID;
+  if ((variant == 2 || variant == 4) && !c->d_fd_mask) {
     rdsp_set_error("the frequency-domain decimator needs decim = 4");
     return RDSP_ERR_UNSUPPORTED;
   }
@@ -1456,8 +1458,9 @@ struct StateHeader {
   int32_t n_groups;      /* followed by n_groups x {has_dev_dphi, dev_dphi}: the NCO increment each group's FIR
                             history was mixed with (a tuning change right before the checkpoint) */
   int32_t has_slip;      /* the last call ran with the I2S slip correction: its carry word travels too */
-  int32_t fir_fd;        /* the last call ran the frequency-domain decimator (informative: both forms keep the
-                            same 256 raw samples, so a stream may be continued in either) */
+  int32_t fir_fd;        /* stage A3 of the saving chain: 0 direct, 1 frequency domain with 448-sample frames, 2 with
+                            granule frames (informative: all keep the same 256 raw samples, so a stream may be
+                            continued in any of them) */
 };
 constexpr uint32_t kStateVersion = 4;
 constexpr uint32_t kStateMagic = 0x50534452u; /* 'R' 'D' 'S' 'P' */
@@ -1509,7 +1512,7 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
   memset(&h, 0, sizeof(h));
   h.magic = kStateMagic; h.version = kStateVersion;
   h.has_slip = c->slip_prev_on ? 1 : 0;
-  h.fir_fd = c->fir_mode == 2 ? 1 : 0;
+  h.fir_fd = c->fir_mode == 2 ? 1 : (c->fir_mode == 0 ? 0 : 2);
   h.n_channels = n_channels; h.fft_l = c->N; h.decim = c->decim;
   h.has_sam = c->d_sam != nullptr; h.has_iir = c->d_iir_state != nullptr;
   h.old_nr_level = c->old_nr_level; h.n_in = c->n_in;

@@ -63,7 +63,8 @@ struct RdspFrontParams {
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
   int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */
   int fir_matrix;          /* 1: decimating FIR as v_mfma GEMM slices (EXPERIMENTAL builds)    */
-  int fir_fd;              /* 1: decimator in the frequency domain (rdsp_front_fd_kernel)      */
+  int fir_fd;              /* decimator in the frequency domain (rdsp_front_fd_kernel): 1 = 448-sample frames anchored at
+                              the call's first sample, 2 = frames of one granule (split-invariant); 0 = direct form */
   const float2 *fd_mask;   /* [4][RDSP_FD_N] spectra of the polyphase branches g_r[k] = h[4k - r],
                               /RDSP_FD_N, digit-reversed thread-major like the filter masks    */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */

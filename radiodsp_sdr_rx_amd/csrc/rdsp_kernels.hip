@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * identity across call splits holds for the direct form only; everything else (pipelining,
  * sub-batches, channel partition) stays bit-identical.  The pre-processor's IQ swap and the noise
  * blanker are compiled in with PRE (the blanker in the one-wave kernels). */
-template <int N, int P, bool LEAN, bool PRE, bool Q4 = false>
+template <int N, int P, bool LEAN, bool PRE, bool Q4 = false, int VC = RDSP_FD_P - 1>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;              /* the overlap-save filter's transform (FFT_L)     */
   constexpr int ND = RDSP_FD_N, PD = RDSP_FD_P; /* the decimator's: 512 points whatever FFT_L is  */
@@ -813,7 +813,14 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   constexpr int NT = PL::NT;
   constexpr int H = N / 2;
   constexpr int PH = P / 2;
-  constexpr int VAL = ND - 64; /* valid outputs per decimator frame */
+  /* VC: quad columns of new input per decimator frame.  7 (448 outputs of the 512-point window: the throughput
+   * form, fir_variant 2) or 4: frames of ONE GRANULE -- 256 outputs, the window's last three columns zeros --
+   * so that every call boundary is a frame boundary and every frame's input is a function of the absolute
+   * sample position: the same bits for any call split (fir_variant 4, the library's default), at 5 transforms
+   * per 256 outputs instead of per 448 */
+  constexpr int VAL = 64 * VC; /* valid outputs per decimator frame */
+  constexpr int NC = VC + 1;   /* data columns of a frame's window: the shared / history column and VC new ones */
+  static_assert(VC == PD - 1 || VC == 4, "448-sample frames or one granule per frame");
   /* FFT_L >= 2048 runs four waves per channel: every wave takes its own decimator frame (four
    * frames per round, no sums across waves), then all of them share the overlap-save frames */
   constexpr int NW = NT / 64;
@@ -823,7 +830,6 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   constexpr int RING = QUAD ? QUAD_RING : ((NW == 1) ? 1024 : 4096); /* >= (H - 1) + NW * VAL, power of two (QUAD: eight padded hops) */
   constexpr bool SAME = (N == ND && P == PD);   /* one plan: twiddles and LDS bases are shared */
   static_assert((NT == 64 || NT == 256) && PLD::NT == 64, "one or four waves per channel, one per decimator frame");
-  static_assert(VAL == 64 * (PD - 1), "the last quad column of a frame is the first of the next");
   static_assert(QUAD || H - 1 + NW * VAL <= RING, "ring holds a round's outputs behind an unfinished hop");
   static_assert(!QUAD || H + (4 * H - 64) + VAL <= QUAD_HOPS * H, "the overlap hop and what is unconsumed (< 4 hops, in steps of 64) survive a frame's seven columns");
 
@@ -874,9 +880,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
     const v4i v = __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, NW == 1 ? 2 : 0);
     return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
   };
-  uint4 rq[PD];
+  uint4 rq[NC];
 #pragma unroll
-  for (int j = 0; j < PD; j++) {
+  for (int j = 0; j < NC; j++) {
     const int q = wave * VAL - 64 + lane + 64 * j;
     if (q < 0) rq[j] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * lane);
     else rq[j] = ld_quad(q);
@@ -956,8 +962,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
        * end of every window from the mean post-blanking power (one wave reduction) */
       auto blank_frame = [&]() {
 #pragma unroll
-        for (int j = 1; j < PD; j++) {
-          const int c = (PD - 1) * fr + (j - 1); /* column of the call */
+        for (int j = 1; j < NC; j++) {
+          const int c = VC * fr + (j - 1); /* column of the call */
           if (64 * c < total) {
             const float thr = nb_level * p.nb_thr;
             uint32_t w[4] = {rq[j].x, rq[j].y, rq[j].z, rq[j].w};
@@ -993,7 +999,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
             nb_acc = nbacc[lane];
             if (fr > 0) rq[0] = nbcol[(w + NW - 1) % NW * 64 + lane]; /* the frame before, as blanked */
             blank_frame();
-            nbcol[w * 64 + lane] = rq[PD - 1];
+            nbcol[w * 64 + lane] = rq[VC];
             nbacc[lane] = nb_acc;
             if (lane == 0) nbs[0] = nb_level;
           }
@@ -1003,7 +1009,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
     }
     /* ---- A2: phasors of this lane's P quad columns (sample 4 q + r of a quad follows by rot_r) */
     const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + lane); /* absolute index of column 0 */
-    float2 pj[PD];
+    float2 pj[NC];
     {
       float2 b1 = make_float2(1.f, 0.f);
       if (G.dphi != 0u) b1 = nco_phasor_alu((nq + 256u) * G.dphi);
@@ -1015,7 +1021,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotq1);
       if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotq2);
 #pragma unroll
-      for (int j = 4; j < PD; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
+      for (int j = 4; j < NC; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
       /* column 0: history of the previous call in frame 0 (mixed with the increment it came in
        * with), else one column before b1 */
       if (fr == 0) {
@@ -1046,7 +1052,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       }
       float2 v[PD];
 #pragma unroll
-      for (int j = 0; j < PD; j++) {
+      for (int j = NC; j < PD; j++) v[j] = make_float2(0.f, 0.f); /* granule frames: the rest of the window is zeros */
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
         uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
         if (j == 0 ? swap0 : SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
         float2 x;
@@ -1061,9 +1069,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
         v[j] = cmul_pinned(x, ph);
       }
       if (r == 3) { /* the raw registers are free: the next frame's loads land behind the transforms */
-        if constexpr (NW == 1) rq[0] = rq[PD - 1]; /* consecutive frames share a column */
+        if constexpr (NW == 1) rq[0] = rq[VC]; /* consecutive frames share a column */
 #pragma unroll
-        for (int j = (NW == 1 ? 1 : 0); j < PD; j++) {
+        for (int j = (NW == 1 ? 1 : 0); j < NC; j++) {
           const int q = (fr + NW) * VAL - 64 + lane + 64 * j; /* >= 0: this is frame 1 or later */
           rq[j] = ld_quad(q);
         }
@@ -1097,9 +1105,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
        * scalar arithmetic per column, one vector add per store (past the end of the call: slots nobody
        * consumes, `produced` stops at total) */
       if constexpr (QUAD) { /* columns of 64 in padded hops */
-        const int w0 = __builtin_amdgcn_readfirstlane((fr * (PD - 1)) % (2 * QUAD_HOPS));
+        const int w0 = __builtin_amdgcn_readfirstlane((fr * VC) % (2 * QUAD_HOPS));
 #pragma unroll
-        for (int j = 1; j < PD; j++) {
+        for (int j = 1; j < NC; j++) {
           int cw = w0 + (j - 1);
           cw = cw >= 2 * QUAD_HOPS ? cw - 2 * QUAD_HOPS : cw;
           ring[cw * 64 + (cw >> 1) * (QUAD_PITCH - 128) + lane] = acc[j];
@@ -1108,7 +1116,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
         const int m0 = __builtin_amdgcn_readfirstlane(fr * VAL);
         static_assert(VAL % 64 == 0 && (QUAD || RING % 64 == 0), "ring columns");
 #pragma unroll
-        for (int j = 1; j < PD; j++) ring[((m0 + 64 * (j - 1)) & (RING - 1)) + lane] = acc[j];
+        for (int j = 1; j < NC; j++) ring[((m0 + 64 * (j - 1)) & (RING - 1)) + lane] = acc[j];
       }
     }
     produced = (round + 1) * NW * VAL < total ? (round + 1) * NW * VAL : total;
@@ -1267,25 +1275,31 @@ int ensure_lds_limit(size_t lds) {
   }
   return 0;
 }
-template <int N, int P, bool LEAN, bool PRE>
-int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+template <int N, int P, bool LEAN, bool PRE, int VC>
+int launch_front_fd_vc(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   if constexpr (N == 256) {
     /* FFT_L 256: four overlap-save frames per pass (front_frame_quad) unless the audio goes on to the tail
      * kernel, which may share the SIMDs (pipelined mode) and leaves no room for that form's registers and LDS */
     if (!p->to_mid) {
       constexpr size_t lds4 = front_fd_lds<N, P, true>();
       static_assert(lds4 <= 48 * 1024, "no raised dynamic-LDS limit needed");
-      hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, true>), dim3(n_channels), dim3(N / P), lds4, stream, *p);
+      hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, true, VC>), dim3(n_channels), dim3(N / P), lds4, stream, *p);
       return (int)hipGetLastError();
     }
   }
   constexpr size_t lds = front_fd_lds<N, P>();
   if constexpr (lds > 48 * 1024) {
-    int e = ensure_lds_limit<&rdsp_front_fd_kernel<N, P, LEAN, PRE>>(lds);
+    int e = ensure_lds_limit<&rdsp_front_fd_kernel<N, P, LEAN, PRE, false, VC>>(lds);
     if (e != 0) return e;
   }
-  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, false, VC>), dim3(n_channels), dim3(N / P), lds, stream, *p);
   return (int)hipGetLastError();
+}
+/* fir_fd 1: 448-sample frames (throughput form, fir_variant 2); 2: one granule per frame (split-invariant, the default) */
+template <int N, int P, bool LEAN, bool PRE>
+int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  return p->fir_fd == 2 ? launch_front_fd_vc<N, P, LEAN, PRE, 4>(p, n_channels, stream)
+                        : launch_front_fd_vc<N, P, LEAN, PRE, RDSP_FD_P - 1>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM, bool LEAN, bool PRE>
 int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {

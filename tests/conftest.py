@@ -28,14 +28,15 @@ def rdsp():
     return R
 
 
-@pytest.fixture(params=["direct", "fd"])
+@pytest.fixture(params=["default", "direct", "fd"])
 def front_form(request):
-    """Stage A3 of the chains a test makes without choosing: the library's default (the direct form, whose
-    bits do not depend on the call split) and the frequency-domain decimator (rdsp_chain_set_fir_variant 2,
-    what bench.py runs).  The GPU test modules use it module-wide, so every chain test covers both front
-    kernels; a test that is about one form sets it explicitly, which wins."""
+    """Stage A3 of the chains a test makes without choosing: the library's default (frequency domain with frames
+    of one granule: the bits do not depend on the call split), the direct form (rdsp_chain_set_fir_variant 0,
+    split-invariant too) and the frequency-domain decimator with 448-sample frames (variant 2, what bench.py
+    runs).  The GPU test modules use it module-wide, so every chain test covers all three; a test that is about
+    one form sets it explicitly, which wins."""
     from radiodsp_sdr_rx_amd.chain import Chain
     old = Chain.default_fir_variant
-    Chain.default_fir_variant = 2 if request.param == "fd" else None
+    Chain.default_fir_variant = {"default": None, "direct": 0, "fd": 2}[request.param]
     yield request.param
     Chain.default_fir_variant = old

@@ -146,7 +146,7 @@ def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, front_form, name
     dev = torch.from_numpy(iq).cuda()
     got = ch.process(dev, want_f32=True)[1].cpu().numpy()
     if cfg.get("decim", 4) == 4:      # the default decimator, whatever FFT_L: no fall-back to the direct form
-        assert ch.front_kernel_name() == ("rdsp_front_fd_kernel" if front_form == "fd" else "rdsp_front_kernel")
+        assert ch.front_kernel_name() == ("rdsp_front_kernel" if front_form == "direct" else "rdsp_front_fd_kernel")
     levels = ch.scalars()[:, 3]
     off = Chain(nch, max_blocks_per_call=nblk, **cfg).process(dev, want_f32=True)[1].cpu().numpy()
     ref_clean = Chain(nch, max_blocks_per_call=nblk, **cfg).process(torch.from_numpy(clean).cuda(), want_f32=True)[1].cpu().numpy()
@@ -224,7 +224,7 @@ def test_noise_blanker_four_wave_kernels_split_and_pipelined(rdsp, oracle, torch
                            want_f32=True)[1] for k in range(calls)]
         ch.flush()
         torch.cuda.synchronize()
-        assert ch.front_kernel_name() == ("rdsp_front_fd_kernel" if front_form == "fd" else "rdsp_front_kernel")
+        assert ch.front_kernel_name() == ("rdsp_front_kernel" if front_form == "direct" else "rdsp_front_fd_kernel")
         return np.concatenate([o.cpu().numpy() for o in outs], 1), ch.scalars()
 
     a, sa = run(False)

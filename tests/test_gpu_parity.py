@@ -423,21 +423,25 @@ def test_chain_with_nlms_is_as_close_to_float64_truth_as_the_oracle(rdsp, oracle
 # ---- streaming state ---------------------------------------------------------------------
 @pytest.mark.parametrize("name,cfg,nblk", [("k2", K1, 64), ("k3", K3, 64), ("k4", K4, 256)])
 def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, cfg, nblk):
-    """State (FIR history, overlap block, NFloor, AGC, NLMS) is carried in HBM across launches, and the
-    default decimator (direct form) computes every output from the absolute sample position: any call split
-    gives the same bits, as the reference's fixed 128-sample blocks do (CONV:231-245).  The opt-in
-    frequency-domain decimator anchors its frames at each call's first sample, so there a different split
-    rounds differently: same result to TOL."""
+    """State (FIR history, overlap block, NFloor, AGC, NLMS) is carried in HBM across launches, and the default
+    decimator (frequency domain, one granule per frame: every frame's input is a function of the absolute
+    sample position) as well as the direct form give the same bits for any call split, as the reference's fixed
+    128-sample blocks do (CONV:231-245).  The throughput form (448-sample frames anchored at each call's first
+    sample) rounds differently under another split: same result to TOL."""
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
     iq = synth_iq(3, nblk * 128, cw=(name == "k4"))
+    calls = 4 if name != "k4" else 2
     saved, Chain.default_fir_variant = Chain.default_fir_variant, None   # the library's default, whatever the module runs under
     try:
-        a16, a32, _ = gpu_run(torch_cuda, iq, cfg, calls=1)
-        calls = 4 if name != "k4" else 2
+        a16, a32, ach = gpu_run(torch_cuda, iq, cfg, calls=1)
         b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
+        assert ach.front_kernel_name() == "rdsp_front_fd_kernel"
     finally:
         Chain.default_fir_variant = saved
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
+    d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, fir=0)
+    e16, e32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, fir=0)
+    assert np.array_equal(d16, e16) and np.array_equal(d32, e32) and normwise(d32, a32) <= TOL
     _, f1, _ = gpu_run(torch_cuda, iq, cfg, calls=1, fir=2)
     _, f4, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, fir=2)
     assert normwise(f4, f1) <= TOL and normwise(f1, a32) <= TOL
@@ -449,14 +453,42 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
             assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
 
+@pytest.mark.parametrize("name,cfg", [("k2", K1), ("k3", K3), ("usb_2048_agc", dict(fft_l=2048, demod="USB", agc_mode="fast"))])
+def test_default_decimator_gives_the_same_bits_for_random_call_splits(rdsp, torch_cuda, name, cfg):
+    """The library's default (frequency domain, one granule per decimator frame) over random call splits, blanker and
+    a tuning offset change included: bit-identical to one call -- the streaming runner and the graph's engine node
+    pick their own batch sizes and must not change a bit of a recording's audio."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    nch, nblk = 4, 128
+    iq = synth_iq(nch, nblk * 128)
+    iq[:, 5000:5003] = 30000
+    rng = np.random.default_rng(17)
+
+    def run(cuts):
+        ch = Chain(nch, max_blocks_per_call=nblk, fir_variant=-1, **cfg)
+        ch.enableNoiseBlanker()
+        o = []
+        for a, b in zip([0] + cuts, cuts + [nblk]):
+            o.append(ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, a * 128:b * 128])).cuda()).cpu().numpy())
+        return np.concatenate(o, 1), ch.scalars()
+
+    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).granule_blocks
+    one, sc = run([])
+    for trial in range(5):
+        cuts = sorted(set(int(x) * gran for x in rng.integers(1, nblk // gran, size=rng.integers(1, 6))))
+        o, s2 = run(cuts)
+        assert np.array_equal(o, one) and np.array_equal(s2, sc), (name, cuts)
+
+
 @pytest.mark.parametrize("name,cfg,bound", [("k2", K1, 1e-6), ("k3", K3, TOL)])
 def test_frequency_domain_decimator_call_split_sensitivity_is_pinned(rdsp, torch_cuda, name, cfg, bound):
-    """The opt-in frequency-domain decimator (rdsp_chain_set_fir_variant 2; bench.py) anchors its frames at each
-    call's first sample: the same stream cut into calls differently is framed differently and rounds
+    """The throughput form of the frequency-domain decimator (rdsp_chain_set_fir_variant 2; bench.py: 448-sample
+    frames) anchors its frames at each call's first sample: the same stream cut into calls differently is framed differently and rounds
     differently.  Pinned here over random call splits: the worst difference from the one-call result stays
     at float32 rounding for the feed-forward chain (measured 2.6e-7 of the output's peak, bound 1e-6; int16
     within 1 LSB) and inside the north-star's 1e-5 (measured 2.8e-6) through K3's recursive stages.  The
-    default (direct form) gives the same BITS for any split:
+    default (one granule per frame) and the direct form give the same BITS for any split:
     test_split_calls_are_bitwise_identical_to_one_call."""
     torch = torch_cuda
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq

@@ -161,10 +161,10 @@ def test_memory_runner_and_callbacks(rdsp, torch_cuda):
     iq = synth_iq(nch, nblk * 128)
     out, st = stream_memory(Chain(nch, max_blocks_per_call=per, **K1), iq, per)
     # the same samples resident in HBM in ONE call: the runner picks its own batches, and the default
-    # decimator's bits do not depend on how a stream is cut into calls (CONV:231-245: fixed blocks)
+    # decimator (one granule per frame) gives the same bits however a stream is cut into calls (CONV:231-245: fixed blocks)
     ref = Chain(nch, max_blocks_per_call=nblk, **K1).process(torch.from_numpy(iq).cuda()).cpu().numpy()
     assert st["blocks"] == nblk and np.array_equal(out, ref)
-    # the frequency-domain decimator (opt-in): the same batches give the same bits, one call differs by rounding
+    # the throughput form (448-sample frames): the same batches give the same bits, one call differs by rounding
     fd = Chain(nch, max_blocks_per_call=per, fir_variant=2, **K1)
     out_fd, _ = stream_memory(fd, iq, per)
     rc = Chain(nch, max_blocks_per_call=per, fir_variant=2, **K1)
