@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """The CPU oracle is (re)built before any test runs, i.e. before anything has initialised the GPU: building
+    it from inside a GPU test would start a child process (make, gcc) from a process that holds a device."""
+    import oracle_lib
+    try:
+        oracle_lib.build()
+    except Exception as e:   # the tests that need it will say so
+        print(f"conftest: oracle build failed: {e}")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
