@@ -798,13 +798,17 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_kernel(RdspFrontParams p)
  * quads of the next and stay in registers; HBM is still read exactly once.  Decimated samples go
  * into a ring in LDS from which the overlap-save frames (front_frame) take N/2 at a time.
  *
- * Frames are anchored at the call's first sample and the last one of a call is partial (inputs
- * past the end of the call are zeros; every output depends on inputs at or before its own time
- * only, so the valid ones are exact).  State is the same 256 raw samples as the direct form.
- * A stream cut into calls differently rounds differently (the frame grid moves): bitwise
- * identity across call splits holds for the direct form only; everything else (pipelining,
- * sub-batches, channel partition) stays bit-identical.  The pre-processor's IQ swap and the noise
- * blanker are compiled in with PRE (the blanker in the one-wave kernels). */
+ * Two frame lengths (template VC, new quad columns per frame; state is the same 256 raw samples as the
+ * direct form in both):
+ *   VC = 7 (fir_variant 2, bench.py): 448 outputs per 512-point window.  Frames are anchored at the call's first
+ *     sample and the last one of a call is partial (inputs past the end of the call are zeros; every output depends
+ *     on inputs at or before its own time only, so the valid ones are exact).  A stream cut into calls differently
+ *     rounds differently (the frame grid moves).
+ *   VC = 4 (the library's default): ONE GRANULE per frame -- 256 outputs, the window's last three columns zeros.
+ *     Every call boundary is a frame boundary and a frame's input is a function of the absolute sample position:
+ *     the same bits for any call split, at 5 transforms per 256 outputs instead of per 448.
+ * Pipelining, sub-batches and the channel partition never change a bit in either.  The pre-processor's IQ swap and
+ * the noise blanker are compiled in with PRE. */
 template <int N, int P, bool LEAN, bool PRE, bool Q4 = false, int VC = RDSP_FD_P - 1>
 __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams p) {
   using PL = FftPlan<N, P>;              /* the overlap-save filter's transform (FFT_L)     */
