@@ -116,3 +116,29 @@ def test_state_argument_errors_are_loud(rdsp):
     ok = Chain(4, max_blocks_per_call=8, **K1)
     ok.setAudioFilterKind(1)
     ok.load_state(i.save_state())
+
+
+def test_a_stream_continues_in_another_decimator_form(rdsp, oracle):
+    """All three forms of stage A3 keep the same state (the last 256 raw samples, the previous hop of the decimated
+    stream), so a stream saved under one may be continued under another -- a recording processed in the throughput
+    form (rdsp_chain_set_fir_variant 2) up to a checkpoint and resumed by a host that wants split-invariant bits, or
+    the other way round.  The two forms round differently, so this is a tolerance statement: every hand-over follows
+    the oracle's uninterrupted stream at 1e-5."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from cases import TOL
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    cfg = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, agc_mode="medium")
+    nch, per = 3, 16
+    iq = synth_iq(nch, per * 4 * 128)
+    parts = _parts(iq, per)
+    ref = np.stack([oracle.OracleChain(**cfg).process(iq[c])[1] for c in range(nch)])
+    for first, second in ((2, -1), (-1, 2), (0, -1), (2, 0)):
+        a = Chain(nch, max_blocks_per_call=per, fir_variant=first, **cfg)
+        got = [a.process(p, want_f32=True)[1].cpu().numpy() for p in parts[:2]]
+        b = Chain(nch, max_blocks_per_call=per, fir_variant=second, **cfg)
+        b.load_state(a.save_state())
+        got += [b.process(p, want_f32=True)[1].cpu().numpy() for p in parts[2:]]
+        got = np.concatenate(got, 1)
+        err = max(np.abs(got[c] - ref[c]).max() / np.abs(ref[c]).max() for c in range(nch))
+        assert err <= TOL, (first, second, err)
