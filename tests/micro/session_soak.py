@@ -13,7 +13,7 @@ m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 from cases import K3
 from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
 import os
-if os.environ.get("RDSP_SOAK_FIR"):   # 2: every chain of the soak runs the frequency-domain decimator (default: the direct form)
+if os.environ.get("RDSP_SOAK_FIR"):   # 0 / 2: every chain of the soak runs the direct form / the 448-sample frames (default: the library's granule frames)
     Chain.default_fir_variant = int(os.environ["RDSP_SOAK_FIR"])
 first, count = int(sys.argv[1]), int(sys.argv[2])
 if len(sys.argv) > 3:          # more channels: longer kernels, the host runs further ahead of the device

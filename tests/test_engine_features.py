@@ -145,7 +145,7 @@ def test_noise_blanker_matches_oracle(rdsp, oracle, torch_cuda, front_form, name
     ch.setNoiseBlankerThresholdDb(8.0)
     dev = torch.from_numpy(iq).cuda()
     got = ch.process(dev, want_f32=True)[1].cpu().numpy()
-    if cfg.get("decim", 4) == 4:      # the default decimator, whatever FFT_L: no fall-back to the direct form
+    if cfg.get("decim", 4) == 4:      # the frequency-domain kernel whatever FFT_L: no fall-back to the direct form
         assert ch.front_kernel_name() == ("rdsp_front_kernel" if front_form == "direct" else "rdsp_front_fd_kernel")
     levels = ch.scalars()[:, 3]
     off = Chain(nch, max_blocks_per_call=nblk, **cfg).process(dev, want_f32=True)[1].cpu().numpy()

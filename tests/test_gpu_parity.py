@@ -70,7 +70,7 @@ def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None, fir=None):
     elif tail:          # "16": rdsp_tail.hip; "16m" / "8m": matrix-pipe reduction
         ch.set_tail_variant(int(tail.rstrip("m")), int(tail.endswith("m")))
     apply_setup(ch, setup)
-    if fir is not None:   # stage A3: 0 direct form, 2 frequency domain (default: the module's `front_form`)
+    if fir is not None:   # stage A3: 0 direct form, 2 frequency domain with 448-sample frames, -1 / 4 granule frames (None: the module's `front_form`)
         ch.set_fir_variant(fir)
     o16, o32 = [], []
     step = n // calls
