@@ -376,6 +376,7 @@ struct orc_chain {
   int iq_slip;            /* +1: the I rail is taken one sample late, -1: the Q rail (I2S channel slip) */
   int16_t slip_i, slip_q; /* the previous raw sample */
   int literal_resynthesis; /* SPEC:221-235 as written: atan2 + table-interpolated arm_cos_f32 / arm_sin_f32 */
+  int literal_filter_off;  /* CONV:303 as written: only FFT_length FLOATS (half the spectrum) are copied */
   int nb_on;
   float nb_thr;   /* threshold as a power ratio, 10^(dB/10) */
   float nb_level; /* reference power: smoothed mean |x|^2 of the past windows */
@@ -472,6 +473,12 @@ void orc_set_spectral_nr(orc_chain_t *c, int on, float level) {
  * the distance between the two forms -- the table's interpolation error, up to (2 pi / 512)^2 / 8 = 1.9e-5 of a
  * bin's magnitude -- can be measured (tests/test_oracle_kat.py).  Test infrastructure only. */
 void orc_set_literal_resynthesis(orc_chain_t *c, int on) { c->literal_resynthesis = on ? 1 : 0; }
+/* CONV:303 as written: with bFilterEnabled == false the sketch copies FFT_length floats, i.e. bins 0 .. FFT_L/2 - 1
+ * of the interleaved spectrum; the upper half of iFFT_buffer keeps what the previous frame's in-place inverse
+ * transform left there (time-domain samples).  The sketch never takes that branch (INO:198 passes `true`); the
+ * restatement (and the product) treat "filter off" as a full bypass.  on = 1 evaluates the line as written, to show
+ * what that choice replaces (tests/test_oracle_kat.py).  Test infrastructure only. */
+void orc_set_literal_filter_off(orc_chain_t *c, int on) { c->literal_filter_off = on ? 1 : 0; }
 static float orc_sin_table[513];
 static int orc_sin_table_ready = 0;
 static float orc_fast_sin_turns(float in) { /* in: the angle in turns (x / 2 pi), any sign */
@@ -751,6 +758,8 @@ static void conv_frame(orc_chain_t *c) {
   }
   if (c->cfg.filter_on) /* CONV:300-301 */
     orc_cmplx_mult_cmplx_f32(F, c->FIR_filter_mask, G, N);
+  else if (c->literal_filter_off) /* CONV:303 as written: FFT_length floats; the rest of iFFT_buffer is stale */
+    memcpy(G, F, N * sizeof(float));
   else /* CONV:303 copies only FFT_length floats (bug, never exercised);
           restated as a full bypass */
     memcpy(G, F, 2 * N * sizeof(float));

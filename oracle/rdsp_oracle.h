@@ -121,6 +121,9 @@ void orc_set_spectral_nr(orc_chain_t *c, int on, float level);
 /* SPEC:221-235 as written (atan2 + table-interpolated arm_cos_f32 / arm_sin_f32) instead of the equivalent
  * X * mag'/mag: bounds how far the two forms are apart (test infrastructure) */
 void orc_set_literal_resynthesis(orc_chain_t *c, int on);
+/* CONV:303 as written (filter off copies half the spectrum, the rest of iFFT_buffer stale) instead of the full
+ * bypass the restatement uses: shows what that choice replaces (test infrastructure) */
+void orc_set_literal_filter_off(orc_chain_t *c, int on);
 float orc_arm_sin_f32(float x);
 float orc_arm_cos_f32(float x);
 /* SAM PLL loop constants at the decimated rate (build-defined, see rdsp_oracle.c) */

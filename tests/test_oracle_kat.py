@@ -365,3 +365,25 @@ def test_literal_resynthesis_bounds_the_equivalent_form(oracle):
         worst[name] = d
     print("literal re-synthesis vs X * mag'/mag, normwise:", {k: f"{v:.2e}" for k, v in worst.items()})
     assert all(2e-6 <= v <= 5e-5 for v in worst.values()), worst
+
+
+def test_literal_filter_off_branch_is_a_bug_not_a_bypass(oracle):
+    """CONV:303: with bFilterEnabled == false the sketch copies FFT_length FLOATS -- bins 0 .. FFT_L/2 - 1 of the
+    interleaved spectrum -- and the inverse transform runs on a buffer whose upper half still holds the previous
+    frame's time-domain output.  The sketch never takes the branch (INO:198 passes `true`); the restatement and the
+    product read "filter off" as a full bypass.  Evaluated as written (orc_set_literal_filter_off) the output is not
+    a bypass of anything: of order one away from the input stream, where the full bypass reproduces it exactly."""
+    from cases import CONV_LITERAL
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    cfg = dict(CONV_LITERAL, filter_on=0, demod="IQ")
+    iq = synth_iq(1, 32 * 128)[0]
+    x = iq.astype(np.float32) / np.float32(32768.0)
+    a = oracle.OracleChain(**cfg)
+    ya = a.process(iq)[1]
+    assert np.abs(ya - x).max() <= 2e-6                       # full bypass: the stream itself, to transform rounding
+    b = oracle.OracleChain(**cfg)
+    b.set_literal_filter_off(True)
+    yb = b.process(iq)[1]
+    d = np.abs(yb - x).max() / np.abs(x).max()
+    print(f"CONV:303 as written: {d:.2f} of the input's peak away from a bypass")
+    assert d > 0.2
