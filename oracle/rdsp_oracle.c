@@ -1043,6 +1043,23 @@ uint32_t orc_sqrt_uint32(uint32_t x) {
   return r;
 }
 
+/* The literal: Teensy Audio's utility/sqrt_integer.h (not in the reference tree, no version pinned) takes a first
+ * guess from a 33-entry table indexed by the count of leading zeros and runs two Newton steps in integer
+ * arithmetic, n = (in / n + n) / 2.  The table is not in the tree either; it is RECONSTRUCTED here as
+ * round(sqrt(2^(31.5 - clz))), the geometric middle of each octave -- an assumption, flagged as such.  After two
+ * steps the result depends on the guess only in its last digits (a guess within a factor 2^(1/4) of the root leaves
+ * (e^2/2)^2/2 <= 2e-4 relative), so the function bounds how far the exact floor square root used by the build sits
+ * from the reference's approximation (tests/test_oracle_kat.py).  Test infrastructure only. */
+uint32_t orc_sqrt_uint32_approx(uint32_t in) {
+  if (in == 0) return 0;
+  const int clz = __builtin_clz(in);
+  uint32_t n = (uint32_t)(sqrt(ldexp(1.0, 31 - clz) * 1.4142135623730951) + 0.5);
+  if (n == 0) n = 1;
+  n = ((in / n) + n) / 2;
+  n = ((in / n) + n) / 2;
+  return n;
+}
+
 struct orc_fft256iq {
   int16_t window[256];
   int has_window;

@@ -180,6 +180,9 @@ typedef struct orc_fft256iq orc_fft256iq_t;
 void orc_window_q15(int window_id, int16_t *w256);           /* 0 none, 1 Hann, 2 Blackman-Harris */
 void orc_cfft_radix4_q15_256(int16_t *buf /* 512: re,im */); /* scaled by 1/256, natural order */
 uint32_t orc_sqrt_uint32(uint32_t x);
+/* sqrt_uint32_approx (FFTIQ.cpp:105) restated from Teensy Audio's published routine with a RECONSTRUCTED guess table
+ * (two integer Newton steps): bounds the distance of the build's exact floor square root (orc_sqrt_uint32) */
+uint32_t orc_sqrt_uint32_approx(uint32_t in);
 orc_fft256iq_t *orc_fft256iq_create(int naverage, int window_id);
 void orc_fft256iq_destroy(orc_fft256iq_t *s);
 void orc_fft256iq_averageTogether(orc_fft256iq_t *s, int n);       /* FFTIQ.h:88-91 */
