@@ -11,6 +11,11 @@ every channel of the rank, already resident in HBM.  Rank 0 prints ONE JSON
 line.  Default workload = BASELINE.json configs[2] (K3, "full SSB+NR chain":
 4096 channels, USB + 512-pt spectral NR + LMS auto-notch + AGC), the
 configuration the metric is quoted on; --config K2|K4|K5 selects the others.
+The default run (no --config) times the K3 headline leg and then, each the same
+way, K2, the K5 per-GPU shape and K4 (`configs` in the line; N > 1: K5 only).
+Stage A3 runs in the throughput form (rdsp_chain_set_fir_variant 2, named in
+`config.decimator`); every leg is preceded by un-timed settle steps
+(`setup_steps`) so that the timed steps are a stream in flight.
 """
 import argparse
 import json
