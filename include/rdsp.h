@@ -429,17 +429,50 @@ int rdsp_chain_decim(const rdsp_chain_t *c);
 int rdsp_chain_device(const rdsp_chain_t *c);   /* the device index given to rdsp_chain_create */
 
 /* ---- F1: IQ panadapter spectrum analyser (AudioAnalyzeFFT256IQ, FFTIQ.h:52-110) ----
- * Integer q15 path batched over channels; bit-exact against the oracle.  window_id:
- * 0 none, 1 Hann, 2 Blackman-Harris (build-defined q15 tables: Teensy windows.c is not
- * in the tree).  read(bin) of the reference is output[bin] * (1.0 / 16384.0). */
+ * Integer q15 path batched over channels; bit-exact against the oracle.
+ *
+ * Tables.  Teensy Audio's windows.c / sqrt_integer.c and CMSIS-DSP are not in the reference tree, but
+ * the tables the sketch links are in its shipped firmware image (pre_compiled/RadioDSP_SDR_RX.ino.hex)
+ * and the generators below reproduce them entry for entry: AudioWindowHanning256 (INO:144),
+ * AudioWindowHanning1024 (INO:147), AudioWindowBlackmanNuttall256 (the constructor's default,
+ * FFTIQ.h:56) = min(32767, round(32768 w(i / (N - 1)))); twiddleCoef_4096_q15; the 33-entry guess
+ * table of sqrt_uint32_approx (tests/test_firmware_tables.py, tests/golden/firmware_tables.npz).
+ * The other window ids follow the same rule from the textbook definitions of the names in
+ * FFTIQ.h:30-50; the image does not hold them (not pinned).  A caller with its own table uses the
+ * reference's signature, rdsp_spectrum_windowFunction_table. */
+enum {
+  RDSP_WINDOW_NONE = 0,             /* windowFunction(NULL): FFTIQ.cpp:81 skips the multiply */
+  RDSP_WINDOW_HANNING = 1,          /* AudioWindowHanning256 / 1024 */
+  RDSP_WINDOW_BLACKMAN_HARRIS = 2,
+  RDSP_WINDOW_BLACKMAN_NUTTALL = 3, /* AudioWindowBlackmanNuttall256 */
+  RDSP_WINDOW_BARTLETT = 4,
+  RDSP_WINDOW_BLACKMAN = 5,
+  RDSP_WINDOW_FLATTOP = 6,
+  RDSP_WINDOW_NUTTALL = 7,
+  RDSP_WINDOW_WELCH = 8,
+  RDSP_WINDOW_HAMMING = 9,
+  RDSP_WINDOW_COSINE = 10,
+  RDSP_WINDOW_TUKEY = 11
+};
 typedef struct rdsp_spectrum rdsp_spectrum_t;
 void rdsp_window_q15(int window_id, int16_t *w256);
+void rdsp_window_q15_n(int window_id, int n, int16_t *w);
+uint32_t rdsp_sqrt_uint32_approx(uint32_t in); /* FFTIQ.cpp:105 (Teensy utility/sqrt_integer.h), host twin of the device routine */
 int rdsp_spectrum_create(int n_channels, int device, int naverage, int window_id, rdsp_spectrum_t **out);
+int rdsp_spectrum_create_default(int n_channels, int device, rdsp_spectrum_t **out); /* FFTIQ.h:55-58: BlackmanNuttall256, naverage 8 */
 void rdsp_spectrum_destroy(rdsp_spectrum_t *s);
 int rdsp_spectrum_device(const rdsp_spectrum_t *s);
 int rdsp_spectrum_averageTogether(rdsp_spectrum_t *s, int n);      /* FFTIQ.h:88 */
-int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id); /* FFTIQ.h:93 */
+int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id); /* FFTIQ.h:93 by table name */
+/* void windowFunction(const int16_t *w), FFTIQ.h:93-95, as the reference declares it: a host pointer
+ * to 256 q15 taps (copied), NULL = no window */
+int rdsp_spectrum_windowFunction_table(rdsp_spectrum_t *s, const int16_t *w256);
 int rdsp_spectrum_outputs_for(const rdsp_spectrum_t *s, int n_blocks);
+/* float read(unsigned int binNumber), FFTIQ.h:70-73, on one output row (uint16 [256]) */
+float rdsp_spectrum_read(const uint16_t *output256, unsigned int binNumber);
+/* float read(unsigned int binFirst, unsigned int binLast), FFTIQ.h:75-86, loop as written (`do ... while
+ * (binFirst < binLast)`: bins binFirst .. binLast - 1; the single bin when the two are equal) */
+float rdsp_spectrum_read_range(const uint16_t *output256, unsigned int binFirst, unsigned int binLast);
 /* n_blocks update() ticks (FFTIQ.cpp:65); d_out uint16 [n_channels][out_stride][256] */
 int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, size_t in_stride, int n_blocks,
                          uint16_t *d_out, size_t out_stride, int *n_outputs, void *stream);
@@ -449,6 +482,8 @@ int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, size_t in_stri
 rdsp_node_t *rdsp_spectrum_node_create(rdsp_graph_t *g, rdsp_spectrum_t *spec);
 int rdsp_spectrum_node_available(rdsp_node_t *n);            /* FFTIQ.h:62-68 */
 const uint16_t *rdsp_spectrum_node_output(rdsp_node_t *n);   /* FFTIQ.h:99, [n_channels][256] */
+float rdsp_spectrum_node_read(rdsp_node_t *n, int ch, unsigned int binNumber);                          /* FFTIQ.h:70 */
+float rdsp_spectrum_node_read_range(rdsp_node_t *n, int ch, unsigned int binFirst, unsigned int binLast); /* FFTIQ.h:75 */
 int rdsp_spectrum_node_status(rdsp_node_t *n);
 
 /* ---- F3: biquad cascades (AudioFilterBiquad, INO:58-59,75-78,155-156; the engine's IIR audio
@@ -485,15 +520,16 @@ int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out20);
 
 /* ---- AudioAnalyzeFFT1024 (Teensy Audio library; `AudioAnalyzeFFT1024 AudioFFT` on Q_out_L,
  * INO:57,87): 1024-point frames of the audio stream with hop 512 (blocks collected eight at a time,
- * four kept), q15 window, fixed-point radix-4 FFT of the real samples, output[i] = |X_i| for the
- * 512 bins from DC up (integer, bit-exact against the test restatement; the library itself is not
- * in the tree, so the rounding of the FFT and of the square root are build-defined as for F1).
- * window_id: 0 none, 1 Hann, 2 Blackman-Harris. */
+ * four kept), q15 window, arm_cfft_radix4_q15 of the real samples, output[i] = sqrt_uint32_approx(|X_i|^2)
+ * for the 512 bins from DC up (integer, bit-exact against the test restatement; FFT, window, twiddles
+ * and square root as for F1).  window_id: RDSP_WINDOW_*. */
 typedef struct rdsp_fft1024 rdsp_fft1024_t;
-void rdsp_window_q15_n(int window_id, int n, int16_t *w);
 int rdsp_fft1024_create(int n_channels, int device, int window_id, rdsp_fft1024_t **out);
 void rdsp_fft1024_destroy(rdsp_fft1024_t *s);
-int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id); /* INO:147 */
+int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id); /* INO:147 by table name */
+int rdsp_fft1024_windowFunction_table(rdsp_fft1024_t *s, const int16_t *w1024); /* windowFunction(const int16_t *), NULL = none */
+float rdsp_fft1024_read(const uint16_t *output512, unsigned int binNumber);   /* AudioAnalyzeFFT1024::read(bin) */
+float rdsp_fft1024_read_range(const uint16_t *output512, unsigned int binFirst, unsigned int binLast); /* ::read(first, last), inclusive */
 int rdsp_fft1024_averageTogether(rdsp_fft1024_t *s, int n);       /* INO:148: a no-op in the library too */
 int rdsp_fft1024_outputs_for(const rdsp_fft1024_t *s, int n_blocks);
 /* n_blocks update() ticks; d_audio int16 [n_channels][in_stride] samples taken every in_step int16
@@ -504,6 +540,8 @@ int rdsp_fft1024_update(rdsp_fft1024_t *s, const int16_t *d_audio, size_t in_str
 rdsp_node_t *rdsp_fft1024_node_create(rdsp_graph_t *g, rdsp_fft1024_t *s); /* 1 input, no outputs */
 int rdsp_fft1024_node_available(rdsp_node_t *n);
 const uint16_t *rdsp_fft1024_node_output(rdsp_node_t *n); /* [n_channels][512] */
+float rdsp_fft1024_node_read(rdsp_node_t *n, int ch, unsigned int binNumber);
+float rdsp_fft1024_node_read_range(rdsp_node_t *n, int ch, unsigned int binFirst, unsigned int binLast);
 int rdsp_fft1024_node_status(rdsp_node_t *n);
 
 /* ---- deterministic synthetic IQ generator (host) -------------------*/

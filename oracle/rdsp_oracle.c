@@ -980,62 +980,166 @@ int orc_multi_process(const orc_config_t *cfg, int n_ch, const int16_t *iq,
 /* F1: IQ panadapter spectrum, analyze_fft256iq.cpp (FFTIQ)                   */
 /* ======================================================================== */
 
-/* q15 window tables (Teensy windows.c is not in the tree): build-defined as
- * w[i] = lround(32767 * window(i / 256)) */
-void orc_window_q15(int window_id, int16_t *w) {
-  for (int i = 0; i < 256; i++) {
-    double t = ORC_TWO_PI * (double)i / 256.0, v;
-    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
-    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
-    else v = 1.0;
-    long q = lround(32767.0 * v);
-    w[i] = (int16_t)(q > 32767 ? 32767 : q);
+/* q15 window tables.  Teensy Audio's windows.c is not in the tree; the tables the sketch links
+ * (AudioWindowHanning256 INO:144, AudioWindowHanning1024 INO:147, AudioWindowBlackmanNuttall256
+ * FFTIQ.h:56) are in the reference's shipped firmware image and equal, entry for entry,
+ *     w[i] = min(32767, round(32768 * window(i / (N - 1))))
+ * (tests/golden/firmware_tables.npz, tests/test_firmware_tables.py).  The remaining windows of
+ * FFTIQ.h:30-50 follow the same rule from their textbook definitions (not in the image: unpinned).
+ * ids: 0 none, 1 Hanning, 2 BlackmanHarris, 3 BlackmanNuttall, 4 Bartlett, 5 Blackman, 6 Flattop,
+ * 7 Nuttall, 8 Welch, 9 Hamming, 10 Cosine, 11 Tukey (alpha 0.5) */
+static double orc_window_shape(int id, double x) {
+  const double t = ORC_TWO_PI * x;
+  switch (id) {
+    case 1: return 0.5 - 0.5 * cos(t);
+    case 2: return 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
+    case 3: return 0.3635819 - 0.4891775 * cos(t) + 0.1365995 * cos(2 * t) - 0.0106411 * cos(3 * t);
+    case 4: return x <= 0.5 ? 2.0 * x : 2.0 - 2.0 * x;
+    case 5: return 0.42 - 0.5 * cos(t) + 0.08 * cos(2 * t);
+    case 6: return 0.21557895 - 0.41663158 * cos(t) + 0.277263158 * cos(2 * t) - 0.083578947 * cos(3 * t) + 0.006947368 * cos(4 * t);
+    case 7: return 0.355768 - 0.487396 * cos(t) + 0.144232 * cos(2 * t) - 0.012604 * cos(3 * t);
+    case 8: { const double u = 2.0 * x - 1.0; return 1.0 - u * u; }
+    case 9: return 0.54 - 0.46 * cos(t);
+    case 10: return sin(0.5 * t);
+    case 11: return x < 0.25 ? 0.5 - 0.5 * cos(2 * t) : (x > 0.75 ? 0.5 - 0.5 * cos(2 * ORC_TWO_PI * (1.0 - x)) : 1.0);
+    default: return 1.0;
   }
 }
+void orc_window_q15_n(int window_id, int n, int16_t *w) {
+  for (int i = 0; i < n; i++) {
+    long q = lround(32768.0 * orc_window_shape(window_id, (double)i / (double)(n - 1)));
+    w[i] = (int16_t)(q > 32767 ? 32767 : (q < -32768 ? -32768 : q));
+  }
+}
+void orc_window_q15(int window_id, int16_t *w) { orc_window_q15_n(window_id, 256, w); }
 
-static inline int32_t sat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+/* ---- arm_cfft_radix4_q15 (FFTIQ.cpp:82; init FFTIQ.h:58: 256 points, forward, bit reversal on) ----
+ * CMSIS-DSP is not in the tree.  This is the library's published routine restated: arm_radix4_butterfly_q15 in its
+ * DSP-extension form (what a Cortex-M7 build runs: two int16 per 32-bit word, __SHADD16 / __QADD16 / __SMUAD ...
+ * written out below on the halves), followed by arm_bitreversal_q15.  What the firmware image pins of it is the
+ * twiddle table (twiddleCoef_4096_q15: 3072 (cos, sin) pairs, floor(32768 x) clamped to int16 -- generated here by
+ * that rule, compared with the image's table in tests/test_firmware_tables.py) and armBitRevTable; the instruction
+ * sequence itself is from the published source and carries no reference-held pin.
+ * Scaling as published: the first stage takes its inputs >> 2 and halves once more, every middle stage divides by
+ * four, the last by two: 1/N in total (1.15 in, 9.7 out for 256 points, 11.5 for 1024). */
+typedef struct { int32_t lo, hi; } orc_pk; /* one packed word: lo = real (even index), hi = imaginary */
+static inline int32_t orc_ssat16(int32_t v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+static inline orc_pk pk_qadd16(orc_pk a, orc_pk b) { return (orc_pk){orc_ssat16(a.lo + b.lo), orc_ssat16(a.hi + b.hi)}; }
+static inline orc_pk pk_qsub16(orc_pk a, orc_pk b) { return (orc_pk){orc_ssat16(a.lo - b.lo), orc_ssat16(a.hi - b.hi)}; }
+static inline orc_pk pk_shadd16(orc_pk a, orc_pk b) { return (orc_pk){(a.lo + b.lo) >> 1, (a.hi + b.hi) >> 1}; }
+static inline orc_pk pk_shsub16(orc_pk a, orc_pk b) { return (orc_pk){(a.lo - b.lo) >> 1, (a.hi - b.hi) >> 1}; }
+/* exchange forms: the top half of the result pairs a.hi with b.lo, the bottom half a.lo with b.hi */
+static inline orc_pk pk_qasx(orc_pk a, orc_pk b) { return (orc_pk){orc_ssat16(a.lo - b.hi), orc_ssat16(a.hi + b.lo)}; }
+static inline orc_pk pk_qsax(orc_pk a, orc_pk b) { return (orc_pk){orc_ssat16(a.lo + b.hi), orc_ssat16(a.hi - b.lo)}; }
+static inline orc_pk pk_shasx(orc_pk a, orc_pk b) { return (orc_pk){(a.lo - b.hi) >> 1, (a.hi + b.lo) >> 1}; }
+static inline orc_pk pk_shsax(orc_pk a, orc_pk b) { return (orc_pk){(a.lo + b.hi) >> 1, (a.hi - b.lo) >> 1}; }
+/* out1 = __SMUAD(C, R) >> 16; out2 = __SMUSDX(C, R); word = (out2 & 0xFFFF0000) | (out1 & 0xFFFF), C = (cos, sin):
+ * R times exp(-j theta), both components >> 16 (32-bit wrap-around arithmetic like the instructions) */
+static inline orc_pk pk_twiddle(orc_pk c, orc_pk r) {
+  const int32_t out1 = (int32_t)((uint32_t)(c.lo * r.lo) + (uint32_t)(c.hi * r.hi));
+  const int32_t out2 = (int32_t)((uint32_t)(c.lo * r.hi) - (uint32_t)(c.hi * r.lo));
+  return (orc_pk){(int16_t)(out1 >> 16), (int16_t)(out2 >> 16)};
+}
+static inline orc_pk pk_load(const int16_t *p) { return (orc_pk){p[0], p[1]}; }
+static inline void pk_store(int16_t *p, orc_pk v) { p[0] = (int16_t)v.lo; p[1] = (int16_t)v.hi; }
+/* twiddleCoef_4096_q15[2k], [2k+1] */
+static inline orc_pk orc_twiddle_4096(uint32_t k) {
+  const double a = ORC_TWO_PI * (double)k / 4096.0;
+  double c = floor(32768.0 * cos(a)), s = floor(32768.0 * sin(a));
+  return (orc_pk){(int32_t)(c > 32767.0 ? 32767.0 : c), (int32_t)(s > 32767.0 ? 32767.0 : s)};
+}
+void orc_twiddle_q15_4096(int16_t *table6144) {
+  for (uint32_t k = 0; k < 3072; k++) pk_store(table6144 + 2 * k, orc_twiddle_4096(k));
+}
 
-/* arm_cfft_radix4_q15 role (FFTIQ.cpp:82, init 256/forward/bit-reverse FFTIQ.h:58):
- * build-defined fixed-point radix-4 decimation-in-frequency, four stages, every
- * butterfly output >> 2 (total 1/256), twiddles lround(32767*cos/sin), products
- * >> 15 with saturation to int16, result in natural bin order. */
-void orc_cfft_radix4_q15_256(int16_t *buf) {
-  int32_t re[256], im[256];
-  for (int i = 0; i < 256; i++) { re[i] = buf[2 * i]; im[i] = buf[2 * i + 1]; }
-  for (int L = 64; L >= 1; L >>= 2) { /* span between the four butterfly inputs */
-    for (int g = 0; g < 256; g += 4 * L) {
-      for (int j = 0; j < L; j++) {
-        int i0 = g + j, i1 = i0 + L, i2 = i0 + 2 * L, i3 = i0 + 3 * L;
-        int32_t s0r = re[i0] + re[i2], s0i = im[i0] + im[i2];
-        int32_t s1r = re[i0] - re[i2], s1i = im[i0] - im[i2];
-        int32_t s2r = re[i1] + re[i3], s2i = im[i1] + im[i3];
-        int32_t s3r = re[i1] - re[i3], s3i = im[i1] - im[i3];
-        int32_t yr[4], yi[4];
-        yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
-        yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2; /* s1 - j*s3 */
-        yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
-        yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2; /* s1 + j*s3 */
-        for (int k = 0; k < 4; k++) {
-          int m = (k * j * (64 / L)) & 255; /* W_256^m, W = exp(-2*pi*i/256) */
-          int32_t wr = (int32_t)lround(32767.0 * cos(ORC_TWO_PI * m / 256.0));
-          int32_t wi = (int32_t)lround(-32767.0 * sin(ORC_TWO_PI * m / 256.0));
-          int32_t pr = (yr[k] * wr - yi[k] * wi) >> 15;
-          int32_t pi = (yr[k] * wi + yi[k] * wr) >> 15;
-          re[g + j + k * L] = sat16(pr);
-          im[g + j + k * L] = sat16(pi);
-        }
+static void orc_radix4_butterfly_q15(int16_t *src, uint32_t fftLen, uint32_t twidCoefModifier) {
+  const orc_pk zero = {0, 0};
+  uint32_t n1, n2 = fftLen >> 2, ic = 0;
+  /* first stage: every input >> 2 (two __SHADD16 with zero) */
+  for (uint32_t j = 0; j < n2; j++) {
+    int16_t *p0 = src + 2 * j, *p1 = p0 + 2 * n2, *p2 = p1 + 2 * n2, *p3 = p2 + 2 * n2;
+    orc_pk T = pk_shadd16(pk_shadd16(pk_load(p0), zero), zero);
+    orc_pk S = pk_shadd16(pk_shadd16(pk_load(p2), zero), zero);
+    orc_pk R = pk_qadd16(T, S);
+    S = pk_qsub16(T, S);
+    T = pk_shadd16(pk_shadd16(pk_load(p1), zero), zero);
+    orc_pk U = pk_shadd16(pk_shadd16(pk_load(p3), zero), zero);
+    orc_pk V = pk_qadd16(T, U);
+    pk_store(p0, pk_shadd16(R, V));
+    R = pk_qsub16(R, V);
+    pk_store(p1, pk_twiddle(orc_twiddle_4096(2 * ic), R)); /* co2, si2: the k = 2 output goes to the second quarter */
+    T = pk_qsub16(T, U);
+    R = pk_qasx(S, T);
+    S = pk_qsax(S, T);
+    pk_store(p2, pk_twiddle(orc_twiddle_4096(ic), S));     /* co1, si1 */
+    pk_store(p3, pk_twiddle(orc_twiddle_4096(3 * ic), R)); /* co3, si3 */
+    ic += twidCoefModifier;
+  }
+  twidCoefModifier <<= 2;
+  /* middle stages */
+  for (uint32_t k = fftLen / 4; k > 4; k >>= 2) {
+    n1 = n2;
+    n2 >>= 2;
+    ic = 0;
+    for (uint32_t j = 0; j <= n2 - 1; j++) {
+      const orc_pk C1 = orc_twiddle_4096(ic), C2 = orc_twiddle_4096(2 * ic), C3 = orc_twiddle_4096(3 * ic);
+      ic += twidCoefModifier;
+      for (uint32_t i0 = j; i0 < fftLen; i0 += n1) {
+        int16_t *p0 = src + 2 * i0, *p1 = p0 + 2 * n2, *p2 = p1 + 2 * n2, *p3 = p2 + 2 * n2;
+        orc_pk T = pk_load(p0), S = pk_load(p2);
+        orc_pk R = pk_qadd16(T, S);
+        S = pk_qsub16(T, S);
+        T = pk_load(p1);
+        orc_pk U = pk_load(p3);
+        orc_pk V = pk_qadd16(T, U);
+        pk_store(p0, pk_shadd16(pk_shadd16(R, V), zero));
+        R = pk_shsub16(R, V);
+        pk_store(p1, pk_twiddle(C2, R));
+        T = pk_qsub16(T, U);
+        R = pk_shasx(S, T);
+        S = pk_shsax(S, T);
+        pk_store(p2, pk_twiddle(C1, S));
+        pk_store(p3, pk_twiddle(C3, R));
       }
     }
+    twidCoefModifier <<= 2;
   }
-  /* position p holds bin digit-reverse_4(p) */
-  for (int p = 0; p < 256; p++) {
-    int k = ((p & 3) << 6) | (((p >> 2) & 3) << 4) | (((p >> 4) & 3) << 2) | ((p >> 6) & 3);
-    buf[2 * k] = (int16_t)re[p];
-    buf[2 * k + 1] = (int16_t)im[p];
+  /* last stage: no twiddles */
+  for (uint32_t j = 0; j < (fftLen >> 2); j++) {
+    int16_t *p = src + 8 * j;
+    const orc_pk xa = pk_load(p), xb = pk_load(p + 2), xc = pk_load(p + 4), xd = pk_load(p + 6);
+    const orc_pk R = pk_qadd16(xa, xc), T = pk_qadd16(xb, xd);
+    pk_store(p, pk_shadd16(R, T));
+    pk_store(p + 2, pk_shsub16(R, T));
+    const orc_pk S = pk_qsub16(xa, xc), U = pk_qsub16(xb, xd);
+    pk_store(p + 4, pk_shsax(S, U));
+    pk_store(p + 6, pk_shasx(S, U));
   }
 }
+/* arm_bitreversal_q15 walks armBitRevTable and swaps pairs; its net effect -- element i <-> element bit-reverse(i)
+ * over log2(n) bits -- is written directly (the table-driven walk is replayed with the image's own table in
+ * tests/test_firmware_tables.py) */
+static void orc_bitreversal_q15(int16_t *src, uint32_t n) {
+  uint32_t bits = 0;
+  while ((1u << bits) < n) bits++;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < bits; b++) r |= ((i >> b) & 1u) << (bits - 1 - b);
+    if (r > i) {
+      int16_t t0 = src[2 * i], t1 = src[2 * i + 1];
+      src[2 * i] = src[2 * r]; src[2 * i + 1] = src[2 * r + 1];
+      src[2 * r] = t0; src[2 * r + 1] = t1;
+    }
+  }
+}
+/* n = 256 or 1024 (twidCoefModifier 4096 / n as arm_cfft_radix4_init_q15 sets it), interleaved re/im int16 */
+void orc_cfft_radix4_q15_n(int16_t *buf, int n) {
+  orc_radix4_butterfly_q15(buf, (uint32_t)n, 4096u / (uint32_t)n);
+  orc_bitreversal_q15(buf, (uint32_t)n);
+}
+void orc_cfft_radix4_q15_256(int16_t *buf) { orc_cfft_radix4_q15_n(buf, 256); }
 
-/* sqrt_uint32_approx role (FFTIQ.cpp:105): build-defined as the exact floor(sqrt(x)) */
+/* exact floor(sqrt(x)): not what the reference runs, kept to state how far its approximation sits from it */
 uint32_t orc_sqrt_uint32(uint32_t x) {
   uint32_t r = (uint32_t)sqrt((double)x);
   while ((uint64_t)r * r > x) r--;
@@ -1043,20 +1147,19 @@ uint32_t orc_sqrt_uint32(uint32_t x) {
   return r;
 }
 
-/* The literal: Teensy Audio's utility/sqrt_integer.h (not in the reference tree, no version pinned) takes a first
- * guess from a 33-entry table indexed by the count of leading zeros and runs two Newton steps in integer
- * arithmetic, n = (in / n + n) / 2.  The table is not in the tree either; it is RECONSTRUCTED here as
- * round(sqrt(2^(31.5 - clz))), the geometric middle of each octave -- an assumption, flagged as such.  After two
- * steps the result depends on the guess only in its last digits (a guess within a factor 2^(1/4) of the root leaves
- * (e^2/2)^2/2 <= 2e-4 relative), so the function bounds how far the exact floor square root used by the build sits
- * from the reference's approximation (tests/test_oracle_kat.py).  Test infrastructure only. */
+/* sqrt_uint32_approx (FFTIQ.cpp:105), Teensy Audio's utility/sqrt_integer.h as published: a first guess from a
+ * 33-entry table indexed by the count of leading zeros, then two Newton steps in integer arithmetic.  The table is
+ * the one in the reference's firmware image (offset 0x1f558; tests/golden/firmware_tables.npz).  in = 0 reads the
+ * guess 0 and divides by it; UDIV by zero yields 0 on the Cortex-M7 (DIV_0_TRP clear), so the result is 0. */
+static const uint16_t orc_sqrt_guess[33] = {55109, 38968, 27555, 19484, 13778, 9742, 6889, 4871, 3445, 2436, 1723,
+                                            1218,  862,   609,   431,   305,   216,  153,  108,  77,   54,   39,
+                                            27,    20,    14,    10,    7,     5,    4,    3,    2,    1,    0};
+const uint16_t *orc_sqrt_guess_table(void) { return orc_sqrt_guess; }
+static inline uint32_t orc_udiv(uint32_t a, uint32_t b) { return b ? a / b : 0; }
 uint32_t orc_sqrt_uint32_approx(uint32_t in) {
-  if (in == 0) return 0;
-  const int clz = __builtin_clz(in);
-  uint32_t n = (uint32_t)(sqrt(ldexp(1.0, 31 - clz) * 1.4142135623730951) + 0.5);
-  if (n == 0) n = 1;
-  n = ((in / n) + n) / 2;
-  n = ((in / n) + n) / 2;
+  uint32_t n = orc_sqrt_guess[in ? __builtin_clz(in) : 32];
+  n = (orc_udiv(in, n) + n) / 2;
+  n = (orc_udiv(in, n) + n) / 2;
   return n;
 }
 
@@ -1085,6 +1188,31 @@ void orc_fft256iq_averageTogether(orc_fft256iq_t *s, int n) { s->naverage = (uin
 void orc_fft256iq_windowFunction(orc_fft256iq_t *s, int window_id) {
   s->has_window = window_id != 0;
   orc_window_q15(window_id, s->window);
+}
+/* the reference's own signature: any table, NULL = no window (`if (window)`, FFTIQ.cpp:81) */
+void orc_fft256iq_windowFunction_table(orc_fft256iq_t *s, const int16_t *w) {
+  s->has_window = w != NULL;
+  if (w) memcpy(s->window, w, sizeof(s->window));
+}
+/* float read(unsigned int binNumber), FFTIQ.h:70-73 */
+float orc_fft256iq_read(const orc_fft256iq_t *s, unsigned int binNumber) {
+  if (binNumber > 255) return 0.0;
+  return (float)(s->output[binNumber]) * (1.0 / 16384.0);
+}
+/* float read(unsigned int binFirst, unsigned int binLast), FFTIQ.h:75-86, as written */
+float orc_fft256iq_read_range(const orc_fft256iq_t *s, unsigned int binFirst, unsigned int binLast) {
+  if (binFirst > binLast) {
+    unsigned int tmp = binLast;
+    binLast = binFirst;
+    binFirst = tmp;
+  }
+  if (binFirst > 255) return 0.0;
+  if (binLast > 255) binLast = 255;
+  uint32_t sum = 0;
+  do {
+    sum += s->output[binFirst++];
+  } while (binFirst < binLast);
+  return (float)sum * (1.0 / 16384.0);
 }
 const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s) { return s->output; }
 
@@ -1118,7 +1246,7 @@ int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *bi, const int16_t *bq)
   int fresh = 0;
   if (++s->count == s->naverage) { /* FFTIQ.cpp:99-113 */
     s->count = 0;
-    for (int i = 0; i < 256; i++) s->output[255 - (i ^ 128)] = (uint16_t)orc_sqrt_uint32(s->sum[i]);
+    for (int i = 0; i < 256; i++) s->output[255 - (i ^ 128)] = (uint16_t)orc_sqrt_uint32_approx(s->sum[i]);
     fresh = 1;
   }
   memcpy(s->prev_i, bi, sizeof(s->prev_i)); /* FFTIQ.cpp:114-117 */
@@ -1131,59 +1259,9 @@ int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *bi, const int16_t *bq)
 /* INO:57,87, read by the display).  Not in the tree: restated from the library's published      */
 /* update(): blocks are collected eight at a time with four kept (1024-sample frames, hop 512),  */
 /* real samples with zero imaginary parts, q15 window (x*w)>>15, arm_cfft_radix4_q15 (here the   */
-/* same build-defined fixed-point radix-4 as F1, five stages), output[i] = sqrt(re^2 + im^2)     */
-/* for the 512 bins at and above DC; no averaging.                                               */
+/* same arm_cfft_radix4_q15 restatement as F1, five stages), output[i] = sqrt_uint32_approx(re^2 */
+/* + im^2) for the 512 bins at and above DC; no averaging.                                       */
 /* ======================================================================== */
-void orc_window_q15_n(int window_id, int n, int16_t *w) {
-  for (int i = 0; i < n; i++) {
-    double t = ORC_TWO_PI * (double)i / (double)n, v;
-    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
-    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
-    else v = 1.0;
-    long q = lround(32767.0 * v);
-    w[i] = (int16_t)(q > 32767 ? 32767 : q);
-  }
-}
-/* n = 4^stages points, interleaved re/im int16, natural order in and out */
-void orc_cfft_radix4_q15_n(int16_t *buf, int n) {
-  int32_t *re = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n), *im = re + n;
-  for (int i = 0; i < n; i++) { re[i] = buf[2 * i]; im[i] = buf[2 * i + 1]; }
-  int stages = 0;
-  for (int L = n / 4; L >= 1; L >>= 2) {
-    stages++;
-    for (int g = 0; g < n; g += 4 * L) {
-      for (int j = 0; j < L; j++) {
-        int i0 = g + j, i1 = i0 + L, i2 = i0 + 2 * L, i3 = i0 + 3 * L;
-        int32_t s0r = re[i0] + re[i2], s0i = im[i0] + im[i2];
-        int32_t s1r = re[i0] - re[i2], s1i = im[i0] - im[i2];
-        int32_t s2r = re[i1] + re[i3], s2i = im[i1] + im[i3];
-        int32_t s3r = re[i1] - re[i3], s3i = im[i1] - im[i3];
-        int32_t yr[4], yi[4];
-        yr[0] = (s0r + s2r) >> 2; yi[0] = (s0i + s2i) >> 2;
-        yr[1] = (s1r + s3i) >> 2; yi[1] = (s1i - s3r) >> 2;
-        yr[2] = (s0r - s2r) >> 2; yi[2] = (s0i - s2i) >> 2;
-        yr[3] = (s1r - s3i) >> 2; yi[3] = (s1i + s3r) >> 2;
-        for (int k = 0; k < 4; k++) {
-          int m = (k * j * (n / (4 * L))) % n; /* W_n^m */
-          int32_t wr = (int32_t)lround(32767.0 * cos(ORC_TWO_PI * m / (double)n));
-          int32_t wi = (int32_t)lround(-32767.0 * sin(ORC_TWO_PI * m / (double)n));
-          int32_t pr = (yr[k] * wr - yi[k] * wi) >> 15;
-          int32_t pi = (yr[k] * wi + yi[k] * wr) >> 15;
-          re[g + j + k * L] = sat16(pr);
-          im[g + j + k * L] = sat16(pi);
-        }
-      }
-    }
-  }
-  for (int p = 0; p < n; p++) { /* position p holds bin digit-reverse_4(p) */
-    int k = 0, q = p;
-    for (int d = 0; d < stages; d++) { k = (k << 2) | (q & 3); q >>= 2; }
-    buf[2 * k] = (int16_t)re[p];
-    buf[2 * k + 1] = (int16_t)im[p];
-  }
-  free(re);
-}
-
 struct orc_fft1024 {
   int16_t window[1024];
   int has_window;
@@ -1198,6 +1276,10 @@ orc_fft1024_t *orc_fft1024_create(int window_id) {
   return s;
 }
 void orc_fft1024_destroy(orc_fft1024_t *s) { free(s); }
+void orc_fft1024_windowFunction_table(orc_fft1024_t *s, const int16_t *w) {
+  s->has_window = w != NULL;
+  if (w) memcpy(s->window, w, sizeof(s->window));
+}
 const uint16_t *orc_fft1024_output(const orc_fft1024_t *s) { return s->output; }
 /* one update() tick with one 128-sample block; 1 when output[] is fresh */
 int orc_fft1024_update(orc_fft1024_t *s, const int16_t *block) {
@@ -1214,7 +1296,7 @@ int orc_fft1024_update(orc_fft1024_t *s, const int16_t *block) {
   orc_cfft_radix4_q15_n(buf, 1024);
   for (int i = 0; i < 512; i++) {
     int32_t r = buf[2 * i], q = buf[2 * i + 1];
-    s->output[i] = (uint16_t)orc_sqrt_uint32((uint32_t)(r * r + q * q));
+    s->output[i] = (uint16_t)orc_sqrt_uint32_approx((uint32_t)(r * r + q * q));
   }
   for (int b = 0; b < 4; b++) memcpy(s->blocks[b], s->blocks[b + 4], 128 * sizeof(int16_t));
   s->state = 4;

@@ -167,26 +167,31 @@ int orc_multi_process(const orc_config_t *cfg, int n_ch, const int16_t *iq,
 #endif
 
 /* ---- F1: IQ panadapter spectrum (analyze_fft256iq.{h,cpp}) -----------------------
- * Restatement of AudioAnalyzeFFT256IQ::update (FFTIQ.cpp:65-118).  The pieces that
- * live outside the tree are build-defined and integer-exact: the q15 window table
- * (Teensy windows.c), arm_cfft_radix4_q15 (CMSIS) and sqrt_uint32_approx (Teensy
- * utility/sqrt_integer.h) -- see oracle/rdsp_oracle.c. */
+ * Restatement of AudioAnalyzeFFT256IQ::update (FFTIQ.cpp:65-118).  The pieces that live
+ * outside the tree follow the libraries' published routines with the tables of the
+ * reference's firmware image: q15 windows (Teensy windows.c), arm_cfft_radix4_q15 (CMSIS,
+ * DSP-extension form, twiddleCoef_4096_q15) and sqrt_uint32_approx (Teensy
+ * utility/sqrt_integer.h, guess table) -- see oracle/rdsp_oracle.c. */
 #ifndef RDSP_ORACLE_SPECTRUM
 #define RDSP_ORACLE_SPECTRUM
 #ifdef __cplusplus
 extern "C" {
 #endif
 typedef struct orc_fft256iq orc_fft256iq_t;
-void orc_window_q15(int window_id, int16_t *w256);           /* 0 none, 1 Hann, 2 Blackman-Harris */
+void orc_window_q15(int window_id, int16_t *w256);           /* ids: see orc_window_q15_n in the .c file */
 void orc_cfft_radix4_q15_256(int16_t *buf /* 512: re,im */); /* scaled by 1/256, natural order */
-uint32_t orc_sqrt_uint32(uint32_t x);
-/* sqrt_uint32_approx (FFTIQ.cpp:105) restated from Teensy Audio's published routine with a RECONSTRUCTED guess table
- * (two integer Newton steps): bounds the distance of the build's exact floor square root (orc_sqrt_uint32) */
+void orc_twiddle_q15_4096(int16_t *table6144);               /* twiddleCoef_4096_q15 by its rule */
+uint32_t orc_sqrt_uint32(uint32_t x);                        /* exact floor root (comparison only) */
+/* sqrt_uint32_approx (FFTIQ.cpp:105): Teensy Audio's published routine with the firmware image's guess table */
 uint32_t orc_sqrt_uint32_approx(uint32_t in);
+const uint16_t *orc_sqrt_guess_table(void);
 orc_fft256iq_t *orc_fft256iq_create(int naverage, int window_id);
 void orc_fft256iq_destroy(orc_fft256iq_t *s);
 void orc_fft256iq_averageTogether(orc_fft256iq_t *s, int n);       /* FFTIQ.h:88-91 */
 void orc_fft256iq_windowFunction(orc_fft256iq_t *s, int window_id); /* FFTIQ.h:93-95 */
+void orc_fft256iq_windowFunction_table(orc_fft256iq_t *s, const int16_t *w256); /* the same, the reference's signature */
+float orc_fft256iq_read(const orc_fft256iq_t *s, unsigned int binNumber);       /* FFTIQ.h:70-73 */
+float orc_fft256iq_read_range(const orc_fft256iq_t *s, unsigned int binFirst, unsigned int binLast); /* FFTIQ.h:75-86 */
 /* one update() tick with a 128-sample I block and Q block; returns 1 when output[] was refreshed */
 int orc_fft256iq_update(orc_fft256iq_t *s, const int16_t *block_i, const int16_t *block_q);
 const uint16_t *orc_fft256iq_output(const orc_fft256iq_t *s); /* uint16 output[256], FFTIQ.h:99 */
@@ -196,6 +201,7 @@ void orc_window_q15_n(int window_id, int n, int16_t *w);
 void orc_cfft_radix4_q15_n(int16_t *buf, int n);
 orc_fft1024_t *orc_fft1024_create(int window_id);
 void orc_fft1024_destroy(orc_fft1024_t *s);
+void orc_fft1024_windowFunction_table(orc_fft1024_t *s, const int16_t *w1024);
 int orc_fft1024_update(orc_fft1024_t *s, const int16_t *block);
 const uint16_t *orc_fft1024_output(const orc_fft1024_t *s); /* uint16 output[512] */
 /* biquad cascades (engine audio filter bank, AudioFilterBiquad): DF1, float, CMSIS coefficient

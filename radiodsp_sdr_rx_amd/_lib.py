@@ -238,6 +238,18 @@ SYMBOLS = [
     ("rdsp_spectrum_windowFunction", _i, [_vp, _i]),
     ("rdsp_spectrum_outputs_for", _i, [_vp, _i]),
     ("rdsp_spectrum_update", _i, [_vp, _vp, _sz, _i, _vp, _sz, C.POINTER(C.c_int), _vp]),
+    ("rdsp_spectrum_create_default", _i, [_i, _i, C.POINTER(_vp)]),
+    ("rdsp_spectrum_windowFunction_table", _i, [_vp, _i16p]),
+    ("rdsp_spectrum_read", _f, [C.POINTER(C.c_uint16), C.c_uint]),
+    ("rdsp_spectrum_read_range", _f, [C.POINTER(C.c_uint16), C.c_uint, C.c_uint]),
+    ("rdsp_spectrum_node_read", _f, [_vp, _i, C.c_uint]),
+    ("rdsp_spectrum_node_read_range", _f, [_vp, _i, C.c_uint, C.c_uint]),
+    ("rdsp_sqrt_uint32_approx", C.c_uint32, [C.c_uint32]),
+    ("rdsp_fft1024_windowFunction_table", _i, [_vp, _i16p]),
+    ("rdsp_fft1024_read", _f, [C.POINTER(C.c_uint16), C.c_uint]),
+    ("rdsp_fft1024_read_range", _f, [C.POINTER(C.c_uint16), C.c_uint, C.c_uint]),
+    ("rdsp_fft1024_node_read", _f, [_vp, _i, C.c_uint]),
+    ("rdsp_fft1024_node_read_range", _f, [_vp, _i, C.c_uint, C.c_uint]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
 

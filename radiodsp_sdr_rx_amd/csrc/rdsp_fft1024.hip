@@ -2,12 +2,13 @@
  * rdsp_fft1024.hip -- AudioAnalyzeFFT1024 batched over channels (the second analyser of the
  * sketch's graph: `AudioAnalyzeFFT1024 AudioFFT;` fed from Q_out_L, RadioDSP_SDR_RX.ino:57,87,
  * read by the display).  The Teensy Audio library is not in the tree; its update() is restated
- * from the library's published behaviour and, where that is fixed-point detail, build-defined
- * exactly like the F1 analyser (rdsp_spectrum.hip): blocks are collected eight at a time and four
+ * from the library's published behaviour: blocks are collected eight at a time and four
  * are kept (1024-sample frames, hop 512), the samples are real (imaginary parts zero), q15 window
- * (x*w) >> 15, fixed-point radix-4 FFT (every butterfly output >> 2, products >> 15, saturated),
- * output[i] = floor(sqrt(re^2 + im^2)) for bins 0..511.  Integer arithmetic: bit-exact against
- * the CPU restatement kept with the tests.
+ * (x*w) >> 15, arm_cfft_radix4_q15 as CMSIS publishes it (rdsp_q15.h),
+ * output[i] = sqrt_uint32_approx(re^2 + im^2) for bins 0..511; window (AudioWindowHanning1024,
+ * INO:147), twiddles and the square root's guess table are those of the reference's firmware
+ * image (rdsp_q15_tables.c).  Integer arithmetic: bit-exact against the CPU restatement kept
+ * with the tests.
  *
  * One wave per channel.  Lane t runs the four butterflies b = t + 64 m of each of the five
  * stages (span L = 256, 64, 16, 4, 1); the packed int16 pairs go through a 4 KiB LDS buffer
@@ -33,7 +34,8 @@ struct RdspFft1024Params {
   int n_frames;         /* frames completed by this call */
   int use_window;
   const int16_t *window;  /* [1024] q15 */
-  const uint32_t *twid;   /* [1024] wr | wi << 16 */
+  const uint32_t *twid;   /* [768] cos | sin << 16 of 2 pi m / 1024 (rdsp_q15_twiddles) */
+  const uint16_t *sqrt_guess; /* [33] */
   uint16_t *out;          /* [ch][out_stride][512] */
   size_t out_stride;
   int keep;             /* samples to buffer after this call */
@@ -50,10 +52,10 @@ __device__ __forceinline__ int sample_at(const RdspFft1024Params &p, size_t ch, 
 
 __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
   __shared__ uint32_t ex[1024];
-  __shared__ Twiddle tws[1024]; /* W_1024^m as the two dot-product operands (rdsp_q15.h) */
+  __shared__ Twiddle tws[768]; /* W_1024^m as the two dot-product operands (rdsp_q15.h) */
   const int t = threadIdx.x;
   const size_t ch = blockIdx.x;
-  for (int i = t; i < 1024; i += 64) tws[i] = make_twiddle(p.twid[i]);
+  for (int i = t; i < 768; i += 64) tws[i] = make_twiddle(p.twid[i]);
   wg_sync<1>();
 
   for (int f = 0; f < p.n_frames; f++) {
@@ -71,9 +73,9 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
         int v = sample_at(p, ch, base + pos);
         if (p.use_window) v = __mul24(v, (int)p.window[pos]) >> 15;
         x[k] = pack16(v, 0);
-        if (k) tw[k] = tws[(k * b) & 1023]; /* j = b, n / (4 L) = 1; k = 0 is W^0 */
+        if (k) tw[k] = tws[k * b]; /* j = b, n / (4 L) = 1; output 0 takes no twiddle */
       }
-      bfly(x, tw);
+      bfly<kFirstStage>(x, tw);
 #pragma unroll
       for (int k = 0; k < 4; k++) ex[b + 256 * k] = x[k];
     }
@@ -91,10 +93,10 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           y[m][k] = ex[g + j + k * L];
-          if (k && L > 1) tw[k] = tws[(k * j * (256 / L)) & 1023];
+          if (k && L > 1) tw[k] = tws[k * j * (256 / L)];
         }
-        if (L > 1) bfly(y[m], tw);
-        else bfly_w0(y[m]); /* last stage: j = 0 */
+        if (L > 1) bfly<kMiddleStage>(y[m], tw);
+        else bfly<kLastStage>(y[m], tw); /* no twiddles */
       }
       wg_sync<1>();
 #pragma unroll
@@ -113,9 +115,7 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
 #pragma unroll
       for (int d = 0; d < 5; d++) { bin = (bin << 2) | (r & 3); r >>= 2; }
       if (bin < 512) {
-        const uint32_t w = ex[q];
-        const int re = lo16(w), im = hi16(w);
-        o[bin] = (uint16_t)isqrt32((uint32_t)(__mul24(re, re) + __mul24(im, im)));
+        o[bin] = (uint16_t)sqrt_uint32_approx(magsq(ex[q]), p.sqrt_guess);
       }
     }
     wg_sync<1>();
@@ -132,23 +132,13 @@ __global__ void __launch_bounds__(64) rdsp_fft1024_kernel(RdspFft1024Params p) {
 }  // namespace
 
 struct rdsp_fft1024 {
-  int n_channels, device, window_id;
+  int n_channels, device;
+  int has_window = 0;
   int have = 0; /* samples buffered per channel */
   int16_t *d_window = nullptr, *d_hist = nullptr;
+  uint16_t *d_guess = nullptr;
   uint32_t *d_twid = nullptr;
 };
-
-extern "C" void rdsp_window_q15_n(int window_id, int n, int16_t *w) {
-  const double two_pi = 6.28318530717958647692;
-  for (int i = 0; i < n; i++) {
-    double t = two_pi * (double)i / (double)n, v;
-    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
-    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
-    else v = 1.0;
-    long q = lround(32767.0 * v);
-    w[i] = (int16_t)(q > 32767 ? 32767 : q);
-  }
-}
 
 #define F1K_TRY(expr)                                                           \
   do {                                                                          \
@@ -159,11 +149,20 @@ extern "C" void rdsp_window_q15_n(int window_id, int n, int16_t *w) {
     }                                                                           \
   } while (0)
 
-static int fft1024_upload_window(rdsp_fft1024_t *s) {
-  std::vector<int16_t> w(1024);
-  rdsp_window_q15_n(s->window_id, 1024, w.data());
-  F1K_TRY(hipMemcpy(s->d_window, w.data(), 1024 * sizeof(int16_t), hipMemcpyHostToDevice));
+static int fft1024_upload_window(rdsp_fft1024_t *s, const int16_t *w1024) {
+  s->has_window = w1024 != nullptr;
+  if (w1024) F1K_TRY(hipMemcpy(s->d_window, w1024, 1024 * sizeof(int16_t), hipMemcpyHostToDevice));
   return RDSP_OK;
+}
+static int fft1024_upload_window_id(rdsp_fft1024_t *s, int window_id) {
+  if (window_id == RDSP_WINDOW_NONE) return fft1024_upload_window(s, nullptr);
+  if (window_id < 0 || window_id > RDSP_WINDOW_TUKEY) {
+    rdsp_set_error("unknown window id %d", window_id);
+    return RDSP_ERR_INVALID;
+  }
+  std::vector<int16_t> w(1024);
+  rdsp_window_q15_n(window_id, 1024, w.data());
+  return fft1024_upload_window(s, w.data());
 }
 
 extern "C" int rdsp_fft1024_create(int n_channels, int device, int window_id, rdsp_fft1024_t **out) {
@@ -178,20 +177,16 @@ extern "C" int rdsp_fft1024_create(int n_channels, int device, int window_id, rd
   rdsp_fft1024_t *s = new rdsp_fft1024();
   s->n_channels = n_channels;
   s->device = device;
-  s->window_id = window_id;
-  std::vector<uint32_t> tw(1024);
-  const double two_pi = 6.28318530717958647692;
-  for (int m = 0; m < 1024; m++) {
-    int wr = (int)lround(32767.0 * cos(two_pi * m / 1024.0));
-    int wi = (int)lround(-32767.0 * sin(two_pi * m / 1024.0));
-    tw[m] = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
-  }
+  std::vector<uint32_t> tw(768);
+  rdsp_q15_twiddles(1024, tw.data());
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&s->d_window, 1024 * sizeof(int16_t)) != hipSuccess ||
-      hipMalloc((void **)&s->d_twid, 1024 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&s->d_twid, 768 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&s->d_guess, 33 * sizeof(uint16_t)) != hipSuccess ||
       hipMalloc((void **)&s->d_hist, (size_t)n_channels * 896 * sizeof(int16_t)) != hipSuccess ||
       hipMemset(s->d_hist, 0, (size_t)n_channels * 896 * sizeof(int16_t)) != hipSuccess ||
-      hipMemcpy(s->d_twid, tw.data(), 1024 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
-      fft1024_upload_window(s) != RDSP_OK) {
+      hipMemcpy(s->d_twid, tw.data(), 768 * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(s->d_guess, rdsp_sqrt_guess_table(), 33 * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
+      fft1024_upload_window_id(s, window_id) != RDSP_OK) {
     rdsp_set_error("rdsp_fft1024_create: device set-up failed");
     rdsp_fft1024_destroy(s);
     return RDSP_ERR_HIP;
@@ -204,6 +199,7 @@ extern "C" void rdsp_fft1024_destroy(rdsp_fft1024_t *s) {
   (void)hipSetDevice(s->device);
   if (s->d_window) (void)hipFree(s->d_window);
   if (s->d_twid) (void)hipFree(s->d_twid);
+  if (s->d_guess) (void)hipFree(s->d_guess);
   if (s->d_hist) (void)hipFree(s->d_hist);
   delete s;
 }
@@ -211,8 +207,15 @@ extern "C" int rdsp_fft1024_windowFunction(rdsp_fft1024_t *s, int window_id) {
   if (!s) return RDSP_ERR_INVALID;
   F1K_TRY(hipSetDevice(s->device));
   F1K_TRY(hipDeviceSynchronize());
-  s->window_id = window_id;
-  return fft1024_upload_window(s);
+  return fft1024_upload_window_id(s, window_id);
+}
+/* windowFunction(const int16_t *w) with the library's own argument: a host pointer to 1024 q15 taps
+ * (AudioWindowHanning1024, INO:147) or NULL */
+extern "C" int rdsp_fft1024_windowFunction_table(rdsp_fft1024_t *s, const int16_t *w1024) {
+  if (!s) return RDSP_ERR_INVALID;
+  F1K_TRY(hipSetDevice(s->device));
+  F1K_TRY(hipDeviceSynchronize());
+  return fft1024_upload_window(s, w1024);
 }
 /* AudioFFT.averageTogether(30) (INO:148): the library's 1024-point analyser declares it and does
  * nothing with it ("not implemented yet"); accepted and ignored here too */
@@ -248,9 +251,10 @@ extern "C" int rdsp_fft1024_update(rdsp_fft1024_t *s, const int16_t *d_audio, si
   p.have = s->have;
   p.st_hist = s->d_hist;
   p.n_frames = nf;
-  p.use_window = s->window_id != 0;
+  p.use_window = s->has_window;
   p.window = s->d_window;
   p.twid = s->d_twid;
+  p.sqrt_guess = s->d_guess;
   p.out = d_out;
   p.out_stride = out_stride;
   p.keep = nf > 0 ? total - 512 * nf : total; /* 4..7 blocks once frames run, everything before */
@@ -341,6 +345,16 @@ extern "C" int rdsp_fft1024_node_available(rdsp_node_t *n) {
 extern "C" const uint16_t *rdsp_fft1024_node_output(rdsp_node_t *n) {
   Fft1024Node *s = static_cast<Fft1024Node *>(rdsp_node_user(n));
   return s ? s->h_out.data() : nullptr;
+}
+extern "C" float rdsp_fft1024_node_read(rdsp_node_t *n, int ch, unsigned int binNumber) {
+  Fft1024Node *s = static_cast<Fft1024Node *>(rdsp_node_user(n));
+  if (!s || ch < 0 || ch >= s->n_channels) return 0.0f;
+  return rdsp_fft1024_read(s->h_out.data() + (size_t)ch * 512, binNumber);
+}
+extern "C" float rdsp_fft1024_node_read_range(rdsp_node_t *n, int ch, unsigned int binFirst, unsigned int binLast) {
+  Fft1024Node *s = static_cast<Fft1024Node *>(rdsp_node_user(n));
+  if (!s || ch < 0 || ch >= s->n_channels) return 0.0f;
+  return rdsp_fft1024_read_range(s->h_out.data() + (size_t)ch * 512, binFirst, binLast);
 }
 extern "C" int rdsp_fft1024_node_status(rdsp_node_t *n) {
   Fft1024Node *s = static_cast<Fft1024Node *>(rdsp_node_user(n));

@@ -257,6 +257,17 @@ extern "C" const uint16_t *rdsp_spectrum_node_output(rdsp_node_t *n) {
   SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
   return s ? s->h_out.data() : nullptr;
 }
+/* FFT.read(bin) / FFT.read(binFirst, binLast) of channel `ch` (FFTIQ.h:70-86) */
+extern "C" float rdsp_spectrum_node_read(rdsp_node_t *n, int ch, unsigned int binNumber) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
+  if (!s || ch < 0 || ch >= s->n_channels) return 0.0f;
+  return rdsp_spectrum_read(s->h_out.data() + (size_t)ch * 256, binNumber);
+}
+extern "C" float rdsp_spectrum_node_read_range(rdsp_node_t *n, int ch, unsigned int binFirst, unsigned int binLast) {
+  SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
+  if (!s || ch < 0 || ch >= s->n_channels) return 0.0f;
+  return rdsp_spectrum_read_range(s->h_out.data() + (size_t)ch * 256, binFirst, binLast);
+}
 extern "C" int rdsp_spectrum_node_status(rdsp_node_t *n) {
   SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
   return s ? s->status : RDSP_ERR_INVALID;

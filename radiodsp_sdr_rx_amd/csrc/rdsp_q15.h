@@ -1,17 +1,28 @@
 /*
  * rdsp_q15.h -- the fixed-point radix-4 butterfly shared by the two analysers
  * (rdsp_spectrum.hip: AudioAnalyzeFFT256IQ, analyze_fft256iq.cpp:82; rdsp_fft1024.hip:
- * AudioAnalyzeFFT1024).  Arithmetic as the test restatement defines it (arm_cfft_radix4_q15 role):
- *   y_k = (four-term sum) >> 2,   out_k = sat16((y_k * W_k) >> 15)   on both components,
- * every intermediate exact in 32 bits.
+ * AudioAnalyzeFFT1024) and their integer square root (analyze_fft256iq.cpp:105).
  *
- * gfx950 mapping.  A complex value is one register, re in the low and im in the high half-word.
- * The first level of sums reads the halves with sign extension through SDWA operand selects (the
- * compiler emits those from the casts), the products are two v_dot2_i32_i16 against the twiddle
- * kept twice, as (wr, -wi) and (wi, wr) -- the table holds round(32767 cos), round(-32767 sin), so
- * -wi always fits -- and v_cvt_pk_i16_i32 saturates and packs both components at once.
- * W^0 = (32767, 0) has no cross terms and cannot saturate: (y * 32767) >> 15 is the high half-word
- * of y * 65534, picked out of the two products by one v_perm_b32.
+ * Arithmetic: arm_cfft_radix4_q15 as CMSIS-DSP publishes it for cores with the DSP extension (the
+ * Cortex-M7 of the reference): two int16 per 32-bit word, real part in the low half, and per
+ * butterfly, with a, b, c, d the inputs at distance N/4 (first stage: each >> 2 first),
+ *   first stage   y0 = (sat(a+c) + sat(b+d)) >> 1          y2 = W2 . sat(sat(a+c) - sat(b+d))
+ *                 y1 = W1 . sat((a-c) - j(b-d))             y3 = W3 . sat((a-c) + j(b-d))
+ *   middle stages y0 = ((sat(a+c) + sat(b+d)) >> 1) >> 1    y2 = W2 . ((sat(a+c) - sat(b+d)) >> 1)
+ *                 y1 = W1 . (((a-c) - j(b-d)) >> 1)         y3 = W3 . (((a-c) + j(b-d)) >> 1)
+ *   last stage    the same sums >> 1, no twiddles
+ * where W . y = ((cos y.re + sin y.im) >> 16, (cos y.im - sin y.re) >> 16) with (cos, sin) from
+ * twiddleCoef_4096_q15 (floor(32768 x) clamped to int16; the reference's firmware image holds the
+ * table, tests/test_firmware_tables.py), every sum of two saturated to int16 (__QADD16, __QSUB16,
+ * __QASX, __QSAX) and every halving an arithmetic shift of the 17-bit sum (__SHADD16, __SHSUB16,
+ * __SHASX, __SHSAX).  Total scale 1/N.  The kernels keep their own data flow (butterfly outputs
+ * in DFT order k = 0..3 at positions base + k L, base-4 digit reversal at the end); CMSIS stores
+ * y2 and y1 exchanged and reverses bits instead, which moves the same values to the same bins.
+ *
+ * gfx950 mapping: the saturating pair operations are v_pk_add_i16 / v_pk_sub_i16 with clamp, the
+ * halving ones (a >> 1) + (b >> 1) + (a & b & 1) on packed halves, the exchange forms one half-word
+ * swap plus a half-word select of the packed sum and difference, the twiddle product two
+ * v_dot2_i32_i16 against (cos, sin) and (-sin, cos) and one v_perm_b32 that takes both high halves.
  */
 #ifndef RDSP_Q15_H
 #define RDSP_Q15_H
@@ -21,94 +32,110 @@
 
 namespace rdsp_q15 {
 
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+__device__ __forceinline__ uint32_t as_u(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+
 __device__ __forceinline__ int lo16(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
 __device__ __forceinline__ int hi16(uint32_t w) { return (int)(int16_t)(w >> 16); }
 __device__ __forceinline__ uint32_t pack16(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
 
-/* a.lo * b.lo + a.hi * b.hi, exact (|result| < 2^31 for q15 operands) */
+/* a.lo * b.lo + a.hi * b.hi in 32 bits (wraps like __SMUAD) */
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b) {
   int d;
   asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-/* saturate both to int16 and pack (lo, hi) */
-__device__ __forceinline__ uint32_t sat_pack(int lo, int hi) {
-  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi));
-}
 /* (bits 16..31 of lo) | (bits 16..31 of hi) << 16 */
 __device__ __forceinline__ uint32_t pack_high_halves(int lo, int hi) {
   return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060302u);
 }
+/* (x.lo, y.hi) */
+__device__ __forceinline__ uint32_t lo_of_hi_of(uint32_t x, uint32_t y) {
+  return __builtin_amdgcn_perm(y, x, 0x07060100u);
+}
+__device__ __forceinline__ uint32_t swap_halves(uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 16); }
 
-/* the twiddle W = (wr, wi) as the two operands of the complex product */
+/* __QADD16, __QSUB16 */
+__device__ __forceinline__ uint32_t qadd16(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_add_sat(as_v(a), as_v(b))); }
+__device__ __forceinline__ uint32_t qsub16(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_sub_sat(as_v(a), as_v(b))); }
+/* both halves >> n, arithmetic */
+template <int N>
+__device__ __forceinline__ uint32_t asr16(uint32_t a) { return as_u(as_v(a) >> (v2s)(short)N); }
+/* __SHADD16: (a + b) >> 1 on the 17-bit sums; __SHSUB16 likewise */
+__device__ __forceinline__ uint32_t shadd16(uint32_t a, uint32_t b) {
+  return as_u(as_v(asr16<1>(a)) + as_v(asr16<1>(b)) + as_v(a & b & 0x00010001u));
+}
+__device__ __forceinline__ uint32_t shsub16(uint32_t a, uint32_t b) {
+  return as_u(as_v(asr16<1>(a)) - as_v(asr16<1>(b)) - as_v(~a & b & 0x00010001u));
+}
+
+/* the twiddle W = (cos, sin) as the two operands of W . y */
 struct Twiddle {
-  uint32_t a; /* (wr, -wi): real part      y.re * wr - y.im * wi */
-  uint32_t b; /* (wi,  wr): imaginary part y.re * wi + y.im * wr */
+  uint32_t a; /* ( cos, sin): real part      cos y.re + sin y.im */
+  uint32_t b; /* (-sin, cos): imaginary part cos y.im - sin y.re */
 };
+/* w = cos | sin << 16 (rdsp_q15_twiddles); sin > -32768 for every entry a 256- or 1024-point plan reads */
 __device__ __forceinline__ Twiddle make_twiddle(uint32_t w) {
-  const int wr = lo16(w), wi = hi16(w);
-  return Twiddle{pack16(wr, -wi), pack16(wi, wr)};
+  return Twiddle{w, pack16(-hi16(w), lo16(w))};
+}
+/* out1 = __SMUAD(C, y) >> 16, out2 = __SMUSDX(C, y), word = (out2 & 0xFFFF0000) | (out1 & 0xFFFF) */
+__device__ __forceinline__ uint32_t twiddle_mul(uint32_t y, const Twiddle &w) {
+  return pack_high_halves(dot2(y, w.a), dot2(y, w.b));
 }
 
-/* the four sums of a radix-4 butterfly before the >> 2 (18-bit values) */
-struct Sums { int r[4], i[4]; };
-__device__ __forceinline__ Sums bfly_sums(const uint32_t *x) {
-  const int ar = lo16(x[0]), ai = hi16(x[0]), br = lo16(x[1]), bi = hi16(x[1]);
-  const int cr = lo16(x[2]), ci = hi16(x[2]), dr = lo16(x[3]), di = hi16(x[3]);
-  const int s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
-  const int s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
-  Sums s;
-  s.r[0] = s0r + s2r; s.i[0] = s0i + s2i;
-  s.r[1] = s1r + s3i; s.i[1] = s1i - s3r;
-  s.r[2] = s0r - s2r; s.i[2] = s0i - s2i;
-  s.r[3] = s1r - s3i; s.i[3] = s1i + s3r;
-  return s;
-}
+enum { kFirstStage = 0, kMiddleStage = 1, kLastStage = 2 };
 
-/* one output of a butterfly times a general twiddle */
-__device__ __forceinline__ uint32_t twiddle_mul(int sr, int si, const Twiddle &w) {
-  const uint32_t y = sat_pack(sr >> 2, si >> 2); /* both fit: the pack is exact */
-  return sat_pack(dot2(y, w.a) >> 15, dot2(y, w.b) >> 15);
-}
-/* ... times W^0 = (32767, 0) */
-__device__ __forceinline__ uint32_t twiddle_mul_w0(int sr, int si) {
-  return pack_high_halves(__mul24(sr >> 2, 65534), __mul24(si >> 2, 65534));
-}
-
-/* x[k] (packed) -> sat16(((sum_k) >> 2) * W_k >> 15); w[0] is W^0 in every stage of a
- * decimation-in-frequency pass (k j = 0), w[1..3] are general */
+/* x = (a, b, c, d) -> (y0, y1, y2, y3); w[1..3] = W^j, W^2j, W^3j (unused in the last stage) */
+template <int STAGE>
 __device__ __forceinline__ void bfly(uint32_t *x, const Twiddle *w) {
-  const Sums s = bfly_sums(x);
-  x[0] = twiddle_mul_w0(s.r[0], s.i[0]);
-#pragma unroll
-  for (int k = 1; k < 4; k++) x[k] = twiddle_mul(s.r[k], s.i[k], w[k]);
-}
-/* last stage: every twiddle is W^0 */
-__device__ __forceinline__ void bfly_w0(uint32_t *x) {
-  const Sums s = bfly_sums(x);
-#pragma unroll
-  for (int k = 0; k < 4; k++) x[k] = twiddle_mul_w0(s.r[k], s.i[k]);
-}
-/* last stage, components left unpacked (they feed re^2 + im^2) */
-__device__ __forceinline__ void bfly_w0_unpacked(const uint32_t *x, int *re, int *im) {
-  const Sums s = bfly_sums(x);
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    re[k] = __mul24(s.r[k] >> 2, 65534) >> 16;
-    im[k] = __mul24(s.i[k] >> 2, 65534) >> 16;
+  uint32_t a = x[0], b = x[1], c = x[2], d = x[3];
+  if (STAGE == kFirstStage) {
+    a = asr16<2>(a); b = asr16<2>(b); c = asr16<2>(c); d = asr16<2>(d);
+  }
+  const uint32_t R = qadd16(a, c), S = qsub16(a, c), V = qadd16(b, d);
+  const uint32_t Tx = swap_halves(qsub16(b, d));
+  /* with T = b - d: A = (S.lo + T.hi, S.hi + T.lo), B = (S.lo - T.hi, S.hi - T.lo);
+   * (a-c) - j(b-d) = (A.lo, B.hi), (a-c) + j(b-d) = (B.lo, A.hi) */
+  if (STAGE == kFirstStage) {
+    const uint32_t A = qadd16(S, Tx), B = qsub16(S, Tx);
+    x[0] = shadd16(R, V);
+    x[2] = twiddle_mul(qsub16(R, V), w[2]);
+    x[1] = twiddle_mul(lo_of_hi_of(A, B), w[1]);
+    x[3] = twiddle_mul(lo_of_hi_of(B, A), w[3]);
+  } else if (STAGE == kMiddleStage) {
+    const uint32_t A = shadd16(S, Tx), B = shsub16(S, Tx);
+    x[0] = asr16<1>(shadd16(R, V));
+    x[2] = twiddle_mul(shsub16(R, V), w[2]);
+    x[1] = twiddle_mul(lo_of_hi_of(A, B), w[1]);
+    x[3] = twiddle_mul(lo_of_hi_of(B, A), w[3]);
+  } else {
+    const uint32_t A = shadd16(S, Tx), B = shsub16(S, Tx);
+    x[0] = shadd16(R, V);
+    x[2] = shsub16(R, V);
+    x[1] = lo_of_hi_of(A, B);
+    x[3] = lo_of_hi_of(B, A);
   }
 }
+
+/* multiply_16tx16t_add_16bx16b(w, w), analyze_fft256iq.cpp:89 */
+__device__ __forceinline__ uint32_t magsq(uint32_t w) { return (uint32_t)dot2(w, w); }
 
 /* q15 window on both components: (x * w) >> 15 = high half-word of x * 2w; w2 = 2 w */
 __device__ __forceinline__ uint32_t window_mul(uint32_t x, int w2) {
   return pack_high_halves(__mul24(lo16(x), w2), __mul24(hi16(x), w2));
 }
 
-__device__ __forceinline__ uint32_t isqrt32(uint32_t x) {
-  uint32_t r = (uint32_t)sqrtf((float)x);
-  while ((unsigned long long)r * r > x) r--;
-  while ((unsigned long long)(r + 1) * (r + 1) <= x) r++;
-  return r;
+/* sqrt_uint32_approx of Teensy Audio's utility/sqrt_integer.h (analyze_fft256iq.cpp:105): first
+ * guess from a 33-entry table by the count of leading zeros (`guess`: rdsp_sqrt_guess_table, the
+ * reference's firmware image holds it), two integer Newton steps.  in = 0: guess 0, and the
+ * Cortex-M7's UDIV by zero yields 0, so the result is 0. */
+__device__ __forceinline__ uint32_t sqrt_uint32_approx(uint32_t in, const uint16_t *guess) {
+  if (in == 0u) return 0u;
+  uint32_t n = guess[__clz((int)in)];
+  n = ((in / n) + n) >> 1;
+  n = ((in / n) + n) >> 1;
+  return n;
 }
 
 }  // namespace rdsp_q15

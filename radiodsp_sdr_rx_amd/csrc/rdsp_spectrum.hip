@@ -3,8 +3,10 @@
  * (AudioAnalyzeFFT256IQ, analyze_fft256iq.{h,cpp}) batched over channels.
  * Integer q15 path, bit-exact against the CPU restatement kept with the tests: pack I | Q << 16
  * (FFTIQ.cpp:38-48), q15 window (x*w) >> 15 (:50-63), 256-point fixed-point
- * radix-4 FFT (arm_cfft_radix4_q15 role, :82), |.|^2 / naverage accumulation
- * (:86-98), integer sqrt and the output[255 - (i ^ 128)] reorder (:99-113).
+ * radix-4 FFT (arm_cfft_radix4_q15 as CMSIS publishes it, :82; rdsp_q15.h), |.|^2 / naverage
+ * accumulation (:86-98), sqrt_uint32_approx and the output[255 - (i ^ 128)] reorder (:99-113).
+ * Windows, twiddles and the square root's guess table are the ones in the reference's firmware
+ * image (rdsp_q15_tables.c).
  *
  * One wave per channel: lane t owns the four inputs t + 64k of a 256-point frame
  * ([previous block | current block], so the previous block simply stays in two
@@ -34,12 +36,13 @@ struct RdspSpecParams {
   /* x / naverage without the ~30-instruction 32-bit division (4 per frame and lane): power of
    * two -> shift; else q = mulhi(div_magic, x) >> div_shift with div_magic = ceil(2^(31+L) / d),
    * L = ceil(log2 d), div_shift = L - 1.  Exact for every x < 2^31 (the error term x e / (d 2^(31+L))
-   * with e < d <= 2^L stays below 1/d), and re^2 + im^2 <= 2 * 32767^2 < 2^31. */
+   * with e < d <= 2^L stays below 1/d for x <= 2^31), and re^2 + im^2 <= 2 * 32768^2 = 2^31. */
   uint32_t div_magic;
   int div_shift, div_pow2;
   int use_window;
   const int16_t *window;  /* [256] q15 */
-  const uint32_t *twid;   /* [256] wr | wi << 16, W_256^m */
+  const uint32_t *twid;   /* [192] cos | sin << 16 of 2 pi m / 256 (rdsp_q15_twiddles) */
+  const uint16_t *sqrt_guess; /* [33] */
   uint32_t *st_prev;      /* [ch][128] previous block */
   uint32_t *st_sum;       /* [ch][256] sum[], position order */
   uint16_t *out;          /* [ch][out_stride][256] */
@@ -55,15 +58,15 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
   const size_t ch = blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
 
-  /* per-lane constants: twiddles of stages 1..3 (k = 0 and the whole of stage 4 are W^0, which
-   * the butterfly knows), window taps doubled (see window_mul) */
+  /* per-lane constants: twiddles of stages 1..3 (output k = 0 and the whole of stage 4 take none),
+   * window taps doubled (see window_mul) */
   Twiddle tw[3][4];
 #pragma unroll
   for (int st = 0; st < 3; st++) {
     const int L = 64 >> (2 * st);
     const int j = t % L;
 #pragma unroll
-    for (int k = 1; k < 4; k++) tw[st][k] = make_twiddle(p.twid[(k * j * (64 / L)) & 255]);
+    for (int k = 1; k < 4; k++) tw[st][k] = make_twiddle(p.twid[k * j * (64 / L)]);
   }
   int win2[4] = {0, 0, 0, 0};
   if (p.use_window) {
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
       for (int k = 0; k < 4; k++) x[k] = window_mul(x[k], win2[k]);
     }
     /* four stages, span L = 64, 16, 4, 1; positions base + k*L */
-    bfly(x, tw[0]);
+    bfly<kFirstStage>(x, tw[0]);
 #pragma unroll
     for (int k = 0; k < 4; k++) ex[t + 64 * k] = x[k];
     wg_sync<1>();
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
       const int base = (t / 16) * 64 + (t % 16);
 #pragma unroll
       for (int k = 0; k < 4; k++) x[k] = ex[base + 16 * k];
-      bfly(x, tw[1]);
+      bfly<kMiddleStage>(x, tw[1]);
       wg_sync<1>();
 #pragma unroll
       for (int k = 0; k < 4; k++) ex[base + 16 * k] = x[k];
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
       const int base = (t / 4) * 16 + (t % 4);
 #pragma unroll
       for (int k = 0; k < 4; k++) x[k] = ex[base + 4 * k];
-      bfly(x, tw[2]);
+      bfly<kMiddleStage>(x, tw[2]);
       wg_sync<1>();
 #pragma unroll
       for (int k = 0; k < 4; k++) ex[base + 4 * k] = x[k];
@@ -126,18 +129,17 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
     wg_sync<1>();
 #pragma unroll
     for (int k = 0; k < 4; k++) x[k] = ex[4 * t + k];
-    int re[4], im[4];
-    bfly_w0_unpacked(x, re, im);
+    bfly<kLastStage>(x, nullptr);
     wg_sync<1>();
     /* FFTIQ.cpp:86-98 */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t magsq = (uint32_t)(__mul24(re[k], re[k]) + __mul24(im[k], im[k]));
+      const uint32_t msq = magsq(x[k]);
       uint32_t term; /* magsq / naverage, FFTIQ.cpp:90 */
       if (p.div_pow2) {
-        term = magsq >> p.div_shift;
+        term = msq >> p.div_shift;
       } else {
-        term = __umulhi(p.div_magic, magsq) >> p.div_shift;
+        term = __umulhi(p.div_magic, msq) >> p.div_shift;
       }
       sum[k] += term;
     }
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int bin = 64 * k + rbase;
-        o[255 - (bin ^ 128)] = (uint16_t)isqrt32(sum[k]);
+        o[255 - (bin ^ 128)] = (uint16_t)sqrt_uint32_approx(sum[k], p.sqrt_guess);
         sum[k] = 0u;
       }
       n_out++;
@@ -169,24 +171,13 @@ __global__ void __launch_bounds__(64) rdsp_spectrum_kernel(RdspSpecParams p) {
 /* ---- host side -------------------------------------------------------------- */
 struct rdsp_spectrum {
   int n_channels, device;
-  int naverage, window_id;
+  int naverage;
+  int has_window; /* `const int16_t *window` non-NULL, FFTIQ.h:101, FFTIQ.cpp:81 */
   int have_prev, count;
   int16_t *d_window = nullptr;
+  uint16_t *d_guess = nullptr;
   uint32_t *d_twid = nullptr, *d_prev = nullptr, *d_sum = nullptr;
 };
-
-/* build-defined q15 window tables (Teensy windows.c is not in the tree) */
-extern "C" void rdsp_window_q15(int window_id, int16_t *w) {
-  const double two_pi = 6.28318530717958647692;
-  for (int i = 0; i < 256; i++) {
-    double t = two_pi * (double)i / 256.0, v;
-    if (window_id == 1) v = 0.5 * (1.0 - cos(t));
-    else if (window_id == 2) v = 0.35875 - 0.48829 * cos(t) + 0.14128 * cos(2 * t) - 0.01168 * cos(3 * t);
-    else v = 1.0;
-    long q = lround(32767.0 * v);
-    w[i] = (int16_t)(q > 32767 ? 32767 : q);
-  }
-}
 
 #define SPEC_TRY(expr)                                                          \
   do {                                                                          \
@@ -197,14 +188,25 @@ extern "C" void rdsp_window_q15(int window_id, int16_t *w) {
     }                                                                           \
   } while (0)
 
-static int upload_window(rdsp_spectrum_t *s) {
-  int16_t w[256];
-  rdsp_window_q15(s->window_id, w);
-  SPEC_TRY(hipMemcpy(s->d_window, w, sizeof(w), hipMemcpyHostToDevice));
+/* windowFunction(const int16_t *w), FFTIQ.h:93-95: the analyser keeps the caller's table (a copy
+ * here: the table lives in device memory); NULL switches the window off (FFTIQ.cpp:81) */
+static int upload_window(rdsp_spectrum_t *s, const int16_t *w256) {
+  s->has_window = w256 != nullptr;
+  if (w256) SPEC_TRY(hipMemcpy(s->d_window, w256, 256 * sizeof(int16_t), hipMemcpyHostToDevice));
   return RDSP_OK;
 }
+static int upload_window_id(rdsp_spectrum_t *s, int window_id) {
+  int16_t w[256];
+  if (window_id == RDSP_WINDOW_NONE) return upload_window(s, nullptr);
+  if (window_id < 0 || window_id > RDSP_WINDOW_TUKEY) {
+    rdsp_set_error("unknown window id %d", window_id);
+    return RDSP_ERR_INVALID;
+  }
+  rdsp_window_q15(window_id, w);
+  return upload_window(s, w);
+}
 
-/* AudioAnalyzeFFT256IQ(), FFTIQ.h:55-60 (default window there: BlackmanNuttall, naverage 8) */
+/* AudioAnalyzeFFT256IQ() with explicit settings (the constructor's own are rdsp_spectrum_create_default) */
 extern "C" int rdsp_spectrum_create(int n_channels, int device, int naverage, int window_id,
                                     rdsp_spectrum_t **out) {
   if (!out || n_channels <= 0 || naverage > 255) {
@@ -219,28 +221,32 @@ extern "C" int rdsp_spectrum_create(int n_channels, int device, int naverage, in
   s->n_channels = n_channels;
   s->device = device;
   s->naverage = naverage <= 0 ? 1 : naverage; /* averageTogether, FFTIQ.h:88-91 */
-  s->window_id = window_id;
+  s->has_window = 0;
   s->have_prev = 0;
   s->count = 0;
   SPEC_TRY(hipSetDevice(device));
   SPEC_TRY(hipMalloc((void **)&s->d_window, 256 * sizeof(int16_t)));
-  SPEC_TRY(hipMalloc((void **)&s->d_twid, 256 * sizeof(uint32_t)));
+  SPEC_TRY(hipMalloc((void **)&s->d_twid, 192 * sizeof(uint32_t)));
+  SPEC_TRY(hipMalloc((void **)&s->d_guess, 33 * sizeof(uint16_t)));
   SPEC_TRY(hipMalloc((void **)&s->d_prev, (size_t)n_channels * 128 * sizeof(uint32_t)));
   SPEC_TRY(hipMalloc((void **)&s->d_sum, (size_t)n_channels * 256 * sizeof(uint32_t)));
   SPEC_TRY(hipMemset(s->d_prev, 0, (size_t)n_channels * 128 * sizeof(uint32_t)));
   SPEC_TRY(hipMemset(s->d_sum, 0, (size_t)n_channels * 256 * sizeof(uint32_t)));
-  uint32_t tw[256];
-  const double two_pi = 6.28318530717958647692;
-  for (int m = 0; m < 256; m++) {
-    int wr = (int)lround(32767.0 * cos(two_pi * m / 256.0));
-    int wi = (int)lround(-32767.0 * sin(two_pi * m / 256.0));
-    tw[m] = ((uint32_t)wr & 0xFFFFu) | ((uint32_t)wi << 16);
-  }
+  uint32_t tw[192];
+  rdsp_q15_twiddles(256, tw);
   SPEC_TRY(hipMemcpy(s->d_twid, tw, sizeof(tw), hipMemcpyHostToDevice));
-  int rc = upload_window(s);
-  if (rc != RDSP_OK) return rc;
+  SPEC_TRY(hipMemcpy(s->d_guess, rdsp_sqrt_guess_table(), 33 * sizeof(uint16_t), hipMemcpyHostToDevice));
+  int rc = upload_window_id(s, window_id);
+  if (rc != RDSP_OK) {
+    rdsp_spectrum_destroy(s);
+    return rc;
+  }
   *out = s;
   return RDSP_OK;
+}
+/* AudioAnalyzeFFT256IQ(), FFTIQ.h:55-60: window(AudioWindowBlackmanNuttall256), naverage(8) */
+extern "C" int rdsp_spectrum_create_default(int n_channels, int device, rdsp_spectrum_t **out) {
+  return rdsp_spectrum_create(n_channels, device, 8, RDSP_WINDOW_BLACKMAN_NUTTALL, out);
 }
 
 extern "C" int rdsp_spectrum_device(const rdsp_spectrum_t *s) { return s ? s->device : -1; }
@@ -249,6 +255,7 @@ extern "C" void rdsp_spectrum_destroy(rdsp_spectrum_t *s) {
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_window);
   (void)hipFree(s->d_twid);
+  (void)hipFree(s->d_guess);
   (void)hipFree(s->d_prev);
   (void)hipFree(s->d_sum);
   delete s;
@@ -263,8 +270,15 @@ extern "C" int rdsp_spectrum_windowFunction(rdsp_spectrum_t *s, int window_id) {
   if (!s) return RDSP_ERR_INVALID;
   SPEC_TRY(hipSetDevice(s->device));
   SPEC_TRY(hipDeviceSynchronize());
-  s->window_id = window_id;
-  return upload_window(s);
+  return upload_window_id(s, window_id);
+}
+/* void windowFunction(const int16_t *w), FFTIQ.h:93-95, with the reference's own argument: a
+ * host pointer to 256 q15 taps (e.g. AudioWindowHanning256, INO:144), or NULL for no window */
+extern "C" int rdsp_spectrum_windowFunction_table(rdsp_spectrum_t *s, const int16_t *w256) {
+  if (!s) return RDSP_ERR_INVALID;
+  SPEC_TRY(hipSetDevice(s->device));
+  SPEC_TRY(hipDeviceSynchronize());
+  return upload_window(s, w256);
 }
 
 /* the reference's frame counter over `frames` frames: `if (++count == naverage) { output; count = 0; }`
@@ -337,9 +351,10 @@ extern "C" int rdsp_spectrum_update(rdsp_spectrum_t *s, const int16_t *d_iq, siz
       p.div_magic = (uint32_t)((n + d - 1) / d); /* < 2^32 because d > 2^fl */
     }
   }
-  p.use_window = s->window_id != 0;
+  p.use_window = s->has_window;
   p.window = s->d_window;
   p.twid = s->d_twid;
+  p.sqrt_guess = s->d_guess;
   p.st_prev = s->d_prev;
   p.st_sum = s->d_sum;
   p.out = d_out;

@@ -6,8 +6,9 @@ import numpy as np
 import torch
 
 from . import _lib
+from .spectrum import WINDOW_IDS
 
-WINDOWS = {"none": 0, "AudioWindowHanning1024": 1, "AudioWindowBlackmanHarris1024": 2}
+WINDOWS = {"none": 0, **{f"AudioWindow{k}1024": v for k, v in WINDOW_IDS.items() if v}}
 
 
 def _stream(stream=None):
@@ -109,7 +110,13 @@ class AnalyzeFFT1024:
             pass
 
     def windowFunction(self, window):
-        _lib.check(self.lib.rdsp_fft1024_windowFunction(self.h, WINDOWS[window]))
+        """A table name, an int16 array of 1024 q15 taps (the library's own argument) or None."""
+        if window is None or isinstance(window, str):
+            _lib.check(self.lib.rdsp_fft1024_windowFunction(self.h, WINDOWS[window or "none"]))
+            return
+        w = np.ascontiguousarray(window, dtype=np.int16)
+        assert w.shape == (1024,)
+        _lib.check(self.lib.rdsp_fft1024_windowFunction_table(self.h, w.ctypes.data_as(C.POINTER(C.c_int16))))
 
     def averageTogether(self, n):   # INO:148; the library ignores it
         _lib.check(self.lib.rdsp_fft1024_averageTogether(self.h, int(n)))
@@ -137,7 +144,10 @@ class AnalyzeFFT1024:
         f, self._flag = self._flag, False
         return f
 
-    def read(self, channel, binNumber):
-        if binNumber > 511 or self.output is None:
+    def read(self, channel, binFirst, binLast=None):
+        if self.output is None:
             return 0.0
-        return float(int(self.output[channel, binNumber].item()) & 0xFFFF) * (1.0 / 16384.0)
+        row = np.ascontiguousarray(self.output[channel].cpu().numpy().view(np.uint16)).ctypes.data_as(C.POINTER(C.c_uint16))
+        if binLast is None:
+            return float(self.lib.rdsp_fft1024_read(row, int(binFirst)))
+        return float(self.lib.rdsp_fft1024_read_range(row, int(binFirst), int(binLast)))

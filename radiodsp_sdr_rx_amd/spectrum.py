@@ -2,15 +2,28 @@
 panadapter spectrum analyser on the GPU (integer q15 path, bit-exact against the CPU restatement kept with the tests)."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
 
-WINDOWS = {"none": 0, "AudioWindowHanning256": 1, "AudioWindowBlackmanHarris256": 2}
+# the table names of analyze_fft256iq.h:30-50 -> RDSP_WINDOW_* (include/rdsp.h)
+WINDOW_IDS = {"none": 0, "Hanning": 1, "BlackmanHarris": 2, "BlackmanNuttall": 3, "Bartlett": 4, "Blackman": 5,
+              "Flattop": 6, "Nuttall": 7, "Welch": 8, "Hamming": 9, "Cosine": 10, "Tukey": 11}
+WINDOWS = {"none": 0, **{f"AudioWindow{k}256": v for k, v in WINDOW_IDS.items() if v}}
+
+
+def window_q15(window_id, n=256):
+    """The q15 table the Teensy Audio library holds under that name (int16 [n])."""
+    w = np.zeros(n, np.int16)
+    _lib.load().rdsp_window_q15_n(int(window_id), int(n), w.ctypes.data_as(C.POINTER(C.c_int16)))
+    return w
 
 
 class AnalyzeFFT256IQ:
-    def __init__(self, n_channels, naverage=8, window="AudioWindowHanning256", device=0):
+    """`AnalyzeFFT256IQ(n)` is the reference's constructor (FFTIQ.h:55-58): BlackmanNuttall256, naverage 8."""
+
+    def __init__(self, n_channels, naverage=8, window="AudioWindowBlackmanNuttall256", device=0):
         self.lib = _lib.load()
         self.n_channels = n_channels
         h = C.c_void_p()
@@ -34,7 +47,13 @@ class AnalyzeFFT256IQ:
         _lib.check(self.lib.rdsp_spectrum_averageTogether(self.h, int(n)))
 
     def windowFunction(self, window):
-        _lib.check(self.lib.rdsp_spectrum_windowFunction(self.h, WINDOWS[window]))
+        """FFTIQ.h:93-95: a table name, an int16 array of 256 q15 taps (the reference's own argument) or None."""
+        if window is None or isinstance(window, str):
+            _lib.check(self.lib.rdsp_spectrum_windowFunction(self.h, WINDOWS[window or "none"]))
+            return
+        w = np.ascontiguousarray(window, dtype=np.int16)
+        assert w.shape == (256,)
+        _lib.check(self.lib.rdsp_spectrum_windowFunction_table(self.h, w.ctypes.data_as(C.POINTER(C.c_int16))))
 
     def update(self, iq, stream=None):
         """iq: int16 cuda tensor [n_channels, n_blocks*128, 2]; returns uint16-valued int16-storage
@@ -58,7 +77,13 @@ class AnalyzeFFT256IQ:
         f, self._flag = self._flag, False
         return f
 
-    def read(self, channel, binNumber):  # FFTIQ.h:70-73
-        if binNumber > 255 or self.output is None:
+    def _row(self, channel):
+        return np.ascontiguousarray(self.output[channel].cpu().numpy().view(np.uint16))
+
+    def read(self, channel, binFirst, binLast=None):  # FFTIQ.h:70-73 and :75-86
+        if self.output is None:
             return 0.0
-        return float(int(self.output[channel, binNumber].item()) & 0xFFFF) * (1.0 / 16384.0)
+        row = self._row(channel).ctypes.data_as(C.POINTER(C.c_uint16))
+        if binLast is None:
+            return float(self.lib.rdsp_spectrum_read(row, int(binFirst)))
+        return float(self.lib.rdsp_spectrum_read_range(row, int(binFirst), int(binLast)))

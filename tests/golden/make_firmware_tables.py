@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Constant tables of the reference's own shipped firmware, as test fixtures.
+
+Runs in the build container only (the reference tree does not travel).  Reads
+/root/reference/pre_compiled/RadioDSP_SDR_RX.ino.hex with a small Intel-HEX reader, cuts out the
+read-only tables named below by their offsets in the flat image (first byte of the image = 0) and
+writes tests/golden/firmware_tables.npz.  Data only: no code bytes, never the hex itself.
+
+These are the only reference-held numbers that can pin anything in this build (SURVEY Appendix C,
+DESIGN.md section 2):
+
+  hann256               AudioWindowHanning256,           FFT.windowFunction(...)       INO:144
+  hann1024              AudioWindowHanning1024,          AudioFFT.windowFunction(...)  INO:147
+  blackman_nuttall256   AudioWindowBlackmanNuttall256,   constructor default           FFTIQ.h:56
+  sqrt_guess            sqrt_integer_guess_table[33]     sqrt_uint32_approx            FFTIQ.cpp:105
+  twiddle_q15_4096      CMSIS twiddleCoef_4096_q15 (cos, sin pairs; 3/4 of a turn)     FFTIQ.cpp:82
+  bitrev_1024           CMSIS armBitRevTable[1024]                                      FFTIQ.cpp:82
+  twiddle_f32_256/_128  CMSIS twiddleCoef_256 / _128 (arm_cfft_f32, CONV:291,309)
+  biquad_sets           15 x {b0,b1,b2,a1,a2} x 4: the engine's IIR audio filters       CTL:153-177
+  hilbert_half64        64 odd taps of one side of the engine's Hilbert transformer
+  sine257               sin(2 pi k / 256), k = 0..256: the engine's oscillator table
+
+Each entry was located by its content (a symmetric 256-entry int16 table that starts 0, 5, 20, 45
+is a Hann window whatever it is called); the names are those of the libraries' published headers.
+"""
+import os
+import sys
+
+import numpy as np
+
+HEX = "/root/reference/pre_compiled/RadioDSP_SDR_RX.ino.hex"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "firmware_tables.npz")
+
+# name: (image offset, count, dtype)
+TABLES = {
+    "blackman_nuttall256": (0x1E8F4, 256, "<i2"),
+    "hann1024": (0x1EAF4, 1024, "<i2"),
+    "hann256": (0x1F2F4, 256, "<i2"),
+    "sqrt_guess": (0x1F558, 33, "<u2"),
+    "twiddle_f32_256": (0x1F92C, 512, "<f4"),
+    "twiddle_q15_4096": (0x2012C, 6144, "<i2"),
+    "bitrev_1024": (0x2312C, 1024, "<u2"),
+    "twiddle_f32_128": (0x2392C, 256, "<f4"),
+    "biquad_sets": (0x1DCBC, 15 * 20, "<f4"),
+    "hilbert_half64": (0x1DCBC + 4 * 300, 64, "<f4"),
+    "sine257": (0x1DCBC + 4 * 364, 257, "<f4"),
+}
+
+
+def read_ihex(path):
+    """Intel HEX -> (lowest address, flat bytes).  Record types 00 data, 01 end, 02/04 base."""
+    mem = {}
+    base = 0
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line.startswith(":"):
+                continue
+            rec = bytes.fromhex(line[1:])
+            if sum(rec) & 0xFF:
+                raise ValueError("checksum: " + line)
+            n, addr, typ, data = rec[0], (rec[1] << 8) | rec[2], rec[3], rec[4:-1]
+            assert len(data) == n
+            if typ == 0:
+                for i, b in enumerate(data):
+                    mem[base + addr + i] = b
+            elif typ == 2:
+                base = ((data[0] << 8) | data[1]) << 4
+            elif typ == 4:
+                base = ((data[0] << 8) | data[1]) << 16
+            elif typ == 1:
+                break
+    lo, hi = min(mem), max(mem)
+    img = bytearray(hi - lo + 1)
+    for a, b in mem.items():
+        img[a - lo] = b
+    return lo, bytes(img)
+
+
+def main():
+    if not os.path.exists(HEX):
+        sys.exit("the reference tree is not here: this script runs in the build container only")
+    lo, img = read_ihex(HEX)
+    assert lo == 0x60000000 and len(img) == 206012, (hex(lo), len(img))
+    out = {}
+    for name, (off, count, dt) in TABLES.items():
+        size = np.dtype(dt).itemsize * count
+        out[name] = np.frombuffer(img[off:off + size], dtype=dt).copy()
+        out[name + "_offset"] = np.int64(off)
+    out["biquad_sets"] = out["biquad_sets"].reshape(15, 4, 5)
+    # sanity: what each table is, so a wrong offset cannot slip through
+    i = np.arange(256)
+    assert np.array_equal(out["hann256"], np.minimum(32767, np.round(32768 * 0.5 * (1 - np.cos(2 * np.pi * i / 255)))))
+    assert out["sqrt_guess"][0] == 55109 and out["sqrt_guess"][32] == 0
+    assert out["bitrev_1024"][0] == 0x400 and out["twiddle_q15_4096"][3] == 50
+    assert abs(out["hilbert_half64"][63] + 2 / np.pi) < 1e-4 and out["sine257"][64] == 1.0
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

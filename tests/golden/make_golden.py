@@ -23,8 +23,9 @@ from radiodsp_sdr_rx_amd.chain import synth_iq  # noqa: E402
 
 def make_nodes():
     """graph nodes beside the chain (integer analysers, int16 biquad): nodes.npz holds one input and what
-    the oracle's restatements give for it -- the panadapter analyser (naverage 5, Hann), the audio
-    analyser on the I side (Hann) and `setHighpass(0, 500, 0.5)` + a notch on the I side"""
+    the oracle's restatements give for it -- the panadapter analyser (naverage 5, AudioWindowHanning256), the
+    audio analyser on the I side (AudioWindowHanning1024; both tables as in the reference's firmware image) and
+    `setHighpass(0, 500, 0.5)` + a notch on the I side"""
     import ctypes as C
     lib = oracle_lib.load()
     I16P, F32P = C.POINTER(C.c_int16), C.POINTER(C.c_float)
@@ -87,8 +88,12 @@ def make_nodes():
 
 def main():
     oracle_lib.build()
-    make_nodes()
+    only = set(sys.argv[1:])   # e.g. `make_golden.py nodes` regenerates that fixture alone
+    if not only or "nodes" in only:
+        make_nodes()
     for name, case in GOLDEN_CASES.items():
+        if only and name not in only:
+            continue
         iq = synth_iq(case["channels"], case["blocks"] * 128, cw=case.get("cw", False))
         if case.get("impulses"):
             iq = add_impulses(iq)

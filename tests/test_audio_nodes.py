@@ -149,7 +149,7 @@ def test_oracle_fft1024_known_answers(oracle):
 
 # ---- GPU ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", ["none", "AudioWindowHanning1024", "AudioWindowBlackmanHarris1024"])
+@pytest.mark.parametrize("window", ["none", "AudioWindowHanning1024", "AudioWindowBlackmanHarris1024", "AudioWindowFlattop1024"])
 def test_gpu_fft1024_is_bit_exact(rdsp, oracle, window):
     import torch
     from radiodsp_sdr_rx_amd.chain import synth_iq
@@ -175,6 +175,41 @@ def test_gpu_fft1024_is_bit_exact(rdsp, oracle, window):
         pos += k
     assert np.array_equal(np.concatenate(got, axis=1), one)
     assert an2.available() and not an2.available()
+
+
+@pytest.mark.gpu
+def test_gpu_fft1024_with_the_firmware_window_by_pointer(rdsp, oracle):
+    """`AudioFFT.windowFunction(AudioWindowHanning1024)` (INO:147) with the table of the reference's firmware
+    image handed over by pointer, an arbitrary table, and NULL; read(bin) / read(first, last)."""
+    import os
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024
+    lib = _bind(oracle.load())
+    lib.orc_fft1024_windowFunction_table.argtypes = [C.c_void_p, I16P]
+    fw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "firmware_tables.npz"))
+    nch, nblk = 3, 28
+    audio = synth_iq(nch, nblk * 128)[..., 1].copy()
+    dev = torch.from_numpy(audio).cuda()
+    for tab in (fw["hann1024"], np.random.default_rng(8).integers(-32768, 32768, 1024).astype(np.int16), None):
+        an = AnalyzeFFT1024(nch, window="AudioWindowBlackmanHarris1024")
+        an.windowFunction(tab)
+        got = an.update(dev).cpu().numpy().view(np.uint16)
+        for c in range(nch):
+            s = lib.orc_fft1024_create(2)
+            lib.orc_fft1024_windowFunction_table(s, tab.ctypes.data_as(I16P) if tab is not None else None)
+            want = []
+            for b in range(nblk):
+                if lib.orc_fft1024_update(s, np.ascontiguousarray(audio[c, b * 128:(b + 1) * 128]).ctypes.data_as(I16P)):
+                    want.append(np.ctypeslib.as_array(lib.orc_fft1024_output(s), (512,)).copy())
+            lib.orc_fft1024_destroy(s)
+            assert np.array_equal(got[c], np.stack(want))
+        if tab is fw["hann1024"]:
+            named = AnalyzeFFT1024(nch, window="AudioWindowHanning1024").update(dev).cpu().numpy().view(np.uint16)
+            assert np.array_equal(named, got)
+    row = got[1, -1]
+    assert an.read(1, 40) == row[40] / 16384.0 and an.read(1, 512) == 0.0
+    assert an.read(1, 30, 34) == float(np.float32(int(row[30:35].sum()))) / 16384.0     # inclusive in the Teensy library
 
 
 @pytest.mark.gpu

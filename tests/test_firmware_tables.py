@@ -1,0 +1,199 @@
+"""The reference-held pins: constant tables cut out of the reference's own shipped firmware image
+(tests/golden/firmware_tables.npz, made by tests/golden/make_firmware_tables.py in the build
+container) against the generators of the product (host C in librdsp_hip.so, no GPU needed) and of
+the oracle.  These are the only numbers in this repository that come from the reference itself."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+I16P = C.POINTER(C.c_int16)
+U16P = C.POINTER(C.c_uint16)
+
+
+@pytest.fixture(scope="module")
+def fw():
+    return np.load(os.path.join(HERE, "golden", "firmware_tables.npz"))
+
+
+@pytest.fixture(scope="module")
+def plib(rdsp):
+    lib = rdsp.load()
+    lib.rdsp_q15_twiddles.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+    lib.rdsp_q15_twiddles.restype = None
+    lib.rdsp_sqrt_guess_table.restype = U16P
+    return lib
+
+
+def _olib(oracle):
+    lib = oracle.load()
+    lib.orc_window_q15_n.argtypes = [C.c_int, C.c_int, I16P]
+    lib.orc_twiddle_q15_4096.argtypes = [I16P]
+    lib.orc_sqrt_guess_table.restype = U16P
+    lib.orc_sqrt_uint32_approx.restype = C.c_uint32
+    lib.orc_sqrt_uint32_approx.argtypes = [C.c_uint32]
+    lib.orc_sqrt_uint32.restype = C.c_uint32
+    lib.orc_sqrt_uint32.argtypes = [C.c_uint32]
+    lib.orc_cfft_radix4_q15_n.argtypes = [I16P, C.c_int]
+    return lib
+
+
+PINNED_WINDOWS = [("hann256", 1, 256), ("hann1024", 1, 1024), ("blackman_nuttall256", 3, 256)]
+
+
+@pytest.mark.parametrize("name,wid,n", PINNED_WINDOWS)
+def test_window_tables_equal_the_firmware_image(fw, plib, oracle, name, wid, n):
+    """AudioWindowHanning256 (INO:144), AudioWindowHanning1024 (INO:147) and the constructor's default
+    AudioWindowBlackmanNuttall256 (FFTIQ.h:56): product and oracle generators reproduce the image's tables."""
+    want = fw[name]
+    assert want.shape == (n,) and want.dtype == np.int16
+    got = np.zeros(n, np.int16)
+    plib.rdsp_window_q15_n(wid, n, got.ctypes.data_as(I16P))
+    assert np.array_equal(got, want)
+    got_o = np.zeros(n, np.int16)
+    _olib(oracle).orc_window_q15_n(wid, n, got_o.ctypes.data_as(I16P))
+    assert np.array_equal(got_o, want)
+    # what rounds 1-4 generated instead, for the record: lround(32767 w(i / N))
+    old = np.round(32767 * 0.5 * (1 - np.cos(2 * np.pi * np.arange(n) / n))) if wid == 1 else None
+    if old is not None:
+        assert np.abs(old - want).max() in (309, 77)
+
+
+def test_unpinned_windows_are_sane_and_agree_between_product_and_oracle(plib, oracle):
+    olib = _olib(oracle)
+    for wid in range(1, 12):
+        for n in (256, 1024):
+            a, b = np.zeros(n, np.int16), np.zeros(n, np.int16)
+            plib.rdsp_window_q15_n(wid, n, a.ctypes.data_as(I16P))
+            olib.orc_window_q15_n(wid, n, b.ctypes.data_as(I16P))
+            assert np.abs(a.astype(int) - b.astype(int)).max() <= 1, wid   # two libm evaluations of the same formula
+            assert np.array_equal(a, a[::-1]) or np.abs(a.astype(int) - a[::-1].astype(int)).max() <= 1
+            assert a.max() >= 32600 and a.min() >= (-2400 if wid == 6 else 0) and a[0] < 3000   # flat-top has negative side lobes
+
+
+def test_q15_twiddles_equal_the_firmware_image(fw, plib, oracle):
+    """twiddleCoef_4096_q15 (arm_cfft_radix4_q15, FFTIQ.cpp:82): floor(32768 x) clamped; the 256- and
+    1024-point plans read it with stride 16 and 4 (arm_cfft_radix4_init_q15)."""
+    want = fw["twiddle_q15_4096"]
+    t = np.zeros(6144, np.int16)
+    _olib(oracle).orc_twiddle_q15_4096(t.ctypes.data_as(I16P))
+    assert np.array_equal(t, want)
+    for n in (256, 1024):
+        tw = np.zeros(3 * n // 4, np.uint32)
+        plib.rdsp_q15_twiddles(n, tw.ctypes.data_as(C.POINTER(C.c_uint32)))
+        cos = (tw & 0xFFFF).astype(np.uint16).view(np.int16)
+        sin = (tw >> 16).astype(np.uint16).view(np.int16)
+        step = 4096 // n
+        assert np.array_equal(cos, want[0::2][::step][:len(cos)])
+        assert np.array_equal(sin, want[1::2][::step][:len(sin)])
+        assert sin[:3 * (n // 4 - 1) + 1].min() > -32768     # every entry a plan reads (m <= 3 (n/4 - 1)): the kernels negate it
+
+
+def test_bit_reversal_walk_with_the_images_table_is_a_bit_reversal(fw):
+    """arm_bitreversal_q15 replayed with armBitRevTable from the image: the oracle and the kernels apply the
+    permutation directly."""
+    tab = fw["bitrev_1024"]
+    for n, factor, first in ((256, 16, 15), (1024, 4, 3)):   # pBitRevTable = &armBitRevTable[factor - 1]
+        src = list(range(n))
+        half = n // 2
+        j, k = 0, first
+        for i in range(0, half - 1, 2):
+            if i < j:
+                src[i], src[j] = src[j], src[i]
+                src[i + half + 1], src[j + half + 1] = src[j + half + 1], src[i + half + 1]
+            src[i + 1], src[j + half] = src[j + half], src[i + 1]
+            j = int(tab[k])
+            k += factor
+        bits = n.bit_length() - 1
+        want = [int(format(i, f"0{bits}b")[::-1], 2) for i in range(n)]
+        assert src == want
+
+
+def test_sqrt_guess_table_and_the_literal_routine(fw, plib, oracle):
+    """sqrt_uint32_approx (FFTIQ.cpp:105): guess table of the image, two Newton steps; product host twin and
+    oracle agree everywhere tried, and the literal sits -1 ... +8 counts from the exact floor root."""
+    olib = _olib(oracle)
+    want = fw["sqrt_guess"]
+    assert np.array_equal(np.ctypeslib.as_array(plib.rdsp_sqrt_guess_table(), (33,)), want)
+    assert np.array_equal(np.ctypeslib.as_array(olib.orc_sqrt_guess_table(), (33,)), want)
+    rng = np.random.default_rng(3)
+    xs = np.unique(np.concatenate([np.arange(0, 70000), (np.arange(1, 65536, 7).astype(np.uint64) ** 2),
+                                   rng.integers(0, 2 ** 32, 60000, dtype=np.uint64),
+                                   (2.0 ** rng.uniform(0, 32, 40000)).astype(np.uint64),
+                                   np.array([2 ** 31, 2 ** 32 - 1], np.uint64)]))
+    xs = xs[xs < 2 ** 32]
+    lo, hi = 0, 0
+    for x in xs:
+        x = int(x)
+        a = int(olib.orc_sqrt_uint32_approx(x))
+        assert a == int(plib.rdsp_sqrt_uint32_approx(x)), x
+        n = int(want[32 if x == 0 else 32 - x.bit_length()])    # the routine as published, in Python
+        if n:
+            n = (x // n + n) // 2
+            n = (x // n + n) // 2
+        assert a == n, x
+        e = int(olib.orc_sqrt_uint32(x))
+        lo, hi = min(lo, a - e), max(hi, a - e)
+    print(f"sqrt_uint32_approx - floor(sqrt): {lo} ... +{hi}")
+    assert lo >= -1 and hi <= 10
+    assert int(olib.orc_sqrt_uint32_approx(0)) == 0 and int(olib.orc_sqrt_uint32_approx(3)) == 2
+
+
+def test_read_range_keeps_the_loop_as_written(plib, oracle):
+    """FFTIQ.h:75-86: `do { sum += output[binFirst++]; } while (binFirst < binLast);` never adds binLast
+    (unless the two are equal); arguments swap, clamp to 255, bins > 255 read 0."""
+    out = (np.arange(256, dtype=np.uint16) * 7 + 3)
+    p = out.ctypes.data_as(U16P)
+    k = 1.0 / 16384.0
+    assert plib.rdsp_spectrum_read(p, 5) == out[5] * k and plib.rdsp_spectrum_read(p, 256) == 0.0
+    assert plib.rdsp_spectrum_read_range(p, 10, 14) == float(out[10:14].sum()) * k        # 10..13
+    assert plib.rdsp_spectrum_read_range(p, 14, 10) == float(out[10:14].sum()) * k        # swapped
+    assert plib.rdsp_spectrum_read_range(p, 7, 7) == out[7] * k                           # the do-while's one pass
+    assert plib.rdsp_spectrum_read_range(p, 250, 400) == float(out[250:255].sum()) * k    # clamp to 255, 255 not added
+    assert plib.rdsp_spectrum_read_range(p, 300, 400) == 0.0
+    # the 1024-point analyser of the Teensy library includes binLast
+    o2 = (np.arange(512, dtype=np.uint16) * 3 + 1)
+    p2 = o2.ctypes.data_as(U16P)
+    assert plib.rdsp_fft1024_read_range(p2, 10, 14) == float(o2[10:15].sum()) * k
+    assert plib.rdsp_fft1024_read(p2, 512) == 0.0
+    # oracle's restatement of the same lines
+    olib = oracle.load()
+    olib.orc_fft256iq_create.restype = C.c_void_p
+    olib.orc_fft256iq_create.argtypes = [C.c_int, C.c_int]
+    olib.orc_fft256iq_read_range.restype = C.c_float
+    olib.orc_fft256iq_read_range.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    olib.orc_fft256iq_output.restype = U16P
+    olib.orc_fft256iq_output.argtypes = [C.c_void_p]
+    olib.orc_fft256iq_destroy.argtypes = [C.c_void_p]
+    s = olib.orc_fft256iq_create(1, 0)
+    np.ctypeslib.as_array(olib.orc_fft256iq_output(s), (256,))[:] = out
+    for a, b in ((10, 14), (14, 10), (7, 7), (250, 400), (300, 400), (0, 255)):
+        assert olib.orc_fft256iq_read_range(s, a, b) == plib.rdsp_spectrum_read_range(p, a, b)
+    olib.orc_fft256iq_destroy(s)
+
+
+def test_float_twiddles_of_the_image_are_the_float_cosines(fw):
+    """twiddleCoef_256 / _128 (arm_cfft_f32, CONV:291,309): float32 cos / sin of 2 pi k / N to the last bit but
+    for entries that are zero in exact arithmetic -- nothing a float FFT restatement could be pinned by beyond
+    'its twiddles are correctly rounded', which the oracle's are."""
+    for n in (256, 128):
+        t = fw[f"twiddle_f32_{n}"].astype(np.float64)
+        k = np.arange(n)
+        assert np.abs(t[0::2] - np.cos(2 * np.pi * k / n)).max() < 6.1e-8
+        assert np.abs(t[1::2] - np.sin(2 * np.pi * k / n)).max() < 6.1e-8
+
+
+def test_engine_tables_in_the_image_are_what_the_docs_say(fw):
+    """The engine's IIR sets (15 x 4 sections), one side of its Hilbert transformer and its 257-entry sine
+    table: evidence about the un-vendored AudioSDR library, not pins of this build's chain."""
+    bq = fw["biquad_sets"]
+    assert bq.shape == (15, 4, 5)
+    assert np.allclose(bq[0, 0], [0.28125435, -0.562494, 0.28125435, 1.9529972, -0.95392203], atol=1e-7)
+    h = fw["hilbert_half64"].astype(np.float64)
+    n = 2 * np.arange(63, -1, -1) + 1                       # odd tap distances 127 ... 1
+    assert np.all(h < 0) and np.abs(h[-4:] * n[-4:] * np.pi / 2 + 1).max() < 0.01   # -2 / (pi n) near the centre (windowed further out)
+    s = fw["sine257"]
+    assert np.array_equal(s, np.sin(2 * np.pi * np.arange(257) / 256).astype(np.float32)) or \
+        np.abs(s - np.sin(2 * np.pi * np.arange(257) / 256)).max() < 1e-7

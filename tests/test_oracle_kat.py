@@ -387,37 +387,3 @@ def test_literal_filter_off_branch_is_a_bug_not_a_bypass(oracle):
     d = np.abs(yb - x).max() / np.abs(x).max()
     print(f"CONV:303 as written: {d:.2f} of the input's peak away from a bypass")
     assert d > 0.2
-
-
-def test_exact_integer_sqrt_against_the_teensy_approximation(oracle):
-    """FFTIQ.cpp:105 calls sqrt_uint32_approx of the Teensy Audio library (utility/sqrt_integer.h: a table guess by
-    the count of leading zeros and two integer Newton steps); the build uses the exact floor square root, which is
-    what keeps the analyser bit-exact between the CPU restatement and the GPU.  The library is not in the tree; its
-    routine is restated in the oracle with a reconstructed guess table (flagged there).  Over the whole range the
-    analyser can produce (sums up to 65535^2) the approximation is never below the exact root minus one and at
-    most 8 counts above it (0.02 %, at the top of the scale; one count below 5000): that is all the build-defined
-    choice can move a spectrum bin by."""
-    import ctypes as C
-    lib = oracle.load()
-    lib.orc_sqrt_uint32_approx.restype = C.c_uint32
-    lib.orc_sqrt_uint32_approx.argtypes = [C.c_uint32]
-    lib.orc_sqrt_uint32.restype = C.c_uint32
-    lib.orc_sqrt_uint32.argtypes = [C.c_uint32]
-    rng = np.random.default_rng(3)
-    xs = np.unique(np.concatenate([np.arange(0, 70000), (np.arange(1, 65536, 7).astype(np.uint64) ** 2),
-                                   rng.integers(0, 65535 ** 2, 60000, dtype=np.uint64),
-                                   (2.0 ** rng.uniform(0, 32, 40000)).astype(np.uint64)]))
-    xs = xs[xs <= 65535 ** 2]
-    worst_abs, worst_rel, worst_small = 0, 0.0, 0
-    for x in xs:
-        a, e = int(lib.orc_sqrt_uint32_approx(int(x))), int(lib.orc_sqrt_uint32(int(x)))
-        assert e * e <= x < (e + 1) * (e + 1)
-        assert a >= e - 1, (x, a, e)
-        d = a - e
-        worst_abs = max(worst_abs, d)
-        if e > 0:
-            worst_rel = max(worst_rel, d / e)
-        if e < 5000:
-            worst_small = max(worst_small, abs(d))
-    print(f"approximate vs exact integer sqrt: at most +{worst_abs} counts, {worst_rel:.2e} relative (e >= 1), {worst_small} below 5000")
-    assert worst_abs <= 10 and worst_small <= 1     # measured 8 and 1

@@ -20,6 +20,11 @@ def _olib(oracle):
     lib.orc_fft256iq_output.argtypes = [C.c_void_p]
     lib.orc_fft256iq_averageTogether.argtypes = [C.c_void_p, C.c_int]
     lib.orc_fft256iq_windowFunction.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_fft256iq_windowFunction_table.argtypes = [C.c_void_p, I16P]
+    lib.orc_fft256iq_read.restype = C.c_float
+    lib.orc_fft256iq_read.argtypes = [C.c_void_p, C.c_uint]
+    lib.orc_fft256iq_read_range.restype = C.c_float
+    lib.orc_fft256iq_read_range.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
     lib.orc_cfft_radix4_q15_256.argtypes = [I16P]
     lib.orc_window_q15.argtypes = [C.c_int, I16P]
     lib.orc_sqrt_uint32.argtypes = [C.c_uint32]
@@ -28,8 +33,13 @@ def _olib(oracle):
 
 
 def oracle_spectra(lib, iq, naverage, window):
-    """iq int16 [n, 2] (n multiple of 128) -> list of uint16[256] spectra, in order."""
-    s = lib.orc_fft256iq_create(naverage, window)
+    """iq int16 [n, 2] (n multiple of 128) -> list of uint16[256] spectra, in order.  window: an id, or an int16
+    table handed over the way the reference does (windowFunction(const int16_t *), FFTIQ.h:93)."""
+    if isinstance(window, np.ndarray):
+        s = lib.orc_fft256iq_create(naverage, 0)
+        lib.orc_fft256iq_windowFunction_table(s, np.ascontiguousarray(window, np.int16).ctypes.data_as(I16P))
+    else:
+        s = lib.orc_fft256iq_create(naverage, window)
     outs = []
     i = np.ascontiguousarray(iq[:, 0])
     q = np.ascontiguousarray(iq[:, 1])
@@ -53,7 +63,70 @@ def test_fixed_point_fft_tracks_float_dft(oracle):
     assert lib.orc_sqrt_uint32(4294967295) == 65535
     w = np.zeros(256, np.int16)
     lib.orc_window_q15(1, w.ctypes.data_as(I16P))
-    assert w[0] == 0 and w[128] == 32767 and np.abs(w[1:].astype(int) - w[:0:-1].astype(int)).max() <= 1
+    assert w[0] == 0 and w[127] == w[128] == 32767 and np.array_equal(w, w[::-1])   # symmetric about 127.5: i / (N - 1)
+    # the published routine in a second, independent form: plain-integer radix-4 DIF with the stage scalings of
+    # arm_radix4_butterfly_q15 written out per component
+    assert np.array_equal(buf, _cmsis_radix4_q15_model(x.reshape(-1), 256))
+    rails = rng.choice(np.array([-32768, 32767], np.int16), size=2048)
+    b2 = rails.copy()
+    lib.orc_cfft_radix4_q15_n.argtypes = [I16P, C.c_int]
+    lib.orc_cfft_radix4_q15_n(b2.ctypes.data_as(I16P), 1024)
+    assert np.array_equal(b2, _cmsis_radix4_q15_model(rails, 1024))                # saturating paths included
+
+
+def _cmsis_radix4_q15_model(buf, n):
+    """Python integers; natural-order radix-4 decimation in frequency, outputs k = 0..3 of a butterfly at
+    base + k L, digit reversal at the end -- the data flow of the GPU kernels, not CMSIS' in-place order."""
+    import os
+    tw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "firmware_tables.npz"))["twiddle_q15_4096"]
+    sat = lambda v: max(-32768, min(32767, v))
+    re = [int(v) for v in buf[0::2]]
+    im = [int(v) for v in buf[1::2]]
+    stages = {256: 4, 1024: 5}[n]
+    L = n // 4
+    for st in range(stages):
+        first, last = st == 0, st == stages - 1
+        for g in range(0, n, 4 * L):
+            for j in range(L):
+                idx = [g + j + k * L for k in range(4)]
+                a, b, c, d = [(re[i] >> 2, im[i] >> 2) if first else (re[i], im[i]) for i in idx]
+                R = (sat(a[0] + c[0]), sat(a[1] + c[1]))
+                S = (sat(a[0] - c[0]), sat(a[1] - c[1]))
+                V = (sat(b[0] + d[0]), sat(b[1] + d[1]))
+                T = (sat(b[0] - d[0]), sat(b[1] - d[1]))
+                if first:
+                    y0 = ((R[0] + V[0]) >> 1, (R[1] + V[1]) >> 1)
+                    y2 = (sat(R[0] - V[0]), sat(R[1] - V[1]))
+                    y1 = (sat(S[0] + T[1]), sat(S[1] - T[0]))
+                    y3 = (sat(S[0] - T[1]), sat(S[1] + T[0]))
+                elif not last:
+                    y0 = (((R[0] + V[0]) >> 1) >> 1, ((R[1] + V[1]) >> 1) >> 1)
+                    y2 = ((R[0] - V[0]) >> 1, (R[1] - V[1]) >> 1)
+                    y1 = ((S[0] + T[1]) >> 1, (S[1] - T[0]) >> 1)
+                    y3 = ((S[0] - T[1]) >> 1, (S[1] + T[0]) >> 1)
+                else:
+                    y0 = ((R[0] + V[0]) >> 1, (R[1] + V[1]) >> 1)
+                    y2 = ((R[0] - V[0]) >> 1, (R[1] - V[1]) >> 1)
+                    y1 = ((S[0] + T[1]) >> 1, (S[1] - T[0]) >> 1)
+                    y3 = ((S[0] - T[1]) >> 1, (S[1] + T[0]) >> 1)
+                ys = [y0, y1, y2, y3]
+                if not last:
+                    for k in (1, 2, 3):
+                        m = k * j * (n // (4 * L)) * (4096 // n)
+                        co, si = int(tw[2 * m]), int(tw[2 * m + 1])
+                        yr, yi = ys[k]
+                        ys[k] = ((co * yr + si * yi) >> 16, (co * yi - si * yr) >> 16)
+                for k in range(4):
+                    re[idx[k]], im[idx[k]] = ys[k]
+        L //= 4
+    out = np.zeros(2 * n, np.int16)
+    for p in range(n):
+        k, q = 0, p
+        for _ in range(stages):
+            k = (k << 2) | (q & 3)
+            q >>= 2
+        out[2 * k], out[2 * k + 1] = re[p], im[p]
+    return out
 
 
 def test_tone_lands_on_the_reference_bin_order(oracle):
@@ -73,7 +146,8 @@ def test_tone_lands_on_the_reference_bin_order(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("naverage,window,calls", [(1, "none", 1), (8, "AudioWindowHanning256", 1),
-                                                    (30, "AudioWindowHanning256", 3), (5, "AudioWindowBlackmanHarris256", 4)])
+                                                    (30, "AudioWindowHanning256", 3), (5, "AudioWindowBlackmanHarris256", 4),
+                                                    (8, "AudioWindowBlackmanNuttall256", 2), (3, "AudioWindowFlattop256", 1)])
 def test_gpu_spectrum_is_bit_exact(rdsp, oracle, naverage, window, calls):
     import torch
     assert torch.cuda.is_available()
@@ -107,6 +181,61 @@ def test_gpu_spectrum_is_bit_exact(rdsp, oracle, naverage, window, calls):
         assert fft.available() and not fft.available()
         assert fft.read(0, 300) == 0.0
         assert fft.read(0, 5) == got[0, -1, 5] / 16384.0
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_with_the_firmware_tables_like_the_sketch(rdsp, oracle):
+    """`FFT.windowFunction(AudioWindowHanning256); FFT.averageTogether(30);` (INO:144-145) with the table the
+    reference's firmware image holds handed over by pointer (FFTIQ.h:93-95), the constructor's own settings
+    (BlackmanNuttall256, naverage 8, FFTIQ.h:55-58) and windowFunction(NULL); read(bin), read(first, last)."""
+    import os
+    import torch
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    from radiodsp_sdr_rx_amd.spectrum import WINDOWS, AnalyzeFFT256IQ, window_q15
+    lib = _olib(oracle)
+    fw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "firmware_tables.npz"))
+    nch, nblk = 4, 61
+    iq = synth_iq(nch, nblk * 128)
+    iq[3] = np.random.default_rng(5).integers(-32768, 32768, size=iq[3].shape).astype(np.int16)
+    dev = torch.from_numpy(iq).cuda()
+    # the constructor's defaults, untouched
+    fft = AnalyzeFFT256IQ(nch)
+    got = fft.update(dev).cpu().numpy().view(np.uint16)
+    for c in range(nch):
+        assert np.array_equal(got[c], np.stack(oracle_spectra(lib, iq[c], 8, fw["blackman_nuttall256"])))
+        assert np.array_equal(got[c], np.stack(oracle_spectra(lib, iq[c], 8, WINDOWS["AudioWindowBlackmanNuttall256"])))
+    # the sketch's setup() calls, table by pointer
+    fft = AnalyzeFFT256IQ(nch)
+    fft.windowFunction(fw["hann256"])
+    fft.averageTogether(30)
+    got = fft.update(dev).cpu().numpy().view(np.uint16)
+    assert got.shape[1] == 2
+    for c in range(nch):
+        assert np.array_equal(got[c], np.stack(oracle_spectra(lib, iq[c], 30, fw["hann256"])))
+    assert np.array_equal(window_q15(1), fw["hann256"])
+    row = got[0, -1]
+    assert fft.read(0, 12) == row[12] / 16384.0
+    assert fft.read(0, 75, 85) == float(np.float32(int(row[75:85].sum()))) / 16384.0     # `while (binFirst < binLast)`: bin 85 is not added
+    assert fft.read(0, 9, 9) == row[9] / 16384.0 and fft.read(0, 300, 400) == 0.0
+    # an arbitrary caller table, then no window at all
+    tab = np.random.default_rng(6).integers(-32768, 32768, 256).astype(np.int16)
+    fft = AnalyzeFFT256IQ(nch, naverage=2)
+    fft.windowFunction(tab)
+    got = fft.update(dev[:, :33 * 128].contiguous()).cpu().numpy().view(np.uint16)
+    fft.windowFunction(None)
+    got2 = fft.update(dev[:, 33 * 128:].contiguous()).cpu().numpy().view(np.uint16)
+    for c in range(nch):
+        o = lib.orc_fft256iq_create(2, 0)
+        lib.orc_fft256iq_windowFunction_table(o, tab.ctypes.data_as(I16P))
+        want = []
+        for b in range(nblk):
+            if b == 33:
+                lib.orc_fft256iq_windowFunction_table(o, None)
+            i, q = np.ascontiguousarray(iq[c, b * 128:(b + 1) * 128, 0]), np.ascontiguousarray(iq[c, b * 128:(b + 1) * 128, 1])
+            if lib.orc_fft256iq_update(o, i.ctypes.data_as(I16P), q.ctypes.data_as(I16P)):
+                want.append(np.ctypeslib.as_array(lib.orc_fft256iq_output(o), (256,)).copy())
+        lib.orc_fft256iq_destroy(o)
+        assert np.array_equal(np.concatenate([got[c], got2[c]]), np.stack(want))
 
 
 @pytest.mark.gpu
