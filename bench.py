@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the K2 / K4 / K5 legs that follow the headline leg of the default run")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
-    ap.add_argument("--lib", default=os.environ.get("RDSP_BENCH_LIB"),
+    ap.add_argument("--lib", default=None,   # a flag only: no environment variable can put another library under the metric run
                     help="A/B runs: another build of librdsp_hip.so (default: the in-tree one); named in the JSON line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction / JSON plumbing only, no device work (CPU-side test of --gpus N)")

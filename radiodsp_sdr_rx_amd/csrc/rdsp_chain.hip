@@ -1512,7 +1512,7 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
   memset(&h, 0, sizeof(h));
   h.magic = kStateMagic; h.version = kStateVersion;
   h.has_slip = c->slip_prev_on ? 1 : 0;
-  h.fir_fd = c->fir_mode == 2 ? 1 : (c->fir_mode == 0 ? 0 : 2);
+  h.fir_fd = !c->d_fd_mask ? 0 : (c->fir_mode == 2 ? 1 : (c->fir_mode == 0 ? 0 : 2)); /* decim 1: no decimator */
   h.n_channels = n_channels; h.fft_l = c->N; h.decim = c->decim;
   h.has_sam = c->d_sam != nullptr; h.has_iir = c->d_iir_state != nullptr;
   h.old_nr_level = c->old_nr_level; h.n_in = c->n_in;

@@ -240,7 +240,7 @@ int rdsp_estimate_iq_slip(const int16_t *iq, size_t n_samples, int *slip, double
   double *re = (double *)malloc(sizeof(double) * 2 * (size_t)n);
   if (!re) {
     rdsp_set_error("rdsp_estimate_iq_slip: out of memory (%d-point transform)", n);
-    return RDSP_ERR_INVALID;
+    return RDSP_ERR_NOMEM;
   }
   double *im = re + n;
   static const int hyp[3] = {0, 1, -1};

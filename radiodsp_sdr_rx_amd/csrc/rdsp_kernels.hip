@@ -1013,34 +1013,45 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
     }
     /* ---- A2: phasors of this lane's P quad columns (sample 4 q + r of a quad follows by rot_r) */
     const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * VAL - 64 + lane); /* absolute index of column 0 */
-    float2 pj[NC];
-    {
-      float2 b1 = make_float2(1.f, 0.f);
-      if (G.dphi != 0u) b1 = nco_phasor_alu((nq + 256u) * G.dphi);
-      /* Without PRE the launch code guarantees one gain for I and Q, history included: it rides on the
-       * phasors (two packed multiplies per frame) instead of on every sample (32); x (g ph) = (x g) ph
-       * to the bit when g is a power of two -- unit input gain -- and to an ulp otherwise */
-      if constexpr (!PRE) b1 = make_float2(b1.x * p.scale_i, b1.y * p.scale_i);
-      pj[1] = b1;
-      if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotq1);
-      if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotq2);
-#pragma unroll
-      for (int j = 4; j < NC; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
-      /* column 0: history of the previous call in frame 0 (mixed with the increment it came in
-       * with), else one column before b1 */
-      if (fr == 0) {
-        pj[0] = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
-        if constexpr (!PRE) pj[0] = make_float2(pj[0].x * p.scale_i, pj[0].y * p.scale_i);
-      } else {
-        pj[0] = cmulc_uniform(b1, G.rotq1);
-      }
-    }
     const bool hist = (fr == 0);
     /* column 0 of the call's first frame is the previous call's samples: they keep the swap flag and
      * the gains they came in with (uniform values, chosen once per frame).  Only the PRE kernels carry
      * this: the launch code picks them for the one call after such a setting changed */
     const float si0 = (PRE && hist) ? p.scale_i_hist : p.scale_i, sq0 = (PRE && hist) ? p.scale_q_hist : p.scale_q;
     const bool swap0 = PRE && (hist ? p.swap_hist != 0 : p.swap_iq != 0);
+    /* Gains.  A column whose I and Q gains are equal carries its gain on the phasor (two packed multiplies per
+     * frame instead of 32 on the samples; x (g ph) = (x g) ph to the bit when g is a power of two -- unit input
+     * gain -- and to an ulp otherwise); a column with two gains (IQ balance) is scaled per sample.  The rule
+     * looks at the column's own gains only, in the kernels with and without PRE alike (without PRE the launch
+     * code guarantees one gain, history included), so how a sample rounds does not depend on which of the two
+     * kernels a call split happens to run it through */
+    const bool fold = !PRE || p.scale_i == p.scale_q, fold0 = !PRE || si0 == sq0;
+    const float gph = fold ? p.scale_i : 1.0f, gph0 = fold0 ? si0 : 1.0f;      /* on the phasor ...           */
+    const float sxi = fold ? 1.0f : p.scale_i, sxq = fold ? 1.0f : p.scale_q;  /* ... or on the samples (x 1.0 is exact) */
+    const float sxi0 = fold0 ? 1.0f : si0, sxq0 = fold0 ? 1.0f : sq0;
+    float2 pj[NC];
+    {
+      float2 b1u = make_float2(1.f, 0.f);
+      if (G.dphi != 0u) b1u = nco_phasor_alu((nq + 256u) * G.dphi);
+      const float2 b1 = make_float2(b1u.x * gph, b1u.y * gph); /* the gain first, the rotations after it */
+      /* column 0: one column before b1, evaluated the same way in every frame -- a frame's phasors are a
+       * function of its absolute position (and the column's own gain), not of where the call began.  Only
+       * behind a retune (the previous call's samples were mixed with another increment) it is evaluated
+       * directly with that increment */
+      if (hist && G.dphi_hist != G.dphi) {
+        const float2 d = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
+        pj[0] = make_float2(d.x * gph0, d.y * gph0);
+      } else if (PRE && gph0 != gph) {
+        pj[0] = cmulc_uniform(make_float2(b1u.x * gph0, b1u.y * gph0), G.rotq1);
+      } else {
+        pj[0] = cmulc_uniform(b1, G.rotq1);
+      }
+      pj[1] = b1;
+      if constexpr (PD > 2) pj[2] = cmul_pinned_u(b1, G.rotq1);
+      if constexpr (PD > 3) pj[3] = cmul_pinned_u(b1, G.rotq2);
+#pragma unroll
+      for (int j = 4; j < NC; j++) pj[j] = cmul_pinned_u(pj[j - 3], G.rotq3);
+    }
 
     /* ---- A1 + A3: four branch transforms, multiply-accumulate with the branch spectra ------- */
     float2 acc[PD];
@@ -1061,9 +1072,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
       for (int j = 0; j < NC; j++) {
         uint32_t w = (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w;
         if (j == 0 ? swap0 : SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
-        float2 x;
-        if constexpr (PRE) x = unpack_iq(w, j == 0 ? si0 : p.scale_i, j == 0 ? sq0 : p.scale_q);
-        else x = make_float2((float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16));
+        float2 x = make_float2((float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16));
+        if constexpr (PRE) x = make_float2(x.x * (j == 0 ? sxi0 : sxi), x.y * (j == 0 ? sxq0 : sxq));
         float2 ph = pj[j];
         if (r > 0) {
           const float2 rr = (r == 1) ? G.rot1 : (r == 2) ? G.rot2 : G.rot3;

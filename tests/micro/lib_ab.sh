@@ -3,7 +3,7 @@
 # (RDSP_BENCH_LIB picks the library; configs via CONFIGS="K3 K2", extra bench flags via BFLAGS)
 mkdir -p gpurun_out
 for rep in 1 2; do for lib in "$@"; do for K in ${CONFIGS:-K3}; do
-  RDSP_BENCH_LIB=$PWD/$lib python bench.py --config $K --steps ${STEPS:-10} --warmup ${WARMUP:-2} --no-cpu-baseline --no-host-io --no-extra-legs $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
+  python bench.py --lib $PWD/$lib --config $K --steps ${STEPS:-10} --warmup ${WARMUP:-2} --no-cpu-baseline --no-host-io --no-extra-legs $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
   python - "$lib" "$K" <<PY
 import json,sys
 d=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])

@@ -3,7 +3,7 @@
 #   REPS=4 CONFIGS="K3" bash tests/micro/lib_ab3.sh variants/a.so variants/b.so
 mkdir -p gpurun_out; : > gpurun_out/ab3.txt
 for rep in $(seq 1 ${REPS:-3}); do for lib in "$@"; do for K in ${CONFIGS:-K3}; do
-  RDSP_BENCH_LIB=$PWD/$lib python bench.py --config $K --steps ${STEPS:-50} --warmup ${WARMUP:-10} --no-cpu-baseline --no-host-io --no-extra-legs $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
+  python bench.py --lib $PWD/$lib --config $K --steps ${STEPS:-50} --warmup ${WARMUP:-10} --no-cpu-baseline --no-host-io --no-extra-legs $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
   python - "$lib" "$K" <<PY | tee -a gpurun_out/ab3.txt
 import json,sys
 d=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])

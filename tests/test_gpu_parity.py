@@ -421,7 +421,8 @@ def test_chain_with_nlms_is_as_close_to_float64_truth_as_the_oracle(rdsp, oracle
 
 
 # ---- streaming state ---------------------------------------------------------------------
-@pytest.mark.parametrize("name,cfg,nblk", [("k2", K1, 64), ("k3", K3, 64), ("k4", K4, 256)])
+@pytest.mark.parametrize("name,cfg,nblk", [("k2", K1, 64), ("k3", K3, 64), ("k4", K4, 256),
+                                           ("k3_odd_nco", dict(K3, nco_hz=12345.678), 64)])
 def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, cfg, nblk):
     """State (FIR history, overlap block, NFloor, AGC, NLMS) is carried in HBM across launches, and the default
     decimator (frequency domain, one granule per frame: every frame's input is a function of the absolute
@@ -445,7 +446,7 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     _, f1, _ = gpu_run(torch_cuda, iq, cfg, calls=1, fir=2)
     _, f4, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, fir=2)
     assert normwise(f4, f1) <= TOL and normwise(f1, a32) <= TOL
-    if name == "k3":  # the other tail kernels carry the same state
+    if name.startswith("k3"):  # the other tail kernels carry the same state
         for tail in TAILS:
             c16, c32, _ = gpu_run(torch_cuda, iq, cfg, calls=1, tail=tail, fir=0)
             d16, d32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls, tail=tail, fir=0)
@@ -453,32 +454,52 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
             assert np.abs(c32 - a32).max() <= 1e-5 * np.abs(a32).max()
 
 
+@pytest.mark.parametrize("nco_hz", [12000.0, 12345.678])
 @pytest.mark.parametrize("name,cfg", [("k2", K1), ("k3", K3), ("usb_2048_agc", dict(fft_l=2048, demod="USB", agc_mode="fast"))])
-def test_default_decimator_gives_the_same_bits_for_random_call_splits(rdsp, torch_cuda, name, cfg):
-    """The library's default (frequency domain, one granule per decimator frame) over random call splits, blanker and
-    a tuning offset change included: bit-identical to one call -- the streaming runner and the graph's engine node
-    pick their own batch sizes and must not change a bit of a recording's audio."""
+def test_default_decimator_gives_the_same_bits_for_random_call_splits(rdsp, torch_cuda, name, cfg, nco_hz):
+    """The library's default (frequency domain, one granule per decimator frame) over random call splits: int16,
+    float32 and the per-channel scalars bit-identical to one call -- the streaming runner and the graph's engine
+    node pick their own batch sizes and must not change a bit of a recording's audio.  The noise blanker is on,
+    and a session of control calls runs at fixed stream positions (which every split therefore has as call
+    boundaries): a retune, a non-power-of-two input gain, an IQ balance, an IQ swap.  nco_hz 12000 at fs 96000 is
+    the degenerate case (every column phasor is exactly +-1 or +-j); 12345.678 is a generic increment, where a
+    frame's column phasors only agree between splits if they are a function of the absolute position alone."""
     torch = torch_cuda
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
     nch, nblk = 4, 128
     iq = synth_iq(nch, nblk * 128)
     iq[:, 5000:5003] = 30000
     rng = np.random.default_rng(17)
+    cfg = dict(cfg, nco_hz=nco_hz)
+    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).granule_blocks
+    n_gran = nblk // gran
+    script = {n_gran // 4: lambda ch: ch.setTuningOffsetHz(nco_hz - 2468.3),
+              n_gran // 2: lambda ch: ch.setInputGain(0.7),
+              5 * n_gran // 8: lambda ch: ch.swapIQ(True),
+              3 * n_gran // 4: lambda ch: ch.setIQgainBalance(1.02),
+              7 * n_gran // 8: lambda ch: (ch.setIQgainBalance(1.0), ch.swapIQ(False), ch.setInputGain(1.3))}
 
     def run(cuts):
         ch = Chain(nch, max_blocks_per_call=nblk, fir_variant=-1, **cfg)
         ch.enableNoiseBlanker()
-        o = []
-        for a, b in zip([0] + cuts, cuts + [nblk]):
-            o.append(ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, a * 128:b * 128])).cuda()).cpu().numpy())
-        return np.concatenate(o, 1), ch.scalars()
+        o, f = [], []
+        edges = sorted(set(cuts) | set(script))
+        for a, b in zip([0] + edges, edges + [n_gran]):
+            if a in script:
+                script[a](ch)
+            part = torch.from_numpy(np.ascontiguousarray(iq[:, a * gran * 128:b * gran * 128])).cuda()
+            x16, x32 = ch.process(part, want_f32=True)
+            torch.cuda.synchronize()
+            o.append(x16.cpu().numpy())
+            f.append(x32.cpu().numpy())
+        return np.concatenate(o, 1), np.concatenate(f, 1), ch.scalars()
 
-    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).granule_blocks
-    one, sc = run([])
+    one, one32, sc = run([])
+    assert np.abs(one32).max() > 0.01
     for trial in range(5):
-        cuts = sorted(set(int(x) * gran for x in rng.integers(1, nblk // gran, size=rng.integers(1, 6))))
-        o, s2 = run(cuts)
-        assert np.array_equal(o, one) and np.array_equal(s2, sc), (name, cuts)
+        cuts = sorted(set(int(x) for x in rng.integers(1, n_gran, size=rng.integers(1, 7))))
+        o, f, s2 = run(cuts)
+        assert np.array_equal(o, one) and np.array_equal(f, one32) and np.array_equal(s2, sc), (name, cuts)
 
 
 @pytest.mark.parametrize("name,cfg,bound", [("k2", K1, 1e-6), ("k3", K3, TOL)])
