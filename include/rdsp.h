@@ -109,7 +109,16 @@ int rdsp_chain_create(const rdsp_chain_config_t *cfg, int n_channels, int device
 void rdsp_chain_destroy(rdsp_chain_t *c);
 int rdsp_chain_channels(const rdsp_chain_t *c);
 /* number of 128-sample input blocks per call must be a multiple of this
- * (N_BLOCKS of CONV:38-39 seen from the input rate) */
+ * (N_BLOCKS of CONV:38-39 seen from the input rate: 8 for FFT_L <= 512 at decim 4) */
+int rdsp_chain_call_unit_blocks(const rdsp_chain_t *c);
+/* The unit a stream is cut in for output bits that do not depend on the cut.  The call unit for the default
+ * decimator, the direct form and decim-1 chains (any call split gives the same bits).  With the 448-sample decimator
+ * frames of rdsp_chain_set_fir_variant(c, 2) -- 14 input blocks a frame -- lcm(14, call unit): 56 blocks for
+ * FFT_L <= 512.  Calls of whole granules are whole frames, the frame grid then sits at absolute stream positions,
+ * and the stream gives the same bits however it is cut into such calls: restricting the call boundaries is how the
+ * reference has the property too (`available() > N_BLOCKS`, CONV:231).  Other multiples of the call unit are
+ * accepted in that form; such a call ends in a partial frame and re-anchors the grid at the next call's first
+ * sample (valid output, rounds differently: <= 3e-7 of the peak). */
 int rdsp_chain_granule_blocks(const rdsp_chain_t *c);
 /* zero all per-channel state (overlap block, FIR history, NLMS, NFloor, AGC) */
 int rdsp_chain_reset(rdsp_chain_t *c, void *stream);
@@ -258,10 +267,14 @@ int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio
  * boundary and every frame's input is a function of the absolute sample position, so a stream gives the same
  * bits however it is cut into calls -- the property the reference has by construction (fixed 128-sample
  * blocks, CONV:231-245).  0: the direct form (packed FMAs): split-invariant too, about 1.3x slower.  2: the
- * frequency domain with 448-sample frames anchored at each call's first sample: 5 transforms per 448 outputs
- * instead of per 256 (the front kernel ~1.4x faster), for callers who do not need split-invariant bits -- another
- * call split frames and rounds differently (2.6e-7 of the output's peak over random splits, 2.8e-6 through K3's
- * recursive stages: tests/test_gpu_parity.py pins both).  bench.py selects 2 and says so in its `config`.  All
+ * frequency domain with 448-sample frames: 5 transforms per 448 outputs instead of per 256 (the front kernel
+ * ~1.4x faster).  The frames start at the call's first sample, so this form has the property for a restricted
+ * set of call boundaries: calls that are multiples of rdsp_chain_granule_blocks() (56 input blocks for FFT_L <=
+ * 512) are whole frames and give the same bits for any split into such calls
+ * (test_throughput_decimator_is_split_invariant_on_whole_frames); any other multiple of the call unit is accepted
+ * and ends in a partial frame -- another split then frames and rounds differently (2.6e-7 of the output's peak
+ * over random splits, 2.8e-6 through K3's recursive stages: tests/test_gpu_parity.py pins both).  bench.py selects 2
+ * with BASELINE.md's 512-block steps (9 frames and a partial one) and says so in its `config`.  All
  * three are the same exact linear convolution with the same taps (RDSP_ERR_UNSUPPORTED for 2 / 4 on decim-1
  * chains, which have no decimator).  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the
  * tail stage shares the SIMDs. */
@@ -353,7 +366,8 @@ int rdsp_audio_writer_close(rdsp_audio_writer_t *w); /* patches the WAV sizes */
  * the blocks delivered (fewer = end of stream; a trailing partial granule is not
  * processed, as the sketch never processes one); sink receives the int16 L,R rows.
  * Uploads, kernels and downloads of consecutive batches overlap (three streams,
- * two pinned slots).  blocks_per_call must be a multiple of the chain's granule;
+ * two pinned slots).  blocks_per_call must be a multiple of the chain's call unit (of
+ * rdsp_chain_granule_blocks() for audio that does not depend on the batch size in every decimator form);
  * max_blocks <= 0 means "until the source ends". */
 typedef int (*rdsp_source_fn)(void *user, int16_t *dst, size_t stride_pairs, int n_blocks);
 typedef int (*rdsp_sink_fn)(void *user, const int16_t *src, size_t stride_pairs, int n_pairs);

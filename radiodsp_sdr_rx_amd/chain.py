@@ -38,11 +38,21 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_create(C.byref(self.cfg), self.n_channels, self.device,
                                               int(max_blocks_per_call), C.byref(h)))
         self.h = h
-        self.granule_blocks = self.lib.rdsp_chain_granule_blocks(self.h)
         if fir_variant is None and self.decim == 4:
             fir_variant = self.default_fir_variant
         if fir_variant is not None:
             self.set_fir_variant(fir_variant)
+
+    @property
+    def call_unit_blocks(self):
+        """128-sample input blocks per call must be a multiple of this (N_BLOCKS of CONV:38-39 at the input rate)"""
+        return self.lib.rdsp_chain_call_unit_blocks(self.h)
+
+    @property
+    def granule_blocks(self):
+        """cut a stream in multiples of this and the bits do not depend on the cut: the call unit, but with 448-sample
+        decimator frames (fir_variant 2) lcm(14, call unit) -- whole frames"""
+        return self.lib.rdsp_chain_granule_blocks(self.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -196,8 +206,9 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 
     def set_fir_variant(self, variant):
-        """stage A3: -1 / 4 frequency domain with granule frames (split-invariant bits, default), 0 the direct
-        form, 2 frequency domain with 448-sample frames (throughput; bits depend on the call split)"""
+        """stage A3: -1 / 4 frequency domain with one-granule frames (split-invariant bits, default), 0 the direct
+        form, 2 frequency domain with 448-sample frames (throughput; split-invariant bits for calls that are
+        multiples of `granule_blocks`, i.e. whole frames)"""
         _lib.check(self.lib.rdsp_chain_set_fir_variant(self.h, int(variant)))
 
     def set_tail_variant(self, lanes_per_channel, matrix_reduce=None):

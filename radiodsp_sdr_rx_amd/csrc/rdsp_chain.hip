@@ -492,11 +492,25 @@ extern "C" int rdsp_chain_channels(const rdsp_chain_t *c) { return c ? c->n_chan
 extern "C" int rdsp_chain_decim(const rdsp_chain_t *c) { return c ? c->decim : 0; }
 extern "C" int rdsp_chain_device(const rdsp_chain_t *c) { return c ? c->device : -1; }
 
-extern "C" int rdsp_chain_granule_blocks(const rdsp_chain_t *c) {
+/* the smallest call: one kernel chunk = 256 output samples; an overlap-save frame needs fft_l/2 of them */
+extern "C" int rdsp_chain_call_unit_blocks(const rdsp_chain_t *c) {
   if (!c) return 0;
-  /* one kernel chunk = 256 output samples; a frame needs fft_l/2 of them */
   const int out_samples = c->hop > 256 ? c->hop : 256;
   return out_samples * c->decim / RDSP_BLOCK;
+}
+/* the unit a stream is cut in for bits that do not depend on the cut.  Default decimator, direct form, decim 1:
+ * the call unit.  448-sample decimator frames (fir_variant 2; 14 input blocks each): the least common multiple of
+ * a frame and the call unit -- calls of whole granules are whole frames, so the frame grid sits at absolute stream
+ * positions whatever the split (the reference restricts its call boundaries the same way: `available() >
+ * N_BLOCKS`, CONV:231) */
+extern "C" int rdsp_chain_granule_blocks(const rdsp_chain_t *c) {
+  if (!c) return 0;
+  const int unit = rdsp_chain_call_unit_blocks(c);
+  if (c->fir_mode != 2 || !c->d_fd_mask) return unit;
+  const int frame = 14; /* 448 outputs x 4 / 128 */
+  int a = unit, b = frame;
+  while (b) { const int t = a % b; a = b; b = t; }
+  return unit / a * frame;
 }
 
 extern "C" int rdsp_chain_reset(rdsp_chain_t *c, void *stream_) {
@@ -603,9 +617,9 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     rdsp_set_error("rdsp_chain_process: bad argument");
     return RDSP_ERR_INVALID;
   }
-  const int gran = rdsp_chain_granule_blocks(c);
+  const int gran = rdsp_chain_call_unit_blocks(c);
   if (n_blocks % gran != 0) {
-    rdsp_set_error("n_blocks %d is not a multiple of the granule %d", n_blocks, gran);
+    rdsp_set_error("n_blocks %d is not a multiple of the call unit %d", n_blocks, gran);
     return RDSP_ERR_NOT_READY;
   }
   if (n_blocks > c->max_blocks) {

@@ -120,7 +120,7 @@ extern "C" rdsp_node_t *rdsp_sdr_node_create(rdsp_graph_t *g, rdsp_chain_t *chai
   SdrNode *s = new SdrNode();
   s->chain = chain;
   s->n_channels = rdsp_chain_channels(chain);
-  s->gran = rdsp_chain_granule_blocks(chain);
+  s->gran = rdsp_chain_call_unit_blocks(chain); /* one call per call unit: a fixed split, the same grid on every run */
   s->decim = rdsp_chain_decim(chain);
   s->have = 0;
   const size_t in_n = (size_t)s->n_channels * s->gran * RDSP_BLOCK_SAMPLES * 2;

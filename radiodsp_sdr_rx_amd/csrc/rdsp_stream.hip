@@ -37,9 +37,9 @@ extern "C" int rdsp_stream_run(rdsp_chain_t *c, rdsp_source_fn source, void *sou
     rdsp_set_error("rdsp_stream_run: bad argument");
     return RDSP_ERR_INVALID;
   }
-  const int gran = rdsp_chain_granule_blocks(c);
+  const int gran = rdsp_chain_call_unit_blocks(c);
   if (blocks_per_call % gran != 0) {
-    rdsp_set_error("blocks_per_call %d is not a multiple of the granule %d", blocks_per_call, gran);
+    rdsp_set_error("blocks_per_call %d is not a multiple of the call unit %d", blocks_per_call, gran);
     return RDSP_ERR_NOT_READY;
   }
   /* the runner's buffers, streams and events live on the chain's device, whatever the calling thread had
@@ -269,9 +269,9 @@ static bool is_pinned_host(const void *p) {
 
 static int stream_pinned(rdsp_chain_t *c, const int16_t *host_iq, size_t in_stride, int64_t n_blocks, int16_t *host_out,
                          size_t out_stride, int blocks_per_call, rdsp_stream_stats_t *stats) {
-  const int gran = rdsp_chain_granule_blocks(c);
+  const int gran = rdsp_chain_call_unit_blocks(c);
   if (blocks_per_call <= 0 || blocks_per_call % gran != 0) {
-    rdsp_set_error("blocks_per_call %d is not a multiple of the granule %d", blocks_per_call, gran);
+    rdsp_set_error("blocks_per_call %d is not a multiple of the call unit %d", blocks_per_call, gran);
     return RDSP_ERR_NOT_READY;
   }
   if (hipSetDevice(rdsp_chain_device(c)) != hipSuccess) {

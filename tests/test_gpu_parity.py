@@ -471,7 +471,7 @@ def test_default_decimator_gives_the_same_bits_for_random_call_splits(rdsp, torc
     iq[:, 5000:5003] = 30000
     rng = np.random.default_rng(17)
     cfg = dict(cfg, nco_hz=nco_hz)
-    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).granule_blocks
+    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).call_unit_blocks
     n_gran = nblk // gran
     script = {n_gran // 4: lambda ch: ch.setTuningOffsetHz(nco_hz - 2468.3),
               n_gran // 2: lambda ch: ch.setInputGain(0.7),
@@ -502,6 +502,53 @@ def test_default_decimator_gives_the_same_bits_for_random_call_splits(rdsp, torc
         assert np.array_equal(o, one) and np.array_equal(f, one32) and np.array_equal(s2, sc), (name, cuts)
 
 
+@pytest.mark.parametrize("nco_hz", [12000.0, 12345.678])
+@pytest.mark.parametrize("name,cfg", [("k2", K1), ("k3", K3), ("k4", K4), ("usb_1024", dict(fft_l=1024, demod="USB", agc_mode="medium"))])
+def test_throughput_decimator_is_split_invariant_on_whole_frames(rdsp, torch_cuda, name, cfg, nco_hz):
+    """rdsp_chain_set_fir_variant(2) (448-sample decimator frames, what bench.py runs): a stream cut into calls that
+    are multiples of rdsp_chain_granule_blocks() = lcm(14 blocks, call unit) is cut at frame boundaries, the frame
+    grid sits at absolute stream positions and int16, float32 and scalars are bit-identical to one call for any
+    such split -- with the blanker on and a retune / gain / balance / swap session at granule positions."""
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    probe = Chain(2, max_blocks_per_call=8, fir_variant=2, **cfg)
+    gran, unit = probe.granule_blocks, probe.call_unit_blocks
+    assert gran % 14 == 0 and gran % unit == 0 and gran == unit * 14 // np.gcd(unit, 14)
+    assert Chain(2, max_blocks_per_call=8, fir_variant=-1, **cfg).granule_blocks == unit
+    n_gran = 8 if gran <= 112 else 4
+    nch, nblk = 3, n_gran * gran
+    iq = synth_iq(nch, nblk * 128, cw=(name == "k4"))
+    iq[:, 7000:7003] = 30000
+    cfg = dict(cfg, nco_hz=nco_hz)
+    script = {n_gran // 4: lambda ch: ch.setTuningOffsetHz(nco_hz - 1357.9),
+              n_gran // 2: lambda ch: (ch.setInputGain(0.7), ch.swapIQ(True)),
+              3 * n_gran // 4: lambda ch: (ch.setIQgainBalance(1.02), ch.swapIQ(False))}
+
+    def run(cuts):
+        ch = Chain(nch, max_blocks_per_call=nblk, fir_variant=2, **cfg)
+        ch.enableNoiseBlanker()
+        o, f = [], []
+        edges = sorted(set(cuts) | set(script))
+        for a, b in zip([0] + edges, edges + [n_gran]):
+            if a in script:
+                script[a](ch)
+            x16, x32 = ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, a * gran * 128:b * gran * 128])).cuda(), want_f32=True)
+            torch.cuda.synchronize()
+            o.append(x16.cpu().numpy())
+            f.append(x32.cpu().numpy())
+        return np.concatenate(o, 1), np.concatenate(f, 1), ch.scalars()
+
+    one, one32, sc = run([])
+    assert np.abs(one32).max() > 0.01
+    rng = np.random.default_rng(23)
+    for trial in range(4):
+        cuts = sorted(set(int(x) for x in rng.integers(1, n_gran, size=rng.integers(1, 5))))
+        o, f, s2 = run(cuts)
+        assert np.array_equal(o, one) and np.array_equal(f, one32) and np.array_equal(s2, sc), (name, cuts)
+    o, f, s2 = run(list(range(1, n_gran)))      # every granule its own call
+    assert np.array_equal(o, one) and np.array_equal(f, one32) and np.array_equal(s2, sc)
+
+
 @pytest.mark.parametrize("name,cfg,bound", [("k2", K1, 1e-6), ("k3", K3, TOL)])
 def test_frequency_domain_decimator_call_split_sensitivity_is_pinned(rdsp, torch_cuda, name, cfg, bound):
     """The throughput form of the frequency-domain decimator (rdsp_chain_set_fir_variant 2; bench.py: 448-sample
@@ -515,7 +562,7 @@ def test_frequency_domain_decimator_call_split_sensitivity_is_pinned(rdsp, torch
     from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
     nch, nblk = 4, 128
     iq = synth_iq(nch, nblk * 128)
-    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).granule_blocks
+    gran = Chain(nch, max_blocks_per_call=nblk, **cfg).call_unit_blocks   # cuts off the frame grid (granule_blocks is 56 here)
     one16, one32, _ = gpu_run(torch, iq, cfg, calls=1, fir=2)
     rng = np.random.default_rng(5)
     worst, worst_lsb = 0.0, 0
