@@ -61,6 +61,9 @@ def parse():
                     help="skip the extra PCIe-inclusive leg (host memory -> chain -> host memory)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the K2 / K4 / K5 legs that follow the headline leg of the default run")
+    ap.add_argument("--spectral-as-written", action="store_true",
+                    help="spectral stage re-synthesis as SPEC:229-232 writes it (atan2 + CMSIS table sine / cosine) instead of "
+                         "the exact-arithmetic equivalent X mag'/mag (rdsp_set_spectral_resynthesis)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the tail stage in-stream (no overlap with the next step's front stage)")
     ap.add_argument("--lib", default=None,   # a flag only: no environment variable can put another library under the metric run
                     help="A/B runs: another build of librdsp_hip.so (default: the in-tree one); named in the JSON line")
@@ -511,6 +514,8 @@ def main():
     fir_variant = int(os.environ.get("RDSP_FIR_VARIANT", "2"))   # A/B runs: -1 = the library default, 0 = the direct form
     chain = Chain(nch, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **cfg)
     chain.set_pipelined(not args.no_pipeline)
+    if args.spectral_as_written:
+        chain.set_spectral_resynthesis(True)
     if args.groups > 1:
         import numpy as np
         chain.set_groups(np.arange(nch, dtype=np.uint16) % args.groups)
@@ -664,8 +669,12 @@ def main():
                 "pipelined": not args.no_pipeline,
                 "decimator": {2: "frequency domain, 448-sample frames (rdsp_chain_set_fir_variant 2)", 0: "direct form (variant 0)"}.get(
                     fir_variant, "frequency domain, one granule per frame (library default, split-invariant)"),
+                "spectral_resynthesis": ("as written (SPEC:229-232: atan2, arm_cos_f32 / arm_sin_f32 table)" if args.spectral_as_written
+                                         else "X mag'/mag (exact-arithmetic equivalent of SPEC:229-232; the as-written form sits 1.7e-5..1.9e-5 away)"),
                 "groups": args.groups,
                 "retune_every_steps": args.retune_every,
+                # A/B switches read from the environment by measurement scripts; a driver run shows an empty dict
+                "ab_switches": {k: v for k, v in os.environ.items() if k.startswith("RDSP_") and k != "RDSP_BENCH_ONE_DEVICE"},
             },
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
                           "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS,

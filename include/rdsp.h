@@ -209,6 +209,13 @@ int rdsp_sdr_setMute(rdsp_chain_t *c, int mute);                  /* INO:177 */
 int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz);       /* NCO side of CTL:447 */
 int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, GEN:111, CTL:237-297 */
 int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* on: 0, 1 (SPEC:112 iNRLevel), 2 (older variant, level unused) */
+/* How the spectral stage rebuilds a bin from its new magnitude (SPEC:221-235).  literal = 1: as the file writes it,
+ * `mag' * arm_cos_f32(phi)`, `mag' * arm_sin_f32(phi)` with `phi = atan2(im, re)` -- CMSIS-DSP's table sine (513
+ * entries, linear interpolation) restated from the published routine.  literal = 0 (default): the exact-arithmetic
+ * equivalent X mag'/mag.  The two sit 1.7e-5 ... 1.9e-5 of the output's peak apart (the table's interpolation error,
+ * (2 pi / 512)^2 / 8), so "within 1e-5 of the reference's CPU path" can only hold for one of them at a time: each form
+ * is tested <= 1e-5 against the oracle evaluating the SAME form (tests/test_gpu_parity.py). */
+int rdsp_set_spectral_resynthesis(rdsp_chain_t *c, int literal);
 
 /* ---- receiver groups: per-group retune / PBT / mode tables -------
  * The sketch has one receiver, so one filter mask, one tuning offset and one

@@ -15,6 +15,7 @@
 #include "rdsp_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -483,7 +484,13 @@ static float orc_sin_table[513];
 static int orc_sin_table_ready = 0;
 static float orc_fast_sin_turns(float in) { /* in: the angle in turns (x / 2 pi), any sign */
   if (!orc_sin_table_ready) {
-    for (int k = 0; k <= 512; k++) orc_sin_table[k] = (float)sin(2.0 * 3.14159265358979323846 * (double)k / 512.0);
+    /* sinTable_f32 as published: decimal literals with eight places ("0.01227154f"), i.e. the float nearest to the
+     * rounded decimal, not to the sine -- the last bit differs for about one entry in five */
+    for (int k = 0; k <= 512; k++) {
+      char lit[32];
+      snprintf(lit, sizeof lit, "%.8f", sin(2.0 * 3.14159265358979323846 * (double)k / 512.0));
+      orc_sin_table[k] = strtof(lit, NULL);
+    }
     orc_sin_table_ready = 1;
   }
   int32_t n = (int32_t)in;
@@ -495,6 +502,10 @@ static float orc_fast_sin_turns(float in) { /* in: the angle in turns (x / 2 pi)
   const float fract = findex - (float)index;
   const float a = orc_sin_table[index], b = orc_sin_table[index + 1];
   return (1.0f - fract) * a + fract * b;
+}
+void orc_arm_sin_table(float *tab513) {
+  (void)orc_fast_sin_turns(0.0f);
+  memcpy(tab513, orc_sin_table, sizeof(orc_sin_table));
 }
 float orc_arm_sin_f32(float x) { return orc_fast_sin_turns(x * 0.159154943092f); }
 float orc_arm_cos_f32(float x) { return orc_fast_sin_turns(x * 0.159154943092f + 0.25f); }

@@ -125,6 +125,7 @@ void orc_set_literal_resynthesis(orc_chain_t *c, int on);
  * bypass the restatement uses: shows what that choice replaces (test infrastructure) */
 void orc_set_literal_filter_off(orc_chain_t *c, int on);
 float orc_arm_sin_f32(float x);
+void orc_arm_sin_table(float *tab513); /* sinTable_f32 as published (eight-place decimal literals) */
 float orc_arm_cos_f32(float x);
 /* SAM PLL loop constants at the decimated rate (build-defined, see rdsp_oracle.c) */
 void orc_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax);

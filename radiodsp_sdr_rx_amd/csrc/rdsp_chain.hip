@@ -95,6 +95,8 @@ struct rdsp_chain {
   bool fence_valid = false;
   float *d_fir_hc = nullptr;
   float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (decim 4 only) */
+  float *d_sin_table = nullptr; /* [513] sinTable_f32 (spectral stage as written, rdsp_set_spectral_resynthesis); made on first use */
+  int spectral_literal = 0;
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
   float *d_scal = nullptr;
@@ -459,7 +461,7 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_sin_table, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_status, c->d_mid, c->d_slip_buf, c->d_slip_carry[0], c->d_slip_carry[1]};
   for (void *p : ptrs)
@@ -704,6 +706,8 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     fp.vad_lo = 30 * c->N / 256; /* STATING_BIN_VAD_ANALISYS, SPEC:34, scaled with FFT_L */
     fp.vad_hi = 180 * c->N / 256;
   }
+  fp.spectral_literal = (c->spectral_literal && cf.spectral_nr == 1) ? 1 : 0; /* SPEC only: the older variant scales the bin (BK_INO:1614-1628) */
+  fp.sin_table = c->d_sin_table;
   fp.to_mid = tail ? 1 : 0;
   fp.agc_on = cf.agc_mode != RDSP_AGC_OFF;
   fp.agc_attack = attack;
@@ -1051,6 +1055,22 @@ extern "C" int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level) {
   if (on < 0 || on > 2) return RDSP_ERR_INVALID;
   c->cfg.spectral_nr = on;
   c->cfg.spectral_level = level;
+  return RDSP_OK;
+}
+
+/* SPEC:226-235 writes the re-synthesis as mag' (arm_cos_f32(phi) + j arm_sin_f32(phi)), phi = atan2(im, re).  0
+ * (default): the exact-arithmetic equivalent X mag'/mag; 1: as written, with CMSIS' table-interpolated sine and
+ * cosine as published (the two are 1.7e-5 - 1.9e-5 of the peak apart: the table's own interpolation error) */
+extern "C" int rdsp_set_spectral_resynthesis(rdsp_chain_t *c, int literal) {
+  NEED(c);
+  if (literal && !c->d_sin_table) {
+    if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+    float tab[513];
+    rdsp_arm_sin_table(tab);
+    HIP_TRY(hipMalloc((void **)&c->d_sin_table, sizeof(tab)));
+    HIP_TRY(hipMemcpy(c->d_sin_table, tab, sizeof(tab), hipMemcpyHostToDevice));
+  }
+  c->spectral_literal = literal ? 1 : 0;
   return RDSP_OK;
 }
 

@@ -284,6 +284,16 @@ void rdsp_design_audio_iir(double f1, double f2, double fs, float *coef20) {
 }
 
 /* NCO: phase increment in turns*2^32; constant rotations for k samples */
+/* sinTable_f32 of CMSIS-DSP's arm_sin_f32 / arm_cos_f32 (SPEC:231-232): 513 entries sin(2 pi k / 512), which the
+ * published source lists as decimal literals with eight places ("0.01227154f") -- the table is the float nearest
+ * to each of THOSE, not to the sine itself (the two differ in the last bit of about one entry in five) */
+void rdsp_arm_sin_table(float *tab513) {
+  for (int k = 0; k <= 512; k++) {
+    const double v = sin(2.0 * kPi * (double)k / 512.0);
+    tab513[k] = (float)(floor(fabs(v) * 1e8 + 0.5) / 1e8 * (v < 0.0 ? -1.0 : 1.0));
+  }
+}
+
 uint32_t rdsp_nco_dphi(double hz, double fs) {
   const double turns = hz / fs;
   const long long q = llround(turns * 4294967296.0);

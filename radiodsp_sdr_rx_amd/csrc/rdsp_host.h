@@ -21,6 +21,7 @@ void rdsp_nco_rot(uint32_t dphi, int k, float *out2);
 float rdsp_lms_mu(int strength);
 void rdsp_sam_constants(double fs_out, float *g1, float *g2, float *wmin, float *wmax);
 void rdsp_set_error(const char *fmt, ...);
+void rdsp_arm_sin_table(float *tab513);          /* sinTable_f32 of arm_sin_f32 / arm_cos_f32 */
 void rdsp_q15_twiddles(int n, uint32_t *out);   /* [3n/4] cos | sin << 16 of 2 pi m / n, twiddleCoef_4096_q15's rule */
 const uint16_t *rdsp_sqrt_guess_table(void);   /* [33] */
 void rdsp_host_fft(double *re, double *im, int n); /* in-place radix-2 forward transform, n a power of two */

@@ -59,6 +59,9 @@ struct RdspFrontParams {
   int spectral_on;         /* 1: SPEC:112-269 (smoothed floor); 2: the older variant of
                               backup/RadioDSP_SDR_RX_Conv.ino:1586-1630 (floor = threshold) */
   float spectral_k;        /* (float)(level*1.5); 3 for the older variant    */
+  int spectral_literal;    /* 1: re-synthesis as SPEC:229-232 writes it: mag' (arm_cos_f32(phi) + j arm_sin_f32(phi)),
+                              phi = atan2(im, re); 0: the exact-arithmetic equivalent X mag'/mag */
+  const float *sin_table;  /* [513] sinTable_f32 of arm_sin_f32 / arm_cos_f32 (rdsp_arm_sin_table)  */
   int vad_lo, vad_hi;      /* inclusive natural bin range                    */
   int to_mid;              /* 1: write mono float audio for the tail kernel  */
   int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */

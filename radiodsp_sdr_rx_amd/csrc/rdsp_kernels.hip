@@ -48,6 +48,45 @@ struct FrontLds {
   static constexpr int TAPS_N = (DECIM == 4) ? (FM ? RDSP_HZ_N / 2 : 128) : 0;
   static constexpr size_t BYTES = (size_t)(XS_N + HB_N + WB_N + TAPS_N) * sizeof(float2) + 64 * sizeof(float);
 };
+/* arm_sin_f32 / arm_cos_f32 of CMSIS-DSP as published (FastMathFunctions): the angle in turns, its fractional
+ * part times 512 as a table index, linear interpolation between neighbouring entries of the 513-entry table.
+ * `in` = x * 0.159154943092f for the sine, + 0.25f for the cosine. */
+__device__ __forceinline__ float arm_fast_sin_turns(float in, const float *tab) {
+  int n = (int)in;
+  if (in < 0.0f) n--;
+  in = in - (float)n;
+  float findex = 512.0f * in;
+  int index = (int)findex;
+  if (index >= 512) { index = 0; findex -= 512.0f; }
+  const float fract = findex - (float)index;
+  const float a = tab[index], b = tab[index + 1];
+  return (1.0f - fract) * a + fract * b;
+}
+/* SPEC:213-217 and 226-235 as written, for the P bins of a thread: the new magnitude (0.2 mag at or under the
+ * floor, mag - floor above it) and the bin rebuilt from it and the original phase,
+ *   phi = atan2(im, re);  re' = mag' arm_cos_f32(phi);  im' = mag' arm_sin_f32(phi).
+ * An opt-in mode (rdsp_set_spectral_resynthesis) inside kernels whose register budget decides their occupancy: the
+ * bins go through the transform's work buffer in LDS -- `slot(e)`: the thread's own entries of the last forward /
+ * first inverse pass -- and ONE rolled loop does the work, so the mode costs the default path
+ * no registers (unrolled in place, sixteen atan2 chains took the 512-point kernel from 176 to 253 VGPRs). */
+template <int P, typename SLOT>
+__device__ __forceinline__ void spec_resynthesize_literal(float2 (&v)[P], float floor_, const float *tab, float2 *wb, SLOT slot) {
+#pragma unroll
+  for (int e = 0; e < P; e++) wb[slot(e)] = v[e];
+#pragma unroll 1
+  for (int e = 0; e < P; e++) {
+    const float2 x = wb[slot(e)];
+    const float pw = fmaf(x.y, x.y, fmaf(x.x, x.x, 1e-30f)); /* the same |X| as the caller's (SPEC:182) */
+    const float m0 = pw * __builtin_amdgcn_rsqf(pw);
+    const float m1 = (m0 <= floor_) ? 0.2f * m0 : m0 - floor_;                     /* SPEC:213-217 */
+    const float turns = atan2f(x.y, x.x) * 0.159154943092f;                        /* SPEC:229 */
+    wb[slot(e)] = make_float2(m1 * arm_fast_sin_turns(turns + 0.25f, tab),         /* SPEC:231 */
+                              m1 * arm_fast_sin_turns(turns, tab));                /* SPEC:232 */
+  }
+#pragma unroll
+  for (int e = 0; e < P; e++) v[e] = wb[slot(e)];
+}
+
 /* ---- A5/A6 + epilogue: one overlap-save frame of H = N/2 new samples ------------------
  * Shared by the front kernels (direct-form and FFT-domain decimator).  fetch(i) returns new
  * sample i of the hop from wherever the producer left it in LDS. */
@@ -113,13 +152,21 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
       nfloor += (th - nfloor) * 0.65f;             /* SPEC:205 */
       nfloor = nfloor > 0.f ? nfloor : 0.f;        /* SPEC:206 */
     }
+    if (p.spectral_literal) { /* rdsp_set_spectral_resynthesis(c, 1): SPEC:213-217 then SPEC:226-235 as written */
+      /* the thread's own P entries of the work buffer: what it read in the last forward pass and writes in the
+       * first inverse pass, so no other lane ever touches them in between (and they are inside the buffer under
+       * either map, also where it is cut into the FIR planes behind their history) */
+      const int own = lb.bi[PL::NP - 1];
+      spec_resynthesize_literal<P>(v, nfloor, p.sin_table, wb, [&](int e) { return own + e; });
+    } else {
 #pragma unroll
-    for (int e = 0; e < P; e++) {
-      /* SPEC:213-217, 226-235: X * mag'/mag with mag' = 0.2 mag at or under the floor and
-       * mag - floor above it, i.e. a gain of 0.2 or 1 - floor/mag (an empty bin stays 0) */
-      const float sc = (mag[e] <= nfloor) ? 0.2f : fmaf(-nfloor, rmag[e], 1.f);
-      v[e].x *= sc;
-      v[e].y *= sc;
+      for (int e = 0; e < P; e++) {
+        /* SPEC:213-217, 226-235: X * mag'/mag with mag' = 0.2 mag at or under the floor and
+         * mag - floor above it, i.e. a gain of 0.2 or 1 - floor/mag (an empty bin stays 0) */
+        const float sc = (mag[e] <= nfloor) ? 0.2f : fmaf(-nfloor, rmag[e], 1.f);
+        v[e].x *= sc;
+        v[e].y *= sc;
+      }
     }
   }
   /* CONV:301: spectrum x mask */
@@ -340,11 +387,16 @@ __device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const
       n = n > 0.f ? n : 0.f;                              /* SPEC:206 */
       return old_variant ? t : n;                         /* BK_INO:1595-1596: no smoothing */
     });
+    if (p.spectral_literal) { /* SPEC:226-235 as written, as in front_frame */
+      const int own = lb.bi[FftPlan<256, 16>::NP - 1];
+      spec_resynthesize_literal<P>(v, mine, p.sin_table, wbg, [&](int e) { return own + e; });
+    } else {
 #pragma unroll
-    for (int e = 0; e < P; e++) {
-      const float sc = (mag[e] <= mine) ? 0.2f : fmaf(-mine, rmag[e], 1.f); /* SPEC:213-217, 226-235 */
-      v[e].x *= sc;
-      v[e].y *= sc;
+      for (int e = 0; e < P; e++) {
+        const float sc = (mag[e] <= mine) ? 0.2f : fmaf(-mine, rmag[e], 1.f); /* SPEC:213-217, 226-235 */
+        v[e].x *= sc;
+        v[e].y *= sc;
+      }
     }
   }
 #pragma unroll
