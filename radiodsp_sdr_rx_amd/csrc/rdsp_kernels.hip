@@ -59,7 +59,8 @@ __device__ __forceinline__ float arm_fast_sin_turns(float in, const float *tab) 
   int index = (int)findex;
   if (index >= 512) { index = 0; findex -= 512.0f; }
   const float fract = findex - (float)index;
-  const float a = tab[index], b = tab[index + 1];
+  const auto gt = (const __attribute__((address_space(1))) float *)tab; /* a global load, not a FLAT one */
+  const float a = gt[index], b = gt[index + 1];
   return (1.0f - fract) * a + fract * b;
 }
 /* SPEC:213-217 and 226-235 as written, for the P bins of a thread: the new magnitude (0.2 mag at or under the
@@ -75,7 +76,7 @@ __device__ __forceinline__ void spec_resynthesize_literal(float2 (&v)[P], float 
   for (int e = 0; e < P; e++) wb[slot(e)] = v[e];
 #pragma unroll 1
   for (int e = 0; e < P; e++) {
-    const float2 x = wb[slot(e)];
+    const float2 x = lds_ld(&wb[slot(e)]);
     const float pw = fmaf(x.y, x.y, fmaf(x.x, x.x, 1e-30f)); /* the same |X| as the caller's (SPEC:182) */
     const float m0 = pw * __builtin_amdgcn_rsqf(pw);
     const float m1 = (m0 <= floor_) ? 0.2f * m0 : m0 - floor_;                     /* SPEC:213-217 */
@@ -84,7 +85,7 @@ __device__ __forceinline__ void spec_resynthesize_literal(float2 (&v)[P], float 
                               m1 * arm_fast_sin_turns(turns, tab));                /* SPEC:232 */
   }
 #pragma unroll
-  for (int e = 0; e < P; e++) v[e] = wb[slot(e)];
+  for (int e = 0; e < P; e++) v[e] = lds_ld(&wb[slot(e)]); /* single ds_read_b64, like the transform's passes */
 }
 
 /* ---- A5/A6 + epilogue: one overlap-save frame of H = N/2 new samples ------------------
