@@ -348,6 +348,21 @@ def cpu_baseline_worker(args):
                       "single_thread_value": one, "single_thread_sample": f"{n1} channels x {nblk} blocks"}))
 
 
+def gather_per_rank(torch, dist, world, elapsed_s, steps, steady_ms):
+    """(max elapsed over ranks, per-rank record).  Every rank's own wall time per step and steady-state period go into
+    the line beside the max, so that a scaling curve below N x can be read: one slow rank (a straggler card at its
+    own power cap) shows as one large entry, host launch overhead as all of them rising with N."""
+    mine = [elapsed_s / steps * 1e3, float(steady_ms) if steady_ms is not None else -1.0]
+    if world <= 1:
+        return elapsed_s, {"ms_per_step": [mine[0]], "ms_per_step_steady": [steady_ms]}
+    t = torch.tensor(mine, dtype=torch.float64)
+    parts = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(parts, t)
+    per = [float(x[0]) for x in parts]
+    steady = [float(x[1]) if float(x[1]) >= 0 else None for x in parts]
+    return max(per) * steps / 1e3, {"ms_per_step": per, "ms_per_step_steady": steady}
+
+
 def dry_run(args, rank, world, dist):
     """No device work: every rank pretends one step takes (1 + rank) ms, then the same barrier /
     max-over-ranks / one-JSON-line protocol as the real run.  Exercised by the CPU-side test of
@@ -361,14 +376,13 @@ def dry_run(args, rank, world, dist):
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank = gather_per_rank(torch, dist, world, elapsed, args.steps, 1.0 + rank)   # the real run's reduction
+    if world > 1:
         dist.destroy_process_group()
     if rank == 0:
         line = {"metric": "dry run of the launcher (no device work)", "value": None, "unit": "IQ Msamples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": elapsed / args.steps * 1e3, "data": "dry-run",
+                "ms_per_step": elapsed / args.steps * 1e3, "per_rank_ms": per_rank, "data": "dry-run",
                 "config": {"workload": f"{args.config}: {kc_channels} channels/GPU (not run)",
                            "sharding": f"channels x{world}, no collectives"}}
         if world > 1 and args.config == "K3":   # the shape of the second leg of a real N > 1 run
@@ -377,6 +391,8 @@ def dry_run(args, rank, world, dist):
         print(json.dumps(line))
 
 
+DECIMATOR_TEXT = {2: "frequency domain, 448-sample frames (rdsp_chain_set_fir_variant 2)", 0: "direct form (variant 0)",
+                  -1: "frequency domain, one granule per frame (library default, split-invariant for any call split)"}
 WORKLOAD_TEXT = {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
                  "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
                  "K4": "NCO mix + 256-tap polyphase /4 + 4096-pt overlap-save CW filter (2049 taps) + AGC",
@@ -393,7 +409,7 @@ def dominant_kernel(fname, front_avg, tail_avg, decim):
     return fname, front_avg, algorithmic_bytes_per_sample(decim)
 
 
-def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant, barrier, iq=None):
+def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant, barrier, iq=None, label=None):
     """One more BASELINE.json configuration after the headline leg, timed the same way (inputs resident in HBM,
     warm-up, barrier + synchronize on both sides, max over ranks, per-kernel HIP events): K2 / K4 / the K5
     per-GPU shape, so that the driver's one run carries a number for every GPU configuration."""
@@ -425,17 +441,16 @@ def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_ra
     span, _ = ch.get_timing_span()
     ch.set_timing(False)
     fname = ch.front_kernel_name()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank = gather_per_rank(torch, dist, world, elapsed, steps, span / (calls - 1) if calls > 1 else None)
     f_avg, t_avg = f_ms / max(calls, 1), t_ms / max(calls, 1)
     dom, dom_ms, b_own = dominant_kernel(fname, f_avg, t_avg, decim)
     B = algorithmic_bytes_per_sample(decim)
     ach = B * nch * n_samples / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
     ctr, note = load_counters(name)
-    leg = {"config": name, "workload": f"{name}: {nch} channels/GPU x {nblk} blocks of 128 int16 IQ samples per step; {WORKLOAD_TEXT[name]}",
+    leg = {"config": label or name, "workload": f"{name}: {nch} channels/GPU x {nblk} blocks of 128 int16 IQ samples per step; {WORKLOAD_TEXT[name]}",
+           "decimator": DECIMATOR_TEXT.get(fir_variant, DECIMATOR_TEXT[-1]),
            "channels_per_gpu": nch, "channels_total": nch * world, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "per_rank_ms": per_rank,
            "ms_per_step_steady": span / (calls - 1) if calls > 1 else None,
            "value": float(world) * nch * n_samples * steps / elapsed / 1e6, "unit": "IQ Msamples/s",
            "kernels_ms_per_step": {fname: f_avg, "rdsp_tail_kernel": t_avg} if t_avg > 0 else {fname: f_avg},
@@ -589,10 +604,7 @@ def main():
     front_ms, tail_ms, calls = chain.get_timing()
     span_ms, _ = chain.get_timing_span()
     chain.set_timing(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank = gather_per_rank(torch, dist, world, elapsed, args.steps, span_ms / (calls - 1) if calls > 1 else None)
 
     # After the headline leg, the other GPU configurations of BASELINE.json, each timed the same way (extra_leg):
     # N = 1: K2, K4 and the K5 per-GPU shape; N > 1: the K5 shape (8192 channels per GPU, 65 536 at N = 8).  The
@@ -601,10 +613,16 @@ def main():
     legs = {}
     default_shape = args.config == "K3" and not args.channels_per_gpu and args.groups == 1
     if default_shape and not args.no_extra_legs and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
-        which = ["K5"] if world > 1 else ["K2", "K5", "K4"]
+        # K3_default: the headline workload with the library's DEFAULT decimator (one granule per frame), i.e. what a
+        # caller who selects nothing gets; then the other configurations in the headline's form
+        which = ["K5"] if world > 1 else ["K3_default", "K2", "K5", "K4"]
         for name in which:
-            reuse = iq if name == "K2" else None      # K2 reads the headline leg's input (same generator, same channels)
+            reuse = iq if name in ("K2", "K3_default") else None   # same generator, same channels as the headline leg
             try:
+                if name == "K3_default":
+                    legs[name] = extra_leg("K3", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, -1,
+                                           barrier, iq=reuse, label="K3_default")
+                    continue
                 legs[name] = extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant,
                                        barrier, iq=reuse)
             except Exception as e:   # an extra leg never takes the headline down
@@ -653,6 +671,7 @@ def main():
             # (HIP events), i.e. without the pipeline's fill -- the first step's front kernel has no tail kernel
             # to overlap with, ~0.6 ms once per timed region, 0.03 ms per step at --steps 20
             "ms_per_step_steady": span_ms / (calls - 1) if calls > 1 else None,
+            "per_rank_ms": per_rank,   # every rank's own wall time per step and steady-state period (value uses the max)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -667,8 +686,7 @@ def main():
                 "blocks_per_step": nblk,
                 "sharding": f"channels x{world}, no collectives",
                 "pipelined": not args.no_pipeline,
-                "decimator": {2: "frequency domain, 448-sample frames (rdsp_chain_set_fir_variant 2)", 0: "direct form (variant 0)"}.get(
-                    fir_variant, "frequency domain, one granule per frame (library default, split-invariant)"),
+                "decimator": DECIMATOR_TEXT.get(fir_variant, DECIMATOR_TEXT[-1]),
                 "spectral_resynthesis": ("as written (SPEC:229-232: atan2, arm_cos_f32 / arm_sin_f32 table)" if args.spectral_as_written
                                          else "X mag'/mag (exact-arithmetic equivalent of SPEC:229-232; the as-written form sits 1.7e-5..1.9e-5 away)"),
                 "groups": args.groups,
@@ -701,7 +719,13 @@ def main():
             # what "matches the reference's CPU path" means here (tests/parity_util.py; a deviation from the
             # north-star's blanket 1e-5 for the bare-recursion chains, stated where the number is read)
             "tolerance": {"int16_unpack_pack": "bit-exact",
-                          "feed_forward_chains_and_K3": "<= 1e-5 normwise per channel vs the float32 CPU oracle (K3 measured 3e-6..6e-6)",
+                          "feed_forward_chains_and_K3": "<= 1e-5 normwise per channel vs the float32 CPU oracle (K3 measured 3e-6..6e-6), "
+                                                        "the spectral stage's re-synthesis in the form named in config.spectral_resynthesis on both sides",
+                          "spectral_resynthesis_forms": "SPEC:229-232 as written (atan2 + CMSIS table sine / cosine) and the exact-arithmetic "
+                                                        "equivalent X mag'/mag sit 1.7e-5..1.9e-5 of the peak apart (the table's interpolation error); "
+                                                        "each GPU form is tested <= 1e-5 against the oracle evaluating the SAME form; the as-written "
+                                                        "form costs +26 % per K3 step (--spectral-as-written)",
+                          "integer_analysers": "bit-exact; windows, q15 twiddles and sqrt guess table equal the reference's firmware image",
                           "bare_recursion_chains": "DSP-NR / ALS without spectral stage + AGC, IIR bank, SAM: truth-anchored -- "
                                                    "err(gpu, float64 model) <= max(1e-5, 1.5 x err(oracle, float64 model)); gpu vs "
                                                    "oracle up to 1.4e-4 there, the float32 oracle itself 4e-5..1.1e-4 from float64",

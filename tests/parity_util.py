@@ -18,6 +18,23 @@ def normwise(y, ref):
     return max(np.abs(y[c] - ref[c]).max() / max(np.abs(ref[c]).max(), 1e-30) for c in range(len(ref)))
 
 
+def oracle_run(oracle, iq, cfg):
+    """the CPU oracle over every channel of iq: (int16 [ch, n, 2], float32 [ch, n, 2])"""
+    o16, o32 = [], []
+    for c in range(iq.shape[0]):
+        a, b = oracle.OracleChain(**cfg).process(iq[c])
+        o16.append(a)
+        o32.append(b)
+    return np.stack(o16), np.stack(o32)
+
+
+def check_i16(o16, r16):
+    """int16 outputs agree to 1 LSB (a float that differs in its last bits may truncate to the neighbouring integer)"""
+    d = np.abs(o16.astype(np.int32) - r16.astype(np.int32))
+    assert d.max() <= 1, f"int16 differs by {d.max()} LSB"
+    return int((d == 1).sum())
+
+
 def model_run(iq, cfg):
     """float64 evaluation of the same chain (tests/np_model.py), one channel at a time"""
     import np_model

@@ -28,7 +28,7 @@ import numpy as np
 import pytest
 
 from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4, TOL, apply_setup
-from parity_util import assert_truth_anchored, model_run, normwise, q15_of  # noqa: F401 (re-exported)
+from parity_util import assert_truth_anchored, check_i16, model_run, normwise, oracle_run, q15_of  # noqa: F401 (re-exported)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("front_form")]   # every test under both front kernels (conftest.py)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -82,22 +82,6 @@ def gpu_run(torch, iq, cfg, calls=1, tail=None, setup=None, fir=None):
         o32.append(b.cpu().numpy())
     return np.concatenate(o16, 1), np.concatenate(o32, 1), ch
 
-
-def oracle_run(oracle, iq, cfg):
-    o16, o32 = [], []
-    for c in range(iq.shape[0]):
-        a, b = oracle.OracleChain(**cfg).process(iq[c])
-        o16.append(a)
-        o32.append(b)
-    return np.stack(o16), np.stack(o32)
-
-
-
-
-def check_i16(o16, r16):
-    d = np.abs(o16.astype(np.int32) - r16.astype(np.int32))
-    assert d.max() <= 1, f"int16 differs by {d.max()} LSB"
-    return int((d == 1).sum())
 
 
 # ---- A1 / A10: the int16 edges, bit-exact ------------------------------------

@@ -315,6 +315,10 @@ def test_bench_gpus_2_launches_two_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["data"] == "dry-run"
     assert d["ms_per_step"] >= 2.0                     # the MAX over ranks: rank 1 sleeps 2 ms per step
+    # ... and every rank's own time beside it (gloo all_gather), so that a curve below N x can be attributed
+    per = d["per_rank_ms"]
+    assert len(per["ms_per_step"]) == 2 and 1.0 <= per["ms_per_step"][0] < per["ms_per_step"][1]
+    assert max(per["ms_per_step"]) == pytest.approx(d["ms_per_step"]) and per["ms_per_step_steady"] == [1.0, 2.0]
     # N > 1 with the default workload carries the second leg at BASELINE.json configs[4]'s shape
     assert d["k5"]["channels_per_gpu"] == 8192 and d["k5"]["channels_total"] == 16384 and d["k5"]["unit"] == d["unit"]
     # a worker whose world size disagrees with --gpus refuses to run
