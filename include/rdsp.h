@@ -538,6 +538,14 @@ int rdsp_biquad_node_status(rdsp_node_t *n);
 enum { RDSP_AUDIO_KIND_MASK = 0, RDSP_AUDIO_KIND_IIR = 1 };
 int rdsp_sdr_setAudioFilterKind(rdsp_chain_t *c, int kind, void *stream);
 int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out20);
+/* An explicit cascade instead of the designed one: coef20 = four sections {b0, b1, b2, a1, a2} in
+ * arm_biquad_cascade_df1_f32 order (feedback terms added), e.g. one of the fifteen sets of the engine's own audio
+ * filters that the reference's firmware image holds (tests/golden/firmware_tables.npz `biquad_sets`; the first eight
+ * are 150 Hz ... 2.1 / 2.3 / 2.5 / 2.7 / 2.9 / 3.1 / 3.3 / 3.9 kHz band-passes for fs = 44 117.647 Hz, each a 4th-order
+ * elliptic-type high-pass and low-pass pair: zeros on the unit circle at 21 / 50 Hz and at 2.8 fu / 5.4 fu).  Needs
+ * RDSP_AUDIO_KIND_IIR; in force until the next setAudioFilter / setDemodMode of the group. */
+int rdsp_group_setAudioIIRCoefficients(rdsp_chain_t *c, int group, const float *coef20);
+int rdsp_sdr_setAudioIIRCoefficients(rdsp_chain_t *c, const float *coef20);
 
 /* ---- AudioAnalyzeFFT1024 (Teensy Audio library; `AudioAnalyzeFFT1024 AudioFFT` on Q_out_L,
  * INO:57,87): 1024-point frames of the audio stream with hop 512 (blocks collected eight at a time,

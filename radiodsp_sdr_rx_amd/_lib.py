@@ -223,6 +223,8 @@ SYMBOLS = [
     ("rdsp_biquad_node_status", _i, [_vp]),
     ("rdsp_sdr_setAudioFilterKind", _i, [_vp, _i, _vp]),
     ("rdsp_chain_get_iir_coeffs", _i, [_vp, _i, _f32p]),
+    ("rdsp_group_setAudioIIRCoefficients", _i, [_vp, _i, _f32p]),
+    ("rdsp_sdr_setAudioIIRCoefficients", _i, [_vp, _f32p]),
     ("rdsp_window_q15_n", None, [_i, _i, _i16p]),
     ("rdsp_fft1024_create", _i, [_i, _i, _i, C.POINTER(_vp)]),
     ("rdsp_fft1024_destroy", None, [_vp]),

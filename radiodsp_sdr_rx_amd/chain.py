@@ -144,6 +144,14 @@ class Chain:
         """0: SDR.setAudioFilter() filters are overlap-save masks; 1: 8th-order IIR band-passes (biquads)"""
         _lib.check(self.lib.rdsp_sdr_setAudioFilterKind(self.h, int(kind), _stream_ptr(stream)))
 
+    def setAudioIIRCoefficients(self, coef20, group=None):
+        """four sections {b0, b1, b2, a1, a2} (CMSIS order, feedback added) instead of the designed cascade"""
+        a = np.ascontiguousarray(coef20, dtype=np.float32).reshape(20)
+        if group is None:
+            _lib.check(self.lib.rdsp_sdr_setAudioIIRCoefficients(self.h, a.ctypes.data_as(_lib._f32p)))
+        else:
+            _lib.check(self.lib.rdsp_group_setAudioIIRCoefficients(self.h, int(group), a.ctypes.data_as(_lib._f32p)))
+
     def iir_coeffs(self, group=0):
         a = np.zeros(20, np.float32)
         _lib.check(self.lib.rdsp_chain_get_iir_coeffs(self.h, int(group), a.ctypes.data_as(_lib._f32p)))

@@ -1145,6 +1145,35 @@ extern "C" int rdsp_sdr_setAudioFilterKind(rdsp_chain_t *c, int kind, void *stre
   }
   return RDSP_OK;
 }
+/* An explicit cascade for the group's audio filter instead of the designed one -- e.g. one of the engine's own
+ * coefficient sets (the reference's firmware image holds fifteen of them): coef20 = four sections
+ * {b0, b1, b2, a1, a2} in arm_biquad_cascade_df1_f32 order (feedback terms added).  Needs RDSP_AUDIO_KIND_IIR; the
+ * mask keeps the side-band selection it has; the next setAudioFilter / setDemodMode designs a cascade again.
+ * The sections' state is kept (a coefficient change mid-stream, like the sketch's filter menu). */
+extern "C" int rdsp_group_setAudioIIRCoefficients(rdsp_chain_t *c, int group, const float *coef20) {
+  if (check_group(c, group) != RDSP_OK || !coef20) return RDSP_ERR_INVALID;
+  if (c->audio_kind != RDSP_AUDIO_KIND_IIR) {
+    rdsp_set_error("rdsp_group_setAudioIIRCoefficients: select RDSP_AUDIO_KIND_IIR first (rdsp_sdr_setAudioFilterKind)");
+    return RDSP_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < 20; i++)
+    if (!(coef20[i] == coef20[i]) || fabsf(coef20[i]) > 1e6f) {
+      rdsp_set_error("rdsp_group_setAudioIIRCoefficients: coefficient %d is not a finite filter coefficient", i);
+      return RDSP_ERR_INVALID;
+    }
+  GroupState &g = c->groups[(size_t)group];
+  memcpy(g.iir, coef20, sizeof(g.iir));
+  g.iir_dirty = true;
+  return RDSP_OK;
+}
+extern "C" int rdsp_sdr_setAudioIIRCoefficients(rdsp_chain_t *c, const float *coef20) {
+  NEED(c);
+  for (size_t i = 0; i < c->groups.size(); i++) {
+    int rc = rdsp_group_setAudioIIRCoefficients(c, (int)i, coef20);
+    if (rc != RDSP_OK) return rc;
+  }
+  return RDSP_OK;
+}
 extern "C" int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out20) {
   if (check_group(c, group) != RDSP_OK || !out20) return RDSP_ERR_INVALID;
   memcpy(out20, c->groups[(size_t)group].iir, sizeof(float) * 20);

@@ -431,6 +431,87 @@ def test_engine_audio_filter_as_iir_bank_matches_oracle(rdsp, oracle, name):
 
 
 @pytest.mark.gpu
+def test_engine_iir_sets_of_the_firmware_image_run_through_the_product(rdsp, oracle):
+    """The reference's firmware image holds the engine's own audio filters (CTL:153-177):
+    fifteen sets of four {b0, b1, b2, a1, a2} sections for fs = 44 117.647 Hz.  Every set, as found:
+      * through AudioFilterBiquad (setCoefficients per stage; the Teensy convention has a1, a2 in the denominator,
+        the table's CMSIS order has them added) on int16 audio: bit-exact against the oracle's cascade;
+      * the eight band-pass sets through the chain at the reference's native rate (decim 1, fs 44 117.647, USB,
+        RDSP_AUDIO_KIND_IIR with the set loaded by rdsp_sdr_setAudioIIRCoefficients), pipelined, two calls:
+        truth-anchored against the float64 model like every chain that ends in a recursion."""
+    import os
+    import torch
+    import np_model
+    from cases import CONV_LITERAL
+    from cases import TOL
+    from parity_util import normwise
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    from radiodsp_sdr_rx_amd.filters import FilterBiquad
+    lib = _bind(oracle.load())
+    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
+    fw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "firmware_tables.npz"))
+    sets = fw["biquad_sets"]
+    fs = 44117.64706
+    nch, nblk = 5, 48
+    iq = synth_iq(nch, nblk * 128)
+    audio = np.ascontiguousarray(iq[..., 0])
+    dev = torch.from_numpy(audio).cuda()
+    for i in range(15):
+        bq = FilterBiquad(nch, fs=fs)
+        for st in range(4):
+            b0, b1, b2, a1, a2 = (float(v) for v in sets[i, st])
+            bq.setCoefficients(st, [b0, b1, b2, -a1, -a2])
+        assert np.array_equal(bq.coeffs(), sets[i].reshape(-1))                 # float32 in, the same float32 in the kernel
+        got = np.concatenate([bq.update(dev[:, :16 * 128].contiguous()).cpu().numpy(), bq.update(dev[:, 16 * 128:].contiguous()).cpu().numpy()], 1)
+        for c in range(nch):
+            y = oracle_biquad(lib, sets[i].reshape(-1), audio[c].astype(np.float32) / np.float32(32768.0))
+            q = np.zeros(len(y), np.int16)
+            lib.orc_float_to_q15(y.ctypes.data_as(F32P), q.ctypes.data_as(I16P), len(y))
+            assert np.array_equal(got[c], q), (i, c)
+    cfg = dict(CONV_LITERAL, demod="USB", flo_hz=50.0, fhi_hz=4000.0, agc_mode="medium")
+    devq = torch.from_numpy(iq).cuda()
+    for i in range(8):
+        coef = sets[i].reshape(-1).astype(np.float32)
+        ch = Chain(nch, max_blocks_per_call=nblk // 2, **cfg)
+        ch.setAudioFilterKind(1)
+        ch.setAudioIIRCoefficients(coef)
+        ch.set_pipelined(True)
+        outs = [ch.process(devq[:, k * (nblk // 2) * 128:(k + 1) * (nblk // 2) * 128].contiguous(), want_f32=True) for k in range(2)]
+        ch.flush()
+        torch.cuda.synchronize()
+        got = np.concatenate([o[1].cpu().numpy() for o in outs], axis=1)
+        assert np.array_equal(ch.iir_coeffs(0), coef)
+        ref, f64 = [], []
+        for c in range(nch):
+            oc = oracle.OracleChain(**cfg)
+            lib.orc_set_audio_iir(oc.h, 1, 150.0, 2700.0)
+            np.ctypeslib.as_array(lib.orc_chain_iir_coeffs(oc.h), (20,))[:] = coef
+            ref.append(oc.process(iq[c])[1])
+            f64.append(np_model.Model(iir_coef=coef, **cfg).process(iq[c]))
+        # sections with poles at r = 0.995 (the 21 Hz / 150 Hz high-pass pair) turn a last-bit difference of their INPUT
+        # into ~200 of them at the output: the cascade's arithmetic is bit-exact on identical input (above), but the
+        # front end in front of it rounds differently on the two sides, so the yardstick here is 3 x (not 1.5 x) the
+        # oracle's own distance from the float64 evaluation -- both float32 results are draws of the same noise
+        f64a, refa = np.stack(f64), np.stack(ref)
+        den = np.abs(f64a).max(axis=(1, 2))
+        eg = np.abs(got - f64a).max(axis=(1, 2)) / den
+        eo = np.abs(refa - f64a).max(axis=(1, 2)) / den
+        print(f"firmware IIR set {i}: err(gpu, f64) {eg.max():.2e}, err(oracle, f64) {eo.max():.2e}, gpu vs oracle {normwise(got, refa):.2e}")
+        assert eg.max() <= max(TOL, 3.0 * eo.max()) and np.median(eg) <= max(TOL, 2.0 * np.median(eo)), (i, eg, eo)
+    # the loader needs the IIR kind and sane numbers
+    from radiodsp_sdr_rx_amd import RdspError
+    plain = Chain(2, max_blocks_per_call=8, **cfg)
+    with pytest.raises(RdspError) as e:
+        plain.setAudioIIRCoefficients(sets[0].reshape(-1))
+    assert e.value.code == -5
+    plain.setAudioFilterKind(1)
+    bad = sets[0].reshape(-1).copy()
+    bad[7] = np.nan
+    with pytest.raises(RdspError):
+        plain.setAudioIIRCoefficients(bad)
+
+
+@pytest.mark.gpu
 def test_argument_errors_are_loud(rdsp):
     """the new entry points reject what they cannot do, with RDSP_ERR_* and a message"""
     import ctypes as C

@@ -197,3 +197,52 @@ def test_engine_tables_in_the_image_are_what_the_docs_say(fw):
     s = fw["sine257"]
     assert np.array_equal(s, np.sin(2 * np.pi * np.arange(257) / 256).astype(np.float32)) or \
         np.abs(s - np.sin(2 * np.pi * np.arange(257) / 256)).max() < 1e-7
+
+
+def test_engine_iir_sets_against_the_builds_butterworth_design(fw, plib):
+    """SURVEY Appendix C / CTL:153-177: the first eight coefficient sets of the image are the engine's audio
+    band-passes for fs = 44 117.647 Hz, 150 Hz up to 2.1 / 2.3 / 2.5 / 2.7 / 2.9 / 3.1 / 3.3 / 3.9 kHz.  Each is a
+    4th-order high-pass and a 4th-order low-pass with their ZEROS ON THE UNIT CIRCLE (21 and 50 Hz; 2.8 and 5.4
+    times the upper edge) and 0.05 dB of pass-band ripple: elliptic-type sections.  rdsp_design_audio_iir (what
+    RDSP_AUDIO_KIND_IIR designs for a band) is an 8th-order Butterworth band-pass with the same -3 dB edges and its
+    zeros at z = +-1: it has the engine's pass band but 6 dB less attenuation at 1.5 x and 10 dB less at 2 x the upper
+    edge, and 9 dB less at 75 Hz.  A host that wants the engine's own sections loads them
+    (rdsp_sdr_setAudioIIRCoefficients; GPU parity in tests/test_audio_nodes.py)."""
+    from scipy import signal
+    fs = 44117.64706
+    f = np.linspace(1.0, fs / 2, 60000)
+    plib.rdsp_design_audio_iir.argtypes = [C.c_double] * 3 + [C.POINTER(C.c_float)]
+
+    def resp(c20):
+        c = np.asarray(c20, np.float64).reshape(4, 5)
+        sos = np.array([[s[0], s[1], s[2], 1.0, -s[3], -s[4]] for s in c])
+        return 20 * np.log10(np.abs(signal.sosfreqz(sos, worN=f, fs=fs)[1]) + 1e-300)
+
+    at = lambda m, x: m[np.argmin(np.abs(f - x))]
+    uppers = []
+    for i, want_up in enumerate((2100, 2300, 2490, 2680, 2885, 3080, 3295, 3900)):
+        c = fw["biquad_sets"][i].astype(np.float64)
+        for sec in c:                                         # zeros on the unit circle, poles inside it
+            zr, pr = np.roots(sec[:3]), np.roots([1.0, -sec[3], -sec[4]])
+            assert np.allclose(np.abs(zr), 1.0, atol=2e-5) and np.all(np.abs(pr) < 0.999)
+        zf = sorted(abs(np.angle(np.roots(sec[:3])[0])) * fs / (2 * np.pi) for sec in c)
+        m = resp(c)
+        band = f[m >= m.max() - 3.0]
+        lo, up = band.min(), band.max()
+        uppers.append(up)
+        assert abs(lo - 150) < 5 and abs(up - want_up) < 12, (i, lo, up)
+        assert 15 < zf[0] < 25 and 45 < zf[1] < 55 and 2.5 * up < zf[2] < 3.0 * up and zf[3] > 4.0 * up, (i, zf)
+        assert m[(f > 300) & (f < 0.8 * up)].min() > -0.1                      # pass-band ripple
+        mine = np.zeros(20, np.float32)
+        plib.rdsp_design_audio_iir(150.0, float(up), fs, mine.ctypes.data_as(C.POINTER(C.c_float)))
+        mm = resp(mine)
+        b2 = f[mm >= mm.max() - 3.0]
+        assert abs(b2.min() - lo) < 5 and abs(b2.max() - up) < 5             # the same -3 dB band ...
+        d15, d2, d75 = at(mm, 1.5 * up) - at(m, 1.5 * up), at(mm, 2 * up) - m[f > 2 * up].max(), at(mm, 75) - at(m, 75)
+        assert 4.5 < d15 < 7.5 and 8.5 < d2 < 12.5 and 7.0 < d75 < 11.0, (i, d15, d2, d75)   # ... a softer stop band
+    print("engine band-passes, upper -3 dB edges:", [round(u) for u in uppers])
+    # the seven sets behind them are narrower filters whose rows do not all parse as {b0, b1, b2, a1, a2} of a
+    # symmetric section (set 8's fourth row, the sign of a1 in set 9's second): kept as found, every section stable
+    for c in fw["biquad_sets"][8:].astype(np.float64):
+        for sec in c:
+            assert np.all(np.abs(np.roots([1.0, -sec[3], -sec[4]])) < 1.0)
