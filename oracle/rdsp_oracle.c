@@ -376,6 +376,7 @@ struct orc_chain {
   int swap_iq;
   int iq_slip;            /* +1: the I rail is taken one sample late, -1: the Q rail (I2S channel slip) */
   int16_t slip_i, slip_q; /* the previous raw sample */
+  int literal_nr_first_block; /* CONV:326-337 as written for N_BLOCKS > 1: NR on the first 128 samples of a hop only */
   int literal_resynthesis; /* SPEC:221-235 as written: atan2 + table-interpolated arm_cos_f32 / arm_sin_f32 */
   int literal_filter_off;  /* CONV:303 as written: only FFT_length FLOATS (half the spectrum) are copied */
   int nb_on;
@@ -480,6 +481,14 @@ void orc_set_literal_resynthesis(orc_chain_t *c, int on) { c->literal_resynthesi
  * restatement (and the product) treat "filter off" as a full bypass.  on = 1 evaluates the line as written, to show
  * what that choice replaces (tests/test_oracle_kat.py).  Test infrastructure only. */
 void orc_set_literal_filter_off(orc_chain_t *c, int on) { c->literal_filter_off = on ? 1 : 0; }
+/* CONV:326-337 as written: `LMS_NoiseReduction(128, float_buffer_L)` and the `x 1.1; R = L` loop over BUFFER_SIZE touch
+ * the first 128 samples of the hop whatever FFT_L is ("apply the LMS but with single block").  For FFT_L = 256
+ * (N_BLOCKS = 1, the shipped value) that is the whole hop.  For FFT_L = 512 ... 4096 the other N_BLOCKS - 1 blocks of
+ * every hop leave as the filter produced them (L = Re y, R = Im y, no NR, no gain), and the NLMS sees one block in
+ * N_BLOCKS, so its 128-sample decorrelation delay becomes a whole hop.  The restatement (and the product) run every
+ * block through the stage; on = 1 evaluates the lines as written, to show what that choice replaces
+ * (tests/test_oracle_kat.py).  Test infrastructure only. */
+void orc_set_literal_nr_first_block(orc_chain_t *c, int on) { c->literal_nr_first_block = on ? 1 : 0; }
 static float orc_sin_table[513];
 static int orc_sin_table_ready = 0;
 static float orc_fast_sin_turns(float in) { /* in: the angle in turns (x / 2 pi), any sign */
@@ -781,8 +790,8 @@ static void conv_frame(orc_chain_t *c) {
   }
 }
 
-/* post-filter stages on one 128-sample block (L, R in place) */
-static void post_block(orc_chain_t *c, float *L, float *R) {
+/* post-filter stages on one 128-sample block (L, R in place); q: the block's offset inside its hop */
+static void post_block(orc_chain_t *c, float *L, float *R, uint32_t q) {
   const orc_config_t *cf = &c->cfg;
   /* demodulator selection (build-defined) */
   if (cf->demod == ORC_DEMOD_AM) {
@@ -810,8 +819,8 @@ static void post_block(orc_chain_t *c, float *L, float *R) {
     orc_biquad_run(&c->iir, L, ORC_BLOCK);
     for (int i = 0; i < ORC_BLOCK; i++) R[i] = L[i];
   }
-  /* CONV:326-337 (applied per 128-block: deviation from the N_BLOCKS>1 bug) */
-  if (cf->lms_nr > 0) {
+  /* CONV:326-337 (applied per 128-block: deviation from the N_BLOCKS>1 bug, unless orc_set_literal_nr_first_block) */
+  if (cf->lms_nr > 0 && !(c->literal_nr_first_block && q != 0)) {
     if (cf->lms_nr != c->oldNRLevel) { /* CONV:327-330 */
       lms_init(&c->nr, cf->lms_nr);
       c->oldNRLevel = cf->lms_nr;
@@ -932,7 +941,7 @@ int orc_chain_process(orc_chain_t *c, const int16_t *iq, int n_blocks,
         conv_frame(c);
         for (uint32_t q = 0; q < c->hop; q += ORC_BLOCK) {
           float *L = &c->float_buffer_L[q], *R = &c->float_buffer_R[q];
-          post_block(c, L, R);
+          post_block(c, L, R, q);
           for (int j = 0; j < ORC_BLOCK; j++) {
             if (out_f32) {
               out_f32[2 * (produced + j)] = L[j];

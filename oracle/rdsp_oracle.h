@@ -124,6 +124,7 @@ void orc_set_literal_resynthesis(orc_chain_t *c, int on);
 /* CONV:303 as written (filter off copies half the spectrum, the rest of iFFT_buffer stale) instead of the full
  * bypass the restatement uses: shows what that choice replaces (test infrastructure) */
 void orc_set_literal_filter_off(orc_chain_t *c, int on);
+void orc_set_literal_nr_first_block(orc_chain_t *c, int on); /* CONV:326-337 as written for N_BLOCKS > 1 */
 float orc_arm_sin_f32(float x);
 void orc_arm_sin_table(float *tab513); /* sinTable_f32 as published (eight-place decimal literals) */
 float orc_arm_cos_f32(float x);

@@ -90,6 +90,7 @@ SYMBOLS = [
     ("rdsp_chain_granule_blocks", _i, [_vp]),
     ("rdsp_chain_call_unit_blocks", _i, [_vp]),
     ("rdsp_set_spectral_resynthesis", _i, [_vp, _i]),
+    ("rdsp_set_nlms_energy_mode", _i, [_vp, _i]),
     ("rdsp_chain_reset", _i, [_vp, _vp]),
     ("rdsp_doConvolutionalInitialize", _i, [_vp, _vp]),
     ("rdsp_reInitializeFilter", _i, [_vp, _d, _d, _vp]),

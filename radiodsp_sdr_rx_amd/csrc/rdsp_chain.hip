@@ -97,6 +97,7 @@ struct rdsp_chain {
   float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (decim 4 only) */
   float *d_sin_table = nullptr; /* [513] sinTable_f32 (spectral stage as written, rdsp_set_spectral_resynthesis); made on first use */
   int spectral_literal = 0;
+  int nlms_energy_running = 0; /* rdsp_set_nlms_energy_mode */
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
   float *d_scal = nullptr;
@@ -871,6 +872,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     tp.st_status = c->d_status;
     tp.st_status_stride = (size_t)c->n_channels;
     tp.prio = piped ? c->tail_prio : 0;
+    tp.energy_running = c->nlms_energy_running;
     tp.out_i16 = reinterpret_cast<uint32_t *>(d_out);
     tp.out_stride = out_stride;
     tp.out_f32 = reinterpret_cast<float2 *>(d_out_f32);
@@ -928,6 +930,7 @@ extern "C" int rdsp_LMS_NoiseReduction(rdsp_chain_t *c, int n_samples, float *d_
   tp.nr_mode = 2;
   tp.nr_mu = c->nr_mu;
   tp.nr_first = (c->nr_calls == 0);
+  tp.energy_running = c->nlms_energy_running;
   tp.nr_w = c->d_nr_w; tp.nr_prev = c->d_nr_prev; tp.nr_energy = c->d_nr_energy;
   tp.st_scal = c->d_scal;
   tp.st_status = c->d_status;
@@ -1058,6 +1061,16 @@ extern "C" int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level) {
   return RDSP_OK;
 }
 
+/* How both NLMS instances keep arm_lms_norm_f32's window energy.  0 (default): the reference's running difference
+ * (`energy -= x0 * x0; energy += in * in`, NR:73) re-started from the exact 96-sample window sum at every 128-sample
+ * block -- a deliberate deviation: after a loud-to-quiet transition the reference's own recursion can leave energy +
+ * 1.19e-7 <= 0 and lose the channel.  1: the reference's arithmetic, one running difference for the whole stream,
+ * for hosts that want NR:73 as it is, residue and all. */
+extern "C" int rdsp_set_nlms_energy_mode(rdsp_chain_t *c, int running) {
+  NEED(c);
+  c->nlms_energy_running = running ? 1 : 0;
+  return RDSP_OK;
+}
 /* SPEC:226-235 writes the re-synthesis as mag' (arm_cos_f32(phi) + j arm_sin_f32(phi)), phi = atan2(im, re).  0
  * (default): the exact-arithmetic equivalent X mag'/mag; 1: as written, with CMSIS' table-interpolated sine and
  * cosine as published (the two are 1.7e-5 - 1.9e-5 of the peak apart: the table's own interpolation error) */

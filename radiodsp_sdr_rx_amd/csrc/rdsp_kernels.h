@@ -113,6 +113,8 @@ struct RdspTailParams {
   int nr_on, als_mode;     /* als_mode: 0 off, 1 notch (e), 2 peak (y)       */
   int nr_mode;             /* 0: 1.1*y (CONV:334), 2: plain y (NR:73)        */
   int prio;                /* wave priority of the tail kernel (s_setprio), 0..3 */
+  int energy_running;      /* 1: arm_lms_norm_f32's energy as NR:73 runs it -- one running difference for the whole
+                              stream; 0 (default): re-started from the exact window sum at every 128-sample block */
   float *raw_out;          /* non-null: write the stage output as floats
                               [ch][mid_stride] and skip AGC/gain/pack         */
   float nr_mu, als_mu;

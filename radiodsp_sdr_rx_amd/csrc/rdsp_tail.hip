@@ -148,7 +148,7 @@ struct NlmsB {
   /* one 128-sample block.  ring is [previous block | current block], 256 floats, so every sample a
    * step looks back at is at a fixed distance below it (no wrap) */
   template <bool OUT_E>
-  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr, int sub) {
+  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr, int sub, bool running) {
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;
@@ -173,6 +173,10 @@ struct NlmsB {
     }
     float b_base = row_allsum(bb);
     float e_base = row_allsum(ee);
+    /* rdsp_set_nlms_energy_mode(chain, 1): the reference's arithmetic -- the energy of the previous block's last
+     * step carries on (`energy -= x0 * x0; energy += in * in` over the whole stream, NR:73 / arm_lms_norm_f32),
+     * residue and all; B is this kernel's own quantity and stays the window sum */
+    e_base = running ? energy : e_base;
     prepare(cur, 0, sub, mu, e_base, b_base, scr, emin);
 #pragma unroll
     for (int m = -5; m <= 0; m++) P[m & 7] = (m & 1) ? pair_ld(mine, m) : pair_ld_even(mine, m);
@@ -352,18 +356,18 @@ __device__ __forceinline__ void tail_body(const RdspTailParams &p) {
     RDSP_TP(0);
     if constexpr (DUAL) { /* CONV:326-337, then the ALS filter */
       float *o = ringB + RDSP_BLOCK;
-      nr.template block<false>(ringA, p.nr_first && b == 0, p.nr_mu, o, scr, sub);
+      nr.template block<false>(ringA, p.nr_first && b == 0, p.nr_mu, o, scr, sub, p.energy_running != 0);
       wg_sync<1>();
       if (p.nr_mode == 0) { /* CONV:334 */
 #pragma unroll
         for (int k = 0; k < SPL; k++) o[sub * SPL + k] = mul_1p1(o[sub * SPL + k]);
         wg_sync<1>();
       }
-      if (p.als_mode == 1) als.template block<true>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub);
-      else als.template block<false>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub);
+      if (p.als_mode == 1) als.template block<true>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub, p.energy_running != 0);
+      else als.template block<false>(ringB, p.als_first && b == 0, p.als_mu, fin, scr, sub, p.energy_running != 0);
     } else if (has_inst) {
-      if (o_mode == 1) als.template block<true>(ringA, o_first && b == 0, o_mu, fin, scr, sub);
-      else als.template block<false>(ringA, o_first && b == 0, o_mu, fin, scr, sub);
+      if (o_mode == 1) als.template block<true>(ringA, o_first && b == 0, o_mu, fin, scr, sub, p.energy_running != 0);
+      else als.template block<false>(ringA, o_first && b == 0, o_mu, fin, scr, sub, p.energy_running != 0);
     }
     wg_sync<1>();
     RDSP_TP(1);

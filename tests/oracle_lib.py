@@ -144,6 +144,7 @@ def load(path=None):
     lib.orc_set_spectral_nr.argtypes = [vp, C.c_int, C.c_float]
     lib.orc_set_literal_resynthesis.argtypes = [vp, C.c_int]
     lib.orc_set_literal_filter_off.argtypes = [vp, C.c_int]
+    lib.orc_set_literal_nr_first_block.argtypes = [vp, C.c_int]
     lib.orc_arm_sin_f32.restype = C.c_float
     lib.orc_arm_sin_f32.argtypes = [C.c_float]
     lib.orc_arm_cos_f32.restype = C.c_float
@@ -247,6 +248,10 @@ class OracleChain:
     def set_literal_filter_off(self, on):
         """CONV:303 as written: filter off copies only half the spectrum"""
         self.lib.orc_set_literal_filter_off(self.h, int(bool(on)))
+
+    def set_literal_nr_first_block(self, on):
+        """CONV:326-337 as written for N_BLOCKS > 1: NR on the first 128 samples of every hop only"""
+        self.lib.orc_set_literal_nr_first_block(self.h, int(bool(on)))
 
     def set_literal_resynthesis(self, on):
         """SPEC:221-235 as written (atan2 + table sin / cos) instead of X * mag'/mag"""

@@ -336,6 +336,64 @@ def test_lms_noise_reduction_isolated(rdsp, oracle, torch_cuda):
         assert np.abs(wg[c] - w).max() <= 2e-5 * np.abs(w).max()
 
 
+@pytest.mark.parametrize("name", ["nr_30", "k3", "literal_512_nr_40"])
+def test_nlms_running_energy_mode_is_the_references_arithmetic(rdsp, oracle, torch_cuda, name):
+    """rdsp_set_nlms_energy_mode(chain, 1): arm_lms_norm_f32's energy as NR:73 runs it -- one running difference for
+    the whole stream, no re-start from the window sum at block boundaries (the default's deviation).  On ordinary
+    signals: the isolated stage (identical float input) within 1e-5 of the oracle, weights included, and the two modes
+    within 1e-5 of each other; through whole chains as close to the float64 evaluation as the oracle, like every
+    chain that ends in this recursion."""
+    import ctypes as C
+    torch = torch_cuda
+    from radiodsp_sdr_rx_amd.chain import Chain, synth_iq
+    if name == "nr_30":
+        rng = np.random.default_rng(12)
+        nch, nblk = 5, 40
+        n = np.arange(nblk * 128)
+        x = np.stack([0.3 * np.sin(2 * np.pi * (400 + 350 * c) / 24000 * n + c) + 0.05 * rng.standard_normal(len(n))
+                      for c in range(nch)]).astype(np.float32)
+        outs = {}
+        for mode in (0, 1):
+            ch = Chain(nch, **K1)
+            ch.set_nlms_energy_mode(mode)
+            ch.Init_LMS_NR(30)
+            a, b = torch.from_numpy(x[:, :16 * 128].copy()).cuda(), torch.from_numpy(x[:, 16 * 128:].copy()).cuda()
+            ch.LMS_NoiseReduction(a)
+            ch.LMS_NoiseReduction(b)
+            torch.cuda.synchronize()
+            outs[mode] = (np.concatenate([a.cpu().numpy(), b.cpu().numpy()], 1), ch.lms_coeffs(0))
+        lib = oracle.load()
+        for c in range(nch):
+            oc = oracle.OracleChain(**K1)
+            lib.orc_Init_LMS_NR(oc.h, 30)
+            ref = []
+            for k in range(nblk):
+                blk = x[c, k * 128:(k + 1) * 128].copy()
+                lib.orc_LMS_NoiseReduction(oc.h, 128, blk.ctypes.data_as(C.POINTER(C.c_float)))
+                ref.append(blk)
+            ref = np.concatenate(ref)
+            for mode in (0, 1):
+                assert np.abs(outs[mode][0][c] - ref).max() / np.abs(ref).max() <= TOL, (mode, c)
+                assert np.abs(outs[mode][1][c] - oc.lms_coeffs(0)).max() <= 2e-5 * np.abs(oc.lms_coeffs(0)).max()
+        assert not np.array_equal(outs[0][0], outs[1][0])                      # two arithmetics ...
+        assert normwise(outs[1][0], outs[0][0]) <= TOL                         # ... one result on an ordinary signal
+        return
+    cfg = {"k3": K3, "literal_512_nr_40": NLMS_CASES["literal_512_nr_40"]}[name]
+    nch, nblk = 5, 64
+    iq = synth_iq(nch, nblk * 128)
+    ch = Chain(nch, max_blocks_per_call=nblk // 2, **cfg)
+    ch.set_nlms_energy_mode(1)
+    o = [ch.process(torch.from_numpy(np.ascontiguousarray(iq[:, k * (nblk // 2) * 128:(k + 1) * (nblk // 2) * 128])).cuda(), want_f32=True)
+         for k in range(2)]
+    torch.cuda.synchronize()
+    o16 = np.concatenate([a[0].cpu().numpy() for a in o], 1)
+    o32 = np.concatenate([a[1].cpu().numpy() for a in o], 1)
+    r16, r32 = oracle_run(oracle, iq, cfg)
+    assert_truth_anchored(o32, r32, model_run(iq, cfg), name + " (running energy)", o16, r16)
+    if name == "k3":
+        assert normwise(o32, r32) <= TOL
+
+
 def test_nlms_health_word_and_the_energy_anchor(rdsp, oracle, torch_cuda):
     """The reference's NLMS keeps its window energy as a running difference for the whole stream (NR:73 ->
     arm_lms_norm_f32): after a loud-to-quiet transition the rounding residue of everything that went through
@@ -394,6 +452,19 @@ def test_nlms_health_word_and_the_energy_anchor(rdsp, oracle, torch_cuda):
     assert not odead[::2].any() and not oflag[::2].any()
     # measured: 0 <= 1 dead, 9 <= 164 flagged (8 and 90 in round 3, before the anchor)
     assert dead.sum() <= odead.sum() and flagged <= 16 and flagged <= oflag.sum()
+    # rdsp_set_nlms_energy_mode(1) takes the anchor away again: the reference's fragility, for hosts that ask for it
+    run = Chain(nch, **K1)
+    run.set_nlms_energy_mode(1)
+    run.Init_LMS_NR(20)
+    rbuf = torch.from_numpy(x.copy()).cuda()
+    run.LMS_NoiseReduction(rbuf[:, :loud].contiguous())
+    run.LMS_NoiseReduction(rbuf[:, loud:].contiguous())
+    torch.cuda.synchronize()
+    rst = run.get_status()
+    rflag = int(((rst & run.STATUS_NR_ENERGY) != 0).sum())
+    rdead = int((~np.isfinite(run.lms_coeffs(0)).all(axis=1)).sum())
+    print(f"running-energy mode: {rdead} dead, divisor <= 0 on {rflag}")
+    assert not rst[::2].any() and rflag > flagged          # measured 90 against 9 in round 3's un-anchored form
     # the non-finite bit, stickiness and the per-channel cure, on channels killed by an infinite sample
     victims = np.array([3, 64, 637])
     more = (1e-4 * rng.standard_normal((nch, 256))).astype(np.float32)

@@ -387,3 +387,36 @@ def test_literal_filter_off_branch_is_a_bug_not_a_bypass(oracle):
     d = np.abs(yb - x).max() / np.abs(x).max()
     print(f"CONV:303 as written: {d:.2f} of the input's peak away from a bypass")
     assert d > 0.2
+
+
+def test_literal_nr_first_block_shows_what_running_every_block_replaces(oracle):
+    """CONV:326-337 as written: `LMS_NoiseReduction(128, float_buffer_L)` and the `x 1.1; R = L` loop over BUFFER_SIZE
+    work on the first 128 samples of a hop whatever FFT_L is.  At the shipped FFT_L = 256 (N_BLOCKS = 1) that is the
+    whole hop and the switch changes nothing, bit for bit.  At FFT_L = 512 the second block of every hop leaves as the
+    filter made it -- L = Re y, R = Im y, equal to the nr_level-0 output to the bit -- only every other block carries
+    the noise reduction (x 1.1, R = L), and the NLMS, fed one block in two, predicts across a whole hop instead of 128
+    samples.  The restatement and the product run every block ('A7'): this is what that replaces."""
+    from cases import CONV_LITERAL
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    iq = synth_iq(1, 64 * 128)[0]
+    for fft_l in (256, 512, 1024):
+        cfg = dict(CONV_LITERAL, fft_l=fft_l, lms_nr=20)
+        a = oracle.OracleChain(**cfg)
+        b = oracle.OracleChain(**cfg)
+        b.set_literal_nr_first_block(True)
+        off = oracle.OracleChain(**dict(cfg, lms_nr=0))
+        ya, yb, y0 = a.process(iq)[1], b.process(iq)[1], off.process(iq)[1]
+        nb = fft_l // 2 // 128
+        blocks = yb.reshape(-1, 128, 2)
+        if nb == 1:
+            assert np.array_equal(ya, yb)
+            continue
+        first = np.arange(len(blocks)) % nb == 0
+        assert np.array_equal(blocks[~first], y0.reshape(-1, 128, 2)[~first])          # untouched: Re y and Im y
+        assert np.array_equal(blocks[first][..., 0], blocks[first][..., 1])             # R = L on the blocks it ran on
+        assert not np.array_equal(blocks[~first][..., 0], blocks[~first][..., 1])
+        d = np.abs(ya - yb).max() / np.abs(ya).max()
+        frac = float(first.mean())
+        print(f"FFT_L {fft_l}: CONV:326-337 as written runs the NR on {frac:.2f} of the blocks; {d:.2f} of the peak away from every-block")
+        assert d > 0.1 and frac == 1.0 / nb
+
