@@ -14,7 +14,7 @@
  * steps per 16-lane reduction with the energy E and the lag-1 correlation B, which depend on the
  * input only, in two DPP prefix scans per 64 steps: ~19 issue slots per step (103 cycles) against a
  * chain of ~98; measured 123 cycles per step.  Taking the chain away (weights one block stale,
- * hand-interleaved issue order: experimental/rdsp_tail_lookahead.h) was built and measured in round 3
+ * hand-interleaved issue order: tests/micro/not_adopted/rdsp_tail_lookahead.h) was built and measured in round 3
  * and loses: its two extra scans cost more issue slots than the chain it removes.
  * Input blocks are fetched from HBM a whole block ahead (round 3: 0.967 -> 0.912 ms alone).
  */
@@ -247,7 +247,7 @@ struct NlmsB {
 };
 
 #ifdef RDSP_EXPERIMENTAL
-#include "experimental/rdsp_tail_lookahead.h"
+#include "rdsp_tail_lookahead.h" /* tests/micro/not_adopted/, on the include path of EXPERIMENTAL=1 builds */
 #endif
 
 /* health word of one NLMS instance at the end of a launch (kernel params, st_status): bit 0 when some
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(64) rdsp_tail_kernel(RdspTailParams p) {
   tail_body<false, NlmsB>(p);
 }
 #ifdef RDSP_EXPERIMENTAL
-/* weights one block stale / four steps per reduction (experimental/rdsp_tail_lookahead.h): measured, not adopted */
+/* weights one block stale / four steps per reduction (tests/micro/not_adopted/rdsp_tail_lookahead.h): measured, not adopted */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(64))) rdsp_tail_lookahead_kernel(RdspTailParams p) {
   tail_body<false, NlmsL>(p);
 }
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(64))) rdsp_
 }  // namespace
 
 #ifdef RDSP_EXPERIMENTAL
-extern "C" int rdsp_launch_tail_shift(const RdspTailParams *p, hipStream_t stream);            /* experimental/rdsp_tail_shift.hip */
-extern "C" int rdsp_launch_tail_layouts(const RdspTailParams *p, int variant, hipStream_t stream); /* experimental/rdsp_tail_layouts.hip */
+extern "C" int rdsp_launch_tail_shift(const RdspTailParams *p, hipStream_t stream);            /* tests/micro/not_adopted/rdsp_tail_shift.hip */
+extern "C" int rdsp_launch_tail_layouts(const RdspTailParams *p, int variant, hipStream_t stream); /* tests/micro/not_adopted/rdsp_tail_layouts.hip */
 #endif
 
 /* variant 100: the product's kernel.  EXPERIMENTAL=1 builds also know 104 (weights one block stale), 105 (four

@@ -91,7 +91,7 @@ struct NlmsL {
   }
 
   template <bool OUT_E>
-  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *, float *scr, int sub) {
+  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *, float *scr, int sub, bool = false) { /* (the energy mode is the product kernel's) */
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;
@@ -336,7 +336,7 @@ struct NlmsQ {
   }
 
   template <bool OUT_E>
-  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr, int sub) {
+  __device__ __forceinline__ void block(const float *ring, bool first, float mu, float *out, float *scr, int sub, bool = false) {
     const float *cur = ring + RDSP_BLOCK;
     const float *dsrc = first ? cur : ring; /* NR:69-79 */
     const float *mine = cur - TPL * sub;
