@@ -33,7 +33,7 @@ def design_audio_iir(f1, f2, fs):
 class FilterBiquad:
     """AudioFilterBiquad: up to four cascaded sections, int16 audio in and out."""
 
-    def __init__(self, n_channels, fs=44117.64706, device=0):
+    def __init__(self, n_channels, fs=44100.0, device=0):
         self.lib = _lib.load()
         self.n_channels = int(n_channels)
         h = C.c_void_p()

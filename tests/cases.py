@@ -4,8 +4,10 @@ K1 = dict(fft_l=256, demod="USB")                       # K1/K2 chain
 K3 = dict(fft_l=512, demod="USB", spectral_nr=1, spectral_level=2.0, als_mode="notch",
           als_strength=20, agc_mode="medium", output_gain=0.5)
 K4 = dict(fft_l=4096, demod="CW_USB", flo_hz=450.0, fhi_hz=950.0, agc_mode="fast", output_gain=0.5)
-CONV_LITERAL = dict(fs_in=44117.64706, decim=1, nco_hz=0.0, fft_l=256, flo_hz=300.0, fhi_hz=4000.0,
-                    demod="IQ")                         # the in-tree CONV stage at its native rate
+CONV_LITERAL = dict(fs_in=44100.0, decim=1, nco_hz=0.0, fft_l=256, flo_hz=300.0, fhi_hz=4000.0,
+                    demod="IQ")                         # the in-tree CONV stage at its native rate: SAMPLE_RATE =
+# (double)AUDIO_SAMPLE_RATE_EXACT (CONV:35) is 44100.0 in the reference's firmware image (tests/golden/firmware_tables.npz
+# `sample_rate`; the Teensy 4 cores define 44100.0f -- 44117.64706, which rounds 1-4 assumed, is the Teensy 3 value)
 
 GOLDEN_CASES = {
     "conv_literal_256": dict(channels=2, blocks=16, cfg=CONV_LITERAL),

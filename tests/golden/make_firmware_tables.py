@@ -19,6 +19,14 @@ DESIGN.md section 2):
   biquad_sets           15 x {b0,b1,b2,a1,a2} x 4: the engine's IIR audio filters       CTL:153-177
   hilbert_half64        64 odd taps of one side of the engine's Hilbert transformer
   sine257               sin(2 pi k / 256), k = 0..256: the engine's oscillator table
+  sample_rate           the double next to the 300.0 / 4000.0 filter edges in the initialised data: 44100.0 --
+                        SAMPLE_RATE = (double)AUDIO_SAMPLE_RATE_EXACT (CONV:35) as this build had it (Teensy 4
+                        cores define 44100.0f; 44117.64706 is the Teensy 3 value)
+  lms_epsilon           1.19209289e-7f in the literal pool of the NLMS code (arm_lms_norm_f32's energy floor, NR:73)
+  nr_gain               the double 1.1 of CONV:334
+  design_constants      the literal pool of calc_cplx_FIR_coeffs (CONV:127-185): pi, 0.01, 2 pi, 4 pi, 6 pi and the
+                        cosine-sum window coefficients of ids 2, 1 and the default
+  iq_gain_balance       1.020f of SDR.setIQgainBalance (INO:135)
 
 Each entry was located by its content (a symmetric 256-entry int16 table that starts 0, 5, 20, 45
 is a Hann window whatever it is called); the names are those of the libraries' published headers.
@@ -44,6 +52,11 @@ TABLES = {
     "biquad_sets": (0x1DCBC, 15 * 20, "<f4"),
     "hilbert_half64": (0x1DCBC + 4 * 300, 64, "<f4"),
     "sine257": (0x1DCBC + 4 * 364, 257, "<f4"),
+    "sample_rate": (0x24B04, 1, "<f8"),
+    "lms_epsilon": (0x14998, 1, "<f4"),
+    "nr_gain": (0x9430, 1, "<f8"),
+    "design_constants": (0x90B0, 15, "<f8"),
+    "iq_gain_balance": (0xB208, 1, "<f4"),
 }
 
 
@@ -94,6 +107,8 @@ def main():
     assert out["sqrt_guess"][0] == 55109 and out["sqrt_guess"][32] == 0
     assert out["bitrev_1024"][0] == 0x400 and out["twiddle_q15_4096"][3] == 50
     assert abs(out["hilbert_half64"][63] + 2 / np.pi) < 1e-4 and out["sine257"][64] == 1.0
+    assert out["sample_rate"][0] == 44100.0 and out["nr_gain"][0] == 1.1 and out["lms_epsilon"][0] == np.float32(1.19209289e-7)
+    assert out["design_constants"][0] == np.pi and out["design_constants"][1] == 0.01 and out["iq_gain_balance"][0] == np.float32(1.02)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

@@ -74,7 +74,7 @@ def make_nodes():
         lib.orc_biquad_init(C.byref(o), 0, None)
         for stage, (kind, f, qq) in ((0, (1, 500.0, 0.5)), (2, (3, 1000.0, 4.0))):
             c5 = np.zeros(5, np.float32)
-            lib.orc_biquad_design(kind, f, qq, 44117.64706, c5.ctypes.data_as(F32P))
+            lib.orc_biquad_design(kind, f, qq, 44100.0, c5.ctypes.data_as(F32P))
             lib.orc_biquad_set_stage(C.byref(o), stage, c5.ctypes.data_as(F32P))
         y = i.astype(np.float32) / np.float32(32768.0)
         lib.orc_biquad_run(C.byref(o), y.ctypes.data_as(F32P), len(y))

@@ -4,7 +4,11 @@
  * replaced by two raw int16 files.  BASELINE config K1: 1 channel, 96 kHz IQ, 128-sample
  * blocks, NR/notch off.
  *
- *   binding_check <iq_in.raw> <audio_out.raw> <n_blocks>
+ *   binding_check <iq_in.raw> <audio_out.raw> <n_blocks> [spectra_out.raw]
+ *
+ * With the fourth argument the panadapter side of the graph runs too (biquad1 / biquad2 high-pass 500 Hz -> FFT with
+ * AudioWindowHanning256 handed over by pointer, averageTogether(30); .ino:57-59,75-78,144-145,155-156) and every
+ * spectrum FFT.available() announces is appended to the file, followed by FFT.read(80) and FFT.read(75, 85).
  *
  * Built by tests/test_boundary_c.py with
  *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include binding_check.c \
@@ -17,7 +21,7 @@
 #define MAX_BLOCKS 16
 #include "rdsp_binding.h"
 
-static FILE *f_in, *f_out;
+static FILE *f_in, *f_out, *f_spec;
 static long blocks_left;
 static int16_t h_iq[MAX_BLOCKS * RDSP_BLOCK_SAMPLES * 2], h_out[MAX_BLOCKS * RDSP_BLOCK_SAMPLES / 4 * 2];
 
@@ -27,6 +31,14 @@ void upload_queued_iq(int16_t *d_iq, int n_blocks, hipStream_t s) {
   if (fread(h_iq, sizeof(int16_t), n, f_in) != n) { fprintf(stderr, "short read\n"); exit(2); }
   blocks_left -= n_blocks;
   if (hipMemcpyAsync(d_iq, h_iq, n * sizeof(int16_t), hipMemcpyHostToDevice, s) != hipSuccess) exit(3);
+  if (f_spec) { /* the audio ISR ticks the panadapter nodes on the same blocks (.ino:75-78) */
+    panadapter_update(d_iq, n_blocks);
+    if (FFT_available()) { /* what the display does with it: output[] and read() */
+      const float r[2] = {FFT_read(80), FFT_read2(75, 85)};
+      fwrite(FFT_output, sizeof(uint16_t), 256, f_spec);
+      fwrite(r, sizeof(float), 2, f_spec);
+    }
+  }
 }
 void play_audio(const int16_t *d_out, int n_pairs, hipStream_t s) {
   if (hipMemcpyAsync(h_out, d_out, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s) != hipSuccess) exit(3);
@@ -50,6 +62,13 @@ static void setup(void) {           /* RadioDSP_SDR_RX.ino:102-187, the DSP part
   SDR_enableAudioFilter();                    /* :137 */
   SDR_setAudioFilter(audio2700);              /* :138 */
   TuningOffset = SDR_setDemodMode(LSBmode);   /* :139 */
+  if (f_spec) {
+    panadapter_begin();                       /* :57-59 */
+    FFT_windowFunction(AudioWindowHanning256);/* :144 */
+    FFT_averageTogether(30);                  /* :145 */
+    biquad1_setHighpass(0, 500, 0.5f);        /* :155 */
+    biquad2_setHighpass(0, 500, 0.5f);        /* :156 */
+  }
   Init_LMS_NR(15);                            /* :172 */
   SDR_setMute(0);                             /* :177 */
   reInitializeFilter(300.0, 4000.0);          /* :183 */
@@ -58,15 +77,18 @@ static void setup(void) {           /* RadioDSP_SDR_RX.ino:102-187, the DSP part
 static void loop(void) { doConvolutionalProcessing((float)nr_level, 1, 300.0, 4000.0); } /* :195-198 */
 
 int main(int argc, char **argv) {
-  if (argc != 4) { fprintf(stderr, "usage: %s iq_in.raw audio_out.raw n_blocks\n", argv[0]); return 64; }
+  if (argc != 4 && argc != 5) { fprintf(stderr, "usage: %s iq_in.raw audio_out.raw n_blocks [spectra_out.raw]\n", argv[0]); return 64; }
   f_in = fopen(argv[1], "rb");
   f_out = fopen(argv[2], "wb");
+  if (argc == 5 && !(f_spec = fopen(argv[4], "wb"))) { fprintf(stderr, "cannot open %s\n", argv[4]); return 66; }
   blocks_left = atol(argv[3]);
   if (!f_in || !f_out || blocks_left <= 0) { fprintf(stderr, "cannot open files\n"); return 66; }
   setup();
   while (g_binding_status == RDSP_OK && queued_blocks() >= rdsp_chain_granule_blocks(g_chain)) loop();
   fclose(f_out);
   fclose(f_in);
+  if (f_spec) fclose(f_spec);
+  (void)FFT_read; (void)FFT_read2; (void)FFT_available; (void)panadapter_update; (void)panadapter_begin;
   if (g_chain) rdsp_chain_destroy(g_chain);
   printf("binding_check: status %d, TuningOffset %u, %s\n", g_binding_status, (unsigned)TuningOffset, rdsp_version());
   return g_binding_status == RDSP_OK ? 0 : 1;

@@ -97,4 +97,49 @@ enum { audioCW = RDSP_AUDIO_CW, audio2100 = RDSP_AUDIO_2100, audio2700 = RDSP_AU
 #define SDR_setDemodMode(m)         rdsp_sdr_setDemodMode(g_chain, (m), g_stream)
 #define SDR_setMute(b)              RDSP_BIND_CHECK(rdsp_sdr_setMute(g_chain, (b)))
 
+/* ---- the panadapter side of the graph: `AudioFilterBiquad biquad1, biquad2; AudioAnalyzeFFT256IQ FFT;`
+ * (.ino:57-59), IQinput -> biquad1 / biquad2 -> FFT (.ino:75-78), `biquadN.setHighpass(0, 500, 0.5)` (.ino:155-156),
+ * `FFT.windowFunction(AudioWindowHanning256); FFT.averageTogether(30);` (.ino:144-145), read by the display through
+ * FFT.available() / FFT.output[] / FFT.read() (analyze_fft256iq.h:62-86,99).  The window table is the caller's, as in
+ * the reference (`const int16_t *`): Teensy's windows.c defines it there; a host port fills it once with
+ * rdsp_window_q15(RDSP_WINDOW_HANNING, ...), which reproduces the table of the reference's firmware image. */
+static rdsp_biquad_t *g_biquad1, *g_biquad2;
+static rdsp_spectrum_t *g_fft;
+static int16_t AudioWindowHanning256[256];
+static int16_t *g_d_filt;              /* device: the two high-passed rails, interleaved like the IQ stream */
+static uint16_t *g_d_spec, FFT_output[N_CH * 256]; /* uint16_t output[256] (analyze_fft256iq.h:99), one row per receiver */
+static int g_fft_outputflag;
+
+static void panadapter_begin(void) {   /* the constructors of .ino:57-59 */
+  rdsp_window_q15(RDSP_WINDOW_HANNING, AudioWindowHanning256);
+  RDSP_BIND_CHECK(rdsp_biquad_create(N_CH, 0, 44100.0, &g_biquad1));   /* AUDIO_SAMPLE_RATE_EXACT of the Teensy 4 build */
+  RDSP_BIND_CHECK(rdsp_biquad_create(N_CH, 0, 44100.0, &g_biquad2));
+  RDSP_BIND_CHECK(rdsp_spectrum_create_default(N_CH, 0, &g_fft));       /* BlackmanNuttall256, naverage 8 */
+  if (hipMalloc((void **)&g_d_filt, N_CH * IN_STRIDE * 4) != hipSuccess ||
+      hipMalloc((void **)&g_d_spec, sizeof(FFT_output) * MAX_BLOCKS) != hipSuccess)
+    g_binding_status = RDSP_ERR_HIP;
+}
+#define biquad1_setHighpass(st, f, q) RDSP_BIND_CHECK(rdsp_biquad_setHighpass(g_biquad1, (st), (f), (q)))
+#define biquad2_setHighpass(st, f, q) RDSP_BIND_CHECK(rdsp_biquad_setHighpass(g_biquad2, (st), (f), (q)))
+#define FFT_windowFunction(w)         RDSP_BIND_CHECK(rdsp_spectrum_windowFunction_table(g_fft, (w)))
+#define FFT_averageTogether(n)        RDSP_BIND_CHECK(rdsp_spectrum_averageTogether(g_fft, (n)))
+/* n_blocks update() ticks of the three nodes on the IQ blocks the chain is about to consume (d_iq as uploaded) */
+static void panadapter_update(const int16_t *d_iq, int n_blocks) {
+  int n_out = 0;
+  RDSP_BIND_CHECK(rdsp_biquad_update(g_biquad1, d_iq, IN_STRIDE, 2, n_blocks, g_d_filt, IN_STRIDE, 2, g_stream));         /* I rail: every 2nd int16 */
+  RDSP_BIND_CHECK(rdsp_biquad_update(g_biquad2, d_iq + 1, IN_STRIDE, 2, n_blocks, g_d_filt + 1, IN_STRIDE, 2, g_stream)); /* Q rail */
+  RDSP_BIND_CHECK(rdsp_spectrum_update(g_fft, g_d_filt, IN_STRIDE, n_blocks, g_d_spec, MAX_BLOCKS, &n_out, g_stream));
+  if (n_out > 0) { /* the display sees the latest completed average */
+    for (int c = 0; c < N_CH; c++)
+      if (hipMemcpyAsync(FFT_output + 256 * c, g_d_spec + ((size_t)c * MAX_BLOCKS + (size_t)(n_out - 1)) * 256, 512,
+                         hipMemcpyDeviceToHost, g_stream) != hipSuccess)
+        g_binding_status = RDSP_ERR_HIP;
+    if (hipStreamSynchronize(g_stream) != hipSuccess) g_binding_status = RDSP_ERR_HIP;
+    g_fft_outputflag = 1;
+  }
+}
+static int FFT_available(void) { const int f = g_fft_outputflag; g_fft_outputflag = 0; return f; } /* analyze_fft256iq.h:62-68 */
+static float FFT_read(unsigned int bin) { return rdsp_spectrum_read(FFT_output, bin); }             /* :70-73 */
+static float FFT_read2(unsigned int first, unsigned int last) { return rdsp_spectrum_read_range(FFT_output, first, last); } /* :75-86 */
+
 #endif

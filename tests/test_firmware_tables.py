@@ -199,6 +199,39 @@ def test_engine_tables_in_the_image_are_what_the_docs_say(fw):
         np.abs(s - np.sin(2 * np.pi * np.arange(257) / 256)).max() < 1e-7
 
 
+def test_scalar_constants_of_the_image(fw, plib, oracle):
+    """What the image says about numbers the sources leave to headers that are not in the tree, or that a restatement
+    could get wrong: AUDIO_SAMPLE_RATE_EXACT (CONV:35) is 44100.0 in this build; arm_lms_norm_f32's energy floor is
+    1.19209289e-7f; the `x 1.1` of CONV:334 is a double; the design routine's literal pool (CONV:127-185) holds pi,
+    0.01 (the centre-tap test), 2 pi, 4 pi, 6 pi and the window coefficients -- the product's and the oracle's taps
+    computed with exactly these constants are the taps they return."""
+    from cases import CONV_LITERAL
+    assert fw["sample_rate"][0] == 44100.0 == CONV_LITERAL["fs_in"]
+    assert fw["lms_epsilon"][0] == np.float32(0.000000119209289)
+    assert fw["nr_gain"][0] == 1.1 and fw["iq_gain_balance"][0] == np.float32(1.020)
+    dc = fw["design_constants"]
+    assert dc[0] == np.pi and dc[1] == 0.01 and dc[2] == 2 * np.pi and dc[3] == 4 * np.pi and dc[4] == 6 * np.pi
+    rows = {2: (dc[6], dc[5], dc[7], dc[8]), 1: (dc[10], dc[9], dc[11], dc[12])}      # a0, a1, a2, a3 (stored a1 first)
+    assert rows[1] == (0.35875, 0.48829, 0.14128, 0.01168) and rows[2] == (0.355768, 0.487396, 0.144232, 0.012604)
+    assert (dc[14], dc[13]) == (0.3635819, 0.4891775)
+    n, lo, hi, fs = 129, 300.0, 4000.0, float(fw["sample_rate"][0])
+    plib.rdsp_calc_cplx_FIR_coeffs.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]
+    olib = oracle.load()
+    olib.orc_calc_cplx_FIR_coeffs.argtypes = plib.rdsp_calc_cplx_FIR_coeffs.argtypes
+    for wid, a in rows.items():
+        i = np.arange(n, dtype=np.float64)
+        x = i - (n - 1) / 2.0
+        nfc, nfs = (hi / fs - lo / fs) / 2.0, dc[0] * (hi / fs + lo / fs)
+        w = a[0] - a[1] * np.cos(dc[2] * i / (n - 1)) + a[2] * np.cos(dc[3] * i / (n - 1)) - a[3] * np.cos(dc[4] * i / (n - 1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            z = np.where(np.abs(x) < dc[1], 2.0 * nfc, np.sin(2 * dc[0] * x * nfc) / (dc[0] * x) * w)
+        want_i, want_q = z * np.cos(nfs * x), z * np.sin(nfs * x)
+        for lib, fn in ((plib, "rdsp_calc_cplx_FIR_coeffs"), (olib, "orc_calc_cplx_FIR_coeffs")):
+            ci, cq = np.zeros(n), np.zeros(n)
+            getattr(lib, fn)(ci.ctypes.data_as(C.POINTER(C.c_double)), cq.ctypes.data_as(C.POINTER(C.c_double)), n, lo, hi, fs, wid)
+            assert np.abs(ci - want_i).max() <= 1e-15 and np.abs(cq - want_q).max() <= 1e-15, (fn, wid)
+
+
 def test_engine_iir_sets_against_the_builds_butterworth_design(fw, plib):
     """SURVEY Appendix C / CTL:153-177: the first eight coefficient sets of the image are the engine's audio
     band-passes for fs = 44 117.647 Hz, 150 Hz up to 2.1 / 2.3 / 2.5 / 2.7 / 2.9 / 3.1 / 3.3 / 3.9 kHz.  Each is a
@@ -209,7 +242,7 @@ def test_engine_iir_sets_against_the_builds_butterworth_design(fw, plib):
     edge, and 9 dB less at 75 Hz.  A host that wants the engine's own sections loads them
     (rdsp_sdr_setAudioIIRCoefficients; GPU parity in tests/test_audio_nodes.py)."""
     from scipy import signal
-    fs = 44117.64706
+    fs = float(fw["sample_rate"][0])
     f = np.linspace(1.0, fs / 2, 60000)
     plib.rdsp_design_audio_iir.argtypes = [C.c_double] * 3 + [C.POINTER(C.c_float)]
 

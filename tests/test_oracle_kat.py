@@ -11,7 +11,8 @@ import np_model
 from cases import CONV_LITERAL, GOLDEN_CASES, K1, K3, K4, apply_setup
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FS_T4 = 44117.64706  # AUDIO_SAMPLE_RATE_EXACT on Teensy 4
+FS_T4 = 44117.64706  # the rate SURVEY 4.2's known answers were computed at (Teensy 3's AUDIO_SAMPLE_RATE_EXACT; the
+                     # reference's own image says 44100.0 for its Teensy 4 build: CONV_LITERAL, tests/test_firmware_tables.py)
 
 
 def _p(a, t):
@@ -95,7 +96,7 @@ def test_overlap_save_is_linear_convolution(oracle):
     rng = np.random.default_rng(1)
     iq = rng.integers(-9000, 9000, size=(128 * 12, 2)).astype(np.int16)
     _, o32 = ch.process(iq)
-    ci, cq = np_model.fir_design(129, 300.0, 4000.0, FS_T4, 1)
+    ci, cq = np_model.fir_design(129, 300.0, 4000.0, CONV_LITERAL["fs_in"], 1)
     h = ci.astype(np.float32).astype(np.float64) + 1j * cq.astype(np.float32).astype(np.float64)
     h[-1] = h[-1].real
     x = (iq[:, 0] + 1j * iq[:, 1]) / 32768.0
