@@ -201,12 +201,13 @@ def f1_main(args):
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "q15", "data": "synthetic",
            "config": {"workload": f"F1: {nch} channels x {nblk} blocks of 128 int16 IQ samples per step; 256-pt q15 "
-                                  "radix-4 FFT per block pair, Hann window, 30-frame power average, integer sqrt"},
+                                  "radix-4 FFT per block pair (arm_cfft_radix4_q15 as published, firmware twiddles), AudioWindowHanning256 "
+                                  "of the firmware image, 30-frame power average, sqrt_uint32_approx"},
            "roofline": {"bound": "hbm", "kernel": "rdsp_spectrum_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "limiter": "valu",
                         "valu": valu, "counters_note": ctr_note,
                         "note": "algorithmic bytes = 4 B per input sample (the spectra written are < 0.1 %); "
-                                "integer VALU issue binds (about 210 instructions per 256-point frame and wave)"}}
+                                "integer VALU issue binds"}}
     if not args.no_cpu_baseline:
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", "F1"],

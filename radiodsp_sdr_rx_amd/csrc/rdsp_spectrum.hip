@@ -224,18 +224,25 @@ extern "C" int rdsp_spectrum_create(int n_channels, int device, int naverage, in
   s->has_window = 0;
   s->have_prev = 0;
   s->count = 0;
-  SPEC_TRY(hipSetDevice(device));
-  SPEC_TRY(hipMalloc((void **)&s->d_window, 256 * sizeof(int16_t)));
-  SPEC_TRY(hipMalloc((void **)&s->d_twid, 192 * sizeof(uint32_t)));
-  SPEC_TRY(hipMalloc((void **)&s->d_guess, 33 * sizeof(uint16_t)));
-  SPEC_TRY(hipMalloc((void **)&s->d_prev, (size_t)n_channels * 128 * sizeof(uint32_t)));
-  SPEC_TRY(hipMalloc((void **)&s->d_sum, (size_t)n_channels * 256 * sizeof(uint32_t)));
-  SPEC_TRY(hipMemset(s->d_prev, 0, (size_t)n_channels * 128 * sizeof(uint32_t)));
-  SPEC_TRY(hipMemset(s->d_sum, 0, (size_t)n_channels * 256 * sizeof(uint32_t)));
   uint32_t tw[192];
   rdsp_q15_twiddles(256, tw);
-  SPEC_TRY(hipMemcpy(s->d_twid, tw, sizeof(tw), hipMemcpyHostToDevice));
-  SPEC_TRY(hipMemcpy(s->d_guess, rdsp_sqrt_guess_table(), 33 * sizeof(uint16_t), hipMemcpyHostToDevice));
+  auto setup = [&]() -> int { /* on any failure the half-made object is destroyed below, not leaked */
+    SPEC_TRY(hipSetDevice(device));
+    SPEC_TRY(hipMalloc((void **)&s->d_window, 256 * sizeof(int16_t)));
+    SPEC_TRY(hipMalloc((void **)&s->d_twid, 192 * sizeof(uint32_t)));
+    SPEC_TRY(hipMalloc((void **)&s->d_guess, 33 * sizeof(uint16_t)));
+    SPEC_TRY(hipMalloc((void **)&s->d_prev, (size_t)n_channels * 128 * sizeof(uint32_t)));
+    SPEC_TRY(hipMalloc((void **)&s->d_sum, (size_t)n_channels * 256 * sizeof(uint32_t)));
+    SPEC_TRY(hipMemset(s->d_prev, 0, (size_t)n_channels * 128 * sizeof(uint32_t)));
+    SPEC_TRY(hipMemset(s->d_sum, 0, (size_t)n_channels * 256 * sizeof(uint32_t)));
+    SPEC_TRY(hipMemcpy(s->d_twid, tw, sizeof(tw), hipMemcpyHostToDevice));
+    SPEC_TRY(hipMemcpy(s->d_guess, rdsp_sqrt_guess_table(), 33 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return RDSP_OK;
+  };
+  if (setup() != RDSP_OK) {
+    rdsp_spectrum_destroy(s);
+    return RDSP_ERR_HIP;
+  }
   int rc = upload_window_id(s, window_id);
   if (rc != RDSP_OK) {
     rdsp_spectrum_destroy(s);
