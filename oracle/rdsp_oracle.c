@@ -1,7 +1,11 @@
 /*
  * rdsp_oracle.c -- CPU ORACLE (test infrastructure; see rdsp_oracle.h header).
- * PARITY UNPINNED: no reference fixtures exist; restated from the reference's
- * sources and anchored by analytic KATs + an independent float64 model.
+ * PARITY: UNPINNED for everything floating-point (no reference fixtures exist; restated from the
+ * reference's sources and anchored by analytic KATs + an independent float64 model); PINNED BY
+ * REFERENCE-HELD DATA where the reference holds some -- the constant tables of its shipped firmware
+ * image (tests/golden/firmware_tables.npz): the analysers' q15 windows, q15 twiddles, bit-reversal
+ * table and square-root guess table, the sample rate, the NLMS epsilon, the 1.1 gain and the design
+ * routine's constants (tests/test_firmware_tables.py).
  *
  * Citation short names (relative to /root/reference/src):
  *   CONV = RadioDSP_SDR_RX/RDSP_convolutional.h

@@ -5,7 +5,10 @@
  * check in __graft_entry__.py and the cpu_baseline leg of bench.py may load
  * it.  The product path (radiodsp_sdr_rx_amd/) never links or calls it.
  *
- * PARITY UNPINNED: the reference (gcallipo/RadioDSP_SDR_RX, an Arduino/Teensy
+ * PARITY UNPINNED for all floating-point stages; pinned by reference-held data only where the
+ * reference's shipped firmware image holds constant tables (the integer analysers' windows,
+ * twiddles and square-root table; sample rate, NLMS epsilon, design constants: see the .c header
+ * and tests/test_firmware_tables.py).  The reference (gcallipo/RadioDSP_SDR_RX, an Arduino/Teensy
  * sketch) ships no tests, golden vectors or fixtures, and cannot be compiled
  * here (needs the Arduino core, Teensy Audio library, CMSIS-DSP and the
  * AudioSDR library, none of them vendored or pinned).  This file is therefore
