@@ -148,8 +148,10 @@ class SpectrumNode(Node):
         p = self.g.lib.rdsp_spectrum_node_output(self.h)
         return np.ctypeslib.as_array(p, (self.g.n_channels, 256)).copy()
 
-    def read(self, channel, binNumber):  # FFTIQ.h:70-73
-        return float(self.output()[channel, binNumber]) * (1.0 / 16384.0)
+    def read(self, channel, binFirst, binLast=None):  # FFTIQ.h:70-73 and :75-86 (binLast itself is not added)
+        if binLast is None:
+            return float(self.g.lib.rdsp_spectrum_node_read(self.h, int(channel), int(binFirst)))
+        return float(self.g.lib.rdsp_spectrum_node_read_range(self.h, int(channel), int(binFirst), int(binLast)))
 
     def status(self):
         return self.g.lib.rdsp_spectrum_node_status(self.h)
@@ -167,6 +169,11 @@ class Fft1024Node(Node):
     def output(self):     # uint16 [n_channels, 512]
         p = self.g.lib.rdsp_fft1024_node_output(self.h)
         return np.ctypeslib.as_array(p, (self.g.n_channels, 512)).copy()
+
+    def read(self, channel, binFirst, binLast=None):  # AudioAnalyzeFFT1024::read (the range form includes binLast)
+        if binLast is None:
+            return float(self.g.lib.rdsp_fft1024_node_read(self.h, int(channel), int(binFirst)))
+        return float(self.g.lib.rdsp_fft1024_node_read_range(self.h, int(channel), int(binFirst), int(binLast)))
 
     def status(self):
         return self.g.lib.rdsp_fft1024_node_status(self.h)

@@ -1,5 +1,5 @@
 /*
- * host_sanitize.c -- the host-only C of the library (rdsp_graph.c, rdsp_io.c, rdsp_design.c) under
+ * host_sanitize.c -- the host-only C of the library (rdsp_graph.c, rdsp_io.c, rdsp_design.c, rdsp_q15_tables.c) under
  * AddressSanitizer + UndefinedBehaviorSanitizer + LeakSanitizer on the CPU build (the GPU pool has
  * no sanitizer runs).  tests/test_host_logic.py compiles this file together with those three
  * sources and expects exit code 0 and no sanitizer report.  Walks the block graph of the sketch
@@ -321,6 +321,49 @@ static void design_checks(void) {
   rdsp_synth_iq(b, 5, 1, 1u << 20, 300, &cfg, 2);
 }
 
+/* ---- the analysers' tables and accessors (rdsp_q15_tables.c), exactly sized buffers ------------------- */
+void rdsp_q15_twiddles(int n, uint32_t *out);
+const uint16_t *rdsp_sqrt_guess_table(void);
+void rdsp_arm_sin_table(float *tab513);
+static void table_checks(void) {
+  for (int id = 0; id <= RDSP_WINDOW_TUKEY; id++) {
+    for (int n = 256; n <= 1024; n *= 4) {
+      int16_t *w = (int16_t *)malloc(sizeof(int16_t) * (size_t)n);
+      rdsp_window_q15_n(id, n, w);
+      CHECK(id == RDSP_WINDOW_NONE ? w[n / 2] == 32767 : w[0] <= 3000);
+      free(w);
+    }
+  }
+  for (int n = 256; n <= 1024; n *= 4) {
+    uint32_t *t = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(3 * n / 4));
+    rdsp_q15_twiddles(n, t);
+    CHECK((t[0] & 0xFFFFu) == 32767u && (t[0] >> 16) == 0u);
+    free(t);
+  }
+  CHECK(rdsp_sqrt_guess_table()[0] == 55109 && rdsp_sqrt_guess_table()[32] == 0);
+  CHECK(rdsp_sqrt_uint32_approx(0) == 0 && rdsp_sqrt_uint32_approx(1) == 1 && rdsp_sqrt_uint32_approx(0xFFFFFFFFu) >= 65535u);
+  for (uint32_t x = 1; x; x <<= 1) CHECK(rdsp_sqrt_uint32_approx(x) > 0 && rdsp_sqrt_uint32_approx(x - 1 + (x == 1)) <= 65543u);
+  float *tab = (float *)malloc(sizeof(float) * 513);
+  rdsp_arm_sin_table(tab);
+  CHECK(tab[0] == 0.0f && tab[128] == 1.0f && tab[384] == -1.0f && fabsf(tab[512]) < 1e-7f);
+  free(tab);
+  uint16_t *row = (uint16_t *)malloc(sizeof(uint16_t) * 256), *row2 = (uint16_t *)malloc(sizeof(uint16_t) * 512);
+  for (int i = 0; i < 256; i++) row[i] = (uint16_t)(65535 - i);
+  for (int i = 0; i < 512; i++) row2[i] = (uint16_t)i;
+  /* every corner of the two read() forms on exactly sized rows: first == last, swapped, clamped, out of range */
+  CHECK(rdsp_spectrum_read(row, 255) > 0.f && rdsp_spectrum_read(row, 256) == 0.f);
+  CHECK(rdsp_spectrum_read_range(row, 255, 255) == rdsp_spectrum_read(row, 255));
+  CHECK(rdsp_spectrum_read_range(row, 254, 9999) == rdsp_spectrum_read(row, 254));          /* clamp to 255, 255 not added */
+  CHECK(rdsp_spectrum_read_range(row, 9999, 254) == rdsp_spectrum_read(row, 254));
+  CHECK(rdsp_spectrum_read_range(row, 0, 255) > 0.f && rdsp_spectrum_read_range(row, 256, 300) == 0.f);
+  CHECK(rdsp_fft1024_read(row2, 511) > 0.f && rdsp_fft1024_read(row2, 512) == 0.f);
+  CHECK(rdsp_fft1024_read_range(row2, 511, 511) == rdsp_fft1024_read(row2, 511));
+  CHECK(rdsp_fft1024_read_range(row2, 510, 9999) == (float)(510 + 511) * (float)(1.0 / 16384.0));
+  CHECK(rdsp_fft1024_read_range(row2, 0, 511) > 0.f && rdsp_fft1024_read_range(row2, 512, 600) == 0.f);
+  free(row);
+  free(row2);
+}
+
 int main(int argc, char **argv) {
   if (argc != 2) {
     fprintf(stderr, "usage: host_sanitize <scratch directory>\n");
@@ -330,6 +373,7 @@ int main(int argc, char **argv) {
   graph_checks(7);
   io_checks(argv[1]);
   design_checks();
+  table_checks();
   puts("host_sanitize OK");
   return 0;
 }

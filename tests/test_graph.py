@@ -281,6 +281,12 @@ def test_the_whole_graph_of_the_sketch(rdsp, oracle):
     assert got.shape == r16.shape and np.abs(got.astype(np.int32) - r16.astype(np.int32)).max() <= 1
     assert rf >= 3 and af >= 3                                   # 96 IQ ticks / 30; 24 audio blocks: frames at 8, 12, ...
     spec = AudioFFT.output()[0].astype(int)
+    # what the display does with the two analysers: read(bin) and read(first, last) (FFTIQ.h:70-86 keeps binLast out,
+    # the Teensy library's 1024-point analyser includes it)
+    pan = FFT.output()[0].astype(int)
+    assert FFT.read(0, 80) == pan[80] / 16384.0 and FFT.read(0, 75, 85) == float(np.float32(pan[75:85].sum())) / 16384.0
+    assert AudioFFT.read(0, 30) == spec[30] / 16384.0 and AudioFFT.read(0, 28, 32) == float(np.float32(spec[28:33].sum())) / 16384.0
+    assert FFT.read(0, 256) == 0.0 and AudioFFT.read(0, 512) == 0.0 and FFT.read(1, 3) == 0.0     # no such bin / channel
     for f in (700.0, 1000.0, 1900.0):                            # the USB tones of the synthetic input, 24 kHz / 1024 per bin
         k = int(round(f / (24000.0 / 1024)))
         assert spec[k - 1:k + 2].max() > 8 * np.median(spec[:128])

@@ -253,7 +253,7 @@ def test_host_c_under_address_and_ub_sanitizers(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fopenmp",
                            "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host", "host_sanitize.c")]
-                          + [os.path.join(csrc, f) for f in ("rdsp_graph.c", "rdsp_io.c", "rdsp_design.c")]
+                          + [os.path.join(csrc, f) for f in ("rdsp_graph.c", "rdsp_io.c", "rdsp_design.c", "rdsp_q15_tables.c")]
                           + ["-lm", "-o", exe])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, env=env, timeout=300)

@@ -24,7 +24,7 @@ def make_script(rng, n_ops=40, granule=8):
     ops = []
     for _ in range(n_ops):
         kind = rng.choice(["proc", "proc", "proc", "als", "nr", "spec", "agc", "gdemod", "gfilt", "gpbt", "goff", "gaf",
-                           "nb", "swap", "slip", "mute", "ogain", "igain", "bal", "afk"])
+                           "nb", "swap", "slip", "mute", "ogain", "igain", "bal", "afk", "specform", "emode"])
         g = int(rng.integers(0, NGROUPS))
         if kind == "proc":
             ops.append(("proc", granule * int(rng.integers(1, 32 // granule + 1))))
@@ -63,6 +63,10 @@ def make_script(rng, n_ops=40, granule=8):
             ops.append(("bal", float(rng.choice([1.0, 1.02, 0.97]))))
         elif kind == "afk":
             ops.append(("afk", int(rng.integers(0, 2))))
+        elif kind == "specform":     # SPEC:229-232 as written / the exact-arithmetic equivalent
+            ops.append(("specform", bool(rng.integers(0, 2))))
+        elif kind == "emode":        # NR:73's running energy / the per-block re-start
+            ops.append(("emode", bool(rng.integers(0, 2))))
     ops.append(("proc", 2 * granule if granule <= 16 else granule))
     ops.append(("proc", granule))
     return ops
@@ -119,6 +123,10 @@ def apply_setter(ch, rdsp, op):
         ch.setIQgainBalance(op[1])
     elif k == "afk":
         ch.setAudioFilterKind(op[1])
+    elif k == "specform":
+        ch.set_spectral_resynthesis(op[1])
+    elif k == "emode":
+        ch.set_nlms_energy_mode(op[1])
     else:
         raise ValueError(op)
 
@@ -229,7 +237,7 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
     band = [(300.0, 2700.0)] * n_groups
     gains = dict(input_gain=1.0, iq_balance=1.0, output_gain=0.5, mute=False)
     for _ in range(n_ops):
-        kind = str(rng.choice(["proc", "proc", "proc", "dcp", "mode", "filt", "pbt", "nco", "swap", "slip", "nb", "gain", "agc", "spec"]))
+        kind = str(rng.choice(["proc", "proc", "proc", "dcp", "mode", "filt", "pbt", "nco", "swap", "slip", "nb", "gain", "agc", "spec", "specform"]))
         g = int(rng.integers(0, n_groups))
         if kind == "proc":
             ops.append(("proc", granule * int(rng.integers(1, 4))))
@@ -261,6 +269,8 @@ def _oracle_script(rng, oracle, rdsp, n_groups, granule, n_ops=28):
             ops.append(("agc", str(rng.choice(["off", "fast", "medium", "slow"]))))
         elif kind == "spec":
             ops.append(("spec", int(rng.choice([0, 1, 2])), float(rng.choice([1.0, 2.0, 3.0]))))
+        elif kind == "specform":
+            ops.append(("specform", bool(rng.integers(0, 2))))
         elif kind == "gain":
             which = str(rng.choice(["input_gain", "iq_balance", "output_gain", "mute"]))
             gains[which] = {"input_gain": float(rng.choice([0.5, 1.0, 1.4])), "iq_balance": float(rng.choice([1.0, 1.02, 0.96])),
@@ -368,6 +378,10 @@ def test_random_retune_session_matches_oracle(rdsp, oracle, seed):
             ch.set_spectral_nr(op[1], op[2])
             for oc in ocs:
                 oc.set_spectral_nr(op[1], op[2])
+        elif k == "specform":   # SPEC:229-232 as written on both sides, or the equivalent form on both
+            ch.set_spectral_resynthesis(op[1])
+            for oc in ocs:
+                oc.set_literal_resynthesis(op[1])
         elif k == "gain":
             gn = op[1]
             ch.setInputGain(gn["input_gain"]); ch.setIQgainBalance(gn["iq_balance"])

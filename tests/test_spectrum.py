@@ -272,6 +272,7 @@ def test_analyser_as_a_graph_node_like_the_sketch(rdsp, oracle):
         for k, r in enumerate(ref):
             assert np.array_equal(outs[k][c], r)
     assert fft.read(0, 10) == outs[-1][0, 10] / 16384.0
+    assert fft.read(2, 10, 14) == float(np.float32(int(outs[-1][2, 10:14].sum()))) / 16384.0
 
 
 @pytest.mark.gpu
