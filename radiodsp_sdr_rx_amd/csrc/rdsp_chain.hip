@@ -144,7 +144,12 @@ struct rdsp_chain {
    * own to front_fir_prio during the FIR, the frequency-domain one never does; the tail kernel runs
    * at tail_prio throughout.  Round 2, frequency-domain front kernel, tail priority 0 / 1 / 2 / 3:
    * K3 1.191 / - / 1.188 / - ms, K5 2.72 / 2.36 / 2.34 / 2.36 ms per step (at equal priority the tail
-   * kernels of two sub-batches are starved by the front waves) */
+   * kernels of two sub-batches are starved by the front waves).  Round 5 looked at the library's default decimator
+   * (one granule per frame: half as much front-kernel work again per step), where the tail kernel is the starved one
+   * (1.4 - 2.0 ms per launch against 1.06 alone): tail priority 0 instead of 2 measured 1.335-1.513 against 1.423-1.689
+   * ms per K3 step in one interleaved A/B, 1.387-1.472 against 1.465-1.543 in a second, and 1.95 against 1.63 under
+   * the profiler and 1.83 against 1.50 as a leg of the default bench run -- no consistent gain, so the priority stays 2
+   * in every form (tests/micro/prio_default.sh, default_form_trace.sh) */
   int front_fir_prio = 2, tail_prio = 2;
   /* tail kernel: 100 = the product's (rdsp_tail.hip: a channel per 16-lane DPP row, two steps per reduction);
    * other values select the EXPERIMENTAL=1 variants (rdsp_launch_tail) */
@@ -1325,6 +1330,8 @@ extern "C" int rdsp_chain_set_pipelined(rdsp_chain_t *c, int on) {
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   if (drain_tail(c) != RDSP_OK) return RDSP_ERR_HIP;
   if (on && !c->s_tail) {
+    /* (a queue priority on this stream, hipStreamCreateWithPriority high or low, changes nothing: K3 1.168-1.192 /
+     * 1.165-1.178 against 1.163-1.190 ms, K5 2.305-2.316 / 2.323-2.415 against 2.293-2.335; round 5, same box) */
     HIP_TRY(hipStreamCreateWithFlags(&c->s_tail, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->s_mid, hipStreamNonBlocking));
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_mid[i], hipEventDisableTiming));

@@ -547,6 +547,23 @@ def test_argument_errors_are_loud(rdsp):
         with pytest.raises(RdspError) as e:
             ch.set_fir_variant(1)                       # matrix-core FIR: EXPERIMENTAL builds only
         assert e.value.code == -5
+    # round 5's entry points
+    h = C.c_void_p()
+    assert lib.rdsp_spectrum_create(2, 0, 8, 99, C.byref(h)) == -1 and b"window id" in lib.rdsp_last_error()
+    assert lib.rdsp_spectrum_create(2, 0, 8, -3, C.byref(h)) == -1
+    assert lib.rdsp_fft1024_create(2, 0, 12, C.byref(h)) != 0
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    fft = AnalyzeFFT256IQ(2)
+    assert lib.rdsp_spectrum_windowFunction(fft.h, 12) == -1 and lib.rdsp_spectrum_windowFunction_table(None, None) == -1
+    assert lib.rdsp_fft1024_windowFunction(an.h, -1) == -1 and lib.rdsp_fft1024_windowFunction_table(None, None) == -1
+    assert lib.rdsp_spectrum_windowFunction_table(fft.h, None) == 0           # windowFunction(NULL): no window, FFTIQ.cpp:81
+    assert lib.rdsp_set_spectral_resynthesis(None, 1) == -1 and lib.rdsp_set_nlms_energy_mode(None, 1) == -1
+    assert lib.rdsp_sdr_setAudioIIRCoefficients(ch.h, None) == -1
+    assert lib.rdsp_chain_call_unit_blocks(None) == 0 and lib.rdsp_chain_granule_blocks(None) == 0
+    assert ch.call_unit_blocks == 2 and ch.granule_blocks == 2               # decim 1, FFT_L 256: one 256-sample chunk
+    with pytest.raises(RdspError) as e:
+        ch.process(torch.zeros((2, 3 * 128, 2), dtype=torch.int16, device="cuda"))
+    assert e.value.code == -4 and "call unit" in str(e.value)
 
 
 # ---- committed fixture of the graph nodes (tests/golden/nodes.npz, made by make_golden.py) --------
