@@ -5,7 +5,9 @@
  * REFERENCE-HELD DATA where the reference holds some -- the constant tables of its shipped firmware
  * image (tests/golden/firmware_tables.npz): the analysers' q15 windows, q15 twiddles, bit-reversal
  * table and square-root guess table, the sample rate, the NLMS epsilon, the 1.1 gain and the design
- * routine's constants (tests/test_firmware_tables.py).
+ * routine's constants; and the ORDER OF OPERATIONS of arm_radix4_butterfly_q15, of the analysers'
+ * update() with sqrt_uint32_approx, and of arm_lms_norm_f32 (unfused multiply-then-add), read out of
+ * the image's code as instruction classes and offsets (tests/test_firmware_tables.py).
  *
  * Citation short names (relative to /root/reference/src):
  *   CONV = RadioDSP_SDR_RX/RDSP_convolutional.h

@@ -27,6 +27,19 @@ DESIGN.md section 2):
   design_constants      the literal pool of calc_cplx_FIR_coeffs (CONV:127-185): pi, 0.01, 2 pi, 4 pi, 6 pi and the
                         cosine-sum window coefficients of ids 2, 1 and the default
   iq_gain_balance       1.020f of SDR.setIQgainBalance (INO:135)
+  code_ops_names / code_ops_offsets
+                        NOT data tables: where in the image's CODE a handful of Thumb-2 instruction classes occur -- the
+                        DSP-extension parallel arithmetic (SHADD16, QADD16, QSUB16, SHSUB16, QASX, QSAX, SHASX, SHSAX), the
+                        dual multiplies (SMUAD, SMUADX, SMUSD, SMUSDX), CLZ and UDIV -- as class names and offsets,
+                        decoded here from their fixed bit patterns (no operands, no other instructions, no bytes).
+                        Their ORDER is what the restatements of arm_radix4_butterfly_q15, of the analysers' update()
+                        and of sqrt_uint32_approx are checked against (tests/test_firmware_tables.py): the image
+                        cannot be run here, but the sequence of these operations in it can be read.
+  code_vfp_names / code_vfp_offsets
+                        likewise the single-precision VFP arithmetic classes (VMUL, VADD, VSUB, VDIV, VNMUL and the
+                        multiply-accumulates VMLA / VMLS / VFMA / VFMS / VFNMA / VFNMS): whether the image's CMSIS
+                        routines round products and sums separately (they do) and in which order arm_lms_norm_f32
+                        updates its energy, takes the dot product, forms the step and updates the taps.
 
 Each entry was located by its content (a symmetric 256-entry int16 table that starts 0, 5, 20, 45
 is a Hann window whatever it is called); the names are those of the libraries' published headers.
@@ -90,6 +103,54 @@ def read_ihex(path):
     return lo, bytes(img)
 
 
+def dsp_opcode_classes(img):
+    """(offsets, names) of the instruction classes listed in the module docstring, in address order.  Thumb-2
+    32-bit encodings, two little-endian halfwords: parallel add/sub 1111 1010 1ooo nnnn | 1111 dddd 0ppp mmmm
+    (ooo: 001 ADD16, 101 SUB16, 010 ASX, 110 SAX; ppp: 001 saturating, 010 halving); SMUAD{X} 1111 1011 0010 nnnn
+    | 1111 dddd 000x mmmm; SMUSD{X} ... 0100 ...; CLZ 1111 1010 1011 mmmm | 1111 dddd 1000 mmmm; UDIV 1111 1011 1011
+    nnnn | 1111 dddd 1111 mmmm."""
+    hw = np.frombuffer(img[:len(img) // 2 * 2], dtype="<u2").astype(np.int64)
+    par = {0xFA90: "ADD16", 0xFAD0: "SUB16", 0xFAA0: "ASX", 0xFAE0: "SAX"}
+    offs, names = [], []
+    for i in range(len(hw) - 1):
+        h1, h2 = int(hw[i]), int(hw[i + 1])
+        if (h2 & 0xF000) != 0xF000:
+            continue
+        op, k, name = h1 & 0xFFF0, h2 & 0x00F0, None
+        if op in par and k in (0x10, 0x20):
+            name = ("Q" if k == 0x10 else "SH") + par[op]
+        elif op == 0xFB20 and k in (0x00, 0x10):
+            name = "SMUAD" + ("X" if k else "")
+        elif op == 0xFB40 and k in (0x00, 0x10):
+            name = "SMUSD" + ("X" if k else "")
+        elif op == 0xFAB0 and k == 0x80 and (h1 & 0xF) == (h2 & 0xF):
+            name = "CLZ"
+        elif op == 0xFBB0 and k == 0xF0:
+            name = "UDIV"
+        if name:
+            offs.append(2 * i)
+            names.append(name)
+    return np.array(offs, np.int64), np.array(names)
+
+
+def vfp_f32_classes(img):
+    """(offsets, names) of the single-precision VFP data-processing classes: 1110 1110 op.. | .... 1010 .o.0 ...."""
+    hw = np.frombuffer(img[:len(img) // 2 * 2], dtype="<u2").astype(np.int64)
+    table = {(0xEEA0, 0x00): "VFMA", (0xEEA0, 0x40): "VFMS", (0xEE90, 0x00): "VFNMS", (0xEE90, 0x40): "VFNMA",
+             (0xEE00, 0x00): "VMLA", (0xEE00, 0x40): "VMLS", (0xEE20, 0x00): "VMUL", (0xEE20, 0x40): "VNMUL",
+             (0xEE30, 0x00): "VADD", (0xEE30, 0x40): "VSUB", (0xEE80, 0x00): "VDIV"}
+    offs, names = [], []
+    for i in range(len(hw) - 1):
+        h1, h2 = int(hw[i]), int(hw[i + 1])
+        if (h2 & 0x0F00) != 0x0A00:
+            continue
+        name = table.get((h1 & 0xFFB0, h2 & 0x0050))
+        if name:
+            offs.append(2 * i)
+            names.append(name)
+    return np.array(offs, np.int64), np.array(names)
+
+
 def main():
     if not os.path.exists(HEX):
         sys.exit("the reference tree is not here: this script runs in the build container only")
@@ -101,6 +162,8 @@ def main():
         out[name] = np.frombuffer(img[off:off + size], dtype=dt).copy()
         out[name + "_offset"] = np.int64(off)
     out["biquad_sets"] = out["biquad_sets"].reshape(15, 4, 5)
+    out["code_ops_offsets"], out["code_ops_names"] = dsp_opcode_classes(img)
+    out["code_vfp_offsets"], out["code_vfp_names"] = vfp_f32_classes(img)
     # sanity: what each table is, so a wrong offset cannot slip through
     i = np.arange(256)
     assert np.array_equal(out["hann256"], np.minimum(32767, np.round(32768 * 0.5 * (1 - np.cos(2 * np.pi * i / 255)))))

@@ -279,3 +279,79 @@ def test_engine_iir_sets_against_the_builds_butterworth_design(fw, plib):
     for c in fw["biquad_sets"][8:].astype(np.float64):
         for sec in c:
             assert np.all(np.abs(np.roots([1.0, -sec[3], -sec[4]])) < 1.0)
+
+
+def test_code_of_the_image_runs_the_operation_sequences_the_restatements_follow(fw):
+    """The image cannot be run here, but it can be read.  tests/golden/make_firmware_tables.py lists where a handful
+    of Thumb-2 instruction classes occur in it (class names and offsets only): the DSP-extension parallel arithmetic,
+    the dual 16-bit multiplies, CLZ and UDIV.  Their order pins the structure of three restatements:
+
+    * arm_radix4_butterfly_q15 (FFTIQ.cpp:82): one run of exactly 50 such operations = first stage, middle stage,
+      last stage of the published DSP-extension routine, operation for operation as oracle/rdsp_oracle.c
+      (orc_radix4_butterfly_q15) and csrc/rdsp_q15.h restate it -- inputs >> 2 by two __SHADD16 each, __QADD16 /
+      __QSUB16 sums, __SHADD16 for output 0, __SMUAD + __SMUSDX per twiddle product, __QASX / __QSAX in the first
+      stage and __SHASX / __SHSAX after it, no multiplies in the last stage -- followed by its inverse twin
+      (__SMUSD / __SMUADX, the exchange forms swapped), which the analysers never call;
+    * AudioAnalyzeFFT256IQ::update (FFTIQ.cpp:86-105): SMUAD (re^2 + im^2) and UDIV (/ naverage) once per loop, two
+      loops, then sqrt_uint32_approx = CLZ (the guess index) and two UDIV (the two Newton steps);
+    * AudioAnalyzeFFT1024::update: SMUAD, then CLZ and two UDIV straight away -- no division by naverage, i.e. no
+      averaging, as restated (docs/widened_rows.md 6b)."""
+    names, offs = [str(n) for n in fw["code_ops_names"]], fw["code_ops_offsets"]
+    sh2 = ["SHADD16", "SHADD16"]                                  # T = __SHADD16(__SHADD16(T, 0), 0): the input >> 2
+    first = (sh2 + sh2 + ["QADD16", "QSUB16"]                     # ya, yc; R = T + S, S = T - S
+             + sh2 + sh2 + ["QADD16", "SHADD16", "QSUB16"]        # yb, yd; T = T + U; y0 = (R + T) >> 1; R = R - T
+             + ["SMUAD", "SMUSDX"]                                # co2, si2
+             + sh2 + sh2 + ["QSUB16", "QASX", "QSAX"]             # yb, yd again; T = T - U; R, S = the two exchange forms
+             + ["SMUAD", "SMUSDX", "SMUAD", "SMUSDX"])            # co1, si1; co3, si3
+    middle = (["QADD16", "QSUB16", "QADD16", "SHADD16", "SHADD16", "SHSUB16", "SMUAD", "SMUSDX"]
+              + ["QSUB16", "SHASX", "SHSAX", "SMUAD", "SMUSDX", "SMUAD", "SMUSDX"])
+    last = ["QADD16", "QADD16", "SHADD16", "QADD16", "SHSUB16", "QSUB16", "QSUB16", "SHSAX", "SHASX"]
+    forward = first + middle + last
+    swap = {"SMUAD": "SMUSD", "SMUSDX": "SMUADX", "QASX": "QSAX", "QSAX": "QASX", "SHASX": "SHSAX", "SHSAX": "SHASX"}
+    inverse = [swap.get(o, o) for o in forward]
+    par = [i for i, n in enumerate(names) if n not in ("CLZ", "UDIV", "SMUAD") or n == "SMUAD" and names[max(i - 1, 0)].endswith("16")
+           or n == "SMUAD" and i + 1 < len(names) and names[i + 1] == "SMUSDX"]
+    seq = [names[i] for i in par]
+    assert seq == forward + inverse, seq[:60]                     # nothing else in the image uses these instructions
+    assert len(forward) == 50 and offs[par[-1]] - offs[par[0]] < 0x600
+    # the same counts the restatement's first stage makes: 12 pre-shift halvings, 1 halving sum, 3 twiddle products
+    assert first.count("SHADD16") == 13 and first.count("SMUAD") == 3 and middle.count("SMUAD") == 3 and "SMUAD" not in last
+    # the analysers' update(): what surrounds the three remaining SMUADs
+    rest = [i for i, n in enumerate(names) if n == "SMUAD" and i not in par]
+    assert len(rest) == 3
+    a, b, c = rest
+    assert names[a:a + 2] == ["SMUAD", "UDIV"] and names[b:b + 5] == ["SMUAD", "UDIV", "CLZ", "UDIV", "UDIV"]     # 256IQ
+    assert offs[b + 4] - offs[a] < 0x100
+    assert names[c:c + 4] == ["SMUAD", "CLZ", "UDIV", "UDIV"] and offs[c + 3] - offs[c] < 0x20                      # FFT1024
+
+
+def test_code_of_the_image_runs_arm_lms_norm_f32_in_the_restatements_order_and_unfused(fw):
+    """arm_lms_norm_f32 (NR:73) sits in the image between the q15 butterflies and the literal pool that holds its
+    epsilon.  Its 28 single-precision operations, in address order, are the published per-sample body with its
+    four-times unrolled loops -- and every product is rounded before it is added (VMUL then VADD / VSUB: no VMLA, no
+    fused VFMA), which is what the oracle's plain C under -ffp-contract=off computes (oracle/Makefile):
+        energy -= x0 * x0; energy += in * in;            VMUL VSUB VMUL VADD
+        sum += x[i] * w[i]   (4 per pass + a tail loop)  4 VMUL + 4 VADD, VMUL VADD
+        energy + eps; e = d - sum; (e * mu) / (...)      VADD, VSUB, VMUL, VDIV
+        w[i] += step * x[i]  (4 per pass + a tail loop)  4 x (VMUL VADD), VMUL VADD
+    The CMSIS code of the image as a whole is unfused: its dense float regions hold no fused operation at all."""
+    names, offs = np.array([str(n) for n in fw["code_vfp_names"]]), fw["code_vfp_offsets"]
+    dsp_n, dsp_o = [str(n) for n in fw["code_ops_names"]], fw["code_ops_offsets"]
+    end_q15 = int(max(o for o, n in zip(dsp_o, dsp_n) if n in ("SHASX", "SHSAX")))          # last operation of the inverse butterfly
+    eps_at = int(fw["lms_epsilon_offset"])
+    assert 0 < eps_at - end_q15 < 0x400
+    sel = (offs > end_q15) & (offs < eps_at)
+    seq = names[sel].tolist()
+    assert len(seq) == 28 and not any(n in ("VFMA", "VFMS", "VFNMA", "VFNMS", "VMLA", "VMLS") for n in seq)
+    assert seq[:4] == ["VMUL", "VSUB", "VMUL", "VADD"]                                     # the energy, oldest sample out first
+    dot = seq[4:14]
+    assert dot.count("VMUL") == 5 and dot.count("VADD") == 5 and dot[-2:] == ["VMUL", "VADD"]
+    assert seq[14:18] == ["VADD", "VSUB", "VMUL", "VDIV"]                                   # energy + eps; e; e * mu; the division
+    assert seq[18:] == ["VMUL", "VADD"] * 5                                                 # the taps
+    fused = np.isin(names, ["VFMA", "VFMS", "VFNMA", "VFNMS"])
+    # the CMSIS float routines (transforms, magnitudes, LMS) are the dense float regions of the image: none is fused
+    dense = [(lo, ((offs >= lo) & (offs < lo + 0x400)).sum()) for lo in range(0, int(offs.max()), 0x400)]
+    for lo, cnt in dense:
+        if cnt >= 80 and lo != 0x16400:                     # (0x16400 is newlib's powf -- its L1..L6, cp and ln2 constants sit in
+                                                            # the literal pool behind it -- compiled with contraction, like the sketch)
+            assert not fused[(offs >= lo) & (offs < lo + 0x400)].any(), hex(lo)
