@@ -250,10 +250,13 @@ static void lms_noise_reduction(orc_lms_t *s, int n, float *nrbuffer, float *err
 /* ======================================================================== */
 /* F3: biquad cascades.  arm_biquad_cascade_df1_f32 role (the engine's audio filter bank,
  * {b0,b1,b2,a1,a2} x 4 stages in the firmware image) and Teensy's
- * AudioFilterBiquad (INO:58-59,155-156).  Neither library is in the tree: build-defined as
- * direct form 1 in float, per stage
- *     y = fma(a2, y2, fma(a1, y1, fma(b2, x2, fma(b1, x1, b0 * x))))
- * with the CMSIS sign convention (feedback terms are added).                              */
+ * AudioFilterBiquad (INO:58-59,155-156).  Neither library is in the tree.  arm_biquad_cascade_df1_f32 as
+ * CMSIS-DSP publishes it: direct form 1 in float, per stage
+ *     acc = (b0 * Xn) + (b1 * Xn1) + (b2 * Xn2) + (a1 * Yn1) + (a2 * Yn2)
+ * left to right, every product rounded before it is added (this file is built with -ffp-contract=off), feedback
+ * terms added.  The routine is in the reference's firmware image as 5 VMUL + 4 VADD per sample, unfused
+ * (tests/test_firmware_tables.py).  Teensy's AudioFilterBiquad (a fixed-point routine of the Audio library) stays
+ * build-defined as this same float cascade.                                                */
 /* ======================================================================== */
 void orc_biquad_init(orc_biquad_t *b, int n_stages, const float *coef5) {
   memset(b, 0, sizeof(*b));
@@ -275,11 +278,7 @@ void orc_biquad_run(orc_biquad_t *b, float *x, int n) {
     for (int s = 0; s < ORC_BIQUAD_MAX_STAGES; s++) {
       const float *c = b->coef + 5 * s;
       float *st = b->state + 4 * s; /* x1, x2, y1, y2 */
-      float y = c[0] * v;
-      y = fmaf(c[1], st[0], y);
-      y = fmaf(c[2], st[1], y);
-      y = fmaf(c[3], st[2], y);
-      y = fmaf(c[4], st[3], y);
+      float y = (c[0] * v) + (c[1] * st[0]) + (c[2] * st[1]) + (c[3] * st[2]) + (c[4] * st[3]);
       st[1] = st[0]; st[0] = v;
       st[3] = st[2]; st[2] = y;
       v = y;

@@ -9,10 +9,15 @@
  *     rdsp_sdr_setAudioFilterKind selects it (rdsp_chain.hip);
  *   * AudioFilterBiquad nodes, `biquad1.setHighpass(0, 500, 0.5)` in front of the panadapter
  *     (RadioDSP_SDR_RX.ino:58-59,75-78,155-156): rdsp_biquad_t + rdsp_biquad_node_create.
- * Neither library is in the tree, so the arithmetic is build-defined and the same as the test
- * restatement: direct form 1 in float, per stage
- *     y = fma(a2, y2, fma(a1, y1, fma(b2, x2, fma(b1, x1, b0 * x))))      (feedback terms added,
- * CMSIS coefficient order {b0, b1, b2, a1, a2}); four stages, unused ones pass through exactly.
+ * Neither library is in the tree.  The arithmetic is arm_biquad_cascade_df1_f32's as CMSIS-DSP publishes it:
+ * direct form 1 in float, per stage
+ *     acc = (b0 * Xn) + (b1 * Xn1) + (b2 * Xn2) + (a1 * Yn1) + (a2 * Yn2)
+ * summed left to right, EVERY PRODUCT ROUNDED BEFORE IT IS ADDED (feedback terms added, coefficient order
+ * {b0, b1, b2, a1, a2}) -- the routine is in the reference's firmware image (the engine's audio filters run through
+ * it) as 5 VMUL + 4 VADD per sample, no fused operation (tests/test_firmware_tables.py); until round 5 this was
+ * a chain of four fused multiply-adds.  Four stages, unused ones pass through exactly.  Teensy's AudioFilterBiquad is
+ * a fixed-point routine of the Audio library (not in the tree, not in the image's data): it stays build-defined
+ * as this same float cascade with the int16 pack at its output.
  *
  * Mapping: the recursion is serial in time but the four stages of a cascade pipeline: lane s of a
  * quad runs stage s on sample n = i - s at step i and takes its input from lane s-1 (one DPP
@@ -34,6 +39,20 @@ namespace {
 constexpr int TS = 128; /* samples per LDS tile */
 constexpr int TP = TS + 4;
 typedef float bq_v4 __attribute__((ext_vector_type(4)));
+
+/* one sample of one section: products rounded, sum left to right.  The pragma is what keeps the compiler from
+ * contracting product and sum into v_fmac_f32 (hipcc's default is -ffp-contract=fast, and __fmul_rn / __fadd_rn are
+ * plain operators to it); tests/test_host_logic.py looks at the generated code */
+__device__ __forceinline__ float df1_acc(float b0, float b1, float b2, float a1, float a2, float x, float x1, float x2,
+                                         float y1, float y2) {
+#pragma clang fp contract(off)
+  float acc = b0 * x;
+  acc = acc + b1 * x1;
+  acc = acc + b2 * x2;
+  acc = acc + a1 * y1;
+  acc = acc + a2 * y2;
+  return acc;
+}
 
 __device__ __forceinline__ int q15_trunc(float x) { /* arm_float_to_q15 (CONV:346-347): x*32768, truncate, saturate */
   float v = x * 32768.0f;
@@ -95,11 +114,7 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
       const float xup = __builtin_bit_cast(
           float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yprev), 0x90, 0xF, 0xF, false));
       const float x = (s == 0) ? xin0 : xup;
-      float y = b0 * x;
-      y = fmaf(b1, x1, y);
-      y = fmaf(b2, x2, y);
-      y = fmaf(a1, y1, y);
-      y = fmaf(a2, y2, y);
+      const float y = df1_acc(b0, b1, b2, a1, a2, x, x1, x2, y1, y2);
       if (active) {
         x2 = x1; x1 = x;
         y2 = y1; y1 = y;
@@ -121,11 +136,7 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
           const float xup = __builtin_bit_cast(
               float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yprev), 0x90, 0xF, 0xF, false));
           const float x = (s == 0) ? xin[k] : xup;
-          float y = b0 * x;
-          y = fmaf(b1, x1, y);
-          y = fmaf(b2, x2, y);
-          y = fmaf(a1, y1, y);
-          y = fmaf(a2, y2, y);
+          const float y = df1_acc(b0, b1, b2, a1, a2, x, x1, x2, y1, y2);
           x2 = x1; x1 = x;
           y2 = y1; y1 = y;
           yprev = y;

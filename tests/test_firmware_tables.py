@@ -348,6 +348,14 @@ def test_code_of_the_image_runs_arm_lms_norm_f32_in_the_restatements_order_and_u
     assert dot.count("VMUL") == 5 and dot.count("VADD") == 5 and dot[-2:] == ["VMUL", "VADD"]
     assert seq[14:18] == ["VADD", "VSUB", "VMUL", "VDIV"]                                   # energy + eps; e; e * mu; the division
     assert seq[18:] == ["VMUL", "VADD"] * 5                                                 # the taps
+    # arm_biquad_cascade_df1_f32 (the engine's audio filters): the first dense run behind the LMS code is five samples'
+    # worth -- four unrolled and the tail loop -- of 5 products and 4 sums each, unfused (csrc/rdsp_biquad.hip df1_acc)
+    after = np.where(offs > eps_at)[0]
+    run = [int(after[0])]
+    while run[-1] + 1 < len(offs) and offs[run[-1] + 1] - offs[run[-1]] <= 0x30:
+        run.append(run[-1] + 1)
+    bq = names[run].tolist()
+    assert bq.count("VMUL") == 25 and bq.count("VADD") == 20 and len(bq) == 45 and bq[:6] == ["VMUL"] * 5 + ["VADD"]
     fused = np.isin(names, ["VFMA", "VFMS", "VFNMA", "VFNMS"])
     # the CMSIS float routines (transforms, magnitudes, LMS) are the dense float regions of the image: none is fused
     dense = [(lo, ((offs >= lo) & (offs < lo + 0x400)).sum()) for lo in range(0, int(offs.max()), 0x400)]

@@ -199,6 +199,11 @@ def test_generated_code_keeps_the_instruction_forms_the_measurements_rest_on(tmp
         assert hit and all("s_barrier" not in v for v in hit), name
     tail = [v for n, v in k.items() if "rdsp_tail_kernel" in n][0]
     assert tail.count("ds_read_b64") >= 32   # the even sample pairs
+    # arm_biquad_cascade_df1_f32 rounds every product before it adds it (the reference's image: 5 VMUL + 4 VADD per
+    # sample); hipcc contracts by default, so the cascade kernel must show no fused operation at all
+    bq = [v for n, v in k.items() if "rdsp_biquad_kernel" in n][0]
+    assert not any(i.startswith(("v_fma", "v_fmac", "v_mad_f32", "v_mac_f32", "v_pk_fma")) for i in bq)
+    assert sum(i.startswith("v_mul_f32") for i in bq) >= 45 and sum(i.startswith("v_add_f32") for i in bq) >= 36
 
 
 def test_register_budget_of_the_two_kernels_that_share_a_simd(tmp_path):
