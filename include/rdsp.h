@@ -154,7 +154,10 @@ int rdsp_doConvolutionalProcessing(rdsp_chain_t *c, float iNRLevel, int bFilterE
                                    size_t in_stride, int n_blocks, int16_t *d_out,
                                    size_t out_stride, void *stream);
 
-/* arm_q15_to_float / arm_float_to_q15 call sites CONV:241-242,346-347 */
+/* arm_q15_to_float / arm_float_to_q15 call sites CONV:241-242,346-347.  q / 32768.0f; and, in the variant the reference's
+ * firmware image holds (CMSIS under ARM_MATH_ROUNDING): in = x * 32768, in += in > 0 ? 0.5f : -0.5f, (q15_t)__SSAT((q31_t)in,
+ * 16) -- round to nearest, halves away from zero, saturating; finite input.  Every int16 output of the library is packed
+ * this way. */
 int rdsp_q15_to_float(const int16_t *d_src, float *d_dst, size_t n, void *stream);
 int rdsp_float_to_q15(const float *d_src, int16_t *d_dst, size_t n, void *stream);
 

@@ -42,13 +42,19 @@ void orc_q15_to_float(const int16_t *src, float *dst, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) dst[i] = (float)src[i] / 32768.0f;
 }
 
-/* arm_float_to_q15 without ARM_MATH_ROUNDING: truncate toward zero, then
- * saturate to 16 bits (call sites CONV:346-347). */
+/* arm_float_to_q15 (call sites CONV:346-347) in the variant the reference's firmware image holds -- the one CMSIS
+ * compiles under ARM_MATH_ROUNDING:
+ *     in = *pIn++ * 32768.0f;  in += in > 0.0f ? 0.5f : -0.5f;  *pDst++ = (q15_t)__SSAT((q31_t)in, 16);
+ * i.e. round to nearest, halves away from zero (the image: VMOV #0.5 / #-0.5, VMUL, VCMP #0, VADD, VCVT toward zero,
+ * SSAT #16 per sample; tests/test_firmware_tables.py).  Rounds 1-4 restated the other variant (plain truncation).
+ * The cast saturates like VCVT.S32.F32 does, NaN gives 0. */
 void orc_float_to_q15(const float *src, int16_t *dst, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {
     float v = src[i] * 32768.0f;
+    v += v > 0.0f ? 0.5f : -0.5f;
     int32_t q;
-    if (!(v > -2147483648.0f)) q = INT32_MIN; /* also catches NaN */
+    if (v != v) q = 0;
+    else if (v <= -2147483648.0f) q = INT32_MIN;
     else if (v >= 2147483648.0f) q = INT32_MAX;
     else q = (int32_t)v;
     if (q > 32767) q = 32767;

@@ -54,8 +54,10 @@ __device__ __forceinline__ float df1_acc(float b0, float b1, float b2, float a1,
   return acc;
 }
 
-__device__ __forceinline__ int q15_trunc(float x) { /* arm_float_to_q15 (CONV:346-347): x*32768, truncate, saturate */
+__device__ __forceinline__ int q15_trunc(float x) { /* arm_float_to_q15 (CONV:346-347, the image's rounding variant): x*32768, +-0.5 by sign, truncate, saturate */
+#pragma clang fp contract(off) /* (x * 32768 is exact, so a fused form would give the same bits; kept unfused so that the kernel has no fused operation at all for the generated-code check to look for) */
   float v = x * 32768.0f;
+  v = v + (v > 0.0f ? 0.5f : -0.5f);
   v = fminf(fmaxf(v, -32768.0f), 32767.0f);
   return (int)v;
 }

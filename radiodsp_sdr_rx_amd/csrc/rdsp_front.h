@@ -203,10 +203,12 @@ RDSP_HD float2 cmul_pinned(float2 a, float2 b) { return cmul(a, b); }
 /* ... with b a field of the group record (wave-uniform) */
 RDSP_HD float2 cmul_pinned_u(float2 a, float2 b) { return cmul_uniform(a, b); }
 
-/* arm_float_to_q15 semantics (CONV:346-347): x*32768, truncate, saturate */
+/* arm_float_to_q15 semantics (CONV:346-347; the ARM_MATH_ROUNDING variant, which is what the reference's firmware
+ * image holds): x*32768, +-0.5 by sign, truncate, saturate */
 RDSP_HD int q15_of_float(float x) {
   float v = x * 32768.0f;
-  v = fminf(fmaxf(v, -32768.0f), 32767.0f);
+  v = v + (v > 0.0f ? 0.5f : -0.5f);
+  v = fminf(fmaxf(v, -32768.0f), 32767.0f);   /* (NaN -> -32768 here where the conversion instruction gives 0: rdsp_float_to_q15 documents finite input) */
   return (int)v;
 }
 

@@ -67,13 +67,20 @@ __device__ __forceinline__ float2 unpack_iq(uint32_t w, float si, float sq) {
   return make_float2(xr * si, xi * sq);
 }
 
-/* arm_float_to_q15 of both channels into one word (CONV:346-347): x*32768, truncate, saturate.
- * v_cvt_i32_f32 truncates (and saturates at int32), v_cvt_pk_i16_i32 saturates to int16 and
- * packs: 5 instructions (3 when l == r) where mul + clamp + convert + mask + shift-or took 12. */
+/* arm_float_to_q15 of both channels into one word (CONV:346-347), in the variant the reference's firmware image holds
+ * (CMSIS under ARM_MATH_ROUNDING): in = x * 32768; in += in > 0 ? 0.5f : -0.5f; (q15_t)__SSAT((q31_t)in, 16) -- round to
+ * nearest, halves away from zero.  copysign(0.5, in) stands for the select (it differs for in = +0 only, where 0.5 and
+ * -0.5 both convert to 0): v_bfi_b32 + v_add_f32; v_cvt_i32_f32 truncates (and saturates at int32, NaN -> 0, like
+ * VCVT.S32.F32), v_cvt_pk_i16_i32 saturates to int16 and packs. */
+__device__ __forceinline__ float q15_round_arg(float x) {
+  const float v = x * 32768.0f;
+  const float h = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, v) & 0x80000000u) | 0x3F000000u);
+  return v + h;
+}
 __device__ __forceinline__ uint32_t pack_lr(float l, float r) {
   int a, b;
-  asm("v_cvt_i32_f32 %0, %1" : "=v"(a) : "v"(l * 32768.0f));
-  asm("v_cvt_i32_f32 %0, %1" : "=v"(b) : "v"(r * 32768.0f));
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(a) : "v"(q15_round_arg(l)));
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(b) : "v"(q15_round_arg(r)));
   return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(a, b));
 }
 

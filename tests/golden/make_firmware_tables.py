@@ -35,6 +35,11 @@ DESIGN.md section 2):
                         Their ORDER is what the restatements of arm_radix4_butterfly_q15, of the analysers' update()
                         and of sqrt_uint32_approx are checked against (tests/test_firmware_tables.py): the image
                         cannot be run here, but the sequence of these operations in it can be read.
+  code_pack_names / code_pack_offsets
+                        the conversion routine behind CONV:346-347 (arm_float_to_q15): VMOV.F32 #0.5 / #-0.5, VMUL,
+                        VCMP #0, VADD, VCVT.S32.F32 (toward zero) and SSAT #16 in the code region of the five SSAT #16
+                        without a shift -- which of CMSIS' two variants the image holds (with or without
+                        ARM_MATH_ROUNDING)
   code_vfp_names / code_vfp_offsets
                         likewise the single-precision VFP arithmetic classes (VMUL, VADD, VSUB, VDIV, VNMUL and the
                         multiply-accumulates VMLA / VMLS / VFMA / VFMS / VFNMA / VFNMS): whether the image's CMSIS
@@ -151,6 +156,34 @@ def vfp_f32_classes(img):
     return np.array(offs, np.int64), np.array(names)
 
 
+def pack_routine_classes(img):
+    """The instruction classes of arm_float_to_q15 around the image's `SSAT Rd, #16, Rn` (no shift) instructions."""
+    hw = np.frombuffer(img[:len(img) // 2 * 2], dtype="<u2").astype(np.int64)
+    ssat = [2 * i for i in range(len(hw) - 1)
+            if (int(hw[i]) & 0xFFF0) == 0xF300 and (int(hw[i + 1]) & 0xF0FF) == 0x000F]      # sat_imm - 1 = 15, imm3:imm2 = 0
+    lo, hi = min(ssat) - 0x60, max(ssat) + 4
+    offs, names = [], []
+    for i in range(lo // 2, hi // 2):
+        h1, h2 = int(hw[i]), int(hw[i + 1])
+        name = None
+        if (h1 & 0xFFB0) == 0xEEB0 and (h2 & 0x0FF0) == 0x0A00 and (h1 & 0xF) in (0x6, 0xE) and (h2 & 0xF) == 0:
+            name = "VMOV #0.5" if (h1 & 0xF) == 0x6 else "VMOV #-0.5"
+        elif (h1 & 0xFFBF) == 0xEEB5 and (h2 & 0x0F50) == 0x0A40:
+            name = "VCMP #0"
+        elif (h1 & 0xFFBF) == 0xEEBD and (h2 & 0x0FD0) == 0x0AC0:
+            name = "VCVT.S32.F32"
+        elif (h1 & 0xFFF0) == 0xF300 and (h2 & 0xF0FF) == 0x000F:
+            name = "SSAT #16"
+        elif (h1 & 0xFFB0) == 0xEE20 and (h2 & 0x0F50) == 0x0A00:
+            name = "VMUL"
+        elif (h1 & 0xFFB0) == 0xEE30 and (h2 & 0x0F50) == 0x0A00:
+            name = "VADD"
+        if name:
+            offs.append(2 * i)
+            names.append(name)
+    return np.array(offs, np.int64), np.array(names)
+
+
 def main():
     if not os.path.exists(HEX):
         sys.exit("the reference tree is not here: this script runs in the build container only")
@@ -164,6 +197,7 @@ def main():
     out["biquad_sets"] = out["biquad_sets"].reshape(15, 4, 5)
     out["code_ops_offsets"], out["code_ops_names"] = dsp_opcode_classes(img)
     out["code_vfp_offsets"], out["code_vfp_names"] = vfp_f32_classes(img)
+    out["code_pack_offsets"], out["code_pack_names"] = pack_routine_classes(img)
     # sanity: what each table is, so a wrong offset cannot slip through
     i = np.arange(256)
     assert np.array_equal(out["hann256"], np.minimum(32767, np.round(32768 * 0.5 * (1 - np.cos(2 * np.pi * i / 255)))))

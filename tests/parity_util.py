@@ -29,7 +29,7 @@ def oracle_run(oracle, iq, cfg):
 
 
 def check_i16(o16, r16):
-    """int16 outputs agree to 1 LSB (a float that differs in its last bits may truncate to the neighbouring integer)"""
+    """int16 outputs agree to 1 LSB (a float that differs in its last bits may round to the neighbouring integer)"""
     d = np.abs(o16.astype(np.int32) - r16.astype(np.int32))
     assert d.max() <= 1, f"int16 differs by {d.max()} LSB"
     return int((d == 1).sum())
@@ -42,8 +42,10 @@ def model_run(iq, cfg):
 
 
 def q15_of(x64):
-    """arm_float_to_q15 of the float64 result (truncate, saturate; CONV:346-347)"""
-    return np.clip(np.trunc(x64 * 32768.0), -32768, 32767).astype(np.int32)
+    """arm_float_to_q15 of the float64 result (CONV:346-347; the firmware image's variant: +-0.5 by sign, truncate,
+    saturate = round to nearest, halves away from zero)"""
+    v = x64 * 32768.0
+    return np.clip(np.trunc(v + np.where(v > 0, 0.5, -0.5)), -32768, 32767).astype(np.int32)
 
 
 def assert_truth_anchored(g32, r32, f64, what, g16=None, r16=None):

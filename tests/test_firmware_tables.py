@@ -363,3 +363,21 @@ def test_code_of_the_image_runs_arm_lms_norm_f32_in_the_restatements_order_and_u
         if cnt >= 80 and lo != 0x16400:                     # (0x16400 is newlib's powf -- its L1..L6, cp and ln2 constants sit in
                                                             # the literal pool behind it -- compiled with contraction, like the sketch)
             assert not fused[(offs >= lo) & (offs < lo + 0x400)].any(), hex(lo)
+
+
+def test_pack_routine_of_the_image_rounds(fw, oracle):
+    """CONV:346-347 calls arm_float_to_q15, which CMSIS compiles in one of two variants.  The image holds the one under
+    ARM_MATH_ROUNDING: the constants 0.5 and -0.5 are loaded once per loop, and every sample is VMUL (x 32768), VCMP #0,
+    VADD (the half), VCVT.S32.F32 (toward zero), SSAT #16 -- four unrolled and a tail loop.  (The other variant has no
+    compare and no add.)  Oracle and kernels restate exactly this: round to nearest, halves away from zero."""
+    names = [str(n) for n in fw["code_pack_names"]]
+    start = names.index("VMOV #0.5")
+    seq = names[start:]
+    sample = ["VMUL", "VCMP #0", "VADD", "VCVT.S32.F32", "SSAT #16"]
+    assert seq == ["VMOV #0.5", "VMOV #-0.5"] + sample * 4 + ["VMOV #0.5", "VMOV #-0.5"] + sample
+    lib = oracle.load()
+    lib.orc_float_to_q15.argtypes = [C.POINTER(C.c_float), I16P, C.c_uint32]
+    x = np.array([0.4, 0.5, 0.6, 1.5, 2.5, -0.4, -0.5, -0.6, -1.5, -2.5, 32766.5, 32767.5, -32768.5], np.float32) / np.float32(32768.0)
+    q = np.zeros(len(x), np.int16)
+    lib.orc_float_to_q15(x.ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(I16P), len(x))
+    assert q.tolist() == [0, 1, 1, 2, 3, 0, -1, -1, -2, -3, 32767, 32767, -32768]

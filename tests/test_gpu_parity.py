@@ -18,7 +18,7 @@ Tolerances (written here, used below):
     i.e. the GPU may not be further from the exact result than the reference arithmetic
     is (assert_truth_anchored; measured: the GPU sits at about half the oracle's distance).  No tolerance looser than 1e-5 is expressed against the
     float32 oracle.
-  * int16 outputs: +-1 LSB where the float audio differs across a truncation
+  * int16 outputs: +-1 LSB where the float audio differs across a rounding
     boundary (count reported), never more; on NLMS chains the same truth-anchored rule
     in LSB against the int16 of the float64 result.
 """

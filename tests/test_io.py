@@ -143,7 +143,7 @@ def test_files_through_the_runner_match_resident_processing_and_oracle(rdsp, ora
         parts.append(ref_chain.process(dev).cpu().numpy())
         pos += take
     assert np.array_equal(got, np.concatenate(parts, 1))
-    # and the oracle on the int16 audio: the feed-forward chain directly (one LSB at truncation
+    # and the oracle on the int16 audio: the feed-forward chain directly (one LSB at rounding
     # boundaries); the chain with the NLMS stage is bit-identical to resident processing (above), which
     # the truth-anchored tests of test_gpu_parity.py hold against the oracle and the float64 model
     if name == "k1":

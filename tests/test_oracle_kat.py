@@ -28,15 +28,21 @@ def test_q15_to_float_all_values_bit_exact(oracle):
     assert dst.min() == -1.0 and dst.max() == np.float32(32767 / 32768)
 
 
-def test_float_to_q15_truncates_and_saturates(oracle):
+def test_float_to_q15_rounds_half_away_from_zero_and_saturates(oracle):
+    """arm_float_to_q15 as the reference's firmware image has it (the ARM_MATH_ROUNDING variant: in * 32768, +-0.5 by
+    sign, cast toward zero, __SSAT 16; tests/test_firmware_tables.py reads the sequence out of the image)."""
     lib = oracle.load()
-    src = np.array([0.0, 0.5, -0.5, 0.99999, 1.0, 1.5, -1.0, -1.5, 3.0517578125e-05 * 0.99,
-                    -3.0517578125e-05 * 0.99, 0.25 + 1e-5, 1e9, -1e9], np.float32)
+    lsb = 3.0517578125e-05
+    src = np.array([0.0, 0.5, -0.5, 0.99999, 1.0, 1.5, -1.0, -1.5, lsb * 0.49, -lsb * 0.49, lsb * 0.5, -lsb * 0.5,
+                    lsb * 1.5, -lsb * 2.5, 0.25 + 1e-5, 1e9, -1e9, np.nan, -0.0], np.float32)
     dst = np.zeros(len(src), np.int16)
     lib.orc_float_to_q15(_p(src, C.c_float), _p(dst, C.c_int16), len(src))
-    exp = np.clip(np.trunc(src.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+    v = src.astype(np.float64) * 32768.0
+    with np.errstate(invalid="ignore"):
+        exp = np.clip(np.trunc(np.nan_to_num(v + np.where(v > 0, 0.5, -0.5))), -32768, 32767).astype(np.int16)
     assert np.array_equal(dst, exp)
-    assert dst[8] == 0 and dst[9] == 0  # truncation toward zero, not rounding
+    assert dst[8] == 0 and dst[9] == 0 and dst[10] == 1 and dst[11] == -1 and dst[12] == 2 and dst[13] == -3   # nearest, halves away
+    assert dst[3] == 32767 and dst[4] == 32767 and dst[6] == -32768 and dst[17] == 0
 
 
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096])
