@@ -517,23 +517,40 @@ float rdsp_spectrum_node_read(rdsp_node_t *n, int ch, unsigned int binNumber);  
 float rdsp_spectrum_node_read_range(rdsp_node_t *n, int ch, unsigned int binFirst, unsigned int binLast); /* FFTIQ.h:75 */
 int rdsp_spectrum_node_status(rdsp_node_t *n);
 
-/* ---- F3: biquad cascades (AudioFilterBiquad, INO:58-59,75-78,155-156; the engine's IIR audio
- * filter bank, CTL:153-177 / SURVEY Appendix C) -------------------------------------------------
- * Direct form 1 in float, up to four stages, y = b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2 with the
- * feedback coefficients stored negated like arm_biquad_cascade_df1_f32 (build-defined: neither
- * library is in the tree).  Design helpers (host): */
+/* ---- F3: biquad cascades ----------------------------------------------------------------------------------------
+ * Two different routines of two different libraries, neither in the reference tree, both restated from their published
+ * sources and both confirmed in structure by the code of the reference's firmware image (tests/test_firmware_tables.py):
+ *
+ * (1) the engine's IIR audio filter bank (CTL:153-177 / SURVEY Appendix C): CMSIS-DSP's arm_biquad_cascade_df1_f32 --
+ *     direct form 1 in float, acc = (b0 Xn) + (b1 Xn1) + (b2 Xn2) + (a1 Yn1) + (a2 Yn2), every product rounded
+ *     before it is added, feedback coefficients stored negated.  In the chain: rdsp_sdr_setAudioFilterKind below.
+ *     Design helpers (host): */
 void rdsp_biquad_design(int kind, double freq, double q, double fs, float *coef5); /* 0 LP, 1 HP, 2 BP, 3 notch */
 void rdsp_design_audio_iir(double f1, double f2, double fs, float *coef20);        /* 8th-order Butterworth band-pass */
+/* (2) `AudioFilterBiquad biquad1, biquad2;` (INO:58-59,75-78; `setHighpass(0, 500, 0.5)` INO:155-156): the Teensy Audio
+ *     library's FIXED-POINT cascade -- coefficients int32 x 2^30 (a1, a2 stored negated), five 32 x 16 products per
+ *     sample that keep the top 32 of 48 bits (SMLAWB / SMLAWT), accumulated on the 14 fractional bits the previous
+ *     sample left (`sum &= 0x3FFF`), output `signed_saturate_rshift(sum, 16, 14)`; a fresh object passes nothing
+ *     (all-zero coefficients); update() runs stage 0 and goes on to stage s + 1 only if setCoefficients(s + 1) was
+ *     ever called; a setter clears its stage's residue and keeps its sample history.  int16 in, int16 out, bit-exact
+ *     against the test restatement.  fs: AUDIO_SAMPLE_RATE_EXACT (44100.0 in the reference's image). */
 typedef struct rdsp_biquad rdsp_biquad_t; /* AudioFilterBiquad for n_channels streams */
 int rdsp_biquad_create(int n_channels, int device, double fs, rdsp_biquad_t **out);
 void rdsp_biquad_destroy(rdsp_biquad_t *b);
-/* setCoefficients(stage, {b0, b1, b2, a1, a2}) with H = (b0 + b1/z + b2/z^2) / (1 + a1/z + a2/z^2) */
+/* setCoefficients(stage, const double *{b0, b1, b2, a1, a2}) with H = (b0 + b1/z + b2/z^2) / (1 + a1/z + a2/z^2): each
+ * coefficient x 1073741824.0 converted to int; setCoefficients(stage, const int *) takes them already scaled */
 int rdsp_biquad_setCoefficients(rdsp_biquad_t *b, int stage, const double *coefficients);
+int rdsp_biquad_setCoefficients_int(rdsp_biquad_t *b, int stage, const int32_t *coefficients);
 int rdsp_biquad_setLowpass(rdsp_biquad_t *b, int stage, float frequency, float q);
 int rdsp_biquad_setHighpass(rdsp_biquad_t *b, int stage, float frequency, float q);  /* INO:155-156 */
 int rdsp_biquad_setBandpass(rdsp_biquad_t *b, int stage, float frequency, float q);
 int rdsp_biquad_setNotch(rdsp_biquad_t *b, int stage, float frequency, float q);
-int rdsp_biquad_get_coeffs(const rdsp_biquad_t *b, float *out20);
+/* what the four setters compute (host, no device): RBJ cookbook in double with w0 = frequency * (2 * 3.141592654f / fs)
+ * as a float product, each coefficient x 2^30 / (1 + alpha) converted to int; a1, a2 as the transfer function writes
+ * them (setCoefficients negates).  kind 0 LP, 1 HP, 2 BP, 3 notch */
+void rdsp_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5);
+int rdsp_biquad_get_definition(const rdsp_biquad_t *b, int32_t *out20, int *n_stages); /* b0, b1, b2, -a1, -a2 x 2^30 per stage */
+int rdsp_biquad_get_coeffs(const rdsp_biquad_t *b, float *out20);                    /* the same / 2^30 */
 /* n_blocks update() ticks: int16 [n_channels][stride] samples read / written every `step` int16
  * (1: planar mono blocks; 2: one side of interleaved pairs, e.g. the I or the Q of an IQ stream) */
 int rdsp_biquad_update(rdsp_biquad_t *b, const int16_t *d_in, size_t in_stride, int in_step, int n_blocks,

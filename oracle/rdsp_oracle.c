@@ -255,14 +255,13 @@ static void lms_noise_reduction(orc_lms_t *s, int n, float *nrbuffer, float *err
 /* ------------------------------------------------------------------------ */
 /* ======================================================================== */
 /* F3: biquad cascades.  arm_biquad_cascade_df1_f32 role (the engine's audio filter bank,
- * {b0,b1,b2,a1,a2} x 4 stages in the firmware image) and Teensy's
- * AudioFilterBiquad (INO:58-59,155-156).  Neither library is in the tree.  arm_biquad_cascade_df1_f32 as
+ * {b0,b1,b2,a1,a2} x 4 stages in the firmware image); Teensy's fixed-point
+ * AudioFilterBiquad (INO:58-59,155-156) follows further down.  Neither library is in the tree.  arm_biquad_cascade_df1_f32 as
  * CMSIS-DSP publishes it: direct form 1 in float, per stage
  *     acc = (b0 * Xn) + (b1 * Xn1) + (b2 * Xn2) + (a1 * Yn1) + (a2 * Yn2)
  * left to right, every product rounded before it is added (this file is built with -ffp-contract=off), feedback
  * terms added.  The routine is in the reference's firmware image as 5 VMUL + 4 VADD per sample, unfused
- * (tests/test_firmware_tables.py).  Teensy's AudioFilterBiquad (a fixed-point routine of the Audio library) stays
- * build-defined as this same float cascade.                                                */
+ * (tests/test_firmware_tables.py).                                                           */
 /* ======================================================================== */
 void orc_biquad_init(orc_biquad_t *b, int n_stages, const float *coef5) {
   memset(b, 0, sizeof(*b));
@@ -292,8 +291,8 @@ void orc_biquad_run(orc_biquad_t *b, float *x, int n) {
     x[i] = v;
   }
 }
-/* AudioFilterBiquad::setLowpass/setHighpass/setBandpass/setNotch (Teensy filter_biquad.h; not in
- * the tree: the published RBJ audio-EQ formulas that library documents), double design narrowed
+/* RBJ audio-EQ sections for the float cascade (a design helper of this build, e.g. for single sections of
+ * the engine's bank; AudioFilterBiquad's own setters are orc_teensy_biquad_design below): double design narrowed
  * to float, feedback coefficients stored negated like CMSIS.  kind: 0 LP, 1 HP, 2 BP, 3 notch. */
 void orc_biquad_design(int kind, double freq, double q, double fs, float *coef5) {
   const double w0 = freq * (2.0 * 3.14159265358979323846 / fs);
@@ -310,6 +309,81 @@ void orc_biquad_design(int kind, double freq, double q, double fs, float *coef5)
   coef5[3] = (float)(-((-2.0 * cosW0) * scale));
   coef5[4] = (float)(-((1.0 - alpha) * scale));
 }
+/* ---- AudioFilterBiquad of the Teensy Audio library (INO:58-59,75-78,155-156), as the library publishes it --------
+ * filter_biquad.{h,cpp}: a FIXED-POINT cascade.  Coefficients are int32 scaled by 2^30 (a1, a2 stored negated); the
+ * five products of a sample are 32 x 16 multiplies that keep the top 32 of 48 bits (SMLAWB / SMLAWT:
+ * signed_multiply_accumulate_32x16b / t), accumulated on top of the 14 fractional bits the previous sample left
+ * behind (`sum &= 0x3FFF`: first-order error feedback), and the output is `signed_saturate_rshift(sum, 16, 14)`.
+ * update() works on pairs of samples packed in 32-bit words; unpacked, that is the per-sample recursion below (the
+ * second sample of a pair takes the first one's saturated output as y[n-1], exactly as `a1 * out2` does there).
+ * The reference's firmware image holds the routine: UBFX, SMLAWB, SMLAWT, SMLAWB, SMLAWT, SMLAWB, SSAT #16 ASR #14,
+ * UBFX, SMLAWT, SMLAWB, SMLAWT, SMLAWB, SMLAWT, SSAT #16 ASR #14, PKHBT, UBFX (tests/test_firmware_tables.py), and the
+ * float constant 2 * 3.141592654f / 44100.0f of the setters.  A stage that was never set has all-zero coefficients
+ * ("by default, the filter will not pass anything"); update() always runs stage 0 and goes on to stage s + 1 only
+ * if setCoefficients(s + 1) was ever called (it sets the hand-on bit in stage s). */
+void orc_teensy_biquad_init(orc_teensy_biquad_t *b) { memset(b, 0, sizeof(*b)); }
+/* setCoefficients(uint32_t stage, const int *coefficients) */
+void orc_teensy_biquad_setCoefficients_int(orc_teensy_biquad_t *b, int stage, const int32_t *c) {
+  if (stage < 0 || stage >= 4) return;
+  b->coef[stage][0] = c[0];
+  b->coef[stage][1] = c[1];
+  b->coef[stage][2] = c[2];
+  b->coef[stage][3] = (int32_t)(0u - (uint32_t)c[3]); /* `*coefficients++ * -1` */
+  b->coef[stage][4] = (int32_t)(0u - (uint32_t)c[4]);
+  b->sum[stage] = 0;                                 /* `*dest &= 0x80000000`: the residue goes, x and y history stay */
+  if (stage > 0) b->chained[stage - 1] = 1;          /* `if (stage > 0) *(dest - 1) |= 0x80000000` */
+}
+/* setCoefficients(uint32_t stage, const double *coefficients): each times 1073741824.0, converted to int */
+void orc_teensy_biquad_setCoefficients(orc_teensy_biquad_t *b, int stage, const double *c) {
+  int32_t ci[5];
+  for (int i = 0; i < 5; i++) ci[i] = (int32_t)(c[i] * 1073741824.0);
+  orc_teensy_biquad_setCoefficients_int(b, stage, ci);
+}
+/* setLowpass / setHighpass / setBandpass / setNotch (filter_biquad.h; the RBJ cookbook in double, the angle from a
+ * float product: `frequency * (2.0f * 3.141592654f / AUDIO_SAMPLE_RATE_EXACT)`).  kind 0 LP, 1 HP, 2 BP, 3 notch */
+void orc_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5) {
+  const double w0 = frequency * (2.0f * 3.141592654f / fs);
+  const double sinW0 = sin(w0);
+  const double alpha = sinW0 / ((double)q * 2.0);
+  const double cosW0 = cos(w0);
+  const double scale = 1073741824.0 / (1.0 + alpha);
+  switch (kind) {
+    case 0: coef5[0] = (int32_t)(((1.0 - cosW0) / 2.0) * scale); coef5[1] = (int32_t)((1.0 - cosW0) * scale); coef5[2] = coef5[0]; break;
+    case 1: coef5[0] = (int32_t)(((1.0 + cosW0) / 2.0) * scale); coef5[1] = (int32_t)(-(1.0 + cosW0) * scale); coef5[2] = coef5[0]; break;
+    case 2: coef5[0] = (int32_t)(alpha * scale); coef5[1] = 0; coef5[2] = (int32_t)((-alpha) * scale); break;
+    default: coef5[0] = (int32_t)scale; coef5[1] = (int32_t)((-2.0 * cosW0) * scale); coef5[2] = coef5[0]; break;
+  }
+  coef5[3] = (int32_t)((-2.0 * cosW0) * scale);
+  coef5[4] = (int32_t)((1.0 - alpha) * scale);
+}
+static inline int32_t orc_smlaw(int32_t acc, int32_t c, int16_t v) { /* acc + ((c * v) >> 16), 32-bit wrap-around */
+  return (int32_t)((uint32_t)acc + (uint32_t)(int32_t)(((int64_t)c * (int64_t)v) >> 16));
+}
+/* one update(): n samples of one channel in place, stage after stage */
+void orc_teensy_biquad_update(orc_teensy_biquad_t *b, int16_t *data, int n) {
+  for (int st = 0; st < 4; st++) { /* do { ... flag = *state & 0x80000000; ... } while (flag); */
+    if (st > 0 && !b->chained[st - 1]) break;
+    const int32_t *c = b->coef[st];
+    int16_t x1 = b->x1[st], x2 = b->x2[st], y1 = b->y1[st], y2 = b->y2[st];
+    int32_t sum = b->sum[st] & 0x3FFF;
+    for (int i = 0; i < n; i++) {
+      const int16_t x = data[i];
+      sum = orc_smlaw(sum, c[0], x);
+      sum = orc_smlaw(sum, c[1], x1);
+      sum = orc_smlaw(sum, c[2], x2);
+      sum = orc_smlaw(sum, c[3], y1);
+      sum = orc_smlaw(sum, c[4], y2);
+      int32_t y = sum >> 14;                       /* signed_saturate_rshift(sum, 16, 14) */
+      y = y > 32767 ? 32767 : (y < -32768 ? -32768 : y);
+      sum &= 0x3FFF;
+      x2 = x1; x1 = x;
+      y2 = y1; y1 = (int16_t)y;
+      data[i] = (int16_t)y;
+    }
+    b->x1[st] = x1; b->x2[st] = x2; b->y1[st] = y1; b->y2[st] = y2; b->sum[st] = sum;
+  }
+}
+
 /* 8th-order Butterworth band-pass f1..f2 as four biquads (the shape SURVEY Appendix C reads out
  * of the firmware image: -3 dB at 150 Hz and at 2.1 ... 3.9 kHz): analog 4th-order prototype,
  * LP -> BP, bilinear transform with pre-warped edges; each section has one zero at z = 1 and one

@@ -209,7 +209,7 @@ void orc_fft1024_destroy(orc_fft1024_t *s);
 void orc_fft1024_windowFunction_table(orc_fft1024_t *s, const int16_t *w1024);
 int orc_fft1024_update(orc_fft1024_t *s, const int16_t *block);
 const uint16_t *orc_fft1024_output(const orc_fft1024_t *s); /* uint16 output[512] */
-/* biquad cascades (engine audio filter bank, AudioFilterBiquad): DF1, float, CMSIS coefficient
+/* biquad cascade of the engine's audio filter bank (arm_biquad_cascade_df1_f32): DF1, float, CMSIS coefficient
  * order {b0, b1, b2, a1, a2} per stage with the feedback terms added */
 #define ORC_BIQUAD_MAX_STAGES 4
 typedef struct { int n_stages; float coef[5 * ORC_BIQUAD_MAX_STAGES]; float state[4 * ORC_BIQUAD_MAX_STAGES]; } orc_biquad_t;
@@ -217,6 +217,14 @@ void orc_biquad_init(orc_biquad_t *b, int n_stages, const float *coef5);
 void orc_biquad_set_stage(orc_biquad_t *b, int stage, const float *coef5);
 void orc_biquad_run(orc_biquad_t *b, float *x, int n);
 void orc_biquad_design(int kind, double freq, double q, double fs, float *coef5); /* 0 LP 1 HP 2 BP 3 notch */
+/* AudioFilterBiquad of the Teensy Audio library as published: fixed-point cascade, coefficients x 2^30, SMLAWB/T
+ * products, 14-bit error feedback, SSAT >> 14 (see the .c file) */
+typedef struct { int chained[4]; int32_t coef[4][5]; int16_t x1[4], x2[4], y1[4], y2[4]; int32_t sum[4]; } orc_teensy_biquad_t;
+void orc_teensy_biquad_init(orc_teensy_biquad_t *b);
+void orc_teensy_biquad_setCoefficients_int(orc_teensy_biquad_t *b, int stage, const int32_t *coef5);
+void orc_teensy_biquad_setCoefficients(orc_teensy_biquad_t *b, int stage, const double *coef5);
+void orc_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5);
+void orc_teensy_biquad_update(orc_teensy_biquad_t *b, int16_t *data, int n);
 void orc_design_butter_bp8(double f1, double f2, double fs, float *coef20);
 void orc_set_audio_iir(orc_chain_t *c, int on, double f1, double f2);
 const float *orc_chain_iir_coeffs(const orc_chain_t *c);

@@ -219,6 +219,9 @@ SYMBOLS = [
     ("rdsp_biquad_setBandpass", _i, [_vp, _i, _f, _f]),
     ("rdsp_biquad_setNotch", _i, [_vp, _i, _f, _f]),
     ("rdsp_biquad_get_coeffs", _i, [_vp, _f32p]),
+    ("rdsp_biquad_get_definition", _i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
+    ("rdsp_biquad_setCoefficients_int", _i, [_vp, _i, C.POINTER(C.c_int32)]),
+    ("rdsp_teensy_biquad_design", None, [_i, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]),
     ("rdsp_biquad_update", _i, [_vp, _vp, _sz, _i, _i, _vp, _sz, _i, _vp]),
     ("rdsp_biquad_node_create", _vp, [_vp, _vp]),
     ("rdsp_biquad_node_status", _i, [_vp]),

@@ -1,23 +1,30 @@
 /*
  * rdsp_biquad.hip -- biquad cascades on the GPU.
  *
- * Two callers share one kernel:
+ * Two callers, two routines of two libraries (neither in the tree), one kernel body with two section types:
  *   * the engine's IIR audio filter bank: SDR.setAudioFilter(audioCW ... audioAM)
  *     (RDSP_controls.h:153-177) is a table of 8th-order band-passes in
  *     arm_biquad_cascade_df1_f32 layout in the shipped firmware; the chain
  *     runs it on the demodulated mono audio between the front kernel and the tail stage when
- *     rdsp_sdr_setAudioFilterKind selects it (rdsp_chain.hip);
+ *     rdsp_sdr_setAudioFilterKind selects it (rdsp_chain.hip).  SectionF32: arm_biquad_cascade_df1_f32 as
+ *     CMSIS-DSP publishes it, direct form 1 in float, per stage
+ *         acc = (b0 * Xn) + (b1 * Xn1) + (b2 * Xn2) + (a1 * Yn1) + (a2 * Yn2)
+ *     summed left to right, EVERY PRODUCT ROUNDED BEFORE IT IS ADDED (feedback terms added, coefficient order
+ *     {b0, b1, b2, a1, a2}) -- the routine is in the reference's firmware image as 5 VMUL + 4 VADD per sample, no
+ *     fused operation (tests/test_firmware_tables.py); until round 5 this was a chain of four fused multiply-adds.
+ *     Four stages, unused ones pass through exactly.
  *   * AudioFilterBiquad nodes, `biquad1.setHighpass(0, 500, 0.5)` in front of the panadapter
- *     (RadioDSP_SDR_RX.ino:58-59,75-78,155-156): rdsp_biquad_t + rdsp_biquad_node_create.
- * Neither library is in the tree.  The arithmetic is arm_biquad_cascade_df1_f32's as CMSIS-DSP publishes it:
- * direct form 1 in float, per stage
- *     acc = (b0 * Xn) + (b1 * Xn1) + (b2 * Xn2) + (a1 * Yn1) + (a2 * Yn2)
- * summed left to right, EVERY PRODUCT ROUNDED BEFORE IT IS ADDED (feedback terms added, coefficient order
- * {b0, b1, b2, a1, a2}) -- the routine is in the reference's firmware image (the engine's audio filters run through
- * it) as 5 VMUL + 4 VADD per sample, no fused operation (tests/test_firmware_tables.py); until round 5 this was
- * a chain of four fused multiply-adds.  Four stages, unused ones pass through exactly.  Teensy's AudioFilterBiquad is
- * a fixed-point routine of the Audio library (not in the tree, not in the image's data): it stays build-defined
- * as this same float cascade with the int16 pack at its output.
+ *     (RadioDSP_SDR_RX.ino:58-59,75-78,155-156): rdsp_biquad_t + rdsp_biquad_node_create.  SectionTeensy: the Teensy
+ *     Audio library's FIXED-POINT update() as the firmware image holds it (0xe1b8 ... 0xe21e: SMLAWB / SMLAWT x 5,
+ *     SSAT #16 ASR #14, UBFX #0 #14, twice per loop turn, PKHBT): int32 coefficients x 2^30 with a1, a2 stored
+ *     negated, per sample
+ *         sum += (b0 x) >> 16; sum += (b1 x1) >> 16; sum += (b2 x2) >> 16; sum += (a1 y1) >> 16; sum += (a2 y2) >> 16
+ *         y = ssat16(sum >> 14); sum &= 0x3FFF
+ *     on 48-bit products and a 32-bit wrap-around accumulator; history is int16 (y1, y2 are the SATURATED outputs);
+ *     update() runs stage 0 and goes on to stage s + 1 only if setCoefficients(s + 1) was ever called; a fresh object
+ *     has all-zero coefficients and passes nothing.  Until round 5 this object was the float cascade above with the
+ *     int16 pack at its output -- up to a count away from what the reference's hardware computes, and passing the
+ *     signal through where the reference passes nothing.
  *
  * Mapping: the recursion is serial in time but the four stages of a cascade pipeline: lane s of a
  * quad runs stage s on sample n = i - s at step i and takes its input from lane s-1 (one DPP
@@ -28,6 +35,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "rdsp_host.h"
@@ -62,19 +70,61 @@ __device__ __forceinline__ int q15_trunc(float x) { /* arm_float_to_q15 (CONV:34
   return (int)v;
 }
 
-__global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
-  __shared__ __attribute__((aligned(16))) float tile[16][TP];
+/* one section of a cascade in lane s of a quad: the two arithmetics the kernel runs.  W is the 32-bit word that sits
+ * in the LDS tile and travels between the stages by DPP. */
+struct SectionF32 { /* arm_biquad_cascade_df1_f32 (the chain's IIR bank; float audio in place) */
+  float b0, b1, b2, a1, a2, x1, x2, y1, y2;
+  float *st;
+  __device__ __forceinline__ void load(const RdspBiquadParams &p, int ch, int s) {
+    const uint32_t set = p.set_of ? (uint32_t)p.set_of[ch] : 0u;
+    const float *cf = p.coef + (size_t)set * 20 + 5 * s;
+    b0 = cf[0]; b1 = cf[1]; b2 = cf[2]; a1 = cf[3]; a2 = cf[4];
+    st = p.state + (size_t)ch * 16 + 4 * s;
+    x1 = st[0]; x2 = st[1]; y1 = st[2]; y2 = st[3];
+  }
+  __device__ __forceinline__ float eval(float x) const { return df1_acc(b0, b1, b2, a1, a2, x, x1, x2, y1, y2); }
+  __device__ __forceinline__ void commit(float x, float y) { x2 = x1; x1 = x; y2 = y1; y1 = y; }
+  __device__ __forceinline__ void store() const { st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2; }
+};
+/* AudioFilterBiquad::update of the Teensy Audio library (filter_biquad.cpp), per sample: five 32 x 16 products that keep
+ * the top 32 of 48 bits (SMLAWB / SMLAWT) on top of the 14 fractional bits of the previous sample's sum, output
+ * signed_saturate_rshift(sum, 16, 14), `sum &= 0x3FFF` stays behind.  W = the int16 sample, sign-extended. */
+struct SectionTeensy {
+  int c0, c1, c2, c3, c4, x1, x2, y1, y2, sum;
+  int *st;
+  bool on; /* stages behind the cascade's last one do not run: the audio passes them untouched */
+  static __device__ __forceinline__ int smlaw(int acc, int c, int v) { return acc + (int)(((long long)c * (long long)v) >> 16); }
+  __device__ __forceinline__ void load(const RdspBiquadParams &p, int ch, int s) {
+    const int *cf = p.icoef + 5 * s;
+    c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
+    on = s < (p.n_stages > 0 ? p.n_stages : 1); /* update()'s do-while runs stage 0 even when nothing was ever set */
+    st = p.istate + (size_t)ch * 20 + 5 * s;
+    x1 = st[0]; x2 = st[1]; y1 = st[2]; y2 = st[3]; sum = st[4];
+  }
+  __device__ __forceinline__ int eval(int x) {
+    if (!on) return x;
+    int acc = sum & 0x3FFF;
+    acc = smlaw(acc, c0, x); acc = smlaw(acc, c1, x1); acc = smlaw(acc, c2, x2); acc = smlaw(acc, c3, y1); acc = smlaw(acc, c4, y2);
+    pending = acc;
+    const int y = acc >> 14;
+    return y > 32767 ? 32767 : (y < -32768 ? -32768 : y);
+  }
+  __device__ __forceinline__ void commit(int x, int y) { if (on) { x2 = x1; x1 = x; y2 = y1; y1 = y; sum = pending & 0x3FFF; } }
+  __device__ __forceinline__ void store() const { st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2; st[4] = sum; }
+  int pending;
+};
+
+template <typename SEC, typename W>
+__device__ __forceinline__ void biquad_body(const RdspBiquadParams &p, W (*tile)[TP]) {
   const int lane = threadIdx.x;
   const int cl = lane >> 2, s = lane & 3;
   const int ch0 = p.ch_base + (int)blockIdx.x * 16;
   int ch = ch0 + cl;
   const bool valid = ch < p.n_channels;
   if (!valid) ch = p.n_channels - 1;
-  const uint32_t set = p.set_of ? (uint32_t)p.set_of[ch] : 0u;
-  const float *cf = p.coef + (size_t)set * 20 + 5 * s;
-  const float b0 = cf[0], b1 = cf[1], b2 = cf[2], a1 = cf[3], a2 = cf[4];
-  float *st = p.state + (size_t)ch * 16 + 4 * s;
-  float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+  SEC sec;
+  sec.load(p, ch, s);
+  constexpr bool FIXED = std::is_same<SEC, SectionTeensy>::value;
   /* float tiles: this lane's piece of rows (lane >> 5) + 2 it (rows past the last channel read a real one) */
   size_t row_off[8];
 #pragma unroll
@@ -83,6 +133,9 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
     if (rch >= p.n_channels) rch = p.n_channels - 1;
     row_off[it] = (size_t)rch * p.stride + 4 * (lane & 31);
   }
+  auto dpp_up = [](W v) { /* lane s takes lane s-1's value: quad_perm [0,0,1,2] */
+    return __builtin_bit_cast(W, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x90, 0xF, 0xF, false));
+  };
 
 #pragma unroll 1
   for (int t0 = 0; t0 < p.n_samples; t0 += TS) {
@@ -93,10 +146,15 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
         int rch = ch0 + row;
         if (rch >= p.n_channels) rch = p.n_channels - 1;
         const int16_t *src = p.in16 + ((size_t)rch * p.stride16 + (size_t)(t0 + 2 * c2)) * p.step16;
-        tile[row][2 * c2] = (float)src[0] * (1.0f / 32768.0f);
-        tile[row][2 * c2 + 1] = (float)src[p.step16] * (1.0f / 32768.0f);
+        if constexpr (FIXED) {
+          tile[row][2 * c2] = (W)src[0];
+          tile[row][2 * c2 + 1] = (W)src[p.step16];
+        } else {
+          tile[row][2 * c2] = (W)((float)src[0] * (1.0f / 32768.0f));
+          tile[row][2 * c2 + 1] = (W)((float)src[p.step16] * (1.0f / 32768.0f));
+        }
       }
-    } else {
+    } else if constexpr (!FIXED) {
 #pragma unroll
       for (int it = 0; it < 8; it++) /* 32 lanes per row, two rows per pass */
         *reinterpret_cast<bq_v4 *>(&tile[(lane >> 5) + 2 * it][4 * (lane & 31)]) =
@@ -107,19 +165,16 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
      * inside the tile: they run unmasked, four to a chunk (i = 4c + 3 .. 4c + 6, c = 1 .. TS/4 - 2), so
      * that stage 3 finishes samples 4c .. 4c + 3 and stage 0 starts 4c + 3 .. 4c + 6 -- one 16-byte
      * LDS read and one write per chunk; the ramps at both ends of the tile keep the general form */
-    float yprev = 0.f;
+    W yprev = (W)0;
     auto ramp_step = [&](int i) {
       const int n = i - s;
       const bool active = (n >= 0) && (n < TS);
-      const float xin0 = tile[cl][i < TS ? i : TS - 1];
-      /* lane s takes lane s-1's output of the previous step: quad_perm [0,0,1,2] */
-      const float xup = __builtin_bit_cast(
-          float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yprev), 0x90, 0xF, 0xF, false));
-      const float x = (s == 0) ? xin0 : xup;
-      const float y = df1_acc(b0, b1, b2, a1, a2, x, x1, x2, y1, y2);
+      const W xin0 = tile[cl][i < TS ? i : TS - 1];
+      const W xup = dpp_up(yprev);
+      const W x = (s == 0) ? xin0 : xup;
+      const W y = sec.eval(x);
       if (active) {
-        x2 = x1; x1 = x;
-        y2 = y1; y1 = y;
+        sec.commit(x, y);
         yprev = y;
         if (s == 3) tile[cl][n] = y;
       }
@@ -127,24 +182,23 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
 #pragma unroll
     for (int i = 0; i < 7; i++) ramp_step(i);
     {
-      bq_v4 q = *reinterpret_cast<const bq_v4 *>(&tile[cl][4]);
+      typedef W w4 __attribute__((ext_vector_type(4)));
+      w4 q = *reinterpret_cast<const w4 *>(&tile[cl][4]);
 #pragma unroll 2
       for (int c = 1; c <= TS / 4 - 2; c++) {
-        const bq_v4 qn = *reinterpret_cast<const bq_v4 *>(&tile[cl][4 * c + 4]);
-        const float xin[4] = {q[3], qn[0], qn[1], qn[2]};
-        bq_v4 o;
+        const w4 qn = *reinterpret_cast<const w4 *>(&tile[cl][4 * c + 4]);
+        const W xin[4] = {q[3], qn[0], qn[1], qn[2]};
+        w4 o;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const float xup = __builtin_bit_cast(
-              float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yprev), 0x90, 0xF, 0xF, false));
-          const float x = (s == 0) ? xin[k] : xup;
-          const float y = df1_acc(b0, b1, b2, a1, a2, x, x1, x2, y1, y2);
-          x2 = x1; x1 = x;
-          y2 = y1; y1 = y;
+          const W xup = dpp_up(yprev);
+          const W x = (s == 0) ? xin[k] : xup;
+          const W y = sec.eval(x);
+          sec.commit(x, y);
           yprev = y;
           o[k] = y;
         }
-        if (s == 3) *reinterpret_cast<bq_v4 *>(&tile[cl][4 * c]) = o;
+        if (s == 3) *reinterpret_cast<w4 *>(&tile[cl][4 * c]) = o;
         q = qn;
       }
     }
@@ -158,11 +212,16 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
         const int rch = ch0 + row;
         if (rch < p.n_channels) {
           int16_t *dst = p.out16 + ((size_t)rch * p.ostride16 + (size_t)(t0 + 2 * c2)) * p.ostep16;
-          dst[0] = (int16_t)q15_trunc(tile[row][2 * c2]);
-          dst[p.ostep16] = (int16_t)q15_trunc(tile[row][2 * c2 + 1]);
+          if constexpr (FIXED) {
+            dst[0] = (int16_t)tile[row][2 * c2];
+            dst[p.ostep16] = (int16_t)tile[row][2 * c2 + 1];
+          } else {
+            dst[0] = (int16_t)q15_trunc((float)tile[row][2 * c2]);
+            dst[p.ostep16] = (int16_t)q15_trunc((float)tile[row][2 * c2 + 1]);
+          }
         }
       }
-    } else {
+    } else if constexpr (!FIXED) {
 #pragma unroll
       for (int it = 0; it < 8; it++)
         if (ch0 + (lane >> 5) + 2 * it < p.n_channels)
@@ -171,7 +230,17 @@ __global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
     }
     wg_sync<1>();
   }
-  if (valid) { st[0] = x1; st[1] = x2; st[2] = y1; st[3] = y2; }
+  if (valid) sec.store();
+}
+
+__global__ void __launch_bounds__(64) rdsp_biquad_kernel(RdspBiquadParams p) {
+  __shared__ __attribute__((aligned(16))) float tile[16][TP];
+  biquad_body<SectionF32, float>(p, tile);
+}
+/* AudioFilterBiquad objects: int16 in, int16 out, the library's fixed-point arithmetic */
+__global__ void __launch_bounds__(64) rdsp_biquad_teensy_kernel(RdspBiquadParams p) {
+  __shared__ __attribute__((aligned(16))) int tile[16][TP];
+  biquad_body<SectionTeensy, int>(p, tile);
 }
 
 struct CoefWords { float w[20]; };
@@ -185,7 +254,8 @@ __global__ void rdsp_biquad_coef_store_kernel(float *dst, CoefWords v) {
 extern "C" int rdsp_launch_biquad(const RdspBiquadParams *p, hipStream_t stream) {
   if (p->n_samples <= 0 || p->n_samples % TS != 0 || p->n_channels <= p->ch_base) return (int)hipErrorInvalidValue;
   const int grid = (p->n_channels - p->ch_base + 15) / 16;
-  hipLaunchKernelGGL(rdsp_biquad_kernel, dim3(grid), dim3(64), 0, stream, *p);
+  if (p->icoef) hipLaunchKernelGGL(rdsp_biquad_teensy_kernel, dim3(grid), dim3(64), 0, stream, *p);
+  else hipLaunchKernelGGL(rdsp_biquad_kernel, dim3(grid), dim3(64), 0, stream, *p);
   return (int)hipGetLastError();
 }
 /* one coefficient set (20 floats) rewritten in stream order, values passed by value */
@@ -196,13 +266,20 @@ extern "C" int rdsp_launch_biquad_coef_store(float *dst, const float *coef20, hi
   return (int)hipGetLastError();
 }
 
-/* ---- AudioFilterBiquad object: n_channels independent cascades with common coefficients ---- */
+/* ---- AudioFilterBiquad object: n_channels independent cascades with common coefficients ----------------
+ * The Teensy Audio library's class (filter_biquad.{h,cpp}; not in the reference tree) restated from its published
+ * source: `int32_t definition[32]` = four stages of {b0, b1, b2, -a1, -a2} scaled by 2^30 and three words of state.
+ * The image of the reference confirms update()'s operation sequence and the setters' float constant 2 pi / 44100
+ * (tests/test_firmware_tables.py). */
 struct rdsp_biquad {
   int n_channels, device;
   double fs;
-  float coef[20];
+  int32_t coef[4][5]; /* as definition[] holds them: a1, a2 negated */
+  bool chained[4] = {false, false, false, false}; /* `if (stage > 0) *(dest - 1) |= 0x80000000`: stage - 1 hands on to stage */
+  int n_stages = 0;   /* update() runs stage 0, then every next stage while the one before it is chained to it */
   bool dirty = true;
-  float *d_coef = nullptr, *d_state = nullptr;
+  std::vector<int> clear_sum; /* stages whose residue the next update zeroes (`*dest &= 0x80000000`) */
+  int32_t *d_coef = nullptr, *d_state = nullptr;
 };
 
 #define BQ_TRY(expr)                                                            \
@@ -213,6 +290,18 @@ struct rdsp_biquad {
       return RDSP_ERR_HIP;                                                      \
     }                                                                           \
   } while (0)
+
+namespace {
+struct ICoefWords { int32_t w[20]; };
+__global__ void rdsp_biquad_icoef_store_kernel(int32_t *dst, ICoefWords v) {
+  if (threadIdx.x < 20) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+/* the residue word of one stage of every channel */
+__global__ void rdsp_biquad_clear_sum_kernel(int32_t *state, int n_channels, int stage) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < n_channels) state[(size_t)ch * 20 + 5 * stage + 4] = 0;
+}
+}  // namespace
 
 extern "C" int rdsp_biquad_create(int n_channels, int device, double fs, rdsp_biquad_t **out) {
   if (!out || n_channels <= 0 || !(fs > 0.0)) {
@@ -227,13 +316,10 @@ extern "C" int rdsp_biquad_create(int n_channels, int device, double fs, rdsp_bi
   b->n_channels = n_channels;
   b->device = device;
   b->fs = fs;
-  for (int s = 0; s < 4; s++) { /* a fresh AudioFilterBiquad passes audio through */
-    b->coef[5 * s] = 1.0f;
-    b->coef[5 * s + 1] = b->coef[5 * s + 2] = b->coef[5 * s + 3] = b->coef[5 * s + 4] = 0.0f;
-  }
+  memset(b->coef, 0, sizeof(b->coef)); /* "by default, the filter will not pass anything" (the library's constructor) */
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&b->d_coef, sizeof(b->coef)) != hipSuccess ||
-      hipMalloc((void **)&b->d_state, sizeof(float) * 16 * (size_t)n_channels) != hipSuccess ||
-      hipMemset(b->d_state, 0, sizeof(float) * 16 * (size_t)n_channels) != hipSuccess) {
+      hipMalloc((void **)&b->d_state, sizeof(int32_t) * 20 * (size_t)n_channels) != hipSuccess ||
+      hipMemset(b->d_state, 0, sizeof(int32_t) * 20 * (size_t)n_channels) != hipSuccess) {
     rdsp_set_error("rdsp_biquad_create: device allocation failed");
     rdsp_biquad_destroy(b);
     return RDSP_ERR_HIP;
@@ -248,29 +334,57 @@ extern "C" void rdsp_biquad_destroy(rdsp_biquad_t *b) {
   if (b->d_state) (void)hipFree(b->d_state);
   delete b;
 }
-/* AudioFilterBiquad::setCoefficients(stage, const double *): {b0, b1, b2, a1, a2} of
- * H(z) = (b0 + b1 z^-1 + b2 z^-2) / (1 + a1 z^-1 + a2 z^-2) */
-extern "C" int rdsp_biquad_setCoefficients(rdsp_biquad_t *b, int stage, const double *c5) {
+/* void setCoefficients(uint32_t stage, const int *coefficients): {b0, b1, b2, a1, a2} x 2^30; a1 and a2 are stored
+ * negated, the stage's residue is cleared, its sample history stays ("clearing filter state causes loud pop") */
+extern "C" int rdsp_biquad_setCoefficients_int(rdsp_biquad_t *b, int stage, const int32_t *c5) {
   if (!b || !c5 || stage < 0 || stage > 3) return RDSP_ERR_INVALID;
-  float *c = b->coef + 5 * stage;
-  c[0] = (float)c5[0]; c[1] = (float)c5[1]; c[2] = (float)c5[2];
-  c[3] = (float)(-c5[3]); c[4] = (float)(-c5[4]);
+  int32_t *c = b->coef[stage];
+  c[0] = c5[0]; c[1] = c5[1]; c[2] = c5[2];
+  c[3] = (int32_t)(0u - (uint32_t)c5[3]);
+  c[4] = (int32_t)(0u - (uint32_t)c5[4]);
+  if (stage > 0) b->chained[stage - 1] = true;
+  b->n_stages = 1;
+  while (b->n_stages < 4 && b->chained[b->n_stages - 1]) b->n_stages++;
+  b->clear_sum.push_back(stage);
   b->dirty = true;
   return RDSP_OK;
 }
+/* void setCoefficients(uint32_t stage, const double *coefficients) of
+ * H(z) = (b0 + b1 z^-1 + b2 z^-2) / (1 + a1 z^-1 + a2 z^-2): each times 1073741824.0, converted to int */
+extern "C" int rdsp_biquad_setCoefficients(rdsp_biquad_t *b, int stage, const double *c5) {
+  if (!b || !c5 || stage < 0 || stage > 3) return RDSP_ERR_INVALID;
+  int32_t ci[5];
+  for (int i = 0; i < 5; i++) {
+    const double v = c5[i] * 1073741824.0;
+    if (!(v > -2147483649.0 && v < 2147483648.0)) {
+      rdsp_set_error("rdsp_biquad_setCoefficients: coefficient %d = %g does not fit the library's 2.30 format", i, c5[i]);
+      return RDSP_ERR_INVALID;
+    }
+    ci[i] = (int32_t)v;
+  }
+  return rdsp_biquad_setCoefficients_int(b, stage, ci);
+}
 static int set_design(rdsp_biquad_t *b, int stage, int kind, float freq, float q) {
   if (!b || stage < 0 || stage > 3 || !(freq > 0.f) || !(q > 0.f)) return RDSP_ERR_INVALID;
-  rdsp_biquad_design(kind, (double)freq, (double)q, b->fs, b->coef + 5 * stage);
-  b->dirty = true;
-  return RDSP_OK;
+  int32_t ci[5];
+  rdsp_teensy_biquad_design(kind, freq, q, (float)b->fs, ci);
+  return rdsp_biquad_setCoefficients_int(b, stage, ci);
 }
 extern "C" int rdsp_biquad_setLowpass(rdsp_biquad_t *b, int stage, float f, float q) { return set_design(b, stage, 0, f, q); }
 extern "C" int rdsp_biquad_setHighpass(rdsp_biquad_t *b, int stage, float f, float q) { return set_design(b, stage, 1, f, q); }
 extern "C" int rdsp_biquad_setBandpass(rdsp_biquad_t *b, int stage, float f, float q) { return set_design(b, stage, 2, f, q); }
 extern "C" int rdsp_biquad_setNotch(rdsp_biquad_t *b, int stage, float f, float q) { return set_design(b, stage, 3, f, q); }
-extern "C" int rdsp_biquad_get_coeffs(const rdsp_biquad_t *b, float *out20) {
+/* the coefficient words as definition[] holds them, and how many stages the cascade runs */
+extern "C" int rdsp_biquad_get_definition(const rdsp_biquad_t *b, int32_t *out20, int *n_stages) {
   if (!b || !out20) return RDSP_ERR_INVALID;
   memcpy(out20, b->coef, sizeof(b->coef));
+  if (n_stages) *n_stages = b->n_stages;
+  return RDSP_OK;
+}
+/* the same as floats, {b0, b1, b2, a1, a2} with the feedback terms added (coefficient / 2^30) */
+extern "C" int rdsp_biquad_get_coeffs(const rdsp_biquad_t *b, float *out20) {
+  if (!b || !out20) return RDSP_ERR_INVALID;
+  for (int i = 0; i < 20; i++) out20[i] = (float)((double)b->coef[i / 5][i % 5] / 1073741824.0);
   return RDSP_OK;
 }
 
@@ -287,8 +401,15 @@ extern "C" int rdsp_biquad_update(rdsp_biquad_t *b, const int16_t *d_in, size_t 
   BQ_TRY(hipSetDevice(b->device));
   hipStream_t stream = (hipStream_t)stream_;
   if (b->dirty) {
-    int e = rdsp_launch_biquad_coef_store(b->d_coef, b->coef, stream);
-    if (e != 0) { rdsp_set_error("biquad coefficient store: %s", hipGetErrorString((hipError_t)e)); return RDSP_ERR_HIP; }
+    ICoefWords v;
+    memcpy(v.w, b->coef, sizeof(v.w));
+    hipLaunchKernelGGL(rdsp_biquad_icoef_store_kernel, dim3(1), dim3(32), 0, stream, b->d_coef, v);
+    for (int st : b->clear_sum)
+      hipLaunchKernelGGL(rdsp_biquad_clear_sum_kernel, dim3((b->n_channels + 255) / 256), dim3(256), 0, stream, b->d_state,
+                         b->n_channels, st);
+    b->clear_sum.clear();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rdsp_set_error("biquad coefficient store: %s", hipGetErrorString(e)); return RDSP_ERR_HIP; }
     b->dirty = false;
   }
   RdspBiquadParams p;
@@ -297,8 +418,9 @@ extern "C" int rdsp_biquad_update(rdsp_biquad_t *b, const int16_t *d_in, size_t 
   p.out16 = d_out; p.ostride16 = out_stride; p.ostep16 = out_step;
   p.n_channels = b->n_channels;
   p.n_samples = n_blocks * 128;
-  p.coef = b->d_coef;
-  p.state = b->d_state;
+  p.icoef = b->d_coef;
+  p.n_stages = b->n_stages;
+  p.istate = b->d_state;
   int e = rdsp_launch_biquad(&p, stream);
   if (e != 0) { rdsp_set_error("biquad kernel launch failed: %s", hipGetErrorString((hipError_t)e)); return RDSP_ERR_HIP; }
   return RDSP_OK;

@@ -250,6 +250,38 @@ void rdsp_biquad_design(int kind, double freq, double q, double fs, float *coef5
  * at the geometric centre, the gain shared equally by the sections.  Complex arithmetic in
  * double; the float coefficients are what the kernel and the state read-back use. */
 #include <complex.h>
+/* AudioFilterBiquad::setLowpass / setHighpass / setBandpass / setNotch of the Teensy Audio library (filter_biquad.h) as
+ * published: the RBJ cookbook in double with the angle from a FLOAT product, `frequency * (2.0f * 3.141592654f /
+ * AUDIO_SAMPLE_RATE_EXACT)` (that constant is in the reference's firmware image, for 44100.0f), every coefficient
+ * times 2^30 / (1 + alpha) and converted to int.  coef5 = {b0, b1, b2, a1, a2} as the library hands them to
+ * setCoefficients(stage, const int *).  kind 0 LP, 1 HP, 2 BP, 3 notch. */
+void rdsp_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5) {
+  const double w0 = frequency * (2.0f * 3.141592654f / fs);
+  const double sinW0 = sin(w0);
+  const double alpha = sinW0 / ((double)q * 2.0);
+  const double cosW0 = cos(w0);
+  const double scale = 1073741824.0 / (1.0 + alpha);
+  if (kind == 0) {
+    coef5[0] = (int32_t)(((1.0 - cosW0) / 2.0) * scale);
+    coef5[1] = (int32_t)((1.0 - cosW0) * scale);
+    coef5[2] = coef5[0];
+  } else if (kind == 1) {
+    coef5[0] = (int32_t)(((1.0 + cosW0) / 2.0) * scale);
+    coef5[1] = (int32_t)(-(1.0 + cosW0) * scale);
+    coef5[2] = coef5[0];
+  } else if (kind == 2) {
+    coef5[0] = (int32_t)(alpha * scale);
+    coef5[1] = 0;
+    coef5[2] = (int32_t)((-alpha) * scale);
+  } else {
+    coef5[0] = (int32_t)scale;
+    coef5[1] = (int32_t)((-2.0 * cosW0) * scale);
+    coef5[2] = coef5[0];
+  }
+  coef5[3] = (int32_t)((-2.0 * cosW0) * scale);
+  coef5[4] = (int32_t)((1.0 - alpha) * scale);
+}
+
 void rdsp_design_audio_iir(double f1, double f2, double fs, float *coef20) {
   const double k = 2.0 * fs;
   const double wa = k * tan(kPi * f1 / fs), wb = k * tan(kPi * f2 / fs);

@@ -154,6 +154,10 @@ struct RdspBiquadParams {
   const float *coef;       /* [n_sets][20]: {b0,b1,b2,a1,a2} x 4, feedback terms added */
   const uint16_t *set_of;  /* [ch] coefficient set of each channel; NULL: set 0 */
   float *state;            /* [ch][4 stages][x1,x2,y1,y2]                    */
+  /* AudioFilterBiquad objects (the Teensy library's fixed-point cascade; int16 in and out): non-NULL icoef selects it */
+  const int *icoef;        /* [4][5] b0, b1, b2, -a1, -a2 scaled by 2^30      */
+  int n_stages;            /* the cascade runs stages 0 .. n_stages - 1       */
+  int *istate;             /* [ch][4 stages][x1, x2, y1, y2, sum]             */
 };
 
 #ifdef __cplusplus

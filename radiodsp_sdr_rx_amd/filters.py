@@ -23,6 +23,14 @@ def biquad_design(kind, freq, q, fs):
     return c
 
 
+def teensy_biquad_design(kind, frequency, q, fs=44100.0):
+    """what AudioFilterBiquad's setLowpass / setHighpass / setBandpass / setNotch compute: int32 x 2^30
+    {b0, b1, b2, a1, a2} (setCoefficients negates a1, a2); kind 0 LP, 1 HP, 2 BP, 3 notch"""
+    c = np.zeros(5, np.int32)
+    _lib.load().rdsp_teensy_biquad_design(int(kind), float(frequency), float(q), float(fs), c.ctypes.data_as(C.POINTER(C.c_int32)))
+    return c
+
+
 def design_audio_iir(f1, f2, fs):
     """the engine's 8th-order band-pass (four sections x {b0, b1, b2, -a1, -a2})"""
     c = np.zeros(20, np.float32)
@@ -31,7 +39,9 @@ def design_audio_iir(f1, f2, fs):
 
 
 class FilterBiquad:
-    """AudioFilterBiquad: up to four cascaded sections, int16 audio in and out."""
+    """AudioFilterBiquad of the Teensy Audio library: up to four cascaded fixed-point sections (coefficients x 2^30,
+    32 x 16 products, 14-bit error feedback), int16 audio in and out.  A fresh object passes nothing; update() runs
+    stage 0 and every further stage that was chained on by a setter call for it."""
 
     def __init__(self, n_channels, fs=44100.0, device=0):
         self.lib = _lib.load()
@@ -52,9 +62,21 @@ class FilterBiquad:
             pass
 
     def setCoefficients(self, stage, coefficients):
-        c = np.ascontiguousarray(coefficients, np.float64)
+        """five doubles {b0, b1, b2, a1, a2} of (b0 + b1/z + b2/z^2) / (1 + a1/z + a2/z^2), or five ints already x 2^30"""
+        c = np.asarray(coefficients)
         assert c.shape == (5,)
-        _lib.check(self.lib.rdsp_biquad_setCoefficients(self.h, int(stage), c.ctypes.data_as(_lib._f64p)))
+        if np.issubdtype(c.dtype, np.integer):
+            ci = np.ascontiguousarray(c, np.int32)
+            _lib.check(self.lib.rdsp_biquad_setCoefficients_int(self.h, int(stage), ci.ctypes.data_as(C.POINTER(C.c_int32))))
+        else:
+            cd = np.ascontiguousarray(c, np.float64)
+            _lib.check(self.lib.rdsp_biquad_setCoefficients(self.h, int(stage), cd.ctypes.data_as(_lib._f64p)))
+
+    def definition(self):
+        """(int32 [4, 5] coefficient words as the library's definition[] holds them, stages the cascade runs)"""
+        a, n = np.zeros(20, np.int32), C.c_int()
+        _lib.check(self.lib.rdsp_biquad_get_definition(self.h, a.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+        return a.reshape(4, 5), n.value
 
     def setLowpass(self, stage, frequency, q=0.7071):
         _lib.check(self.lib.rdsp_biquad_setLowpass(self.h, int(stage), float(frequency), float(q)))

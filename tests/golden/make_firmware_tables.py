@@ -184,6 +184,34 @@ def pack_routine_classes(img):
     return np.array(offs, np.int64), np.array(names)
 
 
+def fixed_biquad_classes(img):
+    """The instruction classes of AudioFilterBiquad::update around the image's only SMLAWT instructions: the 32 x 16
+    multiply-accumulates (SMLAWB / SMLAWT), the saturating `SSAT Rd, #16, Rn, ASR #14`, the 14-bit error feedback
+    (`UBFX Rd, Rn, #0, #14`) and the PKHBT that packs the two outputs of a loop turn."""
+    hw = np.frombuffer(img[:len(img) // 2 * 2], dtype="<u2").astype(np.int64)
+
+    def cls(h1, h2):
+        if (h1 & 0xFFF0) == 0xFB30 and (h2 & 0x00E0) == 0 and (h2 & 0xF000) != 0xF000:
+            return "SMLAWT" if h2 & 0x10 else "SMLAWB"
+        if (h1 & 0xFFD0) == 0xF300 and (h2 & 0x8020) == 0:
+            return "SSAT #%d %s #%d" % ((h2 & 0x1F) + 1, "ASR" if h1 & 0x20 else "LSL", ((h2 >> 12) & 7) << 2 | ((h2 >> 6) & 3))
+        if (h1 & 0xFFF0) == 0xF3C0 and (h2 & 0x8020) == 0:
+            return "UBFX #%d #%d" % (((h2 >> 12) & 7) << 2 | ((h2 >> 6) & 3), (h2 & 0x1F) + 1)
+        if (h1 & 0xFFF0) == 0xEAC0 and (h2 & 0x8010) == 0:
+            return "PKHTB" if h2 & 0x20 else "PKHBT"
+        return None
+
+    top = [2 * i for i in range(len(hw) - 1) if cls(int(hw[i]), int(hw[i + 1])) == "SMLAWT"]
+    lo, hi = min(top) - 0x40, max(top) + 0x20
+    offs, names = [], []
+    for i in range(lo // 2, hi // 2):
+        name = cls(int(hw[i]), int(hw[i + 1]))
+        if name:
+            offs.append(2 * i)
+            names.append(name)
+    return np.array(offs, np.int64), np.array(names)
+
+
 def main():
     if not os.path.exists(HEX):
         sys.exit("the reference tree is not here: this script runs in the build container only")
@@ -198,6 +226,12 @@ def main():
     out["code_ops_offsets"], out["code_ops_names"] = dsp_opcode_classes(img)
     out["code_vfp_offsets"], out["code_vfp_names"] = vfp_f32_classes(img)
     out["code_pack_offsets"], out["code_pack_names"] = pack_routine_classes(img)
+    out["code_fixbq_offsets"], out["code_fixbq_names"] = fixed_biquad_classes(img)
+    # AudioFilterBiquad's setters: `2 * 3.141592654f / AUDIO_SAMPLE_RATE_EXACT` folded to one float literal
+    two_pi_fs = np.float32(np.float32(2.0) * np.float32(3.141592654) / np.float32(44100.0))
+    lit = np.frombuffer(img[:len(img) // 4 * 4], dtype="<f4")
+    out["two_pi_over_fs_offsets"] = (4 * np.nonzero(lit == two_pi_fs)[0]).astype(np.int64)
+    out["two_pi_over_fs"] = np.array([two_pi_fs], np.float32)
     # sanity: what each table is, so a wrong offset cannot slip through
     i = np.arange(256)
     assert np.array_equal(out["hann256"], np.minimum(32767, np.round(32768 * 0.5 * (1 - np.cos(2 * np.pi * i / 255)))))

@@ -25,7 +25,7 @@ def make_nodes():
     """graph nodes beside the chain (integer analysers, int16 biquad): nodes.npz holds one input and what
     the oracle's restatements give for it -- the panadapter analyser (naverage 5, AudioWindowHanning256), the
     audio analyser on the I side (AudioWindowHanning1024; both tables as in the reference's firmware image) and
-    `setHighpass(0, 500, 0.5)` + a notch on the I side"""
+    `setHighpass(0, 500, 0.5)` + a notch in stage 1 on the I side (the Teensy library's fixed-point AudioFilterBiquad)"""
     import ctypes as C
     lib = oracle_lib.load()
     I16P, F32P = C.POINTER(C.c_int16), C.POINTER(C.c_float)
@@ -70,16 +70,11 @@ def make_nodes():
                 outs.append(np.ctypeslib.as_array(lib.orc_fft1024_output(s), (512,)).copy())
         lib.orc_fft1024_destroy(s)
         spec1024.append(np.stack(outs))
-        o = OrcBiquad()
-        lib.orc_biquad_init(C.byref(o), 0, None)
-        for stage, (kind, f, qq) in ((0, (1, 500.0, 0.5)), (2, (3, 1000.0, 4.0))):
-            c5 = np.zeros(5, np.float32)
-            lib.orc_biquad_design(kind, f, qq, 44100.0, c5.ctypes.data_as(F32P))
-            lib.orc_biquad_set_stage(C.byref(o), stage, c5.ctypes.data_as(F32P))
-        y = i.astype(np.float32) / np.float32(32768.0)
-        lib.orc_biquad_run(C.byref(o), y.ctypes.data_as(F32P), len(y))
-        r16 = np.zeros(len(y), np.int16)
-        lib.orc_float_to_q15(y.ctypes.data_as(F32P), r16.ctypes.data_as(I16P), len(y))
+        from test_audio_nodes import TeensyBiquadOracle
+        o = TeensyBiquadOracle(lib)
+        o.set(0, "highpass", 500.0, 0.5)
+        o.set(1, "notch", 1000.0, 4.0)
+        r16 = o.update(i)
         bq.append(r16)
     np.savez_compressed(os.path.join(HERE, "nodes.npz"), iq=iq, spectrum256=np.stack(spec256),
                         fft1024=np.stack(spec1024), biquad=np.stack(bq))

@@ -295,6 +295,9 @@ static void design_checks(void) {
   for (int kind = 0; kind < 4; kind++) {
     rdsp_biquad_design(kind, 500.0, 0.5, 24000.0, c5);
     for (int i = 0; i < 5; i++) CHECK(isfinite(c5[i]));
+    int32_t t5[5]; /* the Teensy library's setters: 2.30 fixed point, feedback terms as the difference equation writes them */
+    rdsp_teensy_biquad_design(kind, 500.0f, 0.5f, 44100.0f, t5);
+    CHECK(abs(t5[4]) < (1 << 30) && t5[3] < 0 && t5[3] > -INT32_MAX);
   }
   rdsp_design_audio_iir(300.0, 2700.0, 24000.0, c20);
   for (int s = 0; s < 4; s++) {

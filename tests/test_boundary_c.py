@@ -59,13 +59,10 @@ def test_panadapter_side_through_the_c_binding_matches_the_oracle(rdsp, oracle, 
     biquad1 / biquad2 (high-pass 500 Hz, q 0.5) on the I and Q rails, AudioAnalyzeFFT256IQ with
     AudioWindowHanning256 handed over by pointer and averageTogether(30); every spectrum FFT.available() announces,
     FFT.read(80) and FFT.read(75, 85) come back through a file: bit-exact against the oracle's restatements."""
-    import ctypes as C
     from radiodsp_sdr_rx_amd.chain import synth_iq
-    from test_audio_nodes import F32P, I16P, _bind, oracle_biquad
+    from test_audio_nodes import TeensyBiquadOracle, _bind
     from test_spectrum import _olib, oracle_spectra
     lib = _bind(_olib(oracle))
-    lib.orc_float_to_q15.argtypes = [F32P, I16P, C.c_uint32]
-    lib.orc_biquad_design.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, F32P]
     nblk = 128
     iq = synth_iq(1, nblk * 128)
     fin, fout, fspec = tmp_path / "iq.raw", tmp_path / "audio.raw", tmp_path / "spec.raw"
@@ -76,18 +73,11 @@ def test_panadapter_side_through_the_c_binding_matches_the_oracle(rdsp, oracle, 
     rec = np.fromfile(fspec, dtype=np.uint8).reshape(-1, 512 + 8)
     spectra = rec[:, :512].copy().view(np.uint16)
     reads = rec[:, 512:].copy().view(np.float32)
-    c5 = np.zeros(5, np.float32)
-    lib.orc_biquad_design(1, 500.0, 0.5, 44100.0, c5.ctypes.data_as(F32P))
-    coef = np.zeros(20, np.float32)
-    coef[:5] = c5
-    for st in range(1, 4):
-        coef[5 * st] = 1.0
     filt = np.zeros((nblk * 128, 2), np.int16)
     for side in (0, 1):
-        y = oracle_biquad(lib, coef, iq[0, :, side].astype(np.float32) / np.float32(32768.0))
-        q = np.zeros(len(y), np.int16)
-        lib.orc_float_to_q15(y.ctypes.data_as(F32P), q.ctypes.data_as(I16P), len(y))
-        filt[:, side] = q
+        o = TeensyBiquadOracle(lib)                                   # the Teensy library's fixed-point AudioFilterBiquad
+        o.set(0, "highpass", 500.0, 0.5)
+        filt[:, side] = o.update(np.ascontiguousarray(iq[0, :, side]))
     want = np.stack(oracle_spectra(lib, filt, 30, 1))
     # the C program looks at the flag once per 16-block call: it reports the latest average of each call that completed one
     assert len(spectra) >= 3

@@ -381,3 +381,62 @@ def test_pack_routine_of_the_image_rounds(fw, oracle):
     q = np.zeros(len(x), np.int16)
     lib.orc_float_to_q15(x.ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(I16P), len(x))
     assert q.tolist() == [0, 1, 1, 2, 3, 0, -1, -1, -2, -3, 32767, 32767, -32768]
+
+
+def test_audio_filter_biquad_of_the_image_is_the_fixed_point_routine(fw, oracle):
+    """INO:59-60,155-156 use the Teensy library's AudioFilterBiquad, whose source is not in the reference tree; the image
+    holds its update(): two samples per loop turn, each five 32 x 16 multiply-accumulates that keep the top 32 of the 48
+    product bits -- bottom / top halves alternating B T B T B, then T B T B T --, `SSAT #16, ASR #14`, the residue kept
+    with `UBFX #0, #14`, the two outputs packed with PKHBT; and the setters' `2 * 3.141592654f / AUDIO_SAMPLE_RATE_EXACT`
+    folded to one float literal.  The oracle's one-sample-per-turn restatement is checked against a model that does
+    literally what these instructions do, on packed pairs, rails included."""
+    names = [str(n) for n in fw["code_fixbq_names"]]
+    assert names == (["UBFX #0 #14"] + ["SMLAWB", "SMLAWT", "SMLAWB", "SMLAWT", "SMLAWB"] + ["SSAT #16 ASR #14", "UBFX #0 #14"]
+                     + ["SMLAWT", "SMLAWB", "SMLAWT", "SMLAWB", "SMLAWT"] + ["SSAT #16 ASR #14", "PKHBT", "UBFX #0 #14"])
+    assert len(fw["two_pi_over_fs_offsets"]) >= 1
+    assert fw["two_pi_over_fs"][0] == np.float32(2.0) * np.float32(3.141592654) / fw["sample_rate"][0].astype(np.float32)
+
+    def s32(v):
+        v &= 0xFFFFFFFF
+        return v - (1 << 32) if v & 0x80000000 else v
+
+    def s16(v):
+        v &= 0xFFFF
+        return v - 65536 if v & 0x8000 else v
+
+    def smlawb(acc, a, pair): return s32(acc + ((a * s16(pair)) >> 16))
+    def smlawt(acc, a, pair): return s32(acc + ((a * s16(pair >> 16)) >> 16))
+    def ssat16_asr14(v): return max(-32768, min(32767, v >> 14))
+
+    def model(coef, x):                               # coef as stored (a1, a2 already negated), x int16 [even n]
+        b0, b1, b2, a1, a2 = (int(c) for c in coef)
+        bprev = aprev = 0
+        s = 0
+        y = np.zeros(len(x), np.int16)
+        for i in range(0, len(x), 2):
+            in2 = (int(x[i]) & 0xFFFF) | ((int(x[i + 1]) & 0xFFFF) << 16)
+            s = smlawb(s, b0, in2); s = smlawt(s, b1, bprev); s = smlawb(s, b2, bprev)
+            s = smlawt(s, a1, aprev); s = smlawb(s, a2, aprev)
+            out2 = ssat16_asr14(s); s &= 0x3FFF
+            s = smlawt(s, b0, in2); s = smlawb(s, b1, in2); s = smlawt(s, b2, bprev)
+            s = smlawb(s, a1, out2 & 0xFFFF); s = smlawt(s, a2, aprev)
+            bprev = in2
+            hi = ssat16_asr14(s); s &= 0x3FFF
+            aprev = (out2 & 0xFFFF) | ((hi & 0xFFFF) << 16)                 # PKHBT
+            y[i], y[i + 1] = out2, hi
+        return y
+
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_audio_nodes import TeensyBiquadOracle
+    lib = oracle.load()
+    rng = np.random.default_rng(11)
+    for trial, (kind, f, q) in enumerate((("highpass", 500.0, 0.5), ("lowpass", 3000.0, 0.707), ("notch", 1000.0, 8.0), ("bandpass", 700.0, 30.0))):
+        o = TeensyBiquadOracle(lib)
+        o.set(0, kind, f, q)
+        coef = [int(v) for v in o.o.coef[0]]
+        x = rng.integers(-32768, 32768, 8 * 128).astype(np.int16)          # full-scale noise: the rails are reached
+        x[:256] = 32767 if trial % 2 else -32768
+        want = model(coef, x)
+        got = o.update(x)
+        assert np.array_equal(got, want), (kind, int(np.argmax(got != want)))
