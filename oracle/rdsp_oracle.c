@@ -239,6 +239,26 @@ static void lms_norm_f32(orc_lms_t *s, const float *src, const float *ref,
   memmove(s->state, state, (LMS_TAPS - 1) * sizeof(float));
 }
 
+/* the routine alone, for the known answers the reference's compiled arm_lms_norm_f32 gives (tests/test_firmware_kat.py):
+ * one call of n samples on an instance given as plain arrays -- coeffs[96] in/out, state[96 - 1 + n] in/out (the first
+ * 95 entries carry over), energy_x0[2] in/out */
+void orc_lms_norm_f32_kat(float mu, float *coeffs, float *state95, float *energy_x0, const float *src, const float *ref,
+                          float *out, float *err, uint32_t n) {
+  static orc_lms_t s;
+  if (n > (uint32_t)LMS_DELAY) return;
+  memset(&s, 0, sizeof(s));
+  s.mu = mu;
+  s.energy = energy_x0[0];
+  s.x0 = energy_x0[1];
+  memcpy(s.coeffs, coeffs, LMS_TAPS * sizeof(float));
+  memcpy(s.state, state95, (LMS_TAPS - 1) * sizeof(float));
+  lms_norm_f32(&s, src, ref, out, err, n);
+  memcpy(coeffs, s.coeffs, LMS_TAPS * sizeof(float));
+  memcpy(state95, s.state, (LMS_TAPS - 1) * sizeof(float));
+  energy_x0[0] = s.energy;
+  energy_x0[1] = s.x0;
+}
+
 /* NR:66-80 with the ring statics made per-instance */
 static void lms_noise_reduction(orc_lms_t *s, int n, float *nrbuffer, float *errsig_out) {
   memcpy(&s->delay[s->inbuf], nrbuffer, (size_t)n * sizeof(float)); /* NR:71 */

@@ -107,6 +107,9 @@ void orc_doConvolutionalInitialize(orc_chain_t *c);            /* CONV:187 */
 void orc_reInitializeFilter(orc_chain_t *c, double lo, double hi); /* CONV:209 */
 void orc_Init_LMS_NR(orc_chain_t *c, int strength);            /* NR:35    */
 void orc_LMS_NoiseReduction(orc_chain_t *c, int16_t n, float *nrbuffer); /* NR:66 */
+/* arm_lms_norm_f32 alone (96 taps) on an instance given as arrays: coeffs[96], state95[95], energy_x0[2] in/out */
+void orc_lms_norm_f32_kat(float mu, float *coeffs, float *state95, float *energy_x0, const float *src, const float *ref,
+                          float *out, float *err, uint32_t n);
 void orc_Init_ALS(orc_chain_t *c, int strength);
 void orc_set_nr_level(orc_chain_t *c, int lms_nr);  /* nr_level change, CONV:327 */
 

@@ -1,0 +1,437 @@
+#!/usr/bin/env python3
+"""Known answers computed BY THE REFERENCE'S OWN COMPILED CODE.
+
+The reference ships one artefact that holds its hot path in executable form: pre_compiled/RadioDSP_SDR_RX.ino.hex, a
+Teensy 4 (Cortex-M7) build of the sketch with CMSIS-DSP and the Teensy Audio library linked in.  It cannot be built
+here and there is no ARM machine, but its routines are plain Thumb-2 code working on memory: tests/golden/thumb_emu.py
+interprets that instruction set, tests/golden/firmware_image.py lays the image out as the start-up code does, and this
+script calls single routines of it -- by the addresses the image itself calls them at -- on seeded inputs and writes
+inputs and outputs to tests/golden/firmware_kat.npz.  Data only: nothing of the image is copied.
+
+What is run (ITCM address; how it was identified):
+  arm_cfft_radix4_init_q15 0x12584, arm_cfft_radix4_q15 0x12548   called from both analysers' update()
+  arm_lms_norm_init_f32 0x1262c, arm_lms_norm_f32 0x12668         called from Init_LMS_NR / LMS_NoiseReduction (NR:62,73)
+  arm_biquad_cascade_df1_init_f32 0x128b0, ..._df1_f32 0x128cc    the engine's audio filters
+  arm_q15_to_float 0x116ac, arm_float_to_q15 0x1174c              CONV:241-242, :346-347
+  arm_cfft_f32 0x11f68, arm_cmplx_mult_cmplx_f32 0x12a64          CONV:290, :299, :307
+  Init_LMS_NR 0x6b74, LMS_NoiseReduction 0x6c0c                   NR:35, NR:66
+  calc_cplx_FIR_coeffs 0x6ce0, init_filter_mask 0x6c68, doConvolutionalInitialize 0x704c, reInitializeFilter 0x7094,
+  doConvolutionalProcessing 0x70d0                                CONV:127, :87, :187, :209, :228
+  AudioAnalyzeFFT256IQ::update 0x9a20, AudioAnalyzeFFT1024::update 0xbb18, AudioFilterBiquad::update 0xc09c and
+  ::setCoefficients 0xc17c                                        through the objects' vtables / the sketch's calls
+The AudioStream plumbing the update() methods call (receiveReadOnly / receiveWritable / transmit / release) and the
+record / play queues of doConvolutionalProcessing are replaced by hooks that hand over our buffers; everything else
+-- newlib's powf / sin / cos included -- is the image's code.
+
+Build container only: needs /root/reference.  Run: python tests/golden/make_firmware_kat.py
+"""
+import hashlib
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from firmware_image import SCRATCH, Image  # noqa: E402
+from make_firmware_tables import HEX, TABLES  # noqa: E402
+
+OUT = os.path.join(HERE, "firmware_kat.npz")
+F32, I16 = np.float32, np.int16
+
+# ITCM addresses of the routines (this image only: its SHA-256 is checked below)
+IMAGE_SHA256_16 = None          # filled in on first run and asserted afterwards (see main)
+A = dict(cfft_q15_init=0x12584, cfft_q15=0x12548, lms_init=0x1262c, lms=0x12668, df1_init=0x128b0, df1=0x128cc,
+         q15_to_float=0x116ac, float_to_q15=0x1174c, cfft_f32=0x11f68, cmplx_mult=0x12a64,
+         Init_LMS_NR=0x6b74, LMS_NoiseReduction=0x6c0c, calc_cplx_FIR_coeffs=0x6ce0, init_filter_mask=0x6c68,
+         doConvolutionalInitialize=0x704c, reInitializeFilter=0x7094, doConvolutionalProcessing=0x70d0,
+         fft256iq_update=0x9a20, fft1024_update=0xbb18, biquad_update=0xc09c, biquad_setCoefficients=0xc17c,
+         receiveReadOnly=0x10e04, receiveWritable=0x10e1c, transmit=0x10dd0, release=0x10d7c,
+         rq_available=0xca6c, rq_readBuffer=0xcad0, rq_freeBuffer=0xcb0c, rq_begin=0xca84, pq_getBuffer=0xc9d0, pq_playBuffer=0xc9f4)
+# globals of the sketch (DTCM), read out of the literal pools of the routines above
+G = dict(Q_in_L=0x2001d990, Q_in_R=0x2001a208, Q_out_L=0x2001c430, Q_out_R=0x2001ed48, FIR_Coef_I=0x2001c598, FIR_Coef_Q=0x2001cba8,
+         FIR_filter_mask=0x2001a570, lms_instance=0x2001f2fc, lms_coeffs=0x20019e78, cfft_instance_256=0x20003bf0,
+         FFT_length=0x200089b8, N_BLOCKS=0x20015a28, m_NumTaps=0x20008e08, first_block=0x20008e04)
+
+
+def synth_iq(n, seed):
+    """two tones + a weak carrier + noise on both rails, int16 [n, 2] (any signal would do: it only has to be the same
+    on both sides of the comparison)"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    ph = 2 * np.pi * (1000.0 / 44100.0) * t
+    ph2 = 2 * np.pi * (2600.0 / 44100.0) * t
+    ph3 = 2 * np.pi * (-5200.0 / 44100.0) * t
+    i = 0.30 * np.cos(ph) + 0.12 * np.cos(ph2) + 0.05 * np.cos(ph3) + 0.02 * rng.standard_normal(n)
+    q = 0.30 * np.sin(ph) + 0.12 * np.sin(ph2) + 0.05 * np.sin(ph3) + 0.02 * rng.standard_normal(n)
+    return np.stack([np.clip(np.round(i * 32768), -32768, 32767), np.clip(np.round(q * 32768), -32768, 32767)], 1).astype(I16)
+
+
+class Ref:
+    """one emulated machine with the sketch's start-up state"""
+
+    def __init__(self, im):
+        self.im = im
+        self.cpu = im.machine()
+        self.m = self.cpu.mem
+        self.m.map(0xE000E000, 0x1000)              # NVIC registers reInitializeFilter writes (interrupt enable bits): plain memory here
+        self.next = SCRATCH
+
+    def alloc(self, n, align=8):
+        a = (self.next + align - 1) & ~(align - 1)
+        self.next = a + n
+        assert self.next < SCRATCH + 0x80000
+        return a
+
+    def put(self, addr, arr):
+        self.m.write_bytes(addr, np.ascontiguousarray(arr).tobytes())
+
+    def get(self, addr, n, dt):
+        return np.frombuffer(self.m.read_bytes(addr, n * np.dtype(dt).itemsize), dtype=dt).copy()
+
+    def call(self, name, *args, **kw):
+        return self.cpu.call(A[name], list(args), **kw)
+
+
+# ---- CMSIS leaf routines -------------------------------------------------------------------------------------------------
+def kat_cfft_q15(im, out):
+    rng = np.random.default_rng(101)
+    for n in (256, 1024):
+        r = Ref(im)
+        S, buf = r.alloc(16), r.alloc(4 * n)
+        assert r.call("cfft_q15_init", S, n, 0, 1) == 0              # as the analysers' constructors do
+        xs, ys = [], []
+        for trial in range(4):
+            x = rng.integers(-32768, 32768, 2 * n).astype(I16)
+            if trial == 1:
+                x = np.where(rng.random(2 * n) < 0.5, 32767, -32768).astype(I16)
+            if trial == 2:
+                x = rng.integers(-300, 300, 2 * n).astype(I16)
+            r.put(buf, x)
+            r.call("cfft_q15", S, buf)
+            xs.append(x)
+            ys.append(r.get(buf, 2 * n, I16))
+        out[f"cfft_q15_{n}_in"], out[f"cfft_q15_{n}_out"] = np.stack(xs), np.stack(ys)
+
+
+def kat_lms_norm(im, out):
+    """arm_lms_norm_f32 as NR:62,73 use it: 96 taps, blocks of 128, three consecutive blocks on one instance"""
+    rng = np.random.default_rng(102)
+    r = Ref(im)
+    taps, n, nblk = 96, 128, 3
+    S, co, st = r.alloc(24), r.alloc(4 * taps), r.alloc(4 * (taps + n))
+    src, ref, o, e = (r.alloc(4 * n) for _ in range(4))
+    c0 = (rng.standard_normal(taps) * 0.03).astype(F32)
+    mu = F32(0.1122018)
+    r.put(co, c0)
+    r.call("lms_init", S, taps, co, st, sargs=[float(mu)], stack_args=[n])
+    xs = (rng.standard_normal((nblk, n)) * 0.2).astype(F32)
+    ds = (0.7 * xs + rng.standard_normal((nblk, n)) * 0.05).astype(F32)
+    outs, errs, cos_, inst = [], [], [], []
+    for b in range(nblk):
+        r.put(src, xs[b]); r.put(ref, ds[b])
+        r.call("lms", S, src, ref, o, stack_args=[e, n])
+        outs.append(r.get(o, n, F32)); errs.append(r.get(e, n, F32)); cos_.append(r.get(co, taps, F32))
+        inst.append(r.get(S + 16, 2, F32))                            # energy, x0
+    out.update(lms_taps=np.int64(taps), lms_mu=np.array([mu], F32), lms_coeffs0=c0, lms_src=xs, lms_ref=ds, lms_out=np.stack(outs),
+               lms_err=np.stack(errs), lms_coeffs=np.stack(cos_), lms_energy_x0=np.stack(inst))
+
+
+def kat_df1(im, out, biquad_sets):
+    """arm_biquad_cascade_df1_f32 with the engine's own first set (four sections), 2 x 160 samples on one instance"""
+    rng = np.random.default_rng(103)
+    r = Ref(im)
+    n = 160
+    S, co, st, src, dst = r.alloc(12), r.alloc(80), r.alloc(64), r.alloc(4 * n), r.alloc(4 * n)
+    coef = np.ascontiguousarray(biquad_sets[0].reshape(20), F32)
+    r.put(co, coef)
+    r.call("df1_init", S, 4, co, st)
+    xs = (rng.standard_normal((2, n)) * 0.25).astype(F32)
+    ys = []
+    for b in range(2):
+        r.put(src, xs[b])
+        r.call("df1", S, src, dst, n)
+        ys.append(r.get(dst, n, F32))
+    out.update(df1_coef=coef, df1_in=xs, df1_out=np.stack(ys))
+
+
+def kat_converters(im, out):
+    rng = np.random.default_rng(104)
+    r = Ref(im)
+    n = 203                                                            # not a multiple of four: the tail loop runs too
+    a, b = r.alloc(4 * n), r.alloc(4 * n)
+    x = (rng.standard_normal(n) * 0.4).astype(F32)
+    k = np.array([0.4, 0.5, 0.6, 1.5, 2.5, -0.4, -0.5, -0.6, -1.5, -2.5, 32766.5, 32767.5, -32768.5, 40000.0, -40000.0, 0.0], F32) / F32(32768.0)
+    x[:len(k)] = k
+    r.put(a, x)
+    r.call("float_to_q15", a, b, n)
+    out.update(float_to_q15_in=x, float_to_q15_out=r.get(b, n, I16))
+    q = rng.integers(-32768, 32768, n).astype(I16)
+    q[:3] = (-32768, 32767, 0)
+    r.put(a, q)
+    r.call("q15_to_float", a, b, n)
+    out.update(q15_to_float_in=q, q15_to_float_out=r.get(b, n, F32))
+
+
+def kat_cfft_f32(im, out):
+    """arm_cfft_f32 with the instance the sketch uses (arm_cfft_sR_f32_len256), forward and inverse, bit reversal on;
+    arm_cmplx_mult_cmplx_f32"""
+    rng = np.random.default_rng(105)
+    r = Ref(im)
+    n = 256
+    buf, b2, b3 = r.alloc(8 * n), r.alloc(8 * n), r.alloc(8 * n)
+    x = (rng.standard_normal(2 * n) * 0.3).astype(F32)
+    r.put(buf, x)
+    r.call("cfft_f32", G["cfft_instance_256"], buf, 0, 1)
+    fwd = r.get(buf, 2 * n, F32)
+    r.call("cfft_f32", G["cfft_instance_256"], buf, 1, 1)
+    out.update(cfft_f32_in=x, cfft_f32_fwd=fwd, cfft_f32_inv=r.get(buf, 2 * n, F32))
+    y = (rng.standard_normal(2 * n) * 0.3).astype(F32)
+    r.put(buf, x); r.put(b2, y)
+    r.call("cmplx_mult", buf, b2, b3, n)
+    out.update(cmplx_mult_a=x, cmplx_mult_b=y, cmplx_mult_out=r.get(b3, 2 * n, F32))
+
+
+# ---- the sketch's own routines -----------------------------------------------------------------------------------------------
+class Sketch(Ref):
+    """the CONV stage as .ino:172-198 runs it: Init_LMS_NR(15); doConvolutionalInitialize(); reInitializeFilter(300, 4000);
+    then doConvolutionalProcessing(nr_level, true, 300.0, 4000.0) once per audio block"""
+
+    def __init__(self, im):
+        super().__init__(im)
+        self.buf = {G["Q_in_L"]: self.alloc(256), G["Q_in_R"]: self.alloc(256), G["Q_out_L"]: self.alloc(256), G["Q_out_R"]: self.alloc(256)}
+        h = self.cpu.hooks
+
+        def ret(v):
+            def f(c): c.r[0] = v
+            return f
+
+        def buf_of(c): c.r[0] = self.buf[c.r[0]]
+        h[A["rq_begin"]] = ret(0)
+        h[A["rq_available"]] = ret(2)                                  # "> N_BLOCKS" with N_BLOCKS = 1
+        h[A["rq_readBuffer"]] = buf_of
+        h[A["rq_freeBuffer"]] = ret(0)
+        h[A["pq_getBuffer"]] = buf_of
+        h[A["pq_playBuffer"]] = ret(0)
+        self.prepack = []
+        self.cpu.watch[A["float_to_q15"]] = lambda c: self.prepack.append(self.get(c.r[0], c.r[2], F32))
+        assert self.m.read(G["FFT_length"], 4) == 256 and self.m.read(G["N_BLOCKS"], 4) == 1 and self.m.read(G["m_NumTaps"], 4) == 129
+
+    def setup(self, nr_init=15, lo=300.0, hi=4000.0):
+        self.call("Init_LMS_NR", nr_init)                               # INO:172
+        self.call("doConvolutionalInitialize")                          # INO:180
+        self.call("reInitializeFilter", dargs={0: lo, 1: hi})            # INO:183
+
+    def taps(self):
+        return self.get(G["FIR_Coef_I"], 129, np.float64), self.get(G["FIR_Coef_Q"], 129, np.float64)
+
+    def mask(self):
+        return self.get(G["FIR_filter_mask"], 512, F32)
+
+    def process(self, iq, nr, filt=1):
+        """iq int16 [n, 2] -> (int16 [n, 2], float32 [n, 2] as handed to arm_float_to_q15)"""
+        o16, o32 = [], []
+        for b in range(len(iq) // 128):
+            blk = iq[b * 128:(b + 1) * 128]
+            self.put(self.buf[G["Q_in_L"]], blk[:, 0]); self.put(self.buf[G["Q_in_R"]], blk[:, 1])
+            self.prepack.clear()
+            self.call("doConvolutionalProcessing", int(filt), sargs=[float(nr)], dargs={1: 300.0, 2: 4000.0})
+            assert len(self.prepack) == 2
+            o32.append(np.stack(self.prepack, 1))
+            o16.append(np.stack([self.get(self.buf[G["Q_out_L"]], 128, I16), self.get(self.buf[G["Q_out_R"]], 128, I16)], 1))
+        return np.concatenate(o16), np.concatenate(o32)
+
+
+def kat_design(im, out):
+    """calc_cplx_FIR_coeffs + init_filter_mask through reInitializeFilter for the sketch's pass band and three others
+    (the PBT range of CTL:569-612); Init_LMS_NR's mu for every strength"""
+    bands = [(300.0, 4000.0), (150.0, 2400.0), (700.0, 800.0), (0.0, 4000.0)]
+    ti, tq, mk = [], [], []
+    for lo, hi in bands:
+        s = Sketch(im)
+        s.setup(15, lo, hi)
+        a, b = s.taps()
+        ti.append(a); tq.append(b); mk.append(s.mask())
+    out.update(design_bands=np.array(bands), design_taps_i=np.stack(ti), design_taps_q=np.stack(tq), design_mask=np.stack(mk))
+    s = Sketch(im)
+    mus = []
+    for strength in range(1, 41):
+        s.call("Init_LMS_NR", strength)
+        mus.append(s.get(G["lms_instance"] + 12, 1, F32)[0])
+    out["init_lms_nr_mu"] = np.array(mus, F32)
+
+
+def kat_conv(im, out):
+    """doConvolutionalProcessing block by block on one stream each:
+       conv_plain   nr 0                              32 blocks  (A1 unpack, A5 overlap-save filter, A10 pack)
+       conv_nr15    nr 15 (the sketch's start-up)     48 blocks  (+ A8 NLMS noise reduction, x 1.1, L copied to R)
+       conv_nrstep  nr 15 -> 30 after 16 blocks       32 blocks  (Init_LMS_NR in mid-stream: state cleared, taps kept)
+       conv_pbt     nr 0, reInitializeFilter(450, 2700) after 12 blocks, 24 blocks
+       conv_nofilt  bFilterEnabled false              12 blocks  (CONV:303 copies FFT_length floats = half the spectrum)"""
+    t0 = time.time()
+    iq = synth_iq(48 * 128, 7)
+    s = Sketch(im); s.setup()
+    o16, o32 = s.process(iq[:32 * 128], 0.0)
+    out.update(conv_iq=iq, conv_plain_o16=o16, conv_plain_o32=o32)
+    s = Sketch(im); s.setup()
+    o16, o32 = s.process(iq, 15.0)
+    out.update(conv_nr15_o16=o16, conv_nr15_o32=o32, conv_nr15_coeffs=s.get(G["lms_coeffs"], 96, F32))
+    s = Sketch(im); s.setup()
+    a16, a32 = s.process(iq[:16 * 128], 15.0)
+    b16, b32 = s.process(iq[16 * 128:32 * 128], 30.0)
+    out.update(conv_nrstep_o16=np.concatenate([a16, b16]), conv_nrstep_o32=np.concatenate([a32, b32]))
+    s = Sketch(im); s.setup()
+    a16, a32 = s.process(iq[:12 * 128], 0.0)
+    s.call("reInitializeFilter", dargs={0: 450.0, 1: 2700.0})
+    b16, b32 = s.process(iq[12 * 128:24 * 128], 0.0)
+    out.update(conv_pbt_o16=np.concatenate([a16, b16]), conv_pbt_o32=np.concatenate([a32, b32]))
+    s = Sketch(im); s.setup()
+    o16, o32 = s.process(iq[:12 * 128], 0.0, filt=0)
+    out.update(conv_nofilt_o16=o16, conv_nofilt_o32=o32)
+    print("  conv runs: %.0f s" % (time.time() - t0))
+
+
+# ---- the graph's objects ---------------------------------------------------------------------------------------------------
+class Blocks:
+    """audio_block_t buffers (ref count, pool index, int16 data[128] at +4) handed to update() by the hooks"""
+
+    def __init__(self, ref, n=64):
+        self.ref = ref
+        self.slots = [ref.alloc(260, 4) for _ in range(n)]
+        self.k = 0
+
+    def new(self, data=None):
+        a = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        self.ref.m.write_bytes(a, bytes(4))
+        self.ref.put(a + 4, np.zeros(128, I16) if data is None else np.ascontiguousarray(data, I16))
+        return a
+
+
+def kat_fft256iq(im, out, tables):
+    """AudioAnalyzeFFT256IQ::update on 2 x 40 blocks: object memory zeroed, then the constructor's settings (FFTIQ.h:55-60:
+    window, naverage, arm_cfft_radix4_init_q15 run from the image) and the sketch's (INO:144-145: Hanning, averageTogether(30));
+    every time outputflag comes up the 256 output words are recorded"""
+    iq = synth_iq(40 * 128, 11)
+    iq[5 * 128:6 * 128] = np.where(np.random.default_rng(1).random((128, 2)) < 0.5, 32767, -32768)   # one block on the rails
+    out["fft256iq_iq"] = iq
+    for tag, window, navg in (("sketch", "hann256", 30), ("default", "blackman_nuttall256", 8), ("avg1", "hann256", 1)):
+        r = Ref(im)
+        obj = r.alloc(0xa40 + 16)
+        r.m.write(obj + 536, 4, im.dtcm_of_offset(TABLES[window][0]))
+        r.m.write(obj + 2597, 1, navg)
+        assert r.call("cfft_q15_init", obj + 0xa30, 256, 0, 1) == 0
+        bl = Blocks(r)
+        cur = {}
+        r.cpu.hooks[A["receiveReadOnly"]] = lambda c: c.r.__setitem__(0, cur[c.r[1]])
+        r.cpu.hooks[A["release"]] = lambda c: None
+        spectra, ticks = [], []
+        for b in range(len(iq) // 128):
+            blk = iq[b * 128:(b + 1) * 128]
+            cur[0], cur[1] = bl.new(blk[:, 0]), bl.new(blk[:, 1])
+            r.call("fft256iq_update", obj)
+            if r.m.read(obj + 2598, 1):
+                r.m.write(obj + 2598, 1, 0)                              # available() clears it
+                spectra.append(r.get(obj + 24, 256, np.uint16)); ticks.append(b)
+        out[f"fft256iq_{tag}_out"] = np.stack(spectra)
+        out[f"fft256iq_{tag}_ticks"] = np.array(ticks)
+
+
+def kat_fft1024(im, out, tables):
+    """AudioAnalyzeFFT1024::update (Teensy Audio library, `AudioFFT` on Q_out_L, INO:57,147) on 40 blocks with
+    AudioWindowHanning1024 and with no window"""
+    x = synth_iq(40 * 128, 12)[:, 0].copy()
+    x[9 * 128:10 * 128] = np.where(np.random.default_rng(2).random(128) < 0.5, 32767, -32768)
+    out["fft1024_in"] = x
+    for tag, window in (("hann", "hann1024"), ("nowindow", None)):
+        r = Ref(im)
+        obj = r.alloc(0x1444 + 32)
+        r.m.write(obj + 1048, 4, im.dtcm_of_offset(TABLES[window][0]) if window else 0)
+        assert r.call("cfft_q15_init", obj + 0x1444, 1024, 0, 1) == 0
+        bl = Blocks(r)
+        cur = {}
+        r.cpu.hooks[A["receiveReadOnly"]] = lambda c: c.r.__setitem__(0, cur[0])
+        r.cpu.hooks[A["release"]] = lambda c: None
+        spectra, ticks = [], []
+        for b in range(len(x) // 128):
+            cur[0] = bl.new(x[b * 128:(b + 1) * 128])
+            r.call("fft1024_update", obj)
+            if r.m.read(obj + 0x143d, 1):
+                r.m.write(obj + 0x143d, 1, 0)
+                spectra.append(r.get(obj + 24, 512, np.uint16)); ticks.append(b)
+        out[f"fft1024_{tag}_out"] = np.stack(spectra)
+        out[f"fft1024_{tag}_ticks"] = np.array(ticks)
+
+
+def teensy_biquad_ints(kind, frequency, q, fs=44100.0):
+    """filter_biquad.h's setters as published (float angle product, double cookbook, x 2^30, int conversion)"""
+    w0 = float(F32(frequency) * (F32(2.0) * F32(3.141592654) / F32(fs)))
+    sw, cw = np.sin(w0), np.cos(w0)
+    alpha = sw / (float(F32(q)) * 2.0)
+    scale = 1073741824.0 / (1.0 + alpha)
+    if kind == "lowpass": b = [((1.0 - cw) / 2.0) * scale, (1.0 - cw) * scale]; b.append(b[0])
+    elif kind == "highpass": b = [((1.0 + cw) / 2.0) * scale, -(1.0 + cw) * scale]; b.append(b[0])
+    elif kind == "bandpass": b = [alpha * scale, 0.0, (-alpha) * scale]
+    else: b = [scale, (-2.0 * cw) * scale]; b.append(b[0])
+    c = b + [(-2.0 * cw) * scale, (1.0 - alpha) * scale]
+    return np.array([int(v) for v in c], np.int32)
+
+
+def kat_teensy_biquad(im, out):
+    """AudioFilterBiquad: setCoefficients + update from the image on one object per case:
+       hp      stage 0 = setHighpass(0, 500, 0.5) (INO:155)
+       chain   stages 0, 1, 2 = high-pass, notch, low-pass
+       gap     stages 0 and 2 set, 1 never: update() must stop after stage 0
+       fresh   nothing set: passes nothing
+    32 blocks each; blocks 4-5 are full-scale noise (the saturating path)"""
+    x = synth_iq(32 * 128, 13)[:, 1].copy()
+    x[4 * 128:6 * 128] = np.random.default_rng(3).integers(-32768, 32768, 256).astype(I16)
+    out["tbq_in"] = x
+    cases = dict(hp=[(0, "highpass", 500.0, 0.5)], chain=[(0, "highpass", 500.0, 0.5), (1, "notch", 1000.0, 4.0), (2, "lowpass", 3000.0, 0.707)],
+                 gap=[(0, "lowpass", 2000.0, 0.8), (2, "highpass", 300.0, 0.7)], fresh=[])
+    for tag, stages in cases.items():
+        r = Ref(im)
+        obj = r.alloc(24 + 32 * 4 + 16)
+        cbuf = r.alloc(20)
+        coefs = np.zeros((4, 5), np.int32)
+        for st, kind, f, q in stages:
+            coefs[st] = teensy_biquad_ints(kind, f, q)
+            r.put(cbuf, coefs[st])
+            r.call("biquad_setCoefficients", obj, st, cbuf)
+        bl = Blocks(r)
+        cur, sent = {}, []
+        r.cpu.hooks[A["receiveWritable"]] = lambda c: c.r.__setitem__(0, cur[0])
+        r.cpu.hooks[A["transmit"]] = lambda c: sent.append(r.get(c.r[1] + 4, 128, I16))
+        r.cpu.hooks[A["release"]] = lambda c: None
+        for b in range(len(x) // 128):
+            cur[0] = bl.new(x[b * 128:(b + 1) * 128])
+            r.call("biquad_update", obj)
+        out[f"tbq_{tag}_coefs"] = coefs
+        out[f"tbq_{tag}_stages"] = np.array([s[0] for s in stages], np.int64)
+        out[f"tbq_{tag}_out"] = np.concatenate(sent)
+
+
+def main():
+    if not os.path.exists(HEX):
+        sys.exit("the reference tree is not here: this script runs in the build container only")
+    im = Image()
+    sha = hashlib.sha256(im.img).hexdigest()
+    tables = np.load(os.path.join(HERE, "firmware_tables.npz"))
+    out = {"image_sha256": np.array(sha), "image_bytes": np.int64(len(im.img))}
+    t0 = time.time()
+    for name, f in (("cfft_q15", lambda: kat_cfft_q15(im, out)), ("lms_norm", lambda: kat_lms_norm(im, out)),
+                    ("df1", lambda: kat_df1(im, out, tables["biquad_sets"])), ("converters", lambda: kat_converters(im, out)),
+                    ("cfft_f32", lambda: kat_cfft_f32(im, out)), ("design", lambda: kat_design(im, out)), ("conv", lambda: kat_conv(im, out)),
+                    ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
+                    ("teensy_biquad", lambda: kat_teensy_biquad(im, out))):
+        t = time.time()
+        f()
+        print("%-14s %.1f s" % (name, time.time() - t), flush=True)
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes, %.0f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

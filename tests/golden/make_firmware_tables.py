@@ -232,6 +232,15 @@ def main():
     lit = np.frombuffer(img[:len(img) // 4 * 4], dtype="<f4")
     out["two_pi_over_fs_offsets"] = (4 * np.nonzero(lit == two_pi_fs)[0]).astype(np.int64)
     out["two_pi_over_fs"] = np.array([two_pi_fs], np.float32)
+    # what the image does NOT hold: CMSIS' sinTable_f32 (513 entries, arm_sin_f32 / arm_cos_f32 of SPEC:229-232) -- at any
+    # 2-byte alignment; the only sine table is the engine's 257-entry oscillator table above
+    s513 = np.sin(2 * np.pi * np.arange(1, 4) / 512).astype(np.float32)
+    hits = 0
+    for off in (0, 2):
+        f = np.frombuffer(img[off:off + (len(img) - off) // 4 * 4], dtype="<f4")
+        with np.errstate(invalid="ignore"):
+            hits += int(np.count_nonzero((np.abs(f[:-2] - s513[0]) < 1e-6) & (np.abs(f[1:-1] - s513[1]) < 1e-6) & (np.abs(f[2:] - s513[2]) < 1e-6)))
+    out["cmsis_sin513_occurrences"] = np.int64(hits)
     # sanity: what each table is, so a wrong offset cannot slip through
     i = np.arange(256)
     assert np.array_equal(out["hann256"], np.minimum(32767, np.round(32768 * 0.5 * (1 - np.cos(2 * np.pi * i / 255)))))

@@ -1,0 +1,370 @@
+"""Known answers computed by the reference's own compiled code (tests/golden/firmware_kat.npz).
+
+The vectors were produced in the build container by running routines of the reference's shipped firmware image
+(pre_compiled/RadioDSP_SDR_RX.ino.hex) under an instruction-set interpreter (tests/golden/thumb_emu.py,
+make_firmware_kat.py): CMSIS-DSP's arm_cfft_radix4_q15, arm_lms_norm_f32, arm_biquad_cascade_df1_f32, arm_float_to_q15,
+arm_q15_to_float, arm_cfft_f32, arm_cmplx_mult_cmplx_f32; the sketch's Init_LMS_NR, calc_cplx_FIR_coeffs /
+init_filter_mask (through reInitializeFilter) and doConvolutionalProcessing block by block; the update() methods of
+AudioAnalyzeFFT256IQ, AudioAnalyzeFFT1024 and AudioFilterBiquad.  Inputs and outputs only -- the image does not
+travel.  `-m "not gpu"`: the oracle's restatements against them.  `-m gpu`: the product, through the C-ABI.
+
+Integer routines must agree bit for bit.  Float routines whose operation order the restatement claims to follow
+(arm_lms_norm_f32, arm_biquad_cascade_df1_f32, the converters, arm_cmplx_mult_cmplx_f32) must too; the float FFT and
+what is built on it (the mask, the CONV stage) are held to the north-star's 1e-5 with the measured distance noted."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from cases import CONV_LITERAL
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+I16P, F32P, F64P, I32P = (C.POINTER(t) for t in (C.c_int16, C.c_float, C.c_double, C.c_int32))
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def kat():
+    k = np.load(os.path.join(HERE, "golden", "firmware_kat.npz"))
+    assert int(k["image_bytes"]) == 206012 and len(str(k["image_sha256"])) == 64
+    return k
+
+
+def nrm(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def p(a, t=F32P):
+    return a.ctypes.data_as(t)
+
+
+# ---- CPU: the oracle against the reference's compiled routines -----------------------------------------------------------
+@pytest.mark.parametrize("n", [256, 1024])
+def test_oracle_cfft_radix4_q15_is_the_images(kat, oracle, n):
+    """arm_cfft_radix4_init_q15 + arm_cfft_radix4_q15 of the image (its own twiddle and bit-reversal tables): full-scale
+    noise, every sample on a rail, small signals -- bit for bit"""
+    lib = oracle.load()
+    lib.orc_cfft_radix4_q15_n.argtypes = [I16P, C.c_int]
+    for x, y in zip(kat[f"cfft_q15_{n}_in"], kat[f"cfft_q15_{n}_out"]):
+        o = x.copy()
+        lib.orc_cfft_radix4_q15_n(p(o, I16P), n)
+        assert np.array_equal(o, y)
+
+
+def test_oracle_converters_are_the_images(kat, oracle):
+    """arm_float_to_q15 (CONV:346-347: rounds, halves away from zero, saturates) and arm_q15_to_float (CONV:241-242)"""
+    lib = oracle.load()
+    x = kat["float_to_q15_in"]
+    o = np.zeros(len(x), np.int16)
+    lib.orc_float_to_q15(p(x), p(o, I16P), len(x))
+    assert np.array_equal(o, kat["float_to_q15_out"])
+    assert kat["float_to_q15_out"][:16].tolist() == [0, 1, 1, 2, 3, 0, -1, -1, -2, -3, 32767, 32767, -32768, 32767, -32768, 0]
+    q = kat["q15_to_float_in"]
+    f = np.zeros(len(q), np.float32)
+    lib.orc_q15_to_float(p(q, I16P), p(f), len(q))
+    assert np.array_equal(f, kat["q15_to_float_out"])
+
+
+def test_oracle_lms_norm_is_the_images_bit_for_bit(kat, oracle):
+    """arm_lms_norm_f32 (NR:73), 96 taps, three consecutive blocks of 128 on one instance: outputs, error signal,
+    coefficients, energy and x0 after every block -- the restatement's operation order is the compiled routine's"""
+    lib = oracle.load()
+    lib.orc_lms_norm_f32_kat.argtypes = [C.c_float] + [F32P] * 7 + [C.c_uint32]
+    assert int(kat["lms_taps"]) == 96
+    co, st, ex = kat["lms_coeffs0"].copy(), np.zeros(95, np.float32), np.zeros(2, np.float32)
+    for b in range(len(kat["lms_src"])):
+        src, ref = kat["lms_src"][b].copy(), kat["lms_ref"][b].copy()
+        o, e = np.zeros(128, np.float32), np.zeros(128, np.float32)
+        lib.orc_lms_norm_f32_kat(kat["lms_mu"][0], p(co), p(st), p(ex), p(src), p(ref), p(o), p(e), 128)
+        assert np.array_equal(o, kat["lms_out"][b]) and np.array_equal(e, kat["lms_err"][b])
+        assert np.array_equal(co, kat["lms_coeffs"][b]) and np.array_equal(ex, kat["lms_energy_x0"][b])
+
+
+def test_oracle_df1_cascade_is_the_images_bit_for_bit(kat, oracle):
+    """arm_biquad_cascade_df1_f32 with the engine's own first coefficient set, two calls on one instance"""
+    from test_audio_nodes import OrcBiquad
+    lib = oracle.load()
+    lib.orc_biquad_init.argtypes = [C.POINTER(OrcBiquad), C.c_int, F32P]
+    lib.orc_biquad_run.argtypes = [C.POINTER(OrcBiquad), F32P, C.c_int]
+    b = OrcBiquad()
+    coef = kat["df1_coef"].copy()
+    lib.orc_biquad_init(C.byref(b), 4, p(coef))
+    for x, y in zip(kat["df1_in"], kat["df1_out"]):
+        v = x.copy()
+        lib.orc_biquad_run(C.byref(b), p(v), len(v))
+        assert np.array_equal(v, y)
+
+
+def test_oracle_float_fft_and_complex_product(kat, oracle):
+    """arm_cfft_f32 with arm_cfft_sR_f32_len256 (CONV:290,307), forward and inverse: the oracle's transform orders its
+    additions differently (measured 1.2e-7 / 1.9e-7 normwise); arm_cmplx_mult_cmplx_f32 (CONV:299) bit for bit"""
+    lib = oracle.load()
+    x = kat["cfft_f32_in"].copy()
+    lib.orc_cfft_f32(p(x), 256, 0)
+    assert nrm(x, kat["cfft_f32_fwd"]) < 5e-7
+    lib.orc_cfft_f32(p(x), 256, 1)
+    assert nrm(x, kat["cfft_f32_inv"]) < 5e-7
+    lib.orc_cmplx_mult_cmplx_f32.argtypes = [F32P, F32P, F32P, C.c_uint32]
+    o = np.zeros(512, np.float32)
+    lib.orc_cmplx_mult_cmplx_f32(p(kat["cmplx_mult_a"].copy()), p(kat["cmplx_mult_b"].copy()), p(o), 256)
+    assert np.array_equal(o, kat["cmplx_mult_out"])
+
+
+def _design(fn_taps, fn_mask, lo, hi):
+    ti, tq = np.zeros(129), np.zeros(129)
+    fn_taps(p(ti, F64P), p(tq, F64P), 129, lo, hi, 44100.0, 1)
+    m = np.zeros(512, np.float32)
+    fn_mask(p(m), p(ti, F64P), p(tq, F64P), 256)
+    return ti, tq, m
+
+
+def test_filter_design_is_the_images(kat, oracle, rdsp):
+    """calc_cplx_FIR_coeffs + init_filter_mask as reInitializeFilter runs them in the image (CONV:209-224; newlib's
+    sin / cos, the sketch's own contracted double arithmetic) for the sketch's pass band and three PBT settings: the
+    oracle's and the product's double taps agree to 3e-16 of the largest tap -- identical once narrowed to float,
+    which is all the mask sees -- and the masks to 2e-7 (the float FFT's rounding)"""
+    olib, plib = oracle.load(), rdsp.load()
+    for lib, pre in ((olib, "orc_"), (plib, "rdsp_")):
+        getattr(lib, pre + "calc_cplx_FIR_coeffs").argtypes = [F64P, F64P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]
+        getattr(lib, pre + "calc_cplx_FIR_coeffs").restype = None
+        getattr(lib, pre + "init_filter_mask").argtypes = [F32P, F64P, F64P, C.c_uint32 if pre == "orc_" else C.c_int]
+    for (lo, hi), ri, rq, rm in zip(kat["design_bands"], kat["design_taps_i"], kat["design_taps_q"], kat["design_mask"]):
+        for lib, pre in ((olib, "orc_"), (plib, "rdsp_")):
+            ti, tq, m = _design(getattr(lib, pre + "calc_cplx_FIR_coeffs"), getattr(lib, pre + "init_filter_mask"), float(lo), float(hi))
+            scale = np.abs(ri).max()
+            assert np.abs(ti - ri).max() <= 1e-15 * scale and np.abs(tq - rq).max() <= 1e-15 * scale, (pre, lo, hi)
+            assert np.array_equal(ti.astype(np.float32), ri.astype(np.float32)) and np.array_equal(tq.astype(np.float32), rq.astype(np.float32))
+            assert nrm(m, rm) < 5e-7, (pre, lo, hi, nrm(m, rm))
+
+
+def test_init_lms_nr_step_size_is_the_images(kat, oracle):
+    """NR:48-55 through newlib's powf for strengths 1 ... 40: the same two float operations with this host's powf (what
+    the oracle and the product's host code evaluate) land within two float ulps -- one from powf, doubled by the reciprocal"""
+    mu = kat["init_lms_nr_mu"]
+    assert abs(float(mu[14]) - 10 ** -0.95) < 1e-8                       # Init_LMS_NR(15), INO:172
+    for s in (1, 7, 15, 22, 30, 40):
+        want = np.float32(1) / np.float32(np.power(np.float32(10), (np.float32(s) / np.float32(2) + np.float32(2)) / np.float32(10)))
+        assert abs(float(mu[s - 1]) - float(want)) <= 2.5e-7 * float(want)
+
+
+def _oracle_conv(oracle, kat, tag):
+    from oracle_lib import OracleChain
+    iq = kat["conv_iq"]
+    if tag == "plain":
+        return OracleChain(**CONV_LITERAL).process(iq[:32 * 128])
+    if tag == "nr15":
+        return OracleChain(**dict(CONV_LITERAL, lms_nr=15)).process(iq)
+    if tag == "nrstep":
+        c = OracleChain(**dict(CONV_LITERAL, lms_nr=15))
+        a = c.process(iq[:16 * 128])
+        c.set_nr_level(30)
+        b = c.process(iq[16 * 128:32 * 128])
+    elif tag == "pbt":
+        c = OracleChain(**CONV_LITERAL)
+        a = c.process(iq[:12 * 128])
+        c.reinit_filter(450.0, 2700.0)
+        b = c.process(iq[12 * 128:24 * 128])
+    else:
+        c = OracleChain(**CONV_LITERAL)
+        c.set_filter_on(0)
+        c.set_literal_filter_off(1)
+        return c.process(iq[:12 * 128])
+    return np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]])
+
+
+# measured when the fixture was made (oracle against the image's code): float normwise, int16 samples one count apart
+CONV_RUNS = {"plain": (1.6e-7, 9), "nr15": (1.5e-6, 48), "nrstep": (2.0e-6, 56), "pbt": (1.6e-7, 2), "nofilt": (1.7e-7, 2)}
+
+
+@pytest.mark.parametrize("tag", list(CONV_RUNS))
+def test_oracle_conv_stage_against_the_images_doConvolutionalProcessing(kat, oracle, tag):
+    """The CONV stage exactly as the sketch runs it (INO:172-198: Init_LMS_NR(15), doConvolutionalInitialize,
+    reInitializeFilter(300, 4000), then doConvolutionalProcessing once per 128-sample block), executed from the image:
+    plain (A1 unpack, A5 overlap-save filter from the zero-filled first block on, A10 pack), with the NLMS noise
+    reduction (A8; x 1.1, L copied to R), a noise-reduction level change in mid-stream (NR:35-64 clears the state and
+    keeps the taps), a pass-band change in mid-stream, and the filter-off branch as written (CONV:303 copies half the
+    spectrum).  The oracle's float output, taken where the sketch hands it to arm_float_to_q15, is within 1e-5 normwise
+    (measured: see CONV_RUNS); its int16 output differs by at most one count on a fraction of a percent of the samples."""
+    o16, o32 = _oracle_conv(oracle, kat, tag)
+    r16, r32 = kat[f"conv_{tag}_o16"], kat[f"conv_{tag}_o32"]
+    assert o16.shape == r16.shape
+    e = nrm(o32, r32)
+    d = np.abs(o16.astype(np.int32) - r16)
+    print(f"{tag}: float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
+    assert e <= TOL and e <= 4 * CONV_RUNS[tag][0]
+    assert d.max() <= 1 and (d > 0).sum() <= max(4 * CONV_RUNS[tag][1], 16)
+    if tag == "nr15":
+        from oracle_lib import OracleChain
+        c = OracleChain(**dict(CONV_LITERAL, lms_nr=15))
+        c.process(kat["conv_iq"])
+        assert nrm(c.lms_coeffs(0), kat["conv_nr15_coeffs"]) < 1e-4      # the 96 taps after 48 blocks (measured 1.1e-5)
+
+
+def test_oracle_analysers_are_the_images_update_bit_for_bit(kat, oracle):
+    """AudioAnalyzeFFT256IQ::update (FFTIQ.cpp:38-118) and AudioAnalyzeFFT1024::update, whole: block pairing, window,
+    transform, |X|^2, averaging, sqrt_uint32_approx, output order and the tick on which the flag comes up -- with the
+    sketch's settings (Hanning, averageTogether(30)), the constructor's (BlackmanNuttall, 8), no averaging, no window;
+    one block of the input sits on the rails"""
+    from test_audio_nodes import _bind, oracle_fft1024
+    from test_spectrum import _olib, oracle_spectra
+    lib = _bind(_olib(oracle))
+    iq = kat["fft256iq_iq"]
+    for tag, win, navg in (("sketch", 1, 30), ("default", 3, 8), ("avg1", 1, 1)):
+        want = kat[f"fft256iq_{tag}_out"]
+        got = np.stack(oracle_spectra(lib, iq, navg, win))
+        assert np.array_equal(got, want), tag
+        assert np.array_equal(kat[f"fft256iq_{tag}_ticks"], np.arange(navg, 40, navg) if navg > 1 else np.arange(1, 40))
+    x = kat["fft1024_in"]
+    for tag, win in (("hann", 1), ("nowindow", 0)):
+        assert np.array_equal(oracle_fft1024(lib, x, win), kat[f"fft1024_{tag}_out"]), tag
+        assert np.array_equal(kat[f"fft1024_{tag}_ticks"], np.arange(7, 40, 4))
+
+
+TBQ = ("hp", "chain", "gap", "fresh")
+
+
+def test_oracle_teensy_biquad_is_the_images_update_bit_for_bit(kat, oracle, rdsp):
+    """AudioFilterBiquad::setCoefficients + ::update of the image: one stage (INO:155), three chained stages, a stage
+    set behind one that never was (update() stops in front of the gap), a fresh object (passes nothing); two blocks
+    of full-scale noise drive the saturating path.  The setters' integer coefficients (computed by the published
+    formula for the fixture) are what the oracle's and the product's design routines return."""
+    from test_audio_nodes import TeensyBiquadOracle
+    lib = oracle.load()
+    x = kat["tbq_in"]
+    for tag in TBQ:
+        o = TeensyBiquadOracle(lib)
+        for st in kat[f"tbq_{tag}_stages"]:
+            c5 = np.ascontiguousarray(kat[f"tbq_{tag}_coefs"][st], np.int32)
+            lib.orc_teensy_biquad_setCoefficients_int(C.byref(o.o), int(st), p(c5, I32P))
+        assert np.array_equal(o.update(x), kat[f"tbq_{tag}_out"]), tag
+    assert not kat["tbq_fresh_out"].any() and np.abs(kat["tbq_hp_out"].astype(int)).max() >= 32767
+    plib = rdsp.load()
+    plib.rdsp_teensy_biquad_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, I32P]
+    want = {0: (1, 500.0, 0.5), 1: (3, 1000.0, 4.0), 2: (0, 3000.0, 0.707)}
+    for st, (kind, f, q) in want.items():
+        a, b = np.zeros(5, np.int32), np.zeros(5, np.int32)
+        lib.orc_teensy_biquad_design(kind, f, q, 44100.0, p(a, I32P))
+        plib.rdsp_teensy_biquad_design(kind, f, q, 44100.0, p(b, I32P))
+        assert np.array_equal(a, kat["tbq_chain_coefs"][st]) and np.array_equal(b, kat["tbq_chain_coefs"][st])
+
+
+# ---- GPU: the product against the reference's compiled routines ----------------------------------------------------------
+NCH = 3          # the same stream on three channels: every channel must give the reference's answer
+
+
+def _gpu_conv(torch, kat, tag, named):
+    from radiodsp_sdr_rx_amd.chain import Chain
+    iq = kat["conv_iq"]
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(np.broadcast_to(a, (NCH,) + a.shape))).cuda()
+
+    def run(ch, part, nr=0.0):
+        if named:                                                        # the reference's own entry point, block call by block call
+            o = ch.doConvolutionalProcessing(nr, True, 300.0, 4000.0, dev(part))
+            torch.cuda.synchronize()
+            return o.cpu().numpy(), None
+        a, b = ch.process(dev(part), want_f32=True)
+        torch.cuda.synchronize()
+        return a.cpu().numpy(), b.cpu().numpy()
+
+    cat = lambda x, y: (np.concatenate([x[0], y[0]], 1), None if x[1] is None else np.concatenate([x[1], y[1]], 1))
+    if tag == "plain":
+        return run(Chain(NCH, max_blocks_per_call=32, **CONV_LITERAL), iq[:32 * 128])
+    if tag == "nr15":
+        return run(Chain(NCH, max_blocks_per_call=48, **dict(CONV_LITERAL, lms_nr=15)), iq, 15.0)
+    if tag == "nrstep":
+        ch = Chain(NCH, max_blocks_per_call=16, **dict(CONV_LITERAL, lms_nr=15))
+        a = run(ch, iq[:16 * 128], 15.0)
+        if not named:
+            ch.set_nr_level(30)
+        return cat(a, run(ch, iq[16 * 128:32 * 128], 30.0))
+    ch = Chain(NCH, max_blocks_per_call=12, **CONV_LITERAL)
+    a = run(ch, iq[:12 * 128])
+    ch.reInitializeFilter(450.0, 2700.0)
+    return cat(a, run(ch, iq[12 * 128:24 * 128]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plain", "nr15", "nrstep", "pbt"])
+def test_gpu_conv_stage_against_the_images_doConvolutionalProcessing(rdsp, kat, tag):
+    """The product (HIP kernels through the C-ABI, CONV configuration at its native rate) against what the reference's
+    compiled doConvolutionalProcessing wrote for the same IQ blocks: float output within 1e-5 normwise on every channel,
+    int16 output within one count.  (The filter-off branch is not run: the product reads bFilterEnabled == false as a
+    bypass, a documented deviation from CONV:303's half-copy, which INO:198 never takes.)"""
+    import torch
+    assert torch.cuda.is_available()
+    o16, o32 = _gpu_conv(torch, kat, tag, named=False)
+    r16, r32 = kat[f"conv_{tag}_o16"], kat[f"conv_{tag}_o32"]
+    for c in range(NCH):
+        e = nrm(o32[c], r32)
+        d = np.abs(o16[c].astype(np.int32) - r16)
+        print(f"{tag} ch{c}: float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
+        assert e <= TOL, (tag, c, e)
+        assert d.max() <= 1 and (d > 0).sum() <= max(8 * CONV_RUNS[tag][1], 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plain", "nr15", "nrstep"])
+def test_gpu_reference_named_entry_point_against_the_image(rdsp, kat, tag):
+    """the same through rdsp_doConvolutionalProcessing(iNRLevel, bFilterEnabled, lo, hi, ...), CONV:228's signature --
+    a level change arrives the way the sketch delivers it, as another iNRLevel"""
+    import torch
+    o16, _ = _gpu_conv(torch, kat, tag, named=True)
+    r16 = kat[f"conv_{tag}_o16"]
+    for c in range(NCH):
+        d = np.abs(o16[c].astype(np.int32) - r16)
+        assert d.max() <= 1 and (d > 0).sum() <= max(8 * CONV_RUNS[tag][1], 32), (tag, c, int(d.max()), int((d > 0).sum()))
+
+
+@pytest.mark.gpu
+def test_gpu_analysers_are_the_images_update_bit_for_bit(rdsp, kat):
+    """rdsp_spectrum_* and rdsp_fft1024_* against the image's update() methods, every output, in calls of ragged size"""
+    import torch
+    from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    iq = kat["fft256iq_iq"]
+    dev = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(iq, (NCH,) + iq.shape))).cuda()
+    for tag, win, navg in (("sketch", "AudioWindowHanning256", 30), ("default", None, 8), ("avg1", "AudioWindowHanning256", 1)):
+        a = AnalyzeFFT256IQ(NCH) if win is None else AnalyzeFFT256IQ(NCH, naverage=navg, window=win)
+        got, k = [], 0
+        for nb in (7, 1, 13, 19):
+            o = a.update(dev[:, k * 128:(k + nb) * 128].contiguous())
+            torch.cuda.synchronize()
+            got.append(o.cpu().numpy().view(np.uint16))
+            k += nb
+        got = np.concatenate(got, 1)
+        for c in range(NCH):
+            assert np.array_equal(got[c], kat[f"fft256iq_{tag}_out"]), (tag, c)
+    x = kat["fft1024_in"]
+    dx = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(x, (NCH,) + x.shape))).cuda()
+    for tag, win in (("hann", "AudioWindowHanning1024"), ("nowindow", None)):
+        a = AnalyzeFFT1024(NCH, window=win) if win else AnalyzeFFT1024(NCH, window="AudioWindowHanning1024")
+        if not win:
+            a.windowFunction(None)
+        got, k = [], 0
+        for nb in (5, 3, 11, 21):
+            o = a.update(dx[:, k * 128:(k + nb) * 128].contiguous())
+            torch.cuda.synchronize()
+            got.append(o.cpu().numpy().view(np.uint16))
+            k += nb
+        got = np.concatenate(got, 1)
+        for c in range(NCH):
+            assert np.array_equal(got[c], kat[f"fft1024_{tag}_out"]), (tag, c)
+
+
+@pytest.mark.gpu
+def test_gpu_teensy_biquad_is_the_images_update_bit_for_bit(rdsp, kat):
+    """rdsp_biquad_* (AudioFilterBiquad) against the image's setCoefficients + update: all four cases, in two calls"""
+    import torch
+    from radiodsp_sdr_rx_amd.filters import FilterBiquad
+    x = kat["tbq_in"]
+    dx = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(x, (NCH,) + x.shape))).cuda()
+    for tag in TBQ:
+        bq = FilterBiquad(NCH)
+        for st in kat[f"tbq_{tag}_stages"]:
+            bq.setCoefficients(int(st), [int(v) for v in kat[f"tbq_{tag}_coefs"][st]])
+        got = np.concatenate([bq.update(dx[:, :11 * 128].contiguous()).cpu().numpy(), bq.update(dx[:, 11 * 128:].contiguous()).cpu().numpy()], 1)
+        for c in range(NCH):
+            assert np.array_equal(got[c], kat[f"tbq_{tag}_out"]), (tag, c)

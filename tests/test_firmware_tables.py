@@ -394,6 +394,9 @@ def test_audio_filter_biquad_of_the_image_is_the_fixed_point_routine(fw, oracle)
     assert names == (["UBFX #0 #14"] + ["SMLAWB", "SMLAWT", "SMLAWB", "SMLAWT", "SMLAWB"] + ["SSAT #16 ASR #14", "UBFX #0 #14"]
                      + ["SMLAWT", "SMLAWB", "SMLAWT", "SMLAWB", "SMLAWT"] + ["SSAT #16 ASR #14", "PKHBT", "UBFX #0 #14"])
     assert len(fw["two_pi_over_fs_offsets"]) >= 1
+    # and what the image does not hold: CMSIS' 513-entry sinTable_f32 -- src/backup/ (the spectral stage, SPEC:229-232) is
+    # "not for normal compilation", so its arm_sin_f32 / arm_cos_f32 are not linked; that row stays unpinned
+    assert int(fw["cmsis_sin513_occurrences"]) == 0
     assert fw["two_pi_over_fs"][0] == np.float32(2.0) * np.float32(3.141592654) / fw["sample_rate"][0].astype(np.float32)
 
     def s32(v):
