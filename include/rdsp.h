@@ -545,8 +545,8 @@ int rdsp_biquad_setLowpass(rdsp_biquad_t *b, int stage, float frequency, float q
 int rdsp_biquad_setHighpass(rdsp_biquad_t *b, int stage, float frequency, float q);  /* INO:155-156 */
 int rdsp_biquad_setBandpass(rdsp_biquad_t *b, int stage, float frequency, float q);
 int rdsp_biquad_setNotch(rdsp_biquad_t *b, int stage, float frequency, float q);
-/* what the four setters compute (host, no device): RBJ cookbook in double with w0 = frequency * (2 * 3.141592654f / fs)
- * as a float product, each coefficient x 2^30 / (1 + alpha) converted to int; a1, a2 as the transfer function writes
+/* what the four setters compute (host, no device): RBJ cookbook in double with w0 = frequency * (2 * 3.141592654 / fs),
+ * each coefficient x 2^30 / (1 + alpha) converted to int; a1, a2 as the transfer function writes
  * them (setCoefficients negates).  kind 0 LP, 1 HP, 2 BP, 3 notch */
 void rdsp_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5);
 int rdsp_biquad_get_definition(const rdsp_biquad_t *b, int32_t *out20, int *n_stages); /* b0, b1, b2, -a1, -a2 x 2^30 per stage */

@@ -1,13 +1,16 @@
 /*
  * rdsp_oracle.c -- CPU ORACLE (test infrastructure; see rdsp_oracle.h header).
- * PARITY: UNPINNED for everything floating-point (no reference fixtures exist; restated from the
- * reference's sources and anchored by analytic KATs + an independent float64 model); PINNED BY
- * REFERENCE-HELD DATA where the reference holds some -- the constant tables of its shipped firmware
- * image (tests/golden/firmware_tables.npz): the analysers' q15 windows, q15 twiddles, bit-reversal
- * table and square-root guess table, the sample rate, the NLMS epsilon, the 1.1 gain and the design
- * routine's constants; and the ORDER OF OPERATIONS of arm_radix4_butterfly_q15, of the analysers'
- * update() with sqrt_uint32_approx, and of arm_lms_norm_f32 (unfused multiply-then-add), read out of
- * the image's code as instruction classes and offsets (tests/test_firmware_tables.py).
+ * PARITY: PINNED ON THE REFERENCE'S OWN COMPILED CODE for what its shipped build contains -- routines of the firmware
+ * image (the .hex under pre_compiled) are run under an instruction-set interpreter in the build container and their inputs and
+ * outputs kept as tests/golden/firmware_kat.npz (tests/test_firmware_kat.py): arm_cfft_radix4_q15, arm_lms_norm_f32,
+ * arm_biquad_cascade_df1_f32, the q15 converters, arm_cmplx_mult_cmplx_f32, both analysers' update() and
+ * AudioFilterBiquad's BIT FOR BIT; the design routine's taps identical once narrowed to float; the CONV stage
+ * (doConvolutionalProcessing with and without the NLMS, level and pass-band changes in mid-stream, the filter-off branch
+ * as written) 1.6e-7 ... 2.0e-6 normwise, int16 within one count.  PINNED BY REFERENCE-HELD DATA besides -- the constant
+ * tables of the same image (tests/golden/firmware_tables.npz, tests/test_firmware_tables.py).  UNPINNED for the stages
+ * that are not in the image or not in the tree: the decimator (not in the reference), the spectral stage (src/backup
+ * only), and the build-defined stand-ins for the AudioSDR engine (NCO, ALS, AGC, SAM, blanker) -- those are anchored by
+ * analytic KATs and an independent float64 model only.
  *
  * Citation short names (relative to /root/reference/src):
  *   CONV = RadioDSP_SDR_RX/RDSP_convolutional.h
@@ -337,8 +340,8 @@ void orc_biquad_design(int kind, double freq, double q, double fs, float *coef5)
  * update() works on pairs of samples packed in 32-bit words; unpacked, that is the per-sample recursion below (the
  * second sample of a pair takes the first one's saturated output as y[n-1], exactly as `a1 * out2` does there).
  * The reference's firmware image holds the routine: UBFX, SMLAWB, SMLAWT, SMLAWB, SMLAWT, SMLAWB, SSAT #16 ASR #14,
- * UBFX, SMLAWT, SMLAWB, SMLAWT, SMLAWB, SMLAWT, SSAT #16 ASR #14, PKHBT, UBFX (tests/test_firmware_tables.py), and the
- * float constant 2 * 3.141592654f / 44100.0f of the setters.  A stage that was never set has all-zero coefficients
+ * UBFX, SMLAWT, SMLAWB, SMLAWT, SMLAWB, SMLAWT, SSAT #16 ASR #14, PKHBT, UBFX (tests/test_firmware_tables.py), and run
+ * under an interpreter it gives this restatement's outputs bit for bit (tests/test_firmware_kat.py).  A stage that was never set has all-zero coefficients
  * ("by default, the filter will not pass anything"); update() always runs stage 0 and goes on to stage s + 1 only
  * if setCoefficients(s + 1) was ever called (it sets the hand-on bit in stage s). */
 void orc_teensy_biquad_init(orc_teensy_biquad_t *b) { memset(b, 0, sizeof(*b)); }
@@ -359,10 +362,11 @@ void orc_teensy_biquad_setCoefficients(orc_teensy_biquad_t *b, int stage, const 
   for (int i = 0; i < 5; i++) ci[i] = (int32_t)(c[i] * 1073741824.0);
   orc_teensy_biquad_setCoefficients_int(b, stage, ci);
 }
-/* setLowpass / setHighpass / setBandpass / setNotch (filter_biquad.h; the RBJ cookbook in double, the angle from a
- * float product: `frequency * (2.0f * 3.141592654f / AUDIO_SAMPLE_RATE_EXACT)`).  kind 0 LP, 1 HP, 2 BP, 3 notch */
+/* setLowpass / setHighpass / setBandpass / setNotch (filter_biquad.h; the RBJ cookbook in double, the angle
+ * `frequency * (2 * 3.141592654 / AUDIO_SAMPLE_RATE_EXACT)` in double too: the five integers the reference's setup() holds
+ * for setHighpass(0, 500, 0.5), folded at compile time, come out of exactly this).  kind 0 LP, 1 HP, 2 BP, 3 notch */
 void orc_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5) {
-  const double w0 = frequency * (2.0f * 3.141592654f / fs);
+  const double w0 = (double)frequency * (2.0 * 3.141592654 / (double)fs);
   const double sinW0 = sin(w0);
   const double alpha = sinW0 / ((double)q * 2.0);
   const double cosW0 = cos(w0);

@@ -5,13 +5,15 @@
  * check in __graft_entry__.py and the cpu_baseline leg of bench.py may load
  * it.  The product path (radiodsp_sdr_rx_amd/) never links or calls it.
  *
- * PARITY UNPINNED for all floating-point stages; pinned by reference-held data only where the
- * reference's shipped firmware image holds constant tables (the integer analysers' windows,
- * twiddles and square-root table; sample rate, NLMS epsilon, design constants: see the .c header
- * and tests/test_firmware_tables.py).  The reference (gcallipo/RadioDSP_SDR_RX, an Arduino/Teensy
- * sketch) ships no tests, golden vectors or fixtures, and cannot be compiled
- * here (needs the Arduino core, Teensy Audio library, CMSIS-DSP and the
- * AudioSDR library, none of them vendored or pinned).  This file is therefore
+ * PARITY PINNED on the reference's own compiled code for the stages its shipped build contains (the CONV
+ * stage with its NLMS, the filter design, both integer analysers, AudioFilterBiquad, the CMSIS routines under
+ * them: known answers made by running the firmware image's routines under an instruction-set interpreter,
+ * tests/golden/firmware_kat.npz, tests/test_firmware_kat.py) and on its constant tables
+ * (tests/test_firmware_tables.py); PARITY UNPINNED for the stages that are not in that build or not in the
+ * tree (decimator, spectral stage, the AudioSDR engine's NCO / ALS / AGC): see the .c header.  The reference
+ * (gcallipo/RadioDSP_SDR_RX, an Arduino/Teensy sketch) ships no tests, golden vectors or fixtures, and cannot
+ * be compiled here (needs the Arduino core, Teensy Audio library, CMSIS-DSP and the AudioSDR library, none of
+ * them vendored or pinned).  This file is therefore
  * a plain-C restatement of the in-tree algorithm, following the reference
  * line by line where the code exists:
  *
@@ -25,7 +27,8 @@
  * decimator, demodulator selection, LMS auto-notch (ALS filter), AGC.
  * CMSIS-DSP primitives are restated from their published definitions
  * (arm_q15_to_float, arm_float_to_q15, arm_cfft_f32, arm_cmplx_mult_cmplx_f32,
- * arm_cmplx_mag_f32, arm_lms_norm_f32); bit parity with CMSIS is not claimed.
+ * arm_cmplx_mag_f32, arm_lms_norm_f32); bit parity with the image's CMSIS holds for all of them but the float
+ * FFT (1.2e-7) and arm_cmplx_mag_f32 (not in the image).
  * It is anchored by analytic known-answer tests (tests/test_oracle_*.py) and
  * by an independent float64 NumPy model (tests/np_model.py).
  */

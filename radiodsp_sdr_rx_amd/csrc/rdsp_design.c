@@ -251,12 +251,13 @@ void rdsp_biquad_design(int kind, double freq, double q, double fs, float *coef5
  * double; the float coefficients are what the kernel and the state read-back use. */
 #include <complex.h>
 /* AudioFilterBiquad::setLowpass / setHighpass / setBandpass / setNotch of the Teensy Audio library (filter_biquad.h) as
- * published: the RBJ cookbook in double with the angle from a FLOAT product, `frequency * (2.0f * 3.141592654f /
- * AUDIO_SAMPLE_RATE_EXACT)` (that constant is in the reference's firmware image, for 44100.0f), every coefficient
+ * published: the RBJ cookbook in double, the angle `frequency * (2 * 3.141592654 / AUDIO_SAMPLE_RATE_EXACT)` in DOUBLE too
+ * (the reference's setup() holds `setHighpass(0, 500, 0.5)` folded to five integer literals: only the all-double
+ * evaluation reproduces them, a float angle is 8 ... 16 counts off; tests/test_firmware_tables.py), every coefficient
  * times 2^30 / (1 + alpha) and converted to int.  coef5 = {b0, b1, b2, a1, a2} as the library hands them to
  * setCoefficients(stage, const int *).  kind 0 LP, 1 HP, 2 BP, 3 notch. */
 void rdsp_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5) {
-  const double w0 = frequency * (2.0f * 3.141592654f / fs);
+  const double w0 = (double)frequency * (2.0 * 3.141592654 / (double)fs);
   const double sinW0 = sin(w0);
   const double alpha = sinW0 / ((double)q * 2.0);
   const double cosW0 = cos(w0);

@@ -42,7 +42,6 @@ OUT = os.path.join(HERE, "firmware_kat.npz")
 F32, I16 = np.float32, np.int16
 
 # ITCM addresses of the routines (this image only: its SHA-256 is checked below)
-IMAGE_SHA256_16 = None          # filled in on first run and asserted afterwards (see main)
 A = dict(cfft_q15_init=0x12584, cfft_q15=0x12548, lms_init=0x1262c, lms=0x12668, df1_init=0x128b0, df1=0x128cc,
          q15_to_float=0x116ac, float_to_q15=0x1174c, cfft_f32=0x11f68, cmplx_mult=0x12a64,
          Init_LMS_NR=0x6b74, LMS_NoiseReduction=0x6c0c, calc_cplx_FIR_coeffs=0x6ce0, init_filter_mask=0x6c68,
@@ -93,6 +92,9 @@ class Ref:
 
     def call(self, name, *args, **kw):
         return self.cpu.call(A[name], list(args), **kw)
+
+    def call_addr(self, addr, *args, **kw):
+        return self.cpu.call(addr, list(args), **kw)
 
 
 # ---- CMSIS leaf routines -------------------------------------------------------------------------------------------------
@@ -266,7 +268,7 @@ def kat_design(im, out):
 def kat_conv(im, out):
     """doConvolutionalProcessing block by block on one stream each:
        conv_plain   nr 0                              32 blocks  (A1 unpack, A5 overlap-save filter, A10 pack)
-       conv_nr15    nr 15 (the sketch's start-up)     48 blocks  (+ A8 NLMS noise reduction, x 1.1, L copied to R)
+       conv_nr15    nr 15 (the sketch's start-up)     48 blocks  (+ A7 NLMS noise reduction, x 1.1, L copied to R)
        conv_nrstep  nr 15 -> 30 after 16 blocks       32 blocks  (Init_LMS_NR in mid-stream: state cleared, taps kept)
        conv_pbt     nr 0, reInitializeFilter(450, 2700) after 12 blocks, 24 blocks
        conv_nofilt  bFilterEnabled false              12 blocks  (CONV:303 copies FFT_length floats = half the spectrum)"""
@@ -366,8 +368,9 @@ def kat_fft1024(im, out, tables):
 
 
 def teensy_biquad_ints(kind, frequency, q, fs=44100.0):
-    """filter_biquad.h's setters as published (float angle product, double cookbook, x 2^30, int conversion)"""
-    w0 = float(F32(frequency) * (F32(2.0) * F32(3.141592654) / F32(fs)))
+    """filter_biquad.h's setters as published (all in double, x 2^30, int conversion): gives the five integers the image's
+    setup() holds for setHighpass(0, 500, 0.5)"""
+    w0 = float(F32(frequency)) * (2.0 * 3.141592654 / fs)
     sw, cw = np.sin(w0), np.cos(w0)
     alpha = sw / (float(F32(q)) * 2.0)
     scale = 1073741824.0 / (1.0 + alpha)
@@ -413,6 +416,48 @@ def kat_teensy_biquad(im, out):
         out[f"tbq_{tag}_out"] = np.concatenate(sent)
 
 
+class _Stop(Exception):
+    pass
+
+
+def kat_setup(im, out, tables):
+    """What the sketch's setup() (INO:140-183, ITCM 0x8f28) hands to the objects of the panadapter branch: the function is
+    run with every routine it calls replaced by a no-op, except that AudioFilterBiquad::setCoefficients records its
+    arguments -- `biquad1.setHighpass(0, 500, 0.5)` / `biquad2...` (INO:155-156) are inlined and folded to five integer
+    literals at compile time -- and that the run ends at the second of them.  By then `FFT.windowFunction(
+    AudioWindowHanning256); FFT.averageTogether(30)` (INO:144-145) and `AudioFFT.windowFunction(AudioWindowHanning1024)`
+    (INO:147) have written into their objects."""
+    r = Ref(im)
+    start, stop = 0x8f28, 0x904c
+    code = im.img[im.itcm_off:im.itcm_off + im.etext]
+    for o in range(start, stop, 2):
+        hw1, hw2 = struct.unpack_from("<HH", code, o)
+        if (hw1 & 0xF800) == 0xF000 and (hw2 & 0xD000) == 0xD000:
+            s, j1, j2 = (hw1 >> 10) & 1, (hw2 >> 13) & 1, (hw2 >> 11) & 1
+            imm = (s << 24) | ((1 - (j1 ^ s)) << 23) | ((1 - (j2 ^ s)) << 22) | ((hw1 & 0x3FF) << 12) | ((hw2 & 0x7FF) << 1)
+            if imm & (1 << 24):
+                imm -= 1 << 25
+            r.cpu.hooks[o + 4 + imm] = lambda c: c.r.__setitem__(0, 0)
+    got = []
+
+    def set_coefficients(c):
+        got.append((c.r[0], c.r[1], r.get(c.r[2], 5, np.int32)))
+        if len(got) == 2:
+            raise _Stop
+    r.cpu.hooks[A["biquad_setCoefficients"]] = set_coefficients
+    try:
+        r.call_addr(start)
+    except _Stop:
+        pass
+    assert len(got) == 2 and got[0][1] == 0 and got[1][1] == 0 and got[0][0] != got[1][0]
+    out["setup_sethighpass_500_05"] = np.stack([g[2] for g in got])
+    fft, afft = 0x200167c8, 0x2001ad70                                 # the objects FFT and AudioFFT (literal pool of setup())
+    out["setup_fft_naverage"] = np.int64(r.m.read(fft + 2597, 1))
+    assert r.m.read(fft + 536, 4) == im.dtcm_of_offset(TABLES["hann256"][0])
+    assert r.m.read(afft + 1048, 4) == im.dtcm_of_offset(TABLES["hann1024"][0])
+    out["setup_windows"] = np.array(["hann256", "hann1024"])
+
+
 def main():
     if not os.path.exists(HEX):
         sys.exit("the reference tree is not here: this script runs in the build container only")
@@ -425,7 +470,7 @@ def main():
                     ("df1", lambda: kat_df1(im, out, tables["biquad_sets"])), ("converters", lambda: kat_converters(im, out)),
                     ("cfft_f32", lambda: kat_cfft_f32(im, out)), ("design", lambda: kat_design(im, out)), ("conv", lambda: kat_conv(im, out)),
                     ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
-                    ("teensy_biquad", lambda: kat_teensy_biquad(im, out))):
+                    ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables))):
         t = time.time()
         f()
         print("%-14s %.1f s" % (name, time.time() - t), flush=True)

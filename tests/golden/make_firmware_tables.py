@@ -227,11 +227,6 @@ def main():
     out["code_vfp_offsets"], out["code_vfp_names"] = vfp_f32_classes(img)
     out["code_pack_offsets"], out["code_pack_names"] = pack_routine_classes(img)
     out["code_fixbq_offsets"], out["code_fixbq_names"] = fixed_biquad_classes(img)
-    # AudioFilterBiquad's setters: `2 * 3.141592654f / AUDIO_SAMPLE_RATE_EXACT` folded to one float literal
-    two_pi_fs = np.float32(np.float32(2.0) * np.float32(3.141592654) / np.float32(44100.0))
-    lit = np.frombuffer(img[:len(img) // 4 * 4], dtype="<f4")
-    out["two_pi_over_fs_offsets"] = (4 * np.nonzero(lit == two_pi_fs)[0]).astype(np.int64)
-    out["two_pi_over_fs"] = np.array([two_pi_fs], np.float32)
     # what the image does NOT hold: CMSIS' sinTable_f32 (513 entries, arm_sin_f32 / arm_cos_f32 of SPEC:229-232) -- at any
     # 2-byte alignment; the only sine table is the engine's 257-entry oscillator table above
     s513 = np.sin(2 * np.pi * np.arange(1, 4) / 512).astype(np.float32)

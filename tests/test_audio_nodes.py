@@ -289,7 +289,7 @@ def test_teensy_biquad_restatement_known_answers(rdsp, oracle):
     mine = np.zeros(5, np.int32)
     plib.rdsp_teensy_biquad_design(1, 500.0, 0.5, 44100.0, mine.ctypes.data_as(C.POINTER(C.c_int32)))
     assert np.array_equal(mine, c5)
-    w0 = float(np.float32(500.0) * (np.float32(2.0) * np.float32(3.141592654) / np.float32(44100.0)))
+    w0 = 500.0 * (2.0 * 3.141592654 / 44100.0)
     alpha, cw = np.sin(w0) / (2 * 0.5), np.cos(w0)
     want = np.array([(1 + cw) / 2, -(1 + cw), (1 + cw) / 2, -2 * cw, 1 - alpha]) / (1 + alpha) * 2 ** 30
     assert np.abs(c5 - np.trunc(want)).max() <= 1

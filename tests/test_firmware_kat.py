@@ -182,7 +182,7 @@ def test_oracle_conv_stage_against_the_images_doConvolutionalProcessing(kat, ora
     """The CONV stage exactly as the sketch runs it (INO:172-198: Init_LMS_NR(15), doConvolutionalInitialize,
     reInitializeFilter(300, 4000), then doConvolutionalProcessing once per 128-sample block), executed from the image:
     plain (A1 unpack, A5 overlap-save filter from the zero-filled first block on, A10 pack), with the NLMS noise
-    reduction (A8; x 1.1, L copied to R), a noise-reduction level change in mid-stream (NR:35-64 clears the state and
+    reduction (A7; x 1.1, L copied to R), a noise-reduction level change in mid-stream (NR:35-64 clears the state and
     keeps the taps), a pass-band change in mid-stream, and the filter-off branch as written (CONV:303 copies half the
     spectrum).  The oracle's float output, taken where the sketch hands it to arm_float_to_q15, is within 1e-5 normwise
     (measured: see CONV_RUNS); its int16 output differs by at most one count on a fraction of a percent of the samples."""
@@ -238,6 +238,10 @@ def test_oracle_teensy_biquad_is_the_images_update_bit_for_bit(kat, oracle, rdsp
             c5 = np.ascontiguousarray(kat[f"tbq_{tag}_coefs"][st], np.int32)
             lib.orc_teensy_biquad_setCoefficients_int(C.byref(o.o), int(st), p(c5, I32P))
         assert np.array_equal(o.update(x), kat[f"tbq_{tag}_out"]), tag
+    # what the sketch's own setup() hands over for `biquadN.setHighpass(0, 500, 0.5)` (INO:155-156; folded to integer
+    # literals at compile time, recorded by running setup() up to there): exactly what the design routines return
+    assert np.array_equal(kat["setup_sethighpass_500_05"][0], kat["setup_sethighpass_500_05"][1])
+    assert np.array_equal(kat["setup_sethighpass_500_05"][0], kat["tbq_hp_coefs"][0]) and int(kat["setup_fft_naverage"]) == 30
     assert not kat["tbq_fresh_out"].any() and np.abs(kat["tbq_hp_out"].astype(int)).max() >= 32767
     plib = rdsp.load()
     plib.rdsp_teensy_biquad_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, I32P]

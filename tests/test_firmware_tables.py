@@ -387,17 +387,15 @@ def test_audio_filter_biquad_of_the_image_is_the_fixed_point_routine(fw, oracle)
     """INO:59-60,155-156 use the Teensy library's AudioFilterBiquad, whose source is not in the reference tree; the image
     holds its update(): two samples per loop turn, each five 32 x 16 multiply-accumulates that keep the top 32 of the 48
     product bits -- bottom / top halves alternating B T B T B, then T B T B T --, `SSAT #16, ASR #14`, the residue kept
-    with `UBFX #0, #14`, the two outputs packed with PKHBT; and the setters' `2 * 3.141592654f / AUDIO_SAMPLE_RATE_EXACT`
-    folded to one float literal.  The oracle's one-sample-per-turn restatement is checked against a model that does
-    literally what these instructions do, on packed pairs, rails included."""
+    with `UBFX #0, #14`, the two outputs packed with PKHBT.  (Run instead of read: tests/test_firmware_kat.py.)  The
+    oracle's one-sample-per-turn restatement is checked against a model that does literally what these instructions
+    do, on packed pairs, rails included."""
     names = [str(n) for n in fw["code_fixbq_names"]]
     assert names == (["UBFX #0 #14"] + ["SMLAWB", "SMLAWT", "SMLAWB", "SMLAWT", "SMLAWB"] + ["SSAT #16 ASR #14", "UBFX #0 #14"]
                      + ["SMLAWT", "SMLAWB", "SMLAWT", "SMLAWB", "SMLAWT"] + ["SSAT #16 ASR #14", "PKHBT", "UBFX #0 #14"])
-    assert len(fw["two_pi_over_fs_offsets"]) >= 1
     # and what the image does not hold: CMSIS' 513-entry sinTable_f32 -- src/backup/ (the spectral stage, SPEC:229-232) is
     # "not for normal compilation", so its arm_sin_f32 / arm_cos_f32 are not linked; that row stays unpinned
     assert int(fw["cmsis_sin513_occurrences"]) == 0
-    assert fw["two_pi_over_fs"][0] == np.float32(2.0) * np.float32(3.141592654) / fw["sample_rate"][0].astype(np.float32)
 
     def s32(v):
         v &= 0xFFFFFFFF
