@@ -271,15 +271,25 @@ def kat_conv(im, out):
        conv_nr15    nr 15 (the sketch's start-up)     48 blocks  (+ A7 NLMS noise reduction, x 1.1, L copied to R)
        conv_nrstep  nr 15 -> 30 after 16 blocks       32 blocks  (Init_LMS_NR in mid-stream: state cleared, taps kept)
        conv_pbt     nr 0, reInitializeFilter(450, 2700) after 12 blocks, 24 blocks
-       conv_nofilt  bFilterEnabled false              12 blocks  (CONV:303 copies FFT_length floats = half the spectrum)"""
+       conv_nofilt  bFilterEnabled false              12 blocks  (CONV:303 copies FFT_length floats = half the spectrum)
+       conv_loud    nr 15, input at 3.2 x the level    16 blocks  (rails at the input, arm_float_to_q15 saturating at the output)
+    and the number of instructions the image executes per block (plain / with the NLMS) -- what the reference's own
+    processor has to get through in the 2.9 ms a block lasts"""
     t0 = time.time()
     iq = synth_iq(48 * 128, 7)
     s = Sketch(im); s.setup()
+    c0 = s.cpu.count
     o16, o32 = s.process(iq[:32 * 128], 0.0)
-    out.update(conv_iq=iq, conv_plain_o16=o16, conv_plain_o32=o32)
+    out.update(conv_iq=iq, conv_plain_o16=o16, conv_plain_o32=o32, conv_plain_instructions_per_block=np.int64((s.cpu.count - c0) // 32))
     s = Sketch(im); s.setup()
+    c0 = s.cpu.count
     o16, o32 = s.process(iq, 15.0)
-    out.update(conv_nr15_o16=o16, conv_nr15_o32=o32, conv_nr15_coeffs=s.get(G["lms_coeffs"], 96, F32))
+    out.update(conv_nr15_o16=o16, conv_nr15_o32=o32, conv_nr15_coeffs=s.get(G["lms_coeffs"], 96, F32),
+               conv_nr15_instructions_per_block=np.int64((s.cpu.count - c0) // 48))
+    loud = np.clip(np.round(iq[:16 * 128].astype(np.float64) * 3.2), -32768, 32767).astype(I16)
+    s = Sketch(im); s.setup()
+    o16, o32 = s.process(loud, 15.0)
+    out.update(conv_loud_iq=loud, conv_loud_o16=o16, conv_loud_o32=o32)
     s = Sketch(im); s.setup()
     a16, a32 = s.process(iq[:16 * 128], 15.0)
     b16, b32 = s.process(iq[16 * 128:32 * 128], 30.0)

@@ -31,6 +31,11 @@ def kat():
     return k
 
 
+def test_fixture_records_what_the_references_processor_executes_per_block(kat):
+    """instructions the interpreter counted through doConvolutionalProcessing per 128-sample block"""
+    assert int(kat["conv_plain_instructions_per_block"]) == 52483 and int(kat["conv_nr15_instructions_per_block"]) == 194325
+
+
 def nrm(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
@@ -155,6 +160,8 @@ def _oracle_conv(oracle, kat, tag):
         return OracleChain(**CONV_LITERAL).process(iq[:32 * 128])
     if tag == "nr15":
         return OracleChain(**dict(CONV_LITERAL, lms_nr=15)).process(iq)
+    if tag == "loud":
+        return OracleChain(**dict(CONV_LITERAL, lms_nr=15)).process(kat["conv_loud_iq"])
     if tag == "nrstep":
         c = OracleChain(**dict(CONV_LITERAL, lms_nr=15))
         a = c.process(iq[:16 * 128])
@@ -174,7 +181,12 @@ def _oracle_conv(oracle, kat, tag):
 
 
 # measured when the fixture was made (oracle against the image's code): float normwise, int16 samples one count apart
-CONV_RUNS = {"plain": (1.6e-7, 9), "nr15": (1.5e-6, 48), "nrstep": (2.0e-6, 56), "pbt": (1.6e-7, 2), "nofilt": (1.7e-7, 2)}
+# "loud": the NLMS starts on a clipped signal with next to nothing in its energy term, and the first block amplifies the
+# 1e-7 the two float FFTs differ by to 2.5e-5 of that block (1e-6 from the third block on; against the float64 model the
+# image's own first block sits at 5.8e-6, the oracle's at 2.8e-5 -- in the "nr15" run it is the other way round: 1.4e-6 and
+# 5e-7): six samples there are two counts apart
+CONV_RUNS = {"plain": (1.6e-7, 9, 1), "nr15": (1.5e-6, 48, 1), "nrstep": (2.0e-6, 56, 1), "pbt": (1.6e-7, 2, 1), "nofilt": (1.7e-7, 2, 1),
+             "loud": (4.8e-6, 40, 2)}
 
 
 @pytest.mark.parametrize("tag", list(CONV_RUNS))
@@ -183,8 +195,8 @@ def test_oracle_conv_stage_against_the_images_doConvolutionalProcessing(kat, ora
     reInitializeFilter(300, 4000), then doConvolutionalProcessing once per 128-sample block), executed from the image:
     plain (A1 unpack, A5 overlap-save filter from the zero-filled first block on, A10 pack), with the NLMS noise
     reduction (A7; x 1.1, L copied to R), a noise-reduction level change in mid-stream (NR:35-64 clears the state and
-    keeps the taps), a pass-band change in mid-stream, and the filter-off branch as written (CONV:303 copies half the
-    spectrum).  The oracle's float output, taken where the sketch hands it to arm_float_to_q15, is within 1e-5 normwise
+    keeps the taps), a pass-band change in mid-stream, the filter-off branch as written (CONV:303 copies half the
+    spectrum), and a stream 3.2 times as loud (input on the rails, arm_float_to_q15 saturating 592 output samples).  The oracle's float output, taken where the sketch hands it to arm_float_to_q15, is within 1e-5 normwise
     (measured: see CONV_RUNS); its int16 output differs by at most one count on a fraction of a percent of the samples."""
     o16, o32 = _oracle_conv(oracle, kat, tag)
     r16, r32 = kat[f"conv_{tag}_o16"], kat[f"conv_{tag}_o32"]
@@ -192,8 +204,8 @@ def test_oracle_conv_stage_against_the_images_doConvolutionalProcessing(kat, ora
     e = nrm(o32, r32)
     d = np.abs(o16.astype(np.int32) - r16)
     print(f"{tag}: float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
-    assert e <= TOL and e <= 4 * CONV_RUNS[tag][0]
-    assert d.max() <= 1 and (d > 0).sum() <= max(4 * CONV_RUNS[tag][1], 16)
+    assert e <= TOL and e <= (4 if CONV_RUNS[tag][2] == 1 else 2) * CONV_RUNS[tag][0]
+    assert d.max() <= CONV_RUNS[tag][2] and (d > 0).sum() <= max(4 * CONV_RUNS[tag][1], 16) and (d > 1).sum() <= 8
     if tag == "nr15":
         from oracle_lib import OracleChain
         c = OracleChain(**dict(CONV_LITERAL, lms_nr=15))
@@ -278,6 +290,8 @@ def _gpu_conv(torch, kat, tag, named):
         return run(Chain(NCH, max_blocks_per_call=32, **CONV_LITERAL), iq[:32 * 128])
     if tag == "nr15":
         return run(Chain(NCH, max_blocks_per_call=48, **dict(CONV_LITERAL, lms_nr=15)), iq, 15.0)
+    if tag == "loud":
+        return run(Chain(NCH, max_blocks_per_call=16, **dict(CONV_LITERAL, lms_nr=15)), kat["conv_loud_iq"], 15.0)
     if tag == "nrstep":
         ch = Chain(NCH, max_blocks_per_call=16, **dict(CONV_LITERAL, lms_nr=15))
         a = run(ch, iq[:16 * 128], 15.0)
@@ -291,7 +305,7 @@ def _gpu_conv(torch, kat, tag, named):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["plain", "nr15", "nrstep", "pbt"])
+@pytest.mark.parametrize("tag", ["plain", "nr15", "nrstep", "pbt", "loud"])
 def test_gpu_conv_stage_against_the_images_doConvolutionalProcessing(rdsp, kat, tag):
     """The product (HIP kernels through the C-ABI, CONV configuration at its native rate) against what the reference's
     compiled doConvolutionalProcessing wrote for the same IQ blocks: float output within 1e-5 normwise on every channel,
@@ -306,7 +320,7 @@ def test_gpu_conv_stage_against_the_images_doConvolutionalProcessing(rdsp, kat, 
         d = np.abs(o16[c].astype(np.int32) - r16)
         print(f"{tag} ch{c}: float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
         assert e <= TOL, (tag, c, e)
-        assert d.max() <= 1 and (d > 0).sum() <= max(8 * CONV_RUNS[tag][1], 32)
+        assert d.max() <= CONV_RUNS[tag][2] and (d > 0).sum() <= max(8 * CONV_RUNS[tag][1], 32) and (d > 1).sum() <= 16
 
 
 @pytest.mark.gpu
