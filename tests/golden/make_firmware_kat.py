@@ -273,6 +273,7 @@ def kat_conv(im, out):
        conv_pbt     nr 0, reInitializeFilter(450, 2700) after 12 blocks, 24 blocks
        conv_nofilt  bFilterEnabled false              12 blocks  (CONV:303 copies FFT_length floats = half the spectrum)
        conv_loud    nr 15, input at 3.2 x the level    16 blocks  (rails at the input, arm_float_to_q15 saturating at the output)
+       conv_fade    nr 15, 12 blocks at 2.5 x, then 28 blocks 48 dB down (arm_lms_norm_f32's running energy after a loud passage)
     and the number of instructions the image executes per block (plain / with the NLMS) -- what the reference's own
     processor has to get through in the 2.9 ms a block lasts"""
     t0 = time.time()
@@ -290,6 +291,11 @@ def kat_conv(im, out):
     s = Sketch(im); s.setup()
     o16, o32 = s.process(loud, 15.0)
     out.update(conv_loud_iq=loud, conv_loud_o16=o16, conv_loud_o32=o32)
+    g = np.where(np.arange(40 * 128) < 12 * 128, 2.5, 0.01)[:, None]
+    fade = np.clip(np.round(iq[:40 * 128].astype(np.float64) * g), -32768, 32767).astype(I16)
+    s = Sketch(im); s.setup()
+    o16, o32 = s.process(fade, 15.0)
+    out.update(conv_fade_iq=fade, conv_fade_o16=o16, conv_fade_o32=o32, conv_fade_energy_x0=s.get(G["lms_instance"] + 16, 2, F32))
     s = Sketch(im); s.setup()
     a16, a32 = s.process(iq[:16 * 128], 15.0)
     b16, b32 = s.process(iq[16 * 128:32 * 128], 30.0)

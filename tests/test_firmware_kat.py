@@ -213,6 +213,32 @@ def test_oracle_conv_stage_against_the_images_doConvolutionalProcessing(kat, ora
         assert nrm(c.lms_coeffs(0), kat["conv_nr15_coeffs"]) < 1e-4      # the 96 taps after 48 blocks (measured 1.1e-5)
 
 
+def _fade_errors(x32, kat):
+    """(loud part against the image, quiet part against the float64 model, the image's own quiet part against the model)"""
+    from parity_util import model_run
+    f64 = model_run(kat["conv_fade_iq"][None], dict(CONV_LITERAL, lms_nr=15))[0]
+    r32 = kat["conv_fade_o32"]
+    loud, quiet = slice(0, 12 * 128), slice(13 * 128, 40 * 128)
+    return nrm(x32[loud], r32[loud]), nrm(x32[quiet], f64[quiet]), nrm(r32[quiet], f64[quiet])
+
+
+def test_conv_stage_after_a_loud_passage_the_reference_itself_is_the_loose_one(kat, oracle):
+    """12 blocks at 2.5 x the level, then 28 blocks 48 dB down, NLMS on.  arm_lms_norm_f32 keeps its energy term as a
+    running difference (energy -= x0^2; energy += in^2): after the loud passage what is left in it is the rounding
+    residue of numbers 10^5 times larger, of the order of the quiet signal's own energy, and the step size follows it.
+    The image's output there is 3e-3 of the quiet part away from the float64 evaluation of the same formulas (1.7 % in
+    the block after the ringing has died down), and WHERE it lands depends on the last bits of its input: the oracle,
+    whose arm_lms_norm_f32 is the image's bit for bit but whose FFT rounds differently by 1e-7, lands 3e-4 from the
+    float64 result and 2.9e-3 from the image.  So this stream cannot be a 1e-5 comparison with anybody; what can be
+    asked is that nobody is further from the exact result than the reference itself, and that the loud part (where the
+    arithmetic is well conditioned) still agrees to 1e-5."""
+    from oracle_lib import OracleChain
+    o16, o32 = OracleChain(**dict(CONV_LITERAL, lms_nr=15)).process(kat["conv_fade_iq"])
+    loud, quiet, ref_quiet = _fade_errors(o32, kat)
+    print(f"fade: loud part oracle vs image {loud:.2e}; quiet part vs float64: oracle {quiet:.2e}, the image {ref_quiet:.2e}")
+    assert loud <= TOL and 1e-3 < ref_quiet < 1e-2 and quiet <= 1.5 * ref_quiet
+
+
 def test_oracle_analysers_are_the_images_update_bit_for_bit(kat, oracle):
     """AudioAnalyzeFFT256IQ::update (FFTIQ.cpp:38-118) and AudioAnalyzeFFT1024::update, whole: block pairing, window,
     transform, |X|^2, averaging, sqrt_uint32_approx, output order and the tick on which the flag comes up -- with the
@@ -321,6 +347,28 @@ def test_gpu_conv_stage_against_the_images_doConvolutionalProcessing(rdsp, kat, 
         print(f"{tag} ch{c}: float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
         assert e <= TOL, (tag, c, e)
         assert d.max() <= CONV_RUNS[tag][2] and (d > 0).sum() <= max(8 * CONV_RUNS[tag][1], 32) and (d > 1).sum() <= 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("running", [False, True])
+def test_gpu_conv_stage_after_a_loud_passage(rdsp, kat, running):
+    """the loud-then-quiet stream (see the CPU test of the same name): the product's default NLMS re-anchors its energy
+    term on the exact sum once per block and is closer to the float64 result than the reference's own output is; with
+    rdsp_set_nlms_energy_mode(chain, 1) it keeps NR:73's running difference and shares its conditioning"""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import Chain
+    iq = kat["conv_fade_iq"]
+    ch = Chain(NCH, max_blocks_per_call=40, **dict(CONV_LITERAL, lms_nr=15))
+    if running:
+        ch.set_nlms_energy_mode(True)
+    a, b = ch.process(torch.from_numpy(np.ascontiguousarray(np.broadcast_to(iq, (NCH,) + iq.shape))).cuda(), want_f32=True)
+    torch.cuda.synchronize()
+    b = b.cpu().numpy()
+    for c in range(NCH):
+        loud, quiet, ref_quiet = _fade_errors(b[c], kat)
+        print(f"fade ch{c} running={running}: loud part vs image {loud:.2e}; quiet part vs float64: GPU {quiet:.2e}, the image {ref_quiet:.2e}")
+        assert loud <= TOL
+        assert quiet <= (3.0 if running else 0.2) * ref_quiet
 
 
 @pytest.mark.gpu
