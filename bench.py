@@ -787,6 +787,16 @@ def main():
             except Exception as e:  # the baseline is a reported number, never the target
                 res["cpu_baseline"] = {"value": None, "unit": "IQ Msamples/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+            try:   # for scale only: what the reference's own processor executes (counted by the interpreter that made the fixture)
+                kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "firmware_kat.npz"))
+                res["cpu_baseline"]["reference_on_its_own_hardware"] = {
+                    "instructions_per_128_sample_block": {"conv_stage": int(kat["conv_plain_instructions_per_block"]),
+                                                          "conv_stage_with_nlms": int(kat["conv_nr15_instructions_per_block"])},
+                    "note": "the firmware image's doConvolutionalProcessing (one receiver, no decimation / demodulation / AGC: "
+                            "the CONV stage only) counted under tests/golden/thumb_emu.py; a 600 MHz Cortex-M7 issues at most "
+                            "two per cycle; not a timing, not comparable with `value`"}
+            except Exception:
+                pass
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
