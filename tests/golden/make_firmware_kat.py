@@ -265,6 +265,24 @@ def kat_design(im, out):
     out["init_lms_nr_mu"] = np.array(mus, F32)
 
 
+def kat_lms_noise_reduction(im, out):
+    """Init_LMS_NR(20) + LMS_NoiseReduction(128, buffer) (NR:35-80: the 256-float delay ring around arm_lms_norm_f32) on 24
+    float blocks -- row A7 by itself, no transform in front of it"""
+    rng = np.random.default_rng(106)
+    s = Sketch(im)
+    s.call("Init_LMS_NR", 20)
+    n = 24 * 128
+    t = np.arange(n)
+    x = (0.2 * np.sin(2 * np.pi * 0.031 * t) + 0.1 * np.sin(2 * np.pi * 0.113 * t + 1.0) + 0.05 * rng.standard_normal(n)).astype(F32)
+    buf = s.alloc(512)
+    ys = []
+    for b in range(24):
+        s.put(buf, x[b * 128:(b + 1) * 128])
+        s.call("LMS_NoiseReduction", 128, buf)
+        ys.append(s.get(buf, 128, F32))
+    out.update(lmsnr_strength=np.int64(20), lmsnr_in=x, lmsnr_out=np.concatenate(ys), lmsnr_coeffs=s.get(G["lms_coeffs"], 96, F32))
+
+
 def kat_conv(im, out):
     """doConvolutionalProcessing block by block on one stream each:
        conv_plain   nr 0                              32 blocks  (A1 unpack, A5 overlap-save filter, A10 pack)
@@ -484,7 +502,8 @@ def main():
     t0 = time.time()
     for name, f in (("cfft_q15", lambda: kat_cfft_q15(im, out)), ("lms_norm", lambda: kat_lms_norm(im, out)),
                     ("df1", lambda: kat_df1(im, out, tables["biquad_sets"])), ("converters", lambda: kat_converters(im, out)),
-                    ("cfft_f32", lambda: kat_cfft_f32(im, out)), ("design", lambda: kat_design(im, out)), ("conv", lambda: kat_conv(im, out)),
+                    ("cfft_f32", lambda: kat_cfft_f32(im, out)), ("design", lambda: kat_design(im, out)), ("lms_noise_reduction", lambda: kat_lms_noise_reduction(im, out)),
+                    ("conv", lambda: kat_conv(im, out)),
                     ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
                     ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables))):
         t = time.time()

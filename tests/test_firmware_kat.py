@@ -86,6 +86,24 @@ def test_oracle_lms_norm_is_the_images_bit_for_bit(kat, oracle):
         assert np.array_equal(co, kat["lms_coeffs"][b]) and np.array_equal(ex, kat["lms_energy_x0"][b])
 
 
+def test_oracle_lms_noise_reduction_is_the_images_bit_for_bit(kat, oracle):
+    """row A7 by itself: Init_LMS_NR(20) and 24 calls of LMS_NoiseReduction(128, buffer) (NR:35-80 -- the 256-float delay
+    ring, its first call, arm_lms_norm_f32) executed from the image on float blocks: the oracle's output and its 96 taps
+    afterwards are the same bits"""
+    from oracle_lib import OracleChain
+    lib = oracle.load()
+    oc = OracleChain(**CONV_LITERAL)
+    lib.orc_Init_LMS_NR(oc.h, int(kat["lmsnr_strength"]))
+    x = kat["lmsnr_in"]
+    got = []
+    for b in range(len(x) // 128):
+        blk = x[b * 128:(b + 1) * 128].copy()
+        lib.orc_LMS_NoiseReduction(oc.h, 128, p(blk))
+        got.append(blk)
+    assert np.array_equal(np.concatenate(got), kat["lmsnr_out"])
+    assert np.array_equal(oc.lms_coeffs(0), kat["lmsnr_coeffs"])
+
+
 def test_oracle_df1_cascade_is_the_images_bit_for_bit(kat, oracle):
     """arm_biquad_cascade_df1_f32 with the engine's own first coefficient set, two calls on one instance"""
     from test_audio_nodes import OrcBiquad
@@ -347,6 +365,33 @@ def test_gpu_conv_stage_against_the_images_doConvolutionalProcessing(rdsp, kat, 
         print(f"{tag} ch{c}: float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
         assert e <= TOL, (tag, c, e)
         assert d.max() <= CONV_RUNS[tag][2] and (d > 0).sum() <= max(8 * CONV_RUNS[tag][1], 32) and (d > 1).sum() <= 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("running", [False, True])
+def test_gpu_lms_noise_reduction_against_the_images(rdsp, kat, running):
+    """row A7 by itself on the GPU (rdsp_Init_LMS_NR + rdsp_LMS_NoiseReduction on the image's float blocks, in two
+    calls): the tail kernel sums its 96 products in a tree where arm_lms_norm_f32 sums them in order -- within 1e-5 of
+    the image's output, the taps within 2e-5, in both energy modes"""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import Chain
+    x = kat["lmsnr_in"]
+    ch = Chain(NCH, **CONV_LITERAL)
+    if running:
+        ch.set_nlms_energy_mode(True)
+    ch.Init_LMS_NR(int(kat["lmsnr_strength"]))
+    dev = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(x, (NCH,) + x.shape))).cuda()
+    a, b = dev[:, :10 * 128].contiguous(), dev[:, 10 * 128:].contiguous()
+    ch.LMS_NoiseReduction(a)
+    ch.LMS_NoiseReduction(b)
+    torch.cuda.synchronize()
+    got = np.concatenate([a.cpu().numpy(), b.cpu().numpy()], 1)
+    w = ch.lms_coeffs(0)
+    for c in range(NCH):
+        e = nrm(got[c], kat["lmsnr_out"])
+        ew = float(np.abs(w[c] - kat["lmsnr_coeffs"]).max() / np.abs(kat["lmsnr_coeffs"]).max())
+        print(f"LMS_NoiseReduction ch{c} running={running}: output {e:.2e}, taps {ew:.2e}")
+        assert e <= TOL and ew <= 2e-5
 
 
 @pytest.mark.gpu
