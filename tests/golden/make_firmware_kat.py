@@ -23,7 +23,9 @@ The AudioStream plumbing the update() methods call (receiveReadOnly / receiveWri
 record / play queues of doConvolutionalProcessing are replaced by hooks that hand over our buffers; everything else
 -- newlib's powf / sin / cos included -- is the image's code.
 
-Build container only: needs /root/reference.  Run: python tests/golden/make_firmware_kat.py
+Build container only: needs /root/reference.  Run: python tests/golden/make_firmware_kat.py            (writes the fixture)
+                                                      python tests/golden/make_firmware_kat.py --check    (recomputes everything
+and compares with the committed fixture array by array; exit status 1 on any difference)
 """
 import hashlib
 import os
@@ -509,6 +511,12 @@ def main():
         t = time.time()
         f()
         print("%-14s %.1f s" % (name, time.time() - t), flush=True)
+    if "--check" in sys.argv[1:]:
+        have = np.load(OUT)
+        bad = [k for k in out if k not in have.files or not np.array_equal(np.asarray(out[k]), have[k])]
+        bad += [k for k in have.files if k not in out]
+        print("check against", OUT, ":", "identical (%d arrays)" % len(out) if not bad else "DIFFERENT: %s" % bad, "-- %.0f s" % (time.time() - t0))
+        sys.exit(1 if bad else 0)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes, %.0f s" % (time.time() - t0))
 
