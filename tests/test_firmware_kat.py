@@ -368,6 +368,27 @@ def test_gpu_conv_stage_against_the_images_doConvolutionalProcessing(rdsp, kat, 
 
 
 @pytest.mark.gpu
+def test_gpu_4096_channels_each_give_the_references_answer(rdsp, kat):
+    """K3's channel count, every channel fed the stream the image processed (NLMS on, 48 blocks in calls of 20 and 28):
+    every wave of every compute unit produces the same bits, and those are within 1e-5 of the reference's output"""
+    import torch
+    from radiodsp_sdr_rx_amd.chain import Chain
+    iq = kat["conv_iq"]
+    nch = 4096
+    dev = torch.from_numpy(iq).cuda().unsqueeze(0).expand(nch, -1, -1).contiguous()
+    ch = Chain(nch, max_blocks_per_call=28, **dict(CONV_LITERAL, lms_nr=15))
+    a16, a32 = ch.process(dev[:, :20 * 128].contiguous(), want_f32=True)
+    b16, b32 = ch.process(dev[:, 20 * 128:].contiguous(), want_f32=True)
+    torch.cuda.synchronize()
+    o16, o32 = torch.cat([a16, b16], 1), torch.cat([a32, b32], 1)
+    assert bool((o16 == o16[0:1]).all()) and bool((o32 == o32[0:1]).all())
+    e = nrm(o32[0].cpu().numpy(), kat["conv_nr15_o32"])
+    d = np.abs(o16[0].cpu().numpy().astype(np.int32) - kat["conv_nr15_o16"])
+    print(f"4096 channels: all identical; float {e:.2e}, int16 {int((d > 0).sum())} of {d.size} one count apart")
+    assert e <= TOL and d.max() <= 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("running", [False, True])
 def test_gpu_lms_noise_reduction_against_the_images(rdsp, kat, running):
     """row A7 by itself on the GPU (rdsp_Init_LMS_NR + rdsp_LMS_NoiseReduction on the image's float blocks, in two
