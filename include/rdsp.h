@@ -203,7 +203,14 @@ int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g);             /* INO:134 */
 int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g);          /* INO:135 */
 int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c);                  /* INO:137 */
 int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream); /* INO:138, CTL:153-177 */
-/* returns the tuning offset in Hz like the reference (INO:139, CTL:337-407).  The engine's modes pick
+/* returns the tuning offset in Hz like the reference (INO:139, CTL:337-407) -- the AudioSDR engine's own answers, read
+ * by running its constructor and setDemodMode out of the reference's firmware image (tests/test_firmware_kat.py): a low
+ * IF centred on 6890 Hz, the carrier half a band (SSB 3000 Hz, CW 1000 Hz) above it for the lower and below it for the
+ * upper side band: LSBmode 8390, USBmode 5390, CW_LSBmode 7390, CW_USBmode 6390, AMmode / SAMmode 6890 (RDSP_DEMOD_IQ,
+ * the literal CONV stage: 0).  The sketch puts its LO at vfoFreq - TuningOffset (CTL:447) and the engine moves the
+ * carrier from there to 0 Hz itself; in this library the mixer is a setting of its own, so a host that mirrors the
+ * sketch hands the returned value to rdsp_sdr_setTuningOffsetHz (tests/host/rdsp_binding.h does), and a host with many
+ * carriers in one recorded stream sets each group's mixer to where its carrier is.  The engine's modes pick
  * the side band the selected audio filter sits on, so the pass band is re-applied for the new mode
  * (USB/CW_USB: +a..+b, LSB/CW_LSB: -b..-a, AM/SAM: -b..+b of setAudioFilter's a..b); a later
  * rdsp_reInitializeFilter / PBT step overrides it, as RDSP_controls.h:569-612 does in the sketch. */

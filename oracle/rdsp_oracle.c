@@ -502,14 +502,17 @@ struct orc_chain {
 };
 
 uint32_t orc_demod_tuning_offset(int demod) {
-  /* build-defined (AudioSDR's values are not in the tree): SSB/AM tune to the
-   * carrier; CW modes place the carrier 700 Hz off so it is heard as a tone */
+  /* what AudioSDR::setDemodMode returns (INO:139): the engine is not in the tree but in the firmware image, and run
+   * there it answers IF centre 6890 Hz +- half the band (SSB 3000 Hz, CW 1000 Hz), AM / SAM at the centre
+   * (tests/golden/firmware_kat.npz `engine_tuning_offset`, tests/test_firmware_kat.py) */
   switch (demod) {
-    case ORC_DEMOD_CW_USB:
-    case ORC_DEMOD_CW_LSB:
-      return 700u;
-    default:
-      return 0u;
+    case ORC_DEMOD_LSB: return 8390u;
+    case ORC_DEMOD_USB: return 5390u;
+    case ORC_DEMOD_CW_LSB: return 7390u;
+    case ORC_DEMOD_CW_USB: return 6390u;
+    case ORC_DEMOD_AM:
+    case ORC_DEMOD_SAM: return 6890u;
+    default: return 0u;
   }
 }
 

@@ -200,9 +200,22 @@ static void agc_params(int mode, float *attack, float *decay) {
 }
 
 static uint32_t demod_tuning_offset(int demod) {
-  /* build-defined: CW modes put the carrier 700 Hz off, everything else tunes
-   * to the carrier (the AudioSDR values behind INO:139 are not in the tree) */
-  return (demod == RDSP_DEMOD_CW_USB || demod == RDSP_DEMOD_CW_LSB) ? 700u : 0u;
+  /* `TuningOffset = SDR.setDemodMode(mode)` (INO:139, CTL:337-407): where the engine wants the carrier in the IQ stream.
+   * AudioSDR is not in the tree, but it is in the reference's firmware image, and asked there (its constructor and
+   * setDemodMode run under tests/golden/thumb_emu.py; tests/golden/firmware_kat.npz `engine_tuning_offset`) it answers
+   * as a low-IF receiver: IF centre 6890 Hz, SSB band 3000 Hz, CW band 1000 Hz, the carrier at the centre plus (lower
+   * side band) or minus (upper side band) half the band; AM / SAM at the centre.  (Until round 5: 700 Hz for the CW
+   * modes and 0 otherwise, build-defined.)  The engine also oscillates at this frequency itself; here the mixer is a
+   * setting of its own (rdsp_*_setTuningOffsetHz), so a host that mirrors the sketch hands the value on. */
+  switch (demod) {
+    case RDSP_DEMOD_LSB: return 8390u;
+    case RDSP_DEMOD_USB: return 5390u;
+    case RDSP_DEMOD_CW_LSB: return 7390u;
+    case RDSP_DEMOD_CW_USB: return 6390u;
+    case RDSP_DEMOD_AM:
+    case RDSP_DEMOD_SAM: return 6890u;
+    default: return 0u; /* RDSP_DEMOD_IQ: the literal CONV stage, no engine in front */
+  }
 }
 
 /* ---- receiver groups: double-buffered masks, records rewritten in stream order ---- */

@@ -19,6 +19,7 @@ What is run (ITCM address; how it was identified):
   doConvolutionalProcessing 0x70d0                                CONV:127, :87, :187, :209, :228
   AudioAnalyzeFFT256IQ::update 0x9a20, AudioAnalyzeFFT1024::update 0xbb18, AudioFilterBiquad::update 0xc09c and
   ::setCoefficients 0xc17c                                        through the objects' vtables / the sketch's calls
+  AudioSDR's constructor 0x6744, ::setDemodMode 0xd798, ::setAudioFilter 0xd97c   INO:138-139, CTL:153-177,330-423 (answers only)
 The AudioStream plumbing the update() methods call (receiveReadOnly / receiveWritable / transmit / release) and the
 record / play queues of doConvolutionalProcessing are replaced by hooks that hand over our buffers; everything else
 -- newlib's powf / sin / cos included -- is the image's code.
@@ -452,6 +453,43 @@ def kat_teensy_biquad(im, out):
         out[f"tbq_{tag}_out"] = np.concatenate(sent)
 
 
+def kat_engine(im, out, tables):
+    """What the un-vendored AudioSDR engine answers to the two calls of the sketch's mode menu (CTL:330-423), asked of the
+    engine itself: its constructor (0x6744: AudioStream set-up, the defaults, fifteen coefficient sets copied into the
+    object) is run on zeroed memory, then
+      * setDemodMode(mode) (0xd798) for LSBmode ... SAMmode = 0 ... 5 (the numbers the compiled tuningMode() passes):
+        the TuningOffset it returns (INO:139, CTL:337-407) -- the engine is a low-IF receiver: centre 6890 Hz, SSB band
+        3000 Hz, CW band 1000 Hz (the floats at +32 / +36 / +40 of the object), carrier at centre +- half the band;
+      * setAudioFilter(k) (0xd97c) for k = 0 ... 9: which of the image's fifteen sets of four biquad sections
+        (firmware_tables.npz `biquad_sets`) it installs; the compiled filterMode() / tuningMode() pass audioAM = 0,
+        audioCW = 1, audio2100 = 3, audio2700 = 6, audio3100 = 8; and which sets setDemodMode installs in front of the
+        demodulator (the band-passes around the IF)."""
+    r = Ref(im)
+    sdr = 0x20017208                                                      # where the sketch's `SDR` object lives (.bss)
+    r.call_addr(0x6744, sdr)
+    sets = tables["biquad_sets"].reshape(15, 20)
+    out["engine_if_centre_ssb_cw"] = r.get(sdr + 32, 3, F32)
+    offs = []
+    for mode in range(6):
+        r.call_addr(0xd798, sdr, mode)
+        offs.append(r.cpu.fs(0))
+    out["engine_tuning_offset"] = np.array(offs, F32)
+    out["engine_demod_names"] = np.array(["LSBmode", "USBmode", "CW_LSBmode", "CW_USBmode", "AMmode", "SAMmode"])
+
+    def which(off):
+        a = r.get(sdr + off, 20, F32)
+        hit = [i for i in range(15) if np.array_equal(a, sets[i])]
+        assert len(hit) == 1
+        return hit[0]
+    aud = {0: 0x24d8, 1: 0x2528, 2: 0x2578, 3: 0x22a8, 4: 0x22f8, 5: 0x2348, 6: 0x2398, 7: 0x23e8, 8: 0x2438, 9: 0x2488}   # setAudioFilter's own switch
+    out["engine_audio_filter_set"] = np.array([which(aud[k]) for k in range(10)], np.int64)
+    out["engine_audio_filter_names"] = np.array(["audioAM", "audioCW", "", "audio2100", "", "", "audio2700", "", "audio3100", ""])
+    out["engine_if_filter_set"] = np.array([which(0x2668), which(0x2668), which(0x25c8), which(0x25c8), which(0x2708), which(0x2708)], np.int64)
+    # the instance setAudioFilter(6) leaves behind points at the set it names
+    r.call_addr(0xd97c, sdr, 6)
+    assert r.m.read(sdr + 0x688 + 8, 4) == sdr + aud[6]
+
+
 class _Stop(Exception):
     pass
 
@@ -507,7 +545,8 @@ def main():
                     ("cfft_f32", lambda: kat_cfft_f32(im, out)), ("design", lambda: kat_design(im, out)), ("lms_noise_reduction", lambda: kat_lms_noise_reduction(im, out)),
                     ("conv", lambda: kat_conv(im, out)),
                     ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
-                    ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables))):
+                    ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables)),
+                    ("engine", lambda: kat_engine(im, out, tables))):
         t = time.time()
         f()
         print("%-14s %.1f s" % (name, time.time() - t), flush=True)

@@ -93,8 +93,13 @@ enum { audioCW = RDSP_AUDIO_CW, audio2100 = RDSP_AUDIO_2100, audio2700 = RDSP_AU
 #define SDR_setIQgainBalance(g)     RDSP_BIND_CHECK(rdsp_sdr_setIQgainBalance(g_chain, (g)))
 #define SDR_enableAudioFilter()     RDSP_BIND_CHECK(rdsp_sdr_enableAudioFilter(g_chain))
 #define SDR_setAudioFilter(f)       RDSP_BIND_CHECK(rdsp_sdr_setAudioFilter(g_chain, (f), g_stream))
-/* TuningOffset = SDR.setDemodMode(LSBmode);   .ino:139 */
-#define SDR_setDemodMode(m)         rdsp_sdr_setDemodMode(g_chain, (m), g_stream)
+/* TuningOffset = SDR.setDemodMode(LSBmode);   .ino:139 -- the engine answers with where it wants the carrier (8390 Hz
+ * for LSBmode ...) and from then on moves it to 0 Hz itself; here the mixer is told */
+static inline uint32_t SDR_setDemodMode(int m) {
+  const uint32_t off = rdsp_sdr_setDemodMode(g_chain, m, g_stream);
+  RDSP_BIND_CHECK(rdsp_sdr_setTuningOffsetHz(g_chain, (double)off));
+  return off;
+}
 #define SDR_setMute(b)              RDSP_BIND_CHECK(rdsp_sdr_setMute(g_chain, (b)))
 
 /* ---- the panadapter side of the graph: `AudioFilterBiquad biquad1, biquad2; AudioAnalyzeFFT256IQ FFT;`

@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "tests", "host")
 CFG = dict(fft_l=256, demod="LSB", flo_hz=300.0, fhi_hz=4000.0, agc_mode="medium", input_gain=1.0, output_gain=0.5,
-           iq_balance=1.02)   # what setup() of binding_check.c leaves the engine in
+           iq_balance=1.02, nco_hz=8390.0)   # what setup() of binding_check.c leaves the engine in: LSBmode's TuningOffset
+# (the AudioSDR engine's own answer, tests/golden/firmware_kat.npz) handed to the mixer by the binding
 
 
 def build(tmp_path, name="binding_check"):
@@ -42,7 +43,7 @@ def test_k1_through_the_c_binding_matches_ctypes_path_and_oracle(rdsp, oracle, t
     exe = build(tmp_path)
     r = subprocess.run([exe, str(fin), str(fout), str(nblk)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "TuningOffset 0" in r.stdout                    # LSBmode tunes to the carrier (INO:139)
+    assert "TuningOffset 8390" in r.stdout                 # LSBmode (INO:139): the engine's low IF, 6890 + 1500 Hz
     got = np.fromfile(fout, dtype=np.int16).reshape(-1, 2)
     assert got.shape == (nblk * 32, 2)
     ch = Chain(1, max_blocks_per_call=16, **CFG)

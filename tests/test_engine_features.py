@@ -288,7 +288,7 @@ def test_sam_group_beside_other_groups_and_mode_table_entry(rdsp, oracle, torch_
     base = dict(fft_l=512)
     ch = Chain(nch, max_blocks_per_call=nblk, **base)
     ch.set_groups(np.array([0, 1, 0, 1], np.uint16))
-    assert ch.group_tuningMode(1, 5, 7.2e6) == 0            # "SAM": audioAM + SAMmode, CTL:385-392
+    assert ch.group_tuningMode(1, 5, 7.2e6) == 6890         # "SAM": audioAM + SAMmode, CTL:385-392; TuningOffset = the IF centre
     ch.group_tuningMode(0, 4, 7.2e6)                        # "AM"
     got = ch.process(torch.from_numpy(iq).cuda(), want_f32=True)[1].cpu().numpy()
     ok, filt, demod = oracle.tuning_mode(5, 7.2e6)

@@ -309,6 +309,48 @@ def test_oracle_teensy_biquad_is_the_images_update_bit_for_bit(kat, oracle, rdsp
         assert np.array_equal(a, kat["tbq_chain_coefs"][st]) and np.array_equal(b, kat["tbq_chain_coefs"][st])
 
 
+def test_mode_menu_answers_of_the_engine(kat, oracle, rdsp):
+    """`TuningOffset = SDR.setDemodMode(mode)` (INO:139, CTL:337-407) and `SDR.setAudioFilter(f)` (CTL:153-177) go to the
+    un-vendored AudioSDR engine; the image holds it, and its constructor, setDemodMode and setAudioFilter were run there.
+    The engine is a low-IF receiver -- centre 6890 Hz, SSB band 3000 Hz, CW band 1000 Hz, carrier at the centre plus
+    (lower side band) / minus (upper) half the band -- and those are the numbers the product's and the oracle's
+    setDemodMode return.  Which of the image's fifteen coefficient sets each audio filter name installs is recorded
+    too (a host that wants the engine's own audio2700 loads set 3 with rdsp_sdr_setAudioIIRCoefficients): the
+    150 Hz ... 2.1 / 2.7 / 3.1 / 3.9 kHz band-passes for audio2100 / 2700 / 3100 / AM, a 600 ... 760 Hz peak for audioCW;
+    the sets it puts in front of the demodulator are band-passes around the IF (5.4 ... 8.4 kHz for SSB)."""
+    assert kat["engine_if_centre_ssb_cw"].tolist() == [6890.0, 3000.0, 1000.0]
+    want = dict(zip([str(n) for n in kat["engine_demod_names"]], kat["engine_tuning_offset"].tolist()))
+    assert want == {"LSBmode": 8390.0, "USBmode": 5390.0, "CW_LSBmode": 7390.0, "CW_USBmode": 6390.0, "AMmode": 6890.0, "SAMmode": 6890.0}
+    olib, plib = oracle.load(), rdsp.load()
+    for name, demod in (("LSBmode", "LSB"), ("USBmode", "USB"), ("CW_LSBmode", "CW_LSB"), ("CW_USBmode", "CW_USB"), ("AMmode", "AM"), ("SAMmode", "SAM")):
+        assert olib.orc_demod_tuning_offset(oracle.DEMOD[demod]) == int(want[name])
+    sets = dict(zip([str(n) for n in kat["engine_audio_filter_names"]], kat["engine_audio_filter_set"].tolist()))
+    assert {k: sets[k] for k in ("audioAM", "audioCW", "audio2100", "audio2700", "audio3100")} == {"audioAM": 7, "audioCW": 8, "audio2100": 0, "audio2700": 3, "audio3100": 5}
+    assert kat["engine_if_filter_set"].tolist() == [12, 12, 10, 10, 14, 14]
+    # the product's design for the same names has the same -3 dB edges as the engine's sets (test_audio_nodes.py compares
+    # the responses); here: the upper edges the names promise
+    fw = np.load(os.path.join(HERE, "golden", "firmware_tables.npz"))["biquad_sets"]
+    f = np.linspace(10.0, 8000.0, 16000)
+    z = np.exp(-2j * np.pi * f / 44100.0)
+    for name, hi in (("audio2100", 2100.0), ("audio2700", 2700.0), ("audio3100", 3100.0), ("audioAM", 3900.0)):
+        h = np.ones_like(z)
+        for b0, b1, b2, a1, a2 in fw[sets[name]]:
+            h = h * (b0 + b1 * z + b2 * z * z) / (1 - a1 * z - a2 * z * z)
+        pb = f[np.abs(h) > np.abs(h).max() / np.sqrt(2)]
+        assert abs(pb.min() - 150.0) < 5.0 and abs(pb.max() - hi) < 25.0, (name, pb.min(), pb.max())
+
+
+@pytest.mark.gpu
+def test_gpu_setDemodMode_returns_the_engines_tuning_offsets(rdsp, kat):
+    from radiodsp_sdr_rx_amd.chain import Chain
+    from cases import K1
+    ch = Chain(2, max_blocks_per_call=16, **K1)
+    want = dict(zip([str(n) for n in kat["engine_demod_names"]], kat["engine_tuning_offset"].tolist()))
+    for name, demod in (("LSBmode", "LSB"), ("USBmode", "USB"), ("CW_LSBmode", "CW_LSB"), ("CW_USBmode", "CW_USB"), ("AMmode", "AM"), ("SAMmode", "SAM")):
+        assert ch.setDemodMode(rdsp.DEMOD[demod]) == int(want[name])
+    assert ch.setDemodMode(rdsp.DEMOD["IQ"]) == 0
+
+
 # ---- GPU: the product against the reference's compiled routines ----------------------------------------------------------
 NCH = 3          # the same stream on three channels: every channel must give the reference's answer
 

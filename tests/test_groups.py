@@ -169,8 +169,8 @@ def test_tuning_mode_table_per_group(rdsp, oracle, torch_cuda):
         ok, filt, demod = oracle.tuning_mode(mndx, vfo)
         assert ok and off == oracle.load().orc_demod_tuning_offset(demod)
         lo, hi = oracle.passband(filt, demod)
-        ch.group_setTuningOffsetHz(g, 12000.0 - off)
-        settings.append(dict(demod=names[demod], lo=lo, hi=hi, nco=12000.0 - off))
+        ch.group_setTuningOffsetHz(g, float(off))        # what the engine does itself: the carrier from TuningOffset to 0 Hz
+        settings.append(dict(demod=names[demod], lo=lo, hi=hi, nco=float(off)))
     assert ch.group_tuningMode(0, 9, 7.1e6) == 0 and b"no menu entry" in rdsp.load().rdsp_last_error()
     ch.group_tuningMode(0, *modes[0])
     ch.group_setTuningOffsetHz(0, settings[0]["nco"])

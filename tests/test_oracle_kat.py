@@ -281,8 +281,9 @@ def test_decimator_taps_and_tuning_offsets(oracle):
     assert np.array_equal(h, hi.astype(np.float32))
     assert abs(h.sum() - 1.0) < 1e-3 and np.allclose(h, h[::-1], atol=1e-9)
     lib = oracle.load()
-    assert lib.orc_demod_tuning_offset(oracle.DEMOD["USB"]) == 0
-    assert lib.orc_demod_tuning_offset(oracle.DEMOD["CW_USB"]) == 700
+    assert lib.orc_demod_tuning_offset(oracle.DEMOD["USB"]) == 5390        # the AudioSDR engine's own answers, read by
+    assert lib.orc_demod_tuning_offset(oracle.DEMOD["CW_USB"]) == 6390     # running it (tests/test_firmware_kat.py)
+    assert lib.orc_demod_tuning_offset(oracle.DEMOD["IQ"]) == 0
     assert lib.orc_chain_nco_dphi(ch.h) == 2 ** 29  # 12 kHz at 96 kHz
 
 
