@@ -118,8 +118,6 @@ def _dis32(a, hw1, hw2):
         return "%s %s, #0x%x" % ("movt" if hw1 & 0x80 else "movw", R((hw2 >> 8) & 15), imm)
     if (hw1 & 0xEC00) == 0xEC00:
         cp = (hw2 >> 8) & 15
-        if (hw1 & 0xFF00) in (0xED00,) or (hw1 & 0xFF20) == 0xED00:
-            pass
         if (hw1 & 0xEF00) == 0xED00 and not (hw1 & 0x20):
             l, u, rn = (hw1 >> 4) & 1, (hw1 >> 7) & 1, hw1 & 15
             D, Vd = (hw1 >> 6) & 1, (hw2 >> 12) & 15

@@ -90,9 +90,7 @@ def round_fraction(fr, pbits, emin, emax):
     rem = q - m
     if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (m & 1)):
         m += 1
-    if m.bit_length() > pbits:                                # carried into the next binade: m is a power of two, still exact
-        pass
-    val = math.ldexp(m, scale) if scale > -1100 else 0.0
+    val = math.ldexp(m, scale) if scale > -1100 else 0.0      # (a carry into the next binade leaves m a power of two: still exact)
     if m.bit_length() + scale - 1 > emax:
         return sign * math.inf
     return sign * val
@@ -102,9 +100,9 @@ def fma32(a, b, c):
     if not (math.isfinite(a) and math.isfinite(b) and math.isfinite(c)):
         return f32_round(a * b + c)
     r = round_fraction(Fraction(a) * Fraction(b) + Fraction(c), 24, -126, 127)
-    if r == 0.0:
+    if r == 0.0:                                              # exact zero: IEEE gives -0 only when product and addend are both -0
         p = a * b
-        return math.copysign(0.0, p) if (p == 0.0 and c == 0.0 and math.copysign(1, p) == math.copysign(1, c)) else (0.0 if p + c == 0 else r)
+        return -0.0 if (p == 0.0 and c == 0.0 and math.copysign(1, p) < 0 and math.copysign(1, c) < 0) else 0.0
     return r
 
 
