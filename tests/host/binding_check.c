@@ -51,6 +51,13 @@ static uint32_t TuningOffset;
 
 static void setup(void) {           /* RadioDSP_SDR_RX.ino:102-187, the DSP part */
   doConvolutionalInitialize();      /* the chain must exist before the engine setters can reach it */
+#ifdef RDSP_BIND_LITERAL            /* the CONV stage alone, fed what the image's record queues were fed: no engine in front */
+  if (getenv("RDSP_NR_LEVEL")) nr_level = atoi(getenv("RDSP_NR_LEVEL"));
+  Init_LMS_NR(15);                            /* :172 */
+  reInitializeFilter(300.0, 4000.0);          /* :183 */
+  (void)TuningOffset; (void)SDR_setDemodMode;
+  return;
+#endif
   preProcessor_startAutoI2SerrorDetection();  /* :117 */
   SDR_enableAGC();                            /* :120 */
   SDR_setAGCmode(AGCmedium);                  /* :121 */

@@ -22,7 +22,12 @@
 #define MAX_BLOCKS 64   /* 128-sample blocks per call and channel */
 #endif
 #define IN_STRIDE ((size_t)MAX_BLOCKS * RDSP_BLOCK_SAMPLES)
-#define OUT_STRIDE (IN_STRIDE / 4)
+#ifdef RDSP_BIND_LITERAL /* the CONV stage as the shipped sketch runs it, behind the engine: 44.1 kHz, no mixer, no decimator */
+#define OUT_DIV 1
+#else
+#define OUT_DIV 4
+#endif
+#define OUT_STRIDE (IN_STRIDE / OUT_DIV)
 
 typedef int boolean; /* Arduino */
 
@@ -46,11 +51,20 @@ static int g_binding_status = RDSP_OK; /* the sketch has no error channel: first
   } while (0)
 
 static void doConvolutionalInitialize(void) { /* RDSP_convolutional.h:187 */
+#ifdef RDSP_BIND_LITERAL
+  /* CONV:34-72 as the firmware image has them: SAMPLE_RATE 44100, FFT_L 256, N_BLOCKS 1, 129 taps, window 1, 300 ... 4000 Hz;
+   * L / R in, L / R out (CONV:314-318) */
+  rdsp_chain_config_t cfg = {
+      .fs_in = 44100.0, .decim = 1, .nco_hz = 0.0, .fft_l = 256, .window = 1, .flo_hz = 300.0, .fhi_hz = 4000.0,
+      .filter_on = 1, .demod = RDSP_DEMOD_IQ, .agc_mode = RDSP_AGC_OFF, .input_gain = 1.0f, .output_gain = 1.0f,
+      .iq_balance = 1.0f};
+#else
   rdsp_chain_config_t cfg = {
       .fs_in = 96000.0, .decim = 4, .fir_taps = 256, .fir_cut_hz = 10000.0, .nco_hz = 12000.0,
       .fft_l = 256, .window = 1, .flo_hz = 300.0, .fhi_hz = 4000.0, .filter_on = 1,
       .demod = RDSP_DEMOD_USB, .als_strength = 20, .agc_mode = RDSP_AGC_OFF,
       .input_gain = 1.0f, .output_gain = 1.0f, .iq_balance = 1.0f};
+#endif
   if (hipStreamCreate(&g_stream) != hipSuccess || hipMalloc((void **)&g_d_iq, N_CH * IN_STRIDE * 4) != hipSuccess ||
       hipMalloc((void **)&g_d_out, N_CH * OUT_STRIDE * 4) != hipSuccess) {
     g_binding_status = RDSP_ERR_HIP;
@@ -72,7 +86,7 @@ static void doConvolutionalProcessing(float nr, boolean filt, double lo, double 
   upload_queued_iq(g_d_iq, n, g_stream);
   RDSP_BIND_CHECK(rdsp_doConvolutionalProcessing(g_chain, nr, filt, lo, hi, g_d_iq, IN_STRIDE, n, g_d_out,
                                                  OUT_STRIDE, g_stream));
-  play_audio(g_d_out, n * RDSP_BLOCK_SAMPLES / 4, g_stream);
+  play_audio(g_d_out, n * RDSP_BLOCK_SAMPLES / OUT_DIV, g_stream);
 }
 
 /* the engine object keeps its call sites (RadioDSP_SDR_RX.ino:117-139,177) */

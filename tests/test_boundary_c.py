@@ -15,10 +15,10 @@ CFG = dict(fft_l=256, demod="LSB", flo_hz=300.0, fhi_hz=4000.0, agc_mode="medium
 # (the AudioSDR engine's own answer, tests/golden/firmware_kat.npz) handed to the mixer by the binding
 
 
-def build(tmp_path, name="binding_check"):
-    exe = str(tmp_path / name)
-    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-D__HIP_PLATFORM_AMD__",
-                           "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+def build(tmp_path, name="binding_check", defines=(), out=None):
+    exe = str(tmp_path / (out or name))
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-D__HIP_PLATFORM_AMD__"] + list(defines) +
+                          ["-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
                            os.path.join(HOST, name + ".c"), "-o", exe,
                            "-L", os.path.join(ROOT, "radiodsp_sdr_rx_amd"), "-lrdsp_hip",
                            "-L", "/opt/rocm/lib", "-lamdhip64",
@@ -87,6 +87,37 @@ def test_panadapter_side_through_the_c_binding_matches_the_oracle(rdsp, oracle, 
     for s, rd in zip(spectra, reads):
         assert rd[0] == np.float32(s[80]) * np.float32(1.0 / 16384.0)
         assert rd[1] == np.float32(int(s[75:85].sum())) * np.float32(1.0 / 16384.0)       # FFTIQ.h:75-86: bin 85 is not added
+
+
+def test_literal_sketch_binding_compiles(rdsp, tmp_path):
+    exe = build(tmp_path, defines=["-DRDSP_BIND_LITERAL"], out="binding_literal")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nr", [0, 15])
+def test_the_sketch_over_the_c_binding_against_the_sketchs_own_binary(rdsp, tmp_path, nr):
+    """setup() / loop() of the sketch over the reference-side binding, in C, with the CONV stage configured as the
+    firmware image has it (-DRDSP_BIND_LITERAL: 44.1 kHz, FFT_L 256, 129 taps, 300 ... 4000 Hz, L / R through) and fed
+    the IQ blocks the image's doConvolutionalProcessing was fed under the interpreter (tests/golden/firmware_kat.npz):
+    the int16 audio the C program writes is the image's to one count, with the NLMS noise reduction (Init_LMS_NR(15) in
+    setup(), nr_level 15 in loop()) and without"""
+    kat = np.load(os.path.join(ROOT, "tests", "golden", "firmware_kat.npz"))
+    tag, nblk = ("nr15", 48) if nr else ("plain", 32)
+    iq = kat["conv_iq"][:nblk * 128]
+    fin, fout = tmp_path / "iq.raw", tmp_path / "audio.raw"
+    iq.tofile(fin)
+    exe = build(tmp_path, defines=["-DRDSP_BIND_LITERAL"], out="binding_literal")
+    r = subprocess.run([exe, str(fin), str(fout), str(nblk)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RDSP_NR_LEVEL=str(nr)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(fout, dtype=np.int16).reshape(-1, 2)
+    want = kat[f"conv_{tag}_o16"]
+    assert got.shape == want.shape
+    d = np.abs(got.astype(np.int32) - want)
+    print(f"C binding, {tag}: {int((d > 0).sum())} of {d.size} samples one count from the image's output")
+    assert d.max() <= 1 and (d > 0).sum() <= 400
 
 
 def test_sharding_host_in_c_compiles_and_links(rdsp, tmp_path):
