@@ -404,6 +404,42 @@ def kat_fft1024(im, out, tables):
         out[f"fft1024_{tag}_ticks"] = np.array(ticks)
 
 
+def kat_panadapter(im, out, tables):
+    """The panadapter branch of the sketch's graph, end to end from the image (INO:57-60,75-78,144-145,155-156):
+    IQinput -> biquad1 / biquad2 (setHighpass(0, 500, 0.5): the integers setup() holds) -> FFT (AudioWindowHanning256,
+    averageTogether(30)); 96 blocks, three spectra.  Each update() is the image's; AudioStream's hand-over between the
+    nodes is done by the hooks (biquad output blocks become the analyser's input blocks)."""
+    iq = synth_iq(96 * 128, 14)
+    r = Ref(im)
+    coef = r.alloc(20)
+    r.put(coef, teensy_biquad_ints("highpass", 500.0, 0.5))
+    bq = [r.alloc(24 + 32 * 4 + 16) for _ in range(2)]
+    for o in bq:
+        r.call("biquad_setCoefficients", o, 0, coef)
+    fft = r.alloc(0xa40 + 16)
+    r.m.write(fft + 536, 4, im.dtcm_of_offset(TABLES["hann256"][0]))
+    r.m.write(fft + 2597, 1, 30)
+    assert r.call("cfft_q15_init", fft + 0xa30, 256, 0, 1) == 0
+    bl = Blocks(r, 16)
+    cur, sent = {}, {}
+    r.cpu.hooks[A["receiveWritable"]] = lambda c: c.r.__setitem__(0, cur["w"])
+    r.cpu.hooks[A["transmit"]] = lambda c: sent.__setitem__("b", c.r[1])
+    r.cpu.hooks[A["receiveReadOnly"]] = lambda c: c.r.__setitem__(0, cur[c.r[1]])
+    r.cpu.hooks[A["release"]] = lambda c: None
+    spectra = []
+    for b in range(len(iq) // 128):
+        blk = iq[b * 128:(b + 1) * 128]
+        for side in (0, 1):
+            cur["w"] = bl.new(blk[:, side])
+            r.call("biquad_update", bq[side])
+            cur[side] = sent["b"]
+        r.call("fft256iq_update", fft)
+        if r.m.read(fft + 2598, 1):
+            r.m.write(fft + 2598, 1, 0)
+            spectra.append(r.get(fft + 24, 256, np.uint16))
+    out.update(panadapter_iq=iq, panadapter_out=np.stack(spectra))
+
+
 def teensy_biquad_ints(kind, frequency, q, fs=44100.0):
     """filter_biquad.h's setters as published (all in double, x 2^30, int conversion): gives the five integers the image's
     setup() holds for setHighpass(0, 500, 0.5)"""
@@ -546,7 +582,7 @@ def main():
                     ("conv", lambda: kat_conv(im, out)),
                     ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
                     ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables)),
-                    ("engine", lambda: kat_engine(im, out, tables))):
+                    ("engine", lambda: kat_engine(im, out, tables)), ("panadapter", lambda: kat_panadapter(im, out, tables))):
         t = time.time()
         f()
         print("%-14s %.1f s" % (name, time.time() - t), flush=True)

@@ -277,6 +277,51 @@ def test_oracle_analysers_are_the_images_update_bit_for_bit(kat, oracle):
         assert np.array_equal(kat[f"fft1024_{tag}_ticks"], np.arange(7, 40, 4))
 
 
+def test_oracle_panadapter_branch_is_the_images_end_to_end(kat, oracle):
+    """IQinput -> biquad1 / biquad2 (setHighpass(0, 500, 0.5)) -> FFT (Hanning, averageTogether(30)), INO:57-60,75-78,
+    144-145,155-156, each update() run from the image and chained: 96 blocks, three spectra -- the oracle's fixed-point
+    biquad feeding its analyser gives the same words"""
+    from test_audio_nodes import TeensyBiquadOracle, _bind
+    from test_spectrum import _olib, oracle_spectra
+    lib = _bind(_olib(oracle))
+    iq = kat["panadapter_iq"]
+    filt = np.zeros_like(iq)
+    for side in (0, 1):
+        o = TeensyBiquadOracle(lib)
+        o.set(0, "highpass", 500.0, 0.5)
+        filt[:, side] = o.update(np.ascontiguousarray(iq[:, side]))
+    assert np.array_equal(np.stack(oracle_spectra(lib, filt, 30, 1)), kat["panadapter_out"])
+
+
+@pytest.mark.gpu
+def test_gpu_panadapter_branch_as_graph_nodes_is_the_images_end_to_end(rdsp, kat):
+    """the same branch built out of this library's graph nodes (rdsp_graph_*: input node, two biquad nodes, the analyser
+    node, four AudioConnections), ticked block by block: the spectra are the image's"""
+    from radiodsp_sdr_rx_amd.filters import FilterBiquad
+    from radiodsp_sdr_rx_amd.graph import Graph
+    from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
+    iq = kat["panadapter_iq"]
+    g = Graph(1)
+    g.AudioMemory(40)                                               # INO:151
+    IQinput = g.input_node()                                        # INO:52
+    b1, b2 = FilterBiquad(1), FilterBiquad(1)                       # INO:58-59
+    b1.setHighpass(0, 500, 0.5); b2.setHighpass(0, 500, 0.5)        # INO:155-156
+    biquad1, biquad2 = g.biquad_node(b1), g.biquad_node(b2)
+    fft = AnalyzeFFT256IQ(1)                                        # INO:57: the constructor's defaults ...
+    fft.windowFunction("AudioWindowHanning256"); fft.averageTogether(30)   # ... then INO:144-145
+    FFT = g.spectrum_node(fft)
+    g.AudioConnection(IQinput, 0, biquad1, 0); g.AudioConnection(IQinput, 1, biquad2, 0)   # INO:75-76
+    g.AudioConnection(biquad1, 0, FFT, 0); g.AudioConnection(biquad2, 0, FFT, 1)           # INO:77-78
+    spectra = []
+    for b in range(len(iq) // 128):
+        blk = iq[None, b * 128:(b + 1) * 128]
+        IQinput.push(np.ascontiguousarray(blk[..., 0]), np.ascontiguousarray(blk[..., 1]))
+        assert g.update_all() == 0
+        if FFT.available():
+            spectra.append(np.asarray(FFT.output())[0].astype(np.uint16))
+    assert np.array_equal(np.stack(spectra), kat["panadapter_out"])
+
+
 TBQ = ("hp", "chain", "gap", "fresh")
 
 
