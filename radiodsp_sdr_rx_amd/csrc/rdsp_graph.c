@@ -17,7 +17,11 @@
 #include <string.h>
 
 #define RDSP_MAX_PORTS 4
-#define RDSP_QUEUE_MAX 64 /* AudioRecordQueue keeps up to 53 blocks; same order */
+/* ring sizes of the Teensy 4 Audio library as the reference's firmware image has them (AudioRecordQueue::available():
+ * `head + 209 - tail`; AudioPlayQueue::playBuffer(): `if (++h > 79) h = 0`): a ring of N holds N - 1 blocks */
+#define RDSP_RECORD_QUEUE_MAX 209
+#define RDSP_PLAY_QUEUE_MAX 80
+#define RDSP_QUEUE_MAX RDSP_RECORD_QUEUE_MAX /* storage */
 
 struct rdsp_block {
   int16_t *data; /* [n_channels][128] */
@@ -235,7 +239,7 @@ static void record_update(rdsp_node_t *n, void *user) {
     rdsp_release(b);
     return;
   }
-  int h = (n->head + 1) % RDSP_QUEUE_MAX;
+  int h = (n->head + 1) % RDSP_RECORD_QUEUE_MAX;
   if (h == n->tail) { /* queue full: drop, like the library */
     rdsp_release(b);
     return;
@@ -251,7 +255,7 @@ rdsp_node_t *rdsp_record_queue_create(rdsp_graph_t *g) {
 void rdsp_record_queue_begin(rdsp_node_t *q) { /* Q_in_L.begin(), RDSP_convolutional.h:205 */
   if (!q || q->kind != 1) return;
   while (q->tail != q->head) { /* clear() */
-    q->tail = (q->tail + 1) % RDSP_QUEUE_MAX;
+    q->tail = (q->tail + 1) % RDSP_RECORD_QUEUE_MAX;
     rdsp_release(q->fifo[q->tail]);
   }
   if (q->userblock) { rdsp_release(q->userblock); q->userblock = NULL; }
@@ -260,11 +264,11 @@ void rdsp_record_queue_begin(rdsp_node_t *q) { /* Q_in_L.begin(), RDSP_convoluti
 void rdsp_record_queue_end(rdsp_node_t *q) { if (q && q->kind == 1) q->enabled = 0; }
 int rdsp_record_queue_available(const rdsp_node_t *q) { /* RDSP_convolutional.h:231 */
   if (!q || q->kind != 1) return 0;
-  return (q->head - q->tail + RDSP_QUEUE_MAX) % RDSP_QUEUE_MAX;
+  return (q->head - q->tail + RDSP_RECORD_QUEUE_MAX) % RDSP_RECORD_QUEUE_MAX;
 }
 int16_t *rdsp_record_queue_readBuffer(rdsp_node_t *q) { /* :236-237 */
   if (!q || q->kind != 1 || q->userblock || q->tail == q->head) return NULL;
-  q->tail = (q->tail + 1) % RDSP_QUEUE_MAX;
+  q->tail = (q->tail + 1) % RDSP_RECORD_QUEUE_MAX;
   q->userblock = q->fifo[q->tail];
   return q->userblock->data;
 }
@@ -278,7 +282,7 @@ void rdsp_record_queue_freeBuffer(rdsp_node_t *q) { /* :243-244 */
 static void play_update(rdsp_node_t *n, void *user) {
   (void)user;
   if (n->tail == n->head) return;
-  n->tail = (n->tail + 1) % RDSP_QUEUE_MAX;
+  n->tail = (n->tail + 1) % RDSP_PLAY_QUEUE_MAX;
   rdsp_block_t *b = n->fifo[n->tail];
   rdsp_transmit(n, b, 0);
   rdsp_release(b);
@@ -296,7 +300,7 @@ int16_t *rdsp_play_queue_getBuffer(rdsp_node_t *q) { /* RDSP_convolutional.h:344
 }
 int rdsp_play_queue_playBuffer(rdsp_node_t *q) { /* :348-349 */
   if (!q || q->kind != 2 || !q->userblock) return RDSP_ERR_INVALID;
-  int h = (q->head + 1) % RDSP_QUEUE_MAX;
+  int h = (q->head + 1) % RDSP_PLAY_QUEUE_MAX;
   if (h == q->tail) return RDSP_ERR_NOT_READY; /* the library spins here; we report */
   q->fifo[h] = q->userblock;
   q->head = h;

@@ -291,3 +291,31 @@ def test_the_whole_graph_of_the_sketch(rdsp, oracle):
         k = int(round(f / (24000.0 / 1024)))
         assert spec[k - 1:k + 2].max() > 8 * np.median(spec[:128])
     assert g.memory_usage()[0] == 0 and g.memory_usage()[1] <= 40
+
+
+def test_queue_rings_have_the_sizes_of_the_references_image(rdsp):
+    """AudioRecordQueue is a ring of 209, AudioPlayQueue one of 80 in the Teensy 4 build the reference ships (its
+    available() computes head + 209 - tail, its playBuffer() wraps past 79): a record queue nobody reads keeps 208
+    blocks and drops the rest, a play queue takes 79 before it reports that the library would spin."""
+    from radiodsp_sdr_rx_amd.graph import Graph
+    g = Graph(1)
+    g.AudioMemory(400)
+    src = g.input_node()
+    q = g.record_queue()
+    g.AudioConnection(src, 0, q, 0)
+    q.begin()
+    z = np.zeros((1, 128), np.int16)
+    for t in range(230):
+        src.push(z, z)
+        assert g.update_all() == 0
+    assert q.available() == 208
+    assert g.memory_usage()[0] <= 209 + 2
+    p = g.play_queue()
+    n = 0
+    while n < 100:
+        buf = p.getBuffer()
+        assert buf is not None
+        if p.playBuffer() != 0:
+            break
+        n += 1
+    assert n == 79
