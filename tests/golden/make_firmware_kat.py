@@ -526,6 +526,42 @@ def kat_engine(im, out, tables):
     assert r.m.read(sdr + 0x688 + 8, 4) == sdr + aud[6]
 
 
+def _stub_calls(r, code, start, stop, keep=()):
+    """every BL inside [start, stop) goes to a no-op, except the targets in `keep`"""
+    for o in range(start, stop, 2):
+        hw1, hw2 = struct.unpack_from("<HH", code, o)
+        if (hw1 & 0xF800) == 0xF000 and (hw2 & 0xD000) == 0xD000:
+            s, j1, j2 = (hw1 >> 10) & 1, (hw2 >> 13) & 1, (hw2 >> 11) & 1
+            imm = (s << 24) | ((1 - (j1 ^ s)) << 23) | ((1 - (j2 ^ s)) << 22) | ((hw1 & 0x3FF) << 12) | ((hw2 & 0x7FF) << 1)
+            if imm & (1 << 24):
+                imm -= 1 << 25
+            if o + 4 + imm not in keep:
+                r.cpu.hooks[o + 4 + imm] = lambda c: c.r.__setitem__(0, 0)
+
+
+def kat_mode_menu(im, out):
+    """tuningMode() (CTL:330-423, ITCM 0x8378) as compiled: for every menu entry mndx = 0 ... 6 and a VFO below and above
+    10 MHz the function is run with its display calls stubbed, and what it hands to SDR.setAudioFilter and
+    SDR.setDemodMode is recorded (the engine's own numbers: see kat_engine for the names)"""
+    code = im.img[im.itcm_off:im.itcm_off + im.etext]
+    mndx_addr, vfo_addr = 0x20008dd0, 0x20015a2c                       # literal pool of tuningMode()
+    table = np.zeros((7, 2, 2), np.int64)
+    for mndx in range(7):
+        for k, vfo in enumerate((7030000, 14060000)):
+            r = Ref(im)
+            got = {}
+            _stub_calls(r, code, 0x8378, 0x854c)
+            r.cpu.hooks[0xf494] = lambda c: None                       # delay(200), reached by a tail branch
+            r.cpu.hooks[0xd97c] = lambda c: got.__setitem__("filter", c.r[1])
+            r.cpu.hooks[0xd798] = lambda c: got.__setitem__("mode", c.r[1])
+            r.m.write(mndx_addr, 4, mndx)
+            r.m.write(vfo_addr, 4, vfo)
+            r.call_addr(0x8378)
+            table[mndx, k] = (got["filter"], got["mode"])
+    out["mode_menu_filter_and_mode"] = table
+    out["mode_menu_vfo"] = np.array([7030000, 14060000], np.int64)
+
+
 class _Stop(Exception):
     pass
 
@@ -582,7 +618,7 @@ def main():
                     ("conv", lambda: kat_conv(im, out)),
                     ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
                     ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables)),
-                    ("engine", lambda: kat_engine(im, out, tables)), ("panadapter", lambda: kat_panadapter(im, out, tables))):
+                    ("engine", lambda: kat_engine(im, out, tables)), ("panadapter", lambda: kat_panadapter(im, out, tables)), ("mode_menu", lambda: kat_mode_menu(im, out))):
         t = time.time()
         f()
         print("%-14s %.1f s" % (name, time.time() - t), flush=True)

@@ -385,6 +385,34 @@ def test_mode_menu_answers_of_the_engine(kat, oracle, rdsp):
         assert abs(pb.min() - 150.0) < 5.0 and abs(pb.max() - hi) < 25.0, (name, pb.min(), pb.max())
 
 
+MENU_FILTER = {0: "audioAM", 1: "audioCW", 3: "audio2100", 6: "audio2700", 8: "audio3100"}      # the engine's numbers (kat_engine)
+MENU_MODE = {0: "LSB", 1: "USB", 2: "CW_LSB", 3: "CW_USB", 4: "AM", 5: "SAM"}
+ORACLE_FILTER = {"audioCW": 0, "audio2100": 1, "audio2700": 2, "audio3100": 3, "audioAM": 4}       # ids of the build (include/rdsp.h)
+
+
+def test_mode_menu_table_is_the_compiled_tuningMode(kat, oracle):
+    """tuningMode() (CTL:330-423) run from the image for every menu entry and a VFO either side of 10 MHz: the audio
+    filter and demodulator it hands to the engine are the oracle's table"""
+    t = kat["mode_menu_filter_and_mode"]
+    for mndx in range(7):
+        for k, vfo in enumerate(kat["mode_menu_vfo"]):
+            ok, filt, demod = oracle.tuning_mode(mndx, float(vfo))
+            assert ok and filt == ORACLE_FILTER[MENU_FILTER[int(t[mndx, k, 0])]] and demod == oracle.DEMOD[MENU_MODE[int(t[mndx, k, 1])]]
+
+
+@pytest.mark.gpu
+def test_gpu_tuningMode_is_the_compiled_one(rdsp, kat):
+    from radiodsp_sdr_rx_amd.chain import Chain
+    ch = Chain(2, max_blocks_per_call=8, fft_l=256)
+    t = kat["mode_menu_filter_and_mode"]
+    off = dict(zip([str(n) for n in kat["engine_demod_names"]], kat["engine_tuning_offset"].tolist()))
+    names = {"LSB": "LSBmode", "USB": "USBmode", "CW_LSB": "CW_LSBmode", "CW_USB": "CW_USBmode", "AM": "AMmode", "SAM": "SAMmode"}
+    for mndx in range(7):
+        for k, vfo in enumerate(kat["mode_menu_vfo"]):
+            got = ch.group_tuningMode(0, mndx, float(vfo))
+            assert got == int(off[names[MENU_MODE[int(t[mndx, k, 1])]]]), (mndx, vfo)   # TuningOffset = what the engine returns for that mode
+
+
 @pytest.mark.gpu
 def test_gpu_setDemodMode_returns_the_engines_tuning_offsets(rdsp, kat):
     from radiodsp_sdr_rx_amd.chain import Chain
