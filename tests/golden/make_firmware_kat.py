@@ -562,6 +562,31 @@ def kat_mode_menu(im, out):
     out["mode_menu_vfo"] = np.array([7030000, 14060000], np.int64)
 
 
+def kat_pbt(im, out):
+    """checkPBT_Increase / checkPBT_Decrease (CTL:569-612; ITCM 0x8a48, 0x8b08) as compiled: menu level L4_PBT_LH, one
+    of the two buttons held (digitalRead answered by a hook), reInitializeFilter and showPBT stubbed; a walk of 114 presses
+    from the sketch's start-up cut-offs up and down into all four limits; the cut-offs after every press"""
+    lo_addr, hi_addr, level_addr = 0x20008df8, 0x20008df0, 0x20008e00   # dFLoCut, dFHiCut, iMenuLevel (literal pools)
+    r = Ref(im)
+    pressed = {}
+    r.cpu.hooks[0xf5d4] = lambda c: c.r.__setitem__(0, 0 if c.r[0] == pressed["pin"] else 1)   # digitalRead: LOW = pressed
+    calls = []
+    r.cpu.hooks[A["reInitializeFilter"]] = lambda c: calls.append((c.fd(0), c.fd(1)))
+    r.cpu.hooks[0x7594] = lambda c: None                                  # showPBT
+    r.m.write(level_addr, 4, 4)
+    start = (r.get(lo_addr, 1, np.float64)[0], r.get(hi_addr, 1, np.float64)[0])
+    walk = [(0, +1)] * 12 + [(0, -1)] * 18 + [(1, +1)] * 4 + [(1, -1)] * 70 + [(1, +1)] * 6 + [(0, +1)] * 4      # (edge: 0 LOCUT / D3, 1 HICUT / D6; direction)
+    after = []
+    for edge, direction in walk:
+        pressed["pin"] = 6 if edge == 0 else 3                           # the pin numbers the compiled code asks for, in its order
+        assert r.call_addr(0x8a48 if direction > 0 else 0x8b08) == 1
+        after.append((r.get(lo_addr, 1, np.float64)[0], r.get(hi_addr, 1, np.float64)[0]))
+        assert calls[-1] == after[-1]                                     # reInitializeFilter(dFLoCut, dFHiCut) with the new values
+    pressed["pin"] = 99
+    assert r.call_addr(0x8a48) == 0 and r.call_addr(0x8b08) == 0           # no button: nothing happens
+    out.update(pbt_start=np.array(start), pbt_walk=np.array(walk, np.int64), pbt_after=np.array(after))
+
+
 class _Stop(Exception):
     pass
 
@@ -618,7 +643,7 @@ def main():
                     ("conv", lambda: kat_conv(im, out)),
                     ("fft256iq", lambda: kat_fft256iq(im, out, tables)), ("fft1024", lambda: kat_fft1024(im, out, tables)),
                     ("teensy_biquad", lambda: kat_teensy_biquad(im, out)), ("setup", lambda: kat_setup(im, out, tables)),
-                    ("engine", lambda: kat_engine(im, out, tables)), ("panadapter", lambda: kat_panadapter(im, out, tables)), ("mode_menu", lambda: kat_mode_menu(im, out))):
+                    ("engine", lambda: kat_engine(im, out, tables)), ("panadapter", lambda: kat_panadapter(im, out, tables)), ("mode_menu", lambda: kat_mode_menu(im, out)), ("pbt", lambda: kat_pbt(im, out))):
         t = time.time()
         f()
         print("%-14s %.1f s" % (name, time.time() - t), flush=True)

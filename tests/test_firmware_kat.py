@@ -400,6 +400,22 @@ def test_mode_menu_table_is_the_compiled_tuningMode(kat, oracle):
             assert ok and filt == ORACLE_FILTER[MENU_FILTER[int(t[mndx, k, 0])]] and demod == oracle.DEMOD[MENU_MODE[int(t[mndx, k, 1])]]
 
 
+def test_pbt_steps_are_the_compiled_checkPBT_functions(kat, oracle, rdsp):
+    """checkPBT_Increase / checkPBT_Decrease (CTL:569-612) run from the image through 114 button presses from the sketch's
+    start-up cut-offs (300 / 4000 Hz) into all four limits (LOCUT stops at 700 and at 50 -- `(dFLoCut - 50) > MIN_LOW` never
+    lets it reach 0 --, HICUT at 4000 and at 850): the oracle's and the product's pbt_step follow press by press"""
+    olib, plib = oracle.load(), rdsp.load()
+    plib.rdsp_pbt_step.argtypes = [F64P, F64P, C.c_int, C.c_int]
+    a = kat["pbt_after"]
+    assert kat["pbt_start"].tolist() == [300.0, 4000.0]
+    assert (a[:, 0].min(), a[:, 0].max(), a[:, 1].min(), a[:, 1].max()) == (50.0, 700.0, 850.0, 4000.0)
+    for name, step in (("oracle", olib.orc_pbt_step), ("product", plib.rdsp_pbt_step)):
+        lo, hi = C.c_double(300.0), C.c_double(4000.0)
+        for (edge, direction), want in zip(kat["pbt_walk"], a):
+            step(C.byref(lo), C.byref(hi), int(edge), int(direction))
+            assert (lo.value, hi.value) == tuple(want), (name, edge, direction)
+
+
 @pytest.mark.gpu
 def test_gpu_tuningMode_is_the_compiled_one(rdsp, kat):
     from radiodsp_sdr_rx_amd.chain import Chain
