@@ -244,6 +244,11 @@ def main():
     assert abs(out["hilbert_half64"][63] + 2 / np.pi) < 1e-4 and out["sine257"][64] == 1.0
     assert out["sample_rate"][0] == 44100.0 and out["nr_gain"][0] == 1.1 and out["lms_epsilon"][0] == np.float32(1.19209289e-7)
     assert out["design_constants"][0] == np.pi and out["design_constants"][1] == 0.01 and out["iq_gain_balance"][0] == np.float32(1.02)
+    if "--check" in sys.argv[1:]:                      # recompute and compare with the committed fixture
+        have = np.load(OUT)
+        bad = [k for k in out if k not in have.files or not np.array_equal(np.asarray(out[k]), have[k])] + [k for k in have.files if k not in out]
+        print("check against", OUT, ":", "identical (%d arrays)" % len(out) if not bad else "DIFFERENT: %s" % bad)
+        sys.exit(1 if bad else 0)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
