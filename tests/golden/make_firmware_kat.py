@@ -560,6 +560,18 @@ def kat_mode_menu(im, out):
             table[mndx, k] = (got["filter"], got["mode"])
     out["mode_menu_filter_and_mode"] = table
     out["mode_menu_vfo"] = np.array([7030000, 14060000], np.int64)
+    # filterMode() (CTL:149-191, ITCM 0x8084): the audio filter of menu entry fndx = 0 ... 4
+    filt = []
+    for fndx in range(5):
+        r = Ref(im)
+        got = {}
+        _stub_calls(r, code, 0x8084, 0x8130)
+        r.cpu.hooks[0xf494] = lambda c: None
+        r.cpu.hooks[0xd97c] = lambda c: got.__setitem__("filter", c.r[1])
+        r.m.write(0x20008de4, 4, fndx)
+        r.call_addr(0x8084)
+        filt.append(got["filter"])
+    out["filter_menu_filter"] = np.array(filt, np.int64)
 
 
 def kat_pbt(im, out):

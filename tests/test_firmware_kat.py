@@ -416,6 +416,13 @@ def test_pbt_steps_are_the_compiled_checkPBT_functions(kat, oracle, rdsp):
             assert (lo.value, hi.value) == tuple(want), (name, edge, direction)
 
 
+def test_filter_menu_is_the_compiled_filterMode(kat):
+    """filterMode() (CTL:149-191) run from the image for fndx = 0 ... 4: audioCW, audio2100, audio2700, audio3100, audioAM in
+    the engine's numbering -- the order of the build's RDSP_AUDIO_* ids"""
+    assert [MENU_FILTER[int(k)] for k in kat["filter_menu_filter"]] == ["audioCW", "audio2100", "audio2700", "audio3100", "audioAM"]
+    assert [ORACLE_FILTER[MENU_FILTER[int(k)]] for k in kat["filter_menu_filter"]] == [0, 1, 2, 3, 4]
+
+
 @pytest.mark.gpu
 def test_gpu_tuningMode_is_the_compiled_one(rdsp, kat):
     from radiodsp_sdr_rx_amd.chain import Chain
