@@ -108,12 +108,23 @@ def kat_cfft_q15(im, out):
         S, buf = r.alloc(16), r.alloc(4 * n)
         assert r.call("cfft_q15_init", S, n, 0, 1) == 0              # as the analysers' constructors do
         xs, ys = [], []
-        for trial in range(4):
+        for trial in range(9):
             x = rng.integers(-32768, 32768, 2 * n).astype(I16)
             if trial == 1:
                 x = np.where(rng.random(2 * n) < 0.5, 32767, -32768).astype(I16)
             if trial == 2:
                 x = rng.integers(-300, 300, 2 * n).astype(I16)
+            if trial == 4:                                               # full-scale DC on both rails: every sum saturates or halves
+                x = np.full(2 * n, 32767, I16)
+            if trial == 5:
+                x = np.full(2 * n, -32768, I16)
+            if trial == 6:                                               # Nyquist alternation at full scale
+                x = np.tile(np.array([32767, -32768, -32768, 32767], I16), n // 2)
+            if trial == 7:                                               # one full-scale impulse
+                x = np.zeros(2 * n, I16); x[2 * 37] = -32768; x[2 * 37 + 1] = 32767
+            if trial == 8:                                               # a full-scale complex tone exactly on a bin
+                k = np.arange(n)
+                x = np.stack([np.round(32767 * np.cos(2 * np.pi * 19 * k / n)), np.round(32767 * np.sin(2 * np.pi * 19 * k / n))], 1).astype(I16).reshape(-1)
             r.put(buf, x)
             r.call("cfft_q15", S, buf)
             xs.append(x)
@@ -356,7 +367,16 @@ def kat_fft256iq(im, out, tables):
     iq = synth_iq(40 * 128, 11)
     iq[5 * 128:6 * 128] = np.where(np.random.default_rng(1).random((128, 2)) < 0.5, 32767, -32768)   # one block on the rails
     out["fft256iq_iq"] = iq
-    for tag, window, navg in (("sketch", "hann256", 30), ("default", "blackman_nuttall256", 8), ("avg1", "hann256", 1)):
+    k = np.arange(6 * 128)
+    adv = np.concatenate([
+        np.tile(np.array([[32767, -32768]], I16), (6 * 128, 1)),                                           # full-scale DC
+        np.stack([np.where(k % 2 == 0, 32767, -32768), np.where(k % 2 == 0, -32768, 32767)], 1).astype(I16),   # Nyquist alternation
+        np.stack([np.round(32767 * np.cos(2 * np.pi * 19 * k / 256)), np.round(32767 * np.sin(2 * np.pi * 19 * k / 256))], 1).astype(I16),  # a tone on a bin
+        np.random.default_rng(4).integers(-32768, 32768, (6 * 128, 2)).astype(I16)])                        # full-scale noise
+    out["fft256iq_adv_iq"] = adv
+    for tag, window, navg in (("sketch", "hann256", 30), ("default", "blackman_nuttall256", 8), ("avg1", "hann256", 1), ("adv", "hann256", 2)):
+        if tag == "adv":
+            iq = adv
         r = Ref(im)
         obj = r.alloc(0xa40 + 16)
         r.m.write(obj + 536, 4, im.dtcm_of_offset(TABLES[window][0]))

@@ -265,12 +265,13 @@ def test_oracle_analysers_are_the_images_update_bit_for_bit(kat, oracle):
     from test_audio_nodes import _bind, oracle_fft1024
     from test_spectrum import _olib, oracle_spectra
     lib = _bind(_olib(oracle))
-    iq = kat["fft256iq_iq"]
-    for tag, win, navg in (("sketch", 1, 30), ("default", 3, 8), ("avg1", 1, 1)):
+    for tag, win, navg in (("sketch", 1, 30), ("default", 3, 8), ("avg1", 1, 1), ("adv", 1, 2)):
+        iq = kat["fft256iq_adv_iq"] if tag == "adv" else kat["fft256iq_iq"]     # adv: full-scale DC, Nyquist, a bin tone, noise
         want = kat[f"fft256iq_{tag}_out"]
         got = np.stack(oracle_spectra(lib, iq, navg, win))
         assert np.array_equal(got, want), tag
-        assert np.array_equal(kat[f"fft256iq_{tag}_ticks"], np.arange(navg, 40, navg) if navg > 1 else np.arange(1, 40))
+        nb = len(iq) // 128
+        assert np.array_equal(kat[f"fft256iq_{tag}_ticks"], np.arange(navg, nb, navg) if navg > 1 else np.arange(1, nb))
     x = kat["fft1024_in"]
     for tag, win in (("hann", 1), ("nowindow", 0)):
         assert np.array_equal(oracle_fft1024(lib, x, win), kat[f"fft1024_{tag}_out"]), tag
@@ -594,12 +595,13 @@ def test_gpu_analysers_are_the_images_update_bit_for_bit(rdsp, kat):
     import torch
     from radiodsp_sdr_rx_amd.filters import AnalyzeFFT1024
     from radiodsp_sdr_rx_amd.spectrum import AnalyzeFFT256IQ
-    iq = kat["fft256iq_iq"]
-    dev = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(iq, (NCH,) + iq.shape))).cuda()
-    for tag, win, navg in (("sketch", "AudioWindowHanning256", 30), ("default", None, 8), ("avg1", "AudioWindowHanning256", 1)):
+    for tag, win, navg in (("sketch", "AudioWindowHanning256", 30), ("default", None, 8), ("avg1", "AudioWindowHanning256", 1),
+                           ("adv", "AudioWindowHanning256", 2)):
+        iq = kat["fft256iq_adv_iq"] if tag == "adv" else kat["fft256iq_iq"]
+        dev = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(iq, (NCH,) + iq.shape))).cuda()
         a = AnalyzeFFT256IQ(NCH) if win is None else AnalyzeFFT256IQ(NCH, naverage=navg, window=win)
         got, k = [], 0
-        for nb in (7, 1, 13, 19):
+        for nb in ((7, 1, 13, 19) if tag != "adv" else (5, 1, 11, 7)):
             o = a.update(dev[:, k * 128:(k + nb) * 128].contiguous())
             torch.cuda.synchronize()
             got.append(o.cpu().numpy().view(np.uint16))
