@@ -448,6 +448,48 @@ def test_gpu_setDemodMode_returns_the_engines_tuning_offsets(rdsp, kat):
     assert ch.setDemodMode(rdsp.DEMOD["IQ"]) == 0
 
 
+def test_engine_black_box_facts(oracle):
+    """Not a parity test: the un-vendored AudioSDR engine run as a black box out of the image (tests/golden/
+    make_engine_blackbox.py -> engine_blackbox.npz), so that how this build's stand-ins for rows A2 / A9 differ from it is
+    a set of known numbers (docs/widened_rows.md 6f).  What the engine does, with the sketch's settings (INO:117-139):
+      * SSB conversion gain 1.21 (LSB) / 1.17 (USB) from IQ amplitude to audio amplitude at setOutputGain(0.5) -- this
+        build's Re(y) demodulator gives 0.50;
+      * the other side band 60 dB down or more;
+      * audio2700: -3 dB near 150 Hz and 2.75 kHz (this build: the same edges by design);
+      * AGC: a hang AGC -- output held near 160 ... 230 counts rms over a 30 dB input step, attack within five blocks,
+        and after the signal drops the gain stays down for 0.12 s (fast) / 0.55 s (medium) / more than 0.8 s (slow)
+        before it recovers; this build's AGC has no hang and a target 25 dB higher."""
+    from oracle_lib import OracleChain
+    d = np.load(os.path.join(HERE, "golden", "engine_blackbox.npz"))
+    g = dict(zip(d["audio_hz"].tolist(), d["lsb_gain_vs_audio_hz"].tolist()))
+    assert 1.15 < g[1000.0] < 1.27 and 1.12 < float(d["gain_demod1_+1000"]) < 1.22
+    assert float(d["gain_demod0_-1000"]) < 2e-3 and float(d["gain_demod1_-1000"]) < 2e-3
+    assert g[100.0] < 0.15 * g[1000.0] and 0.6 < g[150.0] / g[1000.0] < 0.8 and 0.5 < g[2800.0] / g[1000.0] < 0.65 and g[4000.0] < 2e-3
+    off = d["agc_rms_mode0"]
+    assert abs(off[60:70].mean() / off[20:30].mean() - 30.0) < 1.0          # AGC off: linear
+    hang = {}
+    for mode in (1, 2, 3):
+        r = d[f"agc_rms_mode{mode}"]
+        pre, loud = r[20:30].mean(), r[60:70].mean()
+        assert 150 < pre < 175 and 215 < loud < 235                           # 30 dB in, 3 dB out
+        after = r[73:]
+        floor = after[:20].mean()
+        hang[mode] = int(np.argmax(after > 1.5 * floor)) + 3 if (after > 1.5 * floor).any() else None
+    assert 30 <= hang[1] <= 55 and 150 <= hang[2] <= 230 and hang[3] is None
+    # this build, same experiment (the oracle; the GPU follows it): conversion gain and AGC level
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_engine_blackbox import block_rms, tone
+    cfg = dict(fs_in=44100.0, decim=1, nco_hz=8390.0, fft_l=256, flo_hz=-2700.0, fhi_hz=-150.0, demod="LSB", output_gain=0.5, iq_balance=1.02)
+    i, q = tone(8390.0 - 1000.0, 0.05, 40 * 128)
+    y = OracleChain(**dict(cfg, agc_mode="off")).process(np.stack([i, q], 1))[0][24 * 128:, 0]
+    assert abs(np.sqrt((y.astype(float) ** 2).mean()) / (0.05 * 32768 / np.sqrt(2)) - 0.50) < 0.01
+    amp = np.concatenate([np.full(30 * 128, 0.01), np.full(40 * 128, 0.3), np.full(100 * 128, 0.01)])
+    i, q = tone(8390.0 - 1000.0, amp, len(amp))
+    r = block_rms(OracleChain(**dict(cfg, agc_mode="fast")).process(np.stack([i, q], 1))[0][:, 0])
+    assert 3900 < r[60:70].mean() < 4200                                      # its target level: 25 dB above the engine's
+
+
 # ---- GPU: the product against the reference's compiled routines ----------------------------------------------------------
 NCH = 3          # the same stream on three channels: every channel must give the reference's answer
 
