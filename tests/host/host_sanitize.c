@@ -62,6 +62,41 @@ static void sink_update(rdsp_node_t *n, void *user) {
 static int g_destroyed;
 static void count_destroy(void *p) { (void)p; g_destroyed++; }
 
+/* the rings of the queues at the sizes of the reference's image (209 / 80), across their wrap-around */
+static void queue_ring_checks(void) {
+  rdsp_graph_t *g = rdsp_graph_create(1);
+  CHECK(g && rdsp_memory(g, 300) == RDSP_OK);
+  rdsp_node_t *in = rdsp_input_node_create(g), *q = rdsp_record_queue_create(g), *qd = rdsp_record_queue_create(g);
+  rdsp_node_t *play = rdsp_play_queue_create(g);
+  CHECK(in && q && qd && play && rdsp_connect(in, 0, q, 0) == RDSP_OK && rdsp_connect(in, 1, qd, 0) == RDSP_OK);
+  rdsp_record_queue_begin(q); /* qd is never begun: it releases what it receives */
+  int16_t ti[RDSP_BLOCK_SAMPLES], tq[RDSP_BLOCK_SAMPLES];
+  memset(tq, 0, sizeof(tq));
+  int next = 0, expect = 0;
+  for (int round = 0; round < 3; round++) {
+    for (int t = 0; t < 230; t++) {
+      for (int i = 0; i < RDSP_BLOCK_SAMPLES; i++) ti[i] = (int16_t)next;
+      CHECK(rdsp_input_node_push(in, ti, tq) == RDSP_OK && rdsp_update_all(g) == RDSP_OK);
+      if (t < 208) next++; /* blocks 208 ... 229 of a round find the ring full and are dropped */
+    }
+    CHECK(rdsp_record_queue_available(q) == 208 && rdsp_memory_usage(g) == 208);
+    for (int k = 0; k < 208; k++) {
+      int16_t *b = rdsp_record_queue_readBuffer(q);
+      CHECK(b && b[5] == (int16_t)expect);
+      expect++;
+      rdsp_record_queue_freeBuffer(q);
+    }
+    CHECK(rdsp_record_queue_available(q) == 0 && rdsp_memory_usage(g) == 0);
+  }
+  for (int round = 0; round < 3; round++) { /* the play queue: 79 fit, the 80th reports; one tick plays one */
+    int n = 0;
+    while (rdsp_play_queue_getBuffer(play) && rdsp_play_queue_playBuffer(play) == RDSP_OK) n++;
+    CHECK(n == (round == 0 ? 79 : 40));
+    for (int t = 0; t < 40; t++) CHECK(rdsp_update_all(g) == RDSP_OK);
+  }
+  rdsp_graph_destroy(g);
+}
+
 static void graph_checks(int nch) {
   rdsp_graph_t *g = rdsp_graph_create(nch);
   CHECK(g && rdsp_graph_channels(g) == nch);
@@ -374,6 +409,7 @@ int main(int argc, char **argv) {
   }
   graph_checks(1);
   graph_checks(7);
+  queue_ring_checks();
   io_checks(argv[1]);
   design_checks();
   table_checks();
