@@ -238,4 +238,32 @@ uint64_t orc_fft256iq_multi(int naverage, int window_id, int n_ch, const int16_t
 #ifdef __cplusplus
 }
 #endif
+/* ---- the reference's AudioSDR engine as its firmware image computes it (oracle/rdsp_engine_oracle.c) ---------------- */
+typedef struct orc_engine orc_engine_t;
+float orc_newlib_expf(float x);
+orc_engine_t *orc_engine_create(const float *biquad_sets15x20, const float *hilbert64);
+void orc_engine_destroy(orc_engine_t *e);
+void orc_engine_update(orc_engine_t *e, const int16_t *i128, const int16_t *q128, int16_t *out128); /* image 0xe730 */
+float orc_engine_setDemodMode(orc_engine_t *e, int mode);   /* INO:139, CTL:337-407 */
+void orc_engine_setAudioFilter(orc_engine_t *e, int id);    /* INO:138, CTL:153-177 */
+void orc_engine_enableAudioFilter(orc_engine_t *e);         /* INO:137 */
+void orc_engine_setInputGain(orc_engine_t *e, float g);     /* INO:133 */
+void orc_engine_setOutputGain(orc_engine_t *e, float g);    /* INO:134 */
+void orc_engine_setIQgainBalance(orc_engine_t *e, float b); /* INO:135 */
+void orc_engine_setMute(orc_engine_t *e, int on);           /* INO:177 */
+void orc_engine_enableAGC(orc_engine_t *e);                 /* INO:120 */
+void orc_engine_setAGCmode(orc_engine_t *e, int mode);      /* INO:121, CTL:200-218 */
+void orc_engine_enableALSfilter(orc_engine_t *e);           /* CTL:259 */
+void orc_engine_disableALSfilter(orc_engine_t *e);          /* INO:125 */
+void orc_engine_setALSfilterNotch(orc_engine_t *e);         /* CTL:260 */
+void orc_engine_setALSfilterPeak(orc_engine_t *e);
+void orc_engine_setALSfilterAdaptive(orc_engine_t *e);      /* CTL:261 */
+void orc_engine_enableNoiseBlanker(orc_engine_t *e);
+void orc_engine_disableNoiseBlanker(orc_engine_t *e);       /* INO:131 */
+void orc_engine_set_tap(orc_engine_t *e, float *buf9x2x128);
+float orc_engine_scalar(const orc_engine_t *e, int which);
+const float *orc_engine_agc_curve(const orc_engine_t *e);
+const float *orc_engine_sine(const orc_engine_t *e);
+const float *orc_engine_als_taps(const orc_engine_t *e);
+
 #endif

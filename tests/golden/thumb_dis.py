@@ -93,6 +93,9 @@ def _dis32(a, hw1, hw2):
         size, l, sign, rn, rt = (hw1 >> 5) & 3, (hw1 >> 4) & 1, (hw1 >> 8) & 1, hw1 & 15, (hw2 >> 12) & 15
         n = ("ldr" if l else "str") + ("s" if sign else "") + ("b", "h", "", "?")[size]
         if rn == 15:
+            if _CODE is not None and size == 2 and l:
+                t = ((a + 4) & ~3) + (hw2 & 0xFFF) * (1 if hw1 & 0x80 else -1)
+                return "%s %s, [pc -> 0x%x] = 0x%08x" % (n, R(rt), t, struct.unpack_from("<I", _CODE, t)[0])
             return "%s %s, [pc, #%s%d]" % (n, R(rt), "" if hw1 & 0x80 else "-", hw2 & 0xFFF)
         if hw1 & 0x80:
             return "%s.w %s, [%s, #%d]" % (n, R(rt), R(rn), hw2 & 0xFFF)
@@ -122,8 +125,12 @@ def _dis32(a, hw1, hw2):
             l, u, rn = (hw1 >> 4) & 1, (hw1 >> 7) & 1, hw1 & 15
             D, Vd = (hw1 >> 6) & 1, (hw2 >> 12) & 15
             reg = ("d%d" % ((D << 4) | Vd)) if cp == 11 else ("s%d" % ((Vd << 1) | D))
+            if rn == 15 and _CODE is not None:
+                t = ((a + 4) & ~3) + ((hw2 & 0xFF) << 2) * (1 if u else -1)
+                v = struct.unpack_from("<d" if cp == 11 else "<f", _CODE, t)[0]
+                return "vldr %s, [pc -> 0x%x] = %.17g" % (reg, t, v)
             return "%s %s, [%s, #%s%d]" % ("vldr" if l else "vstr", reg, R(rn), "" if u else "-", (hw2 & 0xFF) << 2)
-        return "vfp 0x%04x 0x%04x" % (hw1, hw2)
+        return _vfp(a, hw1, hw2)
     if (hw1 & 0xFA00) == 0xF000 and not (hw2 & 0x8000):
         op, s, rn, rd = (hw1 >> 5) & 15, (hw1 >> 4) & 1, hw1 & 15, (hw2 >> 8) & 15
         imm12 = (((hw1 >> 10) & 1) << 11) | (((hw2 >> 12) & 7) << 8) | (hw2 & 0xFF)
@@ -150,10 +157,101 @@ def _dis32(a, hw1, hw2):
         if rn == 15 and op == 2: return "mov%s.w %s, %s%s" % ("s" if s else "", R(rd), R(rm), sh)
         if rd == 15 and s: return "%s.w %s, %s%s" % ({0: "tst", 4: "teq", 8: "cmn", 13: "cmp"}.get(op, n), R(rn), R(rm), sh)
         return "%s%s.w %s, %s, %s%s" % (n, "s" if s else "", R(rd), R(rn), R(rm), sh)
+    if (hw1 & 0xFFD0) in (0xF3C0, 0xF340) and not (hw2 & 0x8000):
+        lsb, w = (((hw2 >> 12) & 7) << 2) | ((hw2 >> 6) & 3), (hw2 & 31) + 1
+        return "%s %s, %s, #%d, #%d" % ("ubfx" if hw1 & 0x80 else "sbfx", R((hw2 >> 8) & 15), R(hw1 & 15), lsb, w)
+    if (hw1 & 0xFFF0) == 0xFAB0 and (hw2 & 0xF0F0) == 0xF080:
+        return "clz %s, %s" % (R((hw2 >> 8) & 15), R(hw2 & 15))
+    if (hw1 & 0xFF80) == 0xFA00 and (hw2 & 0xF0F0) == 0xF000:
+        return "%s%s.w %s, %s, %s" % (("lsl", "lsr", "asr", "ror")[(hw1 >> 5) & 3], "s" if hw1 & 0x10 else "", R((hw2 >> 8) & 15), R(hw1 & 15), R(hw2 & 15))
+    if (hw1 & 0xFF80) == 0xFB00:
+        op1, op2, ra = (hw1 >> 4) & 7, (hw2 >> 4) & 15, (hw2 >> 12) & 15
+        if op1 == 0:
+            n = "mls" if op2 == 1 else ("mul" if ra == 15 else "mla")
+            return "%s %s, %s, %s%s" % (n, R((hw2 >> 8) & 15), R(hw1 & 15), R(hw2 & 15), "" if ra == 15 else ", " + R(ra))
+        return "mul32 op1=%d op2=%d %s, %s, %s, ra=%s" % (op1, op2, R((hw2 >> 8) & 15), R(hw1 & 15), R(hw2 & 15), R(ra))
+    if (hw1 & 0xFF80) == 0xFB80:
+        n = {0: "smull", 1: "sdiv", 2: "umull", 3: "udiv", 4: "smlal", 6: "umlal"}.get((hw1 >> 4) & 7, "mul64?")
+        return "%s %s, %s, %s, %s" % (n, R((hw2 >> 12) & 15), R((hw2 >> 8) & 15), R(hw1 & 15), R(hw2 & 15))
     return "?32 0x%04x 0x%04x" % (hw1, hw2)
 
 
+def _vfp(a, hw1, hw2):
+    """the VFP / FPv5 encodings the image uses (data processing, transfers, multiple loads and stores)"""
+    R = lambda n: ("sp", "lr", "pc")[n - 13] if n >= 13 else "r%d" % n
+    cp = (hw2 >> 8) & 15
+    dbl = cp == 11
+    D, Vn, Vd = (hw1 >> 6) & 1, hw1 & 15, (hw2 >> 12) & 15
+    N, M, Vm = (hw2 >> 7) & 1, (hw2 >> 5) & 1, hw2 & 15
+    if dbl: d, n, m = "d%d" % ((D << 4) | Vd), "d%d" % ((N << 4) | Vn), "d%d" % ((M << 4) | Vm)
+    else: d, n, m = "s%d" % ((Vd << 1) | D), "s%d" % ((Vn << 1) | N), "s%d" % ((Vm << 1) | M)
+    sd, sm = "s%d" % ((Vd << 1) | D), "s%d" % ((Vm << 1) | M)
+    sz = ".f64" if dbl else ".f32"
+    if (hw1 & 0xFF00) == 0xFE00:
+        if (hw1 & 0xFF80) == 0xFE00 and (hw2 & 0x50) == 0:
+            return "vsel%s%s %s, %s, %s" % (("eq", "vs", "ge", "gt")[(hw1 >> 4) & 3], sz, d, n, m)
+        if (hw1 & 0xFFB0) == 0xFE80 and (hw2 & 0x10) == 0:
+            return "%s%s %s, %s, %s" % ("vminnm" if hw2 & 0x40 else "vmaxnm", sz, d, n, m)
+        if (hw1 & 0xFFBC) == 0xFEBC and (hw2 & 0x50) == 0x40:
+            return "vcvt%s.%s32%s %s, %s" % ("anpm"[hw1 & 3], "s" if hw2 & 0x80 else "u", sz, sd, m)
+        if (hw1 & 0xFFBC) == 0xFEB8 and (hw2 & 0x50) == 0x40:
+            return "vrint%s%s %s, %s" % ("anpm"[hw1 & 3], sz, d, m)
+        return "fpv5 0x%04x 0x%04x" % (hw1, hw2)
+    if (hw1 & 0xEF00) == 0xEE00:
+        if hw2 & 0x10:
+            rt, l, k = (hw2 >> 12) & 15, (hw1 >> 4) & 1, (hw1 >> 5) & 7
+            if cp == 10 and k == 0:
+                return ("vmov %s, s%d" if l else "vmov s%d, %s") % ((R(rt), (Vn << 1) | N) if l else ((Vn << 1) | N, R(rt)))
+            if cp == 10 and k == 7:
+                return ("vmrs %s, fpscr" % ("APSR_nzcv" if rt == 15 else R(rt))) if l else "vmsr fpscr, %s" % R(rt)
+            if cp == 11:
+                dd, x = (N << 4) | Vn, (hw1 >> 5) & 1
+                return ("vmov %s, d%d[%d]" % (R(rt), dd, x)) if l else ("vmov d%d[%d], %s" % (dd, x, R(rt)))
+            return "vfp-xfer 0x%04x 0x%04x" % (hw1, hw2)
+        o1, o2, op = (hw1 >> 7) & 1, (hw1 >> 4) & 3, (hw2 >> 6) & 1
+        if (o1, o2) != (1, 3):
+            nm = {(0, 0): ("vmla", "vmls"), (0, 1): ("vnmls", "vnmla"), (0, 2): ("vmul", "vnmul"), (0, 3): ("vadd", "vsub"),
+                  (1, 0): ("vdiv", "vdiv?"), (1, 1): ("vfnms", "vfnma"), (1, 2): ("vfma", "vfms")}[(o1, o2)][op]
+            return "%s%s %s, %s, %s" % (nm, sz, d, n, m)
+        if op == 0:
+            imm8 = ((hw1 & 15) << 4) | (hw2 & 15)
+            sg, b, rest = (imm8 >> 7) & 1, (imm8 >> 6) & 1, imm8 & 0x3F
+            bits = (sg << 31) | ((1 - b) << 30) | ((0x1F if b else 0) << 25) | (rest << 19)
+            return "vmov%s %s, #%g" % (sz, d, struct.unpack("<f", struct.pack("<I", bits))[0])
+        opc2, b7 = hw1 & 15, (hw2 >> 7) & 1
+        if opc2 == 0: return "%s%s %s, %s" % ("vabs" if b7 else "vmov", sz, d, m)
+        if opc2 == 1: return "%s%s %s, %s" % ("vsqrt" if b7 else "vneg", sz, d, m)
+        if opc2 in (4, 5): return "vcmp%s%s %s, %s" % ("e" if b7 else "", sz, d, "#0" if opc2 == 5 else m)
+        if opc2 == 7 and b7:
+            return ("vcvt.f32.f64 %s, %s" % (sd, m)) if dbl else ("vcvt.f64.f32 d%d, %s" % ((D << 4) | Vd, m))
+        if opc2 == 8: return "vcvt%s.%s32 %s, %s" % (sz, "s" if b7 else "u", d, sm)
+        if opc2 in (12, 13): return "vcvt%s.%s32%s %s, %s" % ("" if b7 else "r", "s" if opc2 == 13 else "u", sz, sd, m)
+        if opc2 in (10, 11, 14, 15):
+            size = 32 if b7 else 16
+            fb = size - (((hw2 & 15) << 1) | ((hw2 >> 5) & 1))
+            t = "%s%d" % ("u" if opc2 & 1 else "s", size)
+            return ("vcvt.%s%s %s, %s, #%d" % (t, sz, d, d, fb)) if opc2 & 4 else ("vcvt%s.%s %s, %s, #%d" % (sz, t, d, d, fb))
+        return "vfp-other 0x%04x 0x%04x" % (hw1, hw2)
+    p, u, w, l, rn, imm8 = (hw1 >> 8) & 1, (hw1 >> 7) & 1, (hw1 >> 5) & 1, (hw1 >> 4) & 1, hw1 & 15, hw2 & 0xFF
+    if p == 0 and u == 0 and w == 0:
+        rt, rt2 = (hw2 >> 12) & 15, hw1 & 15
+        regs = ("d%d" % ((M << 4) | Vm)) if dbl else ("s%d, s%d" % ((Vm << 1) | M, ((Vm << 1) | M) + 1))
+        return ("vmov %s, %s, %s" % (R(rt), R(rt2), regs)) if l else ("vmov %s, %s, %s" % (regs, R(rt), R(rt2)))
+    nregs = imm8 // 2 if dbl else imm8
+    first = ((D << 4) | Vd) if dbl else ((Vd << 1) | D)
+    pre = "d" if dbl else "s"
+    lst = "{%s%d-%s%d}" % (pre, first, pre, first + nregs - 1)
+    if rn == 13 and w and ((l and u) or (not l and not u)):
+        return "%s %s" % ("vpop" if l else "vpush", lst)
+    return "%s%s %s%s, %s" % ("vldm" if l else "vstm", "ia" if u else "db", R(rn), "!" if w else "", lst)
+
+
+_CODE = None
+
+
 def listing(code, start, end):
+    global _CODE
+    _CODE = code
     a = start
     out = []
     while a < end:
