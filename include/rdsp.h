@@ -620,6 +620,53 @@ typedef struct {
 void rdsp_synth_iq(int16_t *dst, int ch0, int n_ch, uint64_t t0, int n_samples,
                    const rdsp_synth_config_t *cfg, int n_threads);
 
+/* ---- `AudioSDR SDR;` as the reference's engine computes it (INO:54; wired INO:81-86) ------------------------------
+ * The engine (Derek Rowell's AudioSDR library) is not in the reference tree; its compiled code is, in
+ * pre_compiled/RadioDSP_SDR_RX.ino.hex.  rdsp_engine_t follows that code (AudioSDR::update, ITCM 0xe730, and the setters
+ * the sketch calls) for n_channels receivers: on the same int16 IQ blocks it returns the int16 audio the image's update()
+ * returns (tests/test_engine_kat.py; csrc/rdsp_engine.hip describes the signal path and the kernels).  Native rate only:
+ * 44.1 kHz, one 128-sample block in, one out, no decimation.  The rdsp_sdr_* setters above belong to rdsp_chain_t, this
+ * build's own many-channel receiver with a decimator in front; these are the reference's.  Numbers are the engine's
+ * (`mode`: 0 LSBmode, 1 USBmode, 2 CW_LSBmode, 3 CW_USBmode, 4 AMmode, 5 SAMmode, as the compiled tuningMode() passes
+ * them, CTL:337-407; audio filter ids as the compiled filterMode() passes them: 0 audioAM, 1 audioCW, 3 audio2100,
+ * 6 audio2700, 8 audio3100, 10 = none, CTL:153-177; AGC modes 0 off ... 3 slow, CTL:200-218). */
+typedef struct rdsp_engine rdsp_engine_t;
+int rdsp_engine_create(int n_channels, int device, int max_blocks_per_call, rdsp_engine_t **out); /* AudioSDR::AudioSDR */
+void rdsp_engine_destroy(rdsp_engine_t *e);
+int rdsp_engine_reset(rdsp_engine_t *e, void *stream); /* signal state as the constructor leaves it; settings kept */
+/* The engine's tables without a closed form, in the image's order: fifteen sets of four {b0, b1, b2, a1, a2} sections
+ * (arm_biquad_cascade_df1_f32 layout) and the 64 taps of one side of its Hilbert transformer, outermost first.
+ * rdsp_engine_update fails with RDSP_ERR_NOT_READY until they are loaded. */
+int rdsp_engine_load_tables(rdsp_engine_t *e, const float *biquad_sets15x20, const float *hilbert64);
+int rdsp_engine_enableAGC(rdsp_engine_t *e);                       /* INO:120 */
+int rdsp_engine_setAGCmode(rdsp_engine_t *e, int mode);            /* INO:121, CTL:200-218 */
+int rdsp_engine_enableALSfilter(rdsp_engine_t *e);                 /* CTL:259 (clears the filter) */
+int rdsp_engine_disableALSfilter(rdsp_engine_t *e);                /* INO:125 */
+int rdsp_engine_setALSfilterNotch(rdsp_engine_t *e);               /* CTL:260 */
+int rdsp_engine_setALSfilterPeak(rdsp_engine_t *e);                /* backup/RadioDSP_SDR_RX_Conv.ino:665 */
+int rdsp_engine_setALSfilterAdaptive(rdsp_engine_t *e);            /* CTL:261 */
+int rdsp_engine_enableNoiseBlanker(rdsp_engine_t *e);              /* backup/RadioDSP_SDR_RX_Conv.ino:1259; the constructor's default */
+int rdsp_engine_disableNoiseBlanker(rdsp_engine_t *e);             /* INO:131 */
+int rdsp_engine_setInputGain(rdsp_engine_t *e, float g);           /* INO:133 */
+int rdsp_engine_setOutputGain(rdsp_engine_t *e, float g);          /* INO:134 */
+int rdsp_engine_setIQgainBalance(rdsp_engine_t *e, float b);       /* INO:135 */
+int rdsp_engine_enableAudioFilter(rdsp_engine_t *e);               /* INO:137 */
+int rdsp_engine_setAudioFilter(rdsp_engine_t *e, int id);          /* INO:138, CTL:153-177 */
+float rdsp_engine_setDemodMode(rdsp_engine_t *e, int mode);        /* INO:139: returns TuningOffset, Hz */
+int rdsp_engine_setMute(rdsp_engine_t *e, int on);                 /* INO:177 */
+/* AudioSDR::update() for n_blocks consecutive blocks of every channel, stream-ordered.  d_iq: [ch][t] int16 pairs (I, Q),
+ * in_stride pairs between channel rows; d_lr: [ch][t] int16 pairs = the engine's two outputs (the same block on both). */
+int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, int n_blocks, int16_t *d_lr,
+                       size_t out_stride, void *stream);
+int rdsp_engine_channels(const rdsp_engine_t *e);
+int rdsp_engine_device(const rdsp_engine_t *e);
+int rdsp_engine_max_blocks(const rdsp_engine_t *e);
+/* [n_channels][8]: oscillator phase, AGC gain, AGC envelope, hang counter, AGC-active flag, PLL frequency estimate (Hz),
+ * PLL lock flag, blanker-hit flag */
+int rdsp_engine_get_scalars(rdsp_engine_t *e, float *host_out, void *stream);
+const float *rdsp_engine_agc_curve(const rdsp_engine_t *e); /* host copy, 130 entries (the engine uses 129) */
+const float *rdsp_engine_sine_table(const rdsp_engine_t *e); /* host copy, 257 entries */
+
 #ifdef __cplusplus
 }
 #endif

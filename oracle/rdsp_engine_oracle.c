@@ -247,7 +247,7 @@ orc_engine_t *orc_engine_create(const float *biquad_sets15x20, const float *hilb
   e->if_centre = 6890.0f; e->ssb_band = 3000.0f; e->cw_band = 1000.0f;
   e->input_gain = e->gain_i = e->gain_q = e->iq_balance = e->output_gain = 1.0f;
   e->als_taps = 55; e->als_delay = 3; e->als_mu = 0.5f; e->als_on = 0; e->als_notch = 1; e->als_adaptive = 1;
-  e->agc_makeup = 10.0f;
+  e->agc_makeup = 10.0f; e->agc_active = 1; /* +0x103c: the constructor's value, until the AGC first runs */
   e->nb_keep = 0.995f; e->nb_new = bits_f(0x3ba3d700); e->nb_ratio = 1.2f; e->nb_avg = 10.0f; e->nb_before = e->nb_after = 10; e->nb_on = 1;
   e->sam_keep = 0.995f; e->sam_new = bits_f(0x3ba3d700); e->sam_hz_per_rad = bits_f(0x45db55dd); e->sam_lock_lo = 3890.0f;
   e->sam_lock_hi = 9890.0f; e->sam_hz = 1890.0f; e->sam_wn = bits_f(0x3e50fac7); e->sam_zeta = 2.0f; e->sam_kd = e->sam_ko = 1.0f;
@@ -482,4 +482,62 @@ void orc_engine_update(orc_engine_t *e, const int16_t *i128, const int16_t *q128
   tap(e, 8, A, 0);
   for (int i = 0; i < 128; i++) /* 0xebfa: times 32767, toward zero, the low half-word stored */
     out128[i] = e->mute ? 0 : (int16_t)(uint16_t)trunc_s32((double)(A[i] * e->output_gain) * 32767.0);
+}
+
+/* ---- AudioSDRpreProcessor (`AudioSDRpreProcessor preProcessor;`, INO:53, wired INO:71-72, :117-118) ----------------------
+ * ::update at ITCM 0xee88, ::startAutoI2SerrorDetection at 0xf084; the object is set up inline by the sketch's static
+ * initialiser (0x93e8 ... 0x9442).  It repairs the one-sample slip between the I and Q rails that the Teensy's I2S input
+ * can start up with: while detection is on, each block goes through a 128-point complex FFT; if the strongest bin
+ * (5 ... 122) stands more than 10 x above the mean and its mirror image is less than 20 dB down, a bad-count rises, and at
+ * the eleventh bad block in a row the correction moves on (none -> I delayed -> Q delayed -> none); after 1000 checked
+ * blocks detection switches itself off.  The FFT here is the oracle's arm_cfft_f32 (5e-7 from the image's,
+ * tests/test_firmware_kat.py): the decisions compare ratios against 10, so a last-bit difference matters only on a
+ * knife edge; the int16 blocks it hands on are exact given the same decisions. */
+struct orc_preproc { int16_t slip, saved, bad, checks; uint8_t swap, detect; float buf[256]; };
+orc_preproc_t *orc_preproc_create(void) { return (orc_preproc_t *)calloc(1, sizeof(orc_preproc_t)); }
+void orc_preproc_destroy(orc_preproc_t *p) { free(p); }
+void orc_preproc_startAutoI2SerrorDetection(orc_preproc_t *p) { p->slip = 0; p->detect = 1; p->bad = 0; p->checks = 0; } /* 0xf084 */
+void orc_preproc_swapIQ(orc_preproc_t *p, int on) { p->swap = (uint8_t)(on != 0); } /* INO:118; not in the image: the flag at +1072 */
+int orc_preproc_state(const orc_preproc_t *p, int which) { return which == 0 ? p->slip : which == 1 ? p->bad : which == 2 ? p->checks : p->detect; }
+void orc_preproc_update(orc_preproc_t *p, int16_t *i128, int16_t *q128) {
+  if (p->slip == 1 || p->slip == -1) { /* 0xefd4 / 0xf040: one rail a sample late, the last sample carried to the next block */
+    int16_t *d = p->slip == 1 ? i128 : q128;
+    const int16_t last = d[127];
+    memmove(d + 1, d, 127 * sizeof(int16_t));
+    d[0] = p->saved;
+    p->saved = last;
+  }
+  if (p->detect) {
+    for (int k = 0; k < 128; k++) { p->buf[2 * k] = (float)i128[k] / 32767.0f; p->buf[2 * k + 1] = (float)q128[k] / 32767.0f; }
+    orc_cfft_f32(p->buf, 128, 0);
+    orc_cmplx_mag_f32(p->buf, p->buf, 128);
+    float top = 0.0f, sum = 0.0f;
+    int at = 0;
+    for (int k = 5; k < 123; k++) {
+      sum = sum + p->buf[k];
+      if (p->buf[k] > top) { top = p->buf[k]; at = k; }
+    }
+    const float mean = sum / 118.0f;
+    int checks = p->checks;
+    if ((double)top > (double)mean * 10.0) {
+      const float image = p->buf[128 - at];
+      if (top / image < 10.0f) {
+        p->bad = (int16_t)(p->bad + 1);
+        if (p->bad > 10) {
+          int s = (int16_t)(p->slip + 1);
+          p->bad = 0;
+          if (s > 1) s = -1;
+          p->slip = (int16_t)s;
+          checks = 1;
+        } else checks = (int16_t)(checks + 1);
+      } else {
+        checks = (int16_t)(checks + 1);
+        p->bad = 0;
+      }
+      p->checks = (int16_t)checks;
+    }
+    if (checks > 1000) p->detect = 0;
+  }
+  if (p->swap)
+    for (int k = 0; k < 128; k++) { const int16_t t = i128[k]; i128[k] = q128[k]; q128[k] = t; }
 }

@@ -266,4 +266,13 @@ const float *orc_engine_agc_curve(const orc_engine_t *e);
 const float *orc_engine_sine(const orc_engine_t *e);
 const float *orc_engine_als_taps(const orc_engine_t *e);
 
+/* AudioSDRpreProcessor, INO:53,117-118 (image 0xee88, 0xf084) */
+typedef struct orc_preproc orc_preproc_t;
+orc_preproc_t *orc_preproc_create(void);
+void orc_preproc_destroy(orc_preproc_t *p);
+void orc_preproc_startAutoI2SerrorDetection(orc_preproc_t *p);
+void orc_preproc_swapIQ(orc_preproc_t *p, int on);
+int orc_preproc_state(const orc_preproc_t *p, int which); /* 0 slip (-1, 0, 1), 1 bad count, 2 checked blocks, 3 detecting */
+void orc_preproc_update(orc_preproc_t *p, int16_t *i128, int16_t *q128);
+
 #endif

@@ -258,6 +258,33 @@ SYMBOLS = [
     ("rdsp_fft1024_read_range", _f, [C.POINTER(C.c_uint16), C.c_uint, C.c_uint]),
     ("rdsp_fft1024_node_read", _f, [_vp, _i, C.c_uint]),
     ("rdsp_fft1024_node_read_range", _f, [_vp, _i, C.c_uint, C.c_uint]),
+    ("rdsp_engine_create", _i, [_i, _i, _i, C.POINTER(_vp)]),
+    ("rdsp_engine_destroy", None, [_vp]),
+    ("rdsp_engine_reset", _i, [_vp, _vp]),
+    ("rdsp_engine_load_tables", _i, [_vp, _f32p, _f32p]),
+    ("rdsp_engine_enableAGC", _i, [_vp]),
+    ("rdsp_engine_setAGCmode", _i, [_vp, _i]),
+    ("rdsp_engine_enableALSfilter", _i, [_vp]),
+    ("rdsp_engine_disableALSfilter", _i, [_vp]),
+    ("rdsp_engine_setALSfilterNotch", _i, [_vp]),
+    ("rdsp_engine_setALSfilterPeak", _i, [_vp]),
+    ("rdsp_engine_setALSfilterAdaptive", _i, [_vp]),
+    ("rdsp_engine_enableNoiseBlanker", _i, [_vp]),
+    ("rdsp_engine_disableNoiseBlanker", _i, [_vp]),
+    ("rdsp_engine_setInputGain", _i, [_vp, _f]),
+    ("rdsp_engine_setOutputGain", _i, [_vp, _f]),
+    ("rdsp_engine_setIQgainBalance", _i, [_vp, _f]),
+    ("rdsp_engine_enableAudioFilter", _i, [_vp]),
+    ("rdsp_engine_setAudioFilter", _i, [_vp, _i]),
+    ("rdsp_engine_setDemodMode", _f, [_vp, _i]),
+    ("rdsp_engine_setMute", _i, [_vp, _i]),
+    ("rdsp_engine_update", _i, [_vp, _vp, _sz, _i, _vp, _sz, _vp]),
+    ("rdsp_engine_channels", _i, [_vp]),
+    ("rdsp_engine_device", _i, [_vp]),
+    ("rdsp_engine_max_blocks", _i, [_vp]),
+    ("rdsp_engine_get_scalars", _i, [_vp, _f32p, _vp]),
+    ("rdsp_engine_agc_curve", _f32p, [_vp]),
+    ("rdsp_engine_sine_table", _f32p, [_vp]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
 

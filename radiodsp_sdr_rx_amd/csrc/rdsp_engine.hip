@@ -1,0 +1,755 @@
+/*
+ * rdsp_engine.hip -- `AudioSDR SDR;` (RadioDSP_SDR_RX.ino:54; wired :81-86, configured :117-139, driven from
+ * RDSP_controls.h:149-423) for n_channels receivers on one GPU, computing what the reference's engine computes.
+ *
+ * The engine is Derek Rowell's AudioSDR library, which is not in the reference tree; what the reference holds of it is
+ * its compiled code in pre_compiled/RadioDSP_SDR_RX.ino.hex (AudioSDR::update at ITCM 0xe730).  The arithmetic below
+ * follows that code stage by stage -- which products are rounded before they are added, which are fused, where it widens
+ * to double, its truncating conversions -- so that, on the same int16 IQ, this object returns the int16 audio the
+ * image's update() returns (tests/test_engine_kat.py: the known answers are the image's own, recorded under the
+ * interpreter of tests/golden/).  It is a low-IF receiver: IQ / 32767 x gains -> [impulse blanker] -> IF band-pass
+ * (4 biquad sections per rail) -> table oscillator shifts the carrier to 0 Hz -> I delayed 128 samples, Q through a
+ * 257-tap Hilbert transformer, sum or difference picks the side band  (AM: second IF pass, shift by the IF, low-pass,
+ * envelope; SAM: a PLL on the IF signal with the envelope detector as its out-of-lock fallback) -> audio band-pass
+ * -> hang AGC (peak envelope, gain by a curve) -> ALS line enhancer (delayed-input LMS) -> x output gain x 32767.
+ *
+ * Mapping to the machine (every stage but the Hilbert transformer is a recursion in time, so the parallel axes are
+ * channels, rails and -- for the transformer -- samples):
+ *   rdsp_engine_front_kernel   one lane per (channel, rail), 32 channels per one-wave workgroup.  int16 IQ rows come in
+ *                              through an LDS tile (coalesced 256-byte row segments; a lane then walks its row at a
+ *                              129-word pitch, conflict-free), the two lanes of a channel trade samples through the
+ *                              tile, results leave the same way into a per-channel ring in HBM.
+ *   rdsp_engine_hilbert_kernel one lane per output sample: 64 fused multiply-adds on an LDS window of the ring,
+ *                              in the image's tap order.
+ *   rdsp_engine_tail_kernel    one lane per channel, 64 per workgroup: audio cascade, AGC, ALS, pack; rows through LDS.
+ * The three launches of a call are stream-ordered; a call takes any number of 128-sample blocks up to the engine's
+ * max_blocks_per_call.  HBM traffic is 8 B per sample of algorithm (int16 IQ in, int16 L = R out) plus 28 B of float
+ * intermediates (the ring and the audio row): the path is bound by the latency of its recursions, not by bandwidth.
+ *
+ * Three of the engine's tables have no closed form (fifteen sets of four biquad sections, 64 Hilbert taps): the host
+ * loads them (rdsp_engine_load_tables; tests take them from tests/golden/firmware_tables.npz); update() refuses to run
+ * without them.  The sine table and the AGC's gain curve are generated here the way the library generates them.
+ *
+ * Compiled with -ffp-contract=off: every fused operation below is written as one (fmaf / fma).
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rdsp_host.h"
+#include "rdsp_sync.h"
+
+namespace {
+
+constexpr int BS = RDSP_BLOCK_SAMPLES;
+constexpr int PITCH = BS + 1;
+constexpr float TWO_PI_F = 6.2831854820251465f;   /* the float the image holds for 2 pi */
+constexpr float RAD_PER_HZ = 0.00014247586659621447f; /* 2 pi / 44100, its float */
+
+/* per-channel state, floats (ints bit-cast): [channel][NF] */
+enum { ST_PRE = 0, ST_AM = 32, ST_AUDIO = 64, ST_NCO = 80, ST_AMPH, ST_SAM_COS, ST_SAM_SIN, ST_SAM_U, ST_SAM_ERR, ST_SAM_HZ,
+       ST_SAM_PH, ST_SAM_LOCK, ST_AGC_ENV, ST_AGC_GAIN, ST_AGC_HANG, ST_AGC_ACTIVE, ST_NB_AVG, ST_NB_HIT, ST_NB_LAST, NF = 96 };
+enum { RESET_PRE = 1, RESET_AUDIO = 2, RESET_ALS = 4 };
+constexpr int ALS_TAPS = 55, ALS_DELAY = 3, ALS_WPITCH = 64; /* the constructor's values; the image has no setter for them */
+constexpr int ALS_WORDS = 256 + ALS_WPITCH;                /* per channel in HBM: the 256-sample line, then the taps */
+constexpr int NB_WORDS = 2 * 3 * 384;                      /* per channel and lane: I line, Q line, mask */
+
+struct EngParams {
+  const int32_t *iq; size_t in_stride;   /* [ch][t] words: I | Q << 16 */
+  int32_t *out; size_t out_stride;       /* [ch][t] words: L | R << 16 */
+  int n_channels, n_blocks;
+  float *st;
+  float *ring_i, *ring_q; uint32_t ring_size, pos; /* [ch][ring_size], power of two; pos = where this call's first sample goes */
+  float *audio; size_t audio_stride;     /* [ch][max samples per call] */
+  float *nb, *als;
+  const float *sets, *hilbert, *sine, *curve;
+  int mode, mute, audio_on, agc_on, als_notch, als_adaptive, resets;
+  int pre_set, audio_set;
+  float gain_i, gain_q, output_gain, tuning_offset, if_centre;
+  float agc_attack_a, agc_attack_b, agc_decay_a, agc_decay_b, agc_makeup; int agc_hang_time;
+  float nb_keep, nb_new, nb_ratio; int nb_before, nb_after;
+  float sam_keep, sam_new, sam_hz_per_rad, sam_lock_lo, sam_lock_hi, sam_ga, sam_gb;
+};
+
+__device__ __forceinline__ int trunc_s32(double x) { /* VCVT.S32.F64 */
+  if (!(x == x)) return 0;
+  if (x >= 2147483647.0) return 2147483647;
+  if (x <= -2147483648.0) return (int)0x80000000;
+  return (int)x;
+}
+
+/* arm_biquad_cascade_df1_f32 for one sample through four sections held in registers: products rounded, summed left to right */
+struct Cascade {
+  float c[20], s[16];
+  __device__ __forceinline__ void load(const float *coef, const float *state, bool clear) {
+#pragma unroll
+    for (int i = 0; i < 20; i++) c[i] = coef[i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = clear ? 0.0f : state[i];
+  }
+  __device__ __forceinline__ void store(float *state) const {
+#pragma unroll
+    for (int i = 0; i < 16; i++) state[i] = s[i];
+  }
+  __device__ __forceinline__ float run(float v) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float *cf = c + 5 * k;
+      float *st = s + 4 * k; /* x1 x2 y1 y2 */
+      float y = cf[0] * v;
+      y = y + cf[1] * st[0];
+      y = y + cf[2] * st[1];
+      y = y + cf[3] * st[2];
+      y = y + cf[4] * st[3];
+      st[1] = st[0]; st[0] = v; st[3] = st[2]; st[2] = y;
+      v = y;
+    }
+    return v;
+  }
+};
+
+/* the oscillator: sin of a phase in [0, 2 pi) by linear interpolation in the 256-step table, through double as the image does */
+__device__ __forceinline__ float table_sin(const float *sine, float ph) {
+  const int idx = trunc_s32(((double)ph * 65535.0) / (double)TWO_PI_F);
+  const int hi = (idx >> 8) & 0xff;
+  const float lo = (float)(unsigned)(idx & 0xff);
+  const float t0 = sine[hi], t1 = sine[hi + 1];
+  return (float)fma((double)((t1 - t0) * lo), 0.00390625, (double)t0);
+}
+struct Osc { /* one step of the frequency shifter's phase (0xe94e / 0xd600): cos, sin of the current phase, then advance */
+  float ph;
+  __device__ __forceinline__ void step(const float *sine, float inc, float &c, float &s) {
+    float pc = (float)((double)ph + 1.5707963267948966);
+    if (pc >= TWO_PI_F) pc -= TWO_PI_F;
+    if (pc < 0.0f) pc += TWO_PI_F;
+    c = table_sin(sine, pc);
+    float ps = ph >= TWO_PI_F ? ph - TWO_PI_F : ph;
+    ph = ph + inc;
+    if (ps < 0.0f) ps += TWO_PI_F;
+    s = table_sin(sine, ps);
+    if (ph > TWO_PI_F) ph -= TWO_PI_F;
+    else if (ph < 0.0f) ph += TWO_PI_F;
+  }
+};
+__device__ __forceinline__ float quick_root_guess(float p) { return __uint_as_float((__float_as_uint(p) >> 1) + 0x1fa00000u + 0x1b4000u + 3886u); }
+__device__ __forceinline__ float quick_sqrt1(float p) { const float g = quick_root_guess(p); return (p / g + g) * 0.5f; }
+__device__ __forceinline__ float quick_sqrt2(float p) { const float y = quick_sqrt1(p); return (p / y + y) * 0.5f; }
+
+/* rows of a tile <-> rows in HBM, 64 lanes: each row segment is one coalesced 256-byte access */
+template <typename T>
+__device__ __forceinline__ void rows_in(T (*tile)[PITCH], const T *base, size_t stride, int row0, int n_rows, int rows_valid, int lane) {
+  for (int r = 0; r < n_rows; r++) {
+    const bool ok = row0 + r < rows_valid;
+    const T *src = base + (size_t)(row0 + (ok ? r : 0)) * stride;
+    tile[r][lane] = ok ? src[lane] : T(0);
+    tile[r][lane + 64] = ok ? src[lane + 64] : T(0);
+  }
+}
+
+/* ---- front: conversion, blanker, IF filter, frequency shift (SSB / CW) or the AM / SAM detectors ---------------------- */
+template <bool NB>
+__global__ __launch_bounds__(64) void rdsp_engine_front_kernel(const EngParams p) {
+  __shared__ int32_t tin[32][PITCH];
+  __shared__ float tf[64][PITCH];
+  const int lane = threadIdx.x, rail = lane & 1;
+  const int c0 = blockIdx.x * 32, cl = lane >> 1;
+  const bool valid = c0 + cl < p.n_channels;
+  const int ch = valid ? c0 + cl : p.n_channels - 1;
+  float *st = p.st + (size_t)ch * NF;
+  const bool ssb = p.mode <= 3 || p.mode == 6, am = p.mode == 4 || p.mode == 5;
+  Cascade pre, amf;
+  pre.load(p.sets + 20 * p.pre_set, st + ST_PRE + 16 * rail, (p.resets & RESET_PRE) != 0);
+  if (am) amf.load(p.sets + 20 * 13, st + ST_AM + 16 * rail, false);
+  Osc nco{st[ST_NCO]}, amo{st[ST_AMPH]};
+  float sam_c = st[ST_SAM_COS], sam_s = st[ST_SAM_SIN], sam_u = st[ST_SAM_U], sam_err = st[ST_SAM_ERR], sam_hz = st[ST_SAM_HZ],
+        sam_ph = st[ST_SAM_PH];
+  int sam_locked = __float_as_int(st[ST_SAM_LOCK]);
+  float nb_avg = st[ST_NB_AVG], nb_last = st[ST_NB_LAST];
+  int nb_hit = __float_as_int(st[ST_NB_HIT]);
+  const double gain = (double)(rail ? p.gain_q : p.gain_i);
+  const float nco_inc = -(p.tuning_offset * RAD_PER_HZ), am_inc = -p.if_centre * RAD_PER_HZ;
+  float *row = tf[lane];
+  const float *other = tf[lane ^ 1];
+
+  for (int b = 0; b < p.n_blocks; b++) {
+    rows_in<int32_t>(tin, p.iq + (size_t)b * BS, p.in_stride, c0, 32, p.n_channels, lane);
+    wg_sync<1>();
+    for (int t = 0; t < BS; t++) { /* 0xe7b4: / 32767 and the rail's gain, in double */
+      const int w = tin[cl][t];
+      const int v = rail ? (w >> 16) : (int)(int16_t)(w & 0xffff);
+      row[t] = (float)(((double)v / 32767.0) * gain);
+    }
+    if constexpr (NB) { /* 0xe14c: two blocks of delay; |I + jQ| against its running average; blanking mask with a taper.
+                         * Each lane keeps its own copy of both rails' lines and of the mask (the partner's new samples come
+                         * out of the tile), so nothing crosses lanes through HBM */
+      float *li = p.nb + ((size_t)ch * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768;
+      wg_sync<1>();
+      nb_hit = 0;
+      for (int i = 0; i < 256; i++) { li[i] = li[i + 128]; lq[i] = lq[i + 128]; mask[i] = mask[i + 128]; }
+      for (int i = 0; i < 128; i++) {
+        const float mine = row[i], theirs = other[i];
+        li[256 + i] = rail ? theirs : mine; lq[256 + i] = rail ? mine : theirs; mask[256 + i] = 1.0f;
+      }
+      for (int n = 78; n < 256; n++) {
+        const float limit = nb_avg * p.nb_ratio;
+        const float vi = li[n], vq = lq[n];
+        nb_last = quick_sqrt1(fmaf(vi, vi, vq * vq));
+        if (limit < nb_last) {
+          if (-p.nb_before <= p.nb_after)
+            for (int j = n - p.nb_before; j <= n + p.nb_after; j++) mask[j] = 0.0f;
+          nb_hit = 1;
+        }
+        nb_avg = fmaf(nb_avg, p.nb_keep, nb_last * p.nb_new);
+      }
+      const float taper[7] = {0.933f, 0.75f, 0.5f, 0.25f, 0.067f, 0.0f, 0.0f};
+      for (int i = 128; i < 256; i++)
+        if (mask[i] == 1.0f && mask[i - 1] == 0.0f)
+          for (int j = 0; j < 7; j++) mask[i - 7 + j] = taper[j];
+      wg_sync<1>();
+      for (int i = 0; i < 128; i++) row[i] = mask[i] * (rail ? lq[i] : li[i]);
+    }
+    for (int t = 0; t < BS; t++) row[t] = pre.run(row[t]);
+    wg_sync<1>();
+    if (ssb) {
+      for (int t = 0; t < BS; t++) { /* 0xe94e: (I + jQ) e^{j phase}, phase falling by the tuning offset */
+        const float mine = row[t], theirs = other[t];
+        const float x = rail ? theirs : mine, y = rail ? mine : theirs;
+        float c, s;
+        nco.step(p.sine, nco_inc, c, s);
+        const float v = rail ? fmaf(y, c, x * s) : fmaf(x, c, -(s * y));
+        wg_sync<1>();
+        row[t] = v;
+      }
+      wg_sync<1>();
+      for (int r = 0; r < 64; r++) { /* into the rings: row r of the tile is (channel c0 + r / 2, rail r & 1) */
+        if (c0 + (r >> 1) >= p.n_channels) break;
+        float *ring = ((r & 1) ? p.ring_q : p.ring_i) + (size_t)(c0 + (r >> 1)) * p.ring_size;
+        const uint32_t at = p.pos + (uint32_t)b * BS;
+        ring[(at + lane) & (p.ring_size - 1)] = tf[r][lane];
+        ring[(at + lane + 64) & (p.ring_size - 1)] = tf[r][lane + 64];
+      }
+    } else if (am) {
+      for (int t = 0; t < BS; t++) row[t] = pre.run(row[t]); /* 0xec1c: the IF filter a second time */
+      wg_sync<1>();
+      bool envelope = p.mode == 4;
+      if (p.mode == 5) { /* 0xe390: PLL on the IF signal; both lanes of a channel run it, each keeps its own rail */
+        const float HALF_PI = 1.5707963705062866f, A1 = 0.97239410877227783f, A3 = -0.19194795191287994f;
+        for (int t = 0; t < BS; t++) {
+          const float mine = row[t], theirs = other[t];
+          const float x = rail ? theirs : mine, q = rail ? mine : theirs;
+          const float re = fmaf(x, sam_c, q * sam_s), im = fmaf(q, sam_c, -(sam_s * x));
+          float err;
+          if (re == 0.0f) err = im > 0.0f ? HALF_PI : (im < 0.0f ? -HALF_PI : 0.0f);
+          else if (fabsf(re) > fabsf(im)) {
+            const float z = im / re;
+            err = fmaf(z, z * A3, A1) * z;
+            if (!(re > 0.0f)) err = (float)(im >= 0.0f ? (double)err + 3.1415926535897931 : (double)err - 3.1415926535897931);
+          } else {
+            const float z = re / im;
+            err = fmaf(-z, fmaf(z, z * A3, A1), im > 0.0f ? HALF_PI : -HALF_PI);
+          }
+          const float u = fmaf(err, p.sam_ga, p.sam_gb * sam_err);
+          const double phd = fma((double)(u + sam_u), 0.5, (double)sam_ph);
+          sam_hz = fmaf(p.sam_keep, sam_hz, (u * p.sam_hz_per_rad) * p.sam_new);
+          sam_ph = (float)phd;
+          if ((double)sam_ph >= 3.1415926535897931) sam_ph -= TWO_PI_F;
+          if ((double)sam_ph < -3.1415926535897931) sam_ph += TWO_PI_F;
+          sam_locked = sam_hz > p.sam_lock_lo ? (sam_hz < p.sam_lock_hi) : 0;
+          float pc = (float)((double)sam_ph + 1.5707963267948966);
+          if (pc >= TWO_PI_F) pc -= TWO_PI_F;
+          if (pc < 0.0f) pc += TWO_PI_F;
+          sam_c = table_sin(p.sine, pc);
+          float ps = sam_ph >= TWO_PI_F ? sam_ph - TWO_PI_F : sam_ph;
+          if (ps < 0.0f) ps += TWO_PI_F;
+          sam_s = table_sin(p.sine, ps);
+          const float v = rail ? fmaf(-x, sam_s, q * sam_c) : fmaf(x, sam_c, q * sam_s);
+          wg_sync<1>();
+          if (sam_locked) row[t] = v;
+          sam_u = u; sam_err = err;
+        }
+        wg_sync<1>();
+        envelope = !sam_locked; /* 0xed02: out of lock, the envelope detector takes over */
+      }
+      if (envelope) {
+        for (int t = 0; t < BS; t++) {
+          const float mine = row[t], theirs = other[t];
+          const float x = rail ? theirs : mine, y = rail ? mine : theirs;
+          float c, s;
+          amo.step(p.sine, am_inc, c, s);
+          const float v = rail ? fmaf(y, c, x * s) : fmaf(x, c, -(s * y));
+          wg_sync<1>();
+          row[t] = amf.run(v);
+        }
+        wg_sync<1>();
+        for (int t = 0; t < BS; t++) {
+          const float mine = row[t], theirs = other[t];
+          wg_sync<1>();
+          if (!rail) row[t] = quick_sqrt2(fmaf(mine, mine, theirs * theirs));
+        }
+      }
+      wg_sync<1>();
+      for (int r = 0; r < 32; r++) { /* the demodulated audio is in the I rows */
+        if (c0 + r >= p.n_channels) break;
+        float *dst = p.audio + (size_t)(c0 + r) * p.audio_stride + (size_t)b * BS;
+        dst[lane] = tf[2 * r][lane];
+        dst[lane + 64] = tf[2 * r][lane + 64];
+      }
+    }
+    wg_sync<1>();
+  }
+  if (valid) {
+    pre.store(st + ST_PRE + 16 * rail);
+    if (am) amf.store(st + ST_AM + 16 * rail);
+    if (!rail) {
+      st[ST_NCO] = nco.ph; st[ST_AMPH] = amo.ph;
+      st[ST_SAM_COS] = sam_c; st[ST_SAM_SIN] = sam_s; st[ST_SAM_U] = sam_u; st[ST_SAM_ERR] = sam_err; st[ST_SAM_HZ] = sam_hz;
+      st[ST_SAM_PH] = sam_ph; st[ST_SAM_LOCK] = __int_as_float(sam_locked);
+      st[ST_NB_AVG] = nb_avg; st[ST_NB_LAST] = nb_last; st[ST_NB_HIT] = __int_as_float(nb_hit);
+    }
+  }
+}
+
+/* ---- 0xea7e: I delayed by 128, Q through the 257-tap Hilbert transformer (odd taps, antisymmetric), side band by sign --- */
+__global__ __launch_bounds__(256) void rdsp_engine_hilbert_kernel(const EngParams p) {
+  __shared__ float q[512];
+  __shared__ float h[64];
+  const int tid = threadIdx.x, ch = blockIdx.y;
+  const uint32_t t0 = blockIdx.x * 256u, m = p.ring_size - 1;
+  const float *rq = p.ring_q + (size_t)ch * p.ring_size, *ri = p.ring_i + (size_t)ch * p.ring_size;
+  q[tid] = rq[(p.pos + t0 - 256u + (uint32_t)tid) & m];        /* q[j] = sample t0 - 256 + j */
+  q[tid + 256] = rq[(p.pos + t0 + (uint32_t)tid) & m];
+  if (tid < 64) h[tid] = p.hilbert[tid];
+  __syncthreads();
+  const uint32_t t = t0 + (uint32_t)tid;
+  if (t >= (uint32_t)p.n_blocks * BS) return;
+  float acc = 0.0f;
+#pragma unroll 8
+  for (int k = 0; k < 64; k++) acc = fmaf(h[k], q[tid + 255 - 2 * k] - q[tid + 1 + 2 * k], acc);
+  const float i = ri[(p.pos + t - 128u) & m];
+  const bool minus = p.mode == 6 || (p.mode & ~2) == 1;
+  p.audio[(size_t)ch * p.audio_stride + t] = minus ? i - acc : i + acc;
+}
+
+/* ---- tail: audio band-pass (0xd944), AGC (0xdb58), ALS (0xda24), output (0xebfa) ------------------------------------- */
+__device__ __forceinline__ float agc_lookup(const float *curve, float env) {
+  const int idx = trunc_s32((double)env * 32767.0);
+  int hi = (idx >> 8) & 0xff, hi1;
+  if (hi > 127) { hi = 127; hi1 = 128; } else hi1 = hi + 1;
+  const float frac = (float)(unsigned)(idx & 0xff) * 0.00390625f;
+  const float t0 = curve[hi];
+  return fmaf(frac, curve[hi1] - t0, t0);
+}
+
+template <bool ALS>
+__global__ __launch_bounds__(64) void rdsp_engine_tail_kernel(const EngParams p) {
+  __shared__ float ta[64][PITCH];
+  __shared__ float curve[130];
+  __shared__ float line[ALS ? 256 : 1][64];
+  __shared__ float wt[ALS ? ALS_TAPS : 1][64];
+  const int lane = threadIdx.x, c0 = blockIdx.x * 64;
+  const bool valid = c0 + lane < p.n_channels;
+  const int ch = valid ? c0 + lane : p.n_channels - 1;
+  float *st = p.st + (size_t)ch * NF;
+  Cascade aud;
+  aud.load(p.sets + 20 * p.audio_set, st + ST_AUDIO, (p.resets & RESET_AUDIO) != 0);
+  float env = st[ST_AGC_ENV], g = st[ST_AGC_GAIN];
+  int hang = __float_as_int(st[ST_AGC_HANG]), active = __float_as_int(st[ST_AGC_ACTIVE]);
+  for (int i = lane; i < 130; i += 64) curve[i] = p.curve[i];
+  if constexpr (ALS) {
+    const float *a = p.als + (size_t)ch * ALS_WORDS;
+    const bool clear = (p.resets & RESET_ALS) != 0;
+    for (int i = 0; i < 256; i++) line[i][lane] = clear ? 0.0f : a[i];
+    for (int k = 0; k < ALS_TAPS; k++) wt[k][lane] = clear ? 0.0f : a[256 + k];
+  }
+  float *row = ta[lane];
+  for (int b = 0; b < p.n_blocks; b++) {
+    wg_sync<1>();
+    rows_in<float>(ta, p.audio + (size_t)b * BS, p.audio_stride, c0, 64, p.n_channels, lane);
+    wg_sync<1>();
+    for (int t = 0; t < BS; t++) {
+      float a = row[t];
+      if (p.audio_on) a = aud.run(a);
+      if (p.agc_on) {
+        float in = fabsf(a);
+        if (in > 1.0f) in = 1.0f;
+        if (env < in) { /* attack: the hang counter is re-armed */
+          env = fmaf(env, p.agc_attack_a, in * p.agc_attack_b);
+          hang = p.agc_hang_time;
+          g = agc_lookup(curve, env);
+        } else if (hang == 0) {
+          env = fmaf(env, p.agc_decay_a, in * p.agc_decay_b);
+          g = agc_lookup(curve, env);
+        } else {
+          hang--;
+        }
+        active = (double)g < 0.98999999999999999;
+        float y = (g * p.agc_makeup) * a;
+        if (y > 1.0f) y = 1.0f;
+        else if (y < -1.0f) y = -1.0f;
+        a = y;
+      }
+      row[t] = a;
+    }
+    if constexpr (ALS) { /* y = w . x delayed; the taps move on every fourth sample of a block by mu e x (plain LMS) */
+      for (int i = 0; i < 128; i++) { line[i][lane] = line[i + 128][lane]; line[i + 128][lane] = row[i]; }
+      int cnt = 0;
+      for (int n = 128; n < 256; n++) {
+        float y = 0.0f;
+        for (int k = 0; k < ALS_TAPS; k++) y = fmaf(wt[k][lane], line[n - ALS_DELAY - k][lane], y);
+        const float err = line[n][lane] - y;
+        if (p.als_adaptive) {
+          if (cnt == 0)
+            for (int k = 0; k < ALS_TAPS; k++) wt[k][lane] = fmaf(err * line[n - ALS_DELAY - k][lane], 0.5f, wt[k][lane]);
+          cnt = (cnt + 1) & 3;
+        }
+        row[n - 128] = p.als_notch ? err : y;
+      }
+    }
+    for (int t = 0; t < BS; t++) { /* 0xebfa: x output gain x 32767 toward zero, the low half-word, on both outputs */
+      const uint32_t v = p.mute ? 0u : ((uint32_t)trunc_s32((double)(row[t] * p.output_gain) * 32767.0) & 0xffffu);
+      row[t] = __uint_as_float(v | (v << 16));
+    }
+    wg_sync<1>();
+    for (int r = 0; r < 64; r++) {
+      if (c0 + r >= p.n_channels) break;
+      int32_t *dst = p.out + (size_t)(c0 + r) * p.out_stride + (size_t)b * BS;
+      dst[lane] = __float_as_int(ta[r][lane]);
+      dst[lane + 64] = __float_as_int(ta[r][lane + 64]);
+    }
+  }
+  if (valid) {
+    aud.store(st + ST_AUDIO);
+    st[ST_AGC_ENV] = env; st[ST_AGC_GAIN] = g; st[ST_AGC_HANG] = __int_as_float(hang); st[ST_AGC_ACTIVE] = __int_as_float(active);
+    if constexpr (ALS) {
+      float *a = p.als + (size_t)ch * ALS_WORDS;
+      for (int i = 0; i < 256; i++) a[i] = line[i][lane];
+      for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][lane];
+    }
+  }
+}
+
+/* ---- host side ---------------------------------------------------------------------------------------------------- */
+float bits_f(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+uint32_t f_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+
+/* expf of the C library the engine was linked against (newlib's e_expf.c, Sun's algorithm): the gain curve below is built
+ * with it, and a different last bit in one of its 129 entries would be a different gain on every sample that uses it */
+float engine_expf(float x) {
+  const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, inv_ln2 = 1.4426950216e+00f;
+  const float P[5] = {1.6666667163e-01f, -2.7777778450e-03f, 6.6137559770e-05f, -1.6533901999e-06f, 4.1381369442e-08f};
+  const uint32_t hx = f_bits(x) & 0x7fffffffu;
+  const int neg = (int)(f_bits(x) >> 31);
+  if (hx > 0x7f800000u) return x + x;
+  if (hx == 0x7f800000u) return neg ? 0.0f : x;
+  if (x > 8.8721679688e+01f) return INFINITY;
+  if (x < -1.0397208405e+02f) return 0.0f;
+  float hi = 0.0f, lo = 0.0f;
+  int k = 0;
+  if (hx > 0x3eb17218u) {
+    if (hx < 0x3F851592u) { hi = neg ? x + ln2_hi : x - ln2_hi; lo = neg ? -ln2_lo : ln2_lo; k = neg ? -1 : 1; }
+    else { k = (int)(inv_ln2 * x + (neg ? -0.5f : 0.5f)); const float t = (float)k; hi = x - t * ln2_hi; lo = t * ln2_lo; }
+    x = hi - lo;
+  } else if (hx < 0x31800000u) return 1.0f + x;
+  const float t = x * x;
+  const float c = x - t * (P[0] + t * (P[1] + t * (P[2] + t * (P[3] + t * P[4]))));
+  if (k == 0) return 1.0f - ((x * c) / (c - 2.0f) - x);
+  const float y = 1.0f - ((lo - (x * c) / (2.0f - c)) - hi);
+  if (k >= -125) return bits_f(f_bits(y) + ((uint32_t)k << 23));
+  return bits_f(f_bits(y) + ((uint32_t)(k + 100) << 23)) * 7.8886090522e-31f;
+}
+}  // namespace
+
+struct rdsp_engine {
+  int n_channels, device, max_blocks;
+  uint32_t ring_size, pos;
+  bool tables;
+  float *d_st = nullptr, *d_ring_i = nullptr, *d_ring_q = nullptr, *d_audio = nullptr, *d_nb = nullptr, *d_als = nullptr, *d_tab = nullptr;
+  float curve[130], sine[257];
+  /* the object's fields (offsets of the image's AudioSDR in the comments of oracle/rdsp_engine_oracle.c) */
+  float if_centre, ssb_band, cw_band, input_gain, gain_i, gain_q, iq_balance, output_gain, tuning_offset;
+  int mode, mute, audio_on, audio_id, audio_set, pre_set, agc_on, als_on, als_notch, als_adaptive, nb_on, resets;
+  float agc_attack_a, agc_attack_b, agc_decay_a, agc_decay_b, agc_makeup, agc_knee_db, agc_slope, agc_threshold_db;
+  int agc_hang_time;
+  float sam_ga, sam_gb;
+};
+
+namespace {
+constexpr size_t TAB_SETS = 0, TAB_HILBERT = 300, TAB_SINE = 364, TAB_CURVE = 621, TAB_WORDS = 751;
+
+void engine_agc_curve(rdsp_engine_t *e) { /* 0xdd40: soft-knee compressor curve over the envelope, 1/128 per entry */
+  const double ln10ish = 2.3025, db_per_octave = 6.026; /* the library's own constants */
+  const double T = (double)e->agc_threshold_db, W = (double)e->agc_knee_db;
+  const float x_lo = engine_expf((float)(((T - W * 0.5) * ln10ish) / 20.0)), x_hi = engine_expf((float)(((T + W * 0.5) * ln10ish) / 20.0));
+  for (int i = 0; i < 130; i++) {
+    const float x = (float)i * 0.0078125f;
+    if (x_lo > x) { e->curve[i] = 1.0f; continue; }
+    int ex;
+    const float m = frexpf(x, &ex);
+    const float log2x = fmaf(m, fmaf(m, fmaf(m, 1.2314958572387695f, -4.1185250282287598f), 6.021970272064209f), -3.1339645385742188f) + (float)ex;
+    const float xdb = (float)((double)log2x * db_per_octave);
+    float gdb;
+    if (x_hi >= x) {
+      const double d = fma(W, 0.5, (double)(xdb - e->agc_threshold_db));
+      gdb = (float)(((((double)e->agc_slope - 1.0) * d) * d) / (W + W) + (double)xdb) - xdb;
+    } else {
+      gdb = fmaf(xdb - e->agc_threshold_db, e->agc_slope, e->agc_threshold_db) - xdb;
+    }
+    e->curve[i] = engine_expf((float)(((double)gdb * ln10ish) / 20.0));
+  }
+}
+void engine_sam_constants(rdsp_engine_t *e) { /* 0xed34 with the constructor's loop parameters */
+  const float wn = bits_f(0x3e50fac7), zeta = 2.0f, kd = 1.0f, ko = 1.0f;
+  const double k4 = (double)(1.0f / (kd * ko)) * 4.0, den = 1.0 / ((double)zeta * 4.0) + (double)zeta;
+  const float g1 = (float)((k4 * (double)zeta * (double)wn) / den), g2 = (float)((k4 * (double)wn * (double)wn) / (den * den));
+  e->sam_ga = g1 + g2;
+  e->sam_gb = g2;
+}
+int engine_fail(const char *what, hipError_t err) {
+  rdsp_set_error("%s: %s", what, hipGetErrorString(err));
+  return RDSP_ERR_HIP;
+}
+}  // namespace
+
+extern "C" {
+
+int rdsp_engine_setAGCmode(rdsp_engine_t *e, int mode) { /* 0xdfe0 */
+  if (!e) return RDSP_ERR_INVALID;
+  static const uint32_t k[4][4] = {{0, 0, 0, 0}, {0x3f79673b, 0x3cd318a0, 0x3f7fddca, 0x3a08d800}, {0x3f7d5732, 0x3c2a3380, 0x3f7ff250, 0x395b0000},
+                                   {0x3f7eaab6, 0x3baaa500, 0x3f7ff928, 0x38db0000}};
+  static const int hang[4] = {0, 4410, 22050, 88200};
+  if (mode == 0) { e->agc_on = 0; return RDSP_OK; }
+  if (mode < 0 || mode > 3) return RDSP_OK; /* the engine ignores other values */
+  e->agc_attack_a = bits_f(k[mode][0]); e->agc_attack_b = bits_f(k[mode][1]);
+  e->agc_decay_a = bits_f(k[mode][2]); e->agc_decay_b = bits_f(k[mode][3]);
+  e->agc_hang_time = hang[mode];
+  e->agc_on = 1;
+  return RDSP_OK;
+}
+int rdsp_engine_enableAGC(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->agc_on = 1; return RDSP_OK; }
+
+float rdsp_engine_setDemodMode(rdsp_engine_t *e, int mode) { /* 0xd798 */
+  if (!e) return 0.0f;
+  e->mode = mode & 0xffff;
+  switch (e->mode) {
+    case 0: e->tuning_offset = (float)((double)e->if_centre + (double)e->ssb_band * 0.5); e->pre_set = 12; break;
+    case 1: e->tuning_offset = (float)((double)e->if_centre - (double)e->ssb_band * 0.5); e->pre_set = 12; break;
+    case 6: e->tuning_offset = (float)((double)e->if_centre - (double)e->ssb_band * 0.5); e->pre_set = 11; break;
+    case 2: e->tuning_offset = (float)((double)e->if_centre + (double)e->cw_band * 0.5); e->pre_set = 10; break;
+    case 3: e->tuning_offset = (float)((double)e->if_centre - (double)e->cw_band * 0.5); e->pre_set = 10; break;
+    case 4: case 5: e->tuning_offset = e->if_centre; e->pre_set = 14; break;
+    default: return e->tuning_offset;
+  }
+  e->resets |= RESET_PRE; /* arm_biquad_cascade_df1_init_f32 clears the state */
+  return e->tuning_offset;
+}
+int rdsp_engine_setAudioFilter(rdsp_engine_t *e, int id) { /* 0xd97c */
+  static const int set_of_id[10] = {7, 8, 9, 0, 1, 2, 3, 4, 5, 6};
+  if (!e) return RDSP_ERR_INVALID;
+  if (id == 10) e->audio_on = 0;
+  else if (id >= 0 && id < 10) { e->audio_set = set_of_id[id]; e->resets |= RESET_AUDIO; }
+  e->audio_id = id;
+  return RDSP_OK;
+}
+int rdsp_engine_enableAudioFilter(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->audio_on = 1; return RDSP_OK; }
+int rdsp_engine_setInputGain(rdsp_engine_t *e, float g) { /* 0xd8a0 */
+  if (!e) return RDSP_ERR_INVALID;
+  if (g > 10.0f) g = 10.0f;
+  else if (g < 0.0f) g = 0.0f;
+  e->input_gain = g; e->gain_i = e->iq_balance * g; e->gain_q = g;
+  return RDSP_OK;
+}
+int rdsp_engine_setIQgainBalance(rdsp_engine_t *e, float b) { /* 0xd8f0 */
+  if (!e) return RDSP_ERR_INVALID;
+  e->iq_balance = b; e->gain_i = b * e->input_gain; e->gain_q = e->input_gain;
+  return RDSP_OK;
+}
+int rdsp_engine_setOutputGain(rdsp_engine_t *e, float g) { if (!e) return RDSP_ERR_INVALID; e->output_gain = g; return RDSP_OK; }
+int rdsp_engine_setMute(rdsp_engine_t *e, int on) { if (!e) return RDSP_ERR_INVALID; e->mute = on ? 1 : 0; return RDSP_OK; }
+int rdsp_engine_enableALSfilter(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_on = 1; e->resets |= RESET_ALS; return RDSP_OK; }
+int rdsp_engine_disableALSfilter(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_on = 0; return RDSP_OK; }
+int rdsp_engine_setALSfilterNotch(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_notch = 1; return RDSP_OK; }
+int rdsp_engine_setALSfilterPeak(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_notch = 0; return RDSP_OK; }
+int rdsp_engine_setALSfilterAdaptive(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_adaptive = 1; return RDSP_OK; }
+int rdsp_engine_enableNoiseBlanker(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->nb_on = 1; return RDSP_OK; }
+int rdsp_engine_disableNoiseBlanker(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->nb_on = 0; return RDSP_OK; }
+int rdsp_engine_channels(const rdsp_engine_t *e) { return e ? e->n_channels : 0; }
+int rdsp_engine_device(const rdsp_engine_t *e) { return e ? e->device : -1; }
+int rdsp_engine_max_blocks(const rdsp_engine_t *e) { return e ? e->max_blocks : 0; }
+const float *rdsp_engine_agc_curve(const rdsp_engine_t *e) { return e ? e->curve : nullptr; }
+const float *rdsp_engine_sine_table(const rdsp_engine_t *e) { return e ? e->sine : nullptr; }
+
+void rdsp_engine_destroy(rdsp_engine_t *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (float *p : {e->d_st, e->d_ring_i, e->d_ring_q, e->d_audio, e->d_nb, e->d_als, e->d_tab})
+    if (p) (void)hipFree(p);
+  delete e;
+}
+
+/* device state as AudioSDR::AudioSDR (0x6744) + its init (0xede4) leave it: lines and filter states zero, the blanker's
+ * mask lines 1.0, its running average 10.0, the PLL's frequency estimate 1890 Hz */
+int rdsp_engine_reset(rdsp_engine_t *e, void *stream) {
+  if (!e) return RDSP_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipSetDevice(e->device);
+  const size_t n = (size_t)e->n_channels;
+  std::vector<float> st(n * NF, 0.0f), nb(n * NB_WORDS, 0.0f);
+  for (size_t c = 0; c < n; c++) {
+    st[c * NF + ST_SAM_HZ] = 1890.0f;
+    st[c * NF + ST_NB_AVG] = 10.0f;
+    st[c * NF + ST_AGC_ACTIVE] = bits_f(1u); /* the flag's value until the AGC first runs */
+    for (int r = 0; r < 2; r++)
+      for (int i = 0; i < 384; i++) nb[c * NB_WORDS + (size_t)r * (NB_WORDS / 2) + 768 + i] = 1.0f;
+  }
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_st, st.data(), st.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_nb, nb.data(), nb.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemsetAsync(e->d_ring_i, 0, n * e->ring_size * 4, s);
+  if (err == hipSuccess) err = hipMemsetAsync(e->d_ring_q, 0, n * e->ring_size * 4, s);
+  if (err == hipSuccess) err = hipMemsetAsync(e->d_als, 0, n * ALS_WORDS * 4, s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s); /* the host vectors go away */
+  e->pos = 0;
+  e->resets = 0;
+  return err == hipSuccess ? RDSP_OK : engine_fail("rdsp_engine_reset", err);
+}
+
+int rdsp_engine_create(int n_channels, int device, int max_blocks_per_call, rdsp_engine_t **out) {
+  if (!out || n_channels < 1 || max_blocks_per_call < 1 || max_blocks_per_call > 4096) {
+    rdsp_set_error("rdsp_engine_create: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {
+    rdsp_set_error("rdsp_engine_create: no HIP device (this library has no CPU path)");
+    return RDSP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count || hipSetDevice(device) != hipSuccess) {
+    rdsp_set_error("rdsp_engine_create: device %d of %d", device, count);
+    return RDSP_ERR_INVALID;
+  }
+  rdsp_engine_t *e = new rdsp_engine();
+  e->n_channels = n_channels; e->device = device; e->max_blocks = max_blocks_per_call;
+  e->ring_size = 512;
+  while (e->ring_size < (uint32_t)max_blocks_per_call * BS + 256u) e->ring_size <<= 1;
+  e->tables = false;
+  /* the constructor's values */
+  e->if_centre = 6890.0f; e->ssb_band = 3000.0f; e->cw_band = 1000.0f;
+  e->input_gain = e->gain_i = e->gain_q = e->iq_balance = e->output_gain = 1.0f;
+  e->mute = 0; e->audio_on = 0; e->audio_id = 0; e->audio_set = 3; e->nb_on = 1;
+  e->als_on = 0; e->als_notch = 1; e->als_adaptive = 1;
+  e->agc_makeup = 10.0f; e->agc_threshold_db = -60.0f; e->agc_slope = bits_f(0x3dcccccd); e->agc_knee_db = 2.0f;
+  rdsp_engine_setAGCmode(e, 2); /* 0xdf14: the medium attack with the slow decay and the fast hang time */
+  e->agc_decay_a = bits_f(0x3f7ff928); e->agc_decay_b = bits_f(0x38db0000); e->agc_hang_time = 4410;
+  engine_agc_curve(e);
+  engine_sam_constants(e);
+  for (int k = 0; k < 257; k++) e->sine[k] = (float)(round(sin(2.0 * 3.14159265358979323846 * k / 256.0) * 1e8) / 1e8);
+  rdsp_engine_setDemodMode(e, 0);
+  const size_t n = (size_t)n_channels;
+  hipError_t err = hipMalloc((void **)&e->d_st, n * NF * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_ring_i, n * e->ring_size * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_ring_q, n * e->ring_size * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_audio, n * (size_t)max_blocks_per_call * BS * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_nb, n * NB_WORDS * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_als, n * ALS_WORDS * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_tab, TAB_WORDS * 4);
+  if (err != hipSuccess) {
+    rdsp_engine_destroy(e);
+    rdsp_set_error("rdsp_engine_create: %s", hipGetErrorString(err));
+    return RDSP_ERR_NOMEM;
+  }
+  const int rc = rdsp_engine_reset(e, nullptr);
+  if (rc != RDSP_OK) { rdsp_engine_destroy(e); return rc; }
+  *out = e;
+  return RDSP_OK;
+}
+
+/* the engine's coefficient tables: fifteen sets of four {b0, b1, b2, a1, a2} sections in the image's order (ten audio
+ * band-passes, then the IF filters: CW, mode 6, SSB, the AM detector's low-pass, AM) and the 64 taps of one side of the
+ * Hilbert transformer, outermost first */
+int rdsp_engine_load_tables(rdsp_engine_t *e, const float *biquad_sets15x20, const float *hilbert64) {
+  if (!e || !biquad_sets15x20 || !hilbert64) return RDSP_ERR_INVALID;
+  std::vector<float> t(TAB_WORDS);
+  memcpy(&t[TAB_SETS], biquad_sets15x20, 300 * 4);
+  memcpy(&t[TAB_HILBERT], hilbert64, 64 * 4);
+  memcpy(&t[TAB_SINE], e->sine, 257 * 4);
+  memcpy(&t[TAB_CURVE], e->curve, 130 * 4);
+  hipError_t err = hipSetDevice(e->device);
+  if (err == hipSuccess) err = hipMemcpy(e->d_tab, t.data(), TAB_WORDS * 4, hipMemcpyHostToDevice);
+  if (err != hipSuccess) return engine_fail("rdsp_engine_load_tables", err);
+  e->tables = true;
+  return RDSP_OK;
+}
+
+/* AudioSDR::update (0xe730) for n_blocks consecutive 128-sample blocks of every channel.  d_iq: [ch][t] int16 pairs
+ * (I, Q), in_stride pairs from one channel's row to the next; d_lr: [ch][t] int16 pairs, the engine's two outputs
+ * (it transmits the same block on both, INO:81-86) */
+int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, int n_blocks, int16_t *d_lr, size_t out_stride, void *stream) {
+  if (!e || !d_iq || !d_lr || n_blocks < 0 || n_blocks > e->max_blocks || in_stride < (size_t)n_blocks * BS || out_stride < (size_t)n_blocks * BS) {
+    rdsp_set_error("rdsp_engine_update: bad argument (n_blocks %d of at most %d)", n_blocks, e ? e->max_blocks : 0);
+    return RDSP_ERR_INVALID;
+  }
+  if (!e->tables) {
+    rdsp_set_error("rdsp_engine_update: the engine's coefficient tables are not loaded (rdsp_engine_load_tables)");
+    return RDSP_ERR_NOT_READY;
+  }
+  if (n_blocks == 0) return RDSP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipSetDevice(e->device);
+  if (err != hipSuccess) return engine_fail("rdsp_engine_update", err);
+  EngParams p;
+  memset(&p, 0, sizeof p);
+  p.iq = (const int32_t *)d_iq; p.in_stride = in_stride; p.out = (int32_t *)d_lr; p.out_stride = out_stride;
+  p.n_channels = e->n_channels; p.n_blocks = n_blocks; p.st = e->d_st;
+  p.ring_i = e->d_ring_i; p.ring_q = e->d_ring_q; p.ring_size = e->ring_size; p.pos = e->pos;
+  p.audio = e->d_audio; p.audio_stride = (size_t)e->max_blocks * BS; p.nb = e->d_nb; p.als = e->d_als;
+  p.sets = e->d_tab + TAB_SETS; p.hilbert = e->d_tab + TAB_HILBERT; p.sine = e->d_tab + TAB_SINE; p.curve = e->d_tab + TAB_CURVE;
+  p.mode = e->mode; p.mute = e->mute; p.audio_on = e->audio_on; p.agc_on = e->agc_on; p.als_notch = e->als_notch;
+  p.als_adaptive = e->als_adaptive; p.resets = e->resets; p.pre_set = e->pre_set; p.audio_set = e->audio_set;
+  p.gain_i = e->gain_i; p.gain_q = e->gain_q; p.output_gain = e->output_gain; p.tuning_offset = e->tuning_offset; p.if_centre = e->if_centre;
+  p.agc_attack_a = e->agc_attack_a; p.agc_attack_b = e->agc_attack_b; p.agc_decay_a = e->agc_decay_a; p.agc_decay_b = e->agc_decay_b;
+  p.agc_makeup = e->agc_makeup; p.agc_hang_time = e->agc_hang_time;
+  p.nb_keep = 0.995f; p.nb_new = bits_f(0x3ba3d700); p.nb_ratio = 1.2f; p.nb_before = 10; p.nb_after = 10;
+  p.sam_keep = 0.995f; p.sam_new = bits_f(0x3ba3d700); p.sam_hz_per_rad = bits_f(0x45db55dd); p.sam_lock_lo = 3890.0f; p.sam_lock_hi = 9890.0f;
+  p.sam_ga = e->sam_ga; p.sam_gb = e->sam_gb;
+  const bool ssb = e->mode <= 3 || e->mode == 6, known = ssb || e->mode == 4 || e->mode == 5;
+  const dim3 gf((unsigned)((e->n_channels + 31) / 32)), gt((unsigned)((e->n_channels + 63) / 64));
+  if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(64), 0, s, p);
+  if (ssb) {
+    const dim3 gh((unsigned)((n_blocks * BS + 255) / 256), (unsigned)e->n_channels);
+    hipLaunchKernelGGL(rdsp_engine_hilbert_kernel, gh, dim3(256), 0, s, p);
+  } else if (!known) { /* a mode number the engine does not know leaves its audio buffer as it was: the last call's */
+  }
+  if (e->als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(rdsp_engine_tail_kernel<false>, gt, dim3(64), 0, s, p);
+  err = hipGetLastError();
+  if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
+  e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1);
+  e->resets = 0;
+  return RDSP_OK;
+}
+
+/* per-channel scalars for tests and monitoring: [n_channels][8] = oscillator phase, AGC gain, AGC envelope, hang counter,
+ * AGC-active flag, PLL frequency estimate (Hz), PLL lock flag, blanker-hit flag */
+int rdsp_engine_get_scalars(rdsp_engine_t *e, float *host_out, void *stream) {
+  if (!e || !host_out) return RDSP_ERR_INVALID;
+  std::vector<float> st((size_t)e->n_channels * NF);
+  hipError_t err = hipSetDevice(e->device);
+  if (err == hipSuccess) err = hipMemcpyAsync(st.data(), e->d_st, st.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) return engine_fail("rdsp_engine_get_scalars", err);
+  for (int c = 0; c < e->n_channels; c++) {
+    const float *s = &st[(size_t)c * NF];
+    float *o = host_out + (size_t)c * 8;
+    int hang, active, lock, hit;
+    memcpy(&hang, &s[ST_AGC_HANG], 4); memcpy(&active, &s[ST_AGC_ACTIVE], 4); memcpy(&lock, &s[ST_SAM_LOCK], 4); memcpy(&hit, &s[ST_NB_HIT], 4);
+    o[0] = s[ST_NCO]; o[1] = s[ST_AGC_GAIN]; o[2] = s[ST_AGC_ENV]; o[3] = (float)hang; o[4] = (float)active; o[5] = s[ST_SAM_HZ];
+    o[6] = (float)lock; o[7] = (float)hit;
+  }
+  return RDSP_OK;
+}
+
+}  // extern "C"

@@ -299,3 +299,90 @@ def multi_process(iq, n_threads=1, lib=None, **kw):
                                 _p(out, C.c_int16), n_threads)
     assert got == n // decim, (got, n // decim)
     return out
+
+
+# ---- the reference's AudioSDR engine as its firmware image computes it (oracle/rdsp_engine_oracle.c) --------------------
+_F32P, _I16P = C.POINTER(C.c_float), C.POINTER(C.c_int16)
+ENGINE_TAPS = ["in", "nb", "pre", "mix", "hilbert", "demod", "filt", "agc", "als"]
+
+
+def _bind_engine(lib):
+    if getattr(lib, "_engine_bound", False):
+        return lib
+    lib.orc_engine_create.restype = C.c_void_p
+    lib.orc_engine_create.argtypes = [_F32P, _F32P]
+    lib.orc_engine_destroy.argtypes = [C.c_void_p]
+    lib.orc_engine_update.argtypes = [C.c_void_p, _I16P, _I16P, _I16P]
+    lib.orc_engine_set_tap.argtypes = [C.c_void_p, _F32P]
+    lib.orc_engine_setDemodMode.restype = C.c_float
+    lib.orc_engine_setDemodMode.argtypes = [C.c_void_p, C.c_int]
+    for n in ("setAudioFilter", "setAGCmode", "setMute"):
+        getattr(lib, "orc_engine_" + n).argtypes = [C.c_void_p, C.c_int]
+    for n in ("setInputGain", "setOutputGain", "setIQgainBalance"):
+        getattr(lib, "orc_engine_" + n).argtypes = [C.c_void_p, C.c_float]
+    for n in ("enableAGC", "enableAudioFilter", "enableALSfilter", "disableALSfilter", "setALSfilterNotch", "setALSfilterPeak",
+              "setALSfilterAdaptive", "disableNoiseBlanker", "enableNoiseBlanker"):
+        getattr(lib, "orc_engine_" + n).argtypes = [C.c_void_p]
+    lib.orc_engine_scalar.restype = C.c_float
+    lib.orc_engine_scalar.argtypes = [C.c_void_p, C.c_int]
+    for n in ("agc_curve", "sine", "als_taps"):
+        getattr(lib, "orc_engine_" + n).restype = _F32P
+        getattr(lib, "orc_engine_" + n).argtypes = [C.c_void_p]
+    lib.orc_newlib_expf.restype = C.c_float
+    lib.orc_newlib_expf.argtypes = [C.c_float]
+    lib._engine_bound = True
+    return lib
+
+
+def engine_tables():
+    """the two tables of the engine that have no closed form, as data (tests/golden/firmware_tables.npz)"""
+    fw = np.load(os.path.join(_HERE, "golden", "firmware_tables.npz"))
+    return np.ascontiguousarray(fw["biquad_sets"].reshape(-1), np.float32), np.ascontiguousarray(fw["hilbert_half64"], np.float32)
+
+
+class OracleEngine:
+    """orc_engine_t: one receiver; `sketch_setup` = INO:120-139"""
+
+    def __init__(self, sketch_setup=True, taps=False):
+        self.lib = _bind_engine(load())
+        bq, h = engine_tables()
+        self.e = self.lib.orc_engine_create(bq.ctypes.data_as(_F32P), h.ctypes.data_as(_F32P))
+        self.tapbuf = np.zeros((9, 2, 128), np.float32) if taps else None
+        self.taps = {k: [] for k in ENGINE_TAPS}
+        if taps:
+            self.lib.orc_engine_set_tap(self.e, self.tapbuf.ctypes.data_as(_F32P))
+        if sketch_setup:
+            for c in (("enableAGC",), ("setAGCmode", 2), ("disableALSfilter",), ("disableNoiseBlanker",), ("setInputGain", 1.0), ("setOutputGain", 0.5),
+                      ("setIQgainBalance", 1.02), ("enableAudioFilter",), ("setAudioFilter", 6), ("setDemodMode", 0)):
+                self.call(*c)
+
+    def __del__(self):
+        if getattr(self, "e", None):
+            self.lib.orc_engine_destroy(self.e)
+            self.e = None
+
+    def call(self, name, *args):
+        return getattr(self.lib, "orc_engine_" + name)(self.e, *args)
+
+    def update(self, i128, q128):
+        i, q, o = np.ascontiguousarray(i128, np.int16), np.ascontiguousarray(q128, np.int16), np.zeros(128, np.int16)
+        self.lib.orc_engine_update(self.e, i.ctypes.data_as(_I16P), q.ctypes.data_as(_I16P), o.ctypes.data_as(_I16P))
+        if self.tapbuf is not None:
+            for k, n in enumerate(ENGINE_TAPS):
+                self.taps[n].append(self.tapbuf[k].copy())
+        return o
+
+    def run(self, iq, calls=()):
+        """iq int16 [n, 2]; calls [[block, method, args...]] are made before that block -> int16 [n]"""
+        out = np.zeros(len(iq), np.int16)
+        for b in range(len(iq) // 128):
+            for c in calls:
+                if c[0] == b:
+                    self.call(c[1], *c[2:])
+            out[b * 128:(b + 1) * 128] = self.update(iq[b * 128:(b + 1) * 128, 0], iq[b * 128:(b + 1) * 128, 1])
+        return out
+
+    def final(self):
+        """the fixture's `_final` row: oscillator phase, AGC gain / envelope / hang / active, PLL Hz / lock, blanker hit"""
+        s = lambda k: self.lib.orc_engine_scalar(self.e, k)
+        return np.array([s(0), s(1), s(2), s(3), s(4), s(5), s(6), s(9)], np.float32)

@@ -1,0 +1,164 @@
+"""The reference's AudioSDR engine (`AudioSDR SDR;`, INO:54) pinned on its own compiled code.
+
+tests/golden/engine_kat.npz was produced in the build container by running AudioSDR::update() of the reference's firmware
+image (pre_compiled/RadioDSP_SDR_RX.ino.hex, ITCM 0xe730) under tests/golden/thumb_emu.py, through the sketch's settings
+and menus, on seeded int16 IQ (tests/golden/make_engine_kat.py; `--check` reproduces it).  Inputs and outputs only.
+
+`-m "not gpu"`: oracle/rdsp_engine_oracle.c, the restatement written from the image's code, against every case -- the
+int16 audio and the float buffers after each stage, BIT FOR BIT -- and the tables it generates against the object's.
+`-m gpu`: rdsp_engine_t (csrc/rdsp_engine.hip) through the C-ABI against the same int16 audio, bit for bit as well: the
+kernels evaluate the same operations in the same order (the north-star's tolerance for float work is 1e-5; nothing of it
+is used here), on one channel per case, on all cases as channels of the same engine where the settings allow, and with
+the blocks cut into calls of different sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return np.load(os.path.join(HERE, "golden", "engine_kat.npz"))
+
+
+def case_names(k):
+    return [str(n) for n in k["case_names"]]
+
+
+def calls_of(k, name):
+    return json.loads(str(k[name + "_calls"]))
+
+
+# ---- CPU: the restatement against the image -----------------------------------------------------------------------------
+def test_oracle_tables_are_the_objects(kat, oracle):
+    """the sine table (eight-place decimals of sin(2 pi k / 256)), the AGC's gain curve (built with the restated newlib
+    expf), the PLL's loop gains and setDemodMode's answers, against the object after the image's constructor ran"""
+    e = oracle.OracleEngine(sketch_setup=False)
+    lib = e.lib
+    assert np.array_equal(np.ctypeslib.as_array(lib.orc_engine_sine(e.e), (257,)), kat["sine257"])
+    assert np.array_equal(np.ctypeslib.as_array(lib.orc_engine_agc_curve(e.e), (130,))[:129], kat["agc_curve"][:129])
+    got = np.array([lib.orc_newlib_expf(float(x)) for x in kat["expf_x"]], np.float32)
+    assert np.array_equal(got.view(np.uint32), kat["expf_y"].view(np.uint32))
+    assert [e.call("setDemodMode", m) for m in range(7)] == list(kat["tuning_offsets"])
+    assert list(kat["tuning_offsets"][:6]) == [8390.0, 5390.0, 7390.0, 6390.0, 6890.0, 6890.0]
+
+
+def test_oracle_engine_is_the_images_bit_for_bit(kat, oracle):
+    """every case: int16 audio, final scalars, and the stage taps where the fixture has them"""
+    total = 0
+    for name in case_names(kat):
+        calls = calls_of(kat, name)
+        tapped = (name + "_tap_in") in kat.files
+        e = oracle.OracleEngine(taps=tapped)
+        out = e.run(kat[name + "_iq"], calls)
+        assert np.array_equal(out, kat[name + "_out"]), name
+        assert np.array_equal(e.final().view(np.uint32), kat[name + "_final"].view(np.uint32)), (name, e.final(), kat[name + "_final"])
+        total += len(out) // 128
+        if tapped:
+            for st in oracle.ENGINE_TAPS:
+                key = f"{name}_tap_{st}"
+                if key not in kat.files:
+                    continue
+                want = kat[key]
+                got = np.stack(e.taps[st][:len(want)])[:, :want.shape[1]]
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), key
+    assert total > 1500
+
+
+def test_fixture_covers_what_the_sketch_can_ask_of_the_engine(kat):
+    """every demodulator of the mode menu, every audio filter id, every AGC mode, the ALS filter in both outputs, the
+    blanker, mute, the gain setters -- and the engine's behaviours a stand-in would miss: the AGC's hang, the PLL's lock,
+    the wrap-around of the int16 store"""
+    names = case_names(kat)
+    calls = [c for n in names for c in calls_of(kat, n)]
+    assert {c[2] for c in calls if c[1] == "setDemodMode"} >= {0, 1, 2, 3, 4, 5, 6}
+    assert {c[2] for c in calls if c[1] == "setAudioFilter"} >= set(range(11))
+    assert {c[2] for c in calls if c[1] == "setAGCmode"} >= {0, 1, 2, 3}
+    assert {c[1] for c in calls} >= {"enableALSfilter", "setALSfilterNotch", "setALSfilterPeak", "setALSfilterAdaptive", "disableALSfilter",
+                                     "enableNoiseBlanker", "setMute", "setInputGain", "setOutputGain", "setIQgainBalance", "enableAGC"}
+    assert kat["sam_final"][6] == 1.0 and kat["sam_no_carrier_final"][6] == 0.0          # the PLL locks on a carrier and only then
+    assert kat["blanker_on_final"][7] in (0.0, 1.0) and np.abs(kat["blanker_on_tap_nb"] - kat["blanker_on_tap_in"]).max() > 0
+    # the hang AGC: after the 30 dB step down the output stays low for the hang time, then recovers
+    for name, hang_blocks in (("agc_fast", 34), ("agc_medium", 172), ("agc_slow", 689)):
+        rms = np.sqrt((kat[name + "_out"].astype(np.float64).reshape(-1, 128) ** 2).mean(1))
+        held = rms[52:50 + hang_blocks - 2]
+        assert held.max() < 0.2 * rms[45], name                                        # gain held where the loud signal left it
+        assert rms[50 + hang_blocks + 4:].min() > held.mean() and rms[-1] > 1.4 * held.mean(), name   # and let go afterwards (slowly)
+    w = kat["wrap_agc_off_out"].astype(np.int32)
+    assert np.abs(np.diff(w)).max() > 40000                                            # a wrapped store, not a saturated one
+
+
+# ---- GPU: the product against the image ---------------------------------------------------------------------------------
+def _engine(rdsp, n_channels, max_blocks):
+    from radiodsp_sdr_rx_amd.engine import Engine
+    import oracle_lib
+    return Engine(n_channels, max_blocks_per_call=max_blocks, tables=oracle_lib.engine_tables())
+
+
+def _run_product(eng, iq_cases, calls, split):
+    """iq_cases: int16 [n_channels, n, 2]; the engine's setters are called between calls at block boundaries"""
+    import torch
+    n = iq_cases.shape[1]
+    nb = n // 128
+    marks = sorted({0, nb} | {c[0] for c in calls} | set(range(0, nb, split)))
+    out = np.zeros((iq_cases.shape[0], n), np.int16)
+    for a, b in zip(marks[:-1], marks[1:]):
+        for c in calls:
+            if c[0] == a:
+                r = getattr(eng, c[1])(*c[2:])
+        d = torch.from_numpy(np.ascontiguousarray(iq_cases[:, a * 128:b * 128])).cuda()
+        y = eng.update(d).cpu().numpy()
+        assert np.array_equal(y[..., 0], y[..., 1])                                     # the same block on both outputs
+        out[:, a * 128:b * 128] = y[..., 0]
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_engine_tables_and_refusals(kat, rdsp):
+    from radiodsp_sdr_rx_amd.engine import Engine
+    from radiodsp_sdr_rx_amd._lib import RdspError
+    import torch
+    e = Engine(3, max_blocks_per_call=4)
+    assert np.array_equal(e.sine_table(), kat["sine257"]) and np.array_equal(e.agc_curve()[:129], kat["agc_curve"][:129])
+    assert [e.setDemodMode(m) for m in range(7)] == list(kat["tuning_offsets"])
+    with pytest.raises(RdspError):                                                      # no tables, no audio
+        e.update(torch.zeros((3, 128, 2), dtype=torch.int16, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 7, 64])
+def test_gpu_engine_is_the_images_bit_for_bit(kat, rdsp, split):
+    """every case of the fixture through rdsp_engine_update, the stream cut into calls of `split` blocks (and at every
+    setter of the case): int16 audio and the final scalars"""
+    for name in case_names(kat):
+        if split != 64 and len(kat[name + "_iq"]) > 300 * 128:
+            continue                                                                   # the long AGC runs once
+        eng = _engine(rdsp, 1, 64)
+        eng.sketch_setup()
+        out = _run_product(eng, kat[name + "_iq"][None], calls_of(kat, name), split)
+        assert np.array_equal(out[0], kat[name + "_out"]), (name, split, int(np.argmax(out[0] != kat[name + "_out"])))
+        got, want = eng.scalars()[0], kat[name + "_final"]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, got, want)
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_engine_many_channels_are_independent(kat, rdsp):
+    """97 channels (a ragged last workgroup in every kernel) fed rotations of the sketch-default case: channel c must
+    return what one engine alone returns for its input, which for the unrotated channels is the image's own audio"""
+    iq = kat["lsb_sketch_iq"]
+    n = len(iq)
+    rolls = [0 if c % 5 == 0 else 128 * (c % 7) + c for c in range(97)]
+    x = np.stack([np.roll(iq, r, axis=0) for r in rolls])
+    eng = _engine(rdsp, 97, 16)
+    eng.sketch_setup()
+    out = _run_product(eng, x, [], 16)
+    for c in range(97):
+        if rolls[c] == 0:
+            assert np.array_equal(out[c], kat["lsb_sketch_out"]), c
+    import oracle_lib
+    for c in (1, 33, 64, 96):
+        assert np.array_equal(out[c], oracle_lib.OracleEngine().run(x[c])), c
