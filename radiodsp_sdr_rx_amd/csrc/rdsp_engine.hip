@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void rdsp_engine_front_kernel(const EngParams p
     if constexpr (NB) { /* 0xe14c: two blocks of delay; |I + jQ| against its running average; blanking mask with a taper.
                          * Each lane keeps its own copy of both rails' lines and of the mask (the partner's new samples come
                          * out of the tile), so nothing crosses lanes through HBM */
-      float *li = p.nb + ((size_t)ch * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768;
+      float *li = p.nb + ((size_t)(valid ? ch : p.n_channels) * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768; /* lanes past the last channel share a spare slot */
       wg_sync<1>();
       nb_hit = 0;
       for (int i = 0; i < 256; i++) { li[i] = li[i + 128]; lq[i] = lq[i + 128]; mask[i] = mask[i + 128]; }
@@ -596,7 +596,7 @@ int rdsp_engine_reset(rdsp_engine_t *e, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSetDevice(e->device);
   const size_t n = (size_t)e->n_channels;
-  std::vector<float> st(n * NF, 0.0f), nb(n * NB_WORDS, 0.0f);
+  std::vector<float> st(n * NF, 0.0f), nb((n + 1) * NB_WORDS, 0.0f);
   for (size_t c = 0; c < n; c++) {
     st[c * NF + ST_SAM_HZ] = 1890.0f;
     st[c * NF + ST_NB_AVG] = 10.0f;
@@ -652,7 +652,7 @@ int rdsp_engine_create(int n_channels, int device, int max_blocks_per_call, rdsp
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_ring_i, n * e->ring_size * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_ring_q, n * e->ring_size * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_audio, n * (size_t)max_blocks_per_call * BS * 4);
-  if (err == hipSuccess) err = hipMalloc((void **)&e->d_nb, n * NB_WORDS * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_nb, (n + 1) * NB_WORDS * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_als, n * ALS_WORDS * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_tab, TAB_WORDS * 4);
   if (err != hipSuccess) {
@@ -727,7 +727,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   else hipLaunchKernelGGL(rdsp_engine_tail_kernel<false>, gt, dim3(64), 0, s, p);
   err = hipGetLastError();
   if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
-  e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1);
+  if (ssb) e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1); /* the lines only move when the SSB / CW path runs */
   e->resets = 0;
   return RDSP_OK;
 }
