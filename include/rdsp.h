@@ -667,6 +667,26 @@ int rdsp_engine_get_scalars(rdsp_engine_t *e, float *host_out, void *stream);
 const float *rdsp_engine_agc_curve(const rdsp_engine_t *e); /* host copy, 130 entries (the engine uses 129) */
 const float *rdsp_engine_sine_table(const rdsp_engine_t *e); /* host copy, 257 entries */
 
+/* ---- `AudioSDRpreProcessor preProcessor;` (INO:53; wired INO:71-72) as the reference's engine library computes it -------
+ * (image ::update 0xee88): finds and repairs a one-sample slip between the rails with a 128-point FFT per block while
+ * detection is on, and swaps the rails on request.  The chain's own rdsp_pre_* calls above are a different mechanism
+ * (a slip set by the host, an estimator on a recording); this object is the reference's. */
+typedef struct rdsp_preproc rdsp_preproc_t;
+int rdsp_preproc_create(int n_channels, int device, rdsp_preproc_t **out);
+void rdsp_preproc_destroy(rdsp_preproc_t *p);
+int rdsp_preproc_startAutoI2SerrorDetection(rdsp_preproc_t *p); /* INO:117; takes effect at the next update */
+int rdsp_preproc_swapIQ(rdsp_preproc_t *p, int on);             /* INO:118 */
+int rdsp_preproc_update(rdsp_preproc_t *p, const int16_t *d_iq, size_t in_stride, int n_blocks, int16_t *d_out,
+                        size_t out_stride, void *stream);      /* [ch][t] int16 pairs (I, Q) in and out; in place allowed */
+int rdsp_preproc_get_state(rdsp_preproc_t *p, int16_t *host_out, void *stream); /* [ch][4]: remedy (0, 1 = I later, -1 = Q later), bad count, counted blocks, detecting */
+int rdsp_preproc_channels(const rdsp_preproc_t *p);
+int rdsp_preproc_device(const rdsp_preproc_t *p);
+
+/* the two objects as nodes of the block graph (two inputs I / Q, two outputs, one block per tick): INO:71-72, :81-86 */
+rdsp_node_t *rdsp_preproc_node_create(rdsp_graph_t *g, rdsp_preproc_t *p);
+rdsp_node_t *rdsp_engine_node_create(rdsp_graph_t *g, rdsp_engine_t *e);
+int rdsp_engine_node_status(rdsp_node_t *n); /* either kind */
+
 #ifdef __cplusplus
 }
 #endif

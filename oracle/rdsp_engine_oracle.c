@@ -504,7 +504,8 @@ void orc_preproc_update(orc_preproc_t *p, int16_t *i128, int16_t *q128) {
     int16_t *d = p->slip == 1 ? i128 : q128;
     const int16_t last = d[127];
     memmove(d + 1, d, 127 * sizeof(int16_t));
-    d[0] = p->saved;
+    i128[0] = p->saved; /* as compiled (0xefe8 stores through the I block's pointer in both cases): with Q delayed, the carried
+                         * Q sample lands in I[0] and Q[0] keeps the block's own first sample */
     p->saved = last;
   }
   if (p->detect) {

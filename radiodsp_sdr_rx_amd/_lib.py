@@ -285,6 +285,17 @@ SYMBOLS = [
     ("rdsp_engine_get_scalars", _i, [_vp, _f32p, _vp]),
     ("rdsp_engine_agc_curve", _f32p, [_vp]),
     ("rdsp_engine_sine_table", _f32p, [_vp]),
+    ("rdsp_preproc_create", _i, [_i, _i, C.POINTER(_vp)]),
+    ("rdsp_preproc_destroy", None, [_vp]),
+    ("rdsp_preproc_startAutoI2SerrorDetection", _i, [_vp]),
+    ("rdsp_preproc_swapIQ", _i, [_vp, _i]),
+    ("rdsp_preproc_update", _i, [_vp, _vp, _sz, _i, _vp, _sz, _vp]),
+    ("rdsp_preproc_get_state", _i, [_vp, _i16p, _vp]),
+    ("rdsp_preproc_channels", _i, [_vp]),
+    ("rdsp_preproc_device", _i, [_vp]),
+    ("rdsp_preproc_node_create", _vp, [_vp, _vp]),
+    ("rdsp_engine_node_create", _vp, [_vp, _vp]),
+    ("rdsp_engine_node_status", _i, [_vp]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
 

@@ -753,3 +753,172 @@ int rdsp_engine_get_scalars(rdsp_engine_t *e, float *host_out, void *stream) {
 }
 
 }  // extern "C"
+
+/* ==== `AudioSDRpreProcessor preProcessor;` (INO:53, wired INO:71-72, :117-118; image ::update 0xee88) ================
+ * The I2S input of the Teensy can start with one rail a sample late.  While detection is on, every block goes through a
+ * 128-point complex FFT; if the strongest of bins 5 ... 122 stands more than 10 x above their mean and its mirror image
+ * is less than 20 dB down, a bad-count rises; at the eleventh bad block in a row the remedy moves on (none -> I one
+ * sample later -> Q one sample later -> none); after 1000 counted blocks detection switches itself off.  swapIQ
+ * exchanges the rails on the way out.  One wave per channel: the transform is a radix-2 pass per LDS exchange, two
+ * points per lane; the scan over the bins, whose order the sums depend on, is the first lane's.  Blocks of a call are
+ * taken in order, since a block's verdict decides how the next one is read. */
+namespace {
+struct PreParams {
+  const int32_t *iq; size_t in_stride; int32_t *out; size_t out_stride;
+  int n_channels, n_blocks, swap, restart;
+  int16_t *st; /* [ch][6]: slip, saved sample, bad count, counted blocks, detecting, pad */
+  const float *tw; /* 64 x (cos, sin) of -2 pi k / 128 */
+};
+__global__ __launch_bounds__(64) void rdsp_preproc_kernel(const PreParams p) {
+  __shared__ float re[128], im[128];
+  __shared__ int16_t raw[2][129];
+  __shared__ int verdict[4];
+  const int lane = threadIdx.x, ch = blockIdx.x;
+  int16_t *st = p.st + (size_t)ch * 6;
+  int slip = p.restart ? 0 : st[0], saved = st[1], bad = p.restart ? 0 : st[2], checks = p.restart ? 0 : st[3], detect = p.restart ? 1 : st[4];
+  const int32_t *src = p.iq + (size_t)ch * p.in_stride;
+  int32_t *dst = p.out + (size_t)ch * p.out_stride;
+  for (int b = 0; b < p.n_blocks; b++) {
+    const int w0 = src[(size_t)b * BS + lane], w1 = src[(size_t)b * BS + lane + 64];
+    raw[0][lane + 1] = (int16_t)(w0 & 0xffff); raw[1][lane + 1] = (int16_t)(w0 >> 16);
+    raw[0][lane + 65] = (int16_t)(w1 & 0xffff); raw[1][lane + 65] = (int16_t)(w1 >> 16);
+    wg_sync<1>();
+    if (slip != 0) { /* the late rail is read one place to the left; its last sample waits for the next block.  As compiled
+                      * (0xefe8 stores through the I block's pointer in both cases), the carried sample always lands in
+                      * I[0]: with Q delayed, Q[0] keeps the block's own first sample */
+      const int r = slip == 1 ? 0 : 1;
+      const int last = raw[r][128];
+      if (lane == 0) { raw[0][slip == 1 ? 0 : 1] = (int16_t)saved; if (slip == -1) raw[1][0] = raw[1][1]; }
+      saved = last;
+    }
+    wg_sync<1>();
+    const int si = slip == 1 ? 0 : 1, sq = slip == -1 ? 0 : 1;
+    int i0 = raw[0][lane + si], i1 = raw[0][lane + 64 + si], q0 = raw[1][lane + sq], q1 = raw[1][lane + 64 + sq];
+    if (detect) {
+      /* decimation in time: bit-reversed load, then seven passes */
+      re[__brev((unsigned)lane) >> 25] = (float)i0 / 32767.0f; im[__brev((unsigned)lane) >> 25] = (float)q0 / 32767.0f;
+      re[__brev((unsigned)(lane + 64)) >> 25] = (float)i1 / 32767.0f; im[__brev((unsigned)(lane + 64)) >> 25] = (float)q1 / 32767.0f;
+      wg_sync<1>();
+      for (int half = 1; half < 128; half <<= 1) {
+        const int k = lane & (half - 1), a = ((lane - k) << 1) + k, bb = a + half;
+        const float wr = p.tw[2 * (k * (64 / half))], wi = p.tw[2 * (k * (64 / half)) + 1];
+        const float xr = re[bb] * wr - im[bb] * wi, xi = re[bb] * wi + im[bb] * wr;
+        const float ar = re[a], ai = im[a];
+        wg_sync<1>();
+        re[a] = ar + xr; im[a] = ai + xi; re[bb] = ar - xr; im[bb] = ai - xi;
+        wg_sync<1>();
+      }
+      const float m0 = sqrtf(re[lane] * re[lane] + im[lane] * im[lane]), m1 = sqrtf(re[lane + 64] * re[lane + 64] + im[lane + 64] * im[lane + 64]);
+      wg_sync<1>();
+      re[lane] = m0; re[lane + 64] = m1;
+      wg_sync<1>();
+      if (lane == 0) {
+        float top = 0.0f, sum = 0.0f;
+        int at = 0;
+        for (int k = 5; k < 123; k++) {
+          sum = sum + re[k];
+          if (re[k] > top) { top = re[k]; at = k; }
+        }
+        const float mean = sum / 118.0f;
+        if ((double)top > (double)mean * 10.0) {
+          if (top / re[128 - at] < 10.0f) {
+            bad = (int16_t)(bad + 1);
+            if (bad > 10) {
+              int s = (int16_t)(slip + 1);
+              bad = 0;
+              if (s > 1) s = -1;
+              slip = s;
+              checks = 1;
+            } else checks = (int16_t)(checks + 1);
+          } else {
+            checks = (int16_t)(checks + 1);
+            bad = 0;
+          }
+        }
+        if (checks > 1000) detect = 0;
+        verdict[0] = slip; verdict[1] = bad; verdict[2] = checks; verdict[3] = detect;
+      }
+      wg_sync<1>();
+      slip = verdict[0]; bad = verdict[1]; checks = verdict[2]; detect = verdict[3];
+    }
+    if (p.swap) { int t = i0; i0 = q0; q0 = t; t = i1; i1 = q1; q1 = t; }
+    dst[(size_t)b * BS + lane] = (int)((unsigned)(i0 & 0xffff) | ((unsigned)q0 << 16));
+    dst[(size_t)b * BS + lane + 64] = (int)((unsigned)(i1 & 0xffff) | ((unsigned)q1 << 16));
+    wg_sync<1>();
+  }
+  if (lane == 0) { st[0] = (int16_t)slip; st[1] = (int16_t)saved; st[2] = (int16_t)bad; st[3] = (int16_t)checks; st[4] = (int16_t)detect; }
+}
+}  // namespace
+
+struct rdsp_preproc {
+  int n_channels, device, swap, restart;
+  int16_t *d_st = nullptr;
+  float *d_tw = nullptr;
+};
+
+extern "C" {
+void rdsp_preproc_destroy(rdsp_preproc_t *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->d_st) (void)hipFree(p->d_st);
+  if (p->d_tw) (void)hipFree(p->d_tw);
+  delete p;
+}
+int rdsp_preproc_create(int n_channels, int device, rdsp_preproc_t **out) {
+  if (!out || n_channels < 1) return RDSP_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {
+    rdsp_set_error("rdsp_preproc_create: no HIP device (this library has no CPU path)");
+    return RDSP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count || hipSetDevice(device) != hipSuccess) return RDSP_ERR_INVALID;
+  rdsp_preproc_t *p = new rdsp_preproc();
+  p->n_channels = n_channels; p->device = device; p->swap = 0; p->restart = 0;
+  float tw[128];
+  for (int k = 0; k < 64; k++) { tw[2 * k] = (float)cos(-2.0 * 3.14159265358979323846 * k / 128.0); tw[2 * k + 1] = (float)sin(-2.0 * 3.14159265358979323846 * k / 128.0); }
+  hipError_t err = hipMalloc((void **)&p->d_st, (size_t)n_channels * 6 * sizeof(int16_t));
+  if (err == hipSuccess) err = hipMalloc((void **)&p->d_tw, sizeof tw);
+  if (err == hipSuccess) err = hipMemset(p->d_st, 0, (size_t)n_channels * 6 * sizeof(int16_t)); /* the sketch's static initialiser: nothing detected, not detecting */
+  if (err == hipSuccess) err = hipMemcpy(p->d_tw, tw, sizeof tw, hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    rdsp_preproc_destroy(p);
+    rdsp_set_error("rdsp_preproc_create: %s", hipGetErrorString(err));
+    return RDSP_ERR_NOMEM;
+  }
+  *out = p;
+  return RDSP_OK;
+}
+int rdsp_preproc_startAutoI2SerrorDetection(rdsp_preproc_t *p) { if (!p) return RDSP_ERR_INVALID; p->restart = 1; return RDSP_OK; } /* 0xf084 */
+int rdsp_preproc_swapIQ(rdsp_preproc_t *p, int on) { if (!p) return RDSP_ERR_INVALID; p->swap = on ? 1 : 0; return RDSP_OK; }
+int rdsp_preproc_channels(const rdsp_preproc_t *p) { return p ? p->n_channels : 0; }
+int rdsp_preproc_device(const rdsp_preproc_t *p) { return p ? p->device : -1; }
+/* AudioSDRpreProcessor::update() for n_blocks consecutive blocks of every channel; d_out may be d_iq */
+int rdsp_preproc_update(rdsp_preproc_t *p, const int16_t *d_iq, size_t in_stride, int n_blocks, int16_t *d_out, size_t out_stride, void *stream) {
+  if (!p || !d_iq || !d_out || n_blocks < 0 || in_stride < (size_t)n_blocks * BS || out_stride < (size_t)n_blocks * BS) return RDSP_ERR_INVALID;
+  if (n_blocks == 0) return RDSP_OK;
+  hipError_t err = hipSetDevice(p->device);
+  if (err != hipSuccess) return engine_fail("rdsp_preproc_update", err);
+  PreParams a;
+  a.iq = (const int32_t *)d_iq; a.in_stride = in_stride; a.out = (int32_t *)d_out; a.out_stride = out_stride;
+  a.n_channels = p->n_channels; a.n_blocks = n_blocks; a.swap = p->swap; a.restart = p->restart; a.st = p->d_st; a.tw = p->d_tw;
+  hipLaunchKernelGGL(rdsp_preproc_kernel, dim3((unsigned)p->n_channels), dim3(64), 0, (hipStream_t)stream, a);
+  err = hipGetLastError();
+  if (err != hipSuccess) return engine_fail("rdsp_preproc_update launch", err);
+  p->restart = 0;
+  return RDSP_OK;
+}
+/* [n_channels][4]: remedy in force (0 none, 1 I one sample later, -1 Q one sample later), bad count, counted blocks, detecting */
+int rdsp_preproc_get_state(rdsp_preproc_t *p, int16_t *host_out, void *stream) {
+  if (!p || !host_out) return RDSP_ERR_INVALID;
+  std::vector<int16_t> st((size_t)p->n_channels * 6);
+  hipError_t err = hipSetDevice(p->device);
+  if (err == hipSuccess) err = hipMemcpyAsync(st.data(), p->d_st, st.size() * 2, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) return engine_fail("rdsp_preproc_get_state", err);
+  for (int c = 0; c < p->n_channels; c++) {
+    host_out[4 * c] = st[6 * (size_t)c]; host_out[4 * c + 1] = st[6 * (size_t)c + 2]; host_out[4 * c + 2] = st[6 * (size_t)c + 3]; host_out[4 * c + 3] = st[6 * (size_t)c + 4];
+  }
+  return RDSP_OK;
+}
+}  // extern "C"

@@ -272,3 +272,100 @@ extern "C" int rdsp_spectrum_node_status(rdsp_node_t *n) {
   SpectrumNode *s = static_cast<SpectrumNode *>(rdsp_node_user(n));
   return s ? s->status : RDSP_ERR_INVALID;
 }
+
+/* ---- the reference's own engine objects as graph nodes -------------------------------------------------------------------
+ * `AudioSDRpreProcessor preProcessor;` and `AudioSDR SDR;` (RadioDSP_SDR_RX.ino:53-54) wired as INO:71-72,81-86: two inputs
+ * (I, Q tiles), two outputs, one block per tick like the library's update().  The arithmetic is rdsp_preproc_update /
+ * rdsp_engine_update (csrc/rdsp_engine.hip); the node only carries tiles to the device and back. */
+namespace {
+struct PairNode {
+  rdsp_engine_t *engine = nullptr;
+  rdsp_preproc_t *pre = nullptr;
+  int n_channels = 0, device = 0;
+  std::vector<int16_t> h_in, h_out; /* [ch][128][2] */
+  int16_t *d_in = nullptr, *d_out = nullptr;
+  hipStream_t stream = nullptr;
+  int status = RDSP_OK;
+};
+void pair_destroy(void *u) {
+  PairNode *s = static_cast<PairNode *>(u);
+  (void)hipSetDevice(s->device);
+  if (s->d_in) (void)hipFree(s->d_in);
+  if (s->d_out) (void)hipFree(s->d_out);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+void pair_update(rdsp_node_t *n, void *u) {
+  PairNode *s = static_cast<PairNode *>(u);
+  rdsp_block_t *bi = rdsp_receive_readonly(n, 0), *bq = rdsp_receive_readonly(n, 1);
+  if (!bi || !bq) { /* the library's update() returns when a block is missing (image 0xe756 ... 0xe77a, 0xeea4 ... 0xeebc) */
+    rdsp_release(bi);
+    rdsp_release(bq);
+    return;
+  }
+  const int16_t *pi = rdsp_block_data(bi), *pq = rdsp_block_data(bq);
+  for (int c = 0; c < s->n_channels; c++)
+    for (int i = 0; i < RDSP_BLOCK_SAMPLES; i++) {
+      s->h_in[((size_t)c * RDSP_BLOCK_SAMPLES + i) * 2] = pi[(size_t)c * RDSP_BLOCK_SAMPLES + i];
+      s->h_in[((size_t)c * RDSP_BLOCK_SAMPLES + i) * 2 + 1] = pq[(size_t)c * RDSP_BLOCK_SAMPLES + i];
+    }
+  rdsp_release(bi);
+  rdsp_release(bq);
+  hipError_t e = hipSetDevice(s->device);
+  if (e == hipSuccess) e = hipMemcpyAsync(s->d_in, s->h_in.data(), s->h_in.size() * sizeof(int16_t), hipMemcpyHostToDevice, s->stream);
+  int rc = RDSP_OK;
+  if (e == hipSuccess)
+    rc = s->engine ? rdsp_engine_update(s->engine, s->d_in, RDSP_BLOCK_SAMPLES, 1, s->d_out, RDSP_BLOCK_SAMPLES, s->stream)
+                   : rdsp_preproc_update(s->pre, s->d_in, RDSP_BLOCK_SAMPLES, 1, s->d_out, RDSP_BLOCK_SAMPLES, s->stream);
+  if (e == hipSuccess && rc == RDSP_OK)
+    e = hipMemcpyAsync(s->h_out.data(), s->d_out, s->h_out.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && rc == RDSP_OK) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || rc != RDSP_OK) {
+    s->status = rc != RDSP_OK ? rc : RDSP_ERR_HIP;
+    if (e != hipSuccess) rdsp_set_error("engine node: %s", hipGetErrorString(e));
+    return;
+  }
+  rdsp_block_t *b0 = rdsp_allocate(n), *b1 = rdsp_allocate(n);
+  if (b0 && b1) {
+    int16_t *o0 = rdsp_block_data(b0), *o1 = rdsp_block_data(b1);
+    for (int c = 0; c < s->n_channels; c++)
+      for (int i = 0; i < RDSP_BLOCK_SAMPLES; i++) {
+        o0[(size_t)c * RDSP_BLOCK_SAMPLES + i] = s->h_out[((size_t)c * RDSP_BLOCK_SAMPLES + i) * 2];
+        o1[(size_t)c * RDSP_BLOCK_SAMPLES + i] = s->h_out[((size_t)c * RDSP_BLOCK_SAMPLES + i) * 2 + 1];
+      }
+    rdsp_transmit(n, b0, 0);
+    rdsp_transmit(n, b1, 1);
+  }
+  rdsp_release(b0);
+  rdsp_release(b1);
+}
+rdsp_node_t *pair_create(rdsp_graph_t *g, rdsp_engine_t *engine, rdsp_preproc_t *pre) {
+  const int nch = engine ? rdsp_engine_channels(engine) : rdsp_preproc_channels(pre);
+  if (!g || rdsp_graph_channels(g) != nch) {
+    rdsp_set_error("engine / pre-processor node: graph and object must have the same channel count");
+    return nullptr;
+  }
+  PairNode *s = new PairNode();
+  s->engine = engine; s->pre = pre; s->n_channels = nch;
+  s->device = engine ? rdsp_engine_device(engine) : rdsp_preproc_device(pre);
+  s->h_in.assign((size_t)nch * RDSP_BLOCK_SAMPLES * 2, 0);
+  s->h_out.assign(s->h_in.size(), 0);
+  if (hipSetDevice(s->device) != hipSuccess || hipMalloc((void **)&s->d_in, s->h_in.size() * sizeof(int16_t)) != hipSuccess ||
+      hipMalloc((void **)&s->d_out, s->h_in.size() * sizeof(int16_t)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess) {
+    rdsp_set_error("engine / pre-processor node: device allocation failed");
+    pair_destroy(s);
+    return nullptr;
+  }
+  rdsp_node_t *n = rdsp_node_create(g, 2, pair_update, s);
+  if (!n) { pair_destroy(s); return nullptr; }
+  rdsp_node_set_destructor(n, pair_destroy);
+  return n;
+}
+}  // namespace
+
+extern "C" rdsp_node_t *rdsp_engine_node_create(rdsp_graph_t *g, rdsp_engine_t *e) { return e ? pair_create(g, e, nullptr) : nullptr; }
+extern "C" rdsp_node_t *rdsp_preproc_node_create(rdsp_graph_t *g, rdsp_preproc_t *p) { return p ? pair_create(g, nullptr, p) : nullptr; }
+extern "C" int rdsp_engine_node_status(rdsp_node_t *n) {
+  PairNode *s = static_cast<PairNode *>(rdsp_node_user(n));
+  return s ? s->status : RDSP_ERR_INVALID;
+}

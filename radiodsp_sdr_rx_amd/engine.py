@@ -82,3 +82,41 @@ for _n in ("enableAGC", "setAGCmode", "enableALSfilter", "disableALSfilter", "se
            "setALSfilterAdaptive", "enableNoiseBlanker", "disableNoiseBlanker", "setInputGain", "setOutputGain",
            "setIQgainBalance", "enableAudioFilter", "setAudioFilter", "setMute"):
     setattr(Engine, _n, _setter(_n))
+
+
+class PreProcessor:
+    """`AudioSDRpreProcessor preProcessor;` (INO:53): rdsp_preproc_* of include/rdsp.h"""
+
+    def __init__(self, n_channels, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.rdsp_preproc_create(n_channels, device, C.byref(h)))
+        self.h, self.n_channels = h, n_channels
+
+    def close(self):
+        if self.h:
+            self.lib.rdsp_preproc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def startAutoI2SerrorDetection(self):
+        check(self.lib.rdsp_preproc_startAutoI2SerrorDetection(self.h))
+
+    def swapIQ(self, on):
+        check(self.lib.rdsp_preproc_swapIQ(self.h, int(bool(on))))
+
+    def update(self, d_iq, out=None, stream=None):
+        import torch
+        nch, n, two = d_iq.shape
+        assert nch == self.n_channels and two == 2 and n % 128 == 0 and d_iq.dtype == torch.int16 and d_iq.is_contiguous()
+        if out is None:
+            out = torch.empty_like(d_iq)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.rdsp_preproc_update(self.h, d_iq.data_ptr(), n, n // 128, out.data_ptr(), n, C.c_void_p(s)))
+        return out
+
+    def state(self):
+        o = np.zeros((self.n_channels, 4), np.int16)
+        check(self.lib.rdsp_preproc_get_state(self.h, o.ctypes.data_as(C.POINTER(C.c_int16)), None))
+        return o

@@ -64,6 +64,22 @@ class Graph:
         self._keep.append(chain)
         return Node(self, C.c_void_p(h))
 
+    def engine_node(self, engine):
+        """`AudioSDR SDR;` as the reference's engine computes it (INO:54, wired INO:81-86): radiodsp_sdr_rx_amd.engine.Engine"""
+        h = self.lib.rdsp_engine_node_create(self.h, engine.h)
+        if not h:
+            raise _lib.RdspError(-1, self.lib.rdsp_last_error().decode())
+        self._keep.append(engine)
+        return EngineNode(self, C.c_void_p(h))
+
+    def preproc_node(self, pre):
+        """`AudioSDRpreProcessor preProcessor;` (INO:53, wired INO:71-72): radiodsp_sdr_rx_amd.engine.PreProcessor"""
+        h = self.lib.rdsp_preproc_node_create(self.h, pre.h)
+        if not h:
+            raise _lib.RdspError(-1, self.lib.rdsp_last_error().decode())
+        self._keep.append(pre)
+        return EngineNode(self, C.c_void_p(h))
+
     def spectrum_node(self, analyser):
         """AudioAnalyzeFFT256IQ as a node (INO:57,73-74): inputs I, Q; available()/output like FFTIQ.h"""
         h = self.lib.rdsp_spectrum_node_create(self.h, analyser.h)
@@ -138,6 +154,11 @@ class Node:
 
     def status(self):
         return self.g.lib.rdsp_sdr_node_status(self.h)
+
+
+class EngineNode(Node):
+    def status(self):
+        return self.g.lib.rdsp_engine_node_status(self.h)
 
 
 class SpectrumNode(Node):

@@ -94,3 +94,39 @@ class EngineRef:
 
     def tap(self, name):
         return np.stack(self.taps[name])                      # [blocks][buffers][128]
+
+
+class PreRef:
+    """`AudioSDRpreProcessor preProcessor;` (INO:53): the object as the sketch's static initialiser leaves it
+    (ITCM 0x93e8 ... 0x9442: AudioStream's constructor, the vtable, a float 1.0 at +0x420, a flag at +1073, everything else
+    zero), then startAutoI2SerrorDetection() (INO:117) unless told otherwise; update() = 0xee88"""
+    OBJ = 0x2001dd0c
+    UPDATE, START = 0xee88, 0xf084
+
+    def __init__(self, im=None, start=True):
+        self.r = r = M.Ref(im or Image())
+        self.bl = M.Blocks(r, 16)
+        self.cur, self.sent = {}, {}
+        h = r.cpu.hooks
+        h[M.A["receiveWritable"]] = lambda c: c.r.__setitem__(0, self.cur[c.r[1]])
+        h[M.A["release"]] = lambda c: None
+        h[M.A["transmit"]] = lambda c: self.sent.__setitem__(c.r[2], r.get(c.r[1] + 4, 128, np.int16))
+        r.m.write_bytes(self.OBJ, bytes(1080))
+        r.put(self.OBJ + 0x420, np.array([1.0], np.float32))
+        r.m.write(self.OBJ + 1073, 1, 1)
+        if start:
+            r.call_addr(self.START, self.OBJ)
+
+    def swapIQ(self, on):
+        self.r.m.write(self.OBJ + 1072, 1, 1 if on else 0)      # INO:118 (commented out in the sketch; the flag update() reads)
+
+    def state(self):
+        """slip (-1, 0, 1), bad count, checked blocks, detecting"""
+        s = self.r.get(self.OBJ + 1064, 4, np.int16)
+        return int(s[0]), int(s[2]), int(s[3]), int(self.r.m.read(self.OBJ + 1074, 1))
+
+    def update(self, i128, q128):
+        self.cur[0], self.cur[1] = self.bl.new(i128), self.bl.new(q128)
+        self.sent.clear()
+        self.r.call_addr(self.UPDATE, self.OBJ)
+        return self.sent[0].copy(), self.sent[1].copy()

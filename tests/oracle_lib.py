@@ -386,3 +386,33 @@ class OracleEngine:
         """the fixture's `_final` row: oscillator phase, AGC gain / envelope / hang / active, PLL Hz / lock, blanker hit"""
         s = lambda k: self.lib.orc_engine_scalar(self.e, k)
         return np.array([s(0), s(1), s(2), s(3), s(4), s(5), s(6), s(9)], np.float32)
+
+
+class OraclePreProcessor:
+    """orc_preproc_t: AudioSDRpreProcessor (INO:53) for one receiver, as the sketch starts it (INO:117)"""
+
+    def __init__(self, start=True, swap=False):
+        self.lib = load()
+        self.lib.orc_preproc_create.restype = C.c_void_p
+        for n, a in (("destroy", []), ("startAutoI2SerrorDetection", []), ("swapIQ", [C.c_int]), ("state", [C.c_int]), ("update", [_I16P, _I16P])):
+            getattr(self.lib, "orc_preproc_" + n).argtypes = [C.c_void_p] + a
+        self.p = self.lib.orc_preproc_create()
+        if start:
+            self.lib.orc_preproc_startAutoI2SerrorDetection(self.p)
+        if swap:
+            self.lib.orc_preproc_swapIQ(self.p, 1)
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.lib.orc_preproc_destroy(self.p)
+            self.p = None
+
+    def run(self, iq):
+        """int16 [n, 2] -> (int16 [n, 2], state int16 [blocks, 4] = remedy, bad count, counted blocks, detecting)"""
+        out, st = np.zeros_like(iq), np.zeros((len(iq) // 128, 4), np.int16)
+        for b in range(len(iq) // 128):
+            i, q = np.ascontiguousarray(iq[b * 128:(b + 1) * 128, 0]), np.ascontiguousarray(iq[b * 128:(b + 1) * 128, 1])
+            self.lib.orc_preproc_update(self.p, i.ctypes.data_as(_I16P), q.ctypes.data_as(_I16P))
+            out[b * 128:(b + 1) * 128, 0], out[b * 128:(b + 1) * 128, 1] = i, q
+            st[b] = [self.lib.orc_preproc_state(self.p, k) for k in range(4)]
+        return out, st
