@@ -122,7 +122,8 @@ def test_gpu_the_sketchs_graph_block_by_block(kat, rdsp):
     name = "sketch_path_slip"
     iq = kat[name + "_iq"]
     nblk = len(iq) // 128
-    pre, eng, conv = _objects(1, 1)
+    pre, eng, conv = _objects(1, 2)
+    unit = conv.call_unit_blocks
     g = Graph(1)
     g.AudioMemory(40)                                             # INO:151
     IQinput = g.input_node()                                      # INO:52
@@ -152,15 +153,19 @@ def test_gpu_the_sketchs_graph_block_by_block(kat, rdsp):
         if b < nblk:
             IQinput.push(iq[None, b * 128:(b + 1) * 128, 0], iq[None, b * 128:(b + 1) * 128, 1])
         assert g.update_all() == 0
-        while Q_in_L.available() > 0 and Q_in_R.available() > 0:          # loop(), INO:198 (one block at a time here)
-            l, r = Q_in_L.readBuffer().copy(), Q_in_R.readBuffer().copy()
-            Q_in_L.freeBuffer(); Q_in_R.freeBuffer()
-            seen.append(l[0])
-            y = conv.doConvolutionalProcessing(15.0, True, 300.0, 4000.0, torch.from_numpy(np.stack([l, r], 2)).cuda()).cpu().numpy()
-            ol, orr = Q_out_L.getBuffer(), Q_out_R.getBuffer()
-            ol[:] = y[:, :, 0]; orr[:] = y[:, :, 1]
-            assert Q_out_L.playBuffer() == 0 and Q_out_R.playBuffer() == 0
-            assert g.update_all() == 0
+        while Q_in_L.available() >= unit and Q_in_R.available() >= unit:  # loop(), INO:198: the chain's call unit at a time
+            ls, rs = [], []
+            for _ in range(unit):
+                ls.append(Q_in_L.readBuffer().copy()); rs.append(Q_in_R.readBuffer().copy())
+                Q_in_L.freeBuffer(); Q_in_R.freeBuffer()
+                seen.append(ls[-1][0])
+            x = np.stack([np.concatenate(ls, 1), np.concatenate(rs, 1)], 2)
+            y = conv.doConvolutionalProcessing(15.0, True, 300.0, 4000.0, torch.from_numpy(x).cuda()).cpu().numpy()
+            for k in range(unit):
+                ol, orr = Q_out_L.getBuffer(), Q_out_R.getBuffer()
+                ol[:] = y[:, k * 128:(k + 1) * 128, 0]; orr[:] = y[:, k * 128:(k + 1) * 128, 1]
+                assert Q_out_L.playBuffer() == 0 and Q_out_R.playBuffer() == 0
+                assert g.update_all() == 0
     assert SDR.status() == 0 and preProcessor.status() == 0
     assert np.array_equal(np.concatenate(seen), kat[name + "_sdr"])
     assert one_count(np.concatenate(heard), kat[name + "_audio"])
