@@ -23,7 +23,7 @@
 
 static FILE *f_in, *f_out, *f_spec;
 static long blocks_left;
-static int16_t h_iq[MAX_BLOCKS * RDSP_BLOCK_SAMPLES * 2], h_out[MAX_BLOCKS * RDSP_BLOCK_SAMPLES / 4 * 2];
+static int16_t h_iq[MAX_BLOCKS * RDSP_BLOCK_SAMPLES * 2], h_out[MAX_BLOCKS * RDSP_BLOCK_SAMPLES / OUT_DIV * 2];
 
 int queued_blocks(void) { return blocks_left > MAX_BLOCKS ? MAX_BLOCKS : (int)blocks_left; }
 void upload_queued_iq(int16_t *d_iq, int n_blocks, hipStream_t s) {
@@ -51,12 +51,22 @@ static uint32_t TuningOffset;
 
 static void setup(void) {           /* RadioDSP_SDR_RX.ino:102-187, the DSP part */
   doConvolutionalInitialize();      /* the chain must exist before the engine setters can reach it */
-#ifdef RDSP_BIND_LITERAL            /* the CONV stage alone, fed what the image's record queues were fed: no engine in front */
+#if defined(RDSP_BIND_LITERAL) && !defined(RDSP_BIND_ENGINE) /* the CONV stage alone, fed what the image's record queues were fed: no engine in front */
   if (getenv("RDSP_NR_LEVEL")) nr_level = atoi(getenv("RDSP_NR_LEVEL"));
   Init_LMS_NR(15);                            /* :172 */
   reInitializeFilter(300.0, 4000.0);          /* :183 */
   (void)TuningOffset; (void)SDR_setDemodMode;
   return;
+#endif
+#ifdef RDSP_BIND_ENGINE             /* the sketch as shipped: INO:53-54's objects are the reference's own */
+  {
+    static float tables[364];
+    FILE *ft = getenv("RDSP_ENGINE_TABLES") ? fopen(getenv("RDSP_ENGINE_TABLES"), "rb") : NULL;
+    if (!ft || fread(tables, sizeof(float), 364, ft) != 364) { fprintf(stderr, "RDSP_ENGINE_TABLES: 364 floats expected\n"); exit(2); }
+    fclose(ft);
+    engine_begin(tables);
+    nr_level = 15;                            /* RDSP_general_includes.h:111 as the image has it at start-up */
+  }
 #endif
   preProcessor_startAutoI2SerrorDetection();  /* :117 */
   SDR_enableAGC();                            /* :120 */

@@ -22,6 +22,9 @@
 #define MAX_BLOCKS 64   /* 128-sample blocks per call and channel */
 #endif
 #define IN_STRIDE ((size_t)MAX_BLOCKS * RDSP_BLOCK_SAMPLES)
+#ifdef RDSP_BIND_ENGINE  /* the whole sketch as shipped: the reference's own pre-processor and engine in front of its CONV stage */
+#define RDSP_BIND_LITERAL
+#endif
 #ifdef RDSP_BIND_LITERAL /* the CONV stage as the shipped sketch runs it, behind the engine: 44.1 kHz, no mixer, no decimator */
 #define OUT_DIV 1
 #else
@@ -78,17 +81,58 @@ static void reInitializeFilter(double lo, double hi) { /* RDSP_convolutional.h:2
 static void Init_LMS_NR(int strength) { /* RDSP_noise_reduction.h:35 */
   RDSP_BIND_CHECK(rdsp_Init_LMS_NR(g_chain, strength, g_stream));
 }
+#ifdef RDSP_BIND_ENGINE
+static rdsp_preproc_t *g_pre; /* `AudioSDRpreProcessor preProcessor;` INO:53 */
+static rdsp_engine_t *g_sdr;  /* `AudioSDR SDR;`                       INO:54 */
+/* the constructors of INO:53-54; `tables` = the engine's 15 x 20 biquad coefficients and 64 Hilbert taps (no closed form:
+ * a host takes them from the AudioSDR library it has, the tests from tests/golden/firmware_tables.npz) */
+static void engine_begin(const float *tables364) {
+  RDSP_BIND_CHECK(rdsp_preproc_create(N_CH, 0, &g_pre));
+  RDSP_BIND_CHECK(rdsp_engine_create(N_CH, 0, MAX_BLOCKS, &g_sdr));
+  RDSP_BIND_CHECK(rdsp_engine_load_tables(g_sdr, tables364, tables364 + 300));
+}
+/* the audio interrupt's part of a tick, n blocks at a time: IQinput -> preProcessor -> SDR -> record queues (INO:71-72,81-86) */
+static void engine_update(int16_t *d_iq, int n) {
+  RDSP_BIND_CHECK(rdsp_preproc_update(g_pre, d_iq, IN_STRIDE, n, d_iq, IN_STRIDE, g_stream));
+  RDSP_BIND_CHECK(rdsp_engine_update(g_sdr, d_iq, IN_STRIDE, n, d_iq, IN_STRIDE, g_stream));
+}
+#endif
 static void doConvolutionalProcessing(float nr, boolean filt, double lo, double hi) { /* CONV:228 */
   int n = queued_blocks();                     /* Q_in_L.available(), CONV:231 */
   if (n > MAX_BLOCKS) n = MAX_BLOCKS;
   n -= n % rdsp_chain_granule_blocks(g_chain);
   if (n <= 0) return;                          /* the same silent skip as the sketch */
   upload_queued_iq(g_d_iq, n, g_stream);
+#ifdef RDSP_BIND_ENGINE
+  engine_update(g_d_iq, n);                    /* what the record queues hold is the engine's audio */
+#endif
   RDSP_BIND_CHECK(rdsp_doConvolutionalProcessing(g_chain, nr, filt, lo, hi, g_d_iq, IN_STRIDE, n, g_d_out,
                                                  OUT_STRIDE, g_stream));
   play_audio(g_d_out, n * RDSP_BLOCK_SAMPLES / OUT_DIV, g_stream);
 }
 
+#ifdef RDSP_BIND_ENGINE
+/* the engine's own objects behind the sketch's call sites (RadioDSP_SDR_RX.ino:117-139,177), the engine's own numbers */
+enum { AGCoff = 0, AGCfast = 1, AGCmedium = 2, AGCslow = 3 };
+enum { LSBmode = 0, USBmode = 1, CW_LSBmode = 2, CW_USBmode = 3, AMmode = 4, SAMmode = 5 };
+enum { audioAM = 0, audioCW = 1, audio2100 = 3, audio2700 = 6, audio3100 = 8 };
+#define preProcessor_startAutoI2SerrorDetection() RDSP_BIND_CHECK(rdsp_preproc_startAutoI2SerrorDetection(g_pre))
+#define preProcessor_swapIQ(b)      RDSP_BIND_CHECK(rdsp_preproc_swapIQ(g_pre, (b)))
+#define SDR_enableAGC()             RDSP_BIND_CHECK(rdsp_engine_enableAGC(g_sdr))
+#define SDR_setAGCmode(m)           RDSP_BIND_CHECK(rdsp_engine_setAGCmode(g_sdr, (m)))
+#define SDR_enableALSfilter()       RDSP_BIND_CHECK(rdsp_engine_enableALSfilter(g_sdr))
+#define SDR_disableALSfilter()      RDSP_BIND_CHECK(rdsp_engine_disableALSfilter(g_sdr))
+#define SDR_setALSfilterNotch()     RDSP_BIND_CHECK(rdsp_engine_setALSfilterNotch(g_sdr))
+#define SDR_setALSfilterAdaptive()  RDSP_BIND_CHECK(rdsp_engine_setALSfilterAdaptive(g_sdr))
+#define SDR_disableNoiseBlanker()   RDSP_BIND_CHECK(rdsp_engine_disableNoiseBlanker(g_sdr))
+#define SDR_setInputGain(g)         RDSP_BIND_CHECK(rdsp_engine_setInputGain(g_sdr, (g)))
+#define SDR_setOutputGain(g)        RDSP_BIND_CHECK(rdsp_engine_setOutputGain(g_sdr, (g)))
+#define SDR_setIQgainBalance(g)     RDSP_BIND_CHECK(rdsp_engine_setIQgainBalance(g_sdr, (g)))
+#define SDR_enableAudioFilter()     RDSP_BIND_CHECK(rdsp_engine_enableAudioFilter(g_sdr))
+#define SDR_setAudioFilter(f)       RDSP_BIND_CHECK(rdsp_engine_setAudioFilter(g_sdr, (f)))
+#define SDR_setDemodMode(m)         ((uint32_t)rdsp_engine_setDemodMode(g_sdr, (m)))   /* `TuningOffset = SDR.setDemodMode(LSBmode);` INO:139 */
+#define SDR_setMute(b)              RDSP_BIND_CHECK(rdsp_engine_setMute(g_sdr, (b)))
+#else
 /* the engine object keeps its call sites (RadioDSP_SDR_RX.ino:117-139,177) */
 enum { AGCoff = RDSP_AGC_OFF, AGCfast = RDSP_AGC_FAST, AGCmedium = RDSP_AGC_MEDIUM, AGCslow = RDSP_AGC_SLOW };
 enum { LSBmode = RDSP_DEMOD_LSB, USBmode = RDSP_DEMOD_USB, CW_LSBmode = RDSP_DEMOD_CW_LSB,
@@ -115,6 +159,7 @@ static inline uint32_t SDR_setDemodMode(int m) {
   return off;
 }
 #define SDR_setMute(b)              RDSP_BIND_CHECK(rdsp_sdr_setMute(g_chain, (b)))
+#endif
 
 /* ---- the panadapter side of the graph: `AudioFilterBiquad biquad1, biquad2; AudioAnalyzeFFT256IQ FFT;`
  * (.ino:57-59), IQinput -> biquad1 / biquad2 -> FFT (.ino:75-78), `biquadN.setHighpass(0, 500, 0.5)` (.ino:155-156),

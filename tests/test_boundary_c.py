@@ -120,6 +120,39 @@ def test_the_sketch_over_the_c_binding_against_the_sketchs_own_binary(rdsp, tmp_
     assert d.max() <= 1 and (d > 0).sum() <= 400
 
 
+def test_engine_sketch_binding_compiles(rdsp, tmp_path):
+    exe = build(tmp_path, defines=["-DRDSP_BIND_ENGINE"], out="binding_engine")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sketch_path", "sketch_path_slip"])
+def test_the_whole_sketch_over_the_c_binding_against_the_images_audio(rdsp, tmp_path, name):
+    """-DRDSP_BIND_ENGINE: setup() and loop() of the sketch in C with `preProcessor.` and `SDR.` bound to the reference's
+    own objects (rdsp_preproc_t, rdsp_engine_t) in front of the CONV stage, all of INO:117-139,172-183 as written, fed the
+    IQ the firmware image's three routines were fed when chained under the interpreter (tests/golden/sketch_kat.npz):
+    the int16 audio the C program plays is the image's to one count"""
+    import oracle_lib
+    kat = np.load(os.path.join(ROOT, "tests", "golden", "sketch_kat.npz"))
+    iq = kat[name + "_iq"]
+    nblk = len(iq) // 128
+    fin, fout, ftab = tmp_path / "iq.raw", tmp_path / "audio.raw", tmp_path / "tables.raw"
+    iq.tofile(fin)
+    np.concatenate(oracle_lib.engine_tables()).astype(np.float32).tofile(ftab)
+    exe = build(tmp_path, defines=["-DRDSP_BIND_ENGINE"], out="binding_engine")
+    r = subprocess.run([exe, str(fin), str(fout), str(nblk)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RDSP_ENGINE_TABLES=str(ftab)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "TuningOffset 8390" in r.stdout
+    got = np.fromfile(fout, dtype=np.int16).reshape(-1, 2)
+    want = kat[name + "_audio"]
+    assert got.shape == want.shape
+    d = np.abs(got.astype(np.int32) - want)
+    print(f"C binding, {name}: {int((d > 0).sum())} of {d.size} samples one count from the image's audio")
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+
+
 def test_sharding_host_in_c_compiles_and_links(rdsp, tmp_path):
     exe = build(tmp_path, "shard_threads")
     r = subprocess.run([exe], capture_output=True, text=True)
