@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="K3", choices=["K1", "K2", "K3", "K4", "K5", "F1"])
+    ap.add_argument("--config", default="K3", choices=["K1", "K2", "K3", "K4", "K5", "F1", "ENGINE"])
     ap.add_argument("--channels-per-gpu", type=int, default=0)
     ap.add_argument("--blocks", type=int, default=512, help="128-sample input blocks per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -410,7 +410,8 @@ def dominant_kernel(fname, front_avg, tail_avg, decim):
     return fname, front_avg, algorithmic_bytes_per_sample(decim)
 
 
-def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant, barrier, iq=None, label=None):
+def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant, barrier, iq=None, label=None,
+              as_written=False):
     """One more BASELINE.json configuration after the headline leg, timed the same way (inputs resident in HBM,
     warm-up, barrier + synchronize on both sides, max over ranks, per-kernel HIP events): K2 / K4 / the K5
     per-GPU shape, so that the driver's one run carries a number for every GPU configuration."""
@@ -425,6 +426,8 @@ def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_ra
     out = torch.empty((nch, n_samples // decim, 2), dtype=torch.int16, device=dev)
     ch = Chain(nch, max_blocks_per_call=nblk, device=local_rank, fir_variant=fir_variant, **cfg)
     ch.set_pipelined(not args.no_pipeline)
+    if as_written:
+        ch.set_spectral_resynthesis(True)   # SPEC:229-232 as written: atan2, arm_cos_f32 / arm_sin_f32
     steps = max(20, min(args.steps, 60))
     for _ in range(40):   # un-timed: the same settling as the headline leg gets (set-up + warm-up)
         ch.process(iq, out=out)
@@ -458,9 +461,73 @@ def extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_ra
            "roofline": {"bound": "hbm", "limiter": "valu", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": ctr.get(dom, {}).get("hbm_bytes"),
                         "counters_note": note}}
+    if as_written:
+        leg["spectral_resynthesis"] = "as written (SPEC:229-232: atan2, arm_cos_f32 / arm_sin_f32 table)"
     del ch, out, iq
     torch.cuda.empty_cache()
     return leg
+
+
+def engine_leg(torch, args, dev, local_rank, synth_iq):
+    """The reference's own signal path (INO:53-54,81-86,198), not this build's many-channel receiver: rdsp_engine_t =
+    AudioSDR::update() as the firmware image computes it (bit for bit, tests/test_engine_kat.py) and behind it the CONV
+    stage with the NLMS on, at the sketch's start-up settings, native rate (44.1 kHz, no decimation: 8 B per sample of
+    algorithm), 4096 receivers x 32 blocks per step.  Every stage of the engine but its Hilbert transformer is a recursion
+    in time evaluated in the image's operation order, so the parallel axes are channels and rails only: the leg is bound by
+    the latency of those recursions, and its HBM fraction says so.  CPU beside it: the oracle's restatement of the same
+    engine, one thread, a bounded sample."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import oracle_lib
+    from cases import CONV_LITERAL
+    from radiodsp_sdr_rx_amd.chain import Chain
+    from radiodsp_sdr_rx_amd.engine import Engine
+    nch, nblk, steps = 4096, 32, 20
+    n = nblk * 128
+    host = synth_iq(nch, n, n_threads=host_cores(1))
+    iq = torch.from_numpy(host).to(dev)
+    eng = Engine(nch, max_blocks_per_call=nblk, device=local_rank, tables=oracle_lib.engine_tables())
+    eng.sketch_setup()
+    conv = Chain(nch, max_blocks_per_call=nblk, device=local_rank, **dict(CONV_LITERAL, lms_nr=15))
+    mid, out = torch.empty_like(iq), torch.empty_like(iq)
+    res = {}
+    for name, both in (("engine", False), ("engine_then_conv_stage", True)):
+        for _ in range(5):
+            eng.update(iq, out=mid)
+            if both:
+                conv.process(mid, out=out)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for _ in range(steps):
+            eng.update(iq, out=mid)
+            if both:
+                conv.process(mid, out=out)
+        ev[1].record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        v = float(nch) * n * steps / el
+        res[name] = {"ms_per_step": el / steps * 1e3, "ms_per_step_events": ev[0].elapsed_time(ev[1]) / steps, "value": v / 1e6,
+                     "unit": "IQ Msamples/s", "achieved_GBps": 8.0 * v / 1e9, "frac_of_hbm_peak": 8.0 * v / 1e9 / HBM_PEAK_GBS}
+    o = oracle_lib.OracleEngine()
+    x = host[0]
+    t0, blocks = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 3.0:
+        o.run(x)
+        blocks += nblk
+    cpu = blocks * 128 / (time.perf_counter() - t0) / 1e6
+    del eng, conv, iq, mid, out
+    torch.cuda.empty_cache()
+    return {"config": "engine_literal",
+            "workload": f"the reference's own engine: {nch} receivers x {nblk} blocks of 128 int16 IQ samples @44.1 kHz per step; AudioSDR::update() "
+                        "as the firmware image computes it (LSBmode, audio2700, AGC medium; INO:117-139), then the CONV stage with the NLMS (INO:172-198)",
+            "parity": "int16 audio of the engine bit for bit the image's (37 cases, tests/test_engine_kat.py); the chained path within one count "
+                      "(tests/test_sketch_path.py)",
+            "algorithmic_bytes_per_sample": 8.0, "channels_per_gpu": nch, "steps": steps, "legs": res,
+            "bound": "latency of serial recursions (biquad cascades, oscillator phase, AGC): one lane per channel and rail; not HBM",
+            "cpu_baseline": {"value": cpu, "unit": "IQ Msamples/s", "cores": 1, "kind": "port",
+                             "sample": f"oracle/rdsp_engine_oracle.c, one receiver, {blocks} blocks in 3 s"}}
 
 
 def main():
@@ -474,6 +541,13 @@ def main():
         return f1_main(args)
     if args.config == "K1":
         return k1_main(args)
+    if args.config == "ENGINE":   # the reference's own engine path alone (the `engine_literal` leg of the default run)
+        import torch
+        from radiodsp_sdr_rx_amd.chain import synth_iq
+        assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+        torch.cuda.set_device(0)
+        print(json.dumps(engine_leg(torch, args, torch.device("cuda", 0), 0, synth_iq)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)   # before any torch / HIP call in this process
 
@@ -616,13 +690,20 @@ def main():
     if default_shape and not args.no_extra_legs and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
         # K3_default: the headline workload with the library's DEFAULT decimator (one granule per frame), i.e. what a
         # caller who selects nothing gets; then the other configurations in the headline's form
-        which = ["K5"] if world > 1 else ["K3_default", "K2", "K5", "K4"]
+        which = ["K5"] if world > 1 else ["K3_default", "K3_as_written", "K2", "K5", "K4", "engine_literal"]
         for name in which:
-            reuse = iq if name in ("K2", "K3_default") else None   # same generator, same channels as the headline leg
+            reuse = iq if name in ("K2", "K3_default", "K3_as_written") else None   # same generator, same channels as the headline leg
             try:
                 if name == "K3_default":
                     legs[name] = extra_leg("K3", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, -1,
                                            barrier, iq=reuse, label="K3_default")
+                    continue
+                if name == "K3_as_written":   # the headline workload with the spectral stage's re-synthesis as SPEC:229-232 writes it
+                    legs[name] = extra_leg("K3", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant,
+                                           barrier, iq=reuse, label="K3_as_written", as_written=True)
+                    continue
+                if name == "engine_literal":
+                    legs[name] = engine_leg(torch, args, dev, local_rank, synth_iq)
                     continue
                 legs[name] = extra_leg(name, torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, fir_variant,
                                        barrier, iq=reuse)

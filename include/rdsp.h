@@ -231,7 +231,11 @@ int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* on: 0, 1 (S
  * entries, linear interpolation) restated from the published routine.  literal = 0 (default): the exact-arithmetic
  * equivalent X mag'/mag.  The two sit 1.7e-5 ... 1.9e-5 of the output's peak apart (the table's interpolation error,
  * (2 pi / 512)^2 / 8), so "within 1e-5 of the reference's CPU path" can only hold for one of them at a time: each form
- * is tested <= 1e-5 against the oracle evaluating the SAME form (tests/test_gpu_parity.py). */
+ * is tested <= 1e-5 against the oracle evaluating the SAME form (tests/test_gpu_parity.py).  literal = 1 evaluates
+ * the table's interpolation in closed form (csrc/rdsp_kernels.hip spec_table_factor: the as-written bin is the exact one
+ * times 1 - (h^2 / 2) f (1 - f), f the fraction between table nodes; within 5e-8 of the table's own arithmetic, +5 % on a
+ * K3 step); literal = 2 calls atan2f and looks the table up (round 5's code, +35 %); both are held to the oracle's
+ * literal form. */
 int rdsp_set_spectral_resynthesis(rdsp_chain_t *c, int literal);
 
 /* ---- receiver groups: per-group retune / PBT / mode tables -------

@@ -164,7 +164,7 @@ class Chain:
     def set_nr_level(self, lvl): _lib.check(self.lib.rdsp_set_nr_level(self.h, int(lvl)))
     def set_spectral_nr(self, on, level): _lib.check(self.lib.rdsp_set_spectral_nr(self.h, int(on), float(level)))
     def set_nlms_energy_mode(self, running): _lib.check(self.lib.rdsp_set_nlms_energy_mode(self.h, int(bool(running))))
-    def set_spectral_resynthesis(self, literal): _lib.check(self.lib.rdsp_set_spectral_resynthesis(self.h, int(bool(literal))))
+    def set_spectral_resynthesis(self, literal): _lib.check(self.lib.rdsp_set_spectral_resynthesis(self.h, 2 if literal == 2 else int(bool(literal))))
 
     # ---- receiver groups: per-group retune / PBT / mode table (CTL:330-423,569-612) --
     def set_groups(self, group_of_channel):

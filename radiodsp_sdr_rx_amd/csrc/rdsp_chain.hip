@@ -725,7 +725,7 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
     fp.vad_lo = 30 * c->N / 256; /* STATING_BIN_VAD_ANALISYS, SPEC:34, scaled with FFT_L */
     fp.vad_hi = 180 * c->N / 256;
   }
-  fp.spectral_literal = (c->spectral_literal && cf.spectral_nr == 1) ? 1 : 0; /* SPEC only: the older variant scales the bin (BK_INO:1614-1628) */
+  fp.spectral_literal = (c->spectral_literal && cf.spectral_nr == 1) ? c->spectral_literal : 0; /* SPEC only: the older variant scales the bin (BK_INO:1614-1628) */
   fp.sin_table = c->d_sin_table;
   fp.to_mid = tail ? 1 : 0;
   fp.agc_on = cf.agc_mode != RDSP_AGC_OFF;
@@ -1101,7 +1101,7 @@ extern "C" int rdsp_set_spectral_resynthesis(rdsp_chain_t *c, int literal) {
     HIP_TRY(hipMalloc((void **)&c->d_sin_table, sizeof(tab)));
     HIP_TRY(hipMemcpy(c->d_sin_table, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
-  c->spectral_literal = literal ? 1 : 0;
+  c->spectral_literal = literal == 2 ? 2 : (literal ? 1 : 0);
   return RDSP_OK;
 }
 

@@ -88,6 +88,24 @@ __device__ __forceinline__ void spec_resynthesize_literal(float2 (&v)[P], float 
   for (int e = 0; e < P; e++) v[e] = lds_ld(&wb[slot(e)]); /* single ds_read_b64, like the transform's passes */
 }
 
+/* SPEC:229-232 as written -- re' = mag' arm_cos_f32(phi), im' = mag' arm_sin_f32(phi), phi = atan2(im, re) -- evaluated
+ * in closed form.  arm_sin_f32 interpolates linearly in a 512-step table: between the nodes phi0 and phi0 + h
+ * (h = 2 pi / 512) at the fraction f it returns (1 - f) sin(phi0) + f sin(phi0 + h) = A(f) sin(phi) + B(f) cos(phi) with
+ * A = (1 - f) cos(f h) + f cos((1 - f) h) = 1 - (h^2 / 2) f (1 - f) + O(h^4) and |B| < 3e-8; the cosine (phi + a quarter
+ * turn = 128 table steps exactly) meets the same f.  So the as-written bin is the exact one, X mag'/mag, times A(f): what
+ * the table's interpolation costs, 1.9e-5 of the bin at most -- and this expression is within 5e-8 of the table's own
+ * arithmetic (tests/test_host_logic.py evaluates both over the circle).  f (1 - f) is the same in every octant, so
+ * f comes from atan(min / max) alone: a degree-11 odd polynomial in table steps (error 1.4e-4 of a step, 1e-8 of the
+ * result), no branches, no table, 14 operations a bin where atan2f and two interpolated look-ups took 95. */
+__device__ __forceinline__ float spec_table_factor(float2 x) {
+  const float ax = fabsf(x.x), ay = fabsf(x.y);
+  const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+  const float z = mn * __builtin_amdgcn_rcpf(mx), s = z * z;
+  const float u = fmaf(s, fmaf(s, fmaf(s, fmaf(s, fmaf(s, -0.954960883f, 4.29009151f), -9.48728275f), 15.7710886f), -27.1045456f), 81.4854736f) * z;
+  const float f = __builtin_amdgcn_fractf(u);
+  return fmaf(fmaf(-f, f, f), -7.52982e-05f, 1.0f); /* (2 pi / 512)^2 / 2 */
+}
+
 /* ---- A5/A6 + epilogue: one overlap-save frame of H = N/2 new samples ------------------
  * Shared by the front kernels (direct-form and FFT-domain decimator).  fetch(i) returns new
  * sample i of the hop from wherever the producer left it in LDS. */
@@ -153,7 +171,14 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
       nfloor += (th - nfloor) * 0.65f;             /* SPEC:205 */
       nfloor = nfloor > 0.f ? nfloor : 0.f;        /* SPEC:206 */
     }
-    if (p.spectral_literal) { /* rdsp_set_spectral_resynthesis(c, 1): SPEC:213-217 then SPEC:226-235 as written */
+    if (p.spectral_literal == 1) { /* rdsp_set_spectral_resynthesis(c, 1): SPEC:213-217, 226-235 as written, the table's interpolation in closed form */
+#pragma unroll
+      for (int e = 0; e < P; e++) {
+        const float sc = ((mag[e] <= nfloor) ? 0.2f : fmaf(-nfloor, rmag[e], 1.f)) * spec_table_factor(v[e]);
+        v[e].x *= sc;
+        v[e].y *= sc;
+      }
+    } else if (p.spectral_literal) { /* (c, 2): the same with atan2f and the table looked up */
       /* the thread's own P entries of the work buffer: what it read in the last forward pass and writes in the
        * first inverse pass, so no other lane ever touches them in between (and they are inside the buffer under
        * either map, also where it is cut into the FIR planes behind their history) */
@@ -388,7 +413,14 @@ __device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const
       n = n > 0.f ? n : 0.f;                              /* SPEC:206 */
       return old_variant ? t : n;                         /* BK_INO:1595-1596: no smoothing */
     });
-    if (p.spectral_literal) { /* SPEC:226-235 as written, as in front_frame */
+    if (p.spectral_literal == 1) { /* SPEC:226-235 as written, as in front_frame */
+#pragma unroll
+      for (int e = 0; e < P; e++) {
+        const float sc = ((mag[e] <= mine) ? 0.2f : fmaf(-mine, rmag[e], 1.f)) * spec_table_factor(v[e]);
+        v[e].x *= sc;
+        v[e].y *= sc;
+      }
+    } else if (p.spectral_literal) { /* the same with atan2f and the table looked up */
       const int own = lb.bi[FftPlan<256, 16>::NP - 1];
       spec_resynthesize_literal<P>(v, mine, p.sin_table, wbg, [&](int e) { return own + e; });
     } else {

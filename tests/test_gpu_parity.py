@@ -186,17 +186,21 @@ def test_spectral_stage_as_written_matches_the_oracle_as_written(rdsp, oracle, t
             out.append(oc.process(iq[c])[1])
         return np.stack(out)
 
-    g_lit, s_lit = gpu(True)
+    g_lit, s_lit = gpu(1)            # the table's interpolation in closed form (csrc/rdsp_kernels.hip spec_table_factor)
+    g_tab, _ = gpu(2)                # atan2f and the table looked up
     g_eq, s_eq = gpu(False)
     o_lit, o_eq = orc(True), orc(False)
     e_ll, e_ee = normwise(g_lit, o_lit), normwise(g_eq, o_eq)
+    e_tab, e_lt = normwise(g_tab, o_lit), normwise(g_lit, g_tab)
+    print(f"{name}: as written, table looked up, gpu vs oracle {e_tab:.2e}; closed form vs looked up {e_lt:.2e}")
     cross = normwise(g_lit, o_eq)
     # SPEC:213-217 is discontinuous at mag = NFloor (0.2 mag below, mag - NFloor above: a jump of 0.2 NFloor), so one
     # bin whose comparison flips under float32 rounding moves a frame by more than rounding; where the float32 oracle
     # itself sits further than that from the float64 evaluation of the chain (FFT_L 2048: 8.9e-6), the bound follows it
     bound = max(TOL, 1.5 * normwise(o_eq, model_run(iq, cfg)))
     print(f"{name}: as written gpu vs oracle {e_ll:.2e}; equivalent form gpu vs oracle {e_ee:.2e}; as written vs equivalent {cross:.2e}; bound {bound:.2e}")
-    assert e_ll <= bound and e_ee <= bound
+    assert e_ll <= bound and e_ee <= bound and e_tab <= bound
+    assert e_lt <= max(2e-6, 0.5 * bound)                          # the two evaluations of the as-written form: one result
     assert np.allclose(s_lit[:, 0], s_eq[:, 0], rtol=1e-5)         # NFloor: the threshold logic does not depend on the form
     assert 5e-6 <= cross <= 5e-5                                    # the table's interpolation error separates the forms
 

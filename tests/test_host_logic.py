@@ -364,3 +364,57 @@ def test_bench_k1_line_on_the_host(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 0 and d["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and d["roofline"] is None
     assert d["audio_blocks_out"] == 16 and d["config"]["workload"].startswith("K1")
+
+
+def test_as_written_resynthesis_in_closed_form_is_the_tables_own_arithmetic():
+    """SPEC:229-232 multiplies the new magnitude by arm_cos_f32(phi) and arm_sin_f32(phi): CMSIS' 513-entry table with
+    linear interpolation.  csrc/rdsp_kernels.hip (spec_table_factor) evaluates that interpolation in closed form: the table
+    value is the exact sine / cosine times A(f) = 1 - (h^2 / 2) f (1 - f), h = 2 pi / 512, f the fraction between nodes,
+    with f from a degree-11 arctangent of min / max (f (1 - f) is the same in all eight octants).  Here, over the whole
+    circle and in float32 like the kernel: the closed form against the table's own arithmetic (the published routine,
+    restated) -- 1e-7 of the bin where the two FORMS of the stage are 1.9e-5 apart."""
+    k = np.arange(513)
+    tab = np.float32(np.round(np.sin(2 * np.pi * k / 512), 8))                   # sinTable_f32's literals
+    rng = np.random.default_rng(5)
+    phi = np.concatenate([rng.uniform(-np.pi, np.pi, 400000), np.arange(-512, 513) * (np.pi / 512), [0.0, np.pi, -np.pi]])
+    r = rng.uniform(1e-6, 3.0, len(phi))
+    x, y = (r * np.cos(phi)).astype(np.float32), (r * np.sin(phi)).astype(np.float32)
+
+    def table(turns):                                                            # arm_sin_f32, in float32
+        t = np.float32(turns)
+        n = np.floor(t)
+        t = t - n
+        fi = np.float32(512.0) * t
+        idx = fi.astype(np.int32)
+        wrap = idx >= 512
+        idx = np.where(wrap, 0, idx)
+        fi = np.where(wrap, fi - np.float32(512.0), fi)
+        fr = fi - idx.astype(np.float32)
+        return (np.float32(1.0) - fr) * tab[idx] + fr * tab[idx + 1]
+    turns = (np.arctan2(y, x) * np.float32(0.159154943092)).astype(np.float32)
+    want_c, want_s = table(turns + np.float32(0.25)).astype(np.float64), table(turns).astype(np.float64)
+    F = np.float32
+    ax, ay = np.abs(x), np.abs(y)
+    mx, mn = np.maximum(np.maximum(ax, ay), F(1e-30)), np.minimum(ax, ay)
+    z = mn * (F(1.0) / mx)
+    s = z * z
+    u = F(-0.954960883)
+    for c in (4.29009151, -9.48728275, 15.7710886, -27.1045456, 81.4854736):
+        u = u * s + F(c)
+    u = u * z
+    f = u - np.floor(u)
+    a = (F(1.0) + (f - f * f) * F(-7.52982e-05)).astype(np.float64)
+    m = np.hypot(x.astype(np.float64), y.astype(np.float64))
+    got_c, got_s = a * x / m, a * y / m
+    # against the routine in float32 as it runs: 5e-7, which is the routine's own rounding of the angle (a float32 of half a
+    # turn resolves 6e-8 turns = 3.7e-7 rad) ...
+    assert np.abs(got_c - want_c).max() < 6e-7 and np.abs(got_s - want_s).max() < 6e-7
+    # ... and against the same interpolation carried out in float64, where only the formula is left: 1e-7
+    t64 = np.arctan2(y.astype(np.float64), x.astype(np.float64)) / (2 * np.pi)
+
+    def table64(t):
+        fi = 512.0 * (t - np.floor(t))
+        idx = np.minimum(fi.astype(np.int64), 511)
+        return (1.0 - (fi - idx)) * tab[idx] + (fi - idx) * tab[idx + 1]
+    assert np.abs(got_c - table64(t64 + 0.25)).max() < 1e-7 and np.abs(got_s - table64(t64)).max() < 1e-7
+    assert np.abs(x / m - want_c).max() > 1.5e-5                                 # what separates the stage's two forms
