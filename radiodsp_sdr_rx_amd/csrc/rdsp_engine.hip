@@ -134,181 +134,253 @@ struct Osc { /* one step of the frequency shifter's phase (0xe94e / 0xd600): cos
     else if (ph < 0.0f) ph += TWO_PI_F;
   }
 };
+__device__ __forceinline__ float dpp_up1(float v) { /* lane s of a quad takes lane s - 1's value: quad_perm [0,0,1,2] */
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x90, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float quick_root_guess(float p) { return __uint_as_float((__float_as_uint(p) >> 1) + 0x1fa00000u + 0x1b4000u + 3886u); }
 __device__ __forceinline__ float quick_sqrt1(float p) { const float g = quick_root_guess(p); return (p / g + g) * 0.5f; }
 __device__ __forceinline__ float quick_sqrt2(float p) { const float y = quick_sqrt1(p); return (p / y + y) * 0.5f; }
 
-/* rows of a tile <-> rows in HBM, 64 lanes: each row segment is one coalesced 256-byte access */
-template <typename T>
-__device__ __forceinline__ void rows_in(T (*tile)[PITCH], const T *base, size_t stride, int row0, int n_rows, int rows_valid, int lane) {
-  for (int r = 0; r < n_rows; r++) {
-    const bool ok = row0 + r < rows_valid;
-    const T *src = base + (size_t)(row0 + (ok ? r : 0)) * stride;
-    tile[r][lane] = ok ? src[lane] : T(0);
-    tile[r][lane + 64] = ok ? src[lane + 64] : T(0);
+/* ---- stages of a cascade on neighbouring lanes --------------------------------------------------------------------
+ * arm_biquad_cascade_df1_f32 runs section after section over the block; the result is the same when sample n enters
+ * section s at step n + s.  Lane s of a quad holds section s of one row of the tile (its five coefficients and four
+ * state words) and at step i works on sample i - s, taking its input from lane s - 1's previous output (one DPP move):
+ * a block costs 131 steps of ONE section instead of 128 of four, and a row occupies four lanes. */
+struct Section {
+  float b0, b1, b2, a1, a2, x1, x2, y1, y2;
+  __device__ __forceinline__ void load(const float *coef5, const float *state4, bool clear) {
+    b0 = coef5[0]; b1 = coef5[1]; b2 = coef5[2]; a1 = coef5[3]; a2 = coef5[4];
+    x1 = clear ? 0.0f : state4[0]; x2 = clear ? 0.0f : state4[1]; y1 = clear ? 0.0f : state4[2]; y2 = clear ? 0.0f : state4[3];
+  }
+  __device__ __forceinline__ void store(float *state4) const { state4[0] = x1; state4[1] = x2; state4[2] = y1; state4[3] = y2; }
+  __device__ __forceinline__ float eval(float x) const { /* products rounded, summed left to right */
+    float y = b0 * x;
+    y = y + b1 * x1;
+    y = y + b2 * x2;
+    y = y + a1 * y1;
+    y = y + a2 * y2;
+    return y;
+  }
+  __device__ __forceinline__ void commit(float x, float y) { x2 = x1; x1 = x; y2 = y1; y1 = y; }
+};
+/* one block of one tile row through the cascade, in place; called by all four lanes of the row's quad */
+__device__ __forceinline__ void cascade_row(Section &sec, float *row, int s) {
+  float yprev = 0.0f;
+#pragma unroll 4
+  for (int i = 0; i < BS + 3; i++) {
+    const int n = i - s;
+    const float up = dpp_up1(yprev);
+    const float x = s == 0 ? row[i < BS ? i : BS - 1] : up;
+    const float y = sec.eval(x);
+    if (n >= 0 && n < BS) {
+      sec.commit(x, y);
+      yprev = y;
+      if (s == 3) row[n] = y;
+    }
   }
 }
+/* the oscillator in two passes: the phase recursion alone (one lane per channel: a float add and the wrap), then cosine,
+ * sine and the complex product for every sample of the tile in parallel -- they are pure functions of the phase */
+__device__ __forceinline__ void phase_row(float &ph, float inc, float *out) {
+  for (int t = 0; t < BS; t++) {
+    out[t] = ph;
+    ph = ph + inc;
+    if (ph > TWO_PI_F) ph -= TWO_PI_F;
+    else if (ph < 0.0f) ph += TWO_PI_F;
+  }
+}
+__device__ __forceinline__ void rotate_sample(const float *sine, float ph, float &x, float &y) {
+  float pc = (float)((double)ph + 1.5707963267948966);
+  if (pc >= TWO_PI_F) pc -= TWO_PI_F;
+  if (pc < 0.0f) pc += TWO_PI_F;
+  const float c = table_sin(sine, pc);
+  float ps = ph >= TWO_PI_F ? ph - TWO_PI_F : ph;
+  if (ps < 0.0f) ps += TWO_PI_F;
+  const float s = table_sin(sine, ps);
+  const float xi = x, yq = y;
+  x = fmaf(xi, c, -(s * yq));
+  y = fmaf(yq, c, xi * s);
+}
 
-/* ---- front: conversion, blanker, IF filter, frequency shift (SSB / CW) or the AM / SAM detectors ---------------------- */
+/* ---- front: conversion, blanker, IF filter, frequency shift (SSB / CW) or the AM / SAM detectors ----------------------
+ * 32 channels = 64 tile rows (channel, rail) per workgroup of four waves.  Per block: conversion and the mixer's
+ * table work spread over all 256 lanes (element e = lane + 256 j: consecutive lanes on consecutive samples of a row);
+ * the cascades with a quad per row; the oscillator's phase, the PLL and the blanker -- true recursions -- on one lane
+ * per channel or row. */
+constexpr int FW = 256;
 template <bool NB>
-__global__ __launch_bounds__(64) void rdsp_engine_front_kernel(const EngParams p) {
-  __shared__ int32_t tin[32][PITCH];
+__global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p) {
   __shared__ float tf[64][PITCH];
-  const int lane = threadIdx.x, rail = lane & 1;
-  const int c0 = blockIdx.x * 32, cl = lane >> 1;
-  const bool valid = c0 + cl < p.n_channels;
-  const int ch = valid ? c0 + cl : p.n_channels - 1;
-  float *st = p.st + (size_t)ch * NF;
+  __shared__ float phs[32][PITCH];
+  __shared__ int locked_of[32];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 32;
+  const int row = tid >> 2, sct = tid & 3;                       /* cascade role: section sct of tile row `row` */
+  const int rch = min(c0 + (row >> 1), p.n_channels - 1);
+  const bool row_valid = c0 + (row >> 1) < p.n_channels;
   const bool ssb = p.mode <= 3 || p.mode == 6, am = p.mode == 4 || p.mode == 5;
-  Cascade pre, amf;
-  pre.load(p.sets + 20 * p.pre_set, st + ST_PRE + 16 * rail, (p.resets & RESET_PRE) != 0);
-  if (am) amf.load(p.sets + 20 * 13, st + ST_AM + 16 * rail, false);
-  Osc nco{st[ST_NCO]}, amo{st[ST_AMPH]};
-  float sam_c = st[ST_SAM_COS], sam_s = st[ST_SAM_SIN], sam_u = st[ST_SAM_U], sam_err = st[ST_SAM_ERR], sam_hz = st[ST_SAM_HZ],
-        sam_ph = st[ST_SAM_PH];
-  int sam_locked = __float_as_int(st[ST_SAM_LOCK]);
-  float nb_avg = st[ST_NB_AVG], nb_last = st[ST_NB_LAST];
-  int nb_hit = __float_as_int(st[ST_NB_HIT]);
-  const double gain = (double)(rail ? p.gain_q : p.gain_i);
+  Section pre, amf;
+  pre.load(p.sets + 20 * p.pre_set + 5 * sct, p.st + (size_t)rch * NF + ST_PRE + 16 * (row & 1) + 4 * sct, (p.resets & RESET_PRE) != 0);
+  amf.load(p.sets + 20 * 13 + 5 * sct, p.st + (size_t)rch * NF + ST_AM + 16 * (row & 1) + 4 * sct, false);
+  /* serial role: lane tid < 32 owns channel c0 + tid's scalars */
+  const int sch = min(c0 + (tid & 31), p.n_channels - 1);
+  const bool ser = tid < 32, ser_valid = ser && c0 + tid < p.n_channels;
+  float *sst = p.st + (size_t)sch * NF;
+  float nco = sst[ST_NCO], amph = sst[ST_AMPH];
+  float sam_c = sst[ST_SAM_COS], sam_s = sst[ST_SAM_SIN], sam_u = sst[ST_SAM_U], sam_err = sst[ST_SAM_ERR], sam_hz = sst[ST_SAM_HZ],
+        sam_ph = sst[ST_SAM_PH];
+  int sam_locked = __float_as_int(sst[ST_SAM_LOCK]);
+  /* blanker role: lane tid < 64 owns tile row tid */
+  const int bch = min(c0 + (tid >> 1), p.n_channels - 1);
+  const bool bl_valid = tid < 64 && c0 + (tid >> 1) < p.n_channels;
+  float nb_avg = p.st[(size_t)bch * NF + ST_NB_AVG], nb_last = p.st[(size_t)bch * NF + ST_NB_LAST];
+  int nb_hit = __float_as_int(p.st[(size_t)bch * NF + ST_NB_HIT]);
   const float nco_inc = -(p.tuning_offset * RAD_PER_HZ), am_inc = -p.if_centre * RAD_PER_HZ;
-  float *row = tf[lane];
-  const float *other = tf[lane ^ 1];
 
   for (int b = 0; b < p.n_blocks; b++) {
-    rows_in<int32_t>(tin, p.iq + (size_t)b * BS, p.in_stride, c0, 32, p.n_channels, lane);
-    wg_sync<1>();
-    for (int t = 0; t < BS; t++) { /* 0xe7b4: / 32767 and the rail's gain, in double */
-      const int w = tin[cl][t];
-      const int v = rail ? (w >> 16) : (int)(int16_t)(w & 0xffff);
-      row[t] = (float)(((double)v / 32767.0) * gain);
+    for (int j = 0; j < 16; j++) { /* 0xe7b4: / 32767 and the rail's gain, in double; one int16 pair per element */
+      const int e = tid + FW * j, cl = e >> 7, t = e & 127;
+      const int w = c0 + cl < p.n_channels ? p.iq[(size_t)(c0 + cl) * p.in_stride + (size_t)b * BS + t] : 0;
+      tf[2 * cl][t] = (float)(((double)(int)(int16_t)(w & 0xffff) / 32767.0) * (double)p.gain_i);
+      tf[2 * cl + 1][t] = (float)(((double)(w >> 16) / 32767.0) * (double)p.gain_q);
     }
+    __syncthreads();
     if constexpr (NB) { /* 0xe14c: two blocks of delay; |I + jQ| against its running average; blanking mask with a taper.
-                         * Each lane keeps its own copy of both rails' lines and of the mask (the partner's new samples come
-                         * out of the tile), so nothing crosses lanes through HBM */
-      float *li = p.nb + ((size_t)(valid ? ch : p.n_channels) * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768; /* lanes past the last channel share a spare slot */
-      wg_sync<1>();
-      nb_hit = 0;
-      for (int i = 0; i < 256; i++) { li[i] = li[i + 128]; lq[i] = lq[i + 128]; mask[i] = mask[i + 128]; }
-      for (int i = 0; i < 128; i++) {
-        const float mine = row[i], theirs = other[i];
-        li[256 + i] = rail ? theirs : mine; lq[256 + i] = rail ? mine : theirs; mask[256 + i] = 1.0f;
-      }
-      for (int n = 78; n < 256; n++) {
-        const float limit = nb_avg * p.nb_ratio;
-        const float vi = li[n], vq = lq[n];
-        nb_last = quick_sqrt1(fmaf(vi, vi, vq * vq));
-        if (limit < nb_last) {
-          if (-p.nb_before <= p.nb_after)
-            for (int j = n - p.nb_before; j <= n + p.nb_after; j++) mask[j] = 0.0f;
-          nb_hit = 1;
+                         * Each row's lane keeps its own copy of both rails' lines and of the mask in HBM */
+      if (tid < 64) {
+        const int rail = tid & 1;
+        float *li = p.nb + ((size_t)(bl_valid ? bch : p.n_channels) * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768; /* rows past the last channel share a spare slot */
+        float *mine = tf[tid];
+        const float *theirs = tf[tid ^ 1];
+        nb_hit = 0;
+        for (int i = 0; i < 256; i++) { li[i] = li[i + 128]; lq[i] = lq[i + 128]; mask[i] = mask[i + 128]; }
+        for (int i = 0; i < 128; i++) {
+          li[256 + i] = rail ? theirs[i] : mine[i]; lq[256 + i] = rail ? mine[i] : theirs[i]; mask[256 + i] = 1.0f;
         }
-        nb_avg = fmaf(nb_avg, p.nb_keep, nb_last * p.nb_new);
-      }
-      const float taper[7] = {0.933f, 0.75f, 0.5f, 0.25f, 0.067f, 0.0f, 0.0f};
-      for (int i = 128; i < 256; i++)
-        if (mask[i] == 1.0f && mask[i - 1] == 0.0f)
-          for (int j = 0; j < 7; j++) mask[i - 7 + j] = taper[j];
-      wg_sync<1>();
-      for (int i = 0; i < 128; i++) row[i] = mask[i] * (rail ? lq[i] : li[i]);
-    }
-    for (int t = 0; t < BS; t++) row[t] = pre.run(row[t]);
-    wg_sync<1>();
-    if (ssb) {
-      for (int t = 0; t < BS; t++) { /* 0xe94e: (I + jQ) e^{j phase}, phase falling by the tuning offset */
-        const float mine = row[t], theirs = other[t];
-        const float x = rail ? theirs : mine, y = rail ? mine : theirs;
-        float c, s;
-        nco.step(p.sine, nco_inc, c, s);
-        const float v = rail ? fmaf(y, c, x * s) : fmaf(x, c, -(s * y));
+        for (int n = 78; n < 256; n++) {
+          const float limit = nb_avg * p.nb_ratio;
+          const float vi = li[n], vq = lq[n];
+          nb_last = quick_sqrt1(fmaf(vi, vi, vq * vq));
+          if (limit < nb_last) {
+            if (-p.nb_before <= p.nb_after)
+              for (int j = n - p.nb_before; j <= n + p.nb_after; j++) mask[j] = 0.0f;
+            nb_hit = 1;
+          }
+          nb_avg = fmaf(nb_avg, p.nb_keep, nb_last * p.nb_new);
+        }
+        const float taper[7] = {0.933f, 0.75f, 0.5f, 0.25f, 0.067f, 0.0f, 0.0f};
+        for (int i = 128; i < 256; i++)
+          if (mask[i] == 1.0f && mask[i - 1] == 0.0f)
+            for (int j = 0; j < 7; j++) mask[i - 7 + j] = taper[j];
         wg_sync<1>();
-        row[t] = v;
+        for (int i = 0; i < 128; i++) mine[i] = mask[i] * (rail ? lq[i] : li[i]);
       }
-      wg_sync<1>();
-      for (int r = 0; r < 64; r++) { /* into the rings: row r of the tile is (channel c0 + r / 2, rail r & 1) */
-        if (c0 + (r >> 1) >= p.n_channels) break;
-        float *ring = ((r & 1) ? p.ring_q : p.ring_i) + (size_t)(c0 + (r >> 1)) * p.ring_size;
-        const uint32_t at = p.pos + (uint32_t)b * BS;
-        ring[(at + lane) & (p.ring_size - 1)] = tf[r][lane];
-        ring[(at + lane + 64) & (p.ring_size - 1)] = tf[r][lane + 64];
+      __syncthreads();
+    }
+    cascade_row(pre, tf[row], sct);
+    __syncthreads();
+    if (ssb) {
+      if (ser) phase_row(nco, nco_inc, phs[tid]);                /* 0xe94e: the phase falls by the tuning offset */
+      __syncthreads();
+      for (int j = 0; j < 16; j++) {
+        const int e = tid + FW * j, cl = e >> 7, t = e & 127;
+        float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
+        rotate_sample(p.sine, phs[cl][t], x, y);
+        tf[2 * cl][t] = x; tf[2 * cl + 1][t] = y;
+      }
+      __syncthreads();
+      const uint32_t at = p.pos + (uint32_t)b * BS, m = p.ring_size - 1;
+      for (int j = 0; j < 32; j++) { /* into the rings: tile row r is (channel c0 + r / 2, rail r & 1) */
+        const int e = tid + FW * j, r = e >> 7, t = e & 127;
+        if (c0 + (r >> 1) < p.n_channels)
+          ((r & 1) ? p.ring_q : p.ring_i)[(size_t)(c0 + (r >> 1)) * p.ring_size + ((at + (uint32_t)t) & m)] = tf[r][t];
       }
     } else if (am) {
-      for (int t = 0; t < BS; t++) row[t] = pre.run(row[t]); /* 0xec1c: the IF filter a second time */
-      wg_sync<1>();
-      bool envelope = p.mode == 4;
-      if (p.mode == 5) { /* 0xe390: PLL on the IF signal; both lanes of a channel run it, each keeps its own rail */
-        const float HALF_PI = 1.5707963705062866f, A1 = 0.97239410877227783f, A3 = -0.19194795191287994f;
-        for (int t = 0; t < BS; t++) {
-          const float mine = row[t], theirs = other[t];
-          const float x = rail ? theirs : mine, q = rail ? mine : theirs;
-          const float re = fmaf(x, sam_c, q * sam_s), im = fmaf(q, sam_c, -(sam_s * x));
-          float err;
-          if (re == 0.0f) err = im > 0.0f ? HALF_PI : (im < 0.0f ? -HALF_PI : 0.0f);
-          else if (fabsf(re) > fabsf(im)) {
-            const float z = im / re;
-            err = fmaf(z, z * A3, A1) * z;
-            if (!(re > 0.0f)) err = (float)(im >= 0.0f ? (double)err + 3.1415926535897931 : (double)err - 3.1415926535897931);
-          } else {
-            const float z = re / im;
-            err = fmaf(-z, fmaf(z, z * A3, A1), im > 0.0f ? HALF_PI : -HALF_PI);
+      cascade_row(pre, tf[row], sct);                            /* 0xec1c: the IF filter a second time */
+      __syncthreads();
+      if (p.mode == 5) { /* 0xe390: PLL on the IF signal, one lane per channel */
+        if (ser) {
+          const float HALF_PI = 1.5707963705062866f, A1 = 0.97239410877227783f, A3 = -0.19194795191287994f;
+          float *ri = tf[2 * tid], *rq = tf[2 * tid + 1];
+          for (int t = 0; t < BS; t++) {
+            const float x = ri[t], q = rq[t];
+            const float re = fmaf(x, sam_c, q * sam_s), im = fmaf(q, sam_c, -(sam_s * x));
+            float err;
+            if (re == 0.0f) err = im > 0.0f ? HALF_PI : (im < 0.0f ? -HALF_PI : 0.0f);
+            else if (fabsf(re) > fabsf(im)) {
+              const float z = im / re;
+              err = fmaf(z, z * A3, A1) * z;
+              if (!(re > 0.0f)) err = (float)(im >= 0.0f ? (double)err + 3.1415926535897931 : (double)err - 3.1415926535897931);
+            } else {
+              const float z = re / im;
+              err = fmaf(-z, fmaf(z, z * A3, A1), im > 0.0f ? HALF_PI : -HALF_PI);
+            }
+            const float u = fmaf(err, p.sam_ga, p.sam_gb * sam_err);
+            const double phd = fma((double)(u + sam_u), 0.5, (double)sam_ph);
+            sam_hz = fmaf(p.sam_keep, sam_hz, (u * p.sam_hz_per_rad) * p.sam_new);
+            sam_ph = (float)phd;
+            if ((double)sam_ph >= 3.1415926535897931) sam_ph -= TWO_PI_F;
+            if ((double)sam_ph < -3.1415926535897931) sam_ph += TWO_PI_F;
+            sam_locked = sam_hz > p.sam_lock_lo ? (sam_hz < p.sam_lock_hi) : 0;
+            float pc = (float)((double)sam_ph + 1.5707963267948966);
+            if (pc >= TWO_PI_F) pc -= TWO_PI_F;
+            if (pc < 0.0f) pc += TWO_PI_F;
+            sam_c = table_sin(p.sine, pc);
+            float ps = sam_ph >= TWO_PI_F ? sam_ph - TWO_PI_F : sam_ph;
+            if (ps < 0.0f) ps += TWO_PI_F;
+            sam_s = table_sin(p.sine, ps);
+            if (sam_locked) {
+              ri[t] = fmaf(x, sam_c, q * sam_s);
+              rq[t] = fmaf(-x, sam_s, q * sam_c);
+            }
+            sam_u = u; sam_err = err;
           }
-          const float u = fmaf(err, p.sam_ga, p.sam_gb * sam_err);
-          const double phd = fma((double)(u + sam_u), 0.5, (double)sam_ph);
-          sam_hz = fmaf(p.sam_keep, sam_hz, (u * p.sam_hz_per_rad) * p.sam_new);
-          sam_ph = (float)phd;
-          if ((double)sam_ph >= 3.1415926535897931) sam_ph -= TWO_PI_F;
-          if ((double)sam_ph < -3.1415926535897931) sam_ph += TWO_PI_F;
-          sam_locked = sam_hz > p.sam_lock_lo ? (sam_hz < p.sam_lock_hi) : 0;
-          float pc = (float)((double)sam_ph + 1.5707963267948966);
-          if (pc >= TWO_PI_F) pc -= TWO_PI_F;
-          if (pc < 0.0f) pc += TWO_PI_F;
-          sam_c = table_sin(p.sine, pc);
-          float ps = sam_ph >= TWO_PI_F ? sam_ph - TWO_PI_F : sam_ph;
-          if (ps < 0.0f) ps += TWO_PI_F;
-          sam_s = table_sin(p.sine, ps);
-          const float v = rail ? fmaf(-x, sam_s, q * sam_c) : fmaf(x, sam_c, q * sam_s);
-          wg_sync<1>();
-          if (sam_locked) row[t] = v;
-          sam_u = u; sam_err = err;
+          locked_of[tid] = sam_locked;
         }
-        wg_sync<1>();
-        envelope = !sam_locked; /* 0xed02: out of lock, the envelope detector takes over */
+      } else if (ser) locked_of[tid] = 0;
+      __syncthreads();
+      /* AM, and SAM out of lock (0xed02): shift by the IF centre, low-pass, envelope.  A channel in lock keeps the rotated
+       * I rail as its audio and none of the detector's state moves */
+      if (ser && !locked_of[tid]) phase_row(amph, am_inc, phs[tid]);
+      __syncthreads();
+      for (int j = 0; j < 16; j++) {
+        const int e = tid + FW * j, cl = e >> 7, t = e & 127;
+        if (locked_of[cl]) continue;
+        float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
+        rotate_sample(p.sine, phs[cl][t], x, y);
+        tf[2 * cl][t] = x; tf[2 * cl + 1][t] = y;
       }
-      if (envelope) {
-        for (int t = 0; t < BS; t++) {
-          const float mine = row[t], theirs = other[t];
-          const float x = rail ? theirs : mine, y = rail ? mine : theirs;
-          float c, s;
-          amo.step(p.sine, am_inc, c, s);
-          const float v = rail ? fmaf(y, c, x * s) : fmaf(x, c, -(s * y));
-          wg_sync<1>();
-          row[t] = amf.run(v);
-        }
-        wg_sync<1>();
-        for (int t = 0; t < BS; t++) {
-          const float mine = row[t], theirs = other[t];
-          wg_sync<1>();
-          if (!rail) row[t] = quick_sqrt2(fmaf(mine, mine, theirs * theirs));
-        }
+      __syncthreads();
+      const bool detect = !locked_of[row >> 1];
+      Section keep = amf;
+      cascade_row(amf, detect ? tf[row] : phs[0], sct);          /* the quads of a locked channel run on a scratch row ... */
+      if (!detect) amf = keep;                                   /* ... and keep their state */
+      __syncthreads();
+      for (int j = 0; j < 16; j++) {
+        const int e = tid + FW * j, cl = e >> 7, t = e & 127;
+        if (locked_of[cl]) continue;
+        const float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
+        tf[2 * cl][t] = quick_sqrt2(fmaf(x, x, y * y));
       }
-      wg_sync<1>();
-      for (int r = 0; r < 32; r++) { /* the demodulated audio is in the I rows */
-        if (c0 + r >= p.n_channels) break;
-        float *dst = p.audio + (size_t)(c0 + r) * p.audio_stride + (size_t)b * BS;
-        dst[lane] = tf[2 * r][lane];
-        dst[lane + 64] = tf[2 * r][lane + 64];
+      __syncthreads();
+      for (int j = 0; j < 16; j++) { /* the demodulated audio is in the I rows */
+        const int e = tid + FW * j, cl = e >> 7, t = e & 127;
+        if (c0 + cl < p.n_channels) p.audio[(size_t)(c0 + cl) * p.audio_stride + (size_t)b * BS + t] = tf[2 * cl][t];
       }
     }
-    wg_sync<1>();
+    __syncthreads();
   }
-  if (valid) {
-    pre.store(st + ST_PRE + 16 * rail);
-    if (am) amf.store(st + ST_AM + 16 * rail);
-    if (!rail) {
-      st[ST_NCO] = nco.ph; st[ST_AMPH] = amo.ph;
-      st[ST_SAM_COS] = sam_c; st[ST_SAM_SIN] = sam_s; st[ST_SAM_U] = sam_u; st[ST_SAM_ERR] = sam_err; st[ST_SAM_HZ] = sam_hz;
-      st[ST_SAM_PH] = sam_ph; st[ST_SAM_LOCK] = __int_as_float(sam_locked);
-      st[ST_NB_AVG] = nb_avg; st[ST_NB_LAST] = nb_last; st[ST_NB_HIT] = __int_as_float(nb_hit);
-    }
+  if (row_valid) {
+    pre.store(p.st + (size_t)rch * NF + ST_PRE + 16 * (row & 1) + 4 * sct);
+    if (am) amf.store(p.st + (size_t)rch * NF + ST_AM + 16 * (row & 1) + 4 * sct);
+  }
+  if (ser_valid) {
+    sst[ST_NCO] = nco; sst[ST_AMPH] = amph;
+    sst[ST_SAM_COS] = sam_c; sst[ST_SAM_SIN] = sam_s; sst[ST_SAM_U] = sam_u; sst[ST_SAM_ERR] = sam_err; sst[ST_SAM_HZ] = sam_hz;
+    sst[ST_SAM_PH] = sam_ph; sst[ST_SAM_LOCK] = __int_as_float(sam_locked);
+  }
+  if (NB && bl_valid && !(tid & 1)) {
+    float *bst = p.st + (size_t)bch * NF;
+    bst[ST_NB_AVG] = nb_avg; bst[ST_NB_LAST] = nb_last; bst[ST_NB_HIT] = __int_as_float(nb_hit);
   }
 }
 
@@ -343,90 +415,114 @@ __device__ __forceinline__ float agc_lookup(const float *curve, float env) {
   return fmaf(frac, curve[hi1] - t0, t0);
 }
 
+/* 64 channels per workgroup of four waves.  Per block: the audio cascade with a quad per channel; the AGC's envelope --
+ * the only true recursion in it -- on one lane per channel, which leaves for every sample the envelope value its gain is
+ * looked up from (or "none yet": the gain carried in); gain, clamp and pack are then pure functions and run on all lanes. */
 template <bool ALS>
-__global__ __launch_bounds__(64) void rdsp_engine_tail_kernel(const EngParams p) {
+__global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p) {
   __shared__ float ta[64][PITCH];
+  __shared__ float ge[64][PITCH];
   __shared__ float curve[130];
+  __shared__ float g_in[64];
   __shared__ float line[ALS ? 256 : 1][64];
   __shared__ float wt[ALS ? ALS_TAPS : 1][64];
-  const int lane = threadIdx.x, c0 = blockIdx.x * 64;
-  const bool valid = c0 + lane < p.n_channels;
-  const int ch = valid ? c0 + lane : p.n_channels - 1;
-  float *st = p.st + (size_t)ch * NF;
-  Cascade aud;
-  aud.load(p.sets + 20 * p.audio_set, st + ST_AUDIO, (p.resets & RESET_AUDIO) != 0);
-  float env = st[ST_AGC_ENV], g = st[ST_AGC_GAIN];
-  int hang = __float_as_int(st[ST_AGC_HANG]), active = __float_as_int(st[ST_AGC_ACTIVE]);
-  for (int i = lane; i < 130; i += 64) curve[i] = p.curve[i];
+  const int tid = threadIdx.x, c0 = blockIdx.x * 64;
+  const int row = tid >> 2, sct = tid & 3;
+  const int rch = min(c0 + row, p.n_channels - 1);
+  Section aud;
+  aud.load(p.sets + 20 * p.audio_set + 5 * sct, p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct, (p.resets & RESET_AUDIO) != 0);
+  const bool ser = tid < 64, ser_valid = ser && c0 + tid < p.n_channels;
+  const int sch = min(c0 + (tid & 63), p.n_channels - 1);
+  float *sst = p.st + (size_t)sch * NF;
+  float env = sst[ST_AGC_ENV], g = sst[ST_AGC_GAIN];
+  int hang = __float_as_int(sst[ST_AGC_HANG]), active = __float_as_int(sst[ST_AGC_ACTIVE]);
+  for (int i = tid; i < 130; i += FW) curve[i] = p.curve[i];
   if constexpr (ALS) {
-    const float *a = p.als + (size_t)ch * ALS_WORDS;
-    const bool clear = (p.resets & RESET_ALS) != 0;
-    for (int i = 0; i < 256; i++) line[i][lane] = clear ? 0.0f : a[i];
-    for (int k = 0; k < ALS_TAPS; k++) wt[k][lane] = clear ? 0.0f : a[256 + k];
+    if (ser) {
+      const float *a = p.als + (size_t)sch * ALS_WORDS;
+      const bool clear = (p.resets & RESET_ALS) != 0;
+      for (int i = 0; i < 256; i++) line[i][tid] = clear ? 0.0f : a[i];
+      for (int k = 0; k < ALS_TAPS; k++) wt[k][tid] = clear ? 0.0f : a[256 + k];
+    }
   }
-  float *row = ta[lane];
   for (int b = 0; b < p.n_blocks; b++) {
-    wg_sync<1>();
-    rows_in<float>(ta, p.audio + (size_t)b * BS, p.audio_stride, c0, 64, p.n_channels, lane);
-    wg_sync<1>();
-    for (int t = 0; t < BS; t++) {
-      float a = row[t];
-      if (p.audio_on) a = aud.run(a);
-      if (p.agc_on) {
-        float in = fabsf(a);
-        if (in > 1.0f) in = 1.0f;
-        if (env < in) { /* attack: the hang counter is re-armed */
-          env = fmaf(env, p.agc_attack_a, in * p.agc_attack_b);
-          hang = p.agc_hang_time;
-          g = agc_lookup(curve, env);
-        } else if (hang == 0) {
-          env = fmaf(env, p.agc_decay_a, in * p.agc_decay_b);
-          g = agc_lookup(curve, env);
-        } else {
-          hang--;
+    __syncthreads();
+    for (int j = 0; j < 32; j++) {
+      const int e = tid + FW * j, r = e >> 7, t = e & 127;
+      ta[r][t] = c0 + r < p.n_channels ? p.audio[(size_t)(c0 + r) * p.audio_stride + (size_t)b * BS + t] : 0.0f;
+    }
+    __syncthreads();
+    if (p.audio_on) {
+      cascade_row(aud, ta[row], sct);
+      __syncthreads();
+    }
+    if (p.agc_on) {
+      if (ser) {
+        g_in[tid] = g;
+        float last = -1.0f;                      /* the envelope the current gain was looked up from; < 0: none in this block yet */
+        const float *a = ta[tid];
+        for (int t = 0; t < BS; t++) {
+          float in = fabsf(a[t]);
+          if (in > 1.0f) in = 1.0f;
+          if (env < in) {                        /* attack: the hang counter is re-armed */
+            env = fmaf(env, p.agc_attack_a, in * p.agc_attack_b);
+            hang = p.agc_hang_time;
+            last = env;
+          } else if (hang == 0) {
+            env = fmaf(env, p.agc_decay_a, in * p.agc_decay_b);
+            last = env;
+          } else {
+            hang--;
+          }
+          ge[tid][t] = last;
         }
+        if (last >= 0.0f) g = agc_lookup(curve, last);
         active = (double)g < 0.98999999999999999;
-        float y = (g * p.agc_makeup) * a;
+      }
+      __syncthreads();
+      for (int j = 0; j < 32; j++) {
+        const int e = tid + FW * j, r = e >> 7, t = e & 127;
+        const float le = ge[r][t];
+        const float gg = le < 0.0f ? g_in[r] : agc_lookup(curve, le);
+        float y = (gg * p.agc_makeup) * ta[r][t];
         if (y > 1.0f) y = 1.0f;
         else if (y < -1.0f) y = -1.0f;
-        a = y;
+        ta[r][t] = y;
       }
-      row[t] = a;
+      __syncthreads();
     }
     if constexpr (ALS) { /* y = w . x delayed; the taps move on every fourth sample of a block by mu e x (plain LMS) */
-      for (int i = 0; i < 128; i++) { line[i][lane] = line[i + 128][lane]; line[i + 128][lane] = row[i]; }
-      int cnt = 0;
-      for (int n = 128; n < 256; n++) {
-        float y = 0.0f;
-        for (int k = 0; k < ALS_TAPS; k++) y = fmaf(wt[k][lane], line[n - ALS_DELAY - k][lane], y);
-        const float err = line[n][lane] - y;
-        if (p.als_adaptive) {
-          if (cnt == 0)
-            for (int k = 0; k < ALS_TAPS; k++) wt[k][lane] = fmaf(err * line[n - ALS_DELAY - k][lane], 0.5f, wt[k][lane]);
-          cnt = (cnt + 1) & 3;
+      if (ser) {
+        float *rowp = ta[tid];
+        for (int i = 0; i < 128; i++) { line[i][tid] = line[i + 128][tid]; line[i + 128][tid] = rowp[i]; }
+        int cnt = 0;
+        for (int n = 128; n < 256; n++) {
+          float y = 0.0f;
+          for (int k = 0; k < ALS_TAPS; k++) y = fmaf(wt[k][tid], line[n - ALS_DELAY - k][tid], y);
+          const float err = line[n][tid] - y;
+          if (p.als_adaptive) {
+            if (cnt == 0)
+              for (int k = 0; k < ALS_TAPS; k++) wt[k][tid] = fmaf(err * line[n - ALS_DELAY - k][tid], 0.5f, wt[k][tid]);
+            cnt = (cnt + 1) & 3;
+          }
+          rowp[n - 128] = p.als_notch ? err : y;
         }
-        row[n - 128] = p.als_notch ? err : y;
       }
+      __syncthreads();
     }
-    for (int t = 0; t < BS; t++) { /* 0xebfa: x output gain x 32767 toward zero, the low half-word, on both outputs */
-      const uint32_t v = p.mute ? 0u : ((uint32_t)trunc_s32((double)(row[t] * p.output_gain) * 32767.0) & 0xffffu);
-      row[t] = __uint_as_float(v | (v << 16));
-    }
-    wg_sync<1>();
-    for (int r = 0; r < 64; r++) {
-      if (c0 + r >= p.n_channels) break;
-      int32_t *dst = p.out + (size_t)(c0 + r) * p.out_stride + (size_t)b * BS;
-      dst[lane] = __float_as_int(ta[r][lane]);
-      dst[lane + 64] = __float_as_int(ta[r][lane + 64]);
+    for (int j = 0; j < 32; j++) { /* 0xebfa: x output gain x 32767 toward zero, the low half-word, on both outputs */
+      const int e = tid + FW * j, r = e >> 7, t = e & 127;
+      const uint32_t v = p.mute ? 0u : ((uint32_t)trunc_s32((double)(ta[r][t] * p.output_gain) * 32767.0) & 0xffffu);
+      if (c0 + r < p.n_channels) p.out[(size_t)(c0 + r) * p.out_stride + (size_t)b * BS + t] = (int32_t)(v | (v << 16));
     }
   }
-  if (valid) {
-    aud.store(st + ST_AUDIO);
-    st[ST_AGC_ENV] = env; st[ST_AGC_GAIN] = g; st[ST_AGC_HANG] = __int_as_float(hang); st[ST_AGC_ACTIVE] = __int_as_float(active);
+  if (c0 + row < p.n_channels) aud.store(p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct);
+  if (ser_valid) {
+    sst[ST_AGC_ENV] = env; sst[ST_AGC_GAIN] = g; sst[ST_AGC_HANG] = __int_as_float(hang); sst[ST_AGC_ACTIVE] = __int_as_float(active);
     if constexpr (ALS) {
-      float *a = p.als + (size_t)ch * ALS_WORDS;
-      for (int i = 0; i < 256; i++) a[i] = line[i][lane];
-      for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][lane];
+      float *a = p.als + (size_t)sch * ALS_WORDS;
+      for (int i = 0; i < 256; i++) a[i] = line[i][tid];
+      for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][tid];
     }
   }
 }
@@ -468,7 +564,7 @@ struct rdsp_engine {
   bool tables;
   float *d_st = nullptr, *d_ring_i = nullptr, *d_ring_q = nullptr, *d_audio = nullptr, *d_nb = nullptr, *d_als = nullptr, *d_tab = nullptr;
   float curve[130], sine[257];
-  /* the object's fields (offsets of the image's AudioSDR in the comments of oracle/rdsp_engine_oracle.c) */
+  /* the object's fields (docs/engine.md has their places in the image's AudioSDR) */
   float if_centre, ssb_band, cw_band, input_gain, gain_i, gain_q, iq_balance, output_gain, tuning_offset;
   int mode, mute, audio_on, audio_id, audio_set, pre_set, agc_on, als_on, als_notch, als_adaptive, nb_on, resets;
   float agc_attack_a, agc_attack_b, agc_decay_a, agc_decay_b, agc_makeup, agc_knee_db, agc_slope, agc_threshold_db;
@@ -716,15 +812,15 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   p.sam_ga = e->sam_ga; p.sam_gb = e->sam_gb;
   const bool ssb = e->mode <= 3 || e->mode == 6, known = ssb || e->mode == 4 || e->mode == 5;
   const dim3 gf((unsigned)((e->n_channels + 31) / 32)), gt((unsigned)((e->n_channels + 63) / 64));
-  if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(64), 0, s, p);
+  if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
+  else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
   if (ssb) {
     const dim3 gh((unsigned)((n_blocks * BS + 255) / 256), (unsigned)e->n_channels);
     hipLaunchKernelGGL(rdsp_engine_hilbert_kernel, gh, dim3(256), 0, s, p);
   } else if (!known) { /* a mode number the engine does not know leaves its audio buffer as it was: the last call's */
   }
-  if (e->als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(rdsp_engine_tail_kernel<false>, gt, dim3(64), 0, s, p);
+  if (e->als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(FW), 0, s, p);
+  else hipLaunchKernelGGL(rdsp_engine_tail_kernel<false>, gt, dim3(FW), 0, s, p);
   err = hipGetLastError();
   if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
   if (ssb) e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1); /* the lines only move when the SSB / CW path runs */
