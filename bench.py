@@ -532,6 +532,8 @@ def engine_leg(torch, args, dev, local_rank, synth_iq):
 
 def main():
     args = parse()
+    if os.environ.get("RDSP_BENCH_LIB"):
+        sys.exit("RDSP_BENCH_LIB is no longer read: pass --lib PATH (the in-tree library would have been measured silently)")
     if args.lib:   # A/B harness: another build of the library (no torch / HIP touched by this import)
         from radiodsp_sdr_rx_amd import _lib
         _lib.use_library(args.lib)
@@ -774,7 +776,7 @@ def main():
                 "groups": args.groups,
                 "retune_every_steps": args.retune_every,
                 # A/B switches read from the environment by measurement scripts; a driver run shows an empty dict
-                "ab_switches": {k: v for k, v in os.environ.items() if k.startswith("RDSP_") and k != "RDSP_BENCH_ONE_DEVICE"},
+                "ab_switches": {k: v for k, v in os.environ.items() if k.startswith("RDSP_")},
             },
             "chain_hbm": {"algorithmic_bytes_per_sample": B, "achieved_GBps": B * value * 1e6 / 1e9 / world,
                           "frac_of_peak": B * value * 1e6 / 1e9 / world / HBM_PEAK_GBS,

@@ -222,8 +222,12 @@ int rdsp_set_nr_level(rdsp_chain_t *c, int nr_level);             /* nr_level, G
  * difference, re-started from the exact 96-sample window sum at every 128-sample block -- a deviation from NR:73, made
  * because the reference's own float32 recursion leaves `energy + 1.19e-7 <= 0` after loud-to-quiet transitions (164 of
  * 320 in tests/test_gpu_parity.py) and can lose a channel for good; on ordinary signals the two agree to the reference's
- * accumulated rounding (~1e-6).  running = 1: the reference's arithmetic as it is, one running difference for the whole
- * stream (tested <= 1e-5 against the oracle, which always runs this form). */
+ * accumulated rounding (~1e-6).  running = 1: no anchor -- one running sum for the whole stream like NR:73's, but in the
+ * kernel's own form: the increments are fused x^2 - q^2 terms added by a 16-lane prefix scan, where arm_lms_norm_f32
+ * subtracts and adds sample by sample.  Neither bit-equal to the reference's recursion nor statistically the same (the
+ * scan form draws bad residues more often: 90 channels flagged / 8 lost on the loud-to-quiet test against 1 in the CPU
+ * restatement); tested <= 1e-5 against the oracle, which always runs the reference's form, and 4.0e-4 (against 1.3e-4 in
+ * the default mode) from the firmware image's own output on the `conv_fade` fixture. */
 int rdsp_set_nlms_energy_mode(rdsp_chain_t *c, int running);
 int rdsp_set_spectral_nr(rdsp_chain_t *c, int on, float level);   /* on: 0, 1 (SPEC:112 iNRLevel), 2 (older variant, level unused) */
 /* How the spectral stage rebuilds a bin from its new magnitude (SPEC:221-235).  literal = 1: as the file writes it,
@@ -581,7 +585,8 @@ int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out20);
  * filters that the reference's firmware image holds (tests/golden/firmware_tables.npz `biquad_sets`; the first eight
  * are 150 Hz ... 2.1 / 2.3 / 2.5 / 2.7 / 2.9 / 3.1 / 3.3 / 3.9 kHz band-passes for fs = 44 117.647 Hz, each a 4th-order
  * elliptic-type high-pass and low-pass pair: zeros on the unit circle at 21 / 50 Hz and at 2.8 fu / 5.4 fu).  Needs
- * RDSP_AUDIO_KIND_IIR; in force until the next setAudioFilter / setDemodMode of the group. */
+ * RDSP_AUDIO_KIND_IIR; in force until the next setAudioFilter / setDemodMode of the group -- or until
+ * rdsp_chain_set_groups, which re-designs every group's filter from its settings: load explicit sets after regrouping. */
 int rdsp_group_setAudioIIRCoefficients(rdsp_chain_t *c, int group, const float *coef20);
 int rdsp_sdr_setAudioIIRCoefficients(rdsp_chain_t *c, const float *coef20);
 

@@ -93,7 +93,9 @@ struct SectionTeensy {
   int c0, c1, c2, c3, c4, x1, x2, y1, y2, sum;
   int *st;
   bool on; /* stages behind the cascade's last one do not run: the audio passes them untouched */
-  static __device__ __forceinline__ int smlaw(int acc, int c, int v) { return acc + (int)(((long long)c * (long long)v) >> 16); }
+  static __device__ __forceinline__ int smlaw(int acc, int c, int v) { /* SMLAW wraps: the sum is formed in unsigned arithmetic */
+    return (int)((unsigned)acc + (unsigned)(int)(((long long)c * (long long)v) >> 16));
+  }
   __device__ __forceinline__ void load(const RdspBiquadParams &p, int ch, int s) {
     const int *cf = p.icoef + 5 * s;
     c0 = cf[0]; c1 = cf[1]; c2 = cf[2]; c3 = cf[3]; c4 = cf[4];
@@ -365,7 +367,7 @@ extern "C" int rdsp_biquad_setCoefficients(rdsp_biquad_t *b, int stage, const do
   return rdsp_biquad_setCoefficients_int(b, stage, ci);
 }
 static int set_design(rdsp_biquad_t *b, int stage, int kind, float freq, float q) {
-  if (!b || stage < 0 || stage > 3 || !(freq > 0.f) || !(q > 0.f)) return RDSP_ERR_INVALID;
+  if (!b || stage < 0 || stage > 3 || !(freq > 0.f) || !(q > 0.f) || !((double)freq < 0.5 * b->fs)) return RDSP_ERR_INVALID; /* at or past fs / 2 the cookbook's x 2^30 coefficients leave the int32 range */
   int32_t ci[5];
   rdsp_teensy_biquad_design(kind, freq, q, (float)b->fs, ci);
   return rdsp_biquad_setCoefficients_int(b, stage, ci);

@@ -256,6 +256,12 @@ void rdsp_biquad_design(int kind, double freq, double q, double fs, float *coef5
  * evaluation reproduces them, a float angle is 8 ... 16 counts off; tests/test_firmware_tables.py), every coefficient
  * times 2^30 / (1 + alpha) and converted to int.  coef5 = {b0, b1, b2, a1, a2} as the library hands them to
  * setCoefficients(stage, const int *).  kind 0 LP, 1 HP, 2 BP, 3 notch. */
+static int32_t sat_i32(double x) { /* the Cortex-M conversion (VCVT.S32.F64) saturates; a plain cast past the range is undefined here */
+  if (!(x == x)) return 0;
+  if (x >= 2147483647.0) return INT32_MAX;
+  if (x <= -2147483648.0) return INT32_MIN;
+  return (int32_t)x;
+}
 void rdsp_teensy_biquad_design(int kind, float frequency, float q, float fs, int32_t *coef5) {
   const double w0 = (double)frequency * (2.0 * 3.141592654 / (double)fs);
   const double sinW0 = sin(w0);
@@ -263,24 +269,24 @@ void rdsp_teensy_biquad_design(int kind, float frequency, float q, float fs, int
   const double cosW0 = cos(w0);
   const double scale = 1073741824.0 / (1.0 + alpha);
   if (kind == 0) {
-    coef5[0] = (int32_t)(((1.0 - cosW0) / 2.0) * scale);
-    coef5[1] = (int32_t)((1.0 - cosW0) * scale);
+    coef5[0] = sat_i32(((1.0 - cosW0) / 2.0) * scale);
+    coef5[1] = sat_i32((1.0 - cosW0) * scale);
     coef5[2] = coef5[0];
   } else if (kind == 1) {
-    coef5[0] = (int32_t)(((1.0 + cosW0) / 2.0) * scale);
-    coef5[1] = (int32_t)(-(1.0 + cosW0) * scale);
+    coef5[0] = sat_i32(((1.0 + cosW0) / 2.0) * scale);
+    coef5[1] = sat_i32(-(1.0 + cosW0) * scale);
     coef5[2] = coef5[0];
   } else if (kind == 2) {
-    coef5[0] = (int32_t)(alpha * scale);
+    coef5[0] = sat_i32(alpha * scale);
     coef5[1] = 0;
-    coef5[2] = (int32_t)((-alpha) * scale);
+    coef5[2] = sat_i32((-alpha) * scale);
   } else {
-    coef5[0] = (int32_t)scale;
-    coef5[1] = (int32_t)((-2.0 * cosW0) * scale);
+    coef5[0] = sat_i32(scale);
+    coef5[1] = sat_i32((-2.0 * cosW0) * scale);
     coef5[2] = coef5[0];
   }
-  coef5[3] = (int32_t)((-2.0 * cosW0) * scale);
-  coef5[4] = (int32_t)((1.0 - alpha) * scale);
+  coef5[3] = sat_i32((-2.0 * cosW0) * scale);
+  coef5[4] = sat_i32((1.0 - alpha) * scale);
 }
 
 void rdsp_design_audio_iir(double f1, double f2, double fs, float *coef20) {

@@ -21,6 +21,7 @@
  * gain, NLMS weights) is read at launch start and written back at the end, so
  * its traffic is amortised over the time batch.
  */
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -1374,6 +1375,14 @@ int ensure_lds_limit(size_t lds) {
   }
   return 0;
 }
+/* The one-granule form beside the tail kernel (pipelined mode): unused LDS asked for on top of the kernel's own, so
+ * that fewer of its workgroups fit on a compute unit.  Measurement switch RDSP_FD_LDS_PAD (bytes) overrides. */
+inline size_t granule_form_lds_pad(int to_mid) {
+  static const long env = getenv("RDSP_FD_LDS_PAD") ? atol(getenv("RDSP_FD_LDS_PAD")) : -1;
+  if (env >= 0) return (size_t)env;
+  (void)to_mid;
+  return 0;
+}
 template <int N, int P, bool LEAN, bool PRE, int VC>
 int launch_front_fd_vc(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   if constexpr (N == 256) {
@@ -1391,7 +1400,9 @@ int launch_front_fd_vc(const RdspFrontParams *p, int n_channels, hipStream_t str
     int e = ensure_lds_limit<&rdsp_front_fd_kernel<N, P, LEAN, PRE, false, VC>>(lds);
     if (e != 0) return e;
   }
-  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, false, VC>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  size_t ask = lds;
+  if constexpr (VC == 4 && lds <= 16 * 1024) ask = lds + granule_form_lds_pad(p->to_mid);
+  hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, false, VC>), dim3(n_channels), dim3(N / P), ask, stream, *p);
   return (int)hipGetLastError();
 }
 /* fir_fd 1: 448-sample frames (throughput form, fir_variant 2); 2: one granule per frame (split-invariant, the default) */

@@ -45,6 +45,10 @@ static double window_value(int id, double x) {
 
 /* the q15 table the library would hold for window `window_id` and n points */
 void rdsp_window_q15_n(int window_id, int n, int16_t *w) {
+  if (n < 2) { /* w(i / (n - 1)) has no meaning for a single point: an empty or one-entry table is left at 0 */
+    if (n == 1) w[0] = 0;
+    return;
+  }
   for (int i = 0; i < n; i++) {
     double q = floor(32768.0 * window_value(window_id, (double)i / (double)(n - 1)) + 0.5);
     if (q > 32767.0) q = 32767.0;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of built libraries: bash tests/micro/lib_ab.sh variants/a.so variants/b.so ...
-# (RDSP_BENCH_LIB picks the library; configs via CONFIGS="K3 K2", extra bench flags via BFLAGS)
+# (each library is passed to bench.py as --lib; configs via CONFIGS="K3 K2", extra bench flags via BFLAGS)
 mkdir -p gpurun_out
 for rep in 1 2; do for lib in "$@"; do for K in ${CONFIGS:-K3}; do
   python bench.py --lib $PWD/$lib --config $K --steps ${STEPS:-10} --warmup ${WARMUP:-2} --no-cpu-baseline --no-host-io --no-extra-legs $BFLAGS > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
