@@ -814,9 +814,14 @@ def main():
                                                    "err(gpu, float64 model) <= max(1e-5, 1.5 x err(oracle, float64 model)); gpu vs "
                                                    "oracle up to 1.4e-4 there, the float32 oracle itself 4e-5..1.1e-4 from float64",
                           "oracle": "pinned on the reference's own compiled code where its shipped build has the stage (firmware routines run "
-                                    "under an instruction-set interpreter, tests/test_firmware_kat.py: CONV stage with NLMS 1.6e-7..2.0e-6 "
-                                    "oracle, 1.5e-7..2.1e-6 GPU; analysers, AudioFilterBiquad, arm_lms_norm_f32 bit for bit); unpinned for "
-                                    "decimator, spectral stage and the engine's NCO / ALS / AGC, i.e. for most of K3 (DESIGN.md 2)"},
+                                    "under an instruction-set interpreter): the CONV stage with NLMS at the ONE shape the image links -- FFT_L 256, "
+                                    "decim 1, 44.1 kHz, 129 taps -- 1.6e-7..2.0e-6 oracle, 1.5e-7..2.1e-6 GPU (FFT_L 512 .. 4096 are other "
+                                    "instantiations checked against the oracle only); analysers, AudioFilterBiquad, arm_lms_norm_f32 bit for bit; "
+                                    "and since round 6 the reference's whole engine (AudioSDR::update: mixer, side-band selection, AM / SAM, audio "
+                                    "filters, hang AGC, ALS, blanker; AudioSDRpreProcessor) bit for bit as rdsp_engine_t / rdsp_preproc_t "
+                                    "(configs.engine_literal).  THIS line's workload, K3, runs rdsp_chain_t: a 96 kHz many-channel chain with a "
+                                    "decimator and a spectral stage the reference has no compiled counterpart of -- its NCO / decimator / "
+                                    "spectral stage / ALS / AGC are this build's designs, checked against the CPU oracle only (DESIGN.md 2)"},
         }
         if args.lib:
             res["library"] = os.path.abspath(args.lib)   # an A/B run, not the in-tree build
