@@ -162,3 +162,35 @@ def test_gpu_engine_many_channels_are_independent(kat, rdsp):
     import oracle_lib
     for c in (1, 33, 64, 96):
         assert np.array_equal(out[c], oracle_lib.OracleEngine().run(x[c])), c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blanker", [False, True])
+def test_gpu_engine_1100_channels_on_a_callers_stream(kat, rdsp, blanker):
+    """1100 channels (35 front workgroups, 18 tail workgroups, the last ones ragged), two calls back to back on a
+    non-default stream with the result read on that stream, with and without the blanker (whose rows past the last channel
+    write to a spare slot) -- channel c must return what one engine alone returns"""
+    import torch
+    import oracle_lib
+    name = "blanker_on" if blanker else "lsb_sketch"
+    iq = kat[name + "_iq"][:24 * 128]
+    nch = 1100
+    rolls = [0 if c % 9 == 0 else 128 * (c % 5) + 3 * c for c in range(nch)]
+    x = np.stack([np.roll(iq, r, axis=0) for r in rolls])
+    eng = _engine(rdsp, nch, 12)
+    eng.sketch_setup()
+    if blanker:
+        eng.enableNoiseBlanker()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        d = torch.from_numpy(x).cuda()
+        out = torch.cat([eng.update(d[:, :12 * 128].contiguous(), stream=st.cuda_stream),
+                         eng.update(d[:, 12 * 128:].contiguous(), stream=st.cuda_stream)], 1)[..., 0].cpu().numpy()
+    for c in range(nch):
+        if rolls[c] == 0:
+            assert np.array_equal(out[c], kat[name + "_out"][:24 * 128]), c
+    for c in (1, 319, 320, 639, 640, 959, 960, 1099):
+        o = oracle_lib.OracleEngine()
+        if blanker:
+            o.call("enableNoiseBlanker")
+        assert np.array_equal(out[c], o.run(x[c])), c
