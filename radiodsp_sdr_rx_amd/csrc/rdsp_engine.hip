@@ -112,8 +112,19 @@ struct Cascade {
 };
 
 /* the oscillator: sin of a phase in [0, 2 pi) by linear interpolation in the 256-step table, through double as the image does */
+/* trunc(RN(a / d)) for a >= 0 and d = the double of the image's 2 pi, without the division: k d is exact for k < 2^16 (a
+ * 24-bit d), so floor(a / d) follows from two exact comparisons around the estimate a (1 / d); and the correctly rounded
+ * quotient cannot lie across an integer from the true one, because a is either exactly k d or at least an ulp of a away
+ * from it, which is more than half an ulp of the quotient (tests/test_host_logic.py walks every k and its neighbours) */
+__device__ __forceinline__ int index_of_phase(double a) {
+  const double d = (double)TWO_PI_F;
+  int k = (int)(a * (1.0 / d));
+  if ((double)k * d > a) k--;
+  else if ((double)(k + 1) * d <= a) k++;
+  return k;
+}
 __device__ __forceinline__ float table_sin(const float *sine, float ph) {
-  const int idx = trunc_s32(((double)ph * 65535.0) / (double)TWO_PI_F);
+  const int idx = index_of_phase((double)ph * 65535.0);
   const int hi = (idx >> 8) & 0xff;
   const float lo = (float)(unsigned)(idx & 0xff);
   const float t0 = sine[hi], t1 = sine[hi + 1];
@@ -202,51 +213,64 @@ __device__ __forceinline__ void rotate_sample(const float *sine, float ph, float
   y = fmaf(yq, c, xi * s);
 }
 
+/* v / 32767.0 correctly rounded without the division: q0 = v y, r = v - 32767 q0 (exact, fused), q = q0 + r y with
+ * y = RN(1 / 32767) -- equal to the IEEE quotient for every int16 v (tests/test_host_logic.py tries all 65 536) */
+__device__ __forceinline__ double over_32767(int v) {
+  const double y = 1.0 / 32767.0, x = (double)v;
+  const double q0 = x * y;
+  return fma(fma(-q0, 32767.0, x), y, q0);
+}
+
 /* ---- front: conversion, blanker, IF filter, frequency shift (SSB / CW) or the AM / SAM detectors ----------------------
- * 32 channels = 64 tile rows (channel, rail) per workgroup of four waves.  Per block: conversion and the mixer's
- * table work spread over all 256 lanes (element e = lane + 256 j: consecutive lanes on consecutive samples of a row);
- * the cascades with a quad per row; the oscillator's phase, the PLL and the blanker -- true recursions -- on one lane
- * per channel or row. */
-constexpr int FW = 256;
+ * 16 channels = 32 tile rows (channel, rail) per workgroup of four waves -- a launch's duration is one workgroup's chain
+ * of blocks whatever the grid, so the fewer channels a workgroup carries the shorter it is, down to what the recursions
+ * need.  Per block: conversion and the mixer's table work spread over all 256 lanes (element e = lane + 256 j: consecutive
+ * lanes on consecutive samples of a row); the cascades with a quad per row on waves 0 and 1 while wave 2 runs the
+ * oscillator's phase, one lane per channel; the PLL and the blanker -- true recursions -- on one lane per channel or row. */
+constexpr int FW = 256, FCH = 16;
 template <bool NB>
 __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p) {
-  __shared__ float tf[64][PITCH];
-  __shared__ float phs[32][PITCH];
-  __shared__ int locked_of[32];
-  const int tid = threadIdx.x, c0 = blockIdx.x * 32;
-  const int row = tid >> 2, sct = tid & 3;                       /* cascade role: section sct of tile row `row` */
+  __shared__ float tf[2 * FCH][PITCH];
+  __shared__ float phs[FCH][PITCH];
+  __shared__ int locked_of[FCH];
+  const int tid = threadIdx.x, c0 = blockIdx.x * FCH;
+  const bool casc = tid < 8 * FCH;                              /* cascade role: section sct of tile row `row` */
+  const int row = (tid >> 2) & (2 * FCH - 1), sct = tid & 3;
   const int rch = min(c0 + (row >> 1), p.n_channels - 1);
-  const bool row_valid = c0 + (row >> 1) < p.n_channels;
+  const bool row_valid = casc && c0 + (row >> 1) < p.n_channels;
   const bool ssb = p.mode <= 3 || p.mode == 6, am = p.mode == 4 || p.mode == 5;
   Section pre, amf;
   pre.load(p.sets + 20 * p.pre_set + 5 * sct, p.st + (size_t)rch * NF + ST_PRE + 16 * (row & 1) + 4 * sct, (p.resets & RESET_PRE) != 0);
   amf.load(p.sets + 20 * 13 + 5 * sct, p.st + (size_t)rch * NF + ST_AM + 16 * (row & 1) + 4 * sct, false);
-  /* serial role: lane tid < 32 owns channel c0 + tid's scalars */
-  const int sch = min(c0 + (tid & 31), p.n_channels - 1);
-  const bool ser = tid < 32, ser_valid = ser && c0 + tid < p.n_channels;
+  /* serial role: lane 128 + c owns channel c0 + c's scalars (wave 2, beside the cascades' waves 0 and 1) */
+  const bool ser = tid >= 128 && tid < 128 + FCH;
+  const int sc = (tid - 128) & (FCH - 1);
+  const int sch = min(c0 + sc, p.n_channels - 1);
+  const bool ser_valid = ser && c0 + sc < p.n_channels;
   float *sst = p.st + (size_t)sch * NF;
   float nco = sst[ST_NCO], amph = sst[ST_AMPH];
   float sam_c = sst[ST_SAM_COS], sam_s = sst[ST_SAM_SIN], sam_u = sst[ST_SAM_U], sam_err = sst[ST_SAM_ERR], sam_hz = sst[ST_SAM_HZ],
         sam_ph = sst[ST_SAM_PH];
   int sam_locked = __float_as_int(sst[ST_SAM_LOCK]);
-  /* blanker role: lane tid < 64 owns tile row tid */
-  const int bch = min(c0 + (tid >> 1), p.n_channels - 1);
-  const bool bl_valid = tid < 64 && c0 + (tid >> 1) < p.n_channels;
+  /* blanker role: lane tid < 32 owns tile row tid */
+  const int bch = min(c0 + ((tid & 31) >> 1), p.n_channels - 1);
+  const bool bl_valid = tid < 2 * FCH && c0 + (tid >> 1) < p.n_channels;
   float nb_avg = p.st[(size_t)bch * NF + ST_NB_AVG], nb_last = p.st[(size_t)bch * NF + ST_NB_LAST];
   int nb_hit = __float_as_int(p.st[(size_t)bch * NF + ST_NB_HIT]);
   const float nco_inc = -(p.tuning_offset * RAD_PER_HZ), am_inc = -p.if_centre * RAD_PER_HZ;
+  constexpr int EP = FCH * BS / FW; /* elements (int16 pairs, complex samples) per lane and pass */
 
   for (int b = 0; b < p.n_blocks; b++) {
-    for (int j = 0; j < 16; j++) { /* 0xe7b4: / 32767 and the rail's gain, in double; one int16 pair per element */
+    for (int j = 0; j < EP; j++) { /* 0xe7b4: / 32767 and the rail's gain, in double; one int16 pair per element */
       const int e = tid + FW * j, cl = e >> 7, t = e & 127;
       const int w = c0 + cl < p.n_channels ? p.iq[(size_t)(c0 + cl) * p.in_stride + (size_t)b * BS + t] : 0;
-      tf[2 * cl][t] = (float)(((double)(int)(int16_t)(w & 0xffff) / 32767.0) * (double)p.gain_i);
-      tf[2 * cl + 1][t] = (float)(((double)(w >> 16) / 32767.0) * (double)p.gain_q);
+      tf[2 * cl][t] = (float)(over_32767((int)(int16_t)(w & 0xffff)) * (double)p.gain_i);
+      tf[2 * cl + 1][t] = (float)(over_32767(w >> 16) * (double)p.gain_q);
     }
     __syncthreads();
     if constexpr (NB) { /* 0xe14c: two blocks of delay; |I + jQ| against its running average; blanking mask with a taper.
                          * Each row's lane keeps its own copy of both rails' lines and of the mask in HBM */
-      if (tid < 64) {
+      if (tid < 2 * FCH) {
         const int rail = tid & 1;
         float *li = p.nb + ((size_t)(bl_valid ? bch : p.n_channels) * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768; /* rows past the last channel share a spare slot */
         float *mine = tf[tid];
@@ -276,12 +300,11 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
       }
       __syncthreads();
     }
-    cascade_row(pre, tf[row], sct);
+    if (casc) cascade_row(pre, tf[row], sct);
+    else if (ser && ssb) phase_row(nco, nco_inc, phs[sc]);       /* 0xe94e: the phase falls by the tuning offset */
     __syncthreads();
     if (ssb) {
-      if (ser) phase_row(nco, nco_inc, phs[tid]);                /* 0xe94e: the phase falls by the tuning offset */
-      __syncthreads();
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < EP; j++) {
         const int e = tid + FW * j, cl = e >> 7, t = e & 127;
         float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
         rotate_sample(p.sine, phs[cl][t], x, y);
@@ -289,18 +312,18 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
       }
       __syncthreads();
       const uint32_t at = p.pos + (uint32_t)b * BS, m = p.ring_size - 1;
-      for (int j = 0; j < 32; j++) { /* into the rings: tile row r is (channel c0 + r / 2, rail r & 1) */
+      for (int j = 0; j < 2 * EP; j++) { /* into the rings: tile row r is (channel c0 + r / 2, rail r & 1) */
         const int e = tid + FW * j, r = e >> 7, t = e & 127;
         if (c0 + (r >> 1) < p.n_channels)
           ((r & 1) ? p.ring_q : p.ring_i)[(size_t)(c0 + (r >> 1)) * p.ring_size + ((at + (uint32_t)t) & m)] = tf[r][t];
       }
     } else if (am) {
-      cascade_row(pre, tf[row], sct);                            /* 0xec1c: the IF filter a second time */
+      if (casc) cascade_row(pre, tf[row], sct);                  /* 0xec1c: the IF filter a second time */
       __syncthreads();
       if (p.mode == 5) { /* 0xe390: PLL on the IF signal, one lane per channel */
         if (ser) {
           const float HALF_PI = 1.5707963705062866f, A1 = 0.97239410877227783f, A3 = -0.19194795191287994f;
-          float *ri = tf[2 * tid], *rq = tf[2 * tid + 1];
+          float *ri = tf[2 * sc], *rq = tf[2 * sc + 1];
           for (int t = 0; t < BS; t++) {
             const float x = ri[t], q = rq[t];
             const float re = fmaf(x, sam_c, q * sam_s), im = fmaf(q, sam_c, -(sam_s * x));
@@ -334,15 +357,15 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
             }
             sam_u = u; sam_err = err;
           }
-          locked_of[tid] = sam_locked;
+          locked_of[sc] = sam_locked;
         }
-      } else if (ser) locked_of[tid] = 0;
+      } else if (ser) locked_of[sc] = 0;
       __syncthreads();
       /* AM, and SAM out of lock (0xed02): shift by the IF centre, low-pass, envelope.  A channel in lock keeps the rotated
        * I rail as its audio and none of the detector's state moves */
-      if (ser && !locked_of[tid]) phase_row(amph, am_inc, phs[tid]);
+      if (ser && !locked_of[sc]) phase_row(amph, am_inc, phs[sc]);
       __syncthreads();
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < EP; j++) {
         const int e = tid + FW * j, cl = e >> 7, t = e & 127;
         if (locked_of[cl]) continue;
         float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
@@ -350,19 +373,21 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
         tf[2 * cl][t] = x; tf[2 * cl + 1][t] = y;
       }
       __syncthreads();
-      const bool detect = !locked_of[row >> 1];
-      Section keep = amf;
-      cascade_row(amf, detect ? tf[row] : phs[0], sct);          /* the quads of a locked channel run on a scratch row ... */
-      if (!detect) amf = keep;                                   /* ... and keep their state */
+      if (casc) {
+        const bool detect = !locked_of[row >> 1];
+        const Section keep = amf;
+        cascade_row(amf, detect ? tf[row] : phs[row >> 1], sct);   /* the quads of a locked channel run on a row nobody reads ... */
+        if (!detect) amf = keep;                                 /* ... and keep their state */
+      }
       __syncthreads();
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < EP; j++) {
         const int e = tid + FW * j, cl = e >> 7, t = e & 127;
         if (locked_of[cl]) continue;
         const float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
         tf[2 * cl][t] = quick_sqrt2(fmaf(x, x, y * y));
       }
       __syncthreads();
-      for (int j = 0; j < 16; j++) { /* the demodulated audio is in the I rows */
+      for (int j = 0; j < EP; j++) { /* the demodulated audio is in the I rows */
         const int e = tid + FW * j, cl = e >> 7, t = e & 127;
         if (c0 + cl < p.n_channels) p.audio[(size_t)(c0 + cl) * p.audio_stride + (size_t)b * BS + t] = tf[2 * cl][t];
       }
@@ -415,24 +440,29 @@ __device__ __forceinline__ float agc_lookup(const float *curve, float env) {
   return fmaf(frac, curve[hi1] - t0, t0);
 }
 
-/* 64 channels per workgroup of four waves.  Per block: the audio cascade with a quad per channel; the AGC's envelope --
- * the only true recursion in it -- on one lane per channel, which leaves for every sample the envelope value its gain is
- * looked up from (or "none yet": the gain carried in); gain, clamp and pack are then pure functions and run on all lanes. */
+/* 16 channels per workgroup of four waves.  Per block: the audio cascade with a quad per channel (wave 0); the AGC's
+ * envelope -- the only true recursion in it -- on one lane per channel (wave 1), which leaves for every sample the
+ * envelope value its gain is looked up from (or "none yet": the gain carried in); gain, clamp and pack are then pure
+ * functions and run on all lanes. */
+constexpr int TCH = 16;
 template <bool ALS>
 __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p) {
-  __shared__ float ta[64][PITCH];
-  __shared__ float ge[64][PITCH];
+  __shared__ float ta[TCH][PITCH];
+  __shared__ float ge[TCH][PITCH];
   __shared__ float curve[130];
-  __shared__ float g_in[64];
-  __shared__ float line[ALS ? 256 : 1][64];
-  __shared__ float wt[ALS ? ALS_TAPS : 1][64];
-  const int tid = threadIdx.x, c0 = blockIdx.x * 64;
-  const int row = tid >> 2, sct = tid & 3;
+  __shared__ float g_in[TCH];
+  __shared__ float line[ALS ? 256 : 1][TCH];
+  __shared__ float wt[ALS ? ALS_TAPS : 1][TCH];
+  const int tid = threadIdx.x, c0 = blockIdx.x * TCH;
+  const bool casc = tid < 4 * TCH;
+  const int row = (tid >> 2) & (TCH - 1), sct = tid & 3;
   const int rch = min(c0 + row, p.n_channels - 1);
   Section aud;
   aud.load(p.sets + 20 * p.audio_set + 5 * sct, p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct, (p.resets & RESET_AUDIO) != 0);
-  const bool ser = tid < 64, ser_valid = ser && c0 + tid < p.n_channels;
-  const int sch = min(c0 + (tid & 63), p.n_channels - 1);
+  const bool ser = tid >= 64 && tid < 64 + TCH;
+  const int sc = (tid - 64) & (TCH - 1);
+  const bool ser_valid = ser && c0 + sc < p.n_channels;
+  const int sch = min(c0 + sc, p.n_channels - 1);
   float *sst = p.st + (size_t)sch * NF;
   float env = sst[ST_AGC_ENV], g = sst[ST_AGC_GAIN];
   int hang = __float_as_int(sst[ST_AGC_HANG]), active = __float_as_int(sst[ST_AGC_ACTIVE]);
@@ -441,26 +471,27 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
     if (ser) {
       const float *a = p.als + (size_t)sch * ALS_WORDS;
       const bool clear = (p.resets & RESET_ALS) != 0;
-      for (int i = 0; i < 256; i++) line[i][tid] = clear ? 0.0f : a[i];
-      for (int k = 0; k < ALS_TAPS; k++) wt[k][tid] = clear ? 0.0f : a[256 + k];
+      for (int i = 0; i < 256; i++) line[i][sc] = clear ? 0.0f : a[i];
+      for (int k = 0; k < ALS_TAPS; k++) wt[k][sc] = clear ? 0.0f : a[256 + k];
     }
   }
+  constexpr int EP = TCH * BS / FW;
   for (int b = 0; b < p.n_blocks; b++) {
     __syncthreads();
-    for (int j = 0; j < 32; j++) {
+    for (int j = 0; j < EP; j++) {
       const int e = tid + FW * j, r = e >> 7, t = e & 127;
       ta[r][t] = c0 + r < p.n_channels ? p.audio[(size_t)(c0 + r) * p.audio_stride + (size_t)b * BS + t] : 0.0f;
     }
     __syncthreads();
     if (p.audio_on) {
-      cascade_row(aud, ta[row], sct);
+      if (casc) cascade_row(aud, ta[row], sct);
       __syncthreads();
     }
     if (p.agc_on) {
       if (ser) {
-        g_in[tid] = g;
+        g_in[sc] = g;
         float last = -1.0f;                      /* the envelope the current gain was looked up from; < 0: none in this block yet */
-        const float *a = ta[tid];
+        const float *a = ta[sc];
         for (int t = 0; t < BS; t++) {
           float in = fabsf(a[t]);
           if (in > 1.0f) in = 1.0f;
@@ -474,13 +505,13 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
           } else {
             hang--;
           }
-          ge[tid][t] = last;
+          ge[sc][t] = last;
         }
         if (last >= 0.0f) g = agc_lookup(curve, last);
         active = (double)g < 0.98999999999999999;
       }
       __syncthreads();
-      for (int j = 0; j < 32; j++) {
+      for (int j = 0; j < EP; j++) {
         const int e = tid + FW * j, r = e >> 7, t = e & 127;
         const float le = ge[r][t];
         const float gg = le < 0.0f ? g_in[r] : agc_lookup(curve, le);
@@ -493,16 +524,16 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
     }
     if constexpr (ALS) { /* y = w . x delayed; the taps move on every fourth sample of a block by mu e x (plain LMS) */
       if (ser) {
-        float *rowp = ta[tid];
-        for (int i = 0; i < 128; i++) { line[i][tid] = line[i + 128][tid]; line[i + 128][tid] = rowp[i]; }
+        float *rowp = ta[sc];
+        for (int i = 0; i < 128; i++) { line[i][sc] = line[i + 128][sc]; line[i + 128][sc] = rowp[i]; }
         int cnt = 0;
         for (int n = 128; n < 256; n++) {
           float y = 0.0f;
-          for (int k = 0; k < ALS_TAPS; k++) y = fmaf(wt[k][tid], line[n - ALS_DELAY - k][tid], y);
-          const float err = line[n][tid] - y;
+          for (int k = 0; k < ALS_TAPS; k++) y = fmaf(wt[k][sc], line[n - ALS_DELAY - k][sc], y);
+          const float err = line[n][sc] - y;
           if (p.als_adaptive) {
             if (cnt == 0)
-              for (int k = 0; k < ALS_TAPS; k++) wt[k][tid] = fmaf(err * line[n - ALS_DELAY - k][tid], 0.5f, wt[k][tid]);
+              for (int k = 0; k < ALS_TAPS; k++) wt[k][sc] = fmaf(err * line[n - ALS_DELAY - k][sc], 0.5f, wt[k][sc]);
             cnt = (cnt + 1) & 3;
           }
           rowp[n - 128] = p.als_notch ? err : y;
@@ -510,19 +541,19 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
       }
       __syncthreads();
     }
-    for (int j = 0; j < 32; j++) { /* 0xebfa: x output gain x 32767 toward zero, the low half-word, on both outputs */
+    for (int j = 0; j < EP; j++) { /* 0xebfa: x output gain x 32767 toward zero, the low half-word, on both outputs */
       const int e = tid + FW * j, r = e >> 7, t = e & 127;
       const uint32_t v = p.mute ? 0u : ((uint32_t)trunc_s32((double)(ta[r][t] * p.output_gain) * 32767.0) & 0xffffu);
       if (c0 + r < p.n_channels) p.out[(size_t)(c0 + r) * p.out_stride + (size_t)b * BS + t] = (int32_t)(v | (v << 16));
     }
   }
-  if (c0 + row < p.n_channels) aud.store(p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct);
+  if (casc && c0 + row < p.n_channels) aud.store(p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct);
   if (ser_valid) {
     sst[ST_AGC_ENV] = env; sst[ST_AGC_GAIN] = g; sst[ST_AGC_HANG] = __int_as_float(hang); sst[ST_AGC_ACTIVE] = __int_as_float(active);
     if constexpr (ALS) {
       float *a = p.als + (size_t)sch * ALS_WORDS;
-      for (int i = 0; i < 256; i++) a[i] = line[i][tid];
-      for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][tid];
+      for (int i = 0; i < 256; i++) a[i] = line[i][sc];
+      for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][sc];
     }
   }
 }
@@ -811,7 +842,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   p.sam_keep = 0.995f; p.sam_new = bits_f(0x3ba3d700); p.sam_hz_per_rad = bits_f(0x45db55dd); p.sam_lock_lo = 3890.0f; p.sam_lock_hi = 9890.0f;
   p.sam_ga = e->sam_ga; p.sam_gb = e->sam_gb;
   const bool ssb = e->mode <= 3 || e->mode == 6, known = ssb || e->mode == 4 || e->mode == 5;
-  const dim3 gf((unsigned)((e->n_channels + 31) / 32)), gt((unsigned)((e->n_channels + 63) / 64));
+  const dim3 gf((unsigned)((e->n_channels + FCH - 1) / FCH)), gt((unsigned)((e->n_channels + TCH - 1) / TCH));
   if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
   else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
   if (ssb) {

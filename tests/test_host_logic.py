@@ -418,3 +418,32 @@ def test_as_written_resynthesis_in_closed_form_is_the_tables_own_arithmetic():
         return (1.0 - (fi - idx)) * tab[idx] + (fi - idx) * tab[idx + 1]
     assert np.abs(got_c - table64(t64 + 0.25)).max() < 1e-7 and np.abs(got_s - table64(t64)).max() < 1e-7
     assert np.abs(x / m - want_c).max() > 1.5e-5                                 # what separates the stage's two forms
+
+
+def test_engine_kernels_division_free_forms_are_the_quotients():
+    """csrc/rdsp_engine.hip replaces two IEEE double divisions of the engine's arithmetic by forms without one and claims
+    the same bits: v / 32767.0 for every int16 v (q0 = v y, r = fma(-q0, 32767, v), q = fma(r, y, q0), y = RN(1 / 32767)),
+    and trunc(a / d) for the table index (d = the double of the float 2 pi; the estimate a (1 / d) corrected by two exact
+    comparisons with k d).  Both are checked here in exact rational arithmetic: all 65 536 int16 values; every index k with
+    a = k d and its two neighbouring doubles, and two million random phases."""
+    from fractions import Fraction
+    y = 1.0 / 32767.0
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))      # exact, then one rounding
+    for v in range(-32768, 32768):
+        q0 = float(v) * y
+        assert fma(fma(-q0, 32767.0, float(v)), y, q0) == v / 32767.0, v
+    d = float(np.float32(6.2831854820251465))
+
+    def index(a):
+        k = np.trunc(a * (1.0 / d)).astype(np.int64)
+        k = np.where(k.astype(np.float64) * d > a, k - 1, k)
+        return np.where((k + 1).astype(np.float64) * d <= a, k + 1, k)
+    n = np.arange(0, 65536, dtype=np.float64)
+    assert all(Fraction(float(k) * d) == Fraction(int(k)) * Fraction(d) for k in n[::97])   # k d is exact in double
+    for a in (n * d, np.nextafter(n * d, np.inf), np.nextafter(n[1:] * d, -np.inf)):
+        assert np.array_equal(index(a), np.trunc(a / d).astype(np.int64))
+    ph = np.random.default_rng(3).uniform(0, 6.2831855, 2_000_000).astype(np.float32).astype(np.float64)
+    a = ph * 65535.0
+    assert np.array_equal(index(a), np.trunc(a / d).astype(np.int64))
