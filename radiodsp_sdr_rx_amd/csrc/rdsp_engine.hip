@@ -176,12 +176,15 @@ struct Section {
 };
 /* one block of one tile row through the cascade, in place; called by all four lanes of the row's quad */
 __device__ __forceinline__ void cascade_row(Section &sec, float *row, int s) {
-  float yprev = 0.0f;
+  float yprev = 0.0f, xnext = row[0];
 #pragma unroll 4
   for (int i = 0; i < BS + 3; i++) {
     const int n = i - s;
     const float up = dpp_up1(yprev);
-    const float x = s == 0 ? row[i < BS ? i : BS - 1] : up;
+    const float xin = xnext;
+    xnext = row[i + 1 < BS ? i + 1 : BS - 1]; /* asked for a step ahead: the read's latency passes behind this step's arithmetic
+                                               * (the row is also written below, so the compiler will not move the read itself) */
+    const float x = s == 0 ? xin : up;
     const float y = sec.eval(x);
     if (n >= 0 && n < BS) {
       sec.commit(x, y);
@@ -222,12 +225,12 @@ __device__ __forceinline__ double over_32767(int v) {
 }
 
 /* ---- front: conversion, blanker, IF filter, frequency shift (SSB / CW) or the AM / SAM detectors ----------------------
- * 16 channels = 32 tile rows (channel, rail) per workgroup of four waves -- a launch's duration is one workgroup's chain
+ * 8 channels = 16 tile rows (channel, rail) per workgroup of four waves -- a launch's duration is one workgroup's chain
  * of blocks whatever the grid, so the fewer channels a workgroup carries the shorter it is, down to what the recursions
  * need.  Per block: conversion and the mixer's table work spread over all 256 lanes (element e = lane + 256 j: consecutive
  * lanes on consecutive samples of a row); the cascades with a quad per row on waves 0 and 1 while wave 2 runs the
  * oscillator's phase, one lane per channel; the PLL and the blanker -- true recursions -- on one lane per channel or row. */
-constexpr int FW = 256, FCH = 16;
+constexpr int FW = 256, FCH = 8;
 template <bool NB>
 __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p) {
   __shared__ float tf[2 * FCH][PITCH];
@@ -440,13 +443,13 @@ __device__ __forceinline__ float agc_lookup(const float *curve, float env) {
   return fmaf(frac, curve[hi1] - t0, t0);
 }
 
-/* 16 channels per workgroup of four waves.  Per block: the audio cascade with a quad per channel (wave 0); the AGC's
+/* 8 channels (16 with the ALS filter) per workgroup of four waves.  Per block: the audio cascade with a quad per channel (wave 0); the AGC's
  * envelope -- the only true recursion in it -- on one lane per channel (wave 1), which leaves for every sample the
  * envelope value its gain is looked up from (or "none yet": the gain carried in); gain, clamp and pack are then pure
  * functions and run on all lanes. */
-constexpr int TCH = 16;
 template <bool ALS>
 __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p) {
+  constexpr int TCH = ALS ? 16 : 8; /* channels per workgroup (measured: 8 is 12 % faster than 16 without the ALS filter, half as fast with it) */
   __shared__ float ta[TCH][PITCH];
   __shared__ float ge[TCH][PITCH];
   __shared__ float curve[130];
@@ -492,19 +495,19 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
         g_in[sc] = g;
         float last = -1.0f;                      /* the envelope the current gain was looked up from; < 0: none in this block yet */
         const float *a = ta[sc];
+        float anext = a[0];
         for (int t = 0; t < BS; t++) {
-          float in = fabsf(a[t]);
+          float in = fabsf(anext);
+          anext = a[t + 1 < BS ? t + 1 : BS - 1];
           if (in > 1.0f) in = 1.0f;
-          if (env < in) {                        /* attack: the hang counter is re-armed */
-            env = fmaf(env, p.agc_attack_a, in * p.agc_attack_b);
-            hang = p.agc_hang_time;
-            last = env;
-          } else if (hang == 0) {
-            env = fmaf(env, p.agc_decay_a, in * p.agc_decay_b);
-            last = env;
-          } else {
-            hang--;
-          }
+          /* attack (the hang counter is re-armed) / decay (counter at 0) / hold (count down): both candidate envelopes
+           * are formed and one is selected -- the channels of a wave are in different states, and as branches every
+           * lane would walk all three arms */
+          const bool attack = env < in, decay = !attack && hang == 0;
+          const float ea = fmaf(env, p.agc_attack_a, in * p.agc_attack_b), ed = fmaf(env, p.agc_decay_a, in * p.agc_decay_b);
+          env = attack ? ea : (decay ? ed : env);
+          hang = attack ? p.agc_hang_time : (decay ? 0 : hang - 1);
+          last = (attack || decay) ? env : last;
           ge[sc][t] = last;
         }
         if (last >= 0.0f) g = agc_lookup(curve, last);
@@ -842,7 +845,8 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   p.sam_keep = 0.995f; p.sam_new = bits_f(0x3ba3d700); p.sam_hz_per_rad = bits_f(0x45db55dd); p.sam_lock_lo = 3890.0f; p.sam_lock_hi = 9890.0f;
   p.sam_ga = e->sam_ga; p.sam_gb = e->sam_gb;
   const bool ssb = e->mode <= 3 || e->mode == 6, known = ssb || e->mode == 4 || e->mode == 5;
-  const dim3 gf((unsigned)((e->n_channels + FCH - 1) / FCH)), gt((unsigned)((e->n_channels + TCH - 1) / TCH));
+  const int tch = e->als_on ? 16 : 8;
+  const dim3 gf((unsigned)((e->n_channels + FCH - 1) / FCH)), gt((unsigned)((e->n_channels + tch - 1) / tch));
   if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
   else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
   if (ssb) {
