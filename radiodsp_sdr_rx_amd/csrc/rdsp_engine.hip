@@ -412,6 +412,68 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
   }
 }
 
+/* ---- the same front stage for the SSB / CW modes without the blanker, as a pipeline of waves ------------------------
+ * A lone wave issues an instruction every five cycles or so whatever it depends on, so a block costs its workgroup the SUM
+ * of its passes' instruction counts -- unless the passes run on different waves at the same time.  Here they do, each on
+ * the block behind the previous one's: waves 2 and 3 convert block s into tile slot s & 3 and rotate / store block s - 2
+ * out of slot (s - 2) & 3, wave 0 runs the cascades of block s - 1, wave 1 the oscillator's phase of block s - 1; one
+ * barrier per step.  A step then lasts as long as its longest pass (the cascade: 131 dependent steps), and the arithmetic
+ * of every sample is what it was. */
+__global__ __launch_bounds__(FW) void rdsp_engine_front_pipe_kernel(const EngParams p) {
+  __shared__ float tf[4][2 * FCH][PITCH];
+  __shared__ float phs[4][FCH][PITCH];
+  const int tid = threadIdx.x, wave = tid >> 6, c0 = blockIdx.x * FCH;
+  const int row = (tid >> 2) & (2 * FCH - 1), sct = tid & 3;      /* wave 0: section sct of tile row `row` */
+  const int rch = min(c0 + (row >> 1), p.n_channels - 1);
+  Section pre;
+  pre.load(p.sets + 20 * p.pre_set + 5 * sct, p.st + (size_t)rch * NF + ST_PRE + 16 * (row & 1) + 4 * sct, (p.resets & RESET_PRE) != 0);
+  const int sc = tid & (FCH - 1);                                 /* wave 1, lanes 64 ... 64 + FCH - 1: channel sc's oscillator */
+  const bool ser = wave == 1 && (tid & 63) < FCH;
+  const int sch = min(c0 + sc, p.n_channels - 1);
+  float nco = p.st[(size_t)sch * NF + ST_NCO];
+  const float nco_inc = -(p.tuning_offset * RAD_PER_HZ);
+  const int wl = tid - 128;                                       /* waves 2 and 3: 128 lanes for the element passes */
+  constexpr int EP = FCH * BS / 128;
+  const uint32_t m = p.ring_size - 1;
+  for (int step = 0; step < p.n_blocks + 2; step++) {
+    if (wave >= 2) {
+      if (step < p.n_blocks) { /* 0xe7b4: block `step` comes in */
+        float (*t0)[PITCH] = tf[step & 3];
+        for (int j = 0; j < EP; j++) {
+          const int e = wl + 128 * j, cl = e >> 7, t = e & 127;
+          const int w = c0 + cl < p.n_channels ? p.iq[(size_t)(c0 + cl) * p.in_stride + (size_t)step * BS + t] : 0;
+          t0[2 * cl][t] = (float)(over_32767((int)(int16_t)(w & 0xffff)) * (double)p.gain_i);
+          t0[2 * cl + 1][t] = (float)(over_32767(w >> 16) * (double)p.gain_q);
+        }
+      }
+      const int b = step - 2;
+      if (b >= 0) { /* 0xe94e: block step - 2, filtered and with its phases known, is rotated and leaves for the rings */
+        float (*t2)[PITCH] = tf[b & 3];
+        const float (*ph)[PITCH] = phs[b & 3];
+        const uint32_t at = p.pos + (uint32_t)b * BS;
+        for (int j = 0; j < EP; j++) {
+          const int e = wl + 128 * j, cl = e >> 7, t = e & 127;
+          float x = t2[2 * cl][t], y = t2[2 * cl + 1][t];
+          rotate_sample(p.sine, ph[cl][t], x, y);
+          if (c0 + cl < p.n_channels) {
+            const size_t o = (size_t)(c0 + cl) * p.ring_size + ((at + (uint32_t)t) & m);
+            p.ring_i[o] = x; p.ring_q[o] = y;
+          }
+        }
+      }
+    } else {
+      const int b = step - 1;
+      if (b >= 0 && b < p.n_blocks) {
+        if (wave == 0) cascade_row(pre, tf[b & 3][row], sct);
+        else if (ser) phase_row(nco, nco_inc, phs[b & 3][sc]);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && c0 + (row >> 1) < p.n_channels) pre.store(p.st + (size_t)rch * NF + ST_PRE + 16 * (row & 1) + 4 * sct);
+  if (ser && c0 + sc < p.n_channels) p.st[(size_t)sch * NF + ST_NCO] = nco;
+}
+
 /* ---- 0xea7e: I delayed by 128, Q through the 257-tap Hilbert transformer (odd taps, antisymmetric), side band by sign --- */
 __global__ __launch_bounds__(256) void rdsp_engine_hilbert_kernel(const EngParams p) {
   __shared__ float q[512];
@@ -558,6 +620,92 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
       for (int i = 0; i < 256; i++) a[i] = line[i][sc];
       for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][sc];
     }
+  }
+}
+
+/* The tail stage without the ALS filter as a pipeline of waves (see rdsp_engine_front_pipe_kernel): waves 2 and 3 bring
+ * block s in and send block s - 3 out (gain by the curve, clamp, pack), wave 0 runs the audio cascade of block s - 1,
+ * wave 1 the AGC's envelope of block s - 2. */
+__global__ __launch_bounds__(FW) void rdsp_engine_tail_pipe_kernel(const EngParams p) {
+  constexpr int TCH = 8;
+  __shared__ float ta[4][TCH][PITCH];
+  __shared__ float ge[4][TCH][PITCH];
+  __shared__ float g_in[4][TCH];
+  __shared__ float curve[130];
+  const int tid = threadIdx.x, wave = tid >> 6, c0 = blockIdx.x * TCH;
+  const int row = (tid >> 2) & (TCH - 1), sct = tid & 3;
+  const bool casc = wave == 0 && tid < 4 * TCH;
+  const int rch = min(c0 + row, p.n_channels - 1);
+  Section aud;
+  aud.load(p.sets + 20 * p.audio_set + 5 * sct, p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct, (p.resets & RESET_AUDIO) != 0);
+  const int sc = tid & (TCH - 1);
+  const bool ser = wave == 1 && (tid & 63) < TCH;
+  const int sch = min(c0 + sc, p.n_channels - 1);
+  float *sst = p.st + (size_t)sch * NF;
+  float env = sst[ST_AGC_ENV], g = sst[ST_AGC_GAIN];
+  int hang = __float_as_int(sst[ST_AGC_HANG]), active = __float_as_int(sst[ST_AGC_ACTIVE]);
+  for (int i = tid; i < 130; i += FW) curve[i] = p.curve[i];
+  const int wl = tid - 128;
+  constexpr int EP = TCH * BS / 128;
+  __syncthreads();
+  for (int step = 0; step < p.n_blocks + 3; step++) {
+    if (wave >= 2) {
+      if (step < p.n_blocks) {
+        float (*t0)[PITCH] = ta[step & 3];
+        for (int j = 0; j < EP; j++) {
+          const int e = wl + 128 * j, r = e >> 7, t = e & 127;
+          t0[r][t] = c0 + r < p.n_channels ? p.audio[(size_t)(c0 + r) * p.audio_stride + (size_t)step * BS + t] : 0.0f;
+        }
+      }
+      const int b = step - 3;
+      if (b >= 0) { /* gain, clamp (0xdc10), then 0xebfa: x output gain x 32767 toward zero, the low half-word, on both outputs */
+        const float (*t3)[PITCH] = ta[b & 3];
+        const float (*e3)[PITCH] = ge[b & 3];
+        for (int j = 0; j < EP; j++) {
+          const int e = wl + 128 * j, r = e >> 7, t = e & 127;
+          float y = t3[r][t];
+          if (p.agc_on) {
+            const float le = e3[r][t];
+            const float gg = le < 0.0f ? g_in[b & 3][r] : agc_lookup(curve, le);
+            y = (gg * p.agc_makeup) * y;
+            if (y > 1.0f) y = 1.0f;
+            else if (y < -1.0f) y = -1.0f;
+          }
+          const uint32_t v = p.mute ? 0u : ((uint32_t)trunc_s32((double)(y * p.output_gain) * 32767.0) & 0xffffu);
+          if (c0 + r < p.n_channels) p.out[(size_t)(c0 + r) * p.out_stride + (size_t)b * BS + t] = (int32_t)(v | (v << 16));
+        }
+      }
+    } else if (wave == 0) {
+      const int b = step - 1;
+      if (casc && p.audio_on && b >= 0 && b < p.n_blocks) cascade_row(aud, ta[b & 3][row], sct);
+    } else {
+      const int b = step - 2;
+      if (ser && p.agc_on && b >= 0 && b < p.n_blocks) {
+        g_in[b & 3][sc] = g;
+        float last = -1.0f;                      /* the envelope the current gain was looked up from; < 0: none in this block yet */
+        const float *a = ta[b & 3][sc];
+        float *lo = ge[b & 3][sc];
+        float anext = a[0];
+        for (int t = 0; t < BS; t++) {
+          float in = fabsf(anext);
+          anext = a[t + 1 < BS ? t + 1 : BS - 1];
+          if (in > 1.0f) in = 1.0f;
+          const bool attack = env < in, decay = !attack && hang == 0;
+          const float ea = fmaf(env, p.agc_attack_a, in * p.agc_attack_b), ed = fmaf(env, p.agc_decay_a, in * p.agc_decay_b);
+          env = attack ? ea : (decay ? ed : env);
+          hang = attack ? p.agc_hang_time : (decay ? 0 : hang - 1);
+          last = (attack || decay) ? env : last;
+          lo[t] = last;
+        }
+        if (last >= 0.0f) g = agc_lookup(curve, last);
+        active = (double)g < 0.98999999999999999;
+      }
+    }
+    __syncthreads();
+  }
+  if (casc && c0 + row < p.n_channels) aud.store(p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct);
+  if (ser && c0 + sc < p.n_channels) {
+    sst[ST_AGC_ENV] = env; sst[ST_AGC_GAIN] = g; sst[ST_AGC_HANG] = __int_as_float(hang); sst[ST_AGC_ACTIVE] = __int_as_float(active);
   }
 }
 
@@ -848,6 +996,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   const int tch = e->als_on ? 16 : 8;
   const dim3 gf((unsigned)((e->n_channels + FCH - 1) / FCH)), gt((unsigned)((e->n_channels + tch - 1) / tch));
   if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
+  else if (ssb) hipLaunchKernelGGL(rdsp_engine_front_pipe_kernel, gf, dim3(FW), 0, s, p);
   else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
   if (ssb) {
     const dim3 gh((unsigned)((n_blocks * BS + 255) / 256), (unsigned)e->n_channels);
@@ -855,7 +1004,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   } else if (!known) { /* a mode number the engine does not know leaves its audio buffer as it was: the last call's */
   }
   if (e->als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(FW), 0, s, p);
-  else hipLaunchKernelGGL(rdsp_engine_tail_kernel<false>, gt, dim3(FW), 0, s, p);
+  else hipLaunchKernelGGL(rdsp_engine_tail_pipe_kernel, gt, dim3(FW), 0, s, p);
   err = hipGetLastError();
   if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
   if (ssb) e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1); /* the lines only move when the SSB / CW path runs */
