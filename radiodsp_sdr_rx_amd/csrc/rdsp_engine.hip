@@ -146,7 +146,8 @@ struct Osc { /* one step of the frequency shifter's phase (0xe94e / 0xd600): cos
   }
 };
 __device__ __forceinline__ float dpp_up1(float v) { /* lane s of a quad takes lane s - 1's value: quad_perm [0,0,1,2] */
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x90, 0xF, 0xF, false));
+  const int w = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(w, w, 0x90, 0xF, 0xF, false)); /* every lane has a source: `old` is never kept */
 }
 __device__ __forceinline__ float quick_root_guess(float p) { return __uint_as_float((__float_as_uint(p) >> 1) + 0x1fa00000u + 0x1b4000u + 3886u); }
 __device__ __forceinline__ float quick_sqrt1(float p) { const float g = quick_root_guess(p); return (p / g + g) * 0.5f; }
@@ -175,6 +176,8 @@ struct Section {
   __device__ __forceinline__ void commit(float x, float y) { x2 = x1; x1 = x; y2 = y1; y1 = y; }
 };
 /* one block of one tile row through the cascade, in place; called by all four lanes of the row's quad */
+/* LEAN: the form for the kernels that carry blanker / detector code beside it (fewer registers: two workgroups per CU) */
+template <bool LEAN = false>
 __device__ __forceinline__ void cascade_row(Section &sec, float *row, int s) {
   float yprev = 0.0f, xnext = row[0];
 #pragma unroll 4
@@ -186,21 +189,27 @@ __device__ __forceinline__ void cascade_row(Section &sec, float *row, int s) {
                                                * (the row is also written below, so the compiler will not move the read itself) */
     const float x = s == 0 ? xin : up;
     const float y = sec.eval(x);
-    if (n >= 0 && n < BS) {
+    const bool live = n >= 0 && n < BS;
+    if (live) {
       sec.commit(x, y);
       yprev = y;
-      if (s == 3) row[n] = y;
+    }
+    if constexpr (LEAN) {
+      if (live && s == 3) row[n] = y;
+    } else {
+      row[(live && s == 3) ? n : BS] = y; /* the last section's lane writes the sample; every other lane the row's spare word */
     }
   }
 }
 /* the oscillator in two passes: the phase recursion alone (one lane per channel: a float add and the wrap), then cosine,
  * sine and the complex product for every sample of the tile in parallel -- they are pure functions of the phase */
 __device__ __forceinline__ void phase_row(float &ph, float inc, float *out) {
-  for (int t = 0; t < BS; t++) {
+  for (int t = 0; t < BS; t++) { /* both wrapped candidates are formed and one value selected: as branches the three cases cost
+                                  * the lone wave more instructions (exec-mask bookkeeping) than the arithmetic */
     out[t] = ph;
     ph = ph + inc;
-    if (ph > TWO_PI_F) ph -= TWO_PI_F;
-    else if (ph < 0.0f) ph += TWO_PI_F;
+    const float down = ph - TWO_PI_F, up = ph + TWO_PI_F;
+    ph = ph > TWO_PI_F ? down : (ph < 0.0f ? up : ph);
   }
 }
 __device__ __forceinline__ void rotate_sample(const float *sine, float ph, float &x, float &y) {
@@ -232,7 +241,7 @@ __device__ __forceinline__ double over_32767(int v) {
  * oscillator's phase, one lane per channel; the PLL and the blanker -- true recursions -- on one lane per channel or row. */
 constexpr int FW = 256, FCH = 8;
 template <bool NB>
-__global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p) {
+__global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParams p) {
   __shared__ float tf[2 * FCH][PITCH];
   __shared__ float phs[FCH][PITCH];
   __shared__ int locked_of[FCH];
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
       }
       __syncthreads();
     }
-    if (casc) cascade_row(pre, tf[row], sct);
+    if (casc) cascade_row<true>(pre, tf[row], sct);
     else if (ser && ssb) phase_row(nco, nco_inc, phs[sc]);       /* 0xe94e: the phase falls by the tuning offset */
     __syncthreads();
     if (ssb) {
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
           ((r & 1) ? p.ring_q : p.ring_i)[(size_t)(c0 + (r >> 1)) * p.ring_size + ((at + (uint32_t)t) & m)] = tf[r][t];
       }
     } else if (am) {
-      if (casc) cascade_row(pre, tf[row], sct);                  /* 0xec1c: the IF filter a second time */
+      if (casc) cascade_row<true>(pre, tf[row], sct);                  /* 0xec1c: the IF filter a second time */
       __syncthreads();
       if (p.mode == 5) { /* 0xe390: PLL on the IF signal, one lane per channel */
         if (ser) {
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
       if (casc) {
         const bool detect = !locked_of[row >> 1];
         const Section keep = amf;
-        cascade_row(amf, detect ? tf[row] : phs[row >> 1], sct);   /* the quads of a locked channel run on a row nobody reads ... */
+        cascade_row<true>(amf, detect ? tf[row] : phs[row >> 1], sct);   /* the quads of a locked channel run on a row nobody reads ... */
         if (!detect) amf = keep;                                 /* ... and keep their state */
       }
       __syncthreads();
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(FW) void rdsp_engine_front_kernel(const EngParams p
  * out of slot (s - 2) & 3, wave 0 runs the cascades of block s - 1, wave 1 the oscillator's phase of block s - 1; one
  * barrier per step.  A step then lasts as long as its longest pass (the cascade: 131 dependent steps), and the arithmetic
  * of every sample is what it was. */
-__global__ __launch_bounds__(FW) void rdsp_engine_front_pipe_kernel(const EngParams p) {
+__global__ __launch_bounds__(FW, 2) void rdsp_engine_front_pipe_kernel(const EngParams p) {
   __shared__ float tf[4][2 * FCH][PITCH];
   __shared__ float phs[4][FCH][PITCH];
   const int tid = threadIdx.x, wave = tid >> 6, c0 = blockIdx.x * FCH;
@@ -510,7 +519,7 @@ __device__ __forceinline__ float agc_lookup(const float *curve, float env) {
  * envelope value its gain is looked up from (or "none yet": the gain carried in); gain, clamp and pack are then pure
  * functions and run on all lanes. */
 template <bool ALS>
-__global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p) {
+__global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_kernel(const EngParams p) {
   constexpr int TCH = ALS ? 16 : 8; /* channels per workgroup (measured: 8 is 12 % faster than 16 without the ALS filter, half as fast with it) */
   __shared__ float ta[TCH][PITCH];
   __shared__ float ge[TCH][PITCH];
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
     }
     __syncthreads();
     if (p.audio_on) {
-      if (casc) cascade_row(aud, ta[row], sct);
+      if (casc) cascade_row<true>(aud, ta[row], sct);
       __syncthreads();
     }
     if (p.agc_on) {
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(FW) void rdsp_engine_tail_kernel(const EngParams p)
 /* The tail stage without the ALS filter as a pipeline of waves (see rdsp_engine_front_pipe_kernel): waves 2 and 3 bring
  * block s in and send block s - 3 out (gain by the curve, clamp, pack), wave 0 runs the audio cascade of block s - 1,
  * wave 1 the AGC's envelope of block s - 2. */
-__global__ __launch_bounds__(FW) void rdsp_engine_tail_pipe_kernel(const EngParams p) {
+__global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_pipe_kernel(const EngParams p) {
   constexpr int TCH = 8;
   __shared__ float ta[4][TCH][PITCH];
   __shared__ float ge[4][TCH][PITCH];
