@@ -483,25 +483,71 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_pipe_kernel(const Eng
   if (ser && c0 + sc < p.n_channels) p.st[(size_t)sch * NF + ST_NCO] = nco;
 }
 
-/* ---- 0xea7e: I delayed by 128, Q through the 257-tap Hilbert transformer (odd taps, antisymmetric), side band by sign --- */
+/* ---- 0xea7e: I delayed by 128, Q through the 257-tap Hilbert transformer (odd taps, antisymmetric), side band by sign ---
+ * out[t] = sum_k h[k] (q[t - 1 - 2k] - q[t - 255 + 2k]), k = 0 .. 63 in this order, one fused multiply-add each.  An output
+ * only meets samples of the other parity, and the outputs t, t + 2, ... meet the same ones shifted by a tap: a lane takes
+ * EIGHT outputs of one parity (t = 2 (8 l + j) + p), keeps the two sliding windows in registers, and reads 142 words of
+ * LDS for them instead of 1024.  The window of the ring sits in LDS split by parity, index m at m + m / 8: lanes are 8
+ * indices apart, so their reads fall 9 words apart (no bank conflicts) and every offset is an immediate.  The delayed I
+ * samples come in, and the audio leaves, through a row at pitch 17 for 16 (coalesced 256-byte segments in HBM). */
+constexpr int HB_OUT = 2048;                      /* outputs per workgroup */
+constexpr int HB_M = (HB_OUT + 256) / 2;          /* samples per parity in the window */
+template <int P>
+__device__ __forceinline__ void hilbert_eight(const float *par, const float *h, float (&acc)[8]) {
+  /* par: the parity array this lane's outputs read (the other parity), already offset by 9 l; P: the outputs' parity */
+  float U[8], L[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int ru = j + 127 + P, rl = j + P;
+    U[j] = par[ru + (ru >> 3)];
+    L[j] = par[rl + (rl >> 3)];
+    acc[j] = 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    const float hk = h[k];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = fmaf(hk, U[j] - L[j], acc[j]);
+    if (k < 63) { /* tap k + 1: the upper window moves one index down, the lower one up */
+#pragma unroll
+      for (int j = 7; j > 0; j--) U[j] = U[j - 1];
+#pragma unroll
+      for (int j = 0; j < 7; j++) L[j] = L[j + 1];
+      const int ru = 127 + P - (k + 1), rl = 7 + P + (k + 1);
+      U[0] = par[ru + (ru >> 3)];
+      L[7] = par[rl + (rl >> 3)];
+    }
+  }
+}
 __global__ __launch_bounds__(256) void rdsp_engine_hilbert_kernel(const EngParams p) {
-  __shared__ float q[512];
+  __shared__ float par[2][HB_M + HB_M / 8];
+  __shared__ float row[HB_OUT + HB_OUT / 16];
   __shared__ float h[64];
   const int tid = threadIdx.x, ch = blockIdx.y;
-  const uint32_t t0 = blockIdx.x * 256u, m = p.ring_size - 1;
+  const uint32_t t0 = blockIdx.x * (uint32_t)HB_OUT, m = p.ring_size - 1, n = (uint32_t)p.n_blocks * BS;
   const float *rq = p.ring_q + (size_t)ch * p.ring_size, *ri = p.ring_i + (size_t)ch * p.ring_size;
-  q[tid] = rq[(p.pos + t0 - 256u + (uint32_t)tid) & m];        /* q[j] = sample t0 - 256 + j */
-  q[tid + 256] = rq[(p.pos + t0 + (uint32_t)tid) & m];
+  for (int i = tid; i < HB_OUT + 256; i += 256) { /* window sample i = t0 - 256 + i, by parity */
+    const int mm = i >> 1;
+    par[i & 1][mm + (mm >> 3)] = rq[(p.pos + t0 - 256u + (uint32_t)i) & m];
+  }
+  for (int i = tid; i < HB_OUT; i += 256) row[i + (i >> 4)] = ri[(p.pos + t0 + (uint32_t)i - 128u) & m];
   if (tid < 64) h[tid] = p.hilbert[tid];
   __syncthreads();
-  const uint32_t t = t0 + (uint32_t)tid;
-  if (t >= (uint32_t)p.n_blocks * BS) return;
-  float acc = 0.0f;
-#pragma unroll 8
-  for (int k = 0; k < 64; k++) acc = fmaf(h[k], q[tid + 255 - 2 * k] - q[tid + 1 + 2 * k], acc);
-  const float i = ri[(p.pos + t - 128u) & m];
+  const int P = tid >> 7, lp = tid & 127;             /* waves 0, 1: the even outputs; waves 2, 3: the odd ones */
+  float acc[8];
+  /* output o = 2 (8 lp + j) + P reads the window at i = o + 255 - 2k and o + 1 + 2k: parity 1 - P, indices
+   * 8 lp + j + 127 + P - k and 8 lp + j + P + k */
+  if (P == 0) hilbert_eight<0>(par[1] + 9 * lp, h, acc);
+  else hilbert_eight<1>(par[0] + 9 * lp, h, acc);
   const bool minus = p.mode == 6 || (p.mode & ~2) == 1;
-  p.audio[(size_t)ch * p.audio_stride + t] = minus ? i - acc : i + acc;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float *slot = &row[17 * lp + 2 * j + P];          /* o + o / 16 with o = 16 lp + 2 j + P */
+    *slot = minus ? *slot - acc[j] : *slot + acc[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < HB_OUT; i += 256)
+    if (t0 + (uint32_t)i < n) p.audio[(size_t)ch * p.audio_stride + t0 + (uint32_t)i] = row[i + (i >> 4)];
 }
 
 /* ---- tail: audio band-pass (0xd944), AGC (0xdb58), ALS (0xda24), output (0xebfa) ------------------------------------- */
@@ -1008,7 +1054,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   else if (ssb) hipLaunchKernelGGL(rdsp_engine_front_pipe_kernel, gf, dim3(FW), 0, s, p);
   else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
   if (ssb) {
-    const dim3 gh((unsigned)((n_blocks * BS + 255) / 256), (unsigned)e->n_channels);
+    const dim3 gh((unsigned)((n_blocks * BS + HB_OUT - 1) / HB_OUT), (unsigned)e->n_channels);
     hipLaunchKernelGGL(rdsp_engine_hilbert_kernel, gh, dim3(256), 0, s, p);
   } else if (!known) { /* a mode number the engine does not know leaves its audio buffer as it was: the last call's */
   }
