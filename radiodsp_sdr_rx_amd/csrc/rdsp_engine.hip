@@ -571,9 +571,14 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_kernel(const EngParams
   __shared__ float ge[TCH][PITCH];
   __shared__ float curve[130];
   __shared__ float g_in[TCH];
-  __shared__ float line[ALS ? 256 : 1][TCH];
-  __shared__ float wt[ALS ? ALS_TAPS : 1][TCH];
+  constexpr int LP = 260;                 /* pitch of a channel's 256-sample ALS line */
+  __shared__ float line[ALS ? TCH : 1][ALS ? LP : 1];
   const int tid = threadIdx.x, c0 = blockIdx.x * TCH;
+  /* ALS role: wave 1 as 16 quads, quad ac on channel c0 + ac; its lane aq works on every fourth sample */
+  const bool als_lane = ALS && (tid >> 6) == 1;
+  const int ac = (tid >> 2) & (TCH - 1), aq = tid & 3;
+  const int ach = min(c0 + ac, p.n_channels - 1);
+  float w[ALS ? ALS_TAPS : 1];
   const bool casc = tid < 4 * TCH;
   const int row = (tid >> 2) & (TCH - 1), sct = tid & 3;
   const int rch = min(c0 + row, p.n_channels - 1);
@@ -588,11 +593,12 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_kernel(const EngParams
   int hang = __float_as_int(sst[ST_AGC_HANG]), active = __float_as_int(sst[ST_AGC_ACTIVE]);
   for (int i = tid; i < 130; i += FW) curve[i] = p.curve[i];
   if constexpr (ALS) {
-    if (ser) {
-      const float *a = p.als + (size_t)sch * ALS_WORDS;
+    if (als_lane) {
+      const float *a = p.als + (size_t)ach * ALS_WORDS;
       const bool clear = (p.resets & RESET_ALS) != 0;
-      for (int i = 0; i < 256; i++) line[i][sc] = clear ? 0.0f : a[i];
-      for (int k = 0; k < ALS_TAPS; k++) wt[k][sc] = clear ? 0.0f : a[256 + k];
+      for (int i = aq; i < 256; i += 4) line[ac][i] = clear ? 0.0f : a[i];
+#pragma unroll
+      for (int k = 0; k < ALS_TAPS; k++) w[k] = clear ? 0.0f : a[256 + k];
     }
   }
   constexpr int EP = TCH * BS / FW;
@@ -642,21 +648,30 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_kernel(const EngParams
       }
       __syncthreads();
     }
-    if constexpr (ALS) { /* y = w . x delayed; the taps move on every fourth sample of a block by mu e x (plain LMS) */
-      if (ser) {
-        float *rowp = ta[sc];
-        for (int i = 0; i < 128; i++) { line[i][sc] = line[i + 128][sc]; line[i + 128][sc] = rowp[i]; }
-        int cnt = 0;
-        for (int n = 128; n < 256; n++) {
+    if constexpr (ALS) {
+      /* 0xda24: y[n] = sum_k w_k x[n - 3 - k] as a chain of 55 fused multiply-adds, e = x[n] - y; on every fourth sample of a
+       * block (its first one included) the taps move by w_k += (e x[n - 3 - k]) / 2.  The chain of one sample cannot be cut,
+       * but the four samples between two tap moves see the same taps: the four lanes of a quad take one each (the taps in
+       * registers, the same in all four), then every lane makes the move with the fourth lane's error.  Quads of four
+       * samples ending on a move: {125 .. 128} (only 128 is this block's), {129 .. 132}, ..., {253 .. 256} (256 is the next
+       * block's first: not computed here, no move). */
+      if (als_lane) {
+        float *x = line[ac], *rowp = ta[ac];
+        for (int i = aq; i < 128; i += 4) { x[i] = x[i + 128]; x[i + 128] = rowp[i]; }
+        wg_sync<1>();
+        for (int g = -1; g < 32; g++) {
+          const int n = 129 + 4 * g + aq;
           float y = 0.0f;
-          for (int k = 0; k < ALS_TAPS; k++) y = fmaf(wt[k][sc], line[n - ALS_DELAY - k][sc], y);
-          const float err = line[n][sc] - y;
-          if (p.als_adaptive) {
-            if (cnt == 0)
-              for (int k = 0; k < ALS_TAPS; k++) wt[k][sc] = fmaf(err * line[n - ALS_DELAY - k][sc], 0.5f, wt[k][sc]);
-            cnt = (cnt + 1) & 3;
+#pragma unroll
+          for (int k = 0; k < ALS_TAPS; k++) y = fmaf(w[k], x[n - ALS_DELAY - k], y);
+          const float err = x[n < 256 ? n : 255] - y;
+          if (n >= 128 && n < 256) rowp[n - 128] = p.als_notch ? err : y;
+          if (p.als_adaptive && g < 31) {
+            const float e3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, err), 0xFF, 0xF, 0xF, false)); /* quad_perm [3,3,3,3] */
+            const float *xm = x + (132 + 4 * g) - ALS_DELAY;
+#pragma unroll
+            for (int k = 0; k < ALS_TAPS; k++) w[k] = fmaf(e3 * xm[-k], 0.5f, w[k]);
           }
-          rowp[n - 128] = p.als_notch ? err : y;
         }
       }
       __syncthreads();
@@ -670,10 +685,15 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_kernel(const EngParams
   if (casc && c0 + row < p.n_channels) aud.store(p.st + (size_t)rch * NF + ST_AUDIO + 4 * sct);
   if (ser_valid) {
     sst[ST_AGC_ENV] = env; sst[ST_AGC_GAIN] = g; sst[ST_AGC_HANG] = __int_as_float(hang); sst[ST_AGC_ACTIVE] = __int_as_float(active);
-    if constexpr (ALS) {
-      float *a = p.als + (size_t)sch * ALS_WORDS;
-      for (int i = 0; i < 256; i++) a[i] = line[i][sc];
-      for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = wt[k][sc];
+  }
+  if constexpr (ALS) {
+    if (als_lane && c0 + ac < p.n_channels) {
+      float *a = p.als + (size_t)ach * ALS_WORDS;
+      for (int i = aq; i < 256; i += 4) a[i] = line[ac][i];
+      if (aq == 0) {
+#pragma unroll
+        for (int k = 0; k < ALS_TAPS; k++) a[256 + k] = w[k];
+      }
     }
   }
 }
