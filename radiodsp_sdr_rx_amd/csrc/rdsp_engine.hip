@@ -13,18 +13,26 @@
  * envelope; SAM: a PLL on the IF signal with the envelope detector as its out-of-lock fallback) -> audio band-pass
  * -> hang AGC (peak envelope, gain by a curve) -> ALS line enhancer (delayed-input LMS) -> x output gain x 32767.
  *
- * Mapping to the machine (every stage but the Hilbert transformer is a recursion in time, so the parallel axes are
- * channels, rails and -- for the transformer -- samples):
- *   rdsp_engine_front_kernel   one lane per (channel, rail), 32 channels per one-wave workgroup.  int16 IQ rows come in
- *                              through an LDS tile (coalesced 256-byte row segments; a lane then walks its row at a
- *                              129-word pitch, conflict-free), the two lanes of a channel trade samples through the
- *                              tile, results leave the same way into a per-channel ring in HBM.
- *   rdsp_engine_hilbert_kernel one lane per output sample: 64 fused multiply-adds on an LDS window of the ring,
- *                              in the image's tap order.
- *   rdsp_engine_tail_kernel    one lane per channel, 64 per workgroup: audio cascade, AGC, ALS, pack; rows through LDS.
- * The three launches of a call are stream-ordered; a call takes any number of 128-sample blocks up to the engine's
- * max_blocks_per_call.  HBM traffic is 8 B per sample of algorithm (int16 IQ in, int16 L = R out) plus 28 B of float
- * intermediates (the ring and the audio row): the path is bound by the latency of its recursions, not by bandwidth.
+ * Mapping to the machine.  Every stage but the Hilbert transformer is a recursion in time that has to be evaluated in the
+ * image's order, so the parallel axes are channels, rails and -- for the transformer -- samples; and a lone wave issues an
+ * instruction every five cycles or so whatever it depends on, so a launch lasts as long as ONE workgroup's chain of
+ * instructions per block, times the blocks.  Hence: few channels per workgroup (8), the sections of a cascade on the four
+ * lanes of a quad (sample n enters section s at step n + s), everything that is a pure function of a recursion's state
+ * (table look-ups, gain curve, conversions, pack) spread over all lanes behind a recursion reduced to its few dependent
+ * operations, and the passes of a block on different waves, each a block behind the previous one's:
+ *   rdsp_engine_front_pipe_kernel  SSB / CW, no blanker: waves 2 + 3 convert block s and rotate / store block s - 2, wave 0
+ *                              runs the IF cascades of block s - 1 (16 rows x 4 sections), wave 1 the oscillator's phase
+ *   rdsp_engine_front_kernel   blanker, AM, SAM: the same passes one after the other (the PLL and the blanker's running
+ *                              average are long recursions of their own)
+ *   rdsp_engine_hilbert_kernel eight outputs of one parity per lane, sliding windows in registers, LDS split by parity
+ *   rdsp_engine_tail_pipe_kernel   waves 2 + 3 load block s and finish block s - 3 (gain by the curve, clamp, pack), wave 0
+ *                              the audio cascade of block s - 1, wave 1 the AGC envelope of block s - 2
+ *   rdsp_engine_tail_kernel    with the ALS filter: its 55-tap chain on the lanes of a quad (the four samples between two
+ *                              tap moves), taps in registers
+ * int16 rows enter and leave in coalesced 256-byte segments through LDS tiles at a 129-word pitch.  The three launches of a
+ * call are stream-ordered; a call takes any number of 128-sample blocks up to the engine's max_blocks_per_call.  HBM
+ * traffic is 8 B per sample of algorithm (int16 IQ in, int16 L = R out) plus 28 B of float intermediates (the ring and the
+ * audio row): the path is bound by the latency of its recursions, not by bandwidth.
  *
  * Three of the engine's tables have no closed form (fifteen sets of four biquad sections, 64 Hilbert taps): the host
  * loads them (rdsp_engine_load_tables; tests take them from tests/golden/firmware_tables.npz); update() refuses to run
@@ -55,7 +63,7 @@ enum { ST_PRE = 0, ST_AM = 32, ST_AUDIO = 64, ST_NCO = 80, ST_AMPH, ST_SAM_COS, 
 enum { RESET_PRE = 1, RESET_AUDIO = 2, RESET_ALS = 4 };
 constexpr int ALS_TAPS = 55, ALS_DELAY = 3, ALS_WPITCH = 64; /* the constructor's values; the image has no setter for them */
 constexpr int ALS_WORDS = 256 + ALS_WPITCH;                /* per channel in HBM: the 256-sample line, then the taps */
-constexpr int NB_WORDS = 2 * 3 * 384;                      /* per channel and lane: I line, Q line, mask */
+constexpr int NB_WORDS = 3 * 384;                          /* per channel: I line, Q line, mask */
 
 struct EngParams {
   const int32_t *iq; size_t in_stride;   /* [ch][t] words: I | Q << 16 */
@@ -81,36 +89,6 @@ __device__ __forceinline__ int trunc_s32(double x) { /* VCVT.S32.F64 */
   return (int)x;
 }
 
-/* arm_biquad_cascade_df1_f32 for one sample through four sections held in registers: products rounded, summed left to right */
-struct Cascade {
-  float c[20], s[16];
-  __device__ __forceinline__ void load(const float *coef, const float *state, bool clear) {
-#pragma unroll
-    for (int i = 0; i < 20; i++) c[i] = coef[i];
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = clear ? 0.0f : state[i];
-  }
-  __device__ __forceinline__ void store(float *state) const {
-#pragma unroll
-    for (int i = 0; i < 16; i++) state[i] = s[i];
-  }
-  __device__ __forceinline__ float run(float v) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float *cf = c + 5 * k;
-      float *st = s + 4 * k; /* x1 x2 y1 y2 */
-      float y = cf[0] * v;
-      y = y + cf[1] * st[0];
-      y = y + cf[2] * st[1];
-      y = y + cf[3] * st[2];
-      y = y + cf[4] * st[3];
-      st[1] = st[0]; st[0] = v; st[3] = st[2]; st[2] = y;
-      v = y;
-    }
-    return v;
-  }
-};
-
 /* the oscillator: sin of a phase in [0, 2 pi) by linear interpolation in the 256-step table, through double as the image does */
 /* trunc(RN(a / d)) for a >= 0 and d = the double of the image's 2 pi, without the division: k d is exact for k < 2^16 (a
  * 24-bit d), so floor(a / d) follows from two exact comparisons around the estimate a (1 / d); and the correctly rounded
@@ -130,21 +108,6 @@ __device__ __forceinline__ float table_sin(const float *sine, float ph) {
   const float t0 = sine[hi], t1 = sine[hi + 1];
   return (float)fma((double)((t1 - t0) * lo), 0.00390625, (double)t0);
 }
-struct Osc { /* one step of the frequency shifter's phase (0xe94e / 0xd600): cos, sin of the current phase, then advance */
-  float ph;
-  __device__ __forceinline__ void step(const float *sine, float inc, float &c, float &s) {
-    float pc = (float)((double)ph + 1.5707963267948966);
-    if (pc >= TWO_PI_F) pc -= TWO_PI_F;
-    if (pc < 0.0f) pc += TWO_PI_F;
-    c = table_sin(sine, pc);
-    float ps = ph >= TWO_PI_F ? ph - TWO_PI_F : ph;
-    ph = ph + inc;
-    if (ps < 0.0f) ps += TWO_PI_F;
-    s = table_sin(sine, ps);
-    if (ph > TWO_PI_F) ph -= TWO_PI_F;
-    else if (ph < 0.0f) ph += TWO_PI_F;
-  }
-};
 __device__ __forceinline__ float dpp_up1(float v) { /* lane s of a quad takes lane s - 1's value: quad_perm [0,0,1,2] */
   const int w = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(w, w, 0x90, 0xF, 0xF, false)); /* every lane has a source: `old` is never kept */
@@ -264,11 +227,22 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
   float sam_c = sst[ST_SAM_COS], sam_s = sst[ST_SAM_SIN], sam_u = sst[ST_SAM_U], sam_err = sst[ST_SAM_ERR], sam_hz = sst[ST_SAM_HZ],
         sam_ph = sst[ST_SAM_PH];
   int sam_locked = __float_as_int(sst[ST_SAM_LOCK]);
-  /* blanker role: lane tid < 32 owns tile row tid */
-  const int bch = min(c0 + ((tid & 31) >> 1), p.n_channels - 1);
-  const bool bl_valid = tid < 2 * FCH && c0 + (tid >> 1) < p.n_channels;
-  float nb_avg = p.st[(size_t)bch * NF + ST_NB_AVG], nb_last = p.st[(size_t)bch * NF + ST_NB_LAST];
-  int nb_hit = __float_as_int(p.st[(size_t)bch * NF + ST_NB_HIT]);
+  /* the blanker's lines: three blocks of I, Q and mask per channel in LDS, slot (n / 128 + nb_base) % 3 holding samples
+   * n .. n + 127 of the 384-sample line, so that a block boundary moves a base instead of 768 words */
+  constexpr int NBP = NB ? 388 : 1;
+  __shared__ float nbl[NB ? 3 : 1][NB ? FCH : 1][NBP];
+  __shared__ float nbmag[NB ? FCH : 1][NB ? 180 : 1];
+  int nb_base = 0;
+  auto nbx = [&](int n) { int sl = (n >> 7) + nb_base; sl = sl >= 3 ? sl - 3 : sl; return sl * 128 + (n & 127); };
+  float nb_avg = sst[ST_NB_AVG], nb_last = sst[ST_NB_LAST];
+  int nb_hit = __float_as_int(sst[ST_NB_HIT]);
+  if constexpr (NB) {
+    for (int e = tid; e < 3 * FCH * 384; e += FW) { /* HBM keeps them in line order: I, Q, mask */
+      const int k = e / (FCH * 384), r = e - k * (FCH * 384), cl = r / 384, i = r - cl * 384;
+      nbl[k][cl][i] = c0 + cl < p.n_channels ? p.nb[(size_t)(c0 + cl) * NB_WORDS + 384 * k + i] : (k == 2 ? 1.0f : 0.0f);
+    }
+    __syncthreads();
+  }
   const float nco_inc = -(p.tuning_offset * RAD_PER_HZ), am_inc = -p.if_centre * RAD_PER_HZ;
   constexpr int EP = FCH * BS / FW; /* elements (int16 pairs, complex samples) per lane and pass */
 
@@ -280,35 +254,46 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
       tf[2 * cl + 1][t] = (float)(over_32767(w >> 16) * (double)p.gain_q);
     }
     __syncthreads();
-    if constexpr (NB) { /* 0xe14c: two blocks of delay; |I + jQ| against its running average; blanking mask with a taper.
-                         * Each row's lane keeps its own copy of both rails' lines and of the mask in HBM */
-      if (tid < 2 * FCH) {
-        const int rail = tid & 1;
-        float *li = p.nb + ((size_t)(bl_valid ? bch : p.n_channels) * 2 + rail) * (NB_WORDS / 2), *lq = li + 384, *mask = li + 768; /* rows past the last channel share a spare slot */
-        float *mine = tf[tid];
-        const float *theirs = tf[tid ^ 1];
+    if constexpr (NB) { /* 0xe14c: two blocks of delay; |I + jQ| against its running average; blanking mask with a taper */
+      nb_base = nb_base == 2 ? 0 : nb_base + 1;                    /* the oldest block's slot takes the new one */
+      for (int j = 0; j < EP; j++) {
+        const int e = tid + FW * j, cl = e >> 7, t = e & 127, at = nbx(256 + t);
+        nbl[0][cl][at] = tf[2 * cl][t]; nbl[1][cl][at] = tf[2 * cl + 1][t]; nbl[2][cl][at] = 1.0f;
+      }
+      __syncthreads();
+      for (int e = tid; e < FCH * 178; e += FW) {                  /* the magnitudes are pure functions of the samples */
+        const int cl = e / 178, n = 78 + e - cl * 178, at = nbx(n);
+        const float vi = nbl[0][cl][at], vq = nbl[1][cl][at];
+        nbmag[cl][n - 78] = quick_sqrt1(fmaf(vi, vi, vq * vq));
+      }
+      __syncthreads();
+      if (ser) { /* what is a recursion: the running average and what it decides, then the taper in front of every 0 -> 1 step */
+        float *mask = nbl[2][sc];
         nb_hit = 0;
-        for (int i = 0; i < 256; i++) { li[i] = li[i + 128]; lq[i] = lq[i + 128]; mask[i] = mask[i + 128]; }
-        for (int i = 0; i < 128; i++) {
-          li[256 + i] = rail ? theirs[i] : mine[i]; lq[256 + i] = rail ? mine[i] : theirs[i]; mask[256 + i] = 1.0f;
-        }
+        int zeroed_to = 67;                      /* hits come in rising order: what an earlier one of this pass zeroed stays zero */
         for (int n = 78; n < 256; n++) {
           const float limit = nb_avg * p.nb_ratio;
-          const float vi = li[n], vq = lq[n];
-          nb_last = quick_sqrt1(fmaf(vi, vi, vq * vq));
+          nb_last = nbmag[sc][n - 78];
           if (limit < nb_last) {
-            if (-p.nb_before <= p.nb_after)
-              for (int j = n - p.nb_before; j <= n + p.nb_after; j++) mask[j] = 0.0f;
+            if (-p.nb_before <= p.nb_after) {
+              const int lo = max(n - p.nb_before, zeroed_to + 1), hi = n + p.nb_after;
+              for (int j = lo; j <= hi; j++) mask[nbx(j)] = 0.0f;
+              zeroed_to = max(zeroed_to, hi);
+            }
             nb_hit = 1;
           }
           nb_avg = fmaf(nb_avg, p.nb_keep, nb_last * p.nb_new);
         }
         const float taper[7] = {0.933f, 0.75f, 0.5f, 0.25f, 0.067f, 0.0f, 0.0f};
         for (int i = 128; i < 256; i++)
-          if (mask[i] == 1.0f && mask[i - 1] == 0.0f)
-            for (int j = 0; j < 7; j++) mask[i - 7 + j] = taper[j];
-        wg_sync<1>();
-        for (int i = 0; i < 128; i++) mine[i] = mask[i] * (rail ? lq[i] : li[i]);
+          if (mask[nbx(i)] == 1.0f && mask[nbx(i - 1)] == 0.0f)
+            for (int j = 0; j < 7; j++) mask[nbx(i - 7 + j)] = taper[j];
+      }
+      __syncthreads();
+      for (int j = 0; j < EP; j++) {
+        const int e = tid + FW * j, cl = e >> 7, t = e & 127, at = nbx(t);
+        const float mk = nbl[2][cl][at];
+        tf[2 * cl][t] = mk * nbl[0][cl][at]; tf[2 * cl + 1][t] = mk * nbl[1][cl][at];
       }
       __syncthreads();
     }
@@ -415,9 +400,13 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
     sst[ST_SAM_COS] = sam_c; sst[ST_SAM_SIN] = sam_s; sst[ST_SAM_U] = sam_u; sst[ST_SAM_ERR] = sam_err; sst[ST_SAM_HZ] = sam_hz;
     sst[ST_SAM_PH] = sam_ph; sst[ST_SAM_LOCK] = __int_as_float(sam_locked);
   }
-  if (NB && bl_valid && !(tid & 1)) {
-    float *bst = p.st + (size_t)bch * NF;
-    bst[ST_NB_AVG] = nb_avg; bst[ST_NB_LAST] = nb_last; bst[ST_NB_HIT] = __int_as_float(nb_hit);
+  if constexpr (NB) {
+    if (ser_valid) { sst[ST_NB_AVG] = nb_avg; sst[ST_NB_LAST] = nb_last; sst[ST_NB_HIT] = __int_as_float(nb_hit); }
+    __syncthreads();
+    for (int e = tid; e < 3 * FCH * 384; e += FW) {
+      const int k = e / (FCH * 384), r = e - k * (FCH * 384), cl = r / 384, i = r - cl * 384;
+      if (c0 + cl < p.n_channels) p.nb[(size_t)(c0 + cl) * NB_WORDS + 384 * k + i] = nbl[k][cl][nbx(i)];
+    }
   }
 }
 
@@ -954,8 +943,7 @@ int rdsp_engine_reset(rdsp_engine_t *e, void *stream) {
     st[c * NF + ST_SAM_HZ] = 1890.0f;
     st[c * NF + ST_NB_AVG] = 10.0f;
     st[c * NF + ST_AGC_ACTIVE] = bits_f(1u); /* the flag's value until the AGC first runs */
-    for (int r = 0; r < 2; r++)
-      for (int i = 0; i < 384; i++) nb[c * NB_WORDS + (size_t)r * (NB_WORDS / 2) + 768 + i] = 1.0f;
+    for (int i = 0; i < 384; i++) nb[c * NB_WORDS + 768 + i] = 1.0f;
   }
   if (err == hipSuccess) err = hipMemcpyAsync(e->d_st, st.data(), st.size() * 4, hipMemcpyHostToDevice, s);
   if (err == hipSuccess) err = hipMemcpyAsync(e->d_nb, nb.data(), nb.size() * 4, hipMemcpyHostToDevice, s);
