@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CFGS=${@:-K3 K2 K4 K5 F1}
+CFGS=${@:-K3 K2 K4 K5 F1 ENGINE}
 B="--steps 100 --warmup 20 --no-cpu-baseline --no-host-io --no-iso --no-extra-legs"
 P="--steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-timing --no-extra-legs"
 for K in $CFGS; do

@@ -23,8 +23,11 @@ def newest(pattern):
 
 
 def short(name):
-    if "rdsp_tail" in name:
+    if "rdsp_tail" in name and "engine" not in name:
         return "rdsp_tail_kernel"
+    for k in ("rdsp_engine_front_pipe_kernel", "rdsp_engine_tail_pipe_kernel", "rdsp_engine_hilbert_kernel", "rdsp_engine_front_kernel", "rdsp_engine_tail_kernel"):
+        if k in name:
+            return k
     for k in ("rdsp_front_fd_kernel", "rdsp_front_kernel", "rdsp_tail_kernel", "rdsp_sam_kernel", "rdsp_spectrum_kernel", "rdsp_group_store_kernel"):
         if k in name:
             return k
@@ -56,7 +59,7 @@ def pmc_per_launch(tag):
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     os.makedirs(PROF, exist_ok=True)
-    for cfg in ("K3", "K2", "K4", "F1", "K5"):
+    for cfg in ("K3", "K2", "K4", "F1", "K5", "ENGINE"):
         stats = newest(os.path.join(OUT, f"prof_{cfg}", "**", "*kernel_stats.csv"))
         if stats:
             shutil.copy(stats, os.path.join(PROF, f"{rnd}_{cfg.lower()}_kernel_stats.csv"))
@@ -77,7 +80,7 @@ def main():
                     open(os.path.join(PROF, f"{rnd}_{name}_bench.{'json' if ext == 'json' else 'txt'}"), "w").write("\n".join(lines[-8:] if ext == "log" else lines[-1:]) + "\n")
     cpath = os.path.join(PROF, "counters.json")
     counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
-    for cfg in ("K2", "K3", "K4", "K5", "F1"):
+    for cfg in ("K2", "K3", "K4", "K5", "F1", "ENGINE"):
         fetch, write, sq = (pmc_per_launch(f"{cfg}_{t}") for t in ("FETCH_SIZE", "WRITE_SIZE", "SQ"))
         if not (fetch or write or sq):
             continue
