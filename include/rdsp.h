@@ -696,6 +696,17 @@ rdsp_node_t *rdsp_preproc_node_create(rdsp_graph_t *g, rdsp_preproc_t *p);
 rdsp_node_t *rdsp_engine_node_create(rdsp_graph_t *g, rdsp_engine_t *e);
 int rdsp_engine_node_status(rdsp_node_t *n); /* either kind */
 
+/* The sketch as shipped inside ONE chain: a chain created as the bare CONV stage (decim 1, 44.1 kHz, RDSP_DEMOD_IQ, no
+ * mixer offset, unit gains, AGC / ALS / spectral stage off -- what loop() runs, INO:198) takes the reference's own
+ * pre-processor and engine in front of it.  rdsp_chain_process then is INO:71-86 + :198 (preProcessor -> SDR ->
+ * doConvolutionalProcessing), rdsp_sdr_node_create wires exactly that into the graph, and the rdsp_sdr_* / rdsp_pre_*
+ * setters above reach rdsp_engine_t / rdsp_preproc_t (the image's arithmetic) instead of this build's stand-ins; mode and
+ * filter arguments stay rdsp_demod_t / rdsp_audio_filter_t and are translated to the engine's numbers. */
+int rdsp_sdr_set_engine_literal(rdsp_chain_t *c, int on);
+int rdsp_sdr_load_engine_tables(rdsp_chain_t *c, const float *biquad_sets15x20, const float *hilbert64);
+rdsp_engine_t *rdsp_chain_engine(rdsp_chain_t *c);   /* the objects themselves (NULL unless engine-literal) */
+rdsp_preproc_t *rdsp_chain_preproc(rdsp_chain_t *c);
+
 #ifdef __cplusplus
 }
 #endif

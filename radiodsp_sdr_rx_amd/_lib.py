@@ -296,6 +296,10 @@ SYMBOLS = [
     ("rdsp_preproc_node_create", _vp, [_vp, _vp]),
     ("rdsp_engine_node_create", _vp, [_vp, _vp]),
     ("rdsp_engine_node_status", _i, [_vp]),
+    ("rdsp_sdr_set_engine_literal", _i, [_vp, _i]),
+    ("rdsp_sdr_load_engine_tables", _i, [_vp, _f32p, _f32p]),
+    ("rdsp_chain_engine", _vp, [_vp]),
+    ("rdsp_chain_preproc", _vp, [_vp]),
     ("rdsp_synth_iq", None, [_i16p, _i, _i, C.c_uint64, _i, C.POINTER(SynthConfig), _i]),
 ]
 

@@ -116,6 +116,15 @@ class Chain:
             out.stride(0) // 2, _stream_ptr(stream)))
         return out
 
+    def set_engine_literal(self, on, tables=None):
+        """the reference's own pre-processor and engine in front of this (bare CONV stage) chain: INO:53-54,71-86"""
+        _lib.check(self.lib.rdsp_sdr_set_engine_literal(self.h, int(bool(on))))
+        if on and tables is not None:
+            import numpy as np
+            b = np.ascontiguousarray(tables[0], np.float32).reshape(-1)
+            h = np.ascontiguousarray(tables[1], np.float32).reshape(-1)
+            _lib.check(self.lib.rdsp_sdr_load_engine_tables(self.h, b.ctypes.data_as(_lib._f32p), h.ctypes.data_as(_lib._f32p)))
+
     def reset(self, stream=None):
         _lib.check(self.lib.rdsp_chain_reset(self.h, _stream_ptr(stream)))
 

@@ -97,6 +97,10 @@ struct rdsp_chain {
   float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (decim 4 only) */
   float *d_sin_table = nullptr; /* [513] sinTable_f32 (spectral stage as written, rdsp_set_spectral_resynthesis); made on first use */
   int spectral_literal = 0;
+  /* rdsp_sdr_set_engine_literal: the reference's own pre-processor and engine in front of the CONV stage (INO:53-54,71-86) */
+  rdsp_engine_t *engine = nullptr;
+  rdsp_preproc_t *pre = nullptr;
+  int16_t *d_engine_io = nullptr; /* [n_channels][max_blocks * 128][2]: what the record queues would hold */
   int nlms_energy_running = 0; /* rdsp_set_nlms_energy_mode */
   uint32_t *d_hist = nullptr;
   float2 *d_prev = nullptr;
@@ -480,6 +484,9 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
 extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->engine) rdsp_engine_destroy(c->engine);
+  if (c->pre) rdsp_preproc_destroy(c->pre);
+  if (c->d_engine_io) (void)hipFree(c->d_engine_io);
   void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_sin_table, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_status, c->d_mid, c->d_slip_buf, c->d_slip_carry[0], c->d_slip_carry[1]};
@@ -658,6 +665,14 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
   if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
   hipStream_t stream = (hipStream_t)stream_;
   const rdsp_chain_config_t &cf = c->cfg;
+  if (c->engine) { /* INO:71-72,81-86: IQ -> preProcessor -> SDR -> the record queues; this chain is the CONV stage behind them */
+    const size_t st = (size_t)c->max_blocks * RDSP_BLOCK;
+    int rc = rdsp_preproc_update(c->pre, d_iq, in_stride, n_blocks, c->d_engine_io, st, stream);
+    if (rc == RDSP_OK) rc = rdsp_engine_update(c->engine, c->d_engine_io, st, n_blocks, c->d_engine_io, st, stream);
+    if (rc != RDSP_OK) return rc;
+    d_iq = c->d_engine_io;
+    in_stride = st;
+  }
 
   /* CONV:326-330: nr level change re-initialises the NLMS instance */
   if (cf.lms_nr > 0 && cf.lms_nr != c->old_nr_level) {
@@ -996,23 +1011,38 @@ extern "C" int rdsp_float_to_q15(const float *d_src, int16_t *d_dst, size_t n, v
 
 /* ---- engine setters ------------------------------------------------------- */
 #define NEED(c) do { if (!(c)) return RDSP_ERR_INVALID; } while (0)
-extern "C" int rdsp_sdr_enableAGC(rdsp_chain_t *c) { NEED(c); if (c->cfg.agc_mode == RDSP_AGC_OFF) c->cfg.agc_mode = c->saved_agc_mode; return RDSP_OK; }
-extern "C" int rdsp_sdr_disableAGC(rdsp_chain_t *c) { NEED(c); if (c->cfg.agc_mode != RDSP_AGC_OFF) c->saved_agc_mode = c->cfg.agc_mode; c->cfg.agc_mode = RDSP_AGC_OFF; return RDSP_OK; }
+/* with rdsp_sdr_set_engine_literal(chain, 1) the `SDR.` / `preProcessor.` calls reach the reference's own objects */
+#define TO_ENGINE(c, call) do { if ((c) && (c)->engine) return (call); } while (0)
+static int engine_mode_of(int demod) { /* rdsp_demod_t -> the engine's numbering (as the compiled tuningMode() passes it) */
+  switch (demod) {
+    case RDSP_DEMOD_LSB: return 0; case RDSP_DEMOD_USB: return 1; case RDSP_DEMOD_CW_LSB: return 2; case RDSP_DEMOD_CW_USB: return 3;
+    case RDSP_DEMOD_AM: return 4; case RDSP_DEMOD_SAM: return 5; default: return -1;
+  }
+}
+static int engine_filter_of(int filter) { /* rdsp_audio_filter_t -> the engine's id (as the compiled filterMode() passes it) */
+  switch (filter) {
+    case RDSP_AUDIO_AM: return 0; case RDSP_AUDIO_CW: return 1; case RDSP_AUDIO_2100: return 3; case RDSP_AUDIO_2700: return 6;
+    case RDSP_AUDIO_3100: return 8; default: return -1;
+  }
+}
+extern "C" int rdsp_sdr_enableAGC(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_enableAGC(c->engine)); if (c->cfg.agc_mode == RDSP_AGC_OFF) c->cfg.agc_mode = c->saved_agc_mode; return RDSP_OK; }
+extern "C" int rdsp_sdr_disableAGC(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_setAGCmode(c->engine, 0)); if (c->cfg.agc_mode != RDSP_AGC_OFF) c->saved_agc_mode = c->cfg.agc_mode; c->cfg.agc_mode = RDSP_AGC_OFF; return RDSP_OK; }
 extern "C" int rdsp_sdr_setAGCmode(rdsp_chain_t *c, int mode) {
   NEED(c);
+  TO_ENGINE(c, rdsp_engine_setAGCmode(c->engine, mode));
   if (mode < RDSP_AGC_OFF || mode > RDSP_AGC_SLOW) return RDSP_ERR_INVALID;
   c->cfg.agc_mode = mode;
   return RDSP_OK;
 }
-extern "C" int rdsp_sdr_enableALSfilter(rdsp_chain_t *c) { NEED(c); if (c->cfg.als_mode == RDSP_ALS_OFF) c->cfg.als_mode = c->saved_als_mode; return RDSP_OK; }
-extern "C" int rdsp_sdr_disableALSfilter(rdsp_chain_t *c) { NEED(c); if (c->cfg.als_mode != RDSP_ALS_OFF) c->saved_als_mode = c->cfg.als_mode; c->cfg.als_mode = RDSP_ALS_OFF; return RDSP_OK; }
-extern "C" int rdsp_sdr_setALSfilterNotch(rdsp_chain_t *c) { NEED(c); c->saved_als_mode = RDSP_ALS_NOTCH; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_NOTCH; return RDSP_OK; }
-extern "C" int rdsp_sdr_setALSfilterPeak(rdsp_chain_t *c) { NEED(c); c->saved_als_mode = RDSP_ALS_PEAK; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_PEAK; return RDSP_OK; }
-extern "C" int rdsp_sdr_setALSfilterAdaptive(rdsp_chain_t *c) { NEED(c); return RDSP_OK; /* the NLMS always adapts */ }
+extern "C" int rdsp_sdr_enableALSfilter(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_enableALSfilter(c->engine)); if (c->cfg.als_mode == RDSP_ALS_OFF) c->cfg.als_mode = c->saved_als_mode; return RDSP_OK; }
+extern "C" int rdsp_sdr_disableALSfilter(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_disableALSfilter(c->engine)); if (c->cfg.als_mode != RDSP_ALS_OFF) c->saved_als_mode = c->cfg.als_mode; c->cfg.als_mode = RDSP_ALS_OFF; return RDSP_OK; }
+extern "C" int rdsp_sdr_setALSfilterNotch(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_setALSfilterNotch(c->engine)); c->saved_als_mode = RDSP_ALS_NOTCH; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_NOTCH; return RDSP_OK; }
+extern "C" int rdsp_sdr_setALSfilterPeak(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_setALSfilterPeak(c->engine)); c->saved_als_mode = RDSP_ALS_PEAK; if (c->cfg.als_mode != RDSP_ALS_OFF) c->cfg.als_mode = RDSP_ALS_PEAK; return RDSP_OK; }
+extern "C" int rdsp_sdr_setALSfilterAdaptive(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_setALSfilterAdaptive(c->engine)); return RDSP_OK; /* the NLMS always adapts */ }
 /* noise blanker (AudioSDR feature; arithmetic build-defined): wide-band,
  * before the mixer; windows of 256*decim input samples */
-extern "C" int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c) { NEED(c); c->nb_on = 1; return RDSP_OK; }
-extern "C" int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c) { NEED(c); c->nb_on = 0; return RDSP_OK; }
+extern "C" int rdsp_sdr_enableNoiseBlanker(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_enableNoiseBlanker(c->engine)); c->nb_on = 1; return RDSP_OK; }
+extern "C" int rdsp_sdr_disableNoiseBlanker(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_engine_disableNoiseBlanker(c->engine)); c->nb_on = 0; return RDSP_OK; }
 extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) {
   NEED(c);
   if (!(db >= 0.0f && db <= 60.0f)) { rdsp_set_error("noise blanker threshold %g dB outside 0..60", (double)db); return RDSP_ERR_INVALID; }
@@ -1020,12 +1050,12 @@ extern "C" int rdsp_sdr_setNoiseBlankerThresholdDb(rdsp_chain_t *c, float db) {
   return RDSP_OK;
 }
 /* AudioSDRpreProcessor (INO:117-118) */
-extern "C" int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap) { NEED(c); c->swap_iq = swap ? 1 : 0; return RDSP_OK; }
+extern "C" int rdsp_pre_swapIQ(rdsp_chain_t *c, int swap) { NEED(c); TO_ENGINE(c, rdsp_preproc_swapIQ(c->pre, swap)); c->swap_iq = swap ? 1 : 0; return RDSP_OK; }
 /* INO:117 guards against a Teensy I2S bus fault that leaves one rail of the codec stream a sample
  * behind the other.  There is no bus here, so there is nothing to watch at run time; a RECORDING made
  * through such a front end carries the fault: rdsp_estimate_iq_slip finds it, rdsp_pre_setIQslip
  * corrects it. */
-extern "C" int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c) { NEED(c); return RDSP_OK; }
+extern "C" int rdsp_pre_startAutoI2SerrorDetection(rdsp_chain_t *c) { NEED(c); TO_ENGINE(c, rdsp_preproc_startAutoI2SerrorDetection(c->pre)); return RDSP_OK; }
 /* slip +1: pair I[n-1] with Q[n] (delay the I rail by one sample); -1: pair I[n] with Q[n-1]; 0: off.
  * Applies to samples as they arrive, from the next call on (what is already in the FIR history keeps
  * the pairing it came in with).  A set-up call: the first non-zero value allocates the corrected-input
@@ -1045,11 +1075,12 @@ extern "C" int rdsp_pre_setIQslip(rdsp_chain_t *c, int slip) {
   c->iq_slip = slip;
   return RDSP_OK;
 }
-extern "C" int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.input_gain = g; return RDSP_OK; }
-extern "C" int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g) { NEED(c); c->cfg.output_gain = g; return RDSP_OK; }
-extern "C" int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g) { NEED(c); c->cfg.iq_balance = g; return RDSP_OK; }
+extern "C" int rdsp_sdr_setInputGain(rdsp_chain_t *c, float g) { NEED(c); TO_ENGINE(c, rdsp_engine_setInputGain(c->engine, g)); c->cfg.input_gain = g; return RDSP_OK; }
+extern "C" int rdsp_sdr_setOutputGain(rdsp_chain_t *c, float g) { NEED(c); TO_ENGINE(c, rdsp_engine_setOutputGain(c->engine, g)); c->cfg.output_gain = g; return RDSP_OK; }
+extern "C" int rdsp_sdr_setIQgainBalance(rdsp_chain_t *c, float g) { NEED(c); TO_ENGINE(c, rdsp_engine_setIQgainBalance(c->engine, g)); c->cfg.iq_balance = g; return RDSP_OK; }
 extern "C" int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c) {
   NEED(c);
+  TO_ENGINE(c, rdsp_engine_enableAudioFilter(c->engine)); /* the engine's audio filter, not the CONV stage's bFilterEnabled */
   c->cfg.filter_on = 1;
   for (size_t i = 0; i < c->groups.size(); i++) {
     int rc = group_stage(c, (int)i);
@@ -1057,7 +1088,7 @@ extern "C" int rdsp_sdr_enableAudioFilter(rdsp_chain_t *c) {
   }
   return RDSP_OK;
 }
-extern "C" int rdsp_sdr_setMute(rdsp_chain_t *c, int mute) { NEED(c); c->cfg.mute = mute ? 1 : 0; return RDSP_OK; }
+extern "C" int rdsp_sdr_setMute(rdsp_chain_t *c, int mute) { NEED(c); TO_ENGINE(c, rdsp_engine_setMute(c->engine, mute)); c->cfg.mute = mute ? 1 : 0; return RDSP_OK; }
 extern "C" int rdsp_group_setTuningOffsetHz(rdsp_chain_t *c, int group, double hz) {
   if (check_group(c, group) != RDSP_OK) return RDSP_ERR_INVALID;
   c->groups[(size_t)group].nco_hz = hz;
@@ -1067,6 +1098,7 @@ extern "C" int rdsp_group_setTuningOffsetHz(rdsp_chain_t *c, int group, double h
 }
 extern "C" int rdsp_sdr_setTuningOffsetHz(rdsp_chain_t *c, double hz) {
   NEED(c);
+  if (c->engine) return RDSP_OK; /* the engine moves the carrier from its own offset to 0 Hz itself (INO:139, CTL:447) */
   for (size_t i = 0; i < c->groups.size(); i++) (void)rdsp_group_setTuningOffsetHz(c, (int)i, hz);
   return RDSP_OK;
 }
@@ -1212,6 +1244,11 @@ extern "C" int rdsp_chain_get_iir_coeffs(rdsp_chain_t *c, int group, float *out2
 }
 extern "C" int rdsp_sdr_setAudioFilter(rdsp_chain_t *c, int filter, void *stream) {
   NEED(c);
+  if (c->engine) {
+    const int id = engine_filter_of(filter);
+    if (id < 0) { rdsp_set_error("rdsp_sdr_setAudioFilter: no engine filter id known for %d", filter); return RDSP_ERR_INVALID; }
+    return rdsp_engine_setAudioFilter(c->engine, id);
+  }
   for (size_t i = 0; i < c->groups.size(); i++) {
     int rc = rdsp_group_setAudioFilter(c, (int)i, filter, stream);
     if (rc != RDSP_OK) return rc;
@@ -1229,6 +1266,7 @@ extern "C" uint32_t rdsp_group_setDemodMode(rdsp_chain_t *c, int group, int mode
 }
 extern "C" uint32_t rdsp_sdr_setDemodMode(rdsp_chain_t *c, int mode, void *stream) {
   if (!c || mode < RDSP_DEMOD_IQ || mode > RDSP_DEMOD_SAM) return 0;
+  if (c->engine) return engine_mode_of(mode) < 0 ? 0u : (uint32_t)rdsp_engine_setDemodMode(c->engine, engine_mode_of(mode));
   for (size_t i = 0; i < c->groups.size(); i++) (void)rdsp_group_setDemodMode(c, (int)i, mode, stream);
   return demod_tuning_offset(mode);
 }
@@ -1791,3 +1829,42 @@ extern "C" int rdsp_chain_get_fir_taps(rdsp_chain_t *c, float *host_out) {
   memcpy(host_out, c->fir_nat.data(), sizeof(float) * 256);
   return RDSP_OK;
 }
+
+/* ---- the sketch as shipped inside one chain (round 6) -----------------------------------------------------------------
+ * A chain created as the bare CONV stage (decim 1, 44.1 kHz, RDSP_DEMOD_IQ, no mixer offset, unit gains, AGC / ALS /
+ * spectral stage off: what loop() runs, INO:198) can take the reference's own pre-processor and engine in front of it:
+ * rdsp_chain_process then is IQ -> AudioSDRpreProcessor::update -> AudioSDR::update -> doConvolutionalProcessing, and the
+ * rdsp_sdr_* / rdsp_pre_* setters reach those objects (rdsp_engine_t, rdsp_preproc_t: the image's arithmetic, bit for bit)
+ * instead of this build's stand-ins.  The engine's coefficient tables come from the host (rdsp_sdr_load_engine_tables). */
+extern "C" int rdsp_sdr_set_engine_literal(rdsp_chain_t *c, int on) {
+  NEED(c);
+  if (!on) {
+    if (c->engine) { rdsp_engine_destroy(c->engine); c->engine = nullptr; }
+    if (c->pre) { rdsp_preproc_destroy(c->pre); c->pre = nullptr; }
+    return RDSP_OK;
+  }
+  if (c->engine) return RDSP_OK;
+  const rdsp_chain_config_t &cf = c->cfg;
+  if (c->decim != 1 || cf.fs_in != 44100.0 || cf.demod != RDSP_DEMOD_IQ || cf.nco_hz != 0.0 || cf.agc_mode != RDSP_AGC_OFF ||
+      cf.als_mode != RDSP_ALS_OFF || cf.spectral_nr != 0 || cf.input_gain != 1.0f || cf.output_gain != 1.0f || cf.iq_balance != 1.0f ||
+      c->groups.size() != 1) {
+    rdsp_set_error("rdsp_sdr_set_engine_literal: the chain must be the bare CONV stage (decim 1, 44.1 kHz, RDSP_DEMOD_IQ, nco 0, "
+                   "AGC / ALS / spectral stage off, unit gains, one group)");
+    return RDSP_ERR_INVALID;
+  }
+  if (check_device(c) != RDSP_OK) return RDSP_ERR_HIP;
+  int rc = rdsp_preproc_create(c->n_channels, c->device, &c->pre);
+  if (rc == RDSP_OK) rc = rdsp_engine_create(c->n_channels, c->device, c->max_blocks, &c->engine);
+  if (rc == RDSP_OK && !c->d_engine_io &&
+      hipMalloc((void **)&c->d_engine_io, (size_t)c->n_channels * (size_t)c->max_blocks * RDSP_BLOCK * 2 * sizeof(int16_t)) != hipSuccess)
+    rc = RDSP_ERR_NOMEM;
+  if (rc != RDSP_OK) (void)rdsp_sdr_set_engine_literal(c, 0);
+  return rc;
+}
+extern "C" int rdsp_sdr_load_engine_tables(rdsp_chain_t *c, const float *biquad_sets15x20, const float *hilbert64) {
+  NEED(c);
+  if (!c->engine) { rdsp_set_error("rdsp_sdr_load_engine_tables: rdsp_sdr_set_engine_literal(chain, 1) first"); return RDSP_ERR_INVALID; }
+  return rdsp_engine_load_tables(c->engine, biquad_sets15x20, hilbert64);
+}
+extern "C" rdsp_engine_t *rdsp_chain_engine(rdsp_chain_t *c) { return c ? c->engine : nullptr; }
+extern "C" rdsp_preproc_t *rdsp_chain_preproc(rdsp_chain_t *c) { return c ? c->pre : nullptr; }

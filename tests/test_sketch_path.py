@@ -170,3 +170,65 @@ def test_gpu_the_sketchs_graph_block_by_block(kat, rdsp):
     assert np.array_equal(np.concatenate(seen), kat[name + "_sdr"])
     assert one_count(np.concatenate(heard), kat[name + "_audio"])
     assert list(pre.state()[0]) == list(kat[name + "_pre_state"][-1])
+
+
+@pytest.mark.gpu
+def test_gpu_one_chain_as_the_sketch_as_shipped(kat, rdsp):
+    """rdsp_sdr_set_engine_literal(chain, 1): ONE rdsp_chain_t, created as the bare CONV stage, with the reference's own
+    pre-processor and engine in front of it.  The sketch's set-up through the chain's rdsp_sdr_* / rdsp_pre_* entry points
+    with the chain's enums (rdsp_demod_t, rdsp_audio_filter_t: INO:117-139 as tests/host/rdsp_binding.h spells it) reaches
+    those objects; rdsp_chain_process and the graph's SDR node then play the image's audio to one count -- and a mode-menu
+    walk through the same entry points gives the engine fixture's audio, engine and CONV stage in one call."""
+    import torch
+    import oracle_lib
+    from radiodsp_sdr_rx_amd.chain import Chain
+    from radiodsp_sdr_rx_amd.config import AUDIO_FILTER, DEMOD
+    from radiodsp_sdr_rx_amd._lib import RdspError
+    name = "sketch_path_slip"
+    iq = kat[name + "_iq"]
+    ch = Chain(2, max_blocks_per_call=8, **CONV)
+    ch.set_engine_literal(True, oracle_lib.engine_tables())
+    ch.startAutoI2SerrorDetection()                                # INO:117
+    ch.enableAGC(); ch.setAGCmode(2); ch.disableALSfilter(); ch.disableNoiseBlanker()   # INO:120-131
+    ch.setInputGain(1.0); ch.setOutputGain(0.5); ch.setIQgainBalance(1.020)             # INO:133-135
+    ch.enableAudioFilter(); ch.setAudioFilter(AUDIO_FILTER["audio2700"])                 # INO:137-138
+    assert ch.lib.rdsp_sdr_setDemodMode(ch.h, DEMOD["LSB"], None) == 8390                # INO:139: TuningOffset
+    ch.setMute(False)                                              # INO:177
+    x = torch.from_numpy(np.stack([iq, iq])).cuda()
+    got = torch.cat([ch.process(x[:, a:a + 8 * 128].contiguous()) for a in range(0, len(iq), 8 * 128)], 1).cpu().numpy()
+    assert np.array_equal(got[0], got[1]) and one_count(got[0], kat[name + "_audio"])
+    with pytest.raises(RdspError):                                 # a chain that is more than the CONV stage is refused
+        Chain(1, max_blocks_per_call=8, **dict(CONV, agc_mode="fast")).set_engine_literal(True)
+    # the mode menu through the chain's entry points: engine_kat's menu_walk, CONV stage switched to pass-through checks
+    ek = np.load(os.path.join(HERE, "golden", "engine_kat.npz"))
+    import json
+    calls = json.loads(str(ek["menu_walk_calls"]))
+    c2 = Chain(1, max_blocks_per_call=2, **dict(CONV, lms_nr=0))
+    c2.set_engine_literal(True, oracle_lib.engine_tables())
+    for cfun, arg in (("enableAGC", None), ("setAGCmode", 2), ("disableALSfilter", None), ("disableNoiseBlanker", None), ("setInputGain", 1.0),
+                      ("setOutputGain", 0.5), ("setIQgainBalance", 1.02), ("enableAudioFilter", None)):
+        getattr(c2, cfun)(*([] if arg is None else [arg]))
+    c2.setAudioFilter(AUDIO_FILTER["audio2700"]); c2.lib.rdsp_sdr_setDemodMode(c2.h, DEMOD["LSB"], None)
+    eng_mode = {0: "LSB", 1: "USB", 2: "CW_LSB", 3: "CW_USB", 4: "AM", 5: "SAM"}
+    eng_filt = {0: "audioAM", 1: "audioCW", 3: "audio2100", 6: "audio2700", 8: "audio3100"}
+    miq = ek["menu_walk_iq"]
+    import radiodsp_sdr_rx_amd.engine as E
+    ref_eng = E.Engine(1, max_blocks_per_call=2, tables=oracle_lib.engine_tables())
+    ref_eng.sketch_setup()
+    for b in range(0, 36, 2):                                      # the CONV stage takes two blocks a call; up to block 36 the fixture's menu calls sit on even blocks
+        for c in calls:
+            if c[0] in (b, b + 1):
+                assert c[0] == b
+                if c[1] == "setDemodMode":
+                    c2.lib.rdsp_sdr_setDemodMode(c2.h, DEMOD[eng_mode[c[2]]], None); ref_eng.setDemodMode(c[2])
+                elif c[1] == "setAudioFilter":
+                    c2.setAudioFilter(AUDIO_FILTER[eng_filt[c[2]]]); ref_eng.setAudioFilter(c[2])
+                else:
+                    getattr(c2, c[1])(*c[2:]); getattr(ref_eng, c[1])(*c[2:])
+        d = torch.from_numpy(miq[None, b * 128:(b + 2) * 128].copy()).cuda()
+        y = c2.process(d)
+        s = ref_eng.update(d)                                       # the engine alone, then a CONV stage of its own
+        assert np.array_equal(s[0, :, 0].cpu().numpy(), ek["menu_walk_out"][b * 128:(b + 2) * 128])
+        if b == 0:
+            conv_ref = Chain(1, max_blocks_per_call=2, **dict(CONV, lms_nr=0))
+        assert torch.equal(y, conv_ref.process(s))
