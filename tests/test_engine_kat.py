@@ -194,3 +194,50 @@ def test_gpu_engine_1100_channels_on_a_callers_stream(kat, rdsp, blanker):
         if blanker:
             o.call("enableNoiseBlanker")
         assert np.array_equal(out[c], o.run(x[c])), c
+
+
+@pytest.mark.gpu
+def test_gpu_engine_at_the_bench_shape(rdsp):
+    """exactly `bench.py --config ENGINE`'s call (4096 receivers x 32 blocks of the synthetic generator's IQ, sketch set-up,
+    two consecutive steps): 40 sampled channels, workgroup and wave boundaries among them, against the CPU restatement --
+    which is the image's arithmetic (test_oracle_engine_is_the_images_bit_for_bit) -- bit for bit"""
+    import torch
+    import oracle_lib
+    from radiodsp_sdr_rx_amd.chain import synth_iq
+    nch, nblk = 4096, 32
+    host = synth_iq(nch, 2 * nblk * 128, n_threads=8)
+    eng = _engine(rdsp, nch, nblk)
+    eng.sketch_setup()
+    d = torch.from_numpy(host).cuda()
+    out = torch.cat([eng.update(d[:, :nblk * 128].contiguous()), eng.update(d[:, nblk * 128:].contiguous())], 1)[..., 0].cpu().numpy()
+    pick = sorted(set([0, 1, 7, 8, 9, 15, 16, 63, 64, 255, 256, 1023, 1024, 2047, 2048, 4088, 4095] + list(np.random.default_rng(1).integers(0, nch, 23))))
+    for c in pick:
+        assert np.array_equal(out[c], oracle_lib.OracleEngine().run(host[c])), c
+
+
+@pytest.mark.gpu
+def test_gpu_engine_reset_and_argument_checks(kat, rdsp):
+    """rdsp_engine_reset gives the signal state of a fresh object and keeps the settings; calls the object cannot honour are
+    refused with a message (too many blocks, short strides); zero blocks is a no-op"""
+    import ctypes as C
+    import torch
+    from radiodsp_sdr_rx_amd._lib import RdspError
+    iq = kat["als_notch_iq"][:16 * 128]
+    calls = calls_of(kat, "als_notch")
+    eng = _engine(rdsp, 2, 16)
+    eng.sketch_setup()
+    for c in calls:
+        getattr(eng, c[1])(*c[2:])
+    d = torch.from_numpy(np.stack([iq, iq])).cuda()
+    first = eng.update(d).cpu().numpy()
+    assert np.array_equal(first[0, :, 0], kat["als_notch_out"][:16 * 128])
+    eng.update(d)                                                    # move every state on, then back to the start
+    eng.reset()
+    assert np.array_equal(eng.update(d).cpu().numpy(), first)        # filter states, lines, rings, AGC, the ALS taps: all as constructed
+    with pytest.raises(RdspError):
+        eng.update(torch.zeros((2, 17 * 128, 2), dtype=torch.int16, device="cuda"))
+    lib = eng.lib
+    assert lib.rdsp_engine_update(eng.h, d.data_ptr(), 16 * 128, 0, d.data_ptr(), 16 * 128, None) == 0
+    assert lib.rdsp_engine_update(eng.h, d.data_ptr(), 100, 16, d.data_ptr(), 16 * 128, None) == -1
+    assert b"n_blocks" in lib.rdsp_last_error()
+    assert lib.rdsp_engine_update(None, d.data_ptr(), 16 * 128, 1, d.data_ptr(), 16 * 128, None) == -1
