@@ -202,13 +202,15 @@ __device__ __forceinline__ double over_32767(int v) {
  * need.  Per block: conversion and the mixer's table work spread over all 256 lanes (element e = lane + 256 j: consecutive
  * lanes on consecutive samples of a row); the cascades with a quad per row on waves 0 and 1 while wave 2 runs the
  * oscillator's phase, one lane per channel; the PLL and the blanker -- true recursions -- on one lane per channel or row. */
-constexpr int FW = 256, FCH = 8;
+constexpr int FW = 256, FCH = 8, PW = 256; /* PW: threads of the pipelined kernels */ /* PW: the pipelined kernels' six waves */
 template <bool NB>
 __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParams p) {
   __shared__ float tf[2 * FCH][PITCH];
   __shared__ float phs[FCH][PITCH];
   __shared__ int locked_of[FCH];
+  __shared__ float sine[257];                                     /* the oscillator's table: the PLL reads it twice per sample of a dependent chain */
   const int tid = threadIdx.x, c0 = blockIdx.x * FCH;
+  for (int i = tid; i < 257; i += FW) sine[i] = p.sine[i];
   const bool casc = tid < 8 * FCH;                              /* cascade role: section sct of tile row `row` */
   const int row = (tid >> 2) & (2 * FCH - 1), sct = tid & 3;
   const int rch = min(c0 + (row >> 1), p.n_channels - 1);
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
       for (int j = 0; j < EP; j++) {
         const int e = tid + FW * j, cl = e >> 7, t = e & 127;
         float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
-        rotate_sample(p.sine, phs[cl][t], x, y);
+        rotate_sample(sine, phs[cl][t], x, y);
         tf[2 * cl][t] = x; tf[2 * cl + 1][t] = y;
       }
       __syncthreads();
@@ -344,10 +346,10 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
             float pc = (float)((double)sam_ph + 1.5707963267948966);
             if (pc >= TWO_PI_F) pc -= TWO_PI_F;
             if (pc < 0.0f) pc += TWO_PI_F;
-            sam_c = table_sin(p.sine, pc);
+            sam_c = table_sin(sine, pc);
             float ps = sam_ph >= TWO_PI_F ? sam_ph - TWO_PI_F : sam_ph;
             if (ps < 0.0f) ps += TWO_PI_F;
-            sam_s = table_sin(p.sine, ps);
+            sam_s = table_sin(sine, ps);
             if (sam_locked) {
               ri[t] = fmaf(x, sam_c, q * sam_s);
               rq[t] = fmaf(-x, sam_s, q * sam_c);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
         const int e = tid + FW * j, cl = e >> 7, t = e & 127;
         if (locked_of[cl]) continue;
         float x = tf[2 * cl][t], y = tf[2 * cl + 1][t];
-        rotate_sample(p.sine, phs[cl][t], x, y);
+        rotate_sample(sine, phs[cl][t], x, y);
         tf[2 * cl][t] = x; tf[2 * cl + 1][t] = y;
       }
       __syncthreads();
@@ -414,13 +416,17 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_kernel(const EngParam
  * A lone wave issues an instruction every five cycles or so whatever it depends on, so a block costs its workgroup the SUM
  * of its passes' instruction counts -- unless the passes run on different waves at the same time.  Here they do, each on
  * the block behind the previous one's: waves 2 and 3 convert block s into tile slot s & 3 and rotate / store block s - 2
- * out of slot (s - 2) & 3, wave 0 runs the cascades of block s - 1, wave 1 the oscillator's phase of block s - 1; one
+ * out of slot (s - 2) & 3 (the longest pass of the step: knocking the rotation out cuts 2.2 us of 8.4 per block, knocking
+ * the cascade out nothing; six waves per workgroup instead of four ran 1.5 x slower), wave 0 runs the cascades of block s - 1, wave 1 the oscillator's phase of block s - 1; one
  * barrier per step.  A step then lasts as long as its longest pass (the cascade: 131 dependent steps), and the arithmetic
  * of every sample is what it was. */
-__global__ __launch_bounds__(FW, 2) void rdsp_engine_front_pipe_kernel(const EngParams p) {
+__global__ __launch_bounds__(PW, 2) void rdsp_engine_front_pipe_kernel(const EngParams p) {
   __shared__ float tf[4][2 * FCH][PITCH];
   __shared__ float phs[4][FCH][PITCH];
+  __shared__ float sine[257];                                     /* the oscillator's table beside the data it turns */
   const int tid = threadIdx.x, wave = tid >> 6, c0 = blockIdx.x * FCH;
+  for (int i = tid; i < 257; i += PW) sine[i] = p.sine[i];
+  __syncthreads();
   const int row = (tid >> 2) & (2 * FCH - 1), sct = tid & 3;      /* wave 0: section sct of tile row `row` */
   const int rch = min(c0 + (row >> 1), p.n_channels - 1);
   Section pre;
@@ -431,14 +437,14 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_pipe_kernel(const Eng
   float nco = p.st[(size_t)sch * NF + ST_NCO];
   const float nco_inc = -(p.tuning_offset * RAD_PER_HZ);
   const int wl = tid - 128;                                       /* waves 2 and 3: 128 lanes for the element passes */
-  constexpr int EP = FCH * BS / 128;
+  constexpr int EP = FCH * BS / (PW - 128);
   const uint32_t m = p.ring_size - 1;
   for (int step = 0; step < p.n_blocks + 2; step++) {
     if (wave >= 2) {
       if (step < p.n_blocks) { /* 0xe7b4: block `step` comes in */
         float (*t0)[PITCH] = tf[step & 3];
         for (int j = 0; j < EP; j++) {
-          const int e = wl + 128 * j, cl = e >> 7, t = e & 127;
+          const int e = wl + (PW - 128) * j, cl = e >> 7, t = e & 127;
           const int w = c0 + cl < p.n_channels ? p.iq[(size_t)(c0 + cl) * p.in_stride + (size_t)step * BS + t] : 0;
           t0[2 * cl][t] = (float)(over_32767((int)(int16_t)(w & 0xffff)) * (double)p.gain_i);
           t0[2 * cl + 1][t] = (float)(over_32767(w >> 16) * (double)p.gain_q);
@@ -450,9 +456,9 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_front_pipe_kernel(const Eng
         const float (*ph)[PITCH] = phs[b & 3];
         const uint32_t at = p.pos + (uint32_t)b * BS;
         for (int j = 0; j < EP; j++) {
-          const int e = wl + 128 * j, cl = e >> 7, t = e & 127;
+          const int e = wl + (PW - 128) * j, cl = e >> 7, t = e & 127;
           float x = t2[2 * cl][t], y = t2[2 * cl + 1][t];
-          rotate_sample(p.sine, ph[cl][t], x, y);
+          rotate_sample(sine, ph[cl][t], x, y);
           if (c0 + cl < p.n_channels) {
             const size_t o = (size_t)(c0 + cl) * p.ring_size + ((at + (uint32_t)t) & m);
             p.ring_i[o] = x; p.ring_q[o] = y;
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_kernel(const EngParams
 /* The tail stage without the ALS filter as a pipeline of waves (see rdsp_engine_front_pipe_kernel): waves 2 and 3 bring
  * block s in and send block s - 3 out (gain by the curve, clamp, pack), wave 0 runs the audio cascade of block s - 1,
  * wave 1 the AGC's envelope of block s - 2. */
-__global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_pipe_kernel(const EngParams p) {
+__global__ __launch_bounds__(PW, 2) void rdsp_engine_tail_pipe_kernel(const EngParams p) {
   constexpr int TCH = 8;
   __shared__ float ta[4][TCH][PITCH];
   __shared__ float ge[4][TCH][PITCH];
@@ -708,16 +714,16 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_pipe_kernel(const EngP
   float *sst = p.st + (size_t)sch * NF;
   float env = sst[ST_AGC_ENV], g = sst[ST_AGC_GAIN];
   int hang = __float_as_int(sst[ST_AGC_HANG]), active = __float_as_int(sst[ST_AGC_ACTIVE]);
-  for (int i = tid; i < 130; i += FW) curve[i] = p.curve[i];
+  for (int i = tid; i < 130; i += PW) curve[i] = p.curve[i];
   const int wl = tid - 128;
-  constexpr int EP = TCH * BS / 128;
+  constexpr int EP = TCH * BS / (PW - 128);
   __syncthreads();
   for (int step = 0; step < p.n_blocks + 3; step++) {
     if (wave >= 2) {
       if (step < p.n_blocks) {
         float (*t0)[PITCH] = ta[step & 3];
         for (int j = 0; j < EP; j++) {
-          const int e = wl + 128 * j, r = e >> 7, t = e & 127;
+          const int e = wl + (PW - 128) * j, r = e >> 7, t = e & 127;
           t0[r][t] = c0 + r < p.n_channels ? p.audio[(size_t)(c0 + r) * p.audio_stride + (size_t)step * BS + t] : 0.0f;
         }
       }
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(FW, 2) void rdsp_engine_tail_pipe_kernel(const EngP
         const float (*t3)[PITCH] = ta[b & 3];
         const float (*e3)[PITCH] = ge[b & 3];
         for (int j = 0; j < EP; j++) {
-          const int e = wl + 128 * j, r = e >> 7, t = e & 127;
+          const int e = wl + (PW - 128) * j, r = e >> 7, t = e & 127;
           float y = t3[r][t];
           if (p.agc_on) {
             const float le = e3[r][t];
@@ -1059,7 +1065,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   const int tch = e->als_on ? 16 : 8;
   const dim3 gf((unsigned)((e->n_channels + FCH - 1) / FCH)), gt((unsigned)((e->n_channels + tch - 1) / tch));
   if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
-  else if (ssb) hipLaunchKernelGGL(rdsp_engine_front_pipe_kernel, gf, dim3(FW), 0, s, p);
+  else if (ssb) hipLaunchKernelGGL(rdsp_engine_front_pipe_kernel, gf, dim3(PW), 0, s, p);
   else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
   if (ssb) {
     const dim3 gh((unsigned)((n_blocks * BS + HB_OUT - 1) / HB_OUT), (unsigned)e->n_channels);
@@ -1067,7 +1073,7 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   } else if (!known) { /* a mode number the engine does not know leaves its audio buffer as it was: the last call's */
   }
   if (e->als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(FW), 0, s, p);
-  else hipLaunchKernelGGL(rdsp_engine_tail_pipe_kernel, gt, dim3(FW), 0, s, p);
+  else hipLaunchKernelGGL(rdsp_engine_tail_pipe_kernel, gt, dim3(PW), 0, s, p);
   err = hipGetLastError();
   if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
   if (ssb) e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1); /* the lines only move when the SSB / CW path runs */
