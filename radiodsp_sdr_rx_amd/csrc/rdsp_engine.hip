@@ -82,11 +82,10 @@ struct EngParams {
   float sam_keep, sam_new, sam_hz_per_rad, sam_lock_lo, sam_lock_hi, sam_ga, sam_gb;
 };
 
-__device__ __forceinline__ int trunc_s32(double x) { /* VCVT.S32.F64 */
-  if (!(x == x)) return 0;
-  if (x >= 2147483647.0) return 2147483647;
-  if (x <= -2147483648.0) return (int)0x80000000;
-  return (int)x;
+__device__ __forceinline__ int trunc_s32(double x) { /* VCVT.S32.F64: toward zero, saturating, NaN -> 0 -- which is what v_cvt_i32_f64 does too */
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 /* the oscillator: sin of a phase in [0, 2 pi) by linear interpolation in the 256-step table, through double as the image does */
