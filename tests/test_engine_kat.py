@@ -241,3 +241,70 @@ def test_gpu_engine_reset_and_argument_checks(kat, rdsp):
     assert lib.rdsp_engine_update(eng.h, d.data_ptr(), 100, 16, d.data_ptr(), 16 * 128, None) == -1
     assert b"n_blocks" in lib.rdsp_last_error()
     assert lib.rdsp_engine_update(None, d.data_ptr(), 16 * 128, 1, d.data_ptr(), 16 * 128, None) == -1
+
+
+# ---- random control sessions ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sessions():
+    return np.load(os.path.join(HERE, "golden", "engine_sessions.npz"))
+
+
+def test_oracle_engine_random_sessions_are_the_images(sessions, oracle):
+    """tests/golden/engine_sessions.npz: six drawn sequences of the sketch's setter calls over changing signals, run by the
+    image's AudioSDR::update() (tests/golden/make_engine_sessions.py): the restatement's audio and final scalars, bit for bit"""
+    seen = set()
+    for name in case_names(sessions):
+        calls = calls_of(sessions, name)
+        seen |= {c[1] for c in calls}
+        e = oracle.OracleEngine()
+        assert np.array_equal(e.run(sessions[name + "_iq"], calls), sessions[name + "_out"]), name
+        assert np.array_equal(e.final().view(np.uint32), sessions[name + "_final"].view(np.uint32)), name
+    assert len(seen) >= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 5])
+def test_gpu_engine_random_sessions_are_the_images(sessions, rdsp, split):
+    for name in case_names(sessions):
+        eng = _engine(rdsp, 1, 8)
+        eng.sketch_setup()
+        out = _run_product(eng, sessions[name + "_iq"][None], calls_of(sessions, name), split)
+        assert np.array_equal(out[0], sessions[name + "_out"]), (name, split, int(np.argmax(out[0] != sessions[name + "_out"])))
+        assert np.array_equal(eng.scalars()[0].view(np.uint32), sessions[name + "_final"].view(np.uint32)), name
+        eng.close()
+
+
+def _drawn_session(seed, n_blocks):
+    r = np.random.default_rng(seed)
+    t = np.arange(n_blocks * 128)
+    z = np.zeros(len(t), np.complex128)
+    for _ in range(int(r.integers(1, 5))):
+        z += r.uniform(0.02, 0.3) * np.exp(2j * np.pi * r.uniform(4000, 10000) / 44100.0 * t + 1j * r.uniform(0, 6))
+    z += r.uniform(0, 0.3) * np.exp(2j * np.pi * 6890.0 / 44100.0 * t) * (1 + 0.5 * np.sin(2 * np.pi * 500.0 / 44100.0 * t))
+    z += r.uniform(0, 0.05) * (r.standard_normal(len(t)) + 1j * r.standard_normal(len(t)))
+    z *= np.repeat(r.choice([0.02, 0.2, 1.0, 3.0], n_blocks // 4 + 1), 4 * 128)[:len(t)]
+    iq = np.stack([np.clip(np.round(z.real * 32767), -32768, 32767), np.clip(np.round(z.imag * 32767), -32768, 32767)], 1).astype(np.int16)
+    menu = [["setDemodMode", int(m)] for m in range(7)] + [["setAudioFilter", int(f)] for f in range(11)] + [["setAGCmode", int(a)] for a in range(4)]
+    menu += [["enableAGC"], ["enableALSfilter"], ["disableALSfilter"], ["setALSfilterNotch"], ["setALSfilterPeak"], ["setALSfilterAdaptive"],
+             ["enableNoiseBlanker"], ["disableNoiseBlanker"], ["setMute", 1], ["setMute", 0], ["enableAudioFilter"]]
+    menu += [["setInputGain", g] for g in (0.25, 1.0, 3.0)] + [["setOutputGain", g] for g in (0.2, 0.5, 0.9)] + [["setIQgainBalance", g] for g in (0.95, 1.0, 1.02)]
+    calls = [[int(b)] + menu[int(r.integers(0, len(menu)))] for b in sorted(r.integers(0, n_blocks, n_blocks // 3))]
+    return iq, calls
+
+
+@pytest.mark.gpu
+def test_gpu_engine_drawn_sessions_against_the_restatement(rdsp):
+    """twenty more sessions of 60 blocks, drawn here, five receivers each with a session of its own setter calls applied to
+    ALL of them (the object's settings are the object's): rdsp_engine_t against the CPU restatement, bit for bit, calls cut
+    at every setter and every 1 ... 7 blocks"""
+    import oracle_lib
+    for s in range(20):
+        sess = [_drawn_session(100 * s + c, 60) for c in range(5)]
+        calls = sess[0][1]
+        x = np.stack([q for q, _ in sess])
+        eng = _engine(rdsp, 5, 8)
+        eng.sketch_setup()
+        out = _run_product(eng, x, calls, 1 + s % 7)
+        for c in range(5):
+            assert np.array_equal(out[c], oracle_lib.OracleEngine().run(x[c], calls)), (s, c)
+        eng.close()
