@@ -667,6 +667,15 @@ int rdsp_engine_setMute(rdsp_engine_t *e, int on);                 /* INO:177 */
  * in_stride pairs between channel rows; d_lr: [ch][t] int16 pairs = the engine's two outputs (the same block on both). */
 int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, int n_blocks, int16_t *d_lr,
                        size_t out_stride, void *stream);
+/* Receiver groups.  The sketch has one receiver -- one mode, one audio filter, one AGC setting; an object of many
+ * channels can be cut into groups of CONSECUTIVE channels that each carry their own settings.  first_channel[g] is group
+ * g's first channel (ascending, first_channel[0] = 0; a new group starts as a copy of the group its first channel was in).
+ * The setters above address the group chosen with rdsp_engine_select_group (-1, the default: every group);
+ * rdsp_engine_setDemodMode returns the offset of the selected group (of group 0 for -1).  A channel's signal state does
+ * not care which group it is in: regrouping in mid-stream only changes which settings reach it. */
+int rdsp_engine_set_groups(rdsp_engine_t *e, int n_groups, const int *first_channel);
+int rdsp_engine_groups(const rdsp_engine_t *e);
+int rdsp_engine_select_group(rdsp_engine_t *e, int group);
 int rdsp_engine_channels(const rdsp_engine_t *e);
 int rdsp_engine_device(const rdsp_engine_t *e);
 int rdsp_engine_max_blocks(const rdsp_engine_t *e);

@@ -279,6 +279,9 @@ SYMBOLS = [
     ("rdsp_engine_setDemodMode", _f, [_vp, _i]),
     ("rdsp_engine_setMute", _i, [_vp, _i]),
     ("rdsp_engine_update", _i, [_vp, _vp, _sz, _i, _vp, _sz, _vp]),
+    ("rdsp_engine_set_groups", _i, [_vp, _i, C.POINTER(C.c_int)]),
+    ("rdsp_engine_groups", _i, [_vp]),
+    ("rdsp_engine_select_group", _i, [_vp, _i]),
     ("rdsp_engine_channels", _i, [_vp]),
     ("rdsp_engine_device", _i, [_vp]),
     ("rdsp_engine_max_blocks", _i, [_vp]),

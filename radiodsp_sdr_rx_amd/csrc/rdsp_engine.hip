@@ -809,18 +809,25 @@ float engine_expf(float x) {
 }
 }  // namespace
 
+/* what the sketch's calls set: one set per receiver group (one group = the whole object unless rdsp_engine_set_groups cut it) */
+struct EngSettings {
+  float input_gain, gain_i, gain_q, iq_balance, output_gain, tuning_offset;
+  int mode, mute, audio_on, audio_id, audio_set, pre_set, agc_on, als_on, als_notch, als_adaptive, nb_on, resets;
+  float agc_attack_a, agc_attack_b, agc_decay_a, agc_decay_b;
+  int agc_hang_time;
+  uint32_t pos; /* where the group's next sample goes in its channels' rings (they only move in the SSB / CW modes) */
+};
 struct rdsp_engine {
   int n_channels, device, max_blocks;
-  uint32_t ring_size, pos;
+  uint32_t ring_size;
   bool tables;
   float *d_st = nullptr, *d_ring_i = nullptr, *d_ring_q = nullptr, *d_audio = nullptr, *d_nb = nullptr, *d_als = nullptr, *d_tab = nullptr;
   float curve[130], sine[257];
-  /* the object's fields (docs/engine.md has their places in the image's AudioSDR) */
-  float if_centre, ssb_band, cw_band, input_gain, gain_i, gain_q, iq_balance, output_gain, tuning_offset;
-  int mode, mute, audio_on, audio_id, audio_set, pre_set, agc_on, als_on, als_notch, als_adaptive, nb_on, resets;
-  float agc_attack_a, agc_attack_b, agc_decay_a, agc_decay_b, agc_makeup, agc_knee_db, agc_slope, agc_threshold_db;
-  int agc_hang_time;
-  float sam_ga, sam_gb;
+  /* constants of the object (docs/engine.md has their places in the image's AudioSDR) */
+  float if_centre, ssb_band, cw_band, agc_makeup, agc_knee_db, agc_slope, agc_threshold_db, sam_ga, sam_gb;
+  std::vector<EngSettings> grp; /* at least one */
+  std::vector<int> first;       /* first channel of each group, ascending; first[0] = 0 */
+  int sel = -1;                 /* the group the setters address; -1: all of them */
 };
 
 namespace {
@@ -858,75 +865,118 @@ int engine_fail(const char *what, hipError_t err) {
   rdsp_set_error("%s: %s", what, hipGetErrorString(err));
   return RDSP_ERR_HIP;
 }
+/* the setters address the selected group, or all of them */
+template <typename F>
+int for_selected(rdsp_engine_t *e, F f) {
+  if (!e) return RDSP_ERR_INVALID;
+  for (size_t g = 0; g < e->grp.size(); g++)
+    if (e->sel < 0 || (size_t)e->sel == g) f(e->grp[g]);
+  return RDSP_OK;
+}
+void settings_agc_mode(EngSettings &s, int mode) { /* 0xdfe0 */
+  static const uint32_t k[4][4] = {{0, 0, 0, 0}, {0x3f79673b, 0x3cd318a0, 0x3f7fddca, 0x3a08d800}, {0x3f7d5732, 0x3c2a3380, 0x3f7ff250, 0x395b0000},
+                                   {0x3f7eaab6, 0x3baaa500, 0x3f7ff928, 0x38db0000}};
+  static const int hang[4] = {0, 4410, 22050, 88200};
+  if (mode == 0) { s.agc_on = 0; return; }
+  if (mode < 0 || mode > 3) return; /* the engine ignores other values */
+  s.agc_attack_a = bits_f(k[mode][0]); s.agc_attack_b = bits_f(k[mode][1]);
+  s.agc_decay_a = bits_f(k[mode][2]); s.agc_decay_b = bits_f(k[mode][3]);
+  s.agc_hang_time = hang[mode];
+  s.agc_on = 1;
+}
+void settings_demod(const rdsp_engine_t *e, EngSettings &s, int mode) { /* 0xd798 */
+  s.mode = mode & 0xffff;
+  switch (s.mode) {
+    case 0: s.tuning_offset = (float)((double)e->if_centre + (double)e->ssb_band * 0.5); s.pre_set = 12; break;
+    case 1: s.tuning_offset = (float)((double)e->if_centre - (double)e->ssb_band * 0.5); s.pre_set = 12; break;
+    case 6: s.tuning_offset = (float)((double)e->if_centre - (double)e->ssb_band * 0.5); s.pre_set = 11; break;
+    case 2: s.tuning_offset = (float)((double)e->if_centre + (double)e->cw_band * 0.5); s.pre_set = 10; break;
+    case 3: s.tuning_offset = (float)((double)e->if_centre - (double)e->cw_band * 0.5); s.pre_set = 10; break;
+    case 4: case 5: s.tuning_offset = e->if_centre; s.pre_set = 14; break;
+    default: return;
+  }
+  s.resets |= RESET_PRE; /* arm_biquad_cascade_df1_init_f32 clears the state */
+}
+EngSettings settings_as_constructed(const rdsp_engine_t *e) { /* AudioSDR::AudioSDR (0x6744) and its init (0xede4) */
+  EngSettings s;
+  memset(&s, 0, sizeof s);
+  s.input_gain = s.gain_i = s.gain_q = s.iq_balance = s.output_gain = 1.0f;
+  s.audio_set = 3; s.nb_on = 1; s.als_notch = 1; s.als_adaptive = 1;
+  settings_agc_mode(s, 2); /* 0xdf14: the medium attack with the slow decay and the fast hang time */
+  s.agc_decay_a = bits_f(0x3f7ff928); s.agc_decay_b = bits_f(0x38db0000); s.agc_hang_time = 4410;
+  settings_demod(e, s, 0);
+  s.resets = 0;
+  return s;
+}
 }  // namespace
 
 extern "C" {
 
-int rdsp_engine_setAGCmode(rdsp_engine_t *e, int mode) { /* 0xdfe0 */
-  if (!e) return RDSP_ERR_INVALID;
-  static const uint32_t k[4][4] = {{0, 0, 0, 0}, {0x3f79673b, 0x3cd318a0, 0x3f7fddca, 0x3a08d800}, {0x3f7d5732, 0x3c2a3380, 0x3f7ff250, 0x395b0000},
-                                   {0x3f7eaab6, 0x3baaa500, 0x3f7ff928, 0x38db0000}};
-  static const int hang[4] = {0, 4410, 22050, 88200};
-  if (mode == 0) { e->agc_on = 0; return RDSP_OK; }
-  if (mode < 0 || mode > 3) return RDSP_OK; /* the engine ignores other values */
-  e->agc_attack_a = bits_f(k[mode][0]); e->agc_attack_b = bits_f(k[mode][1]);
-  e->agc_decay_a = bits_f(k[mode][2]); e->agc_decay_b = bits_f(k[mode][3]);
-  e->agc_hang_time = hang[mode];
-  e->agc_on = 1;
-  return RDSP_OK;
-}
-int rdsp_engine_enableAGC(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->agc_on = 1; return RDSP_OK; }
-
-float rdsp_engine_setDemodMode(rdsp_engine_t *e, int mode) { /* 0xd798 */
+int rdsp_engine_setAGCmode(rdsp_engine_t *e, int mode) { return for_selected(e, [&](EngSettings &s) { settings_agc_mode(s, mode); }); }
+int rdsp_engine_enableAGC(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.agc_on = 1; }); } /* 0xdfd4 */
+float rdsp_engine_setDemodMode(rdsp_engine_t *e, int mode) {
   if (!e) return 0.0f;
-  e->mode = mode & 0xffff;
-  switch (e->mode) {
-    case 0: e->tuning_offset = (float)((double)e->if_centre + (double)e->ssb_band * 0.5); e->pre_set = 12; break;
-    case 1: e->tuning_offset = (float)((double)e->if_centre - (double)e->ssb_band * 0.5); e->pre_set = 12; break;
-    case 6: e->tuning_offset = (float)((double)e->if_centre - (double)e->ssb_band * 0.5); e->pre_set = 11; break;
-    case 2: e->tuning_offset = (float)((double)e->if_centre + (double)e->cw_band * 0.5); e->pre_set = 10; break;
-    case 3: e->tuning_offset = (float)((double)e->if_centre - (double)e->cw_band * 0.5); e->pre_set = 10; break;
-    case 4: case 5: e->tuning_offset = e->if_centre; e->pre_set = 14; break;
-    default: return e->tuning_offset;
-  }
-  e->resets |= RESET_PRE; /* arm_biquad_cascade_df1_init_f32 clears the state */
-  return e->tuning_offset;
+  (void)for_selected(e, [&](EngSettings &s) { settings_demod(e, s, mode); });
+  return e->grp[e->sel < 0 ? 0 : (size_t)e->sel].tuning_offset;
 }
 int rdsp_engine_setAudioFilter(rdsp_engine_t *e, int id) { /* 0xd97c */
   static const int set_of_id[10] = {7, 8, 9, 0, 1, 2, 3, 4, 5, 6};
-  if (!e) return RDSP_ERR_INVALID;
-  if (id == 10) e->audio_on = 0;
-  else if (id >= 0 && id < 10) { e->audio_set = set_of_id[id]; e->resets |= RESET_AUDIO; }
-  e->audio_id = id;
-  return RDSP_OK;
+  return for_selected(e, [&](EngSettings &s) {
+    if (id == 10) s.audio_on = 0;
+    else if (id >= 0 && id < 10) { s.audio_set = set_of_id[id]; s.resets |= RESET_AUDIO; }
+    s.audio_id = id;
+  });
 }
-int rdsp_engine_enableAudioFilter(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->audio_on = 1; return RDSP_OK; }
+int rdsp_engine_enableAudioFilter(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.audio_on = 1; }); }
 int rdsp_engine_setInputGain(rdsp_engine_t *e, float g) { /* 0xd8a0 */
-  if (!e) return RDSP_ERR_INVALID;
   if (g > 10.0f) g = 10.0f;
   else if (g < 0.0f) g = 0.0f;
-  e->input_gain = g; e->gain_i = e->iq_balance * g; e->gain_q = g;
-  return RDSP_OK;
+  return for_selected(e, [&](EngSettings &s) { s.input_gain = g; s.gain_i = s.iq_balance * g; s.gain_q = g; });
 }
 int rdsp_engine_setIQgainBalance(rdsp_engine_t *e, float b) { /* 0xd8f0 */
-  if (!e) return RDSP_ERR_INVALID;
-  e->iq_balance = b; e->gain_i = b * e->input_gain; e->gain_q = e->input_gain;
-  return RDSP_OK;
+  return for_selected(e, [&](EngSettings &s) { s.iq_balance = b; s.gain_i = b * s.input_gain; s.gain_q = s.input_gain; });
 }
-int rdsp_engine_setOutputGain(rdsp_engine_t *e, float g) { if (!e) return RDSP_ERR_INVALID; e->output_gain = g; return RDSP_OK; }
-int rdsp_engine_setMute(rdsp_engine_t *e, int on) { if (!e) return RDSP_ERR_INVALID; e->mute = on ? 1 : 0; return RDSP_OK; }
-int rdsp_engine_enableALSfilter(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_on = 1; e->resets |= RESET_ALS; return RDSP_OK; }
-int rdsp_engine_disableALSfilter(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_on = 0; return RDSP_OK; }
-int rdsp_engine_setALSfilterNotch(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_notch = 1; return RDSP_OK; }
-int rdsp_engine_setALSfilterPeak(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_notch = 0; return RDSP_OK; }
-int rdsp_engine_setALSfilterAdaptive(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->als_adaptive = 1; return RDSP_OK; }
-int rdsp_engine_enableNoiseBlanker(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->nb_on = 1; return RDSP_OK; }
-int rdsp_engine_disableNoiseBlanker(rdsp_engine_t *e) { if (!e) return RDSP_ERR_INVALID; e->nb_on = 0; return RDSP_OK; }
+int rdsp_engine_setOutputGain(rdsp_engine_t *e, float g) { return for_selected(e, [&](EngSettings &s) { s.output_gain = g; }); }
+int rdsp_engine_setMute(rdsp_engine_t *e, int on) { return for_selected(e, [&](EngSettings &s) { s.mute = on ? 1 : 0; }); }
+int rdsp_engine_enableALSfilter(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.als_on = 1; s.resets |= RESET_ALS; }); }
+int rdsp_engine_disableALSfilter(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.als_on = 0; }); }
+int rdsp_engine_setALSfilterNotch(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.als_notch = 1; }); }
+int rdsp_engine_setALSfilterPeak(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.als_notch = 0; }); }
+int rdsp_engine_setALSfilterAdaptive(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.als_adaptive = 1; }); }
+int rdsp_engine_enableNoiseBlanker(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.nb_on = 1; }); }
+int rdsp_engine_disableNoiseBlanker(rdsp_engine_t *e) { return for_selected(e, [](EngSettings &s) { s.nb_on = 0; }); }
 int rdsp_engine_channels(const rdsp_engine_t *e) { return e ? e->n_channels : 0; }
 int rdsp_engine_device(const rdsp_engine_t *e) { return e ? e->device : -1; }
 int rdsp_engine_max_blocks(const rdsp_engine_t *e) { return e ? e->max_blocks : 0; }
 const float *rdsp_engine_agc_curve(const rdsp_engine_t *e) { return e ? e->curve : nullptr; }
 const float *rdsp_engine_sine_table(const rdsp_engine_t *e) { return e ? e->sine : nullptr; }
+
+/* Receiver groups: the sketch has ONE receiver, so one mode, one audio filter, one AGC setting; an object of many channels
+ * can be cut into groups of consecutive channels that each carry their own.  first_channel[g] is group g's first channel
+ * (ascending, first_channel[0] = 0); new groups start as copies of the group their first channel was in.  The setters
+ * address the group chosen with rdsp_engine_select_group (-1, the default: every group).  A call of rdsp_engine_update
+ * launches each group's kernels on its channel range; the signal state of a channel does not care which group it is in. */
+int rdsp_engine_set_groups(rdsp_engine_t *e, int n_groups, const int *first_channel) {
+  if (!e || n_groups < 1 || !first_channel || first_channel[0] != 0) return RDSP_ERR_INVALID;
+  for (int g = 1; g < n_groups; g++)
+    if (first_channel[g] <= first_channel[g - 1] || first_channel[g] >= e->n_channels) return RDSP_ERR_INVALID;
+  std::vector<EngSettings> grp((size_t)n_groups);
+  for (int g = 0; g < n_groups; g++) {
+    size_t from = 0;
+    while (from + 1 < e->first.size() && e->first[from + 1] <= first_channel[g]) from++;
+    grp[(size_t)g] = e->grp[from];
+  }
+  e->grp.swap(grp);
+  e->first.assign(first_channel, first_channel + n_groups);
+  e->sel = -1;
+  return RDSP_OK;
+}
+int rdsp_engine_groups(const rdsp_engine_t *e) { return e ? (int)e->grp.size() : 0; }
+int rdsp_engine_select_group(rdsp_engine_t *e, int group) {
+  if (!e || group < -1 || group >= (int)e->grp.size()) return RDSP_ERR_INVALID;
+  e->sel = group;
+  return RDSP_OK;
+}
 
 void rdsp_engine_destroy(rdsp_engine_t *e) {
   if (!e) return;
@@ -943,7 +993,7 @@ int rdsp_engine_reset(rdsp_engine_t *e, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSetDevice(e->device);
   const size_t n = (size_t)e->n_channels;
-  std::vector<float> st(n * NF, 0.0f), nb((n + 1) * NB_WORDS, 0.0f);
+  std::vector<float> st(n * NF, 0.0f), nb(n * NB_WORDS, 0.0f);
   for (size_t c = 0; c < n; c++) {
     st[c * NF + ST_SAM_HZ] = 1890.0f;
     st[c * NF + ST_NB_AVG] = 10.0f;
@@ -956,8 +1006,7 @@ int rdsp_engine_reset(rdsp_engine_t *e, void *stream) {
   if (err == hipSuccess) err = hipMemsetAsync(e->d_ring_q, 0, n * e->ring_size * 4, s);
   if (err == hipSuccess) err = hipMemsetAsync(e->d_als, 0, n * ALS_WORDS * 4, s);
   if (err == hipSuccess) err = hipStreamSynchronize(s); /* the host vectors go away */
-  e->pos = 0;
-  e->resets = 0;
+  for (auto &g : e->grp) { g.pos = 0; g.resets = 0; }
   return err == hipSuccess ? RDSP_OK : engine_fail("rdsp_engine_reset", err);
 }
 
@@ -983,22 +1032,18 @@ int rdsp_engine_create(int n_channels, int device, int max_blocks_per_call, rdsp
   e->tables = false;
   /* the constructor's values */
   e->if_centre = 6890.0f; e->ssb_band = 3000.0f; e->cw_band = 1000.0f;
-  e->input_gain = e->gain_i = e->gain_q = e->iq_balance = e->output_gain = 1.0f;
-  e->mute = 0; e->audio_on = 0; e->audio_id = 0; e->audio_set = 3; e->nb_on = 1;
-  e->als_on = 0; e->als_notch = 1; e->als_adaptive = 1;
   e->agc_makeup = 10.0f; e->agc_threshold_db = -60.0f; e->agc_slope = bits_f(0x3dcccccd); e->agc_knee_db = 2.0f;
-  rdsp_engine_setAGCmode(e, 2); /* 0xdf14: the medium attack with the slow decay and the fast hang time */
-  e->agc_decay_a = bits_f(0x3f7ff928); e->agc_decay_b = bits_f(0x38db0000); e->agc_hang_time = 4410;
   engine_agc_curve(e);
   engine_sam_constants(e);
   for (int k = 0; k < 257; k++) e->sine[k] = (float)(round(sin(2.0 * 3.14159265358979323846 * k / 256.0) * 1e8) / 1e8);
-  rdsp_engine_setDemodMode(e, 0);
+  e->grp.assign(1, settings_as_constructed(e));
+  e->first.assign(1, 0);
   const size_t n = (size_t)n_channels;
   hipError_t err = hipMalloc((void **)&e->d_st, n * NF * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_ring_i, n * e->ring_size * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_ring_q, n * e->ring_size * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_audio, n * (size_t)max_blocks_per_call * BS * 4);
-  if (err == hipSuccess) err = hipMalloc((void **)&e->d_nb, (n + 1) * NB_WORDS * 4);
+  if (err == hipSuccess) err = hipMalloc((void **)&e->d_nb, n * NB_WORDS * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_als, n * ALS_WORDS * 4);
   if (err == hipSuccess) err = hipMalloc((void **)&e->d_tab, TAB_WORDS * 4);
   if (err != hipSuccess) {
@@ -1045,38 +1090,45 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   hipStream_t s = (hipStream_t)stream;
   hipError_t err = hipSetDevice(e->device);
   if (err != hipSuccess) return engine_fail("rdsp_engine_update", err);
-  EngParams p;
-  memset(&p, 0, sizeof p);
-  p.iq = (const int32_t *)d_iq; p.in_stride = in_stride; p.out = (int32_t *)d_lr; p.out_stride = out_stride;
-  p.n_channels = e->n_channels; p.n_blocks = n_blocks; p.st = e->d_st;
-  p.ring_i = e->d_ring_i; p.ring_q = e->d_ring_q; p.ring_size = e->ring_size; p.pos = e->pos;
-  p.audio = e->d_audio; p.audio_stride = (size_t)e->max_blocks * BS; p.nb = e->d_nb; p.als = e->d_als;
-  p.sets = e->d_tab + TAB_SETS; p.hilbert = e->d_tab + TAB_HILBERT; p.sine = e->d_tab + TAB_SINE; p.curve = e->d_tab + TAB_CURVE;
-  p.mode = e->mode; p.mute = e->mute; p.audio_on = e->audio_on; p.agc_on = e->agc_on; p.als_notch = e->als_notch;
-  p.als_adaptive = e->als_adaptive; p.resets = e->resets; p.pre_set = e->pre_set; p.audio_set = e->audio_set;
-  p.gain_i = e->gain_i; p.gain_q = e->gain_q; p.output_gain = e->output_gain; p.tuning_offset = e->tuning_offset; p.if_centre = e->if_centre;
-  p.agc_attack_a = e->agc_attack_a; p.agc_attack_b = e->agc_attack_b; p.agc_decay_a = e->agc_decay_a; p.agc_decay_b = e->agc_decay_b;
-  p.agc_makeup = e->agc_makeup; p.agc_hang_time = e->agc_hang_time;
-  p.nb_keep = 0.995f; p.nb_new = bits_f(0x3ba3d700); p.nb_ratio = 1.2f; p.nb_before = 10; p.nb_after = 10;
-  p.sam_keep = 0.995f; p.sam_new = bits_f(0x3ba3d700); p.sam_hz_per_rad = bits_f(0x45db55dd); p.sam_lock_lo = 3890.0f; p.sam_lock_hi = 9890.0f;
-  p.sam_ga = e->sam_ga; p.sam_gb = e->sam_gb;
-  const bool ssb = e->mode <= 3 || e->mode == 6, known = ssb || e->mode == 4 || e->mode == 5;
-  const int tch = e->als_on ? 16 : 8;
-  const dim3 gf((unsigned)((e->n_channels + FCH - 1) / FCH)), gt((unsigned)((e->n_channels + tch - 1) / tch));
-  if (e->nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
-  else if (ssb) hipLaunchKernelGGL(rdsp_engine_front_pipe_kernel, gf, dim3(PW), 0, s, p);
-  else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
-  if (ssb) {
-    const dim3 gh((unsigned)((n_blocks * BS + HB_OUT - 1) / HB_OUT), (unsigned)e->n_channels);
-    hipLaunchKernelGGL(rdsp_engine_hilbert_kernel, gh, dim3(256), 0, s, p);
-  } else if (!known) { /* a mode number the engine does not know leaves its audio buffer as it was: the last call's */
+  const size_t audio_stride = (size_t)e->max_blocks * BS;
+  for (size_t g = 0; g < e->grp.size(); g++) {
+    EngSettings &q = e->grp[g];
+    const int c0 = e->first[g], n = (g + 1 < e->grp.size() ? e->first[g + 1] : e->n_channels) - c0;
+    EngParams p;
+    memset(&p, 0, sizeof p);
+    p.iq = (const int32_t *)d_iq + (size_t)c0 * in_stride; p.in_stride = in_stride;
+    p.out = (int32_t *)d_lr + (size_t)c0 * out_stride; p.out_stride = out_stride;
+    p.n_channels = n; p.n_blocks = n_blocks; p.st = e->d_st + (size_t)c0 * NF;
+    p.ring_i = e->d_ring_i + (size_t)c0 * e->ring_size; p.ring_q = e->d_ring_q + (size_t)c0 * e->ring_size;
+    p.ring_size = e->ring_size; p.pos = q.pos;
+    p.audio = e->d_audio + (size_t)c0 * audio_stride; p.audio_stride = audio_stride;
+    p.nb = e->d_nb + (size_t)c0 * NB_WORDS; p.als = e->d_als + (size_t)c0 * ALS_WORDS;
+    p.sets = e->d_tab + TAB_SETS; p.hilbert = e->d_tab + TAB_HILBERT; p.sine = e->d_tab + TAB_SINE; p.curve = e->d_tab + TAB_CURVE;
+    p.mode = q.mode; p.mute = q.mute; p.audio_on = q.audio_on; p.agc_on = q.agc_on; p.als_notch = q.als_notch;
+    p.als_adaptive = q.als_adaptive; p.resets = q.resets; p.pre_set = q.pre_set; p.audio_set = q.audio_set;
+    p.gain_i = q.gain_i; p.gain_q = q.gain_q; p.output_gain = q.output_gain; p.tuning_offset = q.tuning_offset; p.if_centre = e->if_centre;
+    p.agc_attack_a = q.agc_attack_a; p.agc_attack_b = q.agc_attack_b; p.agc_decay_a = q.agc_decay_a; p.agc_decay_b = q.agc_decay_b;
+    p.agc_makeup = e->agc_makeup; p.agc_hang_time = q.agc_hang_time;
+    p.nb_keep = 0.995f; p.nb_new = bits_f(0x3ba3d700); p.nb_ratio = 1.2f; p.nb_before = 10; p.nb_after = 10;
+    p.sam_keep = 0.995f; p.sam_new = bits_f(0x3ba3d700); p.sam_hz_per_rad = bits_f(0x45db55dd); p.sam_lock_lo = 3890.0f; p.sam_lock_hi = 9890.0f;
+    p.sam_ga = e->sam_ga; p.sam_gb = e->sam_gb;
+    const bool ssb = q.mode <= 3 || q.mode == 6;
+    const int tch = q.als_on ? 16 : 8;
+    const dim3 gf((unsigned)((n + FCH - 1) / FCH)), gt((unsigned)((n + tch - 1) / tch));
+    if (q.nb_on) hipLaunchKernelGGL(rdsp_engine_front_kernel<true>, gf, dim3(FW), 0, s, p);
+    else if (ssb) hipLaunchKernelGGL(rdsp_engine_front_pipe_kernel, gf, dim3(PW), 0, s, p);
+    else hipLaunchKernelGGL(rdsp_engine_front_kernel<false>, gf, dim3(FW), 0, s, p);
+    if (ssb) { /* (a mode number the engine does not know leaves its audio buffer as it was: the last call's) */
+      const dim3 gh((unsigned)((n_blocks * BS + HB_OUT - 1) / HB_OUT), (unsigned)n);
+      hipLaunchKernelGGL(rdsp_engine_hilbert_kernel, gh, dim3(256), 0, s, p);
+    }
+    if (q.als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(FW), 0, s, p);
+    else hipLaunchKernelGGL(rdsp_engine_tail_pipe_kernel, gt, dim3(PW), 0, s, p);
+    err = hipGetLastError();
+    if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
+    if (ssb) q.pos = (q.pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1); /* the lines only move when the SSB / CW path runs */
+    q.resets = 0;
   }
-  if (e->als_on) hipLaunchKernelGGL(rdsp_engine_tail_kernel<true>, gt, dim3(FW), 0, s, p);
-  else hipLaunchKernelGGL(rdsp_engine_tail_pipe_kernel, gt, dim3(PW), 0, s, p);
-  err = hipGetLastError();
-  if (err != hipSuccess) return engine_fail("rdsp_engine_update launch", err);
-  if (ssb) e->pos = (e->pos + (uint32_t)n_blocks * BS) & (e->ring_size - 1); /* the lines only move when the SSB / CW path runs */
-  e->resets = 0;
   return RDSP_OK;
 }
 

@@ -56,6 +56,15 @@ class Engine:
         check(self.lib.rdsp_engine_update(self.h, d_iq.data_ptr(), n, n // 128, out.data_ptr(), n, C.c_void_p(s)))
         return out
 
+    def set_groups(self, first_channels):
+        """groups of consecutive channels with settings of their own: first_channels[g] = group g's first channel"""
+        a = (C.c_int * len(first_channels))(*[int(x) for x in first_channels])
+        check(self.lib.rdsp_engine_set_groups(self.h, len(first_channels), a))
+
+    def select_group(self, group):
+        """the group the setters address from now on; -1: all"""
+        check(self.lib.rdsp_engine_select_group(self.h, int(group)))
+
     def scalars(self):
         o = np.zeros((self.n_channels, 8), np.float32)
         check(self.lib.rdsp_engine_get_scalars(self.h, o.ctypes.data_as(_F32P), None))

@@ -308,3 +308,45 @@ def test_gpu_engine_drawn_sessions_against_the_restatement(rdsp):
         for c in range(5):
             assert np.array_equal(out[c], oracle_lib.OracleEngine().run(x[c], calls)), (s, c)
         eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_engine_receiver_groups(kat, sessions, rdsp):
+    """rdsp_engine_set_groups: one object, groups of consecutive channels each in its own mode with its own filter, AGC and
+    gains, driven through their own setter sequences in the same calls -- five fixture cases side by side in 23 channels
+    (groups of 3, 9, 1, 8 and 2 channels: none aligned to a workgroup), every channel against the image's audio for its
+    group's case; then a regrouping in mid-stream"""
+    names = ["lsb_sketch", "am", "session2", "als_notch", "menu_walk"]
+    fx = {n: (kat if n + "_iq" in kat.files else sessions) for n in names}
+    nb = min(len(fx[n][n + "_iq"]) // 128 for n in names)
+    first = [0, 3, 12, 13, 21]
+    size = [3, 9, 1, 8, 2]
+    x = np.concatenate([np.repeat(fx[n][n + "_iq"][None, :nb * 128], k, 0) for n, k in zip(names, size)])
+    eng = _engine(rdsp, 23, 8)
+    eng.sketch_setup()
+    eng.set_groups(first)
+    calls = {n: calls_of(fx[n], n) for n in names}
+    import torch
+    out = np.zeros((23, nb * 128), np.int16)
+    marks = sorted({0, nb} | {c[0] for n in names for c in calls[n] if c[0] < nb} | set(range(0, nb, 5)))
+    for a, b in zip(marks[:-1], marks[1:]):
+        for g, n in enumerate(names):
+            eng.select_group(g)
+            for c in calls[n]:
+                if c[0] == a:
+                    getattr(eng, c[1])(*c[2:])
+        y = eng.update(torch.from_numpy(np.ascontiguousarray(x[:, a * 128:b * 128])).cuda()).cpu().numpy()
+        out[:, a * 128:b * 128] = y[..., 0]
+    for g, n in enumerate(names):
+        for c in range(first[g], first[g] + size[g]):
+            assert np.array_equal(out[c], fx[n][n + "_out"][:nb * 128]), (n, c)
+    # regrouping keeps every channel's signal state; new groups start as copies of the group their first channel was in
+    eng.select_group(-1)
+    assert eng.lib.rdsp_engine_groups(eng.h) == 5
+    eng.set_groups([0, 12])
+    assert eng.lib.rdsp_engine_groups(eng.h) == 2
+    from radiodsp_sdr_rx_amd._lib import RdspError
+    with pytest.raises(RdspError):
+        eng.set_groups([0, 30])
+    with pytest.raises(RdspError):
+        eng.select_group(2)
