@@ -676,6 +676,12 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
 int rdsp_engine_set_groups(rdsp_engine_t *e, int n_groups, const int *first_channel);
 int rdsp_engine_groups(const rdsp_engine_t *e);
 int rdsp_engine_select_group(rdsp_engine_t *e, int group);
+/* The signal state of a channel range as data (resume; receivers moved between objects or GPUs): filter states, oscillator
+ * and detector scalars, AGC, the last 512 samples of the side-band network's lines in time order (independent of either
+ * object's ring size), blanker and ALS lines and taps.  Settings are not part of it.  A loaded range continues bit for bit. */
+size_t rdsp_engine_state_bytes(const rdsp_engine_t *e, int n_channels);
+int rdsp_engine_save_state(rdsp_engine_t *e, int first_channel, int n_channels, void *host_buf, size_t bytes, void *stream);
+int rdsp_engine_load_state(rdsp_engine_t *e, int first_channel, const void *host_buf, size_t bytes, void *stream);
 int rdsp_engine_channels(const rdsp_engine_t *e);
 int rdsp_engine_device(const rdsp_engine_t *e);
 int rdsp_engine_max_blocks(const rdsp_engine_t *e);

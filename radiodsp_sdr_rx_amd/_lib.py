@@ -282,6 +282,9 @@ SYMBOLS = [
     ("rdsp_engine_set_groups", _i, [_vp, _i, C.POINTER(C.c_int)]),
     ("rdsp_engine_groups", _i, [_vp]),
     ("rdsp_engine_select_group", _i, [_vp, _i]),
+    ("rdsp_engine_state_bytes", C.c_size_t, [_vp, _i]),
+    ("rdsp_engine_save_state", _i, [_vp, _i, _i, _vp, C.c_size_t, _vp]),
+    ("rdsp_engine_load_state", _i, [_vp, _i, _vp, C.c_size_t, _vp]),
     ("rdsp_engine_channels", _i, [_vp]),
     ("rdsp_engine_device", _i, [_vp]),
     ("rdsp_engine_max_blocks", _i, [_vp]),

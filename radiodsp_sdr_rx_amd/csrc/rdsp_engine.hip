@@ -1132,6 +1132,88 @@ int rdsp_engine_update(rdsp_engine_t *e, const int16_t *d_iq, size_t in_stride, 
   return RDSP_OK;
 }
 
+/* ---- the signal state of a channel range as data: resume, or move receivers between objects / GPUs ---------------------
+ * Blob = header {magic, version, n_channels} + per channel: the 96 state words, the last 512 samples of both lines of the
+ * side-band network in time order (whatever the ring's size and position here or there), the blanker's lines, the ALS
+ * filter's line and taps.  Settings are not part of it (they belong to the group the channels land in). */
+namespace {
+constexpr uint32_t STATE_MAGIC = 0x45534452u; /* "RDSE" */
+constexpr size_t STATE_CH_WORDS = NF + 1024 + NB_WORDS + ALS_WORDS;
+uint32_t pos_of_channel(const rdsp_engine_t *e, int ch) {
+  size_t g = 0;
+  while (g + 1 < e->first.size() && e->first[g + 1] <= ch) g++;
+  return e->grp[g].pos;
+}
+}  // namespace
+size_t rdsp_engine_state_bytes(const rdsp_engine_t *e, int n_channels) {
+  return (e && n_channels > 0) ? 16 + (size_t)n_channels * STATE_CH_WORDS * 4 : 0;
+}
+int rdsp_engine_save_state(rdsp_engine_t *e, int first_channel, int n_channels, void *host_buf, size_t bytes, void *stream) {
+  if (!e || !host_buf || first_channel < 0 || n_channels < 1 || first_channel + n_channels > e->n_channels ||
+      bytes < rdsp_engine_state_bytes(e, n_channels)) {
+    rdsp_set_error("rdsp_engine_save_state: bad argument");
+    return RDSP_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipSetDevice(e->device);
+  const size_t n = (size_t)n_channels, c0 = (size_t)first_channel, R = e->ring_size;
+  std::vector<float> st(n * NF), ri(n * R), rq(n * R), nb(n * NB_WORDS), als(n * ALS_WORDS);
+  if (err == hipSuccess) err = hipMemcpyAsync(st.data(), e->d_st + c0 * NF, st.size() * 4, hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(ri.data(), e->d_ring_i + c0 * R, ri.size() * 4, hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(rq.data(), e->d_ring_q + c0 * R, rq.size() * 4, hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(nb.data(), e->d_nb + c0 * NB_WORDS, nb.size() * 4, hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(als.data(), e->d_als + c0 * ALS_WORDS, als.size() * 4, hipMemcpyDeviceToHost, s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  if (err != hipSuccess) return engine_fail("rdsp_engine_save_state", err);
+  uint32_t *hdr = (uint32_t *)host_buf;
+  hdr[0] = STATE_MAGIC; hdr[1] = 1; hdr[2] = (uint32_t)n_channels; hdr[3] = 0;
+  float *w = (float *)(hdr + 4);
+  for (size_t c = 0; c < n; c++, w += STATE_CH_WORDS) {
+    const uint32_t pos = pos_of_channel(e, first_channel + (int)c);
+    memcpy(w, &st[c * NF], NF * 4);
+    for (uint32_t i = 0; i < 512; i++) { /* sample pos - 512 + i */
+      w[NF + i] = ri[c * R + ((pos - 512u + i) & (uint32_t)(R - 1))];
+      w[NF + 512 + i] = rq[c * R + ((pos - 512u + i) & (uint32_t)(R - 1))];
+    }
+    memcpy(w + NF + 1024, &nb[c * NB_WORDS], NB_WORDS * 4);
+    memcpy(w + NF + 1024 + NB_WORDS, &als[c * ALS_WORDS], ALS_WORDS * 4);
+  }
+  return RDSP_OK;
+}
+int rdsp_engine_load_state(rdsp_engine_t *e, int first_channel, const void *host_buf, size_t bytes, void *stream) {
+  const uint32_t *hdr = (const uint32_t *)host_buf;
+  if (!e || !host_buf || bytes < 16 || hdr[0] != STATE_MAGIC || hdr[1] != 1) {
+    rdsp_set_error("rdsp_engine_load_state: not an engine state blob of this version");
+    return RDSP_ERR_INVALID;
+  }
+  const size_t n = hdr[2], c0 = (size_t)first_channel, R = e->ring_size;
+  if (first_channel < 0 || n < 1 || c0 + n > (size_t)e->n_channels || bytes < 16 + n * STATE_CH_WORDS * 4) {
+    rdsp_set_error("rdsp_engine_load_state: %zu channels at %d do not fit", n, first_channel);
+    return RDSP_ERR_INVALID;
+  }
+  std::vector<float> st(n * NF), ri(n * R, 0.0f), rq(n * R, 0.0f), nb(n * NB_WORDS), als(n * ALS_WORDS);
+  const float *w = (const float *)(hdr + 4);
+  for (size_t c = 0; c < n; c++, w += STATE_CH_WORDS) {
+    const uint32_t pos = pos_of_channel(e, first_channel + (int)c);
+    memcpy(&st[c * NF], w, NF * 4);
+    for (uint32_t i = 0; i < 512; i++) {
+      ri[c * R + ((pos - 512u + i) & (uint32_t)(R - 1))] = w[NF + i];
+      rq[c * R + ((pos - 512u + i) & (uint32_t)(R - 1))] = w[NF + 512 + i];
+    }
+    memcpy(&nb[c * NB_WORDS], w + NF + 1024, NB_WORDS * 4);
+    memcpy(&als[c * ALS_WORDS], w + NF + 1024 + NB_WORDS, ALS_WORDS * 4);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipSetDevice(e->device);
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_st + c0 * NF, st.data(), st.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_ring_i + c0 * R, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_ring_q + c0 * R, rq.data(), rq.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_nb + c0 * NB_WORDS, nb.data(), nb.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(e->d_als + c0 * ALS_WORDS, als.data(), als.size() * 4, hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  return err == hipSuccess ? RDSP_OK : engine_fail("rdsp_engine_load_state", err);
+}
+
 /* per-channel scalars for tests and monitoring: [n_channels][8] = oscillator phase, AGC gain, AGC envelope, hang counter,
  * AGC-active flag, PLL frequency estimate (Hz), PLL lock flag, blanker-hit flag */
 int rdsp_engine_get_scalars(rdsp_engine_t *e, float *host_out, void *stream) {

@@ -65,6 +65,16 @@ class Engine:
         """the group the setters address from now on; -1: all"""
         check(self.lib.rdsp_engine_select_group(self.h, int(group)))
 
+    def save_state(self, first_channel, n_channels):
+        n = self.lib.rdsp_engine_state_bytes(self.h, n_channels)
+        buf = np.zeros(n, np.uint8)
+        check(self.lib.rdsp_engine_save_state(self.h, first_channel, n_channels, buf.ctypes.data_as(C.c_void_p), n, None))
+        return buf
+
+    def load_state(self, first_channel, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        check(self.lib.rdsp_engine_load_state(self.h, first_channel, blob.ctypes.data_as(C.c_void_p), blob.size, None))
+
     def scalars(self):
         o = np.zeros((self.n_channels, 8), np.float32)
         check(self.lib.rdsp_engine_get_scalars(self.h, o.ctypes.data_as(_F32P), None))

@@ -350,3 +350,36 @@ def test_gpu_engine_receiver_groups(kat, sessions, rdsp):
         eng.set_groups([0, 30])
     with pytest.raises(RdspError):
         eng.select_group(2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lsb_sketch", "als_notch", "blanker_on", "sam", "menu_walk"])
+def test_gpu_engine_state_as_data(kat, rdsp, name):
+    """rdsp_engine_save_state / load_state: a receiver stopped after k blocks and continued in ANOTHER object (other channel
+    count, other ring size, the receiver at another channel index) plays the image's audio to the end, bit for bit"""
+    import torch
+    iq, calls, want = kat[name + "_iq"], calls_of(kat, name), kat[name + "_out"]
+    nb = len(iq) // 128
+    k = nb // 2 - (nb // 2) % 2
+    a = _engine(rdsp, 3, 8)
+    a.sketch_setup()
+    x = np.stack([iq[::-1].copy(), iq, iq])
+    first = _run_product(a, x[:, :k * 128], [c for c in calls if c[0] < k], 3)
+    assert np.array_equal(first[1], want[:k * 128])
+    blob = a.save_state(1, 1)
+    b = _engine(rdsp, 6, 24)
+    b.sketch_setup()
+    for c in calls:                                                 # the settings are not in the blob: the host makes the same calls
+        if c[0] < k:
+            getattr(b, c[1])(*c[2:])
+    b.update(torch.from_numpy(np.zeros((6, 128, 2), np.int16)).cuda())   # b has a past of its own (its rings sit elsewhere)
+    b.load_state(4, blob)
+    y = np.zeros((6, (nb - k) * 128, 2), np.int16)
+    y[4] = iq[k * 128:]
+    rest = _run_product(b, y, [[c[0] - k] + c[1:] for c in calls if c[0] >= k], 7)
+    assert np.array_equal(rest[4], want[k * 128:]), name
+    from radiodsp_sdr_rx_amd._lib import RdspError
+    with pytest.raises(RdspError):
+        b.load_state(0, np.zeros(64, np.uint8))                      # not a blob
+    with pytest.raises(RdspError):
+        b.load_state(6, blob)                                        # no such channel
