@@ -319,8 +319,8 @@ def test_oracle_reproduces_golden_vectors(oracle, name):
 
 
 def test_oracle_kats_pass_under_address_and_ub_sanitizers(tmp_path):
-    """The checker itself checked: oracle/rdsp_oracle.c rebuilt with ASan + UBSan and every CPU
-    test that drives it (known answers, golden vectors, audio nodes, spectrum, groups) run again
+    """The checker itself checked: oracle/rdsp_oracle.c and rdsp_engine_oracle.c rebuilt with ASan + UBSan and every CPU
+    test that drives them (known answers, golden vectors, audio nodes, spectrum, groups, the engine's fixtures) run again
     on that build in a child interpreter.  An out-of-bounds read in the oracle would otherwise
     pass as a plausible number."""
     import subprocess
@@ -331,10 +331,12 @@ def test_oracle_kats_pass_under_address_and_ub_sanitizers(tmp_path):
     so = str(tmp_path / "liboracle_san.so")
     subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-ffp-contract=off", "-fPIC", "-fopenmp",
                            "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-shared", "-o", so,
-                           os.path.join(os.path.dirname(here), "oracle", "rdsp_oracle.c"), "-lm"])
+                           os.path.join(os.path.dirname(here), "oracle", "rdsp_oracle.c"),
+                           os.path.join(os.path.dirname(here), "oracle", "rdsp_engine_oracle.c"), "-lm"])
     rt = [subprocess.check_output(["gcc", "-print-file-name=" + n], text=True).strip() for n in ("libasan.so", "libubsan.so")]
     env = dict(os.environ, LD_PRELOAD=":".join(rt), ASAN_OPTIONS="detect_leaks=0", RDSP_ORACLE_SO=so)
-    files = [os.path.join(here, f) for f in ("test_oracle_kat.py", "test_audio_nodes.py", "test_spectrum.py", "test_groups.py")]
+    files = [os.path.join(here, f) for f in ("test_oracle_kat.py", "test_audio_nodes.py", "test_spectrum.py", "test_groups.py",
+                                                 "test_engine_kat.py", "test_sketch_path.py")]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + files,
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
