@@ -95,6 +95,7 @@ struct rdsp_chain {
   bool fence_valid = false;
   float *d_fir_hc = nullptr;
   float2 *d_fd_mask = nullptr; /* [4][512] branch spectra of the frequency-domain decimator (decim 4 only) */
+  float2 *d_rd_mask = nullptr; /* [4][256] the same for the 256-point windows of the row forms */
   float *d_sin_table = nullptr; /* [513] sinTable_f32 (spectral stage as written, rdsp_set_spectral_resynthesis); made on first use */
   int spectral_literal = 0;
   /* rdsp_sdr_set_engine_literal: the reference's own pre-processor and engine in front of the CONV stage (INO:53-54,71-86) */
@@ -142,7 +143,8 @@ struct rdsp_chain {
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto (= full), 0 full-register front kernel, 1 lean */
   int fir_mode = -1;  /* stage A3 (rdsp_chain_set_fir_variant): -1 / 4 frequency domain, one granule per frame (split-
-                         invariant bits, the default); 0 direct form; 2 frequency domain, 448-sample frames (bench.py);
+                         invariant bits, the default); 0 direct form; 2 frequency domain, 448-sample frames;
+                         5 / 6 frequency domain on 16-lane rows, 128 (split-invariant) / 192 outputs per 256-point window;
                          EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix unless the tail stage shares the SIMDs */
   /* wave priorities while both kernels share the SIMDs: the direct-form front kernel raises its
    * own to front_fir_prio during the FIR, the frequency-domain one never does; the tail kernel runs
@@ -471,6 +473,10 @@ static int chain_build(rdsp_chain_t *c, const rdsp_chain_config_t *cfg, int n_ch
       }
       HIP_TRY(hipMalloc((void **)&c->d_fd_mask, img.size() * sizeof(float)));
       HIP_TRY(hipMemcpy(c->d_fd_mask, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+      std::vector<float> rimg(2 * 4 * 256);
+      rdsp_rd_decimator_image(c->fir_nat.data(), rimg.data());
+      HIP_TRY(hipMalloc((void **)&c->d_rd_mask, rimg.size() * sizeof(float)));
+      HIP_TRY(hipMemcpy(c->d_rd_mask, rimg.data(), rimg.size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
   /* boot order of the sketch: doConvolutionalInitialize (INO:180, mask from the
@@ -487,7 +493,7 @@ extern "C" void rdsp_chain_destroy(rdsp_chain_t *c) {
   if (c->engine) rdsp_engine_destroy(c->engine);
   if (c->pre) rdsp_preproc_destroy(c->pre);
   if (c->d_engine_io) (void)hipFree(c->d_engine_io);
-  void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_sin_table, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
+  void *ptrs[] = {c->d_iir_coef, c->d_iir_state, c->d_fd_mask, c->d_rd_mask, c->d_sin_table, c->d_mid_q[0], c->d_mid_q[1], c->d_mid_q[2], c->d_sam, c->d_groups, c->d_group_of, c->d_mask_pool, c->d_fir_hc, c->d_hist, c->d_prev, c->d_scal,
                   c->d_nr_w, c->d_nr_prev, c->d_nr_energy, c->d_als_w, c->d_als_prev,
                   c->d_als_energy, c->d_status, c->d_mid, c->d_slip_buf, c->d_slip_carry[0], c->d_slip_carry[1]};
   for (void *p : ptrs)
@@ -520,6 +526,18 @@ extern "C" int rdsp_chain_channels(const rdsp_chain_t *c) { return c ? c->n_chan
 extern "C" int rdsp_chain_decim(const rdsp_chain_t *c) { return c ? c->decim : 0; }
 extern "C" int rdsp_chain_device(const rdsp_chain_t *c) { return c ? c->device : -1; }
 
+/* RdspFrontParams::fir_fd of a chain: 0 direct form (and every decim-1 chain), 1 / 2 the wave-wide frequency-domain
+ * forms (448-sample frames / one granule per frame), 3 / 4 the row forms (128 / 192 outputs per window) */
+static int fir_fd_of(const rdsp_chain_t *c) {
+  if (!c->d_fd_mask) return 0;
+  switch (c->fir_mode) {
+    case 2: return 1;
+    case -1: case 4: return 2;
+    case 5: return 3;
+    case 6: return 4;
+    default: return 0;
+  }
+}
 /* the smallest call: one kernel chunk = 256 output samples; an overlap-save frame needs fft_l/2 of them */
 extern "C" int rdsp_chain_call_unit_blocks(const rdsp_chain_t *c) {
   if (!c) return 0;
@@ -534,8 +552,8 @@ extern "C" int rdsp_chain_call_unit_blocks(const rdsp_chain_t *c) {
 extern "C" int rdsp_chain_granule_blocks(const rdsp_chain_t *c) {
   if (!c) return 0;
   const int unit = rdsp_chain_call_unit_blocks(c);
-  if (c->fir_mode != 2 || !c->d_fd_mask) return unit;
-  const int frame = 14; /* 448 outputs x 4 / 128 */
+  if ((c->fir_mode != 2 && c->fir_mode != 6) || !c->d_fd_mask) return unit;
+  const int frame = c->fir_mode == 2 ? 14 : 6; /* 448 (192) outputs x 4 / 128 */
   int a = unit, b = frame;
   while (b) { const int t = a % b; a = b; b = t; }
   return unit / a * frame;
@@ -771,9 +789,10 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
    * (256 outputs per 512-point window): every frame's input is a function of the absolute sample position, so the
    * bits do not depend on how the stream is cut into calls -- like the direct form (0), at about two thirds of
    * its cost.  2: 448-sample frames anchored at the call's first sample: the throughput form bench.py selects. */
-  fp.fir_fd = !c->d_fd_mask ? 0 : (c->fir_mode == 2 ? 1 : ((c->fir_mode == -1 || c->fir_mode == 4) ? 2 : 0));
+  fp.fir_fd = fir_fd_of(c);
   fp.fd_mask = c->d_fd_mask;
-  c->front_name = fp.fir_fd ? "rdsp_front_fd_kernel" : "rdsp_front_kernel";
+  fp.rd_mask = c->d_rd_mask;
+  c->front_name = !fp.fir_fd ? "rdsp_front_kernel" : ((fp.fir_fd >= 3 && !fp.nb_on) ? "rdsp_front_rd_kernel" : "rdsp_front_fd_kernel");
   fp.mid_q = c->d_mid_q[0];
   if (piped) {
     fp.mid = slot ? c->d_midx[slot - 1] : c->d_mid;
@@ -1462,8 +1481,8 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
  * EXPERIMENTAL=1 builds: 1 = v_mfma GEMM slices, 3 = the same unless the tail stage runs concurrently. */
 extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   NEED(c);
-  if (variant < -1 || variant > 4) return RDSP_ERR_INVALID;
-  if ((variant == 2 || variant == 4) && !c->d_fd_mask) {
+  if (variant < -1 || variant > 6) return RDSP_ERR_INVALID;
+  if ((variant == 2 || variant >= 4) && !c->d_fd_mask) {
     rdsp_set_error("the frequency-domain decimator needs decim = 4");
     return RDSP_ERR_UNSUPPORTED;
   }
@@ -1646,7 +1665,7 @@ extern "C" int rdsp_chain_save_state(rdsp_chain_t *c, int first_channel, int n_c
   memset(&h, 0, sizeof(h));
   h.magic = kStateMagic; h.version = kStateVersion;
   h.has_slip = c->slip_prev_on ? 1 : 0;
-  h.fir_fd = !c->d_fd_mask ? 0 : (c->fir_mode == 2 ? 1 : (c->fir_mode == 0 ? 0 : 2)); /* decim 1: no decimator */
+  h.fir_fd = fir_fd_of(c); /* decim 1: no decimator */
   h.n_channels = n_channels; h.fft_l = c->N; h.decim = c->decim;
   h.has_sam = c->d_sam != nullptr; h.has_iir = c->d_iir_state != nullptr;
   h.old_nr_level = c->old_nr_level; h.n_in = c->n_in;

@@ -224,6 +224,32 @@ int rdsp_fd_decimator_image(const float *h_nat, int fft_l, float *image) {
   return 0;
 }
 
+/* The same branch spectra for the decimator on 16-lane rows (rdsp_front_rd_kernel): 256-point windows, 16 points per
+ * lane, bin i + 16 e of lane i at [r][16 e + i]; /256 (the inverse transform is unnormalised). */
+int rdsp_rd_decimator_image(const float *h_nat, float *image) {
+  const int n = 256;
+  for (int r = 0; r < 4; r++) {
+    double g[65];
+    for (int k = 0; k <= 64; k++) {
+      const int t = 4 * k - r;
+      g[k] = (t >= 0 && t < 256) ? (double)h_nat[t] : 0.0;
+    }
+    for (int bin = 0; bin < n; bin++) {
+      double re = 0.0, im = 0.0;
+      for (int k = 0; k <= 64; k++) {
+        const int m = (bin * k) % n;
+        const double a = -2.0 * kPi * (double)m / (double)n;
+        re += g[k] * cos(a);
+        im += g[k] * sin(a);
+      }
+      const size_t o = (size_t)r * n + (size_t)(bin >> 4) * 16 + (size_t)(bin & 15);
+      image[2 * o] = (float)(re / n);
+      image[2 * o + 1] = (float)(im / n);
+    }
+  }
+  return 0;
+}
+
 /* ---- biquad design -------------------------------------------------------
  * AudioFilterBiquad::setLowpass / setHighpass / setBandpass / setNotch (INO:155-156 calls
  * setHighpass(0, 500, 0.5)): the RBJ audio-EQ cookbook sections the Teensy library documents.

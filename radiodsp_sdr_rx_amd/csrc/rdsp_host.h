@@ -16,6 +16,7 @@ int rdsp_bin_of_pos(int fft_l, int i);
 void rdsp_mask_device_image(const float *mask_nat, int fft_l, float *image);
 int rdsp_design_decimator(int ntaps, double cut_hz, double fs, int window, float *h_nat, float *hc);
 int rdsp_fd_decimator_image(const float *h_nat, int fft_l, float *image);
+int rdsp_rd_decimator_image(const float *h_nat, float *image);
 uint32_t rdsp_nco_dphi(double hz, double fs);
 void rdsp_nco_rot(uint32_t dphi, int k, float *out2);
 float rdsp_lms_mu(int strength);

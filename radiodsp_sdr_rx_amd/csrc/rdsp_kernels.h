@@ -67,9 +67,12 @@ struct RdspFrontParams {
   int lean;                /* 1: register-lean variant (FFT twiddles rebuilt per pass)     */
   int fir_matrix;          /* 1: decimating FIR as v_mfma GEMM slices (EXPERIMENTAL builds)    */
   int fir_fd;              /* decimator in the frequency domain (rdsp_front_fd_kernel): 1 = 448-sample frames anchored at
-                              the call's first sample, 2 = frames of one granule (split-invariant); 0 = direct form */
+                              the call's first sample, 2 = frames of one granule (split-invariant); 0 = direct form;
+                              on 16-lane rows (rdsp_front_rd_kernel): 3 = 128 outputs per 256-point window (two frames per
+                              granule: split-invariant), 4 = 192 outputs per window, anchored at the call's first sample */
   const float2 *fd_mask;   /* [4][RDSP_FD_N] spectra of the polyphase branches g_r[k] = h[4k - r],
                               /RDSP_FD_N, digit-reversed thread-major like the filter masks    */
+  const float2 *rd_mask;   /* [4][256] the same spectra for 256-point windows, natural bin order, /256 (fir_fd 3, 4) */
   int front_prio;          /* 1: raise wave priority (tail kernel shares the SIMDs) */
   int agc_on;
   float agc_attack, agc_decay;

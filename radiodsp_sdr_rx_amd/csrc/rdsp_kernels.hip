@@ -361,7 +361,7 @@ __device__ __forceinline__ void quad_chain(float x, int g, int nf, float &state,
   state = nf == 1 ? s1 : (nf == 2 ? s2 : (nf == 3 ? s3 : s4)); /* frames g >= nf are not there: their sums are never used */
 }
 
-template <typename TW>
+template <int HOPS = QUAD_HOPS, typename TW>
 __device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const RdspGroup &G, const TW &tw,
                                                  const LdsBases<256, 16, false> &lb, float2 *wbg, const float2 *ring,
                                                  int rhop, int nf, int mbase, uint32_t vadbits, float vad_inv, float &nfloor,
@@ -369,8 +369,8 @@ __device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const
   constexpr int N = 256, P = 16;
   const int g = lane >> 4, i = lane & 15;
   int hc = rhop + g;
-  hc = hc >= QUAD_HOPS ? hc - QUAD_HOPS : hc;
-  const int hp = hc == 0 ? QUAD_HOPS - 1 : hc - 1;
+  hc = hc >= HOPS ? hc - HOPS : hc;
+  const int hp = hc == 0 ? HOPS - 1 : hc - 1;
   const float2 *cur = ring + hc * QUAD_PITCH + i, *prv = ring + hp * QUAD_PITCH + i;
   /* this lane's sixteen bins of the group's mask: L2-resident, land behind the forward transform */
   float2 mreg[P];
@@ -1288,6 +1288,327 @@ constexpr size_t front_fd_lds() {
          (nw > 1 ? (size_t)nw * 64 * sizeof(uint4) + 64 * sizeof(float) + 16 : 0);
 }
 
+/* ---- front kernel with the frequency-domain decimator on 16-lane rows ----------------------
+ * The same polyphase overlap-save decimator as rdsp_front_fd_kernel -- four low-rate forward transforms of the
+ * mixed input, branch spectra, one inverse -- on 256-point windows, one window per 16-lane DPP row: 16 points per
+ * lane, two radix-16 passes, ONE LDS exchange each way (the plan of front_frame_quad), a wave taking four
+ * consecutive windows at once.  A 512-point radix-8 transform over a whole wave costs 183 instructions per lane
+ * for 8 points; a row's 256-point transform 184 for 16 points in four windows at a time: half per point.  A window
+ * is the 64 quads in front of its frame (the 256 raw samples of the FIR history; the rows and passes re-read them,
+ * an L2 hit) and RV new ones:
+ *   RV = 128 (fir_fd 3): two frames per granule of 256 outputs, the window's last quarter zeros.  Every call
+ *     boundary is a frame boundary and a frame's arithmetic does not depend on the row or pass it lands in: the
+ *     same bits for any call split, like the one-granule form of rdsp_front_fd_kernel;
+ *   RV = 192 (fir_fd 4): the whole window is data; frames anchored at the call's first sample, the last one partial
+ *     (the throughput form: 5 transforms per 4 x 192 outputs).
+ * Mixer: one phasor per lane and pass (its first new column), every (column, branch) by one product with an entry
+ * of a 64-entry table in LDS, exp(-j theta (64 (j - 4) + r)), made at the start of the launch.
+ * Per pass and lane: 64 (48) samples unpacked and mixed, 5 x 184 + 128 transform / spectrum instructions for
+ * 768 (512) outputs: 1.6 (2.4) per output and wave where the wave-wide windows take 2.3 (4.0).
+ * The price is registers (four windows' 16 raw quads, data and accumulator: 238-256 VGPRs): for chains whose audio
+ * does not go on to a tail kernel that shares the SIMDs -- there the 176-register budget keeps rdsp_front_fd_kernel.
+ * The noise blanker (whose decisions go with the raw words from frame to frame) runs in rdsp_front_fd_kernel too:
+ * the launch code falls back to the form with the same split behaviour. */
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int RD_WB = 4 * FftPlan<256, 16>::WB; /* a wave's four row exchange buffers */
+
+template <int N, int P, bool LEAN, bool PRE, bool Q4, int RV>
+__global__ void __launch_bounds__(N / P, 2) rdsp_front_rd_kernel(RdspFrontParams p) {
+  using PL = FftPlan<N, P>;
+  using PR = FftPlan<256, 16>;
+  constexpr int NT = PL::NT;
+  constexpr int NW = NT / 64;
+  constexpr int H = N / 2;
+  constexpr int PH = P / 2;
+  static_assert(RV == 128 || RV == 192, "two frames per granule, or the whole window");
+  constexpr int NJ = 4 + RV / 16; /* data points of a lane: four history columns and RV / 16 new ones */
+  constexpr int PASS = 4 * RV;    /* outputs of one wave's pass */
+  constexpr bool QUAD = Q4;
+  static_assert(!Q4 || N == 256, "the four-frame form exists for FFT_L 256");
+  /* QUAD ring: the overlap hop, what a pass leaves unconsumed (< 4 hops, whole hops: 0 or 2 at RV 192) and a pass */
+  constexpr int HOPS = RV == 128 ? QUAD_HOPS : 9;
+  static_assert(!QUAD || 1 + (RV == 128 ? 0 : 2) + PASS / 128 <= HOPS, "ring hops");
+  constexpr int RING = QUAD ? HOPS * QUAD_PITCH : ((NW == 1) ? 1024 : 4096);
+  /* what a round leaves unconsumed is a multiple of gcd(H, NW PASS) below H */
+  static_assert(QUAD || (H - cgcd(H, NW * PASS)) + NW * PASS <= RING, "ring holds a round's outputs behind an unfinished hop");
+  static_assert(NT == 64 || NT == 256, "one or four waves per channel, a pass of four frames each");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *ring = reinterpret_cast<float2 *>(smem_raw);
+  float2 *wb = ring + RING;
+  constexpr int WBN0 = PL::WB > NW * RD_WB ? PL::WB : NW * RD_WB;
+  constexpr int WBN = (QUAD && QUAD_WB > WBN0) ? QUAD_WB : WBN0;
+  float *red = reinterpret_cast<float *>(wb + WBN);
+  float2 *utab = reinterpret_cast<float2 *>(red + 64); /* [16][4] mixer rotations by 64 (j - 4) + r samples */
+
+  const bool SWAP_IQ = PRE && p.swap_iq != 0;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row = lane >> 4, li = lane & 15;
+  float2 *wbg = wb + wave * RD_WB + row * PR::WB; /* this row's exchange buffer (inside the filter's work buffer) */
+  const size_t ch = (size_t)p.ch_base + blockIdx.x;
+  const uint32_t *iq = p.iq + ch * p.in_stride;
+  RdspGroup G;
+  {
+    const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
+    const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
+    uint32_t r[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) r[i] = (i < 30) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)gw[i]) : 0u;
+    G = __builtin_bit_cast(RdspGroup, r);
+  }
+  const int total = p.n_chunks * 256; /* outputs = input quads of this call */
+  if (tid < 64) {
+    const int j = tid >> 2, r = tid & 3;
+    utab[tid] = (G.dphi != 0u) ? nco_phasor_alu((uint32_t)(64 * (j - 4) + r) * G.dphi) : make_float2(1.f, 0.f);
+  }
+
+  const __amdgpu_buffer_rsrc_t iq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(iq), 0, 16 * total, 0x00020000);
+  auto ld_quad = [&](int q, bool once) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    /* aux 2 = nt for the columns nobody reads again; a frame's last 64 quads are the next one's history */
+    const v4i v = once ? __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, 2)
+                       : __builtin_amdgcn_raw_buffer_load_b128(iq_rsrc, 16 * q, 0, 0);
+    return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+  };
+  /* raw quads of this wave's first pass: frame 4 ps + row, window quads frame * RV - 64 + li + 16 j */
+  uint4 rq[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int q = (4 * wave + row) * RV - 64 + li + 16 * j;
+    if (q < 0) rq[j] = *reinterpret_cast<const uint4 *>(p.st_hist + ch * 256 + 4 * (q + 64));
+    else rq[j] = ld_quad(q, NW == 1 && j >= 4 && j < NJ - 4);
+  }
+
+  Twiddles<N, P, LEAN> tw;
+  LdsBases<N, P, false> lb;
+  if constexpr (!QUAD) {
+    tw.init(tid);
+    make_lds_bases<N, P, false>(tid, lb);
+  }
+  /* the rows' plan (and front_frame_quad's): kept in full where the filter stage uses it too */
+  Twiddles<256, 16, QUAD ? LEAN : true> tw16;
+  LdsBases<256, 16, false> lb16;
+  tw16.init(li);
+  make_lds_bases<256, 16, false>(li, lb16);
+  const int mbase = 16 * (lane & 3) + 4 * ((lane >> 2) & 3);
+  uint32_t vadbits = 0;
+  if constexpr (QUAD) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int k = li + 16 * e;
+      if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      int k = bin_of_pos<N, P>(tid * P + e);
+      if (k >= p.vad_lo && k <= p.vad_hi) vadbits |= 1u << e;
+    }
+  }
+  float nfloor = p.st_scal[ch * 4 + 0];
+  const float vad_inv = 1.0f / (float)(p.vad_hi - p.vad_lo);
+  float agc_g = p.st_scal[ch * 4 + 1];
+  float am_dc = p.st_scal[ch * 4 + 2];
+  float2 vprev[PH];
+  if constexpr (QUAD) {
+#pragma unroll
+    for (int j = 0; j < PH; j++) ring[(HOPS - 1) * QUAD_PITCH + tid + j * NT] = p.st_prev[ch * H + tid + j * NT];
+  } else {
+#pragma unroll
+    for (int j = 0; j < PH; j++) vprev[j] = p.st_prev[ch * H + tid + j * NT];
+  }
+  int frame_idx = 0;
+  int produced = 0, consumed = 0;
+  int rhop = 0; /* QUAD: ring hop of the oldest unconsumed sample */
+  int whop = 0; /* QUAD: ring hop the next pass's first output goes to */
+  wg_sync<NW>(); /* utab */
+
+  /* gains: as rdsp_front_fd_kernel -- one gain rides on the phasor, two (IQ balance) on the samples; the call's
+   * first 64 quads (row 0 of pass 0, columns 0..3) keep the gains, the swap flag and the increment they came in with */
+  const float si0 = PRE ? p.scale_i_hist : p.scale_i, sq0 = PRE ? p.scale_q_hist : p.scale_q;
+  const bool swap0 = PRE && p.swap_hist != 0;
+  const bool fold = !PRE || p.scale_i == p.scale_q, fold0 = !PRE || si0 == sq0;
+  const float gph = fold ? p.scale_i : 1.0f, gph0 = fold0 ? si0 : 1.0f;
+  const float sxi = fold ? 1.0f : p.scale_i, sxq = fold ? 1.0f : p.scale_q;
+  const float sxi0 = fold0 ? 1.0f : si0, sxq0 = fold0 ? 1.0f : sq0;
+
+#pragma unroll 1
+  for (int round = 0; produced < total; round++) {
+    const int ps = round * NW + wave; /* this wave's pass; past the end of the call it works on zeros */
+    const int fr = 4 * ps + row;      /* this row's frame */
+    const uint32_t nq = p.n0 + 4u * (uint32_t)(fr * RV + li); /* absolute index of column 4, branch 0 */
+    float2 Bu = make_float2(1.f, 0.f);
+    if (G.dphi != 0u) Bu = nco_phasor_alu(nq * G.dphi);
+    const float2 B = make_float2(Bu.x * gph, Bu.y * gph); /* the gain first, the rotations after it */
+    /* The call's first 64 quads (row 0 of pass 0, columns 0..3) came in under the previous call's settings.  They take
+     * the same operations as every other column, with their own gain / swap flag, so that nothing rounds differently
+     * when the settings did not change; only behind a retune their phasors are evaluated directly with the increment
+     * they were mixed with.  PRE kernels and retunes only: the launch code picks them for the call after a change. */
+    const bool first_special = ps == 0 && (PRE || G.dphi_hist != G.dphi);
+    const bool hl = ps == 0 && row == 0;
+    const float gh = hl ? gph0 : gph;
+    const float2 Bh = make_float2(Bu.x * gh, Bu.y * gh);
+
+    float2 acc[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float2 gm[16]; /* G_r, bins li + 16 e: L2-resident, lands behind the transform */
+      {
+        const float2 *mp = p.rd_mask + (size_t)r * 256;
+        asm volatile("" : "+s"(mp));
+        const auto gp = as_global(mp);
+#pragma unroll
+        for (int e = 0; e < 16; e++) gm[e] = gp[e * 16 + li];
+      }
+      float2 v[16];
+#pragma unroll
+      for (int j = NJ; j < 16; j++) v[j] = make_float2(0.f, 0.f);
+      auto word = [&](int j) { return (r == 0) ? rq[j].x : (r == 1) ? rq[j].y : (r == 2) ? rq[j].z : rq[j].w; };
+      if (first_special) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint32_t w = word(j);
+          if (hl ? swap0 : SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
+          float2 x = make_float2((float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16));
+          if constexpr (PRE) x = make_float2(x.x * (hl ? sxi0 : sxi), x.y * (hl ? sxq0 : sxq));
+          float2 ph = cmul_pinned(Bh, lds_ld(&utab[4 * j + r]));
+          if (G.dphi_hist != G.dphi) {
+            float2 d = make_float2(1.f, 0.f);
+            if (G.dphi_hist != 0u) d = nco_phasor_alu((nq + (uint32_t)(64 * (j - 4) + r)) * G.dphi_hist);
+            ph = hl ? make_float2(d.x * gph0, d.y * gph0) : ph;
+          }
+          v[j] = cmul_pinned(x, ph);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        if (j < 4 && first_special) continue;
+        uint32_t w = word(j);
+        if (SWAP_IQ) w = __builtin_amdgcn_alignbit(w, w, 16);
+        float2 x = make_float2((float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16));
+        if constexpr (PRE) x = make_float2(x.x * sxi, x.y * sxq);
+        const float2 ph = cmul_pinned(B, lds_ld(&utab[4 * j + r]));
+        v[j] = cmul_pinned(x, ph);
+      }
+      if (r == 3) { /* the raw registers are free: the next pass's loads land behind the transforms */
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int q = (4 * (ps + NW) + row) * RV - 64 + li + 16 * j; /* >= 0: pass 1 or later */
+          rq[j] = ld_quad(q, NW == 1 && j >= 4 && j < NJ - 4);
+        }
+      }
+      {
+        float2 twp[15];
+        tw16.template get<0>(twp);
+        fwd_pass0_store<256, 16>(lb16, v, wbg, twp);
+      }
+      wg_sync<1>(); /* a row's exchange buffer is its own */
+      fwd_pass_last<256, 16>(lb16, v, wbg);
+      wg_sync<1>();
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = (r == 0) ? cmul(v[e], gm[e]) : cmac(acc[e], v[e], gm[e]);
+    }
+    inv_pass_last<256, 16>(lb16, acc, wbg);
+    wg_sync<1>();
+    {
+      float2 twp[15];
+      tw16.template get<0>(twp);
+      inv_pass0_load<256, 16>(lb16, acc, wbg, twp);
+    }
+    /* acc[j] = y at window index li + 16 j; index 64 (j = 4) is output fr * RV of the call */
+    if constexpr (QUAD) {
+      if constexpr (RV == 128) { /* a frame is a hop */
+        int h = whop + wave * 4 + row;
+        h = h >= HOPS ? h - HOPS : h;
+        float2 *dst = ring + h * QUAD_PITCH + li;
+#pragma unroll
+        for (int c = 0; c < 8; c++) dst[16 * c] = acc[4 + c];
+        whop = (whop + 4 * NW) % HOPS;
+      } else { /* a frame is a hop and a half: even rows start a hop, odd ones in the middle of one */
+        const int odd = row & 1;
+        int a = whop + ((3 * row) >> 1);
+        a = a >= HOPS ? a - HOPS : a;
+        const int a1 = a + 1 >= HOPS ? a + 1 - HOPS : a + 1;
+        float2 *dA = ring + a * QUAD_PITCH + (odd ? 64 : 0) + li;
+        float2 *dB = odd ? ring + a1 * QUAD_PITCH + li : ring + a * QUAD_PITCH + 64 + li;
+        float2 *dC = ring + a1 * QUAD_PITCH + (odd ? 64 : 0) + li;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          dA[16 * c] = acc[4 + c];
+          dB[16 * c] = acc[8 + c];
+          dC[16 * c] = acc[12 + c];
+        }
+        whop = (whop + 6) % HOPS;
+      }
+    } else {
+      const int mb = fr * RV; /* of the call; a multiple of 64 like the ring's length */
+#pragma unroll
+      for (int c = 0; c < RV / 16; c++) ring[((mb + 16 * c) & (RING - 1)) + li] = acc[4 + c];
+    }
+    produced = (round + 1) * NW * PASS < total ? (round + 1) * NW * PASS : total;
+    wg_sync<NW>();
+
+    /* ---- A5/A6: overlap-save frames over what the ring holds (as rdsp_front_fd_kernel) ------- */
+    if constexpr (QUAD) {
+#pragma unroll 1
+      while (produced - consumed >= 4 * H || (produced == total && produced - consumed >= H)) {
+        int nf = (produced - consumed) / H;
+        nf = nf > 4 ? 4 : nf;
+        front_frame_quad<HOPS>(p, G, tw16, lb16, wb + row * PR::WB, ring, rhop, nf, mbase, vadbits, vad_inv,
+                               nfloor, agc_g, am_dc, frame_idx, ch, lane);
+        frame_idx += nf;
+        consumed += nf * H;
+        rhop += nf;
+        rhop = rhop >= HOPS ? rhop - HOPS : rhop;
+      }
+      continue;
+    }
+#pragma unroll 1
+    while (produced - consumed >= H) {
+      float2 mreg[P];
+      {
+        const float2 *mp = p.mask_pool + G.mask_off;
+        asm volatile("" : "+s"(mp));
+        const auto gp = as_global(mp);
+#pragma unroll
+        for (int e = 0; e < P; e++) mreg[e] = gp[e * NT + tid];
+      }
+      static_assert(QUAD || RING % H == 0, "a hop never wraps");
+      const float2 *hop = ring + (consumed & (RING - 1));
+      front_frame<N, P, false>(p, G, tw, lb, wb, red, mreg, vadbits, vad_inv, vprev, nfloor, agc_g, am_dc, frame_idx, ch,
+                               tid, [&](int i) { return hop[i]; });
+      consumed += H;
+    }
+  }
+
+  /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
+  if constexpr (QUAD) {
+    const int hp = rhop == 0 ? HOPS - 1 : rhop - 1; /* the last hop consumed */
+#pragma unroll
+    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = ring[hp * QUAD_PITCH + tid + j * NT];
+  } else {
+#pragma unroll
+    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
+  }
+  if (tid < 64)
+    *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) = *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
+  if (tid == 0) {
+    p.st_scal[ch * 4 + 0] = nfloor;
+    if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
+    p.st_scal[ch * 4 + 2] = am_dc;
+  }
+}
+
+template <int N, int P, bool Q4, int RV>
+constexpr size_t front_rd_lds() {
+  constexpr int nw = N / P / 64;
+  constexpr int wbn0 = FftPlan<N, P>::WB > nw * RD_WB ? FftPlan<N, P>::WB : nw * RD_WB;
+  constexpr int wbn = (Q4 && QUAD_WB > wbn0) ? QUAD_WB : wbn0;
+  constexpr int ringn = Q4 ? (RV == 128 ? QUAD_HOPS : 9) * QUAD_PITCH : (nw == 1 ? 1024 : 4096);
+  return (size_t)(ringn + wbn + 64) * sizeof(float2) + 64 * sizeof(float);
+}
+
 /* one group record, rewritten in stream order (32 threads, one dword each) */
 struct RdspGroupWords { uint32_t w[32]; };
 __global__ void rdsp_group_store_kernel(uint32_t *dst, RdspGroupWords v) { dst[threadIdx.x] = v.w[threadIdx.x]; }
@@ -1401,15 +1722,43 @@ int launch_front_fd_vc(const RdspFrontParams *p, int n_channels, hipStream_t str
     if (e != 0) return e;
   }
   size_t ask = lds;
-  if constexpr (VC == 4 && lds <= 16 * 1024) ask = lds + granule_form_lds_pad(p->to_mid);
+  if constexpr (lds <= 16 * 1024) ask = lds + granule_form_lds_pad(p->to_mid);
   hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, false, VC>), dim3(n_channels), dim3(N / P), ask, stream, *p);
   return (int)hipGetLastError();
 }
-/* fir_fd 1: 448-sample frames (throughput form, fir_variant 2); 2: one granule per frame (split-invariant, the default) */
+/* the decimator on 16-lane rows (rdsp_front_rd_kernel); the plan's radix decides LEAN (the `lean` switch is for the
+ * wave-wide forms) */
+template <int N, int P, bool PRE, int RV>
+int launch_front_rd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
+  constexpr bool LEAN = (P == 16);
+  if constexpr (N == 256) {
+    if (!p->to_mid) { /* front_frame_quad behind it, as in launch_front_fd_vc */
+      constexpr size_t lds4 = front_rd_lds<N, P, true, RV>();
+      static_assert(lds4 <= 48 * 1024, "no raised dynamic-LDS limit needed");
+      hipLaunchKernelGGL((rdsp_front_rd_kernel<N, P, LEAN, PRE, true, RV>), dim3(n_channels), dim3(N / P), lds4, stream, *p);
+      return (int)hipGetLastError();
+    }
+  }
+  constexpr size_t lds = front_rd_lds<N, P, false, RV>();
+  if constexpr (lds > 48 * 1024) {
+    int e = ensure_lds_limit<&rdsp_front_rd_kernel<N, P, LEAN, PRE, false, RV>>(lds);
+    if (e != 0) return e;
+  }
+  hipLaunchKernelGGL((rdsp_front_rd_kernel<N, P, LEAN, PRE, false, RV>), dim3(n_channels), dim3(N / P), lds, stream, *p);
+  return (int)hipGetLastError();
+}
+/* fir_fd 1: 448-sample frames (throughput form, fir_variant 2); 2: one granule per frame (split-invariant);
+ * 3 / 4: the row forms with 128 / 192 outputs per window -- with the noise blanker on, the wave-wide form with the
+ * same split behaviour (2 / 1): its decisions travel with the raw words from frame to frame */
 template <int N, int P, bool LEAN, bool PRE>
 int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  return p->fir_fd == 2 ? launch_front_fd_vc<N, P, LEAN, PRE, 4>(p, n_channels, stream)
-                        : launch_front_fd_vc<N, P, LEAN, PRE, RDSP_FD_P - 1>(p, n_channels, stream);
+  if (p->fir_fd >= 3 && !p->nb_on) {
+    if (!p->rd_mask) return (int)hipErrorInvalidValue;
+    return p->fir_fd == 3 ? launch_front_rd<N, P, PRE, 128>(p, n_channels, stream)
+                          : launch_front_rd<N, P, PRE, 192>(p, n_channels, stream);
+  }
+  return (p->fir_fd == 2 || p->fir_fd == 3) ? launch_front_fd_vc<N, P, LEAN, PRE, 4>(p, n_channels, stream)
+                                            : launch_front_fd_vc<N, P, LEAN, PRE, RDSP_FD_P - 1>(p, n_channels, stream);
 }
 template <int N, int P, int DECIM, bool LEAN, bool PRE>
 int launch_front_w(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
