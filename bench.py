@@ -393,7 +393,8 @@ def dry_run(args, rank, world, dist):
 
 
 DECIMATOR_TEXT = {2: "frequency domain, 448-sample frames (rdsp_chain_set_fir_variant 2)", 0: "direct form (variant 0)",
-                  -1: "frequency domain, one granule per frame (library default, split-invariant for any call split)"}
+                  -1: "frequency domain, one granule per frame (library default, split-invariant for any call split)",
+                  5: "frequency domain on 16-lane rows, two frames per granule (variant 5, split-invariant)"}
 WORKLOAD_TEXT = {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
                  "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
                  "K4": "NCO mix + 256-tap polyphase /4 + 4096-pt overlap-save CW filter (2049 taps) + AGC",

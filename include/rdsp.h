@@ -306,10 +306,13 @@ int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio
  * (test_throughput_decimator_is_split_invariant_on_whole_frames); any other multiple of the call unit is accepted
  * and ends in a partial frame -- another split then frames and rounds differently (2.6e-7 of the output's peak
  * over random splits, 2.8e-6 through K3's recursive stages: tests/test_gpu_parity.py pins both).  bench.py selects 2
- * with BASELINE.md's 512-block steps (9 frames and a partial one) and says so in its `config`.  All
- * three are the same exact linear convolution with the same taps (RDSP_ERR_UNSUPPORTED for 2 / 4 on decim-1
- * chains, which have no decimator).  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless the
- * tail stage shares the SIMDs. */
+ * with BASELINE.md's 512-block steps (9 frames and a partial one) and says so in its `config`.  5: the
+ * frequency domain on 16-lane rows (rdsp_front_rd_kernel: 256-point windows, four per wave, 128 outputs each, two
+ * frames per granule): split-invariant like the default and ~10 % faster than it for chains without a tail stage
+ * (K2 0.727 against 0.808 ms per step), no gain beside a tail kernel; with the noise blanker on it runs the default
+ * form.  All of them are the same exact linear convolution with the same taps (RDSP_ERR_UNSUPPORTED for 2 / 4 / 5
+ * on decim-1 chains, which have no decimator).  EXPERIMENTAL=1 builds: 1 matrix-core GEMM slices, 3 the same unless
+ * the tail stage shares the SIMDs, 6 the row form with 192 outputs per window. */
 int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant);
 /* tail-kernel variant: (16, 2) is the product -- a channel per 16-lane DPP row, two
  * steps per DPP reduction, delay line fed from LDS.  EXPERIMENTAL=1 builds: (16, 4) weights one block

@@ -1477,8 +1477,12 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
  * (CONV:231-245).  0: the direct form (packed FMAs), split-invariant too, ~1.3x slower.  2: the frequency domain
  * with 448-sample frames anchored at each call's first sample: 5 transforms per 448 outputs instead of per 256,
  * but a different call split frames and rounds differently (~3e-7): the throughput form, what bench.py selects.
- * Same taps and the same exact linear convolution in all three; the sums associate differently (~2e-7).
- * EXPERIMENTAL=1 builds: 1 = v_mfma GEMM slices, 3 = the same unless the tail stage runs concurrently. */
+ * 5: the frequency domain on 16-lane rows -- 256-point windows, four per wave, 128 outputs each (two frames per
+ * granule): split-invariant like the default, ~10 % faster than it for chains without a tail stage (K2 0.727 against
+ * 0.808 ms), no gain beside a tail kernel (250 registers); with the noise blanker on it runs the default form.
+ * Same taps and the same exact linear convolution in all of them; the sums associate differently (~2e-7).
+ * EXPERIMENTAL=1 builds: 1 = v_mfma GEMM slices, 3 = the same unless the tail stage runs concurrently, 6 = the row
+ * form with 192 outputs per window (frames anchored at the call's first sample; measured, no gain over 2). */
 extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
   NEED(c);
   if (variant < -1 || variant > 6) return RDSP_ERR_INVALID;
@@ -1489,6 +1493,10 @@ extern "C" int rdsp_chain_set_fir_variant(rdsp_chain_t *c, int variant) {
 #ifndef RDSP_EXPERIMENTAL
   if (variant == 1 || variant == 3) {
     rdsp_set_error("the matrix-core FIR is only in EXPERIMENTAL=1 builds of the library");
+    return RDSP_ERR_UNSUPPORTED;
+  }
+  if (variant == 6) {
+    rdsp_set_error("the row form with 192 outputs per window is only in EXPERIMENTAL=1 builds of the library");
     return RDSP_ERR_UNSUPPORTED;
   }
 #endif

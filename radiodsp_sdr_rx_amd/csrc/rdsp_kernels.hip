@@ -1288,26 +1288,28 @@ constexpr size_t front_fd_lds() {
          (nw > 1 ? (size_t)nw * 64 * sizeof(uint4) + 64 * sizeof(float) + 16 : 0);
 }
 
-/* ---- front kernel with the frequency-domain decimator on 16-lane rows ----------------------
+/* ---- front kernel with the frequency-domain decimator on 16-lane rows (round 6) -------------
  * The same polyphase overlap-save decimator as rdsp_front_fd_kernel -- four low-rate forward transforms of the
  * mixed input, branch spectra, one inverse -- on 256-point windows, one window per 16-lane DPP row: 16 points per
  * lane, two radix-16 passes, ONE LDS exchange each way (the plan of front_frame_quad), a wave taking four
- * consecutive windows at once.  A 512-point radix-8 transform over a whole wave costs 183 instructions per lane
- * for 8 points; a row's 256-point transform 184 for 16 points in four windows at a time: half per point.  A window
- * is the 64 quads in front of its frame (the 256 raw samples of the FIR history; the rows and passes re-read them,
- * an L2 hit) and RV new ones:
- *   RV = 128 (fir_fd 3): two frames per granule of 256 outputs, the window's last quarter zeros.  Every call
+ * consecutive windows at once.  A window is the 64 quads in front of its frame (the 256 raw samples of the FIR
+ * history; rows and passes re-read them, an L2 hit) and RV new ones:
+ *   RV = 128 (fir_variant 5): two frames per granule of 256 outputs, the window's last quarter zeros.  Every call
  *     boundary is a frame boundary and a frame's arithmetic does not depend on the row or pass it lands in: the
  *     same bits for any call split, like the one-granule form of rdsp_front_fd_kernel;
- *   RV = 192 (fir_fd 4): the whole window is data; frames anchored at the call's first sample, the last one partial
- *     (the throughput form: 5 transforms per 4 x 192 outputs).
+ *   RV = 192 (EXPERIMENTAL=1 builds, fir_variant 6): the whole window is data; frames anchored at the call's first
+ *     sample, the last one partial.
  * Mixer: one phasor per lane and pass (its first new column), every (column, branch) by one product with an entry
  * of a 64-entry table in LDS, exp(-j theta (64 (j - 4) + r)), made at the start of the launch.
- * Per pass and lane: 64 (48) samples unpacked and mixed, 5 x 184 + 128 transform / spectrum instructions for
- * 768 (512) outputs: 1.6 (2.4) per output and wave where the wave-wide windows take 2.3 (4.0).
- * The price is registers (four windows' 16 raw quads, data and accumulator: 238-256 VGPRs): for chains whose audio
- * does not go on to a tail kernel that shares the SIMDs -- there the 176-register budget keeps rdsp_front_fd_kernel.
- * The noise blanker (whose decisions go with the raw words from frame to frame) runs in rdsp_front_fd_kernel too:
+ * What it costs, from the ISA: a row's transform is 184 packed instructions for 16 points (2 x 77 + 15 twiddle
+ * products), the wave-wide 512-point radix-8 one 113 for 8: 19 % less per point, which the shorter window gives
+ * back -- 1330 packed instructions per pass of 768 (512) outputs against 759 per frame of 448 (256).  Measured at
+ * K2 / K4 (PMC and same-box A/B, tests/micro/rows_ab.sh, rows_pmc.sh): RV 128 0.727 / 2.04 ms per step where the
+ * one-granule form takes 0.808 / 2.10 and 448-sample frames 0.598 / 1.74; RV 192 0.742 / 2.05 (as many vector
+ * instructions as the 448-sample form, 2.19e8 against 2.16e8 per K2 launch, and 38 spilled registers).  So: an
+ * opt-in for chains that want split-invariant bits and whose audio does not go on to a tail kernel on the same
+ * SIMDs (238-256 VGPRs where the wave-wide forms fit 176; K3 pipelined: 1.39-1.43 ms against 1.38-1.46).
+ * The noise blanker (whose decisions go with the raw words from frame to frame) runs in rdsp_front_fd_kernel:
  * the launch code falls back to the form with the same split behaviour. */
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int RD_WB = 4 * FftPlan<256, 16>::WB; /* a wave's four row exchange buffers */
@@ -1696,8 +1698,9 @@ int ensure_lds_limit(size_t lds) {
   }
   return 0;
 }
-/* The one-granule form beside the tail kernel (pipelined mode): unused LDS asked for on top of the kernel's own, so
- * that fewer of its workgroups fit on a compute unit.  Measurement switch RDSP_FD_LDS_PAD (bytes) overrides. */
+/* Measurement switch RDSP_FD_LDS_PAD (bytes): unused LDS asked for on top of the one-wave frequency-domain kernels' own,
+ * so that fewer of their workgroups fit on a compute unit beside the tail kernel (pipelined mode).  Both forms lose by
+ * it (tests/micro/fd_lds_pad_sweep.sh, fd_lds_pad_sweep7.sh): the library never pads. */
 inline size_t granule_form_lds_pad(int to_mid) {
   static const long env = getenv("RDSP_FD_LDS_PAD") ? atol(getenv("RDSP_FD_LDS_PAD")) : -1;
   if (env >= 0) return (size_t)env;
@@ -1730,7 +1733,7 @@ int launch_front_fd_vc(const RdspFrontParams *p, int n_channels, hipStream_t str
  * wave-wide forms) */
 template <int N, int P, bool PRE, int RV>
 int launch_front_rd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
-  constexpr bool LEAN = (P == 16);
+  constexpr bool LEAN = (P >= 8); /* the filter's twiddles by product chains: the rows need the registers */
   if constexpr (N == 256) {
     if (!p->to_mid) { /* front_frame_quad behind it, as in launch_front_fd_vc */
       constexpr size_t lds4 = front_rd_lds<N, P, true, RV>();
@@ -1754,8 +1757,12 @@ template <int N, int P, bool LEAN, bool PRE>
 int launch_front_fd(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   if (p->fir_fd >= 3 && !p->nb_on) {
     if (!p->rd_mask) return (int)hipErrorInvalidValue;
-    return p->fir_fd == 3 ? launch_front_rd<N, P, PRE, 128>(p, n_channels, stream)
-                          : launch_front_rd<N, P, PRE, 192>(p, n_channels, stream);
+#ifdef RDSP_EXPERIMENTAL
+    if (p->fir_fd == 4) return launch_front_rd<N, P, PRE, 192>(p, n_channels, stream);
+#else
+    if (p->fir_fd == 4) return (int)hipErrorNotSupported; /* 192 outputs per window: EXPERIMENTAL=1 builds (measured, no gain) */
+#endif
+    return launch_front_rd<N, P, PRE, 128>(p, n_channels, stream);
   }
   return (p->fir_fd == 2 || p->fir_fd == 3) ? launch_front_fd_vc<N, P, LEAN, PRE, 4>(p, n_channels, stream)
                                             : launch_front_fd_vc<N, P, LEAN, PRE, RDSP_FD_P - 1>(p, n_channels, stream);

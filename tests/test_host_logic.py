@@ -193,6 +193,13 @@ def test_generated_code_keeps_the_instruction_forms_the_measurements_rest_on(tmp
         assert ins.count("buffer_load_dwordx4") >= 7, n
         one_wave = any(t in n for t in ("ILi256ELi4E", "ILi512ELi8E", "ILi1024ELi16E"))
         assert ("s_barrier" in ins) != one_wave, n
+    rd = {n: v for n, v in k.items() if "rdsp_front_rd_kernel" in n}   # the decimator on 16-lane rows: the same forms
+    assert len(rd) >= 12
+    for n, ins in rd.items():
+        assert not any(i.startswith("flat_load") for i in ins) and "ds_read2_b64" not in ins, n
+        assert ins.count("buffer_load_dwordx4") >= 24, n                # twelve quads a lane: prologue and prefetch
+        one_wave = any(t in n for t in ("ILi256ELi4E", "ILi512ELi8E", "ILi1024ELi16E"))
+        assert ("s_barrier" in ins) != one_wave, n
     for name in ("rdsp_tail_kernel", "rdsp_tail_dual_kernel", "rdsp_spectrum_kernel", "rdsp_fft1024_kernel",
                  "rdsp_biquad_kernel", "rdsp_sam_kernel"):
         hit = [v for n, v in k.items() if name in n]
@@ -227,6 +234,35 @@ def test_register_budget_of_the_two_kernels_that_share_a_simd(tmp_path):
     assert tail and front, sorted(vg)[:5]
     alloc = lambda v: (v + 7) // 8 * 8        # gfx950 allocates VGPRs in blocks of 8
     assert alloc(tail[0]) <= 128 and alloc(front[0]) <= 176 and 2 * alloc(front[0]) + alloc(tail[0]) <= 512, (tail, front)
+
+
+def test_branch_spectra_of_the_row_form_are_the_transforms_of_the_polyphase_taps():
+    """rdsp_rd_decimator_image (rdsp_design.c): [r][bin] = DFT_256 of g_r[k] = h[4k - r] (k <= 64), divided by 256 -- what
+    rdsp_front_rd_kernel multiplies the four low-rate transforms with.  Checked against numpy's FFT for a random tap
+    set, and the overlap-save identity behind it on a random stream: windows of 64 + 128 quads, the spectra, the
+    window's outputs 64..191 are the direct 256-tap decimating convolution."""
+    lib = C.CDLL(os.path.join(ROOT, "radiodsp_sdr_rx_amd", "librdsp_hip.so"))
+    f32p = C.POINTER(C.c_float)
+    lib.rdsp_rd_decimator_image.argtypes = [f32p, f32p]
+    lib.rdsp_rd_decimator_image.restype = C.c_int
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal(256).astype(np.float32)
+    img = np.zeros(2 * 4 * 256, np.float32)
+    assert lib.rdsp_rd_decimator_image(h.ctypes.data_as(f32p), img.ctypes.data_as(f32p)) == 0
+    G = (img[0::2] + 1j * img[1::2]).reshape(4, 256)
+    for r in range(4):
+        g = np.zeros(256)
+        for k in range(65):
+            if 0 <= 4 * k - r < 256:
+                g[k] = h[4 * k - r]
+        assert np.abs(G[r] - np.fft.fft(g) / 256).max() <= 2e-7 * np.abs(np.fft.fft(g) / 256).max()
+    x = rng.standard_normal(4 * 192) + 1j * rng.standard_normal(4 * 192)         # 64 history quads and one frame
+    win = np.zeros((4, 256), complex)
+    for r in range(4):
+        win[r, :192] = x[r::4]
+    y = np.fft.ifft(sum(np.fft.fft(win[r]) * G[r] * 256 for r in range(4)))
+    ref = np.array([sum(h[k] * x[4 * m - k] for k in range(256)) for m in range(64, 192)])
+    assert np.abs(y[64:192] - ref).max() <= 1e-5 * np.abs(ref).max()
 
 
 def test_quad_frame_mask_gather_matches_the_radix4_device_image(rdsp):
