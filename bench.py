@@ -693,10 +693,15 @@ def main():
     if default_shape and not args.no_extra_legs and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
         # K3_default: the headline workload with the library's DEFAULT decimator (one granule per frame), i.e. what a
         # caller who selects nothing gets; then the other configurations in the headline's form
-        which = ["K5"] if world > 1 else ["K3_default", "K3_as_written", "K2", "K5", "K4", "engine_literal"]
+        which = ["K5"] if world > 1 else ["K3_default", "K3_as_written", "K2", "K2_default", "K2_rows", "K5", "K4", "engine_literal"]
         for name in which:
-            reuse = iq if name in ("K2", "K3_default", "K3_as_written") else None   # same generator, same channels as the headline leg
+            reuse = iq if name in ("K2", "K2_default", "K2_rows", "K3_default", "K3_as_written") else None   # same generator, same channels as the headline leg
             try:
+                if name in ("K2_default", "K2_rows"):   # K2 under the two split-invariant frequency-domain forms: the library's
+                    # default (one granule per frame) and the row form of round 6 (rdsp_chain_set_fir_variant 5)
+                    legs[name] = extra_leg("K2", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev,
+                                           -1 if name == "K2_default" else 5, barrier, iq=reuse, label=name)
+                    continue
                 if name == "K3_default":
                     legs[name] = extra_leg("K3", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, -1,
                                            barrier, iq=reuse, label="K3_default")
