@@ -393,7 +393,8 @@ def dry_run(args, rank, world, dist):
 
 
 DECIMATOR_TEXT = {2: "frequency domain, 448-sample frames (rdsp_chain_set_fir_variant 2)", 0: "direct form (variant 0)",
-                  -1: "frequency domain, one granule per frame (library default, split-invariant for any call split)",
+                  -1: "library default, split-invariant for any call split: frequency domain, one granule per frame beside a "
+                      "tail stage, on 16-lane rows (two frames per granule) without one",
                   5: "frequency domain on 16-lane rows, two frames per granule (variant 5, split-invariant)"}
 WORKLOAD_TEXT = {"K2": "NCO mix + 256-tap polyphase /4 + 256-pt overlap-save USB filter",
                  "K3": "NCO mix + 256-tap polyphase /4 + 512-pt overlap-save USB filter + spectral NR + LMS auto-notch + AGC",
@@ -693,14 +694,14 @@ def main():
     if default_shape and not args.no_extra_legs and not os.environ.get("RDSP_BENCH_NO_K5_LEG"):
         # K3_default: the headline workload with the library's DEFAULT decimator (one granule per frame), i.e. what a
         # caller who selects nothing gets; then the other configurations in the headline's form
-        which = ["K5"] if world > 1 else ["K3_default", "K3_as_written", "K2", "K2_default", "K2_rows", "K5", "K4", "engine_literal"]
+        which = ["K5"] if world > 1 else ["K3_default", "K3_as_written", "K2", "K2_default", "K5", "K4", "engine_literal"]
         for name in which:
-            reuse = iq if name in ("K2", "K2_default", "K2_rows", "K3_default", "K3_as_written") else None   # same generator, same channels as the headline leg
+            reuse = iq if name in ("K2", "K2_default", "K3_default", "K3_as_written") else None   # same generator, same channels as the headline leg
             try:
-                if name in ("K2_default", "K2_rows"):   # K2 under the two split-invariant frequency-domain forms: the library's
-                    # default (one granule per frame) and the row form of round 6 (rdsp_chain_set_fir_variant 5)
+                if name == "K2_default":   # K2 with the library's default decimator: no tail stage follows, so the row form
+                    # of round 6 (rdsp_front_rd_kernel; split-invariant like the one-granule form K3_default runs)
                     legs[name] = extra_leg("K2", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev,
-                                           -1 if name == "K2_default" else 5, barrier, iq=reuse, label=name)
+                                           -1, barrier, iq=reuse, label=name)
                     continue
                 if name == "K3_default":
                     legs[name] = extra_leg("K3", torch, dist, R, Chain, synth_iq, args, rank, world, local_rank, dev, -1,

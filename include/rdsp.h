@@ -293,12 +293,15 @@ int rdsp_chain_set_sub_batch(rdsp_chain_t *c, int channels);
 
 /* wave priorities in pipelined mode (front kernel during its FIR, tail kernel), 0..3 */
 int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, int tail_prio);
-/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]; decim 4).  -1 (default) and 4: in the frequency
+/* stage A3 (the decimating FIR, y[m] = sum_k h[k] x[4m - k]; decim 4).  4: in the frequency
  * domain -- polyphase overlap-save: four low-rate transforms, branch spectra, one inverse -- with
  * frames of ONE GRANULE (256 outputs, the rest of the 512-point window zeros): every call boundary is a frame
  * boundary and every frame's input is a function of the absolute sample position, so a stream gives the same
  * bits however it is cut into calls -- the property the reference has by construction (fixed 128-sample
- * blocks, CONV:231-245).  0: the direct form (packed FMAs): split-invariant too, about 1.3x slower.  2: the
+ * blocks, CONV:231-245).  -1 (default): that form, or the row form 5 (below; split-invariant in the same way) for a
+ * call that no later stage follows -- no NLMS / ALS / SAM / IIR stage, whose kernel would share the SIMDs -- and
+ * that runs without the noise blanker: a function of the chain's settings at the call, never of the call split.
+ * 0: the direct form (packed FMAs): split-invariant too, about 1.3x slower.  2: the
  * frequency domain with 448-sample frames: 5 transforms per 448 outputs instead of per 256 (the front kernel
  * ~1.4x faster).  The frames start at the call's first sample, so this form has the property for a restricted
  * set of call boundaries: calls that are multiples of rdsp_chain_granule_blocks() (56 input blocks for FFT_L <=

@@ -225,7 +225,8 @@ class Chain:
         _lib.check(self.lib.rdsp_chain_set_front_variant(self.h, int(lean)))
 
     def set_fir_variant(self, variant):
-        """stage A3: -1 / 4 frequency domain with one-granule frames (split-invariant bits, default), 0 the direct
+        """stage A3: 4 frequency domain with one-granule frames (split-invariant bits); -1 (default) that, or 5 for
+        calls no tail stage follows; 0 the direct
         form, 2 frequency domain with 448-sample frames (throughput; split-invariant bits for calls that are
         multiples of `granule_blocks`, i.e. whole frames), 5 frequency domain on 16-lane rows (split-invariant;
         for chains without a tail stage)"""

@@ -142,8 +142,9 @@ struct rdsp_chain {
   std::vector<int> ev_has_tail;
   size_t ev_used = 0; /* calls recorded so far */
   int lean_mode = -1; /* -1 auto (= full), 0 full-register front kernel, 1 lean */
-  int fir_mode = -1;  /* stage A3 (rdsp_chain_set_fir_variant): -1 / 4 frequency domain, one granule per frame (split-
-                         invariant bits, the default); 0 direct form; 2 frequency domain, 448-sample frames;
+  int fir_mode = -1;  /* stage A3 (rdsp_chain_set_fir_variant): 4 frequency domain, one granule per frame (split-
+                         invariant bits); -1 (default) that or 5, by what follows the front kernel; 0 direct form; 2
+                         frequency domain, 448-sample frames;
                          5 / 6 frequency domain on 16-lane rows, 128 (split-invariant) / 192 outputs per 256-point window;
                          EXPERIMENTAL builds: 1 matrix-core FIR, 3 matrix unless the tail stage shares the SIMDs */
   /* wave priorities while both kernels share the SIMDs: the direct-form front kernel raises its
@@ -790,6 +791,11 @@ extern "C" int rdsp_chain_process(rdsp_chain_t *c, const int16_t *d_iq, size_t i
    * bits do not depend on how the stream is cut into calls -- like the direct form (0), at about two thirds of
    * its cost.  2: 448-sample frames anchored at the call's first sample: the throughput form bench.py selects. */
   fp.fir_fd = fir_fd_of(c);
+  /* the default (-1) picks between the two split-invariant frequency-domain forms: on 16-lane rows where no tail kernel
+   * will share the SIMDs with this call's front kernel (4-10 % faster there), wave-wide frames of one granule beside
+   * it (the rows' 233-256 registers would leave one front wave per SIMD).  A function of the chain's settings at this
+   * call, not of how the stream is cut: both give the same bits for any split. */
+  if (c->fir_mode == -1 && fp.fir_fd == 2 && !fp.to_mid) fp.fir_fd = 3;
   fp.fd_mask = c->d_fd_mask;
   fp.rd_mask = c->d_rd_mask;
   c->front_name = !fp.fir_fd ? "rdsp_front_kernel" : ((fp.fir_fd >= 3 && !fp.nb_on) ? "rdsp_front_rd_kernel" : "rdsp_front_fd_kernel");
@@ -1470,7 +1476,8 @@ extern "C" int rdsp_chain_set_priorities(rdsp_chain_t *c, int front_fir_prio, in
   return RDSP_OK;
 }
 /* stage A3 of the front kernel (decim 4; decim-1 chains have no decimator and always run rdsp_front_kernel).
- * -1 (default) and 4: in the frequency domain -- polyphase overlap-save: four low-rate transforms, branch
+ * -1 (default): 4, or 5 for calls that no tail / SAM / IIR stage follows and that run without the blanker (rdsp_chain_process).
+ * 4: in the frequency domain -- polyphase overlap-save: four low-rate transforms, branch
  * spectra, one inverse -- with frames of one granule (256 outputs; the rest of the 512-point window zeros): every
  * call boundary is a frame boundary and every frame's input is a function of the absolute sample position, so a
  * stream gives the same bits however it is cut into calls, like the reference's fixed 128-sample blocks

@@ -41,7 +41,8 @@ def rdsp():
 @pytest.fixture(params=["default", "direct", "fd"])
 def front_form(request):
     """Stage A3 of the chains a test makes without choosing: the library's default (frequency domain with frames
-    of one granule: the bits do not depend on the call split), the direct form (rdsp_chain_set_fir_variant 0,
+    of one granule beside a tail stage, on 16-lane rows without one: the bits do not depend on the call split),
+    the direct form (rdsp_chain_set_fir_variant 0,
     split-invariant too) and the frequency-domain decimator with 448-sample frames (variant 2, what bench.py
     runs).  The GPU test modules use it module-wide, so every chain test covers all three; a test that is about
     one form sets it explicitly, which wins."""

@@ -549,7 +549,8 @@ def test_split_calls_are_bitwise_identical_to_one_call(rdsp, torch_cuda, name, c
     try:
         a16, a32, ach = gpu_run(torch_cuda, iq, cfg, calls=1)
         b16, b32, _ = gpu_run(torch_cuda, iq, cfg, calls=calls)
-        assert ach.front_kernel_name() == "rdsp_front_fd_kernel"
+        # the default picks between its two split-invariant forms by what follows the front kernel (rdsp.h)
+        assert ach.front_kernel_name() == ("rdsp_front_fd_kernel" if name.startswith("k3") else "rdsp_front_rd_kernel")
     finally:
         Chain.default_fir_variant = saved
     assert np.array_equal(a16, b16) and np.array_equal(a32, b32)
