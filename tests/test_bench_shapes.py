@@ -6,7 +6,8 @@ bench.py's step is ONE call of 512 input blocks (65 536 IQ samples) per channel 
 FFT_L 512, 512 NLMS blocks), the same resident input step after step.  Here: the same chain objects and calls, two
 consecutive steps, and sampled channels -- the first, the last, the pair either side of the 4096-channel sub-batch
 boundary and of every 64-channel wave boundary nearby, and a random draw -- against the CPU oracle run over the
-same two steps as one stream.  The `K3_default` leg of the bench line (the library's default decimator) likewise.
+same two steps as one stream.  The `K3_default` / `K2_default` legs of the bench line (the library's default decimator:
+one granule per wave-wide frame beside the tail stage, the row form without one) likewise, and K4's shape under the default.
 """
 import numpy as np
 import pytest
@@ -19,6 +20,8 @@ pytestmark = pytest.mark.gpu
 SHAPES = {
     # name: (chain config, channels, cw input, fir_variant, recursive stage in the chain)
     "K2": (K1, 4096, False, 2, False),
+    "K2_default": (K1, 4096, False, None, False),      # no tail stage: the default runs the row form (rdsp_front_rd_kernel)
+    "K4_default": (K4, 8192, True, None, False),
     "K3": (K3, 4096, False, 2, True),
     "K3_default": (K3, 4096, False, None, True),
     "K4": (K4, 8192, True, 2, False),
@@ -45,7 +48,7 @@ def test_bench_step_shape_matches_the_oracle(rdsp, oracle, name):
         ch.process(dev, out=o16[k], out_f32=o32[k])
     ch.flush()
     torch.cuda.synchronize()
-    assert ch.front_kernel_name() == "rdsp_front_fd_kernel"
+    assert ch.front_kernel_name() == ("rdsp_front_rd_kernel" if name in ("K2_default", "K4_default") else "rdsp_front_fd_kernel")
     rng = np.random.default_rng(len(name))
     edges = [0, 1, 63, 64, 127, 128, 2047, 2048, 4031, 4032, 4095, nch - 65, nch - 64, nch - 2, nch - 1]
     if nch > 4096:
