@@ -621,10 +621,20 @@ def test_argument_errors_are_loud(rdsp):
         ch.setAudioFilterKind(7)
     with pytest.raises(RdspError):
         ch.set_spectral_nr(3, 1.0)
+    with pytest.raises(RdspError) as e:
+        ch.set_fir_variant(5)                           # ... nor its row form
+    assert e.value.code == -5
+    with pytest.raises(RdspError):
+        ch.set_fir_variant(7)
     if not lib.rdsp_experimental_build():
         with pytest.raises(RdspError) as e:
             ch.set_fir_variant(1)                       # matrix-core FIR: EXPERIMENTAL builds only
         assert e.value.code == -5
+        d4 = Chain(2, max_blocks_per_call=8, fft_l=256, demod="USB")
+        with pytest.raises(RdspError) as e:
+            d4.set_fir_variant(6)                       # the row form with 192 outputs per window: measured, not adopted
+        assert e.value.code == -5
+        d4.set_fir_variant(5)
     # round 5's entry points
     h = C.c_void_p()
     assert lib.rdsp_spectrum_create(2, 0, 8, 99, C.byref(h)) == -1 and b"window id" in lib.rdsp_last_error()
