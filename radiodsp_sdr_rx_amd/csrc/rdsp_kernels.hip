@@ -1711,8 +1711,10 @@ template <int N, int P, bool LEAN, bool PRE, int VC>
 int launch_front_fd_vc(const RdspFrontParams *p, int n_channels, hipStream_t stream) {
   if constexpr (N == 256) {
     /* FFT_L 256: four overlap-save frames per pass (front_frame_quad) unless the audio goes on to the tail
-     * kernel, which may share the SIMDs (pipelined mode) and leaves no room for that form's registers and LDS */
-    if (!p->to_mid) {
+     * kernel, which may share the SIMDs (pipelined mode) and leaves no room for that form's registers and LDS.
+     * Measurement switch RDSP_NO_QUAD=1: the one-frame form here too (tests/micro/k2_occupancy.sh). */
+    static const bool no_quad = getenv("RDSP_NO_QUAD") && atoi(getenv("RDSP_NO_QUAD")) != 0;
+    if (!p->to_mid && !no_quad) {
       constexpr size_t lds4 = front_fd_lds<N, P, true>();
       static_assert(lds4 <= 48 * 1024, "no raised dynamic-LDS limit needed");
       hipLaunchKernelGGL((rdsp_front_fd_kernel<N, P, LEAN, PRE, true, VC>), dim3(n_channels), dim3(N / P), lds4, stream, *p);
