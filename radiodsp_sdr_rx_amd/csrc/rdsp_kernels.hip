@@ -107,6 +107,33 @@ __device__ __forceinline__ float spec_table_factor(float2 x) {
   return fmaf(fmaf(-f, f, f), -7.52982e-05f, 1.0f); /* (2 pi / 512)^2 / 2 */
 }
 
+/* A field of the kernel's parameter block (or of the channel's group record) read where it is used, not at kernel
+ * entry.  The compiler loads every kernarg it will ever need in the prologue, and with more than a hundred scalar values
+ * live across the frame loop it spills them to VGPR lanes: 79 spilled SGPRs and ~95 v_readlane reloads per decimator
+ * frame in the K2 instance of rdsp_front_fd_kernel, every one an issue slot of the vector unit.  What only the call's
+ * first frame, an option's own branch or the state write-back at the end needs comes through here instead: a scalar load
+ * from the kernarg segment through a pointer the optimizer cannot identify with the one it loaded from at entry (the
+ * parameter block is the kernels' only argument: offset 0 of the segment). */
+template <typename T>
+__device__ __forceinline__ T kernarg_late(unsigned off) {
+  auto kp = (const __attribute__((address_space(4))) unsigned char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return *reinterpret_cast<const __attribute__((address_space(4))) T *>(kp + off);
+}
+#define RDSP_LATE(field) kernarg_late<decltype(RdspFrontParams::field)>((unsigned)offsetof(RdspFrontParams, field))
+/* the group record's cold fields (what the 256 history samples were mixed with): read like the record at kernel entry,
+ * vector loads of a wave-uniform address, made scalar by v_readfirstlane */
+__device__ __forceinline__ uint32_t group_late_word(uint32_t gi, unsigned off) {
+  const uint32_t *gw = reinterpret_cast<const uint32_t *>(RDSP_LATE(groups) + gi) + off / 4;
+  asm volatile("" : "+s"(gw));
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const __attribute__((address_space(1))) uint32_t *)gw);
+}
+__device__ __forceinline__ float2 group_late_f2(uint32_t gi, unsigned off) {
+  return make_float2(__builtin_bit_cast(float, group_late_word(gi, off)), __builtin_bit_cast(float, group_late_word(gi, off + 4)));
+}
+#define RDSP_GROUP_LATE_F2(gi, field) group_late_f2(gi, (unsigned)offsetof(RdspGroup, field))
+#define RDSP_GROUP_LATE_U32(gi, field) group_late_word(gi, (unsigned)offsetof(RdspGroup, field))
+
 /* ---- A5/A6 + epilogue: one overlap-save frame of H = N/2 new samples ------------------
  * Shared by the front kernels (direct-form and FFT-domain decimator).  fetch(i) returns new
  * sample i of the hop from wherever the producer left it in LDS. */
@@ -184,7 +211,7 @@ __device__ __forceinline__ void front_frame(const RdspFrontParams &p, const Rdsp
        * first inverse pass, so no other lane ever touches them in between (and they are inside the buffer under
        * either map, also where it is cut into the FIR planes behind their history) */
       const int own = lb.bi[PL::NP - 1];
-      spec_resynthesize_literal<P>(v, nfloor, p.sin_table, wb, [&](int e) { return own + e; });
+      spec_resynthesize_literal<P>(v, nfloor, RDSP_LATE(sin_table), wb, [&](int e) { return own + e; });
     } else {
 #pragma unroll
       for (int e = 0; e < P; e++) {
@@ -423,7 +450,7 @@ __device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const
       }
     } else if (p.spectral_literal) { /* the same with atan2f and the table looked up */
       const int own = lb.bi[FftPlan<256, 16>::NP - 1];
-      spec_resynthesize_literal<P>(v, mine, p.sin_table, wbg, [&](int e) { return own + e; });
+      spec_resynthesize_literal<P>(v, mine, RDSP_LATE(sin_table), wbg, [&](int e) { return own + e; });
     } else {
 #pragma unroll
       for (int e = 0; e < P; e++) {
@@ -477,16 +504,7 @@ __device__ __forceinline__ void front_frame_quad(const RdspFrontParams &p, const
   }
   const bool valid = g < nf;
   const size_t tout = (size_t)(frame_idx + g) * RDSP_BLOCK + (size_t)i;
-  if (p.to_mid) {
-    if (valid) {
-#pragma unroll
-      for (int j = 0; j < Q; j++) p.mid[ch * p.mid_stride + tout + 16 * j] = L[j];
-      if (G.demod == RDSP_K_DEMOD_SAM) {
-#pragma unroll
-        for (int j = 0; j < Q; j++) p.mid_q[ch * p.mid_stride + tout + 16 * j] = R[j];
-      }
-    }
-  } else {
+  { /* the launch code takes this form only for chains whose audio ends here (no intermediate for a tail stage) */
     if (p.agc_on) {
       float pw = 0.f;
 #pragma unroll
@@ -944,9 +962,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   float2 *wbd = wb + wave * PLD::WB; /* this wave's decimator work buffer (inside the filter's) */
   const size_t ch = (size_t)p.ch_base + blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
-  RdspGroup G;
+  RdspGroup G; /* its hot fields; what only the call's first frame needs is read there (RDSP_GROUP_LATE_*) */
+  const uint32_t gi = p.group_of ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.group_of[ch]) : 0u;
   {
-    const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
     const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
     uint32_t r[32];
 #pragma unroll
@@ -1074,7 +1092,7 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
             }
             if (64 * (c + 1) == total) {
               if constexpr (NW == 1) hist_save = rq[j];
-              else *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * lane) = rq[j]; /* the call's last 64 quads */
+              else *reinterpret_cast<uint4 *>(RDSP_LATE(st_hist) + ch * 256 + 4 * lane) = rq[j]; /* the call's last 64 quads */
             }
           }
         }
@@ -1103,8 +1121,17 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
     /* column 0 of the call's first frame is the previous call's samples: they keep the swap flag and
      * the gains they came in with (uniform values, chosen once per frame).  Only the PRE kernels carry
      * this: the launch code picks them for the one call after such a setting changed */
-    const float si0 = (PRE && hist) ? p.scale_i_hist : p.scale_i, sq0 = (PRE && hist) ? p.scale_q_hist : p.scale_q;
-    const bool swap0 = PRE && (hist ? p.swap_hist != 0 : p.swap_iq != 0);
+    float si0 = p.scale_i, sq0 = p.scale_q;
+    bool swap0 = PRE && p.swap_iq != 0;
+    uint32_t dphi_hist = G.dphi;
+    if (hist) { /* round 0 only: read here, not held in scalar registers for the whole launch */
+      if constexpr (PRE) {
+        si0 = RDSP_LATE(scale_i_hist);
+        sq0 = RDSP_LATE(scale_q_hist);
+        swap0 = RDSP_LATE(swap_hist) != 0;
+      }
+      dphi_hist = RDSP_GROUP_LATE_U32(gi, dphi_hist);
+    }
     /* Gains.  A column whose I and Q gains are equal carries its gain on the phasor (two packed multiplies per
      * frame instead of 32 on the samples; x (g ph) = (x g) ph to the bit when g is a power of two -- unit input
      * gain -- and to an ulp otherwise); a column with two gains (IQ balance) is scaled per sample.  The rule
@@ -1124,8 +1151,8 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
        * function of its absolute position (and the column's own gain), not of where the call began.  Only
        * behind a retune (the previous call's samples were mixed with another increment) it is evaluated
        * directly with that increment */
-      if (hist && G.dphi_hist != G.dphi) {
-        const float2 d = (G.dphi_hist != 0u) ? nco_phasor_alu(nq * G.dphi_hist) : make_float2(1.f, 0.f);
+      if (hist && dphi_hist != G.dphi) {
+        const float2 d = (dphi_hist != 0u) ? nco_phasor_alu(nq * dphi_hist) : make_float2(1.f, 0.f);
         pj[0] = make_float2(d.x * gph0, d.y * gph0);
       } else if (PRE && gph0 != gph) {
         pj[0] = cmulc_uniform(make_float2(b1u.x * gph0, b1u.y * gph0), G.rotq1);
@@ -1163,8 +1190,13 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
         float2 ph = pj[j];
         if (r > 0) {
           const float2 rr = (r == 1) ? G.rot1 : (r == 2) ? G.rot2 : G.rot3;
-          const float2 rh = (r == 1) ? G.roth1 : (r == 2) ? G.roth2 : G.roth3;
-          ph = (j == 0 && hist) ? cmul_pinned_u(ph, rh) : cmul_pinned_u(ph, rr);
+          if (j == 0) { /* the history column of the call's first frame: the rotation it was mixed with */
+            float2 r0 = rr;
+            if (hist) r0 = (r == 1) ? RDSP_GROUP_LATE_F2(gi, roth1) : (r == 2) ? RDSP_GROUP_LATE_F2(gi, roth2) : RDSP_GROUP_LATE_F2(gi, roth3);
+            ph = cmul_pinned_u(ph, r0);
+          } else {
+            ph = cmul_pinned_u(ph, rr);
+          }
         }
         v[j] = cmul_pinned(x, ph);
       }
@@ -1258,22 +1290,25 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_fd_kernel(RdspFrontParams
   }
 
   /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
+  float2 *const st_prev = RDSP_LATE(st_prev); /* the state pointers again: not kept across the frame loop */
+  uint32_t *const st_hist = RDSP_LATE(st_hist);
+  float *const st_scal = RDSP_LATE(st_scal);
   if constexpr (QUAD) {
     const int hp = rhop == 0 ? QUAD_HOPS - 1 : rhop - 1; /* the last hop consumed */
 #pragma unroll
-    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = ring[hp * QUAD_PITCH + tid + j * NT];
+    for (int j = 0; j < PH; j++) st_prev[ch * H + tid + j * NT] = ring[hp * QUAD_PITCH + tid + j * NT];
   } else {
 #pragma unroll
-    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
+    for (int j = 0; j < PH; j++) st_prev[ch * H + tid + j * NT] = vprev[j];
   }
   if (tid < 64 && !(NB_ON && NW > 1)) /* four waves with the blanker: stored by the wave that blanked them */
-    *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) =
+    *reinterpret_cast<uint4 *>(st_hist + ch * 256 + 4 * tid) =
         NB_ON ? hist_save : *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
   if (tid == 0) {
-    p.st_scal[ch * 4 + 0] = nfloor;
-    if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
-    p.st_scal[ch * 4 + 2] = am_dc;
-    if (NB_ON) p.st_scal[ch * 4 + 3] = (NW > 1) ? nbs[0] : nb_level;
+    st_scal[ch * 4 + 0] = nfloor;
+    if (!p.to_mid) st_scal[ch * 4 + 1] = agc_g;
+    st_scal[ch * 4 + 2] = am_dc;
+    if (NB_ON) st_scal[ch * 4 + 3] = (NW > 1) ? nbs[0] : nb_level;
   }
 }
 
@@ -1350,9 +1385,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_rd_kernel(RdspFrontParams
   float2 *wbg = wb + wave * RD_WB + row * PR::WB; /* this row's exchange buffer (inside the filter's work buffer) */
   const size_t ch = (size_t)p.ch_base + blockIdx.x;
   const uint32_t *iq = p.iq + ch * p.in_stride;
-  RdspGroup G;
+  RdspGroup G; /* its hot fields */
+  const uint32_t gi = p.group_of ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.group_of[ch]) : 0u;
   {
-    const uint32_t gi = p.group_of ? (uint32_t)p.group_of[ch] : 0u;
     const uint32_t *gw = reinterpret_cast<const uint32_t *>(p.groups + gi);
     uint32_t r[32];
 #pragma unroll
@@ -1428,12 +1463,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_rd_kernel(RdspFrontParams
 
   /* gains: as rdsp_front_fd_kernel -- one gain rides on the phasor, two (IQ balance) on the samples; the call's
    * first 64 quads (row 0 of pass 0, columns 0..3) keep the gains, the swap flag and the increment they came in with */
-  const float si0 = PRE ? p.scale_i_hist : p.scale_i, sq0 = PRE ? p.scale_q_hist : p.scale_q;
-  const bool swap0 = PRE && p.swap_hist != 0;
-  const bool fold = !PRE || p.scale_i == p.scale_q, fold0 = !PRE || si0 == sq0;
-  const float gph = fold ? p.scale_i : 1.0f, gph0 = fold0 ? si0 : 1.0f;
+  const bool fold = !PRE || p.scale_i == p.scale_q;
+  const float gph = fold ? p.scale_i : 1.0f;
   const float sxi = fold ? 1.0f : p.scale_i, sxq = fold ? 1.0f : p.scale_q;
-  const float sxi0 = fold0 ? 1.0f : si0, sxq0 = fold0 ? 1.0f : sq0;
 
 #pragma unroll 1
   for (int round = 0; produced < total; round++) {
@@ -1447,7 +1479,20 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_rd_kernel(RdspFrontParams
      * the same operations as every other column, with their own gain / swap flag, so that nothing rounds differently
      * when the settings did not change; only behind a retune their phasors are evaluated directly with the increment
      * they were mixed with.  PRE kernels and retunes only: the launch code picks them for the call after a change. */
-    const bool first_special = ps == 0 && (PRE || G.dphi_hist != G.dphi);
+    uint32_t dphi_hist = G.dphi;
+    float si0 = p.scale_i, sq0 = p.scale_q;
+    bool swap0 = SWAP_IQ;
+    if (ps == 0) { /* read here (RDSP_LATE): not held in scalar registers for the whole launch */
+      dphi_hist = RDSP_GROUP_LATE_U32(gi, dphi_hist);
+      if constexpr (PRE) {
+        si0 = RDSP_LATE(scale_i_hist);
+        sq0 = RDSP_LATE(scale_q_hist);
+        swap0 = RDSP_LATE(swap_hist) != 0;
+      }
+    }
+    const bool fold0 = !PRE || si0 == sq0;
+    const float gph0 = fold0 ? si0 : 1.0f, sxi0 = fold0 ? 1.0f : si0, sxq0 = fold0 ? 1.0f : sq0;
+    const bool first_special = ps == 0 && (PRE || dphi_hist != G.dphi);
     const bool hl = ps == 0 && row == 0;
     const float gh = hl ? gph0 : gph;
     const float2 Bh = make_float2(Bu.x * gh, Bu.y * gh);
@@ -1475,9 +1520,9 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_rd_kernel(RdspFrontParams
           float2 x = make_float2((float)(int16_t)(w & 0xFFFFu), (float)(int16_t)(w >> 16));
           if constexpr (PRE) x = make_float2(x.x * (hl ? sxi0 : sxi), x.y * (hl ? sxq0 : sxq));
           float2 ph = cmul_pinned(Bh, lds_ld(&utab[4 * j + r]));
-          if (G.dphi_hist != G.dphi) {
+          if (dphi_hist != G.dphi) {
             float2 d = make_float2(1.f, 0.f);
-            if (G.dphi_hist != 0u) d = nco_phasor_alu((nq + (uint32_t)(64 * (j - 4) + r)) * G.dphi_hist);
+            if (dphi_hist != 0u) d = nco_phasor_alu((nq + (uint32_t)(64 * (j - 4) + r)) * dphi_hist);
             ph = hl ? make_float2(d.x * gph0, d.y * gph0) : ph;
           }
           v[j] = cmul_pinned(x, ph);
@@ -1585,20 +1630,23 @@ __global__ void __launch_bounds__(N / P, 2) rdsp_front_rd_kernel(RdspFrontParams
   }
 
   /* ---- state out: previous hop, the last 256 raw samples (an L2 re-read), scalars --------- */
+  float2 *const st_prev = RDSP_LATE(st_prev); /* the state pointers again: not kept across the frame loop */
+  uint32_t *const st_hist = RDSP_LATE(st_hist);
+  float *const st_scal = RDSP_LATE(st_scal);
   if constexpr (QUAD) {
     const int hp = rhop == 0 ? HOPS - 1 : rhop - 1; /* the last hop consumed */
 #pragma unroll
-    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = ring[hp * QUAD_PITCH + tid + j * NT];
+    for (int j = 0; j < PH; j++) st_prev[ch * H + tid + j * NT] = ring[hp * QUAD_PITCH + tid + j * NT];
   } else {
 #pragma unroll
-    for (int j = 0; j < PH; j++) p.st_prev[ch * H + tid + j * NT] = vprev[j];
+    for (int j = 0; j < PH; j++) st_prev[ch * H + tid + j * NT] = vprev[j];
   }
   if (tid < 64)
-    *reinterpret_cast<uint4 *>(p.st_hist + ch * 256 + 4 * tid) = *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
+    *reinterpret_cast<uint4 *>(st_hist + ch * 256 + 4 * tid) = *reinterpret_cast<const uint4 *>(iq + 4 * (total - 64 + tid));
   if (tid == 0) {
-    p.st_scal[ch * 4 + 0] = nfloor;
-    if (!p.to_mid) p.st_scal[ch * 4 + 1] = agc_g;
-    p.st_scal[ch * 4 + 2] = am_dc;
+    st_scal[ch * 4 + 0] = nfloor;
+    if (!p.to_mid) st_scal[ch * 4 + 1] = agc_g;
+    st_scal[ch * 4 + 2] = am_dc;
   }
 }
 
