@@ -24,7 +24,7 @@ class Chain:
     # stage A3 of chains made without an explicit choice: None = the library's default (frequency domain with
     # frames of one granule: the bits do not depend on the call split); 0 = the direct form; 2 = the
     # frequency-domain decimator with 448-sample frames (what bench.py runs).  The GPU test modules run under
-    # all three (tests/conftest.py `front_form`).
+    # all three (tests/conftest.py `front_form`); the default itself is one of two kernels (set_fir_variant).
     default_fir_variant = None
 
     def __init__(self, n_channels, max_blocks_per_call=512, device=0, fir_variant=None, **cfg):

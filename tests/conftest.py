@@ -44,7 +44,7 @@ def front_form(request):
     of one granule beside a tail stage, on 16-lane rows without one: the bits do not depend on the call split),
     the direct form (rdsp_chain_set_fir_variant 0,
     split-invariant too) and the frequency-domain decimator with 448-sample frames (variant 2, what bench.py
-    runs).  The GPU test modules use it module-wide, so every chain test covers all three; a test that is about
+    runs).  The GPU test modules use it module-wide, so every chain test covers all three (and through the default both of its kernels: rows without a tail stage, wave-wide frames with one); a test that is about
     one form sets it explicitly, which wins."""
     from radiodsp_sdr_rx_amd.chain import Chain
     old = Chain.default_fir_variant

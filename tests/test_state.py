@@ -119,7 +119,7 @@ def test_state_argument_errors_are_loud(rdsp):
 
 
 def test_a_stream_continues_in_another_decimator_form(rdsp, oracle):
-    """All three forms of stage A3 keep the same state (the last 256 raw samples, the previous hop of the decimated
+    """All forms of stage A3 keep the same state (the last 256 raw samples, the previous hop of the decimated
     stream), so a stream saved under one may be continued under another -- a recording processed in the throughput
     form (rdsp_chain_set_fir_variant 2) up to a checkpoint and resumed by a host that wants split-invariant bits, or
     the other way round.  The two forms round differently, so this is a tolerance statement: every hand-over follows
@@ -133,7 +133,8 @@ def test_a_stream_continues_in_another_decimator_form(rdsp, oracle):
     iq = synth_iq(nch, per * 4 * 128)
     parts = _parts(iq, per)
     ref = np.stack([oracle.OracleChain(**cfg).process(iq[c])[1] for c in range(nch)])
-    for first, second in ((2, -1), (-1, 2), (0, -1), (2, 0)):
+    # -1: the default (no tail stage in this chain: the row form, 5 by name); 4: one granule per wave-wide frame
+    for first, second in ((2, -1), (-1, 2), (0, -1), (2, 0), (4, 5), (5, 4), (-1, 0)):
         a = Chain(nch, max_blocks_per_call=per, fir_variant=first, **cfg)
         got = [a.process(p, want_f32=True)[1].cpu().numpy() for p in parts[:2]]
         b = Chain(nch, max_blocks_per_call=per, fir_variant=second, **cfg)
